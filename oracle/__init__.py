@@ -1,0 +1,262 @@
+"""Test oracle for the batched k-NN hot path -- TEST INFRASTRUCTURE, NOT PRODUCT.
+
+Two CPU implementations sit behind one small ctypes facade:
+
+* ``Oracle("port")``      -> ``oracle/liboracle.so``: this repository's CPU
+  restatement of the reference algorithm (``oracle/ptk_oracle.cpp``).
+* ``Oracle("reference")`` -> ``oracle/_ref/libptk_ref.so``: the actual reference
+  headers compiled in place from ``/root/reference`` (``oracle/ref_driver.cpp``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this package; the product (``pico_tree_amd``, ``include/``) never
+does.  Nothing here reads ``/root/reference`` at run time -- the reference build
+is a prebuilt shared object that travels with the repository snapshot.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from ctypes import c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p, POINTER
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PORT_LIB = os.path.join(_HERE, "liboracle.so")
+REF_LIB = os.path.join(_HERE, "_ref", "libptk_ref.so")
+
+#: Structured dtype of one result record; identical to the reference binding's
+#: ``[('index','<i4'),('distance','<f4')]`` (_pyco_tree/def_core.hpp:17-18).
+NEIGHBOR = np.dtype([("index", "<i4"), ("distance", "<f4")])
+
+
+def build(force: bool = False) -> None:
+    """Compile the oracle (and the reference driver when the sources exist)."""
+    need = force or not os.path.exists(PORT_LIB)
+    ref_src = "/root/reference/src/pico_tree/pico_tree/kd_tree.hpp"
+    if os.path.exists(ref_src) and not os.path.exists(REF_LIB):
+        need = True
+    if need:
+        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+
+
+def have_reference() -> bool:
+    return os.path.exists(REF_LIB)
+
+
+def _fptr(a: np.ndarray):
+    return a.ctypes.data_as(POINTER(c_float))
+
+
+class Oracle:
+    """A CPU kd-tree over ``points`` answering batched queries.
+
+    ``kind`` is ``"port"`` (the restatement) or ``"reference"`` (the compiled
+    reference).  Results use the ``NEIGHBOR`` dtype; radius/box results are
+    ``(offsets[nq+1], flat)`` pairs.
+    """
+
+    def __init__(self, points: np.ndarray, max_leaf_size: int = 10, kind: str = "port"):
+        if kind not in ("port", "reference"):
+            raise ValueError(kind)
+        self.kind = kind
+        path = PORT_LIB if kind == "port" else REF_LIB
+        if not os.path.exists(path):
+            raise RuntimeError(f"oracle library missing: {path} (run oracle.build())")
+        self._lib = ctypes.CDLL(path)
+        self._p = "ptkor_" if kind == "port" else "ptkref_"
+        pts = np.ascontiguousarray(points, dtype=np.float32)
+        if pts.ndim != 2:
+            raise ValueError("points must be (n, dim)")
+        self.n, self.dim = pts.shape
+        self.max_leaf_size = int(max_leaf_size)
+        self._pts = pts
+        create = self._fn("create", c_void_p, [POINTER(c_float), c_size_t, c_size_t, c_size_t])
+        self._h = create(_fptr(pts), self.n, self.dim, self.max_leaf_size)
+        if not self._h:
+            raise RuntimeError("oracle create failed")
+
+    def _fn(self, name, restype, argtypes):
+        f = getattr(self._lib, self._p + name)
+        f.restype = restype
+        f.argtypes = argtypes
+        return f
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._fn("destroy", None, [c_void_p])(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- threads ------------------------------------------------------------
+    def set_threads(self, n: int) -> None:
+        self._fn("set_threads", None, [c_int])(int(n))
+
+    def max_threads(self) -> int:
+        return int(self._fn("max_threads", c_int, [])())
+
+    # -- structure ----------------------------------------------------------
+    def save_bytes(self) -> bytes:
+        """The byte stream ``kd_tree::save`` writes for this tree."""
+        f = self._fn("save", c_size_t, [c_void_p, c_void_p, c_size_t])
+        size = f(self._h, None, 0)
+        buf = np.empty(size, dtype=np.uint8)
+        f(self._h, buf.ctypes.data, size)
+        return buf.tobytes()
+
+    def flatten(self):
+        """(nodes uint32[n_nodes,4], indices int32[n], root_min, root_max, max_depth); port only."""
+        if self.kind != "port":
+            raise RuntimeError("flatten is a port-only helper")
+        f = self._fn("flatten", c_size_t,
+                     [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, POINTER(c_uint32)])
+        count = f(self._h, None, 0, None, None, None, None)
+        nodes = np.empty((count, 4), dtype=np.uint32)
+        indices = np.empty(self.n, dtype=np.int32)
+        rmin = np.empty(self.dim, dtype=np.float32)
+        rmax = np.empty(self.dim, dtype=np.float32)
+        depth = c_uint32(0)
+        f(self._h, nodes.ctypes.data, count, indices.ctypes.data, rmin.ctypes.data,
+          rmax.ctypes.data, ctypes.byref(depth))
+        return nodes, indices, rmin, rmax, int(depth.value)
+
+    # -- queries ------------------------------------------------------------
+    def _queries(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self.dim:
+            raise ValueError("queries must be (nq, dim)")
+        return q
+
+    def search_nn(self, q, e: float | None = None, counters: bool = False):
+        q = self._queries(q)
+        out = np.empty(len(q), dtype=NEIGHBOR)
+        if self.kind == "port":
+            cnt = np.zeros((len(q), 3), dtype=np.uint32) if counters else None
+            self._fn("search_nn", None,
+                     [c_void_p, POINTER(c_float), c_size_t, c_int, c_float, c_void_p, c_void_p])(
+                self._h, _fptr(q), len(q), int(e is not None), float(e or 1.0),
+                out.ctypes.data, cnt.ctypes.data if counters else None)
+            return (out, cnt) if counters else out
+        if e is not None or counters:
+            raise RuntimeError("reference driver: use search_knn(k=1, e) / count_visits")
+        self._fn("search_nn", None, [c_void_p, POINTER(c_float), c_size_t, c_void_p])(
+            self._h, _fptr(q), len(q), out.ctypes.data)
+        return out
+
+    def search_knn(self, q, k: int, e: float | None = None, counters: bool = False):
+        q = self._queries(q)
+        k = int(k)
+        if k < 1 or k > self.n:
+            raise ValueError("oracle requires 1 <= k <= n")
+        out = np.empty((len(q), k), dtype=NEIGHBOR)
+        if self.kind == "port":
+            cnt = np.zeros((len(q), 3), dtype=np.uint32) if counters else None
+            self._fn("search_knn", None,
+                     [c_void_p, POINTER(c_float), c_size_t, c_size_t, c_int, c_float,
+                      c_void_p, c_void_p])(
+                self._h, _fptr(q), len(q), k, int(e is not None), float(e or 1.0),
+                out.ctypes.data, cnt.ctypes.data if counters else None)
+            return (out, cnt) if counters else out
+        if counters:
+            raise RuntimeError("reference driver: use count_visits")
+        if e is None:
+            self._fn("search_knn", None,
+                     [c_void_p, POINTER(c_float), c_size_t, c_size_t, c_void_p])(
+                self._h, _fptr(q), len(q), k, out.ctypes.data)
+        else:
+            self._fn("search_knn_approx", None,
+                     [c_void_p, POINTER(c_float), c_size_t, c_size_t, c_float, c_void_p])(
+                self._h, _fptr(q), len(q), k, float(e), out.ctypes.data)
+        return out
+
+    def search_radius(self, q, radius: float, sort: bool = False, e: float | None = None,
+                      counters: bool = False):
+        q = self._queries(q)
+        offsets = np.zeros(len(q) + 1, dtype=np.uint64)
+        if self.kind == "port":
+            cnt = np.zeros((len(q), 3), dtype=np.uint32) if counters else None
+            h = self._fn("search_radius", c_void_p,
+                         [c_void_p, POINTER(c_float), c_size_t, c_float, c_int, c_int, c_float,
+                          c_void_p, c_void_p])(
+                self._h, _fptr(q), len(q), float(radius), int(sort), int(e is not None),
+                float(e or 1.0), offsets.ctypes.data, cnt.ctypes.data if counters else None)
+        else:
+            if counters:
+                raise RuntimeError("reference driver has no radius counters")
+            cnt = None
+            h = self._fn("search_radius", c_void_p,
+                         [c_void_p, POINTER(c_float), c_size_t, c_float, c_int, c_int, c_float,
+                          c_void_p])(
+                self._h, _fptr(q), len(q), float(radius), int(sort), int(e is not None),
+                float(e or 1.0), offsets.ctypes.data)
+        flat = np.empty(int(offsets[-1]), dtype=NEIGHBOR)
+        self._fn("radius_copy", None, [c_void_p, c_void_p])(h, flat.ctypes.data)
+        self._fn("radius_free", None, [c_void_p])(h)
+        return (offsets, flat, cnt) if counters else (offsets, flat)
+
+    def search_box(self, mins, maxs):
+        mins = self._queries(mins)
+        maxs = self._queries(maxs)
+        offsets = np.zeros(len(mins) + 1, dtype=np.uint64)
+        h = self._fn("search_box", c_void_p,
+                     [c_void_p, POINTER(c_float), POINTER(c_float), c_size_t, c_void_p])(
+            self._h, _fptr(mins), _fptr(maxs), len(mins), offsets.ctypes.data)
+        flat = np.empty(int(offsets[-1]), dtype=np.int32)
+        self._fn("box_copy", None, [c_void_p, c_void_p])(h, flat.ctypes.data)
+        self._fn("box_free", None, [c_void_p])(h)
+        return offsets, flat
+
+
+def reference_count_visits(points, max_leaf_size, q, k):
+    """Per-query (n_branch, n_pts) of the *reference* traversal (counting metric)."""
+    lib = ctypes.CDLL(REF_LIB)
+    pts = np.ascontiguousarray(points, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    nb = np.zeros(len(q), dtype=np.uint32)
+    npts = np.zeros(len(q), dtype=np.uint32)
+    f = lib.ptkref_count_visits
+    f.restype = None
+    f.argtypes = [POINTER(c_float), c_size_t, c_size_t, c_size_t, POINTER(c_float), c_size_t,
+                  c_size_t, c_void_p, c_void_p]
+    f(_fptr(pts), pts.shape[0], pts.shape[1], int(max_leaf_size), _fptr(q), len(q), int(k),
+      nb.ctypes.data, npts.ctypes.data)
+    return nb, npts
+
+
+def sliding_midpoint_2d(kind, pts, indices, box_min, box_max):
+    """Run the sliding-midpoint splitter KAT hook; returns (offset, dim, val, indices)."""
+    lib = ctypes.CDLL(PORT_LIB if kind == "port" else REF_LIB)
+    f = getattr(lib, ("ptkor_" if kind == "port" else "ptkref_") + "sliding_midpoint_2d")
+    f.restype = None
+    f.argtypes = [POINTER(c_float), c_size_t, c_void_p, POINTER(c_float), POINTER(c_float),
+                  POINTER(c_size_t), POINTER(c_size_t), POINTER(c_float)]
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    idx = np.ascontiguousarray(indices, dtype=np.int32).copy()
+    bmin = np.ascontiguousarray(box_min, dtype=np.float32)
+    bmax = np.ascontiguousarray(box_max, dtype=np.float32)
+    off, dim, val = c_size_t(0), c_size_t(0), c_float(0)
+    f(_fptr(pts), len(pts), idx.ctypes.data, _fptr(bmin), _fptr(bmax),
+      ctypes.byref(off), ctypes.byref(dim), ctypes.byref(val))
+    return int(off.value), int(dim.value), float(val.value), idx
+
+
+def l2sq(a, b) -> float:
+    lib = ctypes.CDLL(PORT_LIB)
+    lib.ptkor_l2sq.restype = c_float
+    lib.ptkor_l2sq.argtypes = [POINTER(c_float), POINTER(c_float), c_size_t]
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return float(lib.ptkor_l2sq(_fptr(a), _fptr(b), len(a)))
+
+
+def l2sq_scalar(x: float) -> float:
+    lib = ctypes.CDLL(PORT_LIB)
+    lib.ptkor_l2sq_scalar.restype = c_float
+    lib.ptkor_l2sq_scalar.argtypes = [c_float]
+    return float(lib.ptkor_l2sq_scalar(x))

@@ -1,0 +1,671 @@
+// oracle/ptk_oracle.cpp -- TEST INFRASTRUCTURE, NOT PRODUCT CODE.
+//
+// CPU restatement of the pico_tree hot path named by BASELINE.json.north_star:
+// build a kd-tree with the sliding-midpoint rule and a max-leaf-size stop, then
+// answer nn / knn / radius (exact and approximate) and box queries over it with
+// metric_l2_squared on float32 points and int indices.  Every function cites the
+// reference lines (relative to /root/reference) whose behaviour it restates.
+//
+// PARITY PIN: this file is checked bit-for-bit (indices AND distance bits, and
+// the kd_tree::save byte stream) against the actual reference compiled from its
+// own headers (oracle/ref_driver.cpp -> oracle/_ref/libptk_ref.so) by
+// tests/test_oracle_vs_reference.py in the authoring container, and against the
+// committed golden vectors in tests/golden/ (generated from the compiled
+// reference by tests/golden/make_golden.py) everywhere else.
+//
+// Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
+// the library built from this file.  The product (include/, pico_tree_amd/)
+// never includes, links or calls it.
+//
+// Canonical flags: -O3 -ffp-contract=off (an FMA-contracted build changes
+// distance bits).
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <limits>
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct neighbor_t {  // core.hpp:24-46
+  int index;
+  float distance;
+};
+static_assert(sizeof(neighbor_t) == 8, "layout");
+
+// kd_tree_node.hpp:7-27,31-50: two child pointers + union{leaf, branch}.
+struct node_t {
+  node_t* left = nullptr;
+  node_t* right = nullptr;
+  union {
+    struct {
+      int begin_idx;
+      int end_idx;
+    } leaf;
+    struct {
+      int split_dim;
+      float left_max;
+      float right_min;
+    } branch;
+  } data;
+  bool is_leaf() const { return left == nullptr && right == nullptr; }
+};
+
+// box.hpp:161-193 with run-time size: min[dim] then max[dim].
+struct box_t {
+  std::vector<float> c;
+  size_t dim;
+  explicit box_t(size_t d) : c(2 * d), dim(d) {}
+  float& mn(size_t i) { return c[i]; }
+  float& mx(size_t i) { return c[dim + i]; }
+  float mn(size_t i) const { return c[i]; }
+  float mx(size_t i) const { return c[dim + i]; }
+
+  void fill_inverse_max() {  // box.hpp:54-59
+    for (size_t i = 0; i < dim; ++i) {
+      mn(i) = std::numeric_limits<float>::max();
+      mx(i) = std::numeric_limits<float>::lowest();
+    }
+  }
+  void max_side(size_t& idx, float& val) const {  // box.hpp:71-82
+    val = std::numeric_limits<float>::lowest();
+    for (size_t i = 0; i < dim; ++i) {
+      float const delta = mx(i) - mn(i);
+      if (delta > val) {
+        idx = i;
+        val = delta;
+      }
+    }
+  }
+  void fit(float const* x) {  // box.hpp:86-95
+    for (size_t i = 0; i < dim; ++i) {
+      if (x[i] < mn(i)) mn(i) = x[i];
+      if (x[i] > mx(i)) mx(i) = x[i];
+    }
+  }
+  void fit(box_t const& o) {  // box.hpp:99-110
+    for (size_t i = 0; i < dim; ++i) {
+      if (o.mn(i) < mn(i)) mn(i) = o.mn(i);
+      if (o.mx(i) > mx(i)) mx(i) = o.mx(i);
+    }
+  }
+  bool contains(float const* x) const {  // box.hpp:31-40
+    for (size_t i = 0; i < dim; ++i) {
+      if (mn(i) > x[i] || mx(i) < x[i]) return false;
+    }
+    return true;
+  }
+  bool contains(box_t const& o) const {  // box.hpp:44-47
+    return contains(o.c.data()) && contains(o.c.data() + dim);
+  }
+};
+
+struct visit_counters {
+  std::uint32_t n_branch = 0;
+  std::uint32_t n_leaf = 0;
+  std::uint32_t n_pts = 0;
+};
+
+struct tree_t {
+  size_t dim = 0;
+  size_t n = 0;
+  size_t max_leaf = 0;
+  std::vector<float> pts;          // n x dim row-major, original order
+  std::vector<int> indices;        // kd_tree_data.hpp:67
+  box_t root_box{1};               // kd_tree_data.hpp:69
+  std::vector<std::unique_ptr<node_t[]>> chunks;  // stands in for memory.hpp's pool
+  size_t chunk_used = 256;
+  node_t* root = nullptr;
+
+  float const* point(int idx) const {  // space_wrapper.hpp:30-32
+    return pts.data() + static_cast<size_t>(idx) * dim;
+  }
+
+  node_t* allocate() {
+    if (chunk_used == 256) {
+      chunks.emplace_back(new node_t[256]);
+      chunk_used = 0;
+    }
+    return &chunks.back()[chunk_used++];
+  }
+
+  // splitter_sliding_midpoint_max_side::operator(), kd_tree_builder.hpp:229-276.
+  void split_sliding_midpoint(int* begin, int* end, box_t const& box,
+                              int*& split, size_t& split_dim,
+                              float& split_val) const {
+    float max_delta;
+    box.max_side(split_dim, max_delta);
+    split_val = max_delta / 2.0f + box.mn(split_dim);  // :240 (divide, then add)
+
+    size_t const sd = split_dim;
+    float const sv = split_val;
+    split = std::partition(begin, end, [this, sd, sv](int const i) -> bool {
+      return point(i)[sd] < sv;  // :243-247
+    });
+
+    auto const by_coord = [this, sd](int const a, int const b) -> bool {
+      return point(a)[sd] < point(b)[sd];
+    };
+    if (split == end) {  // :255-264: everything went left, slide one point right
+      --split;
+      std::nth_element(begin, split, end, by_coord);
+      split_val = point(*split)[sd];
+    } else if (split == begin) {  // :265-275: everything went right
+      ++split;
+      std::nth_element(begin, split, end, by_coord);
+      split_val = point(*split)[sd];
+    }
+  }
+
+  // build_kd_tree_impl::create_node, kd_tree_builder.hpp:352-396, with the
+  // max_leaf_size_t stop (:414-415).
+  node_t* create_node(int* begin, int* end, box_t& box) {
+    node_t* node = allocate();
+    if (static_cast<size_t>(end - begin) <= max_leaf) {
+      node->left = nullptr;  // kd_tree_node.hpp:14-19
+      node->right = nullptr;
+      node->data.leaf.begin_idx = static_cast<int>(begin - indices.data());
+      node->data.leaf.end_idx = static_cast<int>(end - indices.data());
+      box.fill_inverse_max();  // :399-407
+      for (int* it = begin; it < end; ++it) box.fit(point(*it));
+    } else {
+      int* split;
+      size_t split_dim;
+      float split_val;
+      split_sliding_midpoint(begin, end, box, split, split_dim, split_val);
+
+      box_t right = box;  // :379-383
+      box.mx(split_dim) = split_val;
+      right.mn(split_dim) = split_val;
+
+      node->left = create_node(begin, split, box);    // :385
+      node->right = create_node(split, end, right);   // :386
+
+      node->data.branch.split_dim = static_cast<int>(split_dim);  // node.hpp:86-92
+      node->data.branch.left_max = box.mx(split_dim);
+      node->data.branch.right_min = right.mn(split_dim);
+
+      box.fit(right);  // :392
+    }
+    return node;
+  }
+
+  // build_kd_tree::operator(), kd_tree_builder.hpp:471-494 with bounds_from_space.
+  void build() {
+    indices.resize(n);
+    for (size_t i = 0; i < n; ++i) indices[i] = static_cast<int>(i);  // :485-486
+    root_box = box_t(dim);
+    root_box.fill_inverse_max();  // space_wrapper.hpp:34-40
+    for (size_t i = 0; i < n; ++i) root_box.fit(point(static_cast<int>(i)));
+    box_t work = root_box;  // :345-348 copies the root box
+    root = create_node(indices.data(), indices.data() + n, work);
+  }
+};
+
+// metric_l2_squared, range form: metric.hpp:107-117 -> internal::sum :36-51 ->
+// squared_r1_distance distance.hpp:38-41.  d starts at 0 and accumulates left to
+// right; every operation rounds to float on its own (no contraction).
+inline float l2sq(float const* a, float const* b, size_t dim) {
+  float d = 0.0f;
+  for (size_t i = 0; i < dim; ++i) {
+    float const t = a[i] - b[i];
+    d += t * t;
+  }
+  return d;
+}
+
+// ---- visitors: search_visitor.hpp ------------------------------------------
+
+struct visit_nn {  // :42-65 (exact) and :165-193 (approximate: scale by 1/e)
+  neighbor_t* nn;
+  bool approx;
+  float e_inv;
+  visit_nn(neighbor_t* out, bool a, float e) : nn(out), approx(a), e_inv(1.0f / e) {
+    nn->distance = std::numeric_limits<float>::max();
+  }
+  float max() const { return nn->distance; }
+  void operator()(int idx, float dst) {
+    if (approx) dst = dst * e_inv;
+    if (max() > dst) {
+      nn->index = idx;
+      nn->distance = dst;
+    }
+  }
+};
+
+struct visit_knn {  // :83-123 (exact) and :198-247 (approximate)
+  neighbor_t* begin;
+  neighbor_t* end;
+  neighbor_t* active_end;
+  bool approx;
+  float e_inv;
+  visit_knn(neighbor_t* b, neighbor_t* e_, bool a, float e)
+      : begin(b), end(e_), active_end(b), approx(a), e_inv(1.0f / e) {
+    (end - 1)->distance = std::numeric_limits<float>::max();  // :102
+  }
+  float max() const { return (end - 1)->distance; }
+  void operator()(int idx, float dst) {
+    if (approx) dst = dst * e_inv;
+    if (max() > dst) {
+      if (active_end < end) ++active_end;  // :108-110
+      // insert_sorted, :24-38: shift while item < *prev (strict => stable).
+      neighbor_t* it = active_end - 1;
+      for (; it > begin && dst < (it - 1)->distance; --it) *it = *(it - 1);
+      it->index = idx;
+      it->distance = dst;
+    }
+  }
+};
+
+struct visit_radius {  // :127-156 (exact) and :252-288 (approximate)
+  std::vector<neighbor_t>* out;
+  float radius;
+  bool approx;
+  float e_inv;
+  visit_radius(float r, std::vector<neighbor_t>* o, bool a, float e)
+      : out(o), radius(r), approx(a), e_inv(1.0f / e) {
+    if (approx) radius = r * e_inv;  // :265
+    out->clear();                    // :136
+  }
+  float max() const { return radius; }
+  void operator()(int idx, float dst) {
+    if (approx) dst = dst * e_inv;
+    if (max() > dst) out->push_back(neighbor_t{idx, dst});  // strict, :141
+  }
+};
+
+// search_nearest_euclidean::search_nearest, kd_tree_search.hpp:52-105.
+template <typename Visitor>
+struct nearest_search {
+  tree_t const& tree;
+  float const* q;
+  Visitor& visitor;
+  std::vector<float> offset;  // node_box_offset_, :111, zeroed per query :47
+  visit_counters* counters;
+
+  nearest_search(tree_t const& t, float const* query, Visitor& v,
+                 visit_counters* c)
+      : tree(t), q(query), visitor(v), offset(t.dim, 0.0f), counters(c) {}
+
+  void run() { descend(tree.root, 0.0f); }
+
+  void descend(node_t const* node, float node_box_distance) {
+    if (node->is_leaf()) {  // :54-59
+      if (counters) ++counters->n_leaf;
+      for (int i = node->data.leaf.begin_idx; i < node->data.leaf.end_idx; ++i) {
+        int const idx = tree.indices[static_cast<size_t>(i)];
+        if (counters) ++counters->n_pts;
+        visitor(idx, l2sq(q, tree.point(idx), tree.dim));
+      }
+      return;
+    }
+    if (counters) ++counters->n_branch;
+    size_t const sd = static_cast<size_t>(node->data.branch.split_dim);  // :63
+    float const v = q[sd];
+    float const left_max = node->data.branch.left_max;
+    float const right_min = node->data.branch.right_min;
+    float new_offset;
+    node_t const* first;
+    node_t const* second;
+    if ((left_max + right_min - v - v) > 0) {  // :76 (left-assoc: ((a+b)-v)-v)
+      first = node->left;
+      second = node->right;
+      float const t = right_min - v;
+      new_offset = t * t;  // :80, metric.hpp:120-123
+    } else {
+      first = node->right;
+      second = node->left;
+      float const t = left_max - v;
+      new_offset = t * t;  // :84
+    }
+    descend(first, node_box_distance);  // :88
+
+    float const old_offset = offset[sd];  // :93
+    node_box_distance = node_box_distance - old_offset + new_offset;  // :94
+    if (visitor.max() >= node_box_distance) {  // :99
+      offset[sd] = new_offset;
+      descend(second, node_box_distance);
+      offset[sd] = old_offset;
+    }
+  }
+};
+
+// search_box, kd_tree_search.hpp:238-381: report every index inside [min,max].
+struct box_search {
+  tree_t const& tree;
+  box_t const& query;
+  std::vector<int>& out;
+
+  void report_all(node_t const* node) {  // :349-361
+    if (node->is_leaf()) {
+      for (int i = node->data.leaf.begin_idx; i < node->data.leaf.end_idx; ++i)
+        out.push_back(tree.indices[static_cast<size_t>(i)]);
+    } else {
+      report_all(node->left);
+      report_all(node->right);
+    }
+  }
+
+  void descend(node_t const* node, box_t& box) {  // :273-345
+    if (node->is_leaf()) {
+      for (int i = node->data.leaf.begin_idx; i < node->data.leaf.end_idx; ++i) {
+        int const idx = tree.indices[static_cast<size_t>(i)];
+        if (query.contains(tree.point(idx))) out.push_back(idx);
+      }
+      return;
+    }
+    size_t const sd = static_cast<size_t>(node->data.branch.split_dim);
+    float old_value = box.mx(sd);
+    box.mx(sd) = node->data.branch.left_max;
+    if (query.contains(box)) {
+      report_all(node->left);
+    } else if (query.mn(sd) <= node->data.branch.left_max) {
+      descend(node->left, box);
+    }
+    box.mx(sd) = old_value;
+
+    old_value = box.mn(sd);
+    box.mn(sd) = node->data.branch.right_min;
+    if (query.contains(box)) {
+      report_all(node->right);
+    } else if (query.mx(sd) >= node->data.branch.right_min) {
+      descend(node->right, box);
+    }
+    box.mn(sd) = old_value;
+  }
+};
+
+// kd_tree_data::write, kd_tree_data.hpp:109-135 + save :50-54, through
+// stream_wrapper.hpp's raw POD writes (size_t counts, native endianness).
+struct byte_sink {
+  std::string s;
+  template <typename T>
+  void put(T const& v) {
+    s.append(reinterpret_cast<char const*>(&v), sizeof(T));
+  }
+  template <typename T>
+  void put_n(T const* p, size_t count) {
+    s.append(reinterpret_cast<char const*>(p), sizeof(T) * count);
+  }
+};
+
+void write_node(node_t const* node, byte_sink& out) {
+  if (node->is_leaf()) {
+    out.put(true);
+    out.put(node->data.leaf);
+  } else {
+    out.put(false);
+    out.put(node->data.branch);
+    write_node(node->left, out);
+    write_node(node->right, out);
+  }
+}
+
+// Flat DFS pre-order export: mirrors the save stream, one 16-byte record per
+// node.  Branch: {left_max, right_min, right_child_index, split_dim};
+// leaf: {begin, end, 0xFFFFFFFF, 0}.  Used by tests to check the product's own
+// flattening.
+struct flat_node {
+  std::uint32_t w[4];
+};
+static_assert(sizeof(flat_node) == 16, "layout");
+
+std::uint32_t flatten(node_t const* node, std::vector<flat_node>& out,
+                      std::uint32_t depth, std::uint32_t& max_depth) {
+  std::uint32_t const self = static_cast<std::uint32_t>(out.size());
+  out.push_back(flat_node{});
+  if (depth > max_depth) max_depth = depth;
+  if (node->is_leaf()) {
+    std::int32_t b = node->data.leaf.begin_idx, e = node->data.leaf.end_idx;
+    std::memcpy(&out[self].w[0], &b, 4);
+    std::memcpy(&out[self].w[1], &e, 4);
+    out[self].w[2] = 0xFFFFFFFFu;
+    out[self].w[3] = 0;
+  } else {
+    flatten(node->left, out, depth + 1, max_depth);
+    std::uint32_t const r = flatten(node->right, out, depth + 1, max_depth);
+    std::memcpy(&out[self].w[0], &node->data.branch.left_max, 4);
+    std::memcpy(&out[self].w[1], &node->data.branch.right_min, 4);
+    out[self].w[2] = r;
+    out[self].w[3] = static_cast<std::uint32_t>(node->data.branch.split_dim);
+  }
+  return self;
+}
+
+constexpr int kChunk = 128;  // _pyco_tree/kd_tree.hpp:94
+
+struct ragged_nb {
+  std::vector<std::vector<neighbor_t>> rows;
+};
+struct ragged_idx {
+  std::vector<std::vector<int>> rows;
+};
+
+}  // namespace
+
+extern "C" {
+
+void* ptkor_create(float const* pts, size_t n, size_t dim, size_t max_leaf) {
+  if (n == 0 || dim == 0 || max_leaf == 0) return nullptr;  // builder.hpp:93,479
+  auto* t = new tree_t;
+  t->dim = dim;
+  t->n = n;
+  t->max_leaf = max_leaf;
+  t->pts.assign(pts, pts + n * dim);
+  t->build();
+  return t;
+}
+
+void ptkor_destroy(void* t) { delete static_cast<tree_t*>(t); }
+
+// The kd_tree::save byte stream (kd_tree.hpp:367-370).
+size_t ptkor_save(void* handle, unsigned char* buf, size_t cap) {
+  auto* t = static_cast<tree_t*>(handle);
+  byte_sink out;
+  out.put(static_cast<size_t>(t->dim));                       // data.hpp:52
+  out.put(static_cast<size_t>(t->indices.size()));            // stream_wrapper.hpp:77-81
+  out.put_n(t->indices.data(), t->indices.size());
+  out.put_n(t->root_box.c.data(), t->dim);                    // min
+  out.put_n(t->root_box.c.data() + t->dim, t->dim);           // max
+  write_node(t->root, out);
+  if (buf != nullptr && cap >= out.s.size())
+    std::memcpy(buf, out.s.data(), out.s.size());
+  return out.s.size();
+}
+
+// Flat export. Call with nodes == nullptr to get the node count.
+size_t ptkor_flatten(void* handle, void* nodes, size_t cap, int* indices,
+                     float* root_min, float* root_max,
+                     std::uint32_t* max_depth_out) {
+  auto* t = static_cast<tree_t*>(handle);
+  std::vector<flat_node> out;
+  std::uint32_t max_depth = 0;
+  flatten(t->root, out, 0, max_depth);
+  if (nodes != nullptr && cap >= out.size()) {
+    std::memcpy(nodes, out.data(), out.size() * sizeof(flat_node));
+    if (indices) std::memcpy(indices, t->indices.data(), t->n * sizeof(int));
+    if (root_min) std::memcpy(root_min, t->root_box.c.data(), t->dim * 4);
+    if (root_max) std::memcpy(root_max, t->root_box.c.data() + t->dim, t->dim * 4);
+    if (max_depth_out) *max_depth_out = max_depth;
+  }
+  return out.size();
+}
+
+void ptkor_set_threads(int threads) {
+  if (threads > 0) omp_set_num_threads(threads);
+}
+
+int ptkor_max_threads() { return omp_get_max_threads(); }
+
+// kd_tree::search_nn over a batch (kd_tree.hpp:126-129,155-159); approx != 0
+// selects the approximate visitor with ratio e.  counters: optional nq x 3
+// uint32 {n_branch, n_leaf, n_pts}.
+void ptkor_search_nn(void* handle, float const* q, size_t nq, int approx,
+                     float e, void* out, std::uint32_t* counters) {
+  auto* t = static_cast<tree_t*>(handle);
+  auto* o = static_cast<neighbor_t*>(out);
+  std::ptrdiff_t const count = static_cast<std::ptrdiff_t>(nq);
+#pragma omp parallel for schedule(dynamic, kChunk)
+  for (std::ptrdiff_t i = 0; i < count; ++i) {
+    visit_counters c;
+    visit_nn v(o + i, approx != 0, e);
+    nearest_search<visit_nn> s(*t, q + static_cast<size_t>(i) * t->dim, v,
+                               counters ? &c : nullptr);
+    s.run();
+    if (counters) {
+      counters[3 * i + 0] = c.n_branch;
+      counters[3 * i + 1] = c.n_leaf;
+      counters[3 * i + 2] = c.n_pts;
+    }
+  }
+}
+
+// kd_tree::search_knn(x, begin, end) over a batch (kd_tree.hpp:169-181,205-218):
+// row i of out holds k slots.  As in the reference, slots beyond min(k, n) are
+// only meaningful when n >= k (the vector overload clamps, kd_tree.hpp:193);
+// callers pass k <= n.
+void ptkor_search_knn(void* handle, float const* q, size_t nq, size_t k,
+                      int approx, float e, void* out,
+                      std::uint32_t* counters) {
+  auto* t = static_cast<tree_t*>(handle);
+  auto* o = static_cast<neighbor_t*>(out);
+  std::ptrdiff_t const count = static_cast<std::ptrdiff_t>(nq);
+#pragma omp parallel for schedule(dynamic, kChunk)
+  for (std::ptrdiff_t i = 0; i < count; ++i) {
+    size_t const ui = static_cast<size_t>(i);
+    visit_counters c;
+    visit_knn v(o + ui * k, o + ui * k + k, approx != 0, e);
+    nearest_search<visit_knn> s(*t, q + ui * t->dim, v, counters ? &c : nullptr);
+    s.run();
+    if (counters) {
+      counters[3 * ui + 0] = c.n_branch;
+      counters[3 * ui + 1] = c.n_leaf;
+      counters[3 * ui + 2] = c.n_pts;
+    }
+  }
+}
+
+// kd_tree::search_radius over a batch (kd_tree.hpp:257-290). sort != 0 applies
+// std::sort by distance (search_visitor.hpp:148), which is unstable: rows with
+// equal distances are only comparable as multisets.
+void* ptkor_search_radius(void* handle, float const* q, size_t nq, float radius,
+                          int sort, int approx, float e, std::uint64_t* offsets,
+                          std::uint32_t* counters) {
+  auto* t = static_cast<tree_t*>(handle);
+  auto* r = new ragged_nb;
+  r->rows.resize(nq);
+  std::ptrdiff_t const count = static_cast<std::ptrdiff_t>(nq);
+#pragma omp parallel for schedule(dynamic, kChunk)
+  for (std::ptrdiff_t i = 0; i < count; ++i) {
+    size_t const ui = static_cast<size_t>(i);
+    visit_counters c;
+    visit_radius v(radius, &r->rows[ui], approx != 0, e);
+    nearest_search<visit_radius> s(*t, q + ui * t->dim, v,
+                                   counters ? &c : nullptr);
+    s.run();
+    if (sort) {
+      std::sort(r->rows[ui].begin(), r->rows[ui].end(),
+                [](neighbor_t const& a, neighbor_t const& b) {
+                  return a.distance < b.distance;  // core.hpp:49-54
+                });
+    }
+    if (counters) {
+      counters[3 * ui + 0] = c.n_branch;
+      counters[3 * ui + 1] = c.n_leaf;
+      counters[3 * ui + 2] = c.n_pts;
+    }
+  }
+  std::uint64_t acc = 0;
+  for (size_t i = 0; i < nq; ++i) {
+    offsets[i] = acc;
+    acc += r->rows[i].size();
+  }
+  offsets[nq] = acc;
+  return r;
+}
+
+void ptkor_radius_copy(void* h, void* out) {
+  auto* r = static_cast<ragged_nb*>(h);
+  auto* o = static_cast<neighbor_t*>(out);
+  for (auto const& row : r->rows) {
+    if (!row.empty()) std::memcpy(o, row.data(), row.size() * sizeof(neighbor_t));
+    o += row.size();
+  }
+}
+
+void ptkor_radius_free(void* h) { delete static_cast<ragged_nb*>(h); }
+
+// kd_tree::search_box over a batch (kd_tree.hpp:296-318).
+void* ptkor_search_box(void* handle, float const* mins, float const* maxs,
+                       size_t nb, std::uint64_t* offsets) {
+  auto* t = static_cast<tree_t*>(handle);
+  auto* r = new ragged_idx;
+  r->rows.resize(nb);
+  std::ptrdiff_t const count = static_cast<std::ptrdiff_t>(nb);
+#pragma omp parallel for schedule(dynamic, kChunk)
+  for (std::ptrdiff_t i = 0; i < count; ++i) {
+    size_t const ui = static_cast<size_t>(i);
+    box_t query(t->dim);
+    for (size_t d = 0; d < t->dim; ++d) {
+      query.mn(d) = mins[ui * t->dim + d];
+      query.mx(d) = maxs[ui * t->dim + d];
+    }
+    box_t work = t->root_box;
+    r->rows[ui].clear();
+    box_search s{*t, query, r->rows[ui]};
+    s.descend(t->root, work);
+  }
+  std::uint64_t acc = 0;
+  for (size_t i = 0; i < nb; ++i) {
+    offsets[i] = acc;
+    acc += r->rows[i].size();
+  }
+  offsets[nb] = acc;
+  return r;
+}
+
+void ptkor_box_copy(void* h, int* out) {
+  auto* r = static_cast<ragged_idx*>(h);
+  for (auto const& row : r->rows) {
+    if (!row.empty()) std::memcpy(out, row.data(), row.size() * sizeof(int));
+    out += row.size();
+  }
+}
+
+void ptkor_box_free(void* h) { delete static_cast<ragged_idx*>(h); }
+
+// Known-answer hook mirroring test/pico_tree/kd_tree_builder_test.cpp:134-197.
+void ptkor_sliding_midpoint_2d(float const* pts, size_t n, int* indices,
+                               float const* box_min, float const* box_max,
+                               size_t* split_offset, size_t* split_dim,
+                               float* split_val) {
+  tree_t t;
+  t.dim = 2;
+  t.n = n;
+  t.pts.assign(pts, pts + 2 * n);
+  box_t box(2);
+  for (size_t i = 0; i < 2; ++i) {
+    box.mn(i) = box_min[i];
+    box.mx(i) = box_max[i];
+  }
+  int* split = nullptr;
+  size_t sd = 0;
+  float sv = 0;
+  t.split_sliding_midpoint(indices, indices + n, box, split, sd, sv);
+  *split_offset = static_cast<size_t>(split - indices);
+  *split_dim = sd;
+  *split_val = sv;
+}
+
+// metric_l2_squared known answers (test/pico_tree/metric_test.cpp:37-45).
+float ptkor_l2sq(float const* a, float const* b, size_t dim) {
+  return l2sq(a, b, dim);
+}
+float ptkor_l2sq_scalar(float x) { return x * x; }
+
+}  // extern "C"

@@ -1,0 +1,114 @@
+"""Seeded synthetic point clouds for the BASELINE.json configurations.
+
+The reference benchmark (``/root/reference/docs/benchmark.md:11-13``) uses the
+Bremen LiDAR scans, which are not redistributable here; BASELINE.md section 3
+defines the stand-ins generated below.  Everything is derived from a
+counter-based SplitMix64 stream evaluated with integer numpy ops only, so the
+raw 24-bit uniforms are bit-reproducible on any machine and independent of any
+C++ ``<random>`` implementation.
+
+* ``uniform_cloud``  -- cloud "U": uniform in ``[0, scale)^dim``.
+* ``lidar_cloud``    -- cloud "L": a terrestrial scanner inside an 80x80x15 room
+  (rays with uniform azimuth, elevation in [-60deg, +40deg], first hit on
+  floor / ceiling / walls, range cap 60, Gaussian range noise sigma = 0.01),
+  multiplied by the unit scale S (default 20).
+* ``morton_order``   -- permutation sorting 3-D points along a 30-bit Z curve
+  (the "coherent" query order of BASELINE.md section 2).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+_M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(x: np.ndarray) -> np.ndarray:
+    """SplitMix64 finaliser on a uint64 array (wrapping arithmetic)."""
+    with np.errstate(over="ignore"):
+        x = (x + np.uint64(0x9E3779B97F4A7C15)) & _M64
+        z = x
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _M64
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _M64
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def raw_uniform24(seed: int, count: int, stream: int = 0) -> np.ndarray:
+    """``count`` floats in [0, 1) with 24 random mantissa bits, float32-exact."""
+    with np.errstate(over="ignore"):
+        base = _splitmix64(np.array([seed * 0x10001 + stream * 0x9E37 + 1], dtype=np.uint64))[0]
+        ctr = np.arange(count, dtype=np.uint64) + base
+    bits = _splitmix64(ctr) >> np.uint64(40)
+    return (bits.astype(np.float32) * np.float32(2.0 ** -24)).astype(np.float32)
+
+
+def uniform_cloud(n: int, dim: int = 3, seed: int = 1, scale: float = 1.0) -> np.ndarray:
+    """Cloud U: ``n`` points uniform in ``[0, scale)^dim`` (float32, C order)."""
+    u = raw_uniform24(seed, n * dim).reshape(n, dim)
+    return np.ascontiguousarray(u * np.float32(scale), dtype=np.float32)
+
+
+def _normal(seed: int, count: int, stream: int) -> np.ndarray:
+    """Box-Muller on two raw uniform streams (float64 math, deterministic)."""
+    u1 = raw_uniform24(seed, count, stream).astype(np.float64)
+    u2 = raw_uniform24(seed, count, stream + 1).astype(np.float64)
+    u1 = np.maximum(u1, 2.0 ** -25)
+    return np.sqrt(-2.0 * np.log(u1)) * np.cos(2.0 * np.pi * u2)
+
+
+def lidar_cloud(n: int, seed: int = 1, pose=(0.0, 0.0), unit_scale: float = 20.0) -> np.ndarray:
+    """Cloud L: LiDAR-like room scan from scanner position ``pose`` (x, y)."""
+    room_min = np.array([-40.0, -40.0, 0.0])
+    room_max = np.array([40.0, 40.0, 15.0])
+    origin = np.array([pose[0], pose[1], 2.0])
+    az = raw_uniform24(seed, n, 10).astype(np.float64) * (2.0 * np.pi)
+    el_lo, el_hi = np.deg2rad(-60.0), np.deg2rad(40.0)
+    el = el_lo + raw_uniform24(seed, n, 11).astype(np.float64) * (el_hi - el_lo)
+    d = np.stack([np.cos(el) * np.cos(az), np.cos(el) * np.sin(az), np.sin(el)], axis=1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        t_lo = (room_min - origin) / d
+        t_hi = (room_max - origin) / d
+    t_exit = np.where(d > 0, t_hi, t_lo)
+    t_exit = np.where(d == 0, np.inf, t_exit)
+    t = np.min(t_exit, axis=1)
+    t = np.minimum(t, 60.0)
+    t = t + 0.01 * _normal(seed, n, 12)
+    pts = origin + d * t[:, None]
+    return np.ascontiguousarray(pts * unit_scale, dtype=np.float32)
+
+
+def _part1by2(x: np.ndarray) -> np.ndarray:
+    x = x.astype(np.uint64) & np.uint64(0x3FF)
+    x = (x | (x << np.uint64(16))) & np.uint64(0x030000FF)
+    x = (x | (x << np.uint64(8))) & np.uint64(0x0300F00F)
+    x = (x | (x << np.uint64(4))) & np.uint64(0x030C30C3)
+    x = (x | (x << np.uint64(2))) & np.uint64(0x09249249)
+    return x
+
+
+def morton_order(points: np.ndarray) -> np.ndarray:
+    """Stable permutation sorting ``points`` (n, <=3) by a 30-bit Morton code."""
+    p = np.asarray(points, dtype=np.float64)
+    lo = p.min(axis=0)
+    ext = np.maximum(p.max(axis=0) - lo, 1e-30)
+    cells = np.minimum(((p - lo) / ext * 1024.0).astype(np.int64), 1023)
+    code = np.zeros(len(p), dtype=np.uint64)
+    for d in range(min(p.shape[1], 3)):
+        code |= _part1by2(cells[:, d]) << np.uint64(d)
+    return np.argsort(code, kind="stable")
+
+
+#: BASELINE.json configs[1]: the README's tree / query sizes.
+CONFIG2_N = 7_733_372
+CONFIG2_NQ = 7_200_863
+
+
+def config2_clouds(cloud: str = "L", n: int = CONFIG2_N, nq: int = CONFIG2_NQ):
+    """(tree points, query points) for BASELINE config 2, cloud "U" or "L"."""
+    if cloud == "U":
+        return uniform_cloud(n, 3, seed=1, scale=100.0), uniform_cloud(nq, 3, seed=2, scale=100.0)
+    if cloud == "L":
+        return (lidar_cloud(n, seed=1, pose=(0.0, 0.0), unit_scale=20.0),
+                lidar_cloud(nq, seed=2, pose=(3.0, 1.5), unit_scale=20.0))
+    raise ValueError("cloud must be 'U' or 'L'")
