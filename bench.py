@@ -1,0 +1,253 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched k-NN hot path on MI355X.
+
+Metric (BASELINE.json): Mqueries/s, knn = 1, 3-D float32, metric_l2_squared,
+7 733 372-point tree / 7 200 863 queries (BASELINE configs[1]).  One "step" is one
+pass of the whole query batch through ``ptk_search_knn_device`` (device-side
+Morton ordering + traversal kernel [+ RCCL gather of the (index, distance) pairs
+to rank 0 when N > 1]).  Tree points and queries are resident in HBM before the
+timed region; the tree is built and uploaded once, outside it.
+
+    python bench.py --gpus N --steps K --warmup W
+
+For N > 1 the driver launches this file under ``torch.distributed.run``; the
+batch is split into N contiguous shards (strong scaling: the total stays
+7.2 M queries), each rank searches its shard against its own replica of the
+tree, and rank 0 gathers the results.
+
+Rank 0 prints ONE JSON line; see README.md / DESIGN.md for the field meanings.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--cloud", choices=["L", "U"], default="L",
+                    help="L = LiDAR-like room scan (headline), U = uniform cube")
+    ap.add_argument("--order", choices=["generated", "morton"], default="generated",
+                    help="order in which the caller hands over the queries")
+    ap.add_argument("--k", type=int, default=1)
+    ap.add_argument("--n", type=int, default=None, help="tree points (default: config 2)")
+    ap.add_argument("--nq", type=int, default=None, help="queries (default: config 2)")
+    ap.add_argument("--leaf", type=int, default=10)
+    ap.add_argument("--reorder", choices=["auto", "on", "off"], default="auto")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0,
+                    help="approximate budget of the OpenMP CPU baseline sample")
+    ap.add_argument("--counter-sample", type=int, default=200_000,
+                    help="queries sampled for the algorithmic-bytes visit counters")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(ref, q_sample, k, dim):
+    """Mean algorithmic bytes per query, SURVEY.md 8(d):
+    B = 4*dim + 8*k + 16*N_branch + 8*N_leaf + (4*dim + 4)*N_pts,
+    with the visit counts of the reference traversal (from the oracle)."""
+    _, cnt = ref.search_knn(q_sample, k, counters=True)
+    mean = cnt.astype(np.float64).mean(axis=0)
+    b = 4 * dim + 8 * k + 16 * mean[0] + 8 * mean[1] + (4 * dim + 4) * mean[2]
+    return float(b), {"n_branch": float(mean[0]), "n_leaf": float(mean[1]), "n_pts": float(mean[2])}
+
+
+def cpu_baseline(pts, q, k, leaf, seconds):
+    """Times the reference (oracle/_ref, compiled from the reference's own headers) or,
+    failing that, the oracle port, on the host cores, on a bounded sample."""
+    import oracle
+
+    kind = "reference" if oracle.have_reference() else "port"
+    t0 = time.perf_counter()
+    cpu = oracle.Oracle(pts, leaf, kind)
+    build_s = time.perf_counter() - t0
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cpu.set_threads(cores)
+    # OpenMP, schedule(dynamic, 128): chunks until the time budget is used.
+    chunk = 250_000
+    done, t_used = 0, 0.0
+    while done < len(q) and t_used < seconds:
+        part = q[done:done + chunk]
+        t0 = time.perf_counter()
+        cpu.search_knn(part, k)
+        t_used += time.perf_counter() - t0
+        done += len(part)
+    omp = done / t_used / 1e6
+    # single thread on a smaller slice
+    cpu.set_threads(1)
+    n1 = min(len(q), max(20_000, int(omp * 1e6 / cores * 3)))
+    t0 = time.perf_counter()
+    cpu.search_knn(q[:n1], k)
+    st = n1 / (time.perf_counter() - t0) / 1e6
+    cpu.close()
+    return {"value": round(omp, 4), "unit": "Mqueries/s", "cores": cores, "kind": kind,
+            "sample": f"first {done} of {len(q)} queries, same order as the GPU run, "
+                      f"OpenMP schedule(dynamic,128) on {cores} threads",
+            "single_thread_value": round(st, 4), "single_thread_sample": f"first {n1} queries",
+            "build_s": round(build_s, 3)}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+
+    import pico_tree_amd as pt
+    from pico_tree_amd import datasets as ds
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        log(f"warning: WORLD_SIZE={world} but --gpus {args.gpus}; using WORLD_SIZE")
+    n_gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    n = args.n or ds.CONFIG2_N
+    nq = args.nq or ds.CONFIG2_NQ
+    k = args.k
+    dim = 3
+
+    t0 = time.perf_counter()
+    pts, q = ds.config2_clouds(args.cloud, n, nq)
+    if args.order == "morton":
+        q = np.ascontiguousarray(q[ds.morton_order(q)])
+    gen_s = time.perf_counter() - t0
+
+    t0 = time.perf_counter()
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, args.leaf, device=local_rank)
+    build_s = time.perf_counter() - t0
+    tree.set_reorder({"auto": pt.REORDER_AUTO, "on": pt.REORDER_ON, "off": pt.REORDER_OFF}[args.reorder])
+    info = tree.info()
+    if rank == 0:
+        log(f"[bench] clouds {args.cloud}/{args.order}: gen {gen_s:.1f}s, host build+upload {build_s:.1f}s, "
+            f"nodes {info['n_nodes']}, depth {info['max_depth']}, HBM {info['device_bytes'] / 1e6:.1f} MB")
+
+    # Shard: contiguous ranges of ceil(nq / world) queries in caller order.
+    per = (nq + world - 1) // world
+    lo, hi = min(rank * per, nq), min((rank + 1) * per, nq)
+    shard = np.zeros((per, dim), dtype=np.float32)
+    shard[:hi - lo] = q[lo:hi]
+    if hi - lo < per:  # pad the last shard with its first query so every rank gathers `per` rows
+        shard[hi - lo:] = q[lo] if hi > lo else q[0]
+    dq = torch.from_numpy(shard).to(dev)
+    out = torch.empty((per, k, 2), dtype=torch.int32, device=dev)
+    gathered = None
+    if world > 1 and rank == 0:
+        gathered = [torch.empty_like(out) for _ in range(world)]
+
+    def step():
+        tree.search_knn(dq, k, out)
+        if world > 1:
+            dist.gather(out, gathered if rank == 0 else None, dst=0)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    tree.profile(enable=True, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    prof = tree.profile(enable=False, reset=True)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+
+    ms_per_step = elapsed / args.steps * 1e3
+    value = nq / (elapsed / args.steps) / 1e6
+
+    result = None
+    if rank == 0:
+        import oracle
+
+        # Sanity: the timed output equals the oracle on a sample (never timed).
+        res = pt.DeviceNeighbors(out).numpy()
+        sample = np.linspace(0, (hi - lo) - 1, num=min(4096, hi - lo), dtype=np.int64)
+        ref_small = oracle.Oracle(pts, args.leaf, "port")
+        want = ref_small.search_knn(q[lo:hi][sample], k)
+        got = res[sample] if k > 1 else res[sample][:, None]
+        parity_ok = bool(got.tobytes() == want.tobytes())
+
+        rng = np.random.default_rng(7)
+        cs = rng.choice(nq, size=min(args.counter_sample, nq), replace=False)
+        b_per_q, visits = algorithmic_bytes(ref_small, q[np.sort(cs)], k, dim)
+        ref_small.close()
+
+        launches = max(int(prof["launches"]), 1)
+        kernel_ms = prof["search_ms"] / launches
+        q_per_launch = prof["queries"] / launches if prof["launches"] else per
+        achieved = (b_per_q * q_per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "kernel": "knn1_kernel" if k == 1 else "knn_kernel",
+                    "kernel_ms": round(kernel_ms, 4), "reorder_ms": round(prof["reorder_ms"] / launches, 4),
+                    "bytes_per_query": round(b_per_q, 1), "queries_per_launch": int(q_per_launch),
+                    "visits_per_query": {kk: round(v, 2) for kk, v in visits.items()}}
+
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline(pts, q, k, args.leaf, args.cpu_seconds)
+
+        result = {
+            "metric": "Mqueries/sec, knn=1 3D L2, 7.73M-pt tree / 7.20M queries" if k == 1 and not args.n
+                      else f"Mqueries/sec, knn={k} 3D L2",
+            "value": round(value, 3), "unit": "Mqueries/s", "n_gpus": n_gpus, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: cloud {args.cloud} "
+                                   f"({'LiDAR-like room scan' if args.cloud == 'L' else 'uniform cube'}), "
+                                   f"{n} tree points / {nq} queries, knn={k}, max_leaf_size={args.leaf}, "
+                                   f"sliding midpoint",
+                       "query_order": args.order, "reorder": args.reorder,
+                       "parallelism": f"queries sharded x{world}, tree replicated"
+                                      + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "tree_nodes": int(info["n_nodes"]), "tree_depth": int(info["max_depth"]),
+                       "host_build_upload_s": round(build_s, 2)},
+            "parity_sample_ok": parity_ok,
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and result is not None and not result["parity_sample_ok"]:
+        raise SystemExit("parity check failed")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,131 @@
+#pragma once
+//! \file backend.hpp
+//! \brief Glue between the header-only host API and the C-ABI HIP backend.
+//! \details Everything that crosses into libptk.so goes through the plain C
+//! functions of include/ptk.h.  A non-zero status becomes a std::runtime_error
+//! carrying ptk_last_error().  There is deliberately NO host fallback here: if
+//! the backend cannot be used (library built without a device, no gfx950 GPU)
+//! the batched calls throw.
+
+#include <cstdint>
+#include <memory>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "../../ptk.h"
+#include "../core.hpp"
+#include "../map.hpp"
+#include "../metric.hpp"
+#include "access.hpp"
+#include "flat_tree.hpp"
+
+namespace pico_tree::internal {
+
+inline void ptk_check(int status, char const* what) {
+  if (status != PTK_OK) {
+    throw std::runtime_error(
+        std::string("pico_tree backend: ") + what + ": " + ptk_last_error());
+  }
+}
+
+//! Which kd_tree instantiations run on the GPU.
+template <typename Metric_, typename Scalar_, typename Index_>
+inline constexpr bool is_accelerated_v =
+    std::is_same_v<Metric_, metric_l2_squared> && std::is_same_v<Scalar_, float> &&
+    std::is_same_v<Index_, int> && sizeof(int) == 4;
+
+//! True for space types whose points are known to be one contiguous row-major
+//! float matrix, so a batch can be handed over without a gather copy.
+template <typename Space_>
+struct is_dense_space : std::false_type {};
+template <typename Scalar_, size_t Dim_>
+struct is_dense_space<space_map<point_map<Scalar_, Dim_>>> : std::true_type {};
+template <typename Scalar_, std::size_t Dim_, typename Alloc_>
+struct is_dense_space<std::vector<std::array<Scalar_, Dim_>, Alloc_>> : std::true_type {};
+
+//! Row-major float matrix view of any space: zero-copy when dense, gathered
+//! otherwise.
+template <typename Space_>
+class dense_rows {
+ public:
+  explicit dense_rows(Space_ const& space) {
+    space_view<Space_> view(space);
+    n_ = view.size();
+    dim_ = view.sdim();
+    if constexpr (is_dense_space<Space_>::value) {
+      data_ = n_ > 0 ? view[size_t(0)] : nullptr;
+    } else {
+      owned_.resize(n_ * dim_);
+      for (size_t i = 0; i < n_; ++i) {
+        float const* p = view[i];
+        for (size_t d = 0; d < dim_; ++d) owned_[i * dim_ + d] = p[d];
+      }
+      data_ = owned_.data();
+    }
+  }
+  float const* data() const { return data_; }
+  size_t rows() const { return n_; }
+  size_t cols() const { return dim_; }
+
+ private:
+  std::vector<float> owned_;
+  float const* data_ = nullptr;
+  size_t n_ = 0;
+  size_t dim_ = 0;
+};
+
+//! Owns the device-side replica of one flat tree; created lazily, shared by
+//! moves of the owning kd_tree.
+class device_tree {
+ public:
+  device_tree() : state_(std::make_shared<state>()) {}
+
+  template <typename Tree_, typename SpaceView_>
+  ptk_tree* get(Tree_ const& tree, SpaceView_ const& space) const {
+    static_assert(sizeof(typename Tree_::node_type) == sizeof(ptk_node), "node layout");
+    std::lock_guard<std::mutex> lock(state_->mutex);
+    if (state_->handle == nullptr) {
+      size_t const n = space.size();
+      size_t const dim = space.sdim();
+      std::vector<float> pts(n * dim);
+      for (size_t i = 0; i < n; ++i) {
+        float const* p = space[i];
+        for (size_t d = 0; d < dim; ++d) pts[i * dim + d] = p[d];
+      }
+      ptk_tree_desc desc{};
+      desc.dim = static_cast<std::uint32_t>(dim);
+      desc.n_points = n;
+      desc.points = pts.data();
+      desc.n_nodes = tree.nodes.size();
+      desc.nodes = reinterpret_cast<ptk_node const*>(tree.nodes.data());
+      desc.indices = tree.indices.data();
+      desc.root_min = tree.root_box.min();
+      desc.root_max = tree.root_box.max();
+      desc.max_depth = tree.max_depth;
+      desc.device = PTK_DEVICE_CURRENT;
+      ptk_tree* h = nullptr;
+      ptk_check(ptk_tree_create(&desc, &h), "ptk_tree_create");
+      state_->handle = h;
+      state_->destroy = &ptk_tree_destroy;
+    }
+    return state_->handle;
+  }
+
+ private:
+  struct state {
+    std::mutex mutex;
+    ptk_tree* handle = nullptr;
+    // Set where the handle is made, so that a translation unit that never issues
+    // a batched call does not reference (and need not link) libptk.
+    void (*destroy)(ptk_tree*) = nullptr;
+    ~state() {
+      if (handle != nullptr && destroy != nullptr) destroy(handle);
+    }
+  };
+  std::shared_ptr<state> state_;
+};
+
+}  // namespace pico_tree::internal

@@ -1,0 +1,221 @@
+#pragma once
+//! \file flat_search.hpp
+//! \brief Single-query traversals over a flat_tree on the host.
+//! \details These serve the per-query members of kd_tree (custom visitors,
+//! custom metrics, double precision): the batched members of the accelerated
+//! instantiation never come here, they go to the HIP backend.
+//!
+//! nearest_search is the reference's near-first depth-first search with
+//! incremental box distances (internal/kd_tree_search.hpp:24-113, after Arya &
+//! Mount) turned into a loop over one LIFO of small records -- the same scheme
+//! the gfx950 kernels run per lane:
+//!
+//!   state     : node, box distance `nbd`, per-axis offsets `off[dim]`
+//!   pending   : {far child, axis, new_offset}   pushed when a branch is passed
+//!   undo_off  : {axis, previous off[axis]}      pushed when a far child is entered
+//!   undo_nbd  : {previous nbd}                  idem
+//!
+//! Popping a pending record recomputes nbd' = nbd - off[axis] + new_offset with
+//! the state of the node that pushed it (the undo records below it have already
+//! restored that state), applies the reference's test `visitor.max() >= nbd'`
+//! (:99) and, if it passes, enters the far child.  Visit order, distance bits
+//! and tie-breaking are therefore those of the recursive reference.
+
+#include <cstdint>
+#include <vector>
+
+#include "../core.hpp"
+#include "flat_tree.hpp"
+
+namespace pico_tree::internal {
+
+template <typename Scalar_>
+struct search_record {
+  enum kind_t : std::uint32_t { pending = 0, undo_off = 1, undo_nbd = 2 };
+  std::uint32_t kind;
+  std::uint32_t node;  //!< pending: far child
+  std::uint32_t axis;  //!< pending, undo_off
+  Scalar_ value;       //!< pending: new_offset; undo_*: value to restore
+};
+
+template <typename Tree_, typename SpaceView_, typename Metric_, typename PointView_, typename Visitor_>
+inline void nearest_search(
+    Tree_ const& tree,
+    SpaceView_ const& space,
+    Metric_ const& metric,
+    PointView_ const& query,
+    Visitor_& visitor) {
+  using scalar = typename Tree_::scalar_type;
+  using record = search_record<scalar>;
+  auto const* const nodes = tree.nodes.data();
+  auto const* const indices = tree.indices.data();
+
+  // Offsets: on the stack for small fixed dimensions, heap otherwise.
+  constexpr size_t kInline = 8;
+  scalar inline_off[kInline] = {};
+  std::vector<scalar> heap_off;
+  size_t const sdim = space.sdim();
+  scalar* off = inline_off;
+  if (sdim > kInline) {
+    heap_off.assign(sdim, scalar(0));
+    off = heap_off.data();
+  }
+
+  constexpr size_t kInlineRecords = 3 * 64;
+  record inline_records[kInlineRecords];
+  std::vector<record> heap_records;
+  record* stack = inline_records;
+  size_t capacity = kInlineRecords;
+  size_t top = 0;
+  auto push = [&](record const& r) {
+    if (top == capacity) {  // rare: very deep tree
+      if (stack == inline_records) heap_records.assign(stack, stack + top);
+      heap_records.resize(capacity * 2);
+      capacity *= 2;
+      stack = heap_records.data();
+    }
+    stack[top++] = r;
+  };
+
+  std::uint32_t node = 0;
+  scalar nbd = scalar(0);
+
+  for (;;) {
+    // Walk down to a leaf, always into the child nearer to the query.
+    while (!nodes[node].is_leaf()) {
+      auto const& b = nodes[node];
+      size_t const axis = b.split_dim;
+      scalar const v = query[axis];
+      std::uint32_t near_child, far_child;
+      scalar new_offset;
+      if ((b.left_max + b.right_min - v - v) > 0) {
+        near_child = node + 1;
+        far_child = b.right;
+        new_offset = metric(b.right_min - v);
+      } else {
+        near_child = b.right;
+        far_child = node + 1;
+        new_offset = metric(b.left_max - v);
+      }
+      push(record{record::pending, far_child, static_cast<std::uint32_t>(axis), new_offset});
+      node = near_child;
+    }
+
+    // Measure the leaf's points in index order.
+    {
+      auto const& leaf = nodes[node];
+      for (auto i = leaf.begin; i < leaf.end; ++i) {
+        auto const idx = indices[i];
+        visitor(idx, metric(query.begin(), query.end(), space[idx]));
+      }
+    }
+
+    // Unwind to the next far child worth entering.
+    for (;;) {
+      if (top == 0) return;
+      record const r = stack[--top];
+      if (r.kind == record::undo_nbd) {
+        nbd = r.value;
+      } else if (r.kind == record::undo_off) {
+        off[r.axis] = r.value;
+      } else {
+        scalar const old_offset = off[r.axis];
+        scalar const far_nbd = nbd - old_offset + r.value;
+        if (visitor.max() >= far_nbd) {
+          push(record{record::undo_off, 0, r.axis, old_offset});
+          push(record{record::undo_nbd, 0, 0, nbd});
+          off[r.axis] = r.value;
+          nbd = far_nbd;
+          node = r.node;
+          break;
+        }
+      }
+    }
+  }
+}
+
+//! All indices inside the closed box [qmin, qmax], in the reference's report
+//! order (internal/kd_tree_search.hpp:238-381): a node whose running box is
+//! fully inside the query is reported wholesale, a partially covered node is
+//! descended, left before right.
+template <typename Tree_, typename SpaceView_, typename Index_>
+inline void box_search(
+    Tree_ const& tree,
+    SpaceView_ const& space,
+    typename Tree_::scalar_type const* qmin,
+    typename Tree_::scalar_type const* qmax,
+    std::vector<Index_>& out) {
+  using scalar = typename Tree_::scalar_type;
+  using box_type = typename Tree_::box_type;
+  auto const* const nodes = tree.nodes.data();
+  auto const* const indices = tree.indices.data();
+  size_t const sdim = space.sdim();
+
+  box_type query(sdim);
+  for (size_t i = 0; i < sdim; ++i) {
+    query.min(i) = qmin[i];
+    query.max(i) = qmax[i];
+  }
+  box_type box = tree.root_box;
+
+  // Range of index positions covered by a subtree: its left-most leaf's begin
+  // and right-most leaf's end.
+  auto const first_pos = [&](std::uint32_t n) {
+    while (!nodes[n].is_leaf()) n = n + 1;
+    return nodes[n].begin;
+  };
+  auto const last_pos = [&](std::uint32_t n) {
+    while (!nodes[n].is_leaf()) n = nodes[n].right;
+    return nodes[n].end;
+  };
+  auto const report = [&](std::uint32_t n) {
+    for (auto i = first_pos(n); i < last_pos(n); ++i) out.push_back(indices[i]);
+  };
+
+  // Explicit stack of {node, phase}; phase 0 = enter, 1 = left done, 2 = right done.
+  struct frame {
+    std::uint32_t node;
+    std::uint32_t phase;
+    scalar saved;
+  };
+  std::vector<frame> stack;
+  stack.push_back(frame{0, 0, scalar(0)});
+  while (!stack.empty()) {
+    frame& f = stack.back();
+    auto const& nd = nodes[f.node];
+    if (nd.is_leaf()) {
+      for (auto i = nd.begin; i < nd.end; ++i) {
+        if (query.contains(space[indices[i]])) out.push_back(indices[i]);
+      }
+      stack.pop_back();
+      continue;
+    }
+    size_t const axis = nd.split_dim;
+    if (f.phase == 0) {
+      f.phase = 1;
+      f.saved = box.max(axis);
+      box.max(axis) = nd.left_max;
+      if (query.contains(box)) {
+        report(f.node + 1);
+      } else if (query.min(axis) <= nd.left_max) {
+        stack.push_back(frame{f.node + 1, 0, scalar(0)});
+      }
+    } else if (f.phase == 1) {
+      f.phase = 2;
+      box.max(axis) = f.saved;
+      f.saved = box.min(axis);
+      box.min(axis) = nd.right_min;
+      if (query.contains(box)) {
+        report(nd.right);
+      } else if (query.max(axis) >= nd.right_min) {
+        std::uint32_t const r = nd.right;
+        stack.push_back(frame{r, 0, scalar(0)});
+      }
+    } else {
+      box.min(axis) = f.saved;
+      stack.pop_back();
+    }
+  }
+}
+
+}  // namespace pico_tree::internal

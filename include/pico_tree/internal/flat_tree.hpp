@@ -1,0 +1,379 @@
+#pragma once
+//! \file flat_tree.hpp
+//! \brief The kd-tree as one flat array: build parameters, storage, builder.
+//! \details The reference stores pointer-linked nodes in a chunk allocator
+//! (internal/kd_tree_node.hpp:7-27, internal/memory.hpp:20-127).  Here the tree
+//! is flat from the start: nodes live in one std::vector in depth-first
+//! pre-order, the left child of a branch is the next element and the right
+//! child is stored as an index.  That order is also the reference's on-disk
+//! order (internal/kd_tree_data.hpp:109-135) and, after re-encoding, the layout
+//! the HIP backend keeps in HBM.
+//!
+//! The builder reproduces the reference tree exactly (same split planes, same
+//! index permutation, same tightened left_max / right_min):
+//!   build_kd_tree_impl::create_node    internal/kd_tree_builder.hpp:352-396
+//!   sliding midpoint / midpoint / median splitters   :144-280
+//!   stop conditions                    :410-425
+//!   start bounds                       :496-511
+//! It calls std::partition / std::nth_element with the same predicates in the
+//! same sequence, because their permutation decides the visit order inside a
+//! leaf and therefore which of two equidistant points a query reports.
+
+#include <algorithm>
+#include <array>
+#include <cassert>
+#include <cstdint>
+#include <limits>
+#include <type_traits>
+#include <vector>
+
+#include "../core.hpp"
+#include "access.hpp"
+
+namespace pico_tree {
+
+// ---- build parameters (public names kept from the reference) ---------------
+
+template <typename Derived_>
+struct splitter_rule_t {
+  Derived_ const& derived() const { return *static_cast<Derived_ const*>(this); }
+
+ protected:
+  constexpr explicit splitter_rule_t() = default;
+  constexpr explicit splitter_rule_t(splitter_rule_t const&) = default;
+  constexpr explicit splitter_rule_t(splitter_rule_t&&) = default;
+};
+
+//! Split on the median along the longest side of the node box.
+struct median_max_side_t : splitter_rule_t<median_max_side_t> {
+  constexpr explicit median_max_side_t() = default;
+};
+//! Split the node box in the middle of its longest side; may leave empty leaves.
+struct midpoint_max_side_t : splitter_rule_t<midpoint_max_side_t> {
+  constexpr explicit midpoint_max_side_t() = default;
+};
+//! Midpoint split that slides to the nearest point when one side would be empty.
+struct sliding_midpoint_max_side_t : splitter_rule_t<sliding_midpoint_max_side_t> {
+  constexpr explicit sliding_midpoint_max_side_t() = default;
+};
+
+inline constexpr median_max_side_t median_max_side{};
+inline constexpr midpoint_max_side_t midpoint_max_side{};
+inline constexpr sliding_midpoint_max_side_t sliding_midpoint_max_side{};
+
+template <typename Derived_>
+struct splitter_stop_condition_t {
+  Derived_ const& derived() const { return *static_cast<Derived_ const*>(this); }
+
+ protected:
+  constexpr explicit splitter_stop_condition_t() = default;
+  constexpr explicit splitter_stop_condition_t(splitter_stop_condition_t const&) = default;
+  constexpr explicit splitter_stop_condition_t(splitter_stop_condition_t&&) = default;
+};
+
+//! A node with at most this many points becomes a leaf.
+struct max_leaf_size_t : splitter_stop_condition_t<max_leaf_size_t> {
+  constexpr max_leaf_size_t(size_t v) : value(v) { assert(value > 0); }
+  size_t value;
+};
+
+//! A node at this depth becomes a leaf (depth 0 = the root).
+struct max_leaf_depth_t : splitter_stop_condition_t<max_leaf_depth_t> {
+  constexpr max_leaf_depth_t(size_t v) : value(v) {}
+  size_t value;
+};
+
+template <typename Derived_>
+struct splitter_start_bounds_t {
+  Derived_ const& derived() const { return *static_cast<Derived_ const*>(this); }
+
+ protected:
+  constexpr explicit splitter_start_bounds_t() = default;
+  constexpr explicit splitter_start_bounds_t(splitter_start_bounds_t const&) = default;
+  constexpr explicit splitter_start_bounds_t(splitter_start_bounds_t&&) = default;
+};
+
+//! Start from the bounding box of the point set.
+struct bounds_from_space_t : splitter_start_bounds_t<bounds_from_space_t> {
+  constexpr explicit bounds_from_space_t() = default;
+};
+inline constexpr bounds_from_space_t bounds_from_space{};
+
+//! Start from a caller-supplied box.
+template <typename Point_>
+struct bounds_t : splitter_start_bounds_t<bounds_t<Point_>> {
+  constexpr explicit bounds_t(Point_ const& min, Point_ const& max)
+      : min_(min), max_(max) {}
+  constexpr Point_ const& min() const { return min_; }
+  constexpr Point_ const& max() const { return max_; }
+
+ private:
+  Point_ min_;
+  Point_ max_;
+};
+
+namespace internal {
+
+inline constexpr std::uint32_t flat_leaf_tag = 0xFFFFFFFFu;
+
+//! One node.  For <int, float> this is 16 bytes and layout-identical to the
+//! C-ABI's ptk_node {a, b, right, split_dim} (include/ptk.h).
+template <typename Index_, typename Scalar_>
+struct flat_node {
+  union {
+    Scalar_ left_max;  //!< branch: max of the (tightened) left box on split_dim
+    Index_ begin;      //!< leaf: first position in indices
+  };
+  union {
+    Scalar_ right_min;  //!< branch: min of the (tightened) right box
+    Index_ end;         //!< leaf: one past the last position in indices
+  };
+  std::uint32_t right;      //!< branch: index of the right child; leaf: flat_leaf_tag
+  std::uint32_t split_dim;  //!< branch: split axis
+
+  bool is_leaf() const { return right == flat_leaf_tag; }
+};
+
+//! Axis-aligned box with compile-time or run-time dimension: min[d], max[d].
+template <typename Scalar_, size_t Dim_>
+class aabb {
+  using storage = std::conditional_t<
+      Dim_ == dynamic_extent,
+      std::vector<Scalar_>,
+      std::array<Scalar_, (Dim_ == dynamic_extent ? 1 : 2 * Dim_)>>;
+
+ public:
+  explicit aabb(size_t d) : d_(d) {
+    if constexpr (Dim_ == dynamic_extent) c_.resize(2 * d);
+  }
+  size_t size() const { return d_; }
+  Scalar_* min() { return c_.data(); }
+  Scalar_* max() { return c_.data() + d_; }
+  Scalar_ const* min() const { return c_.data(); }
+  Scalar_ const* max() const { return c_.data() + d_; }
+  Scalar_& min(size_t i) { return c_[i]; }
+  Scalar_& max(size_t i) { return c_[d_ + i]; }
+  Scalar_ min(size_t i) const { return c_[i]; }
+  Scalar_ max(size_t i) const { return c_[d_ + i]; }
+
+  //! Inverted box that any fit() will shrink-wrap (box.hpp:54-59).
+  void invert() {
+    for (size_t i = 0; i < d_; ++i) {
+      min(i) = std::numeric_limits<Scalar_>::max();
+      max(i) = std::numeric_limits<Scalar_>::lowest();
+    }
+  }
+  void fit(Scalar_ const* x) {
+    for (size_t i = 0; i < d_; ++i) {
+      if (x[i] < min(i)) min(i) = x[i];
+      if (x[i] > max(i)) max(i) = x[i];
+    }
+  }
+  void fit(aabb const& o) {
+    for (size_t i = 0; i < d_; ++i) {
+      if (o.min(i) < min(i)) min(i) = o.min(i);
+      if (o.max(i) > max(i)) max(i) = o.max(i);
+    }
+  }
+  //! First axis with the strictly greatest extent (box.hpp:71-82).
+  void longest_side(size_t& axis, Scalar_& extent) const {
+    extent = std::numeric_limits<Scalar_>::lowest();
+    for (size_t i = 0; i < d_; ++i) {
+      Scalar_ const delta = max(i) - min(i);
+      if (delta > extent) {
+        axis = i;
+        extent = delta;
+      }
+    }
+  }
+  //! Closed containment test (box.hpp:31-47).
+  bool contains(Scalar_ const* x) const {
+    for (size_t i = 0; i < d_; ++i) {
+      if (min(i) > x[i] || max(i) < x[i]) return false;
+    }
+    return true;
+  }
+  bool contains(aabb const& o) const { return contains(o.min()) && contains(o.max()); }
+
+ private:
+  size_t d_;
+  storage c_;
+};
+
+//! The whole index structure.  Points are not stored (the space owns them).
+template <typename Index_, typename Scalar_, size_t Dim_>
+struct flat_tree {
+  using index_type = Index_;
+  using scalar_type = Scalar_;
+  using node_type = flat_node<Index_, Scalar_>;
+  using box_type = aabb<Scalar_, Dim_>;
+  static constexpr size_t dim = Dim_;
+
+  explicit flat_tree(size_t sdim) : root_box(sdim) {}
+
+  std::vector<Index_> indices;   //!< leaf-ordered permutation of [0, n)
+  box_type root_box;             //!< start bounds of the build
+  std::vector<node_type> nodes;  //!< DFS pre-order; nodes[0] is the root
+  std::uint32_t max_depth = 0;   //!< depth of the deepest node (root = 0)
+  size_t leaf_count = 0;
+  size_t max_leaf_points = 0;
+};
+
+//! Builds a flat_tree over a space_view.
+template <typename SpaceView_, typename Index_, typename Rule_, typename Stop_>
+class flat_builder {
+ public:
+  using scalar_type = typename SpaceView_::scalar_type;
+  static constexpr size_t dim = SpaceView_::dim;
+  using tree_type = flat_tree<Index_, scalar_type, dim>;
+  using box_type = typename tree_type::box_type;
+
+  flat_builder(SpaceView_ const& space, size_t stop_value, tree_type& out)
+      : space_(space), stop_(static_cast<Index_>(stop_value)), tree_(out) {}
+
+  void run(box_type const& start_bounds) {
+    size_t const n = space_.size();
+    assert(n > 0);
+    tree_.indices.resize(n);
+    for (size_t i = 0; i < n; ++i) tree_.indices[i] = static_cast<Index_>(i);
+    tree_.root_box = start_bounds;
+    tree_.nodes.clear();
+    // A binary tree with L leaves has 2L - 1 nodes; reserve for ~n / (stop/2).
+    tree_.nodes.reserve(std::is_same_v<Stop_, max_leaf_size_t>
+                            ? 4 * n / static_cast<size_t>(stop_ > 0 ? stop_ : 1) + 16
+                            : 1024);
+    box_type work = start_bounds;
+    Index_* const base = tree_.indices.data();
+    grow(0, base, base + n, work);
+  }
+
+ private:
+  bool stops(std::uint32_t depth, Index_ const* begin, Index_ const* end) const {
+    if constexpr (std::is_same_v<Stop_, max_leaf_size_t>) {
+      return (end - begin) <= stop_;
+    } else {
+      return (static_cast<Index_>(depth) == stop_) || ((end - begin) <= 1);
+    }
+  }
+
+  void split(
+      Index_* begin,
+      Index_* end,
+      box_type const& box,
+      Index_*& cut,
+      size_t& axis,
+      scalar_type& plane) const {
+    scalar_type extent;
+    box.longest_side(axis, extent);
+    size_t const a = axis;
+    auto const by_axis = [this, a](Index_ const i, Index_ const j) -> bool {
+      return space_[i][a] < space_[j][a];
+    };
+
+    if constexpr (std::is_same_v<Rule_, median_max_side_t>) {
+      cut = begin + (end - begin) / 2;
+      std::nth_element(begin, cut, end, by_axis);
+      plane = space_[*cut][a];
+    } else {
+      if constexpr (std::is_same_v<Rule_, midpoint_max_side_t>) {
+        plane = extent * scalar_type(0.5) + box.min(a);
+      } else {
+        plane = extent / scalar_type(2.0) + box.min(a);
+      }
+      scalar_type const p = plane;
+      cut = std::partition(begin, end, [this, a, p](Index_ const i) -> bool {
+        return space_[i][a] < p;
+      });
+      if constexpr (std::is_same_v<Rule_, sliding_midpoint_max_side_t>) {
+        if (cut == end) {  // nothing on the right: slide the largest point over
+          --cut;
+          std::nth_element(begin, cut, end, by_axis);
+          plane = space_[*cut][a];
+        } else if (cut == begin) {  // nothing on the left
+          ++cut;
+          std::nth_element(begin, cut, end, by_axis);
+          plane = space_[*cut][a];
+        }
+      }
+    }
+  }
+
+  std::uint32_t grow(std::uint32_t depth, Index_* begin, Index_* end, box_type& box) {
+    std::uint32_t const self = static_cast<std::uint32_t>(tree_.nodes.size());
+    tree_.nodes.emplace_back();
+    if (depth > tree_.max_depth) tree_.max_depth = depth;
+
+    if (stops(depth, begin, end)) {
+      auto& leaf = tree_.nodes[self];
+      leaf.begin = static_cast<Index_>(begin - tree_.indices.data());
+      leaf.end = static_cast<Index_>(end - tree_.indices.data());
+      leaf.right = flat_leaf_tag;
+      leaf.split_dim = 0;
+      ++tree_.leaf_count;
+      tree_.max_leaf_points =
+          std::max(tree_.max_leaf_points, static_cast<size_t>(end - begin));
+      // Shrink the box to the leaf's points; an empty leaf (midpoint rule only)
+      // keeps the box it was given.
+      if (begin < end || !std::is_same_v<Rule_, midpoint_max_side_t>) {
+        box.invert();
+        for (Index_* it = begin; it < end; ++it) box.fit(space_[*it]);
+      }
+      return self;
+    }
+
+    Index_* cut;
+    size_t axis;
+    scalar_type plane;
+    split(begin, end, box, cut, axis, plane);
+
+    box_type right = box;
+    box.max(axis) = plane;    // `box` now bounds the left child
+    right.min(axis) = plane;
+
+    grow(depth + 1, begin, cut, box);  // lands at self + 1
+    std::uint32_t const r = grow(depth + 1, cut, end, right);
+
+    auto& branch = tree_.nodes[self];  // taken after the recursion: vector may grow
+    branch.left_max = box.max(axis);   // both tightened by the children
+    branch.right_min = right.min(axis);
+    branch.right = r;
+    branch.split_dim = static_cast<std::uint32_t>(axis);
+
+    box.fit(right);  // parent box = union of the children
+    return self;
+  }
+
+  SpaceView_ const& space_;
+  Index_ stop_;
+  tree_type& tree_;
+};
+
+//! Entry point: build with the given parameters.
+template <typename Index_, typename SpaceView_, typename Stop_, typename Bounds_, typename Rule_>
+flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_tree(
+    SpaceView_ const& space,
+    splitter_stop_condition_t<Stop_> const& stop,
+    splitter_start_bounds_t<Bounds_> const& bounds,
+    splitter_rule_t<Rule_> const&) {
+  using scalar_type = typename SpaceView_::scalar_type;
+  using tree_type = flat_tree<Index_, scalar_type, SpaceView_::dim>;
+  using box_type = typename tree_type::box_type;
+
+  size_t const sdim = space.sdim();
+  box_type start(sdim);
+  start.invert();
+  if constexpr (std::is_same_v<Bounds_, bounds_from_space_t>) {
+    for (size_t i = 0; i < space.size(); ++i) start.fit(space[i]);
+  } else {
+    using bound_point = std::decay_t<decltype(bounds.derived().min())>;
+    start.fit(point_view<bound_point>(bounds.derived().min()).data());
+    start.fit(point_view<bound_point>(bounds.derived().max()).data());
+  }
+
+  tree_type tree(sdim);
+  flat_builder<SpaceView_, Index_, Rule_, Stop_>(space, stop.derived().value, tree).run(start);
+  return tree;
+}
+
+}  // namespace internal
+}  // namespace pico_tree

@@ -1,0 +1,420 @@
+#pragma once
+//! \file kd_tree.hpp
+//! \brief pico_tree::kd_tree -- the public search structure.
+//! \details Source-compatible with the reference class
+//! (/root/reference/src/pico_tree/pico_tree/kd_tree.hpp:19-435): same template
+//! parameters, constructor, per-query members, tags, CTAD guide and
+//! make_kd_tree.  Two things differ underneath:
+//!
+//!  1. The tree is a flat depth-first array (internal/flat_tree.hpp) instead of
+//!     pointer-linked nodes.
+//!  2. A family of BATCHED members takes a whole query space at once -- the
+//!     shape of the reference's only batched caller, the OpenMP loops of its
+//!     Python binding (src/pyco_tree/pico_tree/_pyco_tree/kd_tree.hpp:117-268).
+//!     For kd_tree<Space, metric_l2_squared, int> over float they run on the
+//!     MI355X through the C ABI of include/ptk.h (link with -lptk).  They have
+//!     no host fallback: without a usable backend they throw.
+//!
+//! The per-query members (search_nn(x, nn), search_knn(x, k, knn), custom
+//! visitors, other metrics, double) run on the host, as in the reference.
+
+#include <algorithm>
+#include <fstream>
+#include <iostream>
+#include <iterator>
+#include <string>
+#include <type_traits>
+#include <vector>
+
+#include "core.hpp"
+#include "internal/access.hpp"
+#include "internal/backend.hpp"
+#include "internal/flat_search.hpp"
+#include "internal/flat_tree.hpp"
+#include "internal/stream.hpp"
+#include "internal/visitors.hpp"
+#include "metric.hpp"
+
+namespace pico_tree {
+
+template <typename Space_, typename Metric_ = metric_l2_squared, typename Index_ = int>
+class kd_tree {
+  static_assert(
+      std::is_same_v<std::remove_cv_t<Space_>, Space_>,
+      "SPACE_TYPE_MUST_BE_NON-CONST_NON-VOLATILE");
+  static_assert(
+      std::is_same_v<typename Metric_::space_category, euclidean_space_tag>,
+      "ONLY_EUCLIDEAN_METRICS_ARE_SUPPORTED_BY_THIS_BUILD");
+
+  using plain_space_type = internal::unwrap_ref_t<Space_>;
+  using space_view_type = internal::space_view<plain_space_type>;
+
+ public:
+  using size_type = size_t;
+  using index_type = Index_;
+  using scalar_type = typename space_view_type::scalar_type;
+  static constexpr size_type dim = space_view_type::dim;
+  using space_type = Space_;
+  using metric_type = Metric_;
+  using neighbor_type = neighbor<index_type, scalar_type>;
+
+ private:
+  using tree_type = internal::flat_tree<index_type, scalar_type, dim>;
+  static constexpr bool accelerated =
+      internal::is_accelerated_v<Metric_, scalar_type, Index_>;
+
+ public:
+  //! Index positions of one leaf: a [begin, end) range into the tree's indices.
+  class leaf_range_type {
+   public:
+    using iterator_type = typename std::vector<index_type>::const_iterator;
+    leaf_range_type(iterator_type b, iterator_type e) : b_(b), e_(e) {}
+    iterator_type begin() const { return b_; }
+    iterator_type end() const { return e_; }
+
+   private:
+    iterator_type b_;
+    iterator_type e_;
+  };
+
+  //! Builds the tree.  \p space is taken by value: move it in, or use
+  //! std::reference_wrapper<Space> as the space type to borrow it.
+  template <
+      typename Stop_,
+      typename Bounds_ = bounds_from_space_t,
+      typename Rule_ = sliding_midpoint_max_side_t>
+  kd_tree(
+      space_type space,
+      splitter_stop_condition_t<Stop_> const& stop_condition,
+      splitter_start_bounds_t<Bounds_> const& start_bounds = Bounds_{},
+      splitter_rule_t<Rule_> const& rule = Rule_{})
+      : space_(std::move(space)),
+        metric_(),
+        tree_(internal::build_flat_tree<index_type>(
+            view(), stop_condition, start_bounds, rule)) {}
+
+  kd_tree(kd_tree const&) = delete;
+  kd_tree(kd_tree&&) = default;
+  kd_tree& operator=(kd_tree const&) = delete;
+  kd_tree& operator=(kd_tree&&) = default;
+
+  // ---- per-query searches (host) -------------------------------------------
+
+  //! Generic traversal: \p visitor sees every measured point as
+  //! visitor(index, distance) and prunes with visitor.max().
+  template <typename P_, typename V_>
+  inline void search_nearest(P_ const& x, V_& visitor) const {
+    using query_view = internal::point_view<P_>;
+    static_assert(
+        std::is_same_v<scalar_type, typename query_view::scalar_type>,
+        "POINT_AND_TREE_SCALAR_TYPES_DIFFER");
+    static_assert(
+        dim == query_view::dim || dim == dynamic_extent ||
+            query_view::dim == dynamic_extent,
+        "POINT_AND_TREE_DIMS_DIFFER");
+    query_view q(x);
+    space_view_type s = view();
+    internal::nearest_search(tree_, s, metric_, q, visitor);
+  }
+
+  template <typename P_>
+  inline void search_nn(P_ const& x, neighbor_type& nn) const {
+    internal::nn_visitor<neighbor_type> v(nn);
+    search_nearest(x, v);
+  }
+
+  //! Approximate nn: may return a neighbour up to a factor \p e (in metric
+  //! units) farther than the true one; the reported distance is scaled by 1/e.
+  template <typename P_>
+  inline void search_nn(P_ const& x, scalar_type const e, neighbor_type& nn) const {
+    internal::nn_visitor<neighbor_type, true> v(nn, e);
+    search_nearest(x, v);
+  }
+
+  template <typename P_, typename RandomAccessIterator_>
+  inline void search_knn(
+      P_ const& x, RandomAccessIterator_ begin, RandomAccessIterator_ end) const {
+    static_assert(
+        std::is_same_v<
+            typename std::iterator_traits<RandomAccessIterator_>::value_type,
+            neighbor_type>,
+        "ITERATOR_VALUE_TYPE_DOES_NOT_EQUAL_NEIGHBOR_TYPE");
+    internal::knn_visitor<RandomAccessIterator_> v(begin, end);
+    search_nearest(x, v);
+  }
+
+  //! \p knn is resized to min(k, number of points).
+  template <typename P_>
+  inline void search_knn(
+      P_ const& x, size_type const k, std::vector<neighbor_type>& knn) const {
+    knn.resize(std::min(k, view().size()));
+    search_knn(x, knn.begin(), knn.end());
+  }
+
+  template <typename P_, typename RandomAccessIterator_>
+  inline void search_knn(
+      P_ const& x,
+      scalar_type const e,
+      RandomAccessIterator_ begin,
+      RandomAccessIterator_ end) const {
+    static_assert(
+        std::is_same_v<
+            typename std::iterator_traits<RandomAccessIterator_>::value_type,
+            neighbor_type>,
+        "ITERATOR_VALUE_TYPE_DOES_NOT_EQUAL_NEIGHBOR_TYPE");
+    internal::knn_visitor<RandomAccessIterator_, true> v(begin, end, e);
+    search_nearest(x, v);
+  }
+
+  template <typename P_>
+  inline void search_knn(
+      P_ const& x,
+      size_type const k,
+      scalar_type const e,
+      std::vector<neighbor_type>& knn) const {
+    knn.resize(std::min(k, view().size()));
+    search_knn(x, e, knn.begin(), knn.end());
+  }
+
+  //! All points with distance < \p radius (metric units: squared for the
+  //! default metric), in traversal order unless \p sort.
+  template <typename P_>
+  inline void search_radius(
+      P_ const& x,
+      scalar_type const radius,
+      std::vector<neighbor_type>& n,
+      bool const sort = false) const {
+    internal::radius_visitor<neighbor_type> v(radius, n);
+    search_nearest(x, v);
+    if (sort) v.sort();
+  }
+
+  template <typename P_>
+  inline void search_radius(
+      P_ const& x,
+      scalar_type const radius,
+      scalar_type const e,
+      std::vector<neighbor_type>& n,
+      bool const sort = false) const {
+    internal::radius_visitor<neighbor_type, true> v(radius, n, e);
+    search_nearest(x, v);
+    if (sort) v.sort();
+  }
+
+  //! All indices inside the closed box [min, max].
+  template <typename P_>
+  inline void search_box(
+      P_ const& min, P_ const& max, std::vector<index_type>& idxs) const {
+    idxs.clear();
+    space_view_type s = view();
+    internal::box_search(
+        tree_,
+        s,
+        internal::point_view<P_>(min).data(),
+        internal::point_view<P_>(max).data(),
+        idxs);
+  }
+
+  // ---- batched searches (MI355X) -------------------------------------------
+  // QuerySpace_ is anything with space_traits<>.  Row i of every output belongs
+  // to query i.  Only available for the accelerated instantiation.
+
+  //! out[i] = nearest neighbour of query i.  out must hold queries.size().
+  template <typename QuerySpace_>
+  inline void search_nn(QuerySpace_ const& queries, neighbor_type* out) const {
+    search_knn(queries, size_type(1), out);
+  }
+
+  //! out[i * k + j] = j-th nearest neighbour of query i (ascending).  Unlike the
+  //! vector overload k is NOT clamped: k <= number of points is required.
+  template <typename QuerySpace_>
+  inline void search_knn(
+      QuerySpace_ const& queries, size_type const k, neighbor_type* out) const {
+    batched_knn(queries, k, scalar_type(1.0), out);
+  }
+
+  template <typename QuerySpace_>
+  inline void search_knn(
+      QuerySpace_ const& queries,
+      size_type const k,
+      scalar_type const e,
+      neighbor_type* out) const {
+    batched_knn(queries, k, e, out);
+  }
+
+  //! out[i] = all neighbours of query i within \p radius.
+  template <typename QuerySpace_>
+  inline void search_radius(
+      QuerySpace_ const& queries,
+      scalar_type const radius,
+      std::vector<std::vector<neighbor_type>>& out,
+      bool const sort = false) const {
+    batched_radius(queries, radius, scalar_type(1.0), out, sort);
+  }
+
+  template <typename QuerySpace_>
+  inline void search_radius(
+      QuerySpace_ const& queries,
+      scalar_type const radius,
+      scalar_type const e,
+      std::vector<std::vector<neighbor_type>>& out,
+      bool const sort = false) const {
+    batched_radius(queries, radius, e, out, sort);
+  }
+
+  //! Flat ragged form: row i is flat[offsets[i] .. offsets[i + 1]).
+  template <typename QuerySpace_>
+  inline void search_radius(
+      QuerySpace_ const& queries,
+      scalar_type const radius,
+      std::vector<std::uint64_t>& offsets,
+      std::vector<neighbor_type>& flat,
+      bool const sort = false) const {
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
+    check_query_dim(q.cols());
+    offsets.assign(q.rows() + 1, 0);
+    ptk_neighbor* rows = nullptr;
+    internal::ptk_check(
+        ptk_search_radius(
+            device(), q.data(), q.rows(), radius, 1.0f, sort ? 1 : 0,
+            offsets.data(), &rows),
+        "ptk_search_radius");
+    flat.resize(offsets.back());
+    std::copy(rows, rows + flat.size(), reinterpret_cast<ptk_neighbor*>(flat.data()));
+    ptk_free(rows);
+  }
+
+  //! Uploads the tree to the device now instead of at the first batched call.
+  inline void prepare_device() const {
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    (void)device();
+  }
+
+  // ---- introspection --------------------------------------------------------
+
+  //! Index range of every non-empty leaf, in depth-first order.
+  inline std::vector<leaf_range_type> leaf_ranges() const {
+    std::vector<leaf_range_type> ranges;
+    for (auto const& nd : tree_.nodes) {
+      if (nd.is_leaf() && nd.begin != nd.end) {
+        ranges.emplace_back(
+            tree_.indices.cbegin() + nd.begin, tree_.indices.cbegin() + nd.end);
+      }
+    }
+    return ranges;
+  }
+
+  inline space_type const& space() const { return space_; }
+  inline metric_type const& metric() const { return metric_; }
+
+  // ---- persistence (reference-compatible byte stream) ------------------------
+
+  static kd_tree load(space_type space, std::string const& filename) {
+    std::fstream stream =
+        internal::open_stream(filename, std::ios::in | std::ios::binary);
+    return load(std::move(space), stream);
+  }
+  static kd_tree load(space_type space, std::iostream& stream) {
+    return kd_tree(std::move(space), stream);
+  }
+  static void save(kd_tree const& tree, std::string const& filename) {
+    std::fstream stream =
+        internal::open_stream(filename, std::ios::out | std::ios::binary);
+    save(tree, stream);
+  }
+  static void save(kd_tree const& tree, std::iostream& stream) {
+    internal::write_flat_tree(tree.tree_, stream);
+  }
+
+ private:
+  kd_tree(space_type space, std::iostream& stream)
+      : space_(std::move(space)),
+        metric_(),
+        tree_(internal::read_flat_tree<tree_type>(stream)) {}
+
+  template <typename T_>
+  static T_ const& unwrap(T_ const& s) {
+    return s;
+  }
+  template <typename T_>
+  static T_ const& unwrap(std::reference_wrapper<T_> const& s) {
+    return s.get();
+  }
+
+  space_view_type view() const {
+    return space_view_type(unwrap(space_));
+  }
+
+  ptk_tree* device() const { return device_.get(tree_, view()); }
+
+  void check_query_dim(size_type qdim) const {
+    if (qdim != view().sdim()) {
+      throw std::invalid_argument("pico_tree: query dimension differs from the tree's");
+    }
+  }
+
+  template <typename QuerySpace_>
+  void batched_knn(
+      QuerySpace_ const& queries, size_type k, scalar_type e, neighbor_type* out) const {
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    static_assert(sizeof(neighbor_type) == sizeof(ptk_neighbor), "neighbor layout");
+    internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
+    check_query_dim(q.cols());
+    internal::ptk_check(
+        ptk_search_knn(
+            device(), q.data(), q.rows(), static_cast<std::uint32_t>(k), e,
+            reinterpret_cast<ptk_neighbor*>(out)),
+        "ptk_search_knn");
+  }
+
+  template <typename QuerySpace_>
+  void batched_radius(
+      QuerySpace_ const& queries,
+      scalar_type radius,
+      scalar_type e,
+      std::vector<std::vector<neighbor_type>>& out,
+      bool sort) const {
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
+    check_query_dim(q.cols());
+    std::vector<std::uint64_t> offsets(q.rows() + 1, 0);
+    ptk_neighbor* rows = nullptr;
+    internal::ptk_check(
+        ptk_search_radius(
+            device(), q.data(), q.rows(), radius, e, sort ? 1 : 0, offsets.data(), &rows),
+        "ptk_search_radius");
+    out.resize(q.rows());
+    auto const* src = reinterpret_cast<neighbor_type const*>(rows);
+    for (size_type i = 0; i < q.rows(); ++i) {
+      out[i].assign(src + offsets[i], src + offsets[i + 1]);
+    }
+    ptk_free(rows);
+  }
+
+  space_type space_;
+  metric_type metric_;
+  tree_type tree_;
+  internal::device_tree device_;
+};
+
+template <typename Space_, typename... Args>
+kd_tree(Space_, Args...) -> kd_tree<Space_, metric_l2_squared, int>;
+
+template <
+    typename Metric_ = metric_l2_squared,
+    typename Index_ = int,
+    typename Bounds_ = bounds_from_space_t,
+    typename Rule_ = sliding_midpoint_max_side_t,
+    typename Space_,
+    typename Stop_>
+kd_tree<std::decay_t<Space_>, Metric_, Index_> make_kd_tree(
+    Space_&& space,
+    splitter_stop_condition_t<Stop_> const& stop_condition,
+    splitter_start_bounds_t<Bounds_> const& start_bounds = Bounds_{},
+    splitter_rule_t<Rule_> const& rule = Rule_{}) {
+  return kd_tree<std::decay_t<Space_>, Metric_, Index_>(
+      std::forward<Space_>(space), stop_condition, start_bounds, rule);
+}
+
+}  // namespace pico_tree

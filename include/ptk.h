@@ -1,0 +1,220 @@
+/* ptk.h -- C ABI of the MI355X batched k-NN backend (libptk.so).
+ *
+ * This is the drop-in boundary for the hot path named by BASELINE.json: batched
+ * search_nn / search_knn / search_radius (and search_box) on a pico_tree
+ * kd_tree<Space, metric_l2_squared, int> over float32 points.  Plain C types
+ * only: no exceptions, no STL, no torch types cross this line.  Every entry
+ * point returns PTK_OK (0) or a negative ptk_status; the message for the last
+ * failure on the calling thread is available from ptk_last_error().
+ *
+ * What each entry point replaces in the reference (paths relative to
+ * /root/reference):
+ *
+ *   ptk_tree_create_from_points   kd_tree ctor with max_leaf_size_t, bounds from
+ *                                 the space, sliding midpoint rule:
+ *                                 src/pico_tree/pico_tree/kd_tree.hpp:76-88,
+ *                                 internal/kd_tree_builder.hpp:456-512; as bound
+ *                                 by the Python module in
+ *                                 src/pyco_tree/pico_tree/_pyco_tree/kd_tree.hpp:112-115
+ *   ptk_tree_create               the same tree handed over already built and
+ *                                 flattened (what include/pico_tree/kd_tree.hpp
+ *                                 does for arbitrary Space types); the node
+ *                                 stream is the DFS pre-order of
+ *                                 internal/kd_tree_data.hpp:109-135
+ *   ptk_search_knn[_device]       the OpenMP batch loop over kd_tree::search_knn:
+ *                                 _pyco_tree/kd_tree.hpp:117-135 (exact) and
+ *                                 :144-168 (approximate), i.e. kd_tree.hpp:169-181,
+ *                                 :205-218 per row; k == 1 is search_nn
+ *                                 (kd_tree.hpp:126-129)
+ *   ptk_search_radius_*           the batch loop over kd_tree::search_radius:
+ *                                 _pyco_tree/kd_tree.hpp:179-200, :211-233, i.e.
+ *                                 kd_tree.hpp:257-290 per row
+ *   ptk_search_box_*              the batch loop over kd_tree::search_box:
+ *                                 _pyco_tree/kd_tree.hpp:245-268, kd_tree.hpp:296-318
+ *   ptk_tree_destroy              ~kd_tree
+ *
+ * Results contract: neighbour indices are bit-identical to the reference CPU
+ * kd_tree on the same inputs, squared distances bit-identical to the reference
+ * compiled without FMA contraction (-ffp-contract=off).
+ *
+ * Threading: a ptk_tree is immutable after creation; search calls on one handle
+ * may be issued concurrently from several host threads (each call uses its own
+ * scratch; calls that share a HIP stream serialise on it).
+ */
+#ifndef PTK_H_
+#define PTK_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PTK_VERSION 100 /* 0.1.0 */
+
+typedef enum ptk_status {
+  PTK_OK = 0,
+  PTK_ERR_INVALID = -1,     /* bad argument (null pointer, k == 0, dim == 0 ...) */
+  PTK_ERR_UNSUPPORTED = -2, /* valid request this build cannot run on the GPU   */
+  PTK_ERR_DEVICE = -3,      /* HIP runtime error, or no usable gfx950 device    */
+  PTK_ERR_NOMEM = -4        /* host or device allocation failed                 */
+} ptk_status;
+
+/* Layout-identical to pico_tree::neighbor<int, float> (core.hpp:24-46) and to
+ * the Python binding's [('index','<i4'),('distance','<f4')] record. */
+typedef struct ptk_neighbor {
+  int32_t index;
+  float distance;
+} ptk_neighbor;
+
+/* One node of the flat tree, DFS pre-order, 16 bytes.  The left child of a
+ * branch is the next node (self + 1).
+ *   branch: a = bits of float left_max, b = bits of float right_min,
+ *           right = index of the right child, split_dim = split axis
+ *   leaf:   a = begin, b = end (positions in the indices array, int32),
+ *           right = PTK_LEAF, split_dim = 0
+ * Field meanings follow internal/kd_tree_node.hpp:31-50. */
+#define PTK_LEAF 0xFFFFFFFFu
+typedef struct ptk_node {
+  uint32_t a;
+  uint32_t b;
+  uint32_t right;
+  uint32_t split_dim;
+} ptk_node;
+
+typedef struct ptk_tree_desc {
+  uint32_t dim;          /* spatial dimension (>= 1)                            */
+  uint64_t n_points;     /* number of points (>= 1, < 2^31)                     */
+  const float* points;   /* n_points x dim, row-major, ORIGINAL order (host)    */
+  uint64_t n_nodes;      /* number of nodes in the DFS stream                   */
+  const ptk_node* nodes; /* host                                                */
+  const int32_t* indices;/* n_points entries: leaf-ordered permutation (host)   */
+  const float* root_min; /* dim floats: start bounds of the build, or NULL =     */
+  const float* root_max; /*   bounding box of the points (both or neither)      */
+  uint32_t max_depth;    /* informational; recomputed from the node stream      */
+  int32_t device;        /* HIP device ordinal, PTK_DEVICE_CURRENT or _NONE     */
+} ptk_tree_desc;
+
+#define PTK_DEVICE_CURRENT (-1) /* whatever hipGetDevice() returns                 */
+#define PTK_DEVICE_NONE (-2)    /* host-only handle: structure queries work, every
+                                   search returns PTK_ERR_DEVICE                    */
+
+typedef struct ptk_tree ptk_tree; /* opaque */
+
+typedef struct ptk_tree_info {
+  uint32_t dim;
+  uint64_t n_points;
+  uint64_t n_nodes;      /* nodes in the DFS stream (branches + leaves)         */
+  uint64_t n_leaves;
+  uint32_t max_depth;
+  uint32_t max_leaf_count;
+  uint64_t device_bytes; /* HBM held by the handle                              */
+  int32_t device;
+} ptk_tree_info;
+
+/* Query-order policy for the nearest-neighbour kernels.  Coherent (spatially
+ * sorted) batches traverse the tree several times faster; with PTK_REORDER_ON
+ * the backend sorts the batch along a Morton curve on the device and scatters
+ * results back, so the caller-visible row order never changes. */
+enum { PTK_REORDER_AUTO = 0, PTK_REORDER_ON = 1, PTK_REORDER_OFF = 2 };
+
+/* ---- library ---------------------------------------------------------- */
+int ptk_version(void);
+const char* ptk_last_error(void); /* thread-local, never NULL */
+int ptk_device_count(void);       /* number of visible HIP devices, or < 0 */
+
+/* ---- tree lifetime ---------------------------------------------------- */
+
+/* Builds the kd-tree on the host (sliding midpoint, max_leaf_size stop, bounds
+ * from the points) and uploads it.  points may be freed after the call. */
+int ptk_tree_create_from_points(const float* points, uint64_t n_points,
+                                uint32_t dim, uint64_t max_leaf_size,
+                                int32_t device, ptk_tree** out);
+
+/* Uploads an already built flat tree.  All host arrays may be freed after. */
+int ptk_tree_create(const ptk_tree_desc* desc, ptk_tree** out);
+
+void ptk_tree_destroy(ptk_tree* tree);
+
+int ptk_tree_get_info(const ptk_tree* tree, ptk_tree_info* info);
+
+/* Copies the host-side flat tree out (for bindings that save it or inspect it).
+ * Pass NULL to skip an array.  nodes needs n_nodes entries, indices n_points. */
+int ptk_tree_get_flat(const ptk_tree* tree, ptk_node* nodes, int32_t* indices,
+                      float* root_min, float* root_max);
+
+int ptk_tree_set_reorder(ptk_tree* tree, int mode);
+
+/* ---- k nearest neighbours --------------------------------------------- */
+
+/* Host buffers.  queries: nq x dim row-major.  out: nq x k row-major; row i is
+ * the ascending k-list of query i.  k is clamped by the CALLER to <= n_points
+ * (kd_tree.hpp:193); k > n_points is PTK_ERR_INVALID.  e is the approximation
+ * ratio in metric units (kd_tree.hpp:131-153); e == 1 is the exact search. */
+int ptk_search_knn(const ptk_tree* tree, const float* queries, uint64_t nq,
+                   uint32_t k, float e, ptk_neighbor* out);
+
+/* Device buffers on the tree's device; asynchronous on `stream` (a hipStream_t,
+ * NULL = the default stream).  No host synchronisation is performed. */
+int ptk_search_knn_device(const ptk_tree* tree, const float* d_queries,
+                          uint64_t nq, uint32_t k, float e,
+                          ptk_neighbor* d_out, void* stream);
+
+/* ---- radius search (ragged output) ------------------------------------ */
+
+/* Pass 1: counts[i] = number of points with distance < radius (strict,
+ * search_visitor.hpp:141).  radius is in metric units (squared for L2^2). */
+int ptk_search_radius_count(const ptk_tree* tree, const float* queries,
+                            uint64_t nq, float radius, float e,
+                            uint64_t* counts);
+/* Pass 2: offsets has nq + 1 entries (exclusive scan of counts); out receives
+ * offsets[nq] records, row i in reference traversal order, or ascending by
+ * distance when sort != 0 (ties in unspecified order, like std::sort). */
+int ptk_search_radius_fill(const ptk_tree* tree, const float* queries,
+                           uint64_t nq, float radius, float e,
+                           const uint64_t* offsets, ptk_neighbor* out,
+                           int sort);
+
+int ptk_search_radius_count_device(const ptk_tree* tree, const float* d_queries,
+                                   uint64_t nq, float radius, float e,
+                                   uint64_t* d_counts, void* stream);
+int ptk_search_radius_fill_device(const ptk_tree* tree, const float* d_queries,
+                                  uint64_t nq, float radius, float e,
+                                  const uint64_t* d_offsets,
+                                  ptk_neighbor* d_out, int sort, void* stream);
+
+/* Convenience: both passes + the scan on the device.  offsets (nq + 1, host)
+ * is filled; *out is malloc'ed by the library (free with ptk_free). */
+int ptk_search_radius(const ptk_tree* tree, const float* queries, uint64_t nq,
+                      float radius, float e, int sort, uint64_t* offsets,
+                      ptk_neighbor** out);
+
+/* ---- box search (ragged output) --------------------------------------- */
+/* mins / maxs: nb x dim.  Row i lists the indices inside [min_i, max_i]
+ * (closed), in reference traversal order. */
+int ptk_search_box(const ptk_tree* tree, const float* mins, const float* maxs,
+                   uint64_t nb, uint64_t* offsets, int32_t** out);
+
+void ptk_free(void* p);
+
+/* ---- measurement ------------------------------------------------------ */
+/* When enabled, every internal kernel launch of this handle is bracketed by HIP
+ * events recorded on its stream (no host synchronisation at launch time, so it
+ * may stay on inside a timed region).  ptk_profile_get waits for the recorded
+ * events and returns the accumulated per-kernel elapsed times. */
+typedef struct ptk_profile {
+  double search_ms;   /* the traversal kernel(s)                               */
+  double reorder_ms;  /* Morton keys + sort + permutation                      */
+  double other_ms;    /* scans, fills, copies issued by the backend            */
+  uint64_t launches;  /* traversal kernel launches accumulated                 */
+  uint64_t queries;   /* queries those launches processed                      */
+} ptk_profile;
+int ptk_profile_enable(ptk_tree* tree, int on);
+int ptk_profile_get(const ptk_tree* tree, ptk_profile* out, int reset);
+
+#ifdef __cplusplus
+} /* extern "C" */
+#endif
+
+#endif /* PTK_H_ */

@@ -1,0 +1,444 @@
+"""pico_tree_amd -- Python host side of the MI355X batched k-NN backend.
+
+Mirrors the reference's Python module (``pico_tree.KdTree``,
+``/root/reference/src/pyco_tree/pico_tree/_pyco_tree/def_kd_tree.cpp:14-195``):
+same constructor arguments, ``search_knn`` / ``search_radius`` overloads, result
+dtype ``[('index','<i4'),('distance','<f4')]`` and output shapes
+(``(npts,)`` for k == 1, ``(npts, k)`` otherwise;
+``_pyco_tree/kd_tree.hpp:362-378``).  Every search runs on the GPU through the
+C ABI of ``include/ptk.h`` (``pico_tree_amd/csrc/libptk.so``); there is no CPU
+search path here and no fallback: if the library or a device is missing the
+call raises.
+
+Two kinds of buffers are accepted:
+
+* numpy arrays (host): copied to the device and back by the backend;
+* torch CUDA tensors (device): used in place on the current torch stream, the
+  result is a :class:`DeviceNeighbors` holding an ``int32`` tensor of shape
+  ``(nq, k, 2)`` whose last axis is ``(index, bits of the float32 distance)``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import enum
+import os
+from ctypes import (POINTER, Structure, byref, c_char_p, c_double, c_float, c_int, c_int32,
+                    c_uint32, c_uint64, c_void_p)
+
+import numpy as np
+
+from . import datasets  # noqa: F401  (re-export)
+
+__all__ = ["KdTree", "Metric", "NEIGHBOR", "DArray", "DeviceNeighbors", "PtkError",
+           "library_path", "device_count", "datasets"]
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "csrc", "libptk.so")
+
+#: Result record; identical to the reference binding's neighbor dtype.
+NEIGHBOR = np.dtype([("index", "<i4"), ("distance", "<f4")])
+
+PTK_OK = 0
+PTK_DEVICE_CURRENT = -1
+PTK_DEVICE_NONE = -2
+REORDER_AUTO, REORDER_ON, REORDER_OFF = 0, 1, 2
+
+
+class PtkError(RuntimeError):
+    """A non-zero status from libptk (message from ``ptk_last_error``)."""
+
+    def __init__(self, status: int, message: str):
+        super().__init__(f"libptk status {status}: {message}")
+        self.status = status
+
+
+class _Info(Structure):
+    _fields_ = [("dim", c_uint32), ("n_points", c_uint64), ("n_nodes", c_uint64),
+                ("n_leaves", c_uint64), ("max_depth", c_uint32), ("max_leaf_count", c_uint32),
+                ("device_bytes", c_uint64), ("device", c_int32)]
+
+
+class _Profile(Structure):
+    _fields_ = [("search_ms", c_double), ("reorder_ms", c_double), ("other_ms", c_double),
+                ("launches", c_uint64), ("queries", c_uint64)]
+
+
+_lib = None
+
+_SIGNATURES = {
+    "ptk_version": (c_int, []),
+    "ptk_last_error": (c_char_p, []),
+    "ptk_device_count": (c_int, []),
+    "ptk_tree_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_int32,
+                                            POINTER(c_void_p)]),
+    "ptk_tree_create": (c_int, [c_void_p, POINTER(c_void_p)]),
+    "ptk_tree_destroy": (None, [c_void_p]),
+    "ptk_tree_get_info": (c_int, [c_void_p, POINTER(_Info)]),
+    "ptk_tree_get_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "ptk_tree_set_reorder": (c_int, [c_void_p, c_int]),
+    "ptk_search_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p]),
+    "ptk_search_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p,
+                                      c_void_p]),
+    "ptk_search_radius_count": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p]),
+    "ptk_search_radius_fill": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p,
+                                       c_void_p, c_int]),
+    "ptk_search_radius_count_device": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_float,
+                                               c_void_p, c_void_p]),
+    "ptk_search_radius_fill_device": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_float,
+                                              c_void_p, c_void_p, c_int, c_void_p]),
+    "ptk_search_radius": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_float, c_int, c_void_p,
+                                  POINTER(c_void_p)]),
+    "ptk_search_box": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p,
+                               POINTER(c_void_p)]),
+    "ptk_free": (None, [c_void_p]),
+    "ptk_profile_enable": (c_int, [c_void_p, c_int]),
+    "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
+}
+
+#: Every symbol include/ptk.h declares; tests check the library exports them all.
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def _load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise ImportError(
+                f"{_LIB_PATH} is missing: build it with `python -m pico_tree_amd.build` "
+                "(there is no CPU fallback)")
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (restype, argtypes) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = restype
+            fn.argtypes = argtypes
+        _lib = lib
+    return _lib
+
+
+def _check(status: int) -> None:
+    if status != PTK_OK:
+        raise PtkError(status, _load().ptk_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    return int(_load().ptk_device_count())
+
+
+class Metric(enum.Enum):
+    """Metrics of the reference binding; only ``L2Squared`` is built here."""
+    L1 = 1
+    L2Squared = 2
+    LPInf = 3
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
+
+
+class DArray:
+    """Ragged result of a radius (or box) search: a sequence of numpy arrays.
+
+    Same role as the reference's ``DArray`` (``_pyco_tree/darray.hpp:31-288``)
+    but stored flat: row ``i`` is ``flat[offsets[i]:offsets[i + 1]]``.
+    """
+
+    def __init__(self, offsets: np.ndarray, flat: np.ndarray):
+        self.offsets = offsets
+        self.flat = flat
+
+    @property
+    def dtype(self):
+        return self.flat.dtype
+
+    def __len__(self) -> int:
+        return len(self.offsets) - 1
+
+    def __bool__(self) -> bool:
+        return len(self) > 0
+
+    def __getitem__(self, i: int) -> np.ndarray:
+        n = len(self)
+        if i < 0:
+            i += n
+        if not 0 <= i < n:
+            raise IndexError(i)
+        return self.flat[int(self.offsets[i]):int(self.offsets[i + 1])]
+
+    def __iter__(self):
+        for i in range(len(self)):
+            yield self[i]
+
+
+class DeviceNeighbors:
+    """k-NN result resident on the device: ``raw`` is int32 ``(nq, k, 2)``."""
+
+    def __init__(self, raw):
+        self.raw = raw
+
+    @property
+    def index(self):
+        return self.raw[..., 0]
+
+    @property
+    def distance(self):
+        import torch
+        return self.raw[..., 1].view(torch.float32)
+
+    def numpy(self) -> np.ndarray:
+        """Host copy with the :data:`NEIGHBOR` dtype, shape ``(nq,)`` or ``(nq, k)``."""
+        a = self.raw.cpu().numpy()
+        out = np.ascontiguousarray(a).view(NEIGHBOR)[..., 0]
+        return out[:, 0] if out.shape[1] == 1 else out
+
+
+class KdTree:
+    """A kd-tree over float32 points, searched on the MI355X.
+
+    ``KdTree(pts, Metric.L2Squared, max_leaf_size)`` as in the reference.  ``pts``
+    is ``(npts, sdim)`` C-contiguous float32 (an F-contiguous ``(sdim, npts)``
+    array is the same memory and accepted like the reference does).  The tree is
+    built on the host with the sliding-midpoint rule and uploaded once.
+    """
+
+    def __init__(self, pts, metric: Metric = Metric.L2Squared, max_leaf_size: int = 10,
+                 device: int | None = None):
+        if metric is not Metric.L2Squared:
+            raise ValueError("only Metric.L2Squared is available in this build")
+        pts = self._as_matrix(pts, None, "pts")
+        if int(max_leaf_size) <= 0:
+            raise ValueError("max_leaf_size must be positive")
+        self._pts = pts  # keep alive, like py::keep_alive<1, 2>
+        self._npts, self._sdim = pts.shape
+        self._max_leaf_size = int(max_leaf_size)
+        lib = _load()
+        handle = c_void_p()
+        dev = PTK_DEVICE_CURRENT if device is None else int(device)
+        _check(lib.ptk_tree_create_from_points(pts.ctypes.data, self._npts, self._sdim,
+                                               self._max_leaf_size, dev, byref(handle)))
+        self._h = handle
+
+    # -- helpers ---------------------------------------------------------------
+    @staticmethod
+    def _as_matrix(a, sdim, what):
+        """Validates like py_array_map.hpp:37-62 and returns a C-order view."""
+        if not isinstance(a, np.ndarray):
+            raise ValueError(f"{what} must be a numpy array")
+        if a.dtype != np.float32:
+            raise ValueError("unexpected dtype_scalar for data")
+        if a.ndim != 2:
+            raise ValueError(f"{what} must have 2 dimensions")
+        if a.flags.c_contiguous:
+            m = a
+        elif a.flags.f_contiguous:
+            m = a.T  # (sdim, npts) column-major is (npts, sdim) row-major memory
+        else:
+            raise ValueError(f"{what} must be contiguous")
+        if sdim is not None and m.shape[1] != sdim:
+            raise ValueError(f"{what} has spatial dimension {m.shape[1]}, tree has {sdim}")
+        return m
+
+    def close(self) -> None:
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            _load().ptk_tree_destroy(h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __repr__(self) -> str:
+        return (f"KdTree(metric=L2Squared, max_leaf_size={self._max_leaf_size}, "
+                f"dtype=float32, sdim={self._sdim}, npts={self._npts})")
+
+    # -- properties (names of the reference binding) ----------------------------------
+    @property
+    def npts(self) -> int:
+        return self._npts
+
+    @property
+    def sdim(self) -> int:
+        return self._sdim
+
+    @property
+    def dtype_index(self):
+        return np.dtype(np.int32)
+
+    @property
+    def dtype_scalar(self):
+        return np.dtype(np.float32)
+
+    @property
+    def dtype_neighbor(self):
+        return NEIGHBOR
+
+    def metric(self, scalar: float) -> float:
+        """metric_l2_squared's one-dimensional form: ``x * x`` in float32."""
+        x = np.float32(scalar)
+        return float(x * x)
+
+    def info(self) -> dict:
+        inf = _Info()
+        _check(_load().ptk_tree_get_info(self._h, byref(inf)))
+        return {name: getattr(inf, name) for name, _ in _Info._fields_}
+
+    def flat(self):
+        """(nodes uint32[n_nodes, 4], indices int32[npts], root_min, root_max)."""
+        inf = self.info()
+        nodes = np.empty((inf["n_nodes"], 4), dtype=np.uint32)
+        indices = np.empty(self._npts, dtype=np.int32)
+        rmin = np.empty(self._sdim, dtype=np.float32)
+        rmax = np.empty(self._sdim, dtype=np.float32)
+        _check(_load().ptk_tree_get_flat(self._h, nodes.ctypes.data, indices.ctypes.data,
+                                         rmin.ctypes.data, rmax.ctypes.data))
+        return nodes, indices, rmin, rmax
+
+    def set_reorder(self, mode: int) -> None:
+        _check(_load().ptk_tree_set_reorder(self._h, int(mode)))
+
+    def profile(self, enable: bool | None = None, reset: bool = False) -> dict:
+        lib = _load()
+        if enable is not None:
+            _check(lib.ptk_profile_enable(self._h, int(enable)))
+        p = _Profile()
+        _check(lib.ptk_profile_get(self._h, byref(p), int(reset)))
+        return {name: getattr(p, name) for name, _ in _Profile._fields_}
+
+    # -- k nearest neighbours ------------------------------------------------------------
+    def search_knn(self, pts, k: int, *args):
+        """``search_knn(pts, k[, e][, nns])`` -- the four reference overloads.
+
+        Host arrays return (or fill) a numpy array of :data:`NEIGHBOR`; a torch
+        CUDA tensor returns a :class:`DeviceNeighbors` (``nns`` may be a
+        preallocated int32 ``(nq, k, 2)`` tensor).
+        """
+        e, nns = self._split_optional(args)
+        k = int(k)
+        if _is_torch(pts):
+            return self._search_knn_device(pts, k, e, nns)
+        q = self._as_matrix(pts, self._sdim, "pts")
+        nq = q.shape[0]
+        shape = (nq,) if k == 1 else ((nq, k) if pts.flags.c_contiguous else (k, nq))
+        if nns is None:
+            nns = np.empty(shape, dtype=NEIGHBOR)
+        elif not isinstance(nns, np.ndarray) or nns.dtype != NEIGHBOR:
+            raise ValueError("unexpected dtype_neighbor for data")
+        elif nns.size != nq * k or not nns.flags.c_contiguous:
+            # Resized like ensure_size() of the reference (kd_tree.hpp:362-378).
+            try:
+                nns.resize(shape, refcheck=False)
+            except ValueError:
+                nns = np.empty(shape, dtype=NEIGHBOR)
+        if k > 1 and not pts.flags.c_contiguous:
+            # Column-major callers get the transposed (k, npts) layout of the reference
+            # (kd_tree.hpp:362-378): row i of the search is column i of the output.
+            tmp = np.empty((nq, k), dtype=NEIGHBOR)
+            _check(_load().ptk_search_knn(self._h, q.ctypes.data, nq, k, np.float32(e),
+                                          tmp.ctypes.data))
+            nns.reshape(-1)[:] = tmp.reshape(-1)
+            return nns
+        _check(_load().ptk_search_knn(self._h, q.ctypes.data, nq, k, np.float32(e),
+                                      nns.ctypes.data))
+        return nns
+
+    def _search_knn_device(self, q, k, e, out):
+        import torch
+        if q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != self._sdim:
+            raise ValueError("queries must be a float32 (nq, sdim) tensor")
+        if not q.is_cuda or not q.is_contiguous():
+            raise ValueError("queries must be a contiguous CUDA tensor")
+        nq = q.shape[0]
+        if out is None:
+            out = torch.empty((nq, k, 2), dtype=torch.int32, device=q.device)
+        elif isinstance(out, DeviceNeighbors):
+            out = out.raw
+        if out.dtype != torch.int32 or tuple(out.shape) != (nq, k, 2) or not out.is_contiguous():
+            raise ValueError("nns must be a contiguous int32 (nq, k, 2) tensor")
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        _check(_load().ptk_search_knn_device(self._h, q.data_ptr(), nq, k, np.float32(e),
+                                             out.data_ptr(), stream))
+        return DeviceNeighbors(out)
+
+    # -- radius ---------------------------------------------------------------------------
+    def search_radius(self, pts, radius: float, *args, sort: bool = False):
+        """``search_radius(pts, radius[, e][, nns], sort=False)`` -> :class:`DArray`."""
+        e, nns, sort = self._split_optional_radius(args, sort)
+        q = self._as_matrix(pts, self._sdim, "pts")
+        nq = q.shape[0]
+        if nns is not None and not isinstance(nns, DArray):
+            raise ValueError("unexpected dtype_neighbor for data")
+        offsets = np.zeros(nq + 1, dtype=np.uint64)
+        rows = c_void_p()
+        lib = _load()
+        _check(lib.ptk_search_radius(self._h, q.ctypes.data, nq, np.float32(radius),
+                                     np.float32(e), int(bool(sort)), offsets.ctypes.data,
+                                     byref(rows)))
+        total = int(offsets[-1])
+        flat = np.empty(total, dtype=NEIGHBOR)
+        if total:
+            ctypes.memmove(flat.ctypes.data, rows.value, total * NEIGHBOR.itemsize)
+        lib.ptk_free(rows)
+        if nns is None:
+            return DArray(offsets, flat)
+        nns.offsets, nns.flat = offsets, flat
+        return nns
+
+    def search_radius_device(self, q, radius: float, e: float = 1.0, sort: bool = False):
+        """Device form: returns (offsets int64 tensor [nq + 1], raw int32 tensor [total, 2])."""
+        import torch
+        if q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != self._sdim:
+            raise ValueError("queries must be a float32 (nq, sdim) tensor")
+        if not q.is_cuda or not q.is_contiguous():
+            raise ValueError("queries must be a contiguous CUDA tensor")
+        nq = q.shape[0]
+        lib = _load()
+        stream = torch.cuda.current_stream(q.device).cuda_stream
+        counts = torch.zeros(nq + 1, dtype=torch.int64, device=q.device)
+        _check(lib.ptk_search_radius_count_device(self._h, q.data_ptr(), nq, np.float32(radius),
+                                                  np.float32(e), counts.data_ptr(), stream))
+        offsets = torch.zeros(nq + 1, dtype=torch.int64, device=q.device)
+        offsets[1:] = torch.cumsum(counts[:nq], 0)
+        total = int(offsets[-1].item())
+        out = torch.empty((max(total, 1), 2), dtype=torch.int32, device=q.device)
+        _check(lib.ptk_search_radius_fill_device(self._h, q.data_ptr(), nq, np.float32(radius),
+                                                 np.float32(e), offsets.data_ptr(), out.data_ptr(),
+                                                 int(bool(sort)), stream))
+        return offsets, out[:total]
+
+    # -- argument plumbing for the overload sets ------------------------------------------------
+    @staticmethod
+    def _split_optional(args):
+        e, nns = 1.0, None
+        for a in args:
+            if isinstance(a, (int, float, np.floating)) and not isinstance(a, bool):
+                e = float(a)
+            else:
+                nns = a
+        if len(args) > 2:
+            raise TypeError("search_knn(pts, k[, e][, nns])")
+        if not e > 0:
+            raise ValueError("e must be positive")
+        return e, nns
+
+    @staticmethod
+    def _split_optional_radius(args, sort):
+        e, nns = 1.0, None
+        for a in args:
+            if isinstance(a, bool):
+                sort = a
+            elif isinstance(a, (int, float, np.floating)):
+                e = float(a)
+            else:
+                nns = a
+        if len(args) > 3:
+            raise TypeError("search_radius(pts, radius[, e][, nns][, sort])")
+        if not e > 0:
+            raise ValueError("e must be positive")
+        return e, nns, sort

@@ -1,0 +1,750 @@
+// ptk_backend.hip -- host side of libptk.so: the C ABI of include/ptk.h.
+//
+// Responsibilities: validate arguments, build (optionally) and re-encode the flat
+// tree for the device, keep it resident in HBM, order query batches, launch the
+// gfx950 kernels of ptk_kernels.hpp, and move results.  There is no CPU search
+// path in this file: without a usable device every search entry point fails with
+// PTK_ERR_DEVICE.
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <atomic>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <mutex>
+#include <new>
+#include <string>
+#include <vector>
+
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+
+#include "ptk.h"
+#include "ptk_encode.hpp"
+#include "ptk_kernels.hpp"
+
+// Host-side builder: the product's own header-only flat-tree builder.
+#include "pico_tree/internal/flat_tree.hpp"
+#include "pico_tree/map.hpp"
+
+static_assert(sizeof(ptk_neighbor) == 8 && sizeof(ptk::Neighbor) == 8, "neighbor layout");
+static_assert(sizeof(ptk_node) == 16, "node layout");
+static_assert(
+    sizeof(pico_tree::internal::flat_node<int, float>) == sizeof(ptk_node), "flat node layout");
+
+namespace {
+
+thread_local std::string g_error = "";
+
+int fail(int status, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_error = buf;
+  return status;
+}
+
+#define PTK_HIP(expr)                                                              \
+  do {                                                                             \
+    hipError_t e_ = (expr);                                                        \
+    if (e_ != hipSuccess) {                                                        \
+      return fail(PTK_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));  \
+    }                                                                              \
+  } while (0)
+
+constexpr int kDeviceNone = -2;  // handle without a device replica (host tools, CPU-only tests)
+
+struct PendingEvent {
+  hipEvent_t a, b;
+  int kind;  // 0 search, 1 reorder, 2 other
+  uint64_t queries;
+};
+
+struct Profile {
+  std::mutex mutex;
+  bool enabled = false;
+  ptk_profile acc{};
+  std::vector<PendingEvent> pending;  // recorded, not yet read back
+};
+
+}  // namespace
+
+struct ptk_tree {
+  // host copy of the flat tree (DFS stream as handed in / built)
+  uint32_t dim = 0;
+  uint64_t n_points = 0;
+  std::vector<ptk_node> nodes;
+  std::vector<int32_t> indices;
+  std::vector<float> root_min, root_max;
+  uint32_t max_depth = 0;
+  uint64_t n_leaves = 0;
+  uint32_t max_leaf_count = 0;
+
+  // device replica
+  int device = kDeviceNone;
+  ptk::DevTree dev{};
+  void* d_nodes = nullptr;
+  void* d_pts = nullptr;
+  uint64_t device_bytes = 0;
+  bool gpu_layout = false;  // false: dim > 3 (not yet on the device)
+
+  std::atomic<int> reorder{PTK_REORDER_AUTO};
+  mutable Profile profile;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = false;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+    ok = hipSetDevice(dev) == hipSuccess;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+
+int analyse(ptk_tree& t) {
+  ptk::TreeStats st;
+  std::string err = ptk::analyse_stream(t.dim, t.n_points, t.nodes.data(), t.nodes.size(), st, nullptr);
+  if (!err.empty()) return fail(PTK_ERR_INVALID, "%s", err.c_str());
+  t.n_leaves = st.n_leaves;
+  t.max_leaf_count = st.max_leaf_count;
+  t.max_depth = st.max_depth;
+  return PTK_OK;
+}
+
+int upload(ptk_tree& t, const float* points) {
+  int rc = analyse(t);
+  if (rc != PTK_OK) return rc;
+  if (t.dim > 3) {
+    t.gpu_layout = false;  // generic-dimension kernels are not built yet
+    return PTK_OK;
+  }
+  ptk::TreeStats st;
+  ptk::EncodedTree enc;
+  bool unsupported = false;
+  std::string err = ptk::encode_tree(t.dim, t.n_points, points, t.nodes.data(), t.nodes.size(),
+                                     t.indices.data(), st, enc, unsupported);
+  if (!err.empty()) return fail(unsupported ? PTK_ERR_UNSUPPORTED : PTK_ERR_INVALID, "%s", err.c_str());
+
+  static_assert(sizeof(ptk::EncNode) == sizeof(uint4) && sizeof(ptk::EncPoint) == sizeof(float4), "records");
+  PTK_HIP(hipMalloc(&t.d_nodes, enc.nodes.size() * sizeof(uint4)));
+  PTK_HIP(hipMalloc(&t.d_pts, enc.points.size() * sizeof(float4)));
+  PTK_HIP(hipMemcpy(t.d_nodes, enc.nodes.data(), enc.nodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
+  PTK_HIP(hipMemcpy(t.d_pts, enc.points.data(), enc.points.size() * sizeof(float4), hipMemcpyHostToDevice));
+  t.device_bytes = enc.nodes.size() * sizeof(uint4) + enc.points.size() * sizeof(float4);
+  t.dev.nodes = static_cast<const uint4*>(t.d_nodes);
+  t.dev.pts = static_cast<const float4*>(t.d_pts);
+  t.dev.root_ref = enc.root_ref;
+  t.dev.cbits = enc.cbits;
+  t.dev.cmask = (1u << enc.cbits) - 1u;
+  t.dev.n_points = (uint32_t)t.n_points;
+  t.gpu_layout = true;
+  return PTK_OK;
+}
+
+int finish_create(ptk_tree* t, const float* points, int32_t device, ptk_tree** out) {
+  if (t->root_min.empty()) {  // start bounds not supplied: bounding box of the points
+    t->root_min.assign(t->dim, std::numeric_limits<float>::max());
+    t->root_max.assign(t->dim, std::numeric_limits<float>::lowest());
+    for (uint64_t i = 0; i < t->n_points; ++i)
+      for (uint32_t d = 0; d < t->dim; ++d) {
+        const float v = points[i * t->dim + d];
+        t->root_min[d] = std::min(t->root_min[d], v);
+        t->root_max[d] = std::max(t->root_max[d], v);
+      }
+  }
+  if (device == kDeviceNone) {
+    int rc = analyse(*t);
+    if (rc != PTK_OK) {
+      delete t;
+      return rc;
+    }
+    t->device = kDeviceNone;
+    *out = t;
+    return PTK_OK;
+  }
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+    delete t;
+    return fail(PTK_ERR_DEVICE, "no HIP device is visible");
+  }
+  int dev = device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= count) {
+    delete t;
+    return fail(PTK_ERR_INVALID, "device %d out of range (%d visible)", dev, count);
+  }
+  t->device = dev;
+  DeviceGuard guard(dev);
+  if (!guard.ok) {
+    delete t;
+    return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", dev);
+  }
+  int rc = upload(*t, points);
+  if (rc != PTK_OK) {
+    ptk_tree_destroy(t);
+    return rc;
+  }
+  *out = t;
+  return PTK_OK;
+}
+
+// ---- launch helpers ---------------------------------------------------------------
+
+// Optional HIP-event bracket around one kernel.  Recording is asynchronous: the
+// pair is queued on the handle and only read back (with a synchronisation) by
+// ptk_profile_get, so profiling may stay enabled inside a timed region.
+struct Timer {
+  const ptk_tree* t;
+  hipStream_t s;
+  hipEvent_t a = nullptr, b = nullptr;
+  bool on;
+  Timer(const ptk_tree* tree, hipStream_t stream) : t(tree), s(stream) {
+    on = tree->profile.enabled;
+    if (on) {
+      on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+      if (on) (void)hipEventRecord(a, s);
+    }
+  }
+  void stop(int kind, uint64_t queries) {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    std::lock_guard<std::mutex> lock(t->profile.mutex);
+    t->profile.pending.push_back(PendingEvent{a, b, kind, queries});
+    a = b = nullptr;
+  }
+  ~Timer() {
+    if (a) (void)hipEventDestroy(a);
+    if (b) (void)hipEventDestroy(b);
+  }
+};
+
+// Stack geometry: S record slots per lane in LDS, OVF more in private scratch.
+// A traversal holds, per level of the current root path, either one pending
+// record (went near, far child unexplored) or two undo records (went far), so
+// 2 * depth + 2 slots always suffice.  k = 1 keeps 32 slots in LDS (64 KiB per
+// 256-lane block); the k-list and radius kernels keep 16 to leave LDS to the
+// list and to a second resident block.
+int choose_variant(const ptk_tree* t, int s_lds) {
+  const uint32_t need = 2 * t->max_depth + 2;
+  if (need <= (uint32_t)s_lds + 64) return 0;
+  if (need <= (uint32_t)s_lds + 256) return 1;
+  if (need <= (uint32_t)s_lds + 2048) return 2;
+  return -1;
+}
+
+// Dynamic LDS above 64 KiB must be opted into per kernel.
+template <typename K>
+int allow_lds(K kernel, size_t bytes) {
+  if (bytes > 64 * 1024) {
+    PTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
+  }
+  return PTK_OK;
+}
+
+bool want_reorder(const ptk_tree* t, uint64_t nq) {
+  const int mode = t->reorder.load();
+  if (mode == PTK_REORDER_ON) return nq > 1;
+  if (mode == PTK_REORDER_OFF) return false;
+  return nq >= 8192;
+}
+
+// Device-side Morton ordering of a batch: returns a permutation (device, nq
+// uint32) in *perm; the caller frees it with hipFreeAsync on the same stream.
+int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, uint32_t** perm) {
+  *perm = nullptr;
+  if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
+  Timer timer(t, s);
+  uint32_t *keys = nullptr, *keys_out = nullptr, *ids = nullptr, *ids_out = nullptr;
+  void* tmp = nullptr;
+  PTK_HIP(hipMallocAsync((void**)&keys, nq * 4, s));
+  PTK_HIP(hipMallocAsync((void**)&keys_out, nq * 4, s));
+  PTK_HIP(hipMallocAsync((void**)&ids, nq * 4, s));
+  PTK_HIP(hipMallocAsync((void**)&ids_out, nq * 4, s));
+  float3 lo, inv;
+  float lo_[3] = {0, 0, 0}, inv_[3] = {0, 0, 0};
+  for (uint32_t d = 0; d < t->dim && d < 3; ++d) {
+    lo_[d] = t->root_min[d];
+    const float ext = t->root_max[d] - t->root_min[d];
+    inv_[d] = ext > 0 ? 1024.0f / ext : 0.0f;
+  }
+  lo = make_float3(lo_[0], lo_[1], lo_[2]);
+  inv = make_float3(inv_[0], inv_[1], inv_[2]);
+  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+  hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq, lo, inv, keys, ids);
+  size_t tmp_bytes = 0;
+  PTK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, 30, s));
+  PTK_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, s));
+  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, 30, s));
+  PTK_HIP(hipFreeAsync(tmp, s));
+  PTK_HIP(hipFreeAsync(keys, s));
+  PTK_HIP(hipFreeAsync(keys_out, s));
+  PTK_HIP(hipFreeAsync(ids, s));
+  *perm = ids_out;
+  timer.stop(1, 0);
+  return PTK_OK;
+}
+
+int check_search(const ptk_tree* t, const void* q, uint64_t nq) {
+  if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
+  if (nq > 0 && q == nullptr) return fail(PTK_ERR_INVALID, "null query buffer");
+  if (t->device == kDeviceNone) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
+  if (!t->gpu_layout)
+    return fail(PTK_ERR_UNSUPPORTED, "dimension %u: only dim <= 3 runs on the device in this build", t->dim);
+  return PTK_OK;
+}
+
+float inv_ratio(float e) { return 1.0f / e; }
+
+template <int S, int OVF>
+int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
+               ptk::Neighbor* d_out, hipStream_t s) {
+  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+  const size_t stack_bytes = (size_t)S * ptk::kBlock * 8;
+  const float e_inv = inv_ratio(e);
+  Timer timer(t, s);
+  if (k == 1) {
+    int rc = allow_lds(ptk::knn1_kernel<S, OVF>, stack_bytes);
+    if (rc != PTK_OK) return rc;
+    hipLaunchKernelGGL((ptk::knn1_kernel<S, OVF>), dim3(blocks), dim3(ptk::kBlock), stack_bytes, s, t->dev, d_q,
+                       t->dim, perm, nq, e_inv, d_out);
+  } else {
+    const size_t list_bytes = (size_t)k * ptk::kBlock * 8;
+    const bool list_lds = stack_bytes + list_bytes <= 80 * 1024;  // keeps two blocks per CU
+    if (list_lds) {
+      const size_t smem = stack_bytes + list_bytes;
+      int rc = allow_lds(ptk::knn_kernel<S, OVF, true>, smem);
+      if (rc != PTK_OK) return rc;
+      hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, true>), dim3(blocks), dim3(ptk::kBlock), smem, s, t->dev, d_q,
+                         t->dim, perm, nq, k, e_inv, d_out);
+    } else {
+      hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, false>), dim3(blocks), dim3(ptk::kBlock), stack_bytes, s,
+                         t->dev, d_q, t->dim, perm, nq, k, e_inv, d_out);
+    }
+  }
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
+template <int S, int OVF>
+int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
+                  bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out,
+                  hipStream_t s) {
+  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+  const size_t smem = (size_t)S * ptk::kBlock * 8;
+  const float e_inv = inv_ratio(e);
+  Timer timer(t, s);
+  if (!fill) {
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, false>), dim3(blocks), dim3(ptk::kBlock), smem, s, t->dev, d_q,
+                       t->dim, perm, nq, radius, e_inv, d_counts, d_offsets, d_out);
+  } else {
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, true>), dim3(blocks), dim3(ptk::kBlock), smem, s, t->dev, d_q,
+                       t->dim, perm, nq, radius, e_inv, d_counts, d_offsets, d_out);
+  }
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
+#define PTK_DISPATCH_VARIANT(SLDS, variant, CALL)                                                        \
+  switch (variant) {                                                                                     \
+    case 0: { constexpr int S = SLDS, OVF = 64; rc = CALL; } break;                                      \
+    case 1: { constexpr int S = SLDS, OVF = 256; rc = CALL; } break;                                     \
+    case 2: { constexpr int S = SLDS, OVF = 2048; rc = CALL; } break;                                    \
+    default: rc = fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth); \
+  }
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+int ptk_version(void) { return PTK_VERSION; }
+
+const char* ptk_last_error(void) { return g_error.c_str(); }
+
+int ptk_device_count(void) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess) return -1;
+  return count;
+}
+
+int ptk_tree_create(const ptk_tree_desc* d, ptk_tree** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (d == nullptr || d->points == nullptr || d->nodes == nullptr || d->indices == nullptr)
+    return fail(PTK_ERR_INVALID, "null descriptor field");
+  if (d->dim == 0 || d->n_points == 0 || d->n_nodes == 0)
+    return fail(PTK_ERR_INVALID, "dim, n_points and n_nodes must be positive");
+  if (d->n_points >= (1ull << 31)) return fail(PTK_ERR_INVALID, "n_points must be < 2^31");
+  if (d->n_nodes >= (1ull << 32) - 1) return fail(PTK_ERR_INVALID, "n_nodes must be < 2^32 - 1");
+  ptk_tree* t = new (std::nothrow) ptk_tree;
+  if (t == nullptr) return fail(PTK_ERR_NOMEM, "out of memory");
+  try {
+    t->dim = d->dim;
+    t->n_points = d->n_points;
+    t->nodes.assign(d->nodes, d->nodes + d->n_nodes);
+    t->indices.assign(d->indices, d->indices + d->n_points);
+    if (d->root_min != nullptr && d->root_max != nullptr) {
+      t->root_min.assign(d->root_min, d->root_min + d->dim);
+      t->root_max.assign(d->root_max, d->root_max + d->dim);
+    }
+  } catch (const std::bad_alloc&) {
+    delete t;
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  }
+  return finish_create(t, d->points, d->device, out);
+}
+
+int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t dim, uint64_t max_leaf_size,
+                                int32_t device, ptk_tree** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (points == nullptr) return fail(PTK_ERR_INVALID, "null points");
+  if (dim == 0 || n_points == 0 || max_leaf_size == 0)
+    return fail(PTK_ERR_INVALID, "dim, n_points and max_leaf_size must be positive");
+  if (n_points >= (1ull << 31)) return fail(PTK_ERR_INVALID, "n_points must be < 2^31");
+  ptk_tree* t = new (std::nothrow) ptk_tree;
+  if (t == nullptr) return fail(PTK_ERR_NOMEM, "out of memory");
+  try {
+    using namespace pico_tree;
+    using space_t = space_map<point_map<float const, dynamic_extent>>;
+    space_t space(points, n_points, dim);
+    internal::space_view<space_t> view(space);
+    auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
+                                               sliding_midpoint_max_side);
+    t->dim = dim;
+    t->n_points = n_points;
+    t->nodes.resize(flat.nodes.size());
+    std::memcpy(t->nodes.data(), flat.nodes.data(), flat.nodes.size() * sizeof(ptk_node));
+    t->indices = std::move(flat.indices);
+    t->root_min.assign(flat.root_box.min(), flat.root_box.min() + dim);
+    t->root_max.assign(flat.root_box.max(), flat.root_box.max() + dim);
+  } catch (const std::bad_alloc&) {
+    delete t;
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  }
+  return finish_create(t, points, device, out);
+}
+
+void ptk_tree_destroy(ptk_tree* t) {
+  if (t == nullptr) return;
+  if (t->device >= 0) {
+    DeviceGuard guard(t->device);
+    for (PendingEvent& p : t->profile.pending) {
+      (void)hipEventDestroy(p.a);
+      (void)hipEventDestroy(p.b);
+    }
+    if (t->d_nodes) (void)hipFree(t->d_nodes);
+    if (t->d_pts) (void)hipFree(t->d_pts);
+  }
+  delete t;
+}
+
+int ptk_tree_get_info(const ptk_tree* t, ptk_tree_info* info) {
+  if (t == nullptr || info == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  info->dim = t->dim;
+  info->n_points = t->n_points;
+  info->n_nodes = t->nodes.size();
+  info->n_leaves = t->n_leaves;
+  info->max_depth = t->max_depth;
+  info->max_leaf_count = t->max_leaf_count;
+  info->device_bytes = t->device_bytes;
+  info->device = t->device;
+  return PTK_OK;
+}
+
+int ptk_tree_get_flat(const ptk_tree* t, ptk_node* nodes, int32_t* indices, float* root_min, float* root_max) {
+  if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
+  if (nodes) std::memcpy(nodes, t->nodes.data(), t->nodes.size() * sizeof(ptk_node));
+  if (indices) std::memcpy(indices, t->indices.data(), t->indices.size() * sizeof(int32_t));
+  if (root_min) std::memcpy(root_min, t->root_min.data(), t->dim * sizeof(float));
+  if (root_max) std::memcpy(root_max, t->root_max.data(), t->dim * sizeof(float));
+  return PTK_OK;
+}
+
+int ptk_tree_set_reorder(ptk_tree* t, int mode) {
+  if (t == nullptr || mode < PTK_REORDER_AUTO || mode > PTK_REORDER_OFF)
+    return fail(PTK_ERR_INVALID, "bad reorder mode");
+  t->reorder.store(mode);
+  return PTK_OK;
+}
+
+// ---- knn --------------------------------------------------------------------------------
+
+int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t k, float e,
+                          ptk_neighbor* d_out, void* stream) {
+  int rc = check_search(t, d_q, nq);
+  if (rc != PTK_OK) return rc;
+  if (k == 0) return fail(PTK_ERR_INVALID, "k must be >= 1");
+  if (k > t->n_points) return fail(PTK_ERR_INVALID, "k = %u exceeds the number of points (%llu)", k,
+                                   (unsigned long long)t->n_points);
+  if (!(e > 0.0f)) return fail(PTK_ERR_INVALID, "approximation ratio e must be > 0");
+  if (nq == 0) return PTK_OK;
+  if (d_out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  uint32_t* perm = nullptr;
+  if (want_reorder(t, nq)) {
+    rc = make_permutation(t, d_q, nq, s, &perm);
+    if (rc != PTK_OK) return rc;
+  }
+  if (k == 1) {
+    const int variant = choose_variant(t, 32);
+    PTK_DISPATCH_VARIANT(32, variant, (launch_knn<S, OVF>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+  } else {
+    const int variant = choose_variant(t, 16);
+    PTK_DISPATCH_VARIANT(16, variant, (launch_knn<S, OVF>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+  }
+  if (perm) (void)hipFreeAsync(perm, s);
+  return rc;
+}
+
+int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, float e, ptk_neighbor* out) {
+  int rc = check_search(t, q, nq);
+  if (rc != PTK_OK) return rc;
+  if (nq == 0) return PTK_OK;
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  hipStream_t s = nullptr;
+  PTK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  float* d_q = nullptr;
+  ptk_neighbor* d_out = nullptr;
+  const size_t qbytes = (size_t)nq * t->dim * sizeof(float);
+  const size_t obytes = (size_t)nq * (k ? k : 1) * sizeof(ptk_neighbor);
+  hipError_t he = hipMalloc((void**)&d_q, qbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_out, obytes);
+  if (he == hipSuccess) he = hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s);
+  if (he == hipSuccess) {
+    rc = ptk_search_knn_device(t, d_q, nq, k, e, d_out, s);
+    if (rc == PTK_OK) he = hipMemcpyAsync(out, d_out, obytes, hipMemcpyDeviceToHost, s);
+  }
+  hipError_t hs = hipStreamSynchronize(s);
+  if (d_q) (void)hipFree(d_q);
+  if (d_out) (void)hipFree(d_out);
+  (void)hipStreamDestroy(s);
+  if (rc != PTK_OK) return rc;
+  if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  if (hs != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(hs));
+  return PTK_OK;
+}
+
+// ---- radius -------------------------------------------------------------------------------
+
+static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e, bool fill,
+                              uint64_t* d_counts, const uint64_t* d_offsets, ptk_neighbor* d_out, int sort,
+                              hipStream_t s) {
+  int rc = check_search(t, d_q, nq);
+  if (rc != PTK_OK) return rc;
+  if (!(e > 0.0f)) return fail(PTK_ERR_INVALID, "approximation ratio e must be > 0");
+  if (nq == 0) return PTK_OK;
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  uint32_t* perm = nullptr;
+  if (want_reorder(t, nq)) {
+    rc = make_permutation(t, d_q, nq, s, &perm);
+    if (rc != PTK_OK) return rc;
+  }
+  const int variant = choose_variant(t, 16);
+  PTK_DISPATCH_VARIANT(16, variant, (launch_radius<S, OVF>(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
+                                                           reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+  if (perm) (void)hipFreeAsync(perm, s);
+  if (rc == PTK_OK && fill && sort) {
+    Timer timer(t, s);
+    const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+    hipLaunchKernelGGL(ptk::sort_rows_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, nq, d_offsets,
+                       reinterpret_cast<ptk::Neighbor*>(d_out));
+    PTK_HIP(hipGetLastError());
+    timer.stop(2, 0);
+  }
+  return rc;
+}
+
+int ptk_search_radius_count_device(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e,
+                                   uint64_t* d_counts, void* stream) {
+  if (nq > 0 && d_counts == nullptr) return fail(PTK_ERR_INVALID, "null counts buffer");
+  return radius_pass_device(t, d_q, nq, radius, e, false, d_counts, nullptr, nullptr, 0,
+                            static_cast<hipStream_t>(stream));
+}
+
+int ptk_search_radius_fill_device(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e,
+                                  const uint64_t* d_offsets, ptk_neighbor* d_out, int sort, void* stream) {
+  if (nq > 0 && d_offsets == nullptr) return fail(PTK_ERR_INVALID, "null offsets buffer");
+  return radius_pass_device(t, d_q, nq, radius, e, true, nullptr, d_offsets, d_out, sort,
+                            static_cast<hipStream_t>(stream));
+}
+
+int ptk_search_radius_count(const ptk_tree* t, const float* q, uint64_t nq, float radius, float e,
+                            uint64_t* counts) {
+  int rc = check_search(t, q, nq);
+  if (rc != PTK_OK) return rc;
+  if (nq == 0) return PTK_OK;
+  if (counts == nullptr) return fail(PTK_ERR_INVALID, "null counts buffer");
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  float* d_q = nullptr;
+  uint64_t* d_c = nullptr;
+  const size_t qbytes = (size_t)nq * t->dim * sizeof(float);
+  hipError_t he = hipMalloc((void**)&d_q, qbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_c, nq * 8);
+  if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    rc = ptk_search_radius_count_device(t, d_q, nq, radius, e, d_c, nullptr);
+    if (rc == PTK_OK) he = hipMemcpy(counts, d_c, nq * 8, hipMemcpyDeviceToHost);
+  }
+  if (d_q) (void)hipFree(d_q);
+  if (d_c) (void)hipFree(d_c);
+  if (rc != PTK_OK) return rc;
+  if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  return PTK_OK;
+}
+
+int ptk_search_radius_fill(const ptk_tree* t, const float* q, uint64_t nq, float radius, float e,
+                           const uint64_t* offsets, ptk_neighbor* out, int sort) {
+  int rc = check_search(t, q, nq);
+  if (rc != PTK_OK) return rc;
+  if (nq == 0) return PTK_OK;
+  if (offsets == nullptr) return fail(PTK_ERR_INVALID, "null offsets buffer");
+  const uint64_t total = offsets[nq];
+  if (total > 0 && out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  float* d_q = nullptr;
+  uint64_t* d_o = nullptr;
+  ptk_neighbor* d_out = nullptr;
+  const size_t qbytes = (size_t)nq * t->dim * sizeof(float);
+  hipError_t he = hipMalloc((void**)&d_q, qbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nq + 1) * 8);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * 8);
+  if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(d_o, offsets, (nq + 1) * 8, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    rc = ptk_search_radius_fill_device(t, d_q, nq, radius, e, d_o, d_out, sort, nullptr);
+    if (rc == PTK_OK && total > 0) he = hipMemcpy(out, d_out, total * 8, hipMemcpyDeviceToHost);
+  }
+  if (d_q) (void)hipFree(d_q);
+  if (d_o) (void)hipFree(d_o);
+  if (d_out) (void)hipFree(d_out);
+  if (rc != PTK_OK) return rc;
+  if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  return PTK_OK;
+}
+
+int ptk_search_radius(const ptk_tree* t, const float* q, uint64_t nq, float radius, float e, int sort,
+                      uint64_t* offsets, ptk_neighbor** out) {
+  if (out == nullptr || offsets == nullptr) return fail(PTK_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  int rc = check_search(t, q, nq);
+  if (rc != PTK_OK) return rc;
+  offsets[0] = 0;
+  if (nq == 0) return PTK_OK;
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  float* d_q = nullptr;
+  uint64_t *d_c = nullptr, *d_o = nullptr;
+  ptk_neighbor* d_out = nullptr;
+  void* tmp = nullptr;
+  const size_t qbytes = (size_t)nq * t->dim * sizeof(float);
+  hipError_t he = hipMalloc((void**)&d_q, qbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_c, (nq + 1) * 8);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nq + 1) * 8);
+  if (he == hipSuccess) he = hipMemset(d_c, 0, (nq + 1) * 8);
+  if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
+  uint64_t total = 0;
+  if (he == hipSuccess) {
+    rc = ptk_search_radius_count_device(t, d_q, nq, radius, e, d_c, nullptr);
+    if (rc == PTK_OK) {
+      size_t tmp_bytes = 0;
+      he = rocprim::exclusive_scan(nullptr, tmp_bytes, d_c, d_o, (uint64_t)0, nq + 1, rocprim::plus<uint64_t>(),
+                                   (hipStream_t) nullptr);
+      if (he == hipSuccess) he = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+      if (he == hipSuccess)
+        he = rocprim::exclusive_scan(tmp, tmp_bytes, d_c, d_o, (uint64_t)0, nq + 1, rocprim::plus<uint64_t>(),
+                                     (hipStream_t) nullptr);
+      if (he == hipSuccess) he = hipMemcpy(offsets, d_o, (nq + 1) * 8, hipMemcpyDeviceToHost);
+      if (he == hipSuccess) {
+        total = offsets[nq];
+        he = hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * 8);
+      }
+      if (he == hipSuccess) rc = ptk_search_radius_fill_device(t, d_q, nq, radius, e, d_o, d_out, sort, nullptr);
+      if (he == hipSuccess && rc == PTK_OK) {
+        *out = static_cast<ptk_neighbor*>(std::malloc(std::max<uint64_t>(total, 1) * 8));
+        if (*out == nullptr) {
+          rc = fail(PTK_ERR_NOMEM, "out of memory");
+        } else if (total > 0) {
+          he = hipMemcpy(*out, d_out, total * 8, hipMemcpyDeviceToHost);
+        }
+      }
+    }
+  }
+  if (tmp) (void)hipFree(tmp);
+  if (d_q) (void)hipFree(d_q);
+  if (d_c) (void)hipFree(d_c);
+  if (d_o) (void)hipFree(d_o);
+  if (d_out) (void)hipFree(d_out);
+  if (rc == PTK_OK && he != hipSuccess) rc = fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  if (rc != PTK_OK && *out) {
+    std::free(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint64_t nb, uint64_t* offsets,
+                   int32_t** out) {
+  (void)mins; (void)maxs; (void)nb; (void)offsets;
+  if (out) *out = nullptr;
+  if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
+  return fail(PTK_ERR_UNSUPPORTED, "search_box is not on the device yet");
+}
+
+void ptk_free(void* p) { std::free(p); }
+
+int ptk_profile_enable(ptk_tree* t, int on) {
+  if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
+  std::lock_guard<std::mutex> lock(t->profile.mutex);
+  t->profile.enabled = on != 0;
+  return PTK_OK;
+}
+
+int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
+  if (t == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(t->profile.mutex);
+  for (PendingEvent& p : t->profile.pending) {
+    float ms = 0;
+    if (hipEventSynchronize(p.b) == hipSuccess && hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) {
+      if (p.kind == 0) {
+        t->profile.acc.search_ms += ms;
+        t->profile.acc.launches += 1;
+        t->profile.acc.queries += p.queries;
+      } else if (p.kind == 1) {
+        t->profile.acc.reorder_ms += ms;
+      } else {
+        t->profile.acc.other_ms += ms;
+      }
+    }
+    (void)hipEventDestroy(p.a);
+    (void)hipEventDestroy(p.b);
+  }
+  t->profile.pending.clear();
+  *out = t->profile.acc;
+  if (reset) t->profile.acc = ptk_profile{};
+  return PTK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,173 @@
+// ptk_encode.hpp -- host-side re-encoding of the flat DFS tree into the layout
+// the gfx950 kernels traverse (plain C++17, no HIP types).
+//
+// Input : the ptk_node stream of include/ptk.h (DFS pre-order, leaves are nodes,
+//         the reference's on-disk order: internal/kd_tree_data.hpp:109-135),
+//         the leaf-ordered `indices` permutation and the points in original order.
+// Output: * one 16-byte record per BRANCH only:
+//             {left_max, right_min, left_ref, right_ref}
+//           Leaves disappear as nodes: a child reference that points at a leaf
+//           carries the leaf's [begin, count) itself, so reaching a leaf costs no
+//           extra dependent load.
+//         * points copied into LEAF ORDER as 16-byte records {x, y, z, index}
+//           (z = 0 when dim < 3; y = z = 0 when dim == 1), so a leaf is one
+//           contiguous run of 16-byte loads and needs no index indirection.
+//         Reference encoding (32 bits):
+//             bit 31 = 1: leaf,   bits 30:0  = (begin << cbits) | count
+//             bit 31 = 0: branch, bits 30:29 = split axis OF THE CHILD,
+//                                 bits 28:0  = branch index
+//         Zero-padding unused axes is exact: the padded terms contribute
+//         (0 - 0)^2 = +0 to every distance and x + 0 == x bit-for-bit for the
+//         non-negative partial sums involved.
+
+#pragma once
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ptk.h"
+
+namespace ptk {
+
+struct EncNode {
+  uint32_t left_max_bits;
+  uint32_t right_min_bits;
+  uint32_t left_ref;
+  uint32_t right_ref;
+};
+struct EncPoint {
+  float x, y, z;
+  int32_t index;
+};
+static_assert(sizeof(EncNode) == 16 && sizeof(EncPoint) == 16, "device record sizes");
+
+constexpr uint32_t kEncLeafBit = 0x80000000u;
+
+struct TreeStats {
+  uint64_t n_leaves = 0;
+  uint32_t max_leaf_count = 0;
+  uint32_t max_depth = 0;
+};
+
+struct EncodedTree {
+  std::vector<EncNode> nodes;   // at least one element (dummy when the root is a leaf)
+  std::vector<EncPoint> points; // n_points
+  uint32_t root_ref = 0;
+  uint32_t cbits = 0;
+};
+
+inline uint32_t bits_for(uint64_t v) {  // bits needed to represent 0..v
+  uint32_t b = 0;
+  while (v) {
+    ++b;
+    v >>= 1;
+  }
+  return b;
+}
+
+// Validates the DFS stream and gathers statistics; optionally numbers branches.
+// Returns an empty string on success, an error message otherwise.
+inline std::string analyse_stream(
+    uint32_t dim, uint64_t n_points, const ptk_node* nodes, uint64_t n_nodes, TreeStats& st,
+    std::vector<uint32_t>* branch_id) {
+  if (n_nodes == 0) return "empty node stream";
+  if (branch_id) branch_id->assign(n_nodes, 0);
+  st = TreeStats{};
+  uint32_t n_branch = 0;
+  std::vector<std::pair<uint32_t, uint32_t>> pending;  // (right child index, its depth)
+  uint32_t depth = 0;
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    if (!pending.empty() && pending.back().first == i) {
+      depth = pending.back().second;
+      pending.pop_back();
+    }
+    if (depth > st.max_depth) st.max_depth = depth;
+    const ptk_node& nd = nodes[i];
+    if (nd.right == PTK_LEAF) {
+      int32_t b, e;
+      std::memcpy(&b, &nd.a, 4);
+      std::memcpy(&e, &nd.b, 4);
+      if (b < 0 || e < b || (uint64_t)e > n_points)
+        return "leaf " + std::to_string(i) + " has a bad index range";
+      ++st.n_leaves;
+      if ((uint32_t)(e - b) > st.max_leaf_count) st.max_leaf_count = (uint32_t)(e - b);
+    } else {
+      if (nd.right <= i + 1 || nd.right >= n_nodes)
+        return "branch " + std::to_string(i) + " has a bad right child";
+      if (nd.split_dim >= dim) return "branch " + std::to_string(i) + " splits on an axis >= dim";
+      if (branch_id) (*branch_id)[i] = n_branch;
+      ++n_branch;
+      pending.emplace_back(nd.right, depth + 1);
+      ++depth;  // the left child follows immediately
+    }
+  }
+  if (!pending.empty()) return "node stream is truncated";
+  if (st.n_leaves != (uint64_t)n_branch + 1) return "node stream is not a binary tree";
+  return std::string();
+}
+
+// Re-encodes for the device.  `unsupported` is set when the tree is valid but
+// does not fit the 32-bit reference encoding.
+inline std::string encode_tree(
+    uint32_t dim, uint64_t n_points, const float* points, const ptk_node* nodes, uint64_t n_nodes,
+    const int32_t* indices, TreeStats& st, EncodedTree& out, bool& unsupported) {
+  unsupported = false;
+  if (dim == 0 || dim > 3) {
+    unsupported = true;
+    return "only dim <= 3 is encoded for the device";
+  }
+  std::vector<uint32_t> branch_id;
+  std::string err = analyse_stream(dim, n_points, nodes, n_nodes, st, &branch_id);
+  if (!err.empty()) return err;
+
+  const uint64_t n_branch = n_nodes - st.n_leaves;
+  const uint32_t cbits = bits_for(st.max_leaf_count);
+  const uint32_t bbits = bits_for(n_points);
+  if (cbits + bbits > 31) {
+    unsupported = true;
+    return "leaf reference needs " + std::to_string(bbits) + " + " + std::to_string(cbits) +
+           " bits (> 31): n_points x max leaf size too large";
+  }
+  if (n_branch >= (1ull << 28)) {
+    unsupported = true;
+    return "more than 2^28 branch nodes";
+  }
+
+  auto ref_of = [&](uint64_t i) -> uint32_t {
+    const ptk_node& nd = nodes[i];
+    if (nd.right == PTK_LEAF) return kEncLeafBit | (nd.a << cbits) | (nd.b - nd.a);
+    return (nd.split_dim << 29) | branch_id[i];
+  };
+
+  out.nodes.assign(n_branch > 0 ? n_branch : 1, EncNode{0, 0, 0, 0});
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    const ptk_node& nd = nodes[i];
+    if (nd.right == PTK_LEAF) continue;
+    EncNode r;
+    r.left_max_bits = nd.a;
+    r.right_min_bits = nd.b;
+    r.left_ref = ref_of(i + 1);
+    r.right_ref = ref_of(nd.right);
+    out.nodes[branch_id[i]] = r;
+  }
+  out.points.resize(n_points);
+  for (uint64_t pos = 0; pos < n_points; ++pos) {
+    const int32_t idx = indices[pos];
+    if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
+    const float* p = points + (uint64_t)idx * dim;
+    EncPoint v;
+    v.x = p[0];
+    v.y = dim > 1 ? p[1] : 0.0f;
+    v.z = dim > 2 ? p[2] : 0.0f;
+    v.index = idx;
+    out.points[pos] = v;
+  }
+  out.root_ref = ref_of(0);
+  out.cbits = cbits;
+  return std::string();
+}
+
+}  // namespace ptk

@@ -1,0 +1,137 @@
+// tests/cpp/emulate_kernels.cpp -- TEST INFRASTRUCTURE.
+//
+// Compiles the product's device source (pico_tree_amd/csrc/ptk_kernels.hpp) and
+// its host-side tree encoder (ptk_encode.hpp) with g++ against the HIP stand-in
+// in tests/cpp/hip_stub, and runs every lane of every block sequentially.  This
+// lets the CPU-only test tier check the exact kernel logic (record stack, undo
+// records, tie handling, k-list insertion, radius passes) against the oracle
+// before any GPU time is spent.  Float semantics are IEEE on both sides; what
+// this cannot see is scheduling, so the `-m gpu` tests remain the parity proof.
+
+#include <hip/hip_runtime.h>
+
+thread_local dim3 threadIdx;
+thread_local dim3 blockIdx;
+thread_local dim3 gridDim;
+thread_local dim3 blockDim;
+
+#include <string>
+#include <vector>
+
+#include "ptk.h"
+#include "ptk_encode.hpp"
+#include "ptk_kernels.hpp"
+
+namespace ptk {
+unsigned char ptk_smem[192 * 1024] __attribute__((aligned(16)));
+}
+
+namespace {
+
+thread_local std::string g_err;
+
+struct Emu {
+  ptk::EncodedTree enc;
+  ptk::TreeStats st;
+  ptk::DevTree dev;
+  uint32_t dim;
+};
+
+template <typename F>
+void for_each_lane(uint64_t nq, F&& f) {
+  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+  gridDim.x = blocks;
+  blockDim.x = ptk::kBlock;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    blockIdx.x = b;
+    for (uint32_t t = 0; t < (uint32_t)ptk::kBlock; ++t) {
+      threadIdx.x = t;
+      f();
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* emu_last_error() { return g_err.c_str(); }
+
+void* emu_create(const float* points, uint64_t n, uint32_t dim, const ptk_node* nodes, uint64_t n_nodes,
+                 const int32_t* indices) {
+  auto* e = new Emu;
+  bool unsupported = false;
+  g_err = ptk::encode_tree(dim, n, points, nodes, n_nodes, indices, e->st, e->enc, unsupported);
+  if (!g_err.empty()) {
+    delete e;
+    return nullptr;
+  }
+  e->dim = dim;
+  e->dev.nodes = reinterpret_cast<const uint4*>(e->enc.nodes.data());
+  e->dev.pts = reinterpret_cast<const float4*>(e->enc.points.data());
+  e->dev.root_ref = e->enc.root_ref;
+  e->dev.cbits = e->enc.cbits;
+  e->dev.cmask = (1u << e->enc.cbits) - 1u;
+  e->dev.n_points = (uint32_t)n;
+  return e;
+}
+
+void emu_destroy(void* h) { delete static_cast<Emu*>(h); }
+
+uint32_t emu_max_depth(void* h) { return static_cast<Emu*>(h)->st.max_depth; }
+
+// small_stack != 0 exercises the scratch-overflow path (S = 16 even for k = 1).
+int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uint32_t* perm, int small_stack,
+            int list_in_lds, ptk_neighbor* out) {
+  auto* t = static_cast<Emu*>(h);
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  const float e_inv = 1.0f / e;
+  const uint32_t need = 2 * t->st.max_depth + 2;
+  if (need > 16 + 2048) return -2;
+  if (k == 1) {
+    if (small_stack)
+      for_each_lane(nq, [&] { ptk::knn1_kernel<16, 2048>(t->dev, q, t->dim, perm, nq, e_inv, o); });
+    else if (need <= 32 + 64)
+      for_each_lane(nq, [&] { ptk::knn1_kernel<32, 64>(t->dev, q, t->dim, perm, nq, e_inv, o); });
+    else
+      for_each_lane(nq, [&] { ptk::knn1_kernel<32, 2048>(t->dev, q, t->dim, perm, nq, e_inv, o); });
+  } else if (list_in_lds) {
+    if ((size_t)(16 + k) * ptk::kBlock * 8 > sizeof(ptk::ptk_smem)) return -2;
+    for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, true>(t->dev, q, t->dim, perm, nq, k, e_inv, o); });
+  } else {
+    for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, false>(t->dev, q, t->dim, perm, nq, k, e_inv, o); });
+  }
+  return 0;
+}
+
+int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
+                     uint64_t* counts) {
+  auto* t = static_cast<Emu*>(h);
+  const float e_inv = 1.0f / e;
+  for_each_lane(nq, [&] {
+    ptk::radius_kernel<16, 2048, false>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, nullptr, nullptr);
+  });
+  return 0;
+}
+
+int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
+                    const uint64_t* offsets, ptk_neighbor* out, int sort) {
+  auto* t = static_cast<Emu*>(h);
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  const float e_inv = 1.0f / e;
+  for_each_lane(nq, [&] {
+    ptk::radius_kernel<16, 2048, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o);
+  });
+  if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
+  return 0;
+}
+
+// Morton keys + identity ids exactly as the device computes them.
+void emu_morton(const float* q, uint32_t dim, uint64_t nq, const float* lo, const float* inv, uint32_t* keys,
+                uint32_t* ids) {
+  float3 l = make_float3(lo[0], lo[1], lo[2]);
+  float3 i = make_float3(inv[0], inv[1], inv[2]);
+  for_each_lane(nq, [&] { ptk::morton_kernel(q, dim, nq, l, i, keys, ids); });
+}
+
+}  // extern "C"

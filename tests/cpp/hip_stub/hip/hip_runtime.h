@@ -1,0 +1,39 @@
+// Test-only stand-in for <hip/hip_runtime.h>: just enough of the HIP device
+// vocabulary for g++ to compile pico_tree_amd/csrc/ptk_kernels.hpp as ordinary
+// host functions, so that tests/cpp/emulate_kernels.cpp can run the REAL kernel
+// source lane by lane on a CPU-only machine (`-m "not gpu"` tests).  It is never
+// on the include path of the product build.
+#pragma once
+
+#include <cmath>
+#include <cstdint>
+#include <cstring>
+
+#define __device__
+#define __global__
+#define __host__
+#define __shared__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
+struct float3 { float x, y, z; };
+struct float4 { float x, y, z, w; };
+struct dim3 { uint32_t x = 1, y = 1, z = 1; };
+
+inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
+
+// One rounding per operation; the emulator is built with -ffp-contract=off.
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
+inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
+inline int32_t __float_as_int(float f) { int32_t i; std::memcpy(&i, &f, 4); return i; }
+
+extern thread_local dim3 threadIdx;
+extern thread_local dim3 blockIdx;
+extern thread_local dim3 gridDim;
+extern thread_local dim3 blockDim;

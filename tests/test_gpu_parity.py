@@ -1,0 +1,185 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes -> libptk.so),
+against the CPU oracle on the same seeded inputs.  Bar: bit-exact indices AND
+bit-exact float32 distances (the oracle is built without FMA contraction).
+
+Index parity is pinned by the oracle only: the reference's own tests compare
+distances but deliberately not indices
+(/root/reference/test/pico_tree/common.hpp:195-196); the oracle in turn is pinned
+against the compiled reference (tests/test_oracle.py).
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+import pico_tree_amd as pt
+from pico_tree_amd import datasets as ds
+
+pytestmark = pytest.mark.gpu
+
+
+def _clouds(name, n, nq):
+    if name == "uniform":
+        return ds.uniform_cloud(n, 3, 11), ds.uniform_cloud(nq, 3, 12)
+    if name == "lidar":
+        return ds.lidar_cloud(n, 1), ds.lidar_cloud(nq, 2, pose=(3.0, 1.5))
+    if name == "ties":  # coordinates on a coarse lattice: many equal distances, duplicates
+        return (np.round(ds.uniform_cloud(n, 3, 5) * 8) / 8).astype(np.float32), \
+               (np.round(ds.uniform_cloud(nq, 3, 6) * 16) / 16).astype(np.float32)
+    if name == "self":  # queries are tree points: zero distances, exact plane hits
+        p = ds.uniform_cloud(n, 3, 21)
+        return p, p[:nq].copy()
+    raise ValueError(name)
+
+
+@pytest.fixture(scope="module")
+def trees(gpu):
+    cache = {}
+
+    def get(name, n=60_000, nq=20_000, leaf=10):
+        key = (name, n, nq, leaf)
+        if key not in cache:
+            pts, q = _clouds(name, n, nq)
+            cache[key] = (pt.KdTree(pts, pt.Metric.L2Squared, leaf, device=gpu),
+                          oracle.Oracle(pts, leaf, "port"), pts, q)
+        return cache[key]
+
+    return get
+
+
+@pytest.mark.parametrize("cloud", ["uniform", "lidar", "ties", "self"])
+@pytest.mark.parametrize("k", [1, 4, 16, 40])
+def test_knn_bit_exact(trees, cloud, k):
+    tree, ref, _, q = trees(cloud)
+    got = tree.search_knn(q, k)
+    want = ref.search_knn(q, k)
+    if k == 1:
+        want = want[:, 0]
+    assert got.shape == want.shape
+    assert np.array_equal(got["index"], want["index"])
+    assert got.tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("cloud", ["uniform", "ties"])
+def test_reorder_does_not_change_results(trees, cloud):
+    tree, _, _, q = trees(cloud)
+    tree.set_reorder(pt.REORDER_OFF)
+    a1, a8 = tree.search_knn(q, 1), tree.search_knn(q, 8)
+    tree.set_reorder(pt.REORDER_ON)
+    b1, b8 = tree.search_knn(q, 1), tree.search_knn(q, 8)
+    tree.set_reorder(pt.REORDER_AUTO)
+    assert a1.tobytes() == b1.tobytes()
+    assert a8.tobytes() == b8.tobytes()
+
+
+@pytest.mark.parametrize("cloud,radius", [("uniform", 0.0015), ("lidar", 1.0), ("ties", 0.03)])
+def test_radius_bit_exact_traversal_order(trees, cloud, radius):
+    tree, ref, _, q = trees(cloud)
+    got = tree.search_radius(q, radius)
+    off, flat = ref.search_radius(q, radius)
+    assert np.array_equal(got.offsets, off)
+    assert got.flat.tobytes() == flat.tobytes()
+    assert off[-1] > 0
+
+
+def test_radius_strict_and_sorted(trees):
+    tree, ref, pts, q = trees("ties")
+    radius = 0.03
+    got = tree.search_radius(q, radius, sort=True)
+    off, flat = ref.search_radius(q, radius, sort=True)
+    assert np.array_equal(got.offsets, off)
+    # std::sort is unstable: rows agree as sorted distance sequences and as index sets.
+    assert np.array_equal(got.flat["distance"], flat["distance"])
+    for i in range(0, len(q), 97):
+        a, b = got[i], flat[int(off[i]):int(off[i + 1])]
+        assert sorted(a["index"].tolist()) == sorted(b["index"].tolist())
+        assert np.all(np.diff(a["distance"]) >= 0)
+        assert np.all(a["distance"] < np.float32(radius))  # strict (search_visitor.hpp:141)
+
+
+@pytest.mark.parametrize("e", [1.21, 2.0])
+def test_approximate_searches(trees, e):
+    tree, ref, _, q = trees("lidar")
+    assert tree.search_knn(q, 8, e).tobytes() == ref.search_knn(q, 8, e=e).tobytes()
+    assert tree.search_knn(q, 1, e).tobytes() == ref.search_knn(q, 1, e=e)[:, 0].tobytes()
+    got = tree.search_radius(q, 2.0, e)
+    off, flat = ref.search_radius(q, 2.0, e=e)
+    assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+
+
+@pytest.mark.parametrize("dim", [1, 2])
+def test_low_dimensions(gpu, dim):
+    pts, q = ds.uniform_cloud(30_000, dim, 3), ds.uniform_cloud(10_000, dim, 4)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 7, device=gpu)
+    ref = oracle.Oracle(pts, 7, "port")
+    assert tree.search_knn(q, 5).tobytes() == ref.search_knn(q, 5).tobytes()
+    got = tree.search_radius(q, 1e-4 if dim == 2 else 1e-6)
+    off, flat = ref.search_radius(q, 1e-4 if dim == 2 else 1e-6)
+    assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+
+
+def test_deep_tree_uses_scratch_overflow(gpu):
+    """Heavy duplication makes the sliding-midpoint tree > 100 levels deep."""
+    pts = (np.round(ds.uniform_cloud(40_000, 3, 9) * 4) / 4).astype(np.float32)
+    q = ds.uniform_cloud(10_000, 3, 10)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 4, device=gpu)
+    assert tree.info()["max_depth"] > 60
+    ref = oracle.Oracle(pts, 4, "port")
+    assert tree.search_knn(q, 1).tobytes() == ref.search_knn(q, 1)[:, 0].tobytes()
+    assert tree.search_knn(q, 10).tobytes() == ref.search_knn(q, 10).tobytes()
+
+
+@pytest.mark.parametrize("n,leaf", [(1, 1), (7, 10), (64, 1), (1000, 1000)])
+def test_tiny_and_degenerate_trees(gpu, n, leaf):
+    pts, q = ds.uniform_cloud(n, 3, 31), ds.uniform_cloud(500, 3, 32)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, leaf, device=gpu)
+    ref = oracle.Oracle(pts, leaf, "port")
+    for k in {1, min(3, n), n if n <= 64 else 50}:
+        got, want = tree.search_knn(q, k), ref.search_knn(q, k)
+        assert got.tobytes() == (want[:, 0] if k == 1 else want).tobytes()
+
+
+def test_device_buffers_and_streams(trees, gpu):
+    import torch
+
+    tree, ref, _, q = trees("uniform")
+    dq = torch.from_numpy(q).to(f"cuda:{gpu}")
+    side = torch.cuda.Stream(device=gpu)
+    with torch.cuda.stream(side):
+        res = tree.search_knn(dq, 4)
+    side.synchronize()
+    assert res.numpy().tobytes() == ref.search_knn(q, 4).tobytes()
+    off, raw = tree.search_radius_device(dq, 0.0015)
+    torch.cuda.synchronize()
+    o2, flat = ref.search_radius(q, 0.0015)
+    assert np.array_equal(off.cpu().numpy().astype(np.uint64), o2)
+    assert raw.cpu().numpy().tobytes() == flat.tobytes()
+
+
+def test_empty_batch_and_errors(trees):
+    tree, _, pts, q = trees("uniform")
+    assert tree.search_knn(q[:0], 3).shape == (0, 3)
+    assert len(tree.search_radius(q[:0], 1.0)) == 0
+    with pytest.raises(pt.PtkError):
+        tree.search_knn(q, 0)
+    with pytest.raises(pt.PtkError):
+        tree.search_knn(q, len(pts) + 1)
+    with pytest.raises(ValueError):
+        tree.search_knn(q.astype(np.float64), 1)
+    with pytest.raises(ValueError):
+        tree.search_knn(q[:, :2].copy(), 1)
+    with pytest.raises(ValueError):
+        tree.search_knn(q[::2], 1)  # non-contiguous
+
+
+def test_subnormal_and_huge_coordinates(gpu):
+    """float32 subnormals must not be flushed and 1e18-scale values must not overflow early."""
+    base = ds.uniform_cloud(20_000, 3, 41)
+    for scale in (np.float32(1e-38), np.float32(1e-20), np.float32(1e15)):
+        pts = (base * scale).astype(np.float32)
+        q = (ds.uniform_cloud(5_000, 3, 42) * scale).astype(np.float32)
+        tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+        ref = oracle.Oracle(pts, 10, "port")
+        assert tree.search_knn(q, 3).tobytes() == ref.search_knn(q, 3).tobytes()
