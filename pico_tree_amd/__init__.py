@@ -111,6 +111,13 @@ def _load():
             raise ImportError(
                 f"{_LIB_PATH} is missing: build it with `python -m pico_tree_amd.build` "
                 "(there is no CPU fallback)")
+        # PyTorch bundles its own HIP runtime under the same SONAME as the system one
+        # (libamdhip64.so.7).  Import it first so that libptk binds to the runtime that
+        # torch tensors and streams live in, whatever the import order of the caller.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         lib = ctypes.CDLL(_LIB_PATH)
         for name, (restype, argtypes) in _SIGNATURES.items():
             fn = getattr(lib, name)
