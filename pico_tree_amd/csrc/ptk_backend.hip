@@ -230,13 +230,11 @@ struct Timer {
   }
 };
 
-// Stack geometry: S record slots per lane in LDS, OVF more in private scratch.
-// A traversal holds, per level of the current root path, either one pending
-// record (went near, far child unexplored) or two undo records (went far), so
-// 2 * depth + 2 slots always suffice.  k = 1 keeps 32 slots in LDS (64 KiB per
-// 256-lane block); the k-list and radius kernels keep 16 to leave LDS to the
-// list and to a second resident block.
-int choose_variant(const ptk_tree* t, int s_lds) {
+// Stack geometry: the newest S records of a lane live in an LDS ring, older ones
+// spill to OVF private-scratch slots.  A traversal holds, per level of the current
+// root path, either one pending record (went near, far child unexplored) or two
+// undo records (went far), so 2 * depth + 2 slots always suffice.
+int ovf_class(const ptk_tree* t, int s_lds) {
   const uint32_t need = 2 * t->max_depth + 2;
   if (need <= (uint32_t)s_lds + 64) return 0;
   if (need <= (uint32_t)s_lds + 256) return 1;
@@ -252,6 +250,13 @@ int allow_lds(K kernel, size_t bytes) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
   }
   return PTK_OK;
+}
+
+// Tuning knob for A/B measurements (tools/ab_knn1.py): selects among the compiled
+// geometries of the k = 1 kernel.  Unset = the default geometry.
+int env_int(const char* name, int fallback) {
+  const char* v = std::getenv(name);
+  return v ? std::atoi(v) : fallback;
 }
 
 bool want_reorder(const ptk_tree* t, uint64_t nq) {
@@ -308,64 +313,93 @@ int check_search(const ptk_tree* t, const void* q, uint64_t nq) {
 
 float inv_ratio(float e) { return 1.0f / e; }
 
-template <int S, int OVF>
+template <int S, int OVF, int BLOCK, int LEAFB>
+int launch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
+                ptk::Neighbor* d_out, hipStream_t s) {
+  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
+  const size_t smem = (size_t)S * BLOCK * 8;
+  int rc = allow_lds(ptk::knn1_kernel<S, OVF, BLOCK, LEAFB>, smem);
+  if (rc != PTK_OK) return rc;
+  Timer timer(t, s);
+  hipLaunchKernelGGL((ptk::knn1_kernel<S, OVF, BLOCK, LEAFB>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q,
+                     t->dim, perm, nq, inv_ratio(e), d_out);
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
+template <int S, int OVF, int BLOCK, int LEAFB>
 int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
                ptk::Neighbor* d_out, hipStream_t s) {
-  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
-  const size_t stack_bytes = (size_t)S * ptk::kBlock * 8;
-  const float e_inv = inv_ratio(e);
+  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
+  const size_t stack_bytes = (size_t)S * BLOCK * 8;
+  const size_t list_bytes = (size_t)k * BLOCK * 8;
+  // The k-list goes to LDS while a block stays under 1/4 of a CU's 160 KiB.
+  const bool list_lds = stack_bytes + list_bytes <= 40 * 1024;
   Timer timer(t, s);
-  if (k == 1) {
-    int rc = allow_lds(ptk::knn1_kernel<S, OVF>, stack_bytes);
-    if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::knn1_kernel<S, OVF>), dim3(blocks), dim3(ptk::kBlock), stack_bytes, s, t->dev, d_q,
-                       t->dim, perm, nq, e_inv, d_out);
+  if (list_lds) {
+    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, true>), dim3(blocks), dim3(BLOCK),
+                       stack_bytes + list_bytes, s, t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out);
   } else {
-    const size_t list_bytes = (size_t)k * ptk::kBlock * 8;
-    const bool list_lds = stack_bytes + list_bytes <= 80 * 1024;  // keeps two blocks per CU
-    if (list_lds) {
-      const size_t smem = stack_bytes + list_bytes;
-      int rc = allow_lds(ptk::knn_kernel<S, OVF, true>, smem);
-      if (rc != PTK_OK) return rc;
-      hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, true>), dim3(blocks), dim3(ptk::kBlock), smem, s, t->dev, d_q,
-                         t->dim, perm, nq, k, e_inv, d_out);
-    } else {
-      hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, false>), dim3(blocks), dim3(ptk::kBlock), stack_bytes, s,
-                         t->dev, d_q, t->dim, perm, nq, k, e_inv, d_out);
-    }
+    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, false>), dim3(blocks), dim3(BLOCK), stack_bytes, s,
+                       t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out);
   }
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
   return PTK_OK;
 }
 
-template <int S, int OVF>
+template <int S, int OVF, int BLOCK, int LEAFB>
 int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
                   bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out,
                   hipStream_t s) {
-  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
-  const size_t smem = (size_t)S * ptk::kBlock * 8;
-  const float e_inv = inv_ratio(e);
+  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
+  const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
   if (!fill) {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, false>), dim3(blocks), dim3(ptk::kBlock), smem, s, t->dev, d_q,
-                       t->dim, perm, nq, radius, e_inv, d_counts, d_offsets, d_out);
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, false>), dim3(blocks), dim3(BLOCK), smem, s,
+                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
   } else {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, true>), dim3(blocks), dim3(ptk::kBlock), smem, s, t->dev, d_q,
-                       t->dim, perm, nq, radius, e_inv, d_counts, d_offsets, d_out);
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true>), dim3(blocks), dim3(BLOCK), smem, s,
+                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
   }
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
   return PTK_OK;
 }
 
-#define PTK_DISPATCH_VARIANT(SLDS, variant, CALL)                                                        \
-  switch (variant) {                                                                                     \
-    case 0: { constexpr int S = SLDS, OVF = 64; rc = CALL; } break;                                      \
-    case 1: { constexpr int S = SLDS, OVF = 256; rc = CALL; } break;                                     \
-    case 2: { constexpr int S = SLDS, OVF = 2048; rc = CALL; } break;                                    \
+// Runs CALL with OVF bound to the spill capacity the tree's depth needs.
+#define PTK_WITH_OVF(SLDS, CALL)                                                                            \
+  switch (ovf_class(t, SLDS)) {                                                                             \
+    case 0: { constexpr int OVF = 64; rc = CALL; } break;                                                   \
+    case 1: { constexpr int OVF = 256; rc = CALL; } break;                                                  \
+    case 2: { constexpr int OVF = 2048; rc = CALL; } break;                                                 \
     default: rc = fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth); \
   }
+
+// k = 1 geometries.  Variant 0 is the default; the others exist for A/B runs and
+// only for the shallow spill class (OVF = 64).
+int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
+                  ptk::Neighbor* d_out, hipStream_t s) {
+  const int variant = env_int("PTK_KNN1_VARIANT", 0);
+  int rc = PTK_OK;
+  if (variant != 0 && ovf_class(t, 8) == 0) {
+    switch (variant) {
+      case 1: return launch_knn1<32, 64, 256, 1>(t, d_q, perm, nq, e, d_out, s);
+      case 2: return launch_knn1<32, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 3: return launch_knn1<16, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 4: return launch_knn1<16, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 5: return launch_knn1<8, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 6: return launch_knn1<16, 64, 64, 8>(t, d_q, perm, nq, e, d_out, s);
+      case 7: return launch_knn1<8, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 8: return launch_knn1<32, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 9: return launch_knn1<8, 64, 64, 8>(t, d_q, perm, nq, e, d_out, s);
+      default: break;
+    }
+  }
+  PTK_WITH_OVF(16, (launch_knn1<16, OVF, 64, 4>(t, d_q, perm, nq, e, d_out, s)));
+  return rc;
+}
 
 }  // namespace
 
@@ -504,11 +538,9 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
     if (rc != PTK_OK) return rc;
   }
   if (k == 1) {
-    const int variant = choose_variant(t, 32);
-    PTK_DISPATCH_VARIANT(32, variant, (launch_knn<S, OVF>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s);
   } else {
-    const int variant = choose_variant(t, 16);
-    PTK_DISPATCH_VARIANT(16, variant, (launch_knn<S, OVF>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
   }
   if (perm) (void)hipFreeAsync(perm, s);
   return rc;
@@ -560,9 +592,8 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     rc = make_permutation(t, d_q, nq, s, &perm);
     if (rc != PTK_OK) return rc;
   }
-  const int variant = choose_variant(t, 16);
-  PTK_DISPATCH_VARIANT(16, variant, (launch_radius<S, OVF>(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
-                                                           reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+  PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4>(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
+                                                  reinterpret_cast<ptk::Neighbor*>(d_out), s)));
   if (perm) (void)hipFreeAsync(perm, s);
   if (rc == PTK_OK && fill && sort) {
     Timer timer(t, s);

@@ -45,6 +45,7 @@ struct EncPoint {
 static_assert(sizeof(EncNode) == 16 && sizeof(EncPoint) == 16, "device record sizes");
 
 constexpr uint32_t kEncLeafBit = 0x80000000u;
+constexpr uint32_t kEncLeafPad = 8;  // readable records past the last point (== kLeafPad)
 
 struct TreeStats {
   uint64_t n_leaves = 0;
@@ -54,7 +55,7 @@ struct TreeStats {
 
 struct EncodedTree {
   std::vector<EncNode> nodes;   // at least one element (dummy when the root is a leaf)
-  std::vector<EncPoint> points; // n_points
+  std::vector<EncPoint> points; // n_points + kEncLeafPad (the tail repeats the last point)
   uint32_t root_ref = 0;
   uint32_t cbits = 0;
 };
@@ -153,7 +154,7 @@ inline std::string encode_tree(
     r.right_ref = ref_of(nd.right);
     out.nodes[branch_id[i]] = r;
   }
-  out.points.resize(n_points);
+  out.points.resize(n_points + kEncLeafPad);
   for (uint64_t pos = 0; pos < n_points; ++pos) {
     const int32_t idx = indices[pos];
     if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
@@ -165,6 +166,7 @@ inline std::string encode_tree(
     v.index = idx;
     out.points[pos] = v;
   }
+  for (uint32_t i = 0; i < kEncLeafPad; ++i) out.points[n_points + i] = out.points[n_points - 1];
   out.root_ref = ref_of(0);
   out.cbits = cbits;
   return std::string();

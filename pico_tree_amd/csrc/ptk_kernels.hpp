@@ -19,8 +19,12 @@
 //   distance    ((dx*dx + dy*dy) + dz*dz), from d = 0          metric.hpp:36-51
 //
 // Per-lane traversal state is {ref, nbd, off[3]} in registers plus one LIFO of
-// 8-byte records, the first S slots of which live in LDS ([slot][lane], so a
-// wave's access is always conflict-free) and the rest in private scratch:
+// 8-byte records.  The newest S records live in an LDS ring ([slot][lane], so a
+// wave's access is always conflict-free); when the ring is full its OLDEST
+// record is spilled to private scratch, and when it runs empty a batch of the
+// most recently spilled records is brought back with independent loads.  The
+// first descent pushes one record per level and almost all of them are discarded
+// unseen at the end of the query, so the shallow levels are what gets spilled:
 //
 //   pending  {meta = far-side | axis | parent branch, val = far box distance}
 //   undo_off {meta = UNDO | axis,                     val = previous off[axis]}
@@ -63,7 +67,8 @@ constexpr uint32_t kBranchIdxMask = 0x1FFFFFFFu;
 constexpr uint32_t kRecUndo = 0x80000000u;
 constexpr uint32_t kRecSide = 0x40000000u;  // pending: far child is the right one; undo: nbd
 constexpr uint32_t kRecIdxMask = 0x0FFFFFFFu;
-constexpr int kBlock = 256;
+constexpr int kBlock = 256;     // helper kernels (keys, row sort)
+constexpr int kLeafPad = 8;     // readable records past the last point (batched leaf loads)
 
 struct Neighbor {
   int32_t index;
@@ -77,30 +82,51 @@ __device__ __forceinline__ float sel3(uint32_t axis, float a0, float a1, float a
   return axis == 0 ? a0 : (axis == 1 ? a1 : a2);
 }
 
-// ---- record stack: S slots in LDS + OVF slots in private scratch ---------------
-template <int S, int OVF>
+// ---- record stack: ring of S slots in LDS + OVF spill slots in private scratch ----
+// Records are numbered 0, 1, 2, ... in push order.  [base, top) is resident in the
+// ring (record i at slot i mod S); [0, base) has been spilled (record i at
+// ovf[i]).  S is a power of two.
+template <int S, int OVF, int BLOCK>
 struct Stack {
-  uint2* lds;  // this lane's column: slot i at lds[i * kBlock]
+  static_assert((S & (S - 1)) == 0 && S >= 4, "S must be a power of two");
+  static constexpr int kRefill = S / 2 < 8 ? S / 2 : 8;
+  uint2* lds;  // this lane's column: slot i at lds[i * BLOCK]
   uint2 ovf[OVF > 0 ? OVF : 1];
-  int sp;
-  __device__ __forceinline__ void init(uint2* base, int tid) {
-    lds = base + tid;
-    sp = 0;
+  int top;
+  int base;
+  __device__ __forceinline__ void init(uint2* block_base, int tid) {
+    lds = block_base + tid;
+    top = 0;
+    base = 0;
   }
+  __device__ __forceinline__ bool empty() const { return top == 0; }
   __device__ __forceinline__ void push(uint32_t meta, float val) {
-    uint2 r = make_uint2(meta, __float_as_uint(val));
-    if (S > 0 && sp < S) {
-      lds[sp * kBlock] = r;
-    } else if (OVF > 0) {
-      ovf[sp - S] = r;
+    if (top - base == S) {  // ring full: spill the oldest resident record
+      if (OVF > 0) ovf[base] = lds[(base & (S - 1)) * BLOCK];
+      ++base;
     }
-    ++sp;
+    lds[(top & (S - 1)) * BLOCK] = make_uint2(meta, __float_as_uint(val));
+    ++top;
   }
   __device__ __forceinline__ uint2 pop() {
-    --sp;
-    if (S > 0 && sp < S) return lds[sp * kBlock];
-    if (OVF > 0) return ovf[sp - S];
-    return make_uint2(0, 0);
+    if (top == base) {  // ring empty, spilled records remain: refill a batch
+      if (OVF > 0) {
+        uint2 r[kRefill];
+#pragma unroll
+        for (int i = 0; i < kRefill; ++i) {
+          const int idx = base - 1 - i;
+          r[i] = ovf[idx >= 0 ? idx : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < kRefill; ++i) {
+          const int idx = base - 1 - i;
+          if (idx >= 0) lds[(idx & (S - 1)) * BLOCK] = r[i];
+        }
+      }
+      base = base > kRefill ? base - kRefill : 0;
+    }
+    --top;
+    return lds[(top & (S - 1)) * BLOCK];
   }
 };
 
@@ -178,7 +204,7 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
 };
 
 // ---- the traversal ----------------------------------------------------------------
-template <class Policy, class StackT>
+template <int LEAFB, class Policy, class StackT>
 __device__ __forceinline__ void traverse(
     const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st) {
   const uint4* __restrict__ nodes = t.nodes;
@@ -207,24 +233,33 @@ __device__ __forceinline__ void traverse(
       ref = go_left ? nd.z : nd.w;
     }
 
-    // Measure the leaf.
+    // Measure the leaf: LEAFB points are fetched per round trip with independent
+    // loads (the array is padded, so reading past the leaf is harmless), then
+    // visited strictly in index order.
     {
       const uint32_t lv = ref & 0x7FFFFFFFu;
       const uint32_t begin = lv >> t.cbits;
       const uint32_t count = lv & t.cmask;
-      for (uint32_t j = 0; j < count; ++j) {
-        const float4 p = pts[begin + j];
-        const float dx = f_sub(qx, p.x);
-        const float dy = f_sub(qy, p.y);
-        const float dz = f_sub(qz, p.z);
-        const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
-        pol.visit(__float_as_int(p.w), d);
+      for (uint32_t j = 0; j < count; j += LEAFB) {
+        float4 p[LEAFB];
+#pragma unroll
+        for (int u = 0; u < LEAFB; ++u) p[u] = pts[begin + j + u];
+#pragma unroll
+        for (int u = 0; u < LEAFB; ++u) {
+          if (j + u < count) {
+            const float dx = f_sub(qx, p[u].x);
+            const float dy = f_sub(qy, p[u].y);
+            const float dz = f_sub(qz, p[u].z);
+            const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
+            pol.visit(__float_as_int(p[u].w), d);
+          }
+        }
       }
     }
 
     // Back up to the next far child still worth entering.
     for (;;) {
-      if (st.sp == 0) return;
+      if (st.empty()) return;
       const uint2 r = st.pop();
       const float val = __uint_as_float(r.y);
       if (r.x & kRecUndo) {
@@ -280,24 +315,24 @@ __device__ __forceinline__ void load_query(
 extern __shared__ __attribute__((aligned(16))) unsigned char ptk_smem[];
 
 // ---- k = 1 ---------------------------------------------------------------------------
-template <int S, int OVF>
-__global__ __launch_bounds__(kBlock) void knn1_kernel(
+template <int S, int OVF, int BLOCK, int LEAFB>
+__global__ __launch_bounds__(BLOCK) void knn1_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float e_inv, Neighbor* __restrict__ out) {
   const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
-  const uint64_t i = (uint64_t)tile * kBlock + threadIdx.x;
+  const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
-  Stack<S, OVF> st;
+  Stack<S, OVF, BLOCK> st;
   st.init(reinterpret_cast<uint2*>(ptk_smem), threadIdx.x);
   NnPolicy pol;
   pol.best_d = 3.402823466e+38f;
   pol.best_i = 0;
   pol.e_inv = e_inv;
-  traverse(t, qx, qy, qz, pol, st);
+  traverse<LEAFB>(t, qx, qy, qz, pol, st);
 
   Neighbor nb;
   nb.index = pol.best_i;
@@ -308,24 +343,24 @@ __global__ __launch_bounds__(kBlock) void knn1_kernel(
 // ---- general k -------------------------------------------------------------------------
 // LIST_LDS: the k-list lives in LDS behind the stack ([slot][lane]) and is copied
 // to the output row at the end; otherwise the output row itself is the list.
-template <int S, int OVF, bool LIST_LDS>
-__global__ __launch_bounds__(kBlock) void knn_kernel(
+template <int S, int OVF, int BLOCK, int LEAFB, bool LIST_LDS>
+__global__ __launch_bounds__(BLOCK) void knn_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
     Neighbor* __restrict__ out) {
   const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
-  const uint64_t i = (uint64_t)tile * kBlock + threadIdx.x;
+  const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
-  Stack<S, OVF> st;
+  Stack<S, OVF, BLOCK> st;
   st.init(reinterpret_cast<uint2*>(ptk_smem), threadIdx.x);
   KnnPolicy pol;
   if (LIST_LDS) {
-    pol.list = reinterpret_cast<Neighbor*>(ptk_smem + (size_t)S * kBlock * 8) + threadIdx.x;
-    pol.stride = kBlock;
+    pol.list = reinterpret_cast<Neighbor*>(ptk_smem + (size_t)S * BLOCK * 8) + threadIdx.x;
+    pol.stride = BLOCK;
   } else {
     pol.list = out + qi * k;
     pol.stride = 1;
@@ -334,11 +369,11 @@ __global__ __launch_bounds__(kBlock) void knn_kernel(
   pol.filled = 0;
   pol.worst = 3.402823466e+38f;
   pol.e_inv = e_inv;
-  traverse(t, qx, qy, qz, pol, st);
+  traverse<LEAFB>(t, qx, qy, qz, pol, st);
 
   if (LIST_LDS) {
     Neighbor* row = out + qi * k;
-    for (uint32_t j = 0; j < pol.filled; ++j) row[j] = pol.list[j * kBlock];
+    for (uint32_t j = 0; j < pol.filled; ++j) row[j] = pol.list[j * BLOCK];
   }
   if (pol.filled < k) {  // k > reachable points: mirror the reference's sentinel (:102)
     Neighbor nb;
@@ -349,27 +384,27 @@ __global__ __launch_bounds__(kBlock) void knn_kernel(
 }
 
 // ---- radius: count pass and fill pass ------------------------------------------------------
-template <int S, int OVF, bool FILL>
-__global__ __launch_bounds__(kBlock) void radius_kernel(
+template <int S, int OVF, int BLOCK, int LEAFB, bool FILL>
+__global__ __launch_bounds__(BLOCK) void radius_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
     uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
     Neighbor* __restrict__ out) {
   const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
-  const uint64_t i = (uint64_t)tile * kBlock + threadIdx.x;
+  const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
-  Stack<S, OVF> st;
+  Stack<S, OVF, BLOCK> st;
   st.init(reinterpret_cast<uint2*>(ptk_smem), threadIdx.x);
   RadiusPolicy<FILL> pol;
   pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
   pol.e_inv = e_inv;
   pol.count = 0;
   pol.out = FILL ? out + offsets[qi] : nullptr;
-  traverse(t, qx, qy, qz, pol, st);
+  traverse<LEAFB>(t, qx, qy, qz, pol, st);
   if (!FILL) counts[qi] = pol.count;
 }
 

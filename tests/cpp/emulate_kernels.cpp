@@ -38,13 +38,13 @@ struct Emu {
 };
 
 template <typename F>
-void for_each_lane(uint64_t nq, F&& f) {
-  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+void for_each_lane(uint64_t nq, F&& f, uint32_t block = ptk::kBlock) {
+  const uint32_t blocks = (uint32_t)((nq + block - 1) / block);
   gridDim.x = blocks;
-  blockDim.x = ptk::kBlock;
+  blockDim.x = block;
   for (uint32_t b = 0; b < blocks; ++b) {
     blockIdx.x = b;
-    for (uint32_t t = 0; t < (uint32_t)ptk::kBlock; ++t) {
+    for (uint32_t t = 0; t < block; ++t) {
       threadIdx.x = t;
       f();
     }
@@ -80,26 +80,30 @@ void emu_destroy(void* h) { delete static_cast<Emu*>(h); }
 
 uint32_t emu_max_depth(void* h) { return static_cast<Emu*>(h)->st.max_depth; }
 
-// small_stack != 0 exercises the scratch-overflow path (S = 16 even for k = 1).
+// small_stack != 0 runs the smallest LDS ring (4 slots), so nearly every record
+// takes the spill / refill path; otherwise the shipped geometries are used.
 int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uint32_t* perm, int small_stack,
             int list_in_lds, ptk_neighbor* out) {
   auto* t = static_cast<Emu*>(h);
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
   const float e_inv = 1.0f / e;
   const uint32_t need = 2 * t->st.max_depth + 2;
-  if (need > 16 + 2048) return -2;
+  if (need > 4 + 2048) return -2;
   if (k == 1) {
     if (small_stack)
-      for_each_lane(nq, [&] { ptk::knn1_kernel<16, 2048>(t->dev, q, t->dim, perm, nq, e_inv, o); });
-    else if (need <= 32 + 64)
-      for_each_lane(nq, [&] { ptk::knn1_kernel<32, 64>(t->dev, q, t->dim, perm, nq, e_inv, o); });
+      for_each_lane(nq, [&] { ptk::knn1_kernel<4, 2048, 64, 1>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 64);
+    else if (need <= 16 + 64)
+      for_each_lane(nq, [&] { ptk::knn1_kernel<16, 64, 64, 4>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 64);
     else
-      for_each_lane(nq, [&] { ptk::knn1_kernel<32, 2048>(t->dev, q, t->dim, perm, nq, e_inv, o); });
+      for_each_lane(nq, [&] { ptk::knn1_kernel<32, 2048, 256, 8>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 256);
   } else if (list_in_lds) {
-    if ((size_t)(16 + k) * ptk::kBlock * 8 > sizeof(ptk::ptk_smem)) return -2;
-    for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, true>(t->dev, q, t->dim, perm, nq, k, e_inv, o); });
+    if ((size_t)(16 + k) * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
+    if (small_stack)
+      for_each_lane(nq, [&] { ptk::knn_kernel<4, 2048, 64, 4, true>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+    else
+      for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
   } else {
-    for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, false>(t->dev, q, t->dim, perm, nq, k, e_inv, o); });
+    for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, 256, 8, false>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 256);
   }
   return 0;
 }
@@ -109,8 +113,8 @@ int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e
   auto* t = static_cast<Emu*>(h);
   const float e_inv = 1.0f / e;
   for_each_lane(nq, [&] {
-    ptk::radius_kernel<16, 2048, false>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, nullptr, nullptr);
-  });
+    ptk::radius_kernel<8, 2048, 64, 4, false>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, nullptr, nullptr);
+  }, 64);
   return 0;
 }
 
@@ -120,8 +124,8 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
   const float e_inv = 1.0f / e;
   for_each_lane(nq, [&] {
-    ptk::radius_kernel<16, 2048, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o);
-  });
+    ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o);
+  }, 64);
   if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
   return 0;
 }

@@ -1,0 +1,87 @@
+"""ctypes facade over tests/cpp/libptk_emu.so: the product's kernel source
+(pico_tree_amd/csrc/ptk_kernels.hpp) compiled for the host and run lane by lane."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_uint32, c_uint64, c_void_p
+
+import numpy as np
+
+import pico_tree_amd as pt
+
+_LIB = os.path.join(os.path.dirname(os.path.abspath(__file__)), "cpp", "libptk_emu.so")
+
+
+def _lib():
+    lib = ctypes.CDLL(_LIB)
+    lib.emu_create.restype = c_void_p
+    lib.emu_create.argtypes = [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_void_p]
+    lib.emu_destroy.argtypes = [c_void_p]
+    lib.emu_last_error.restype = c_char_p
+    lib.emu_max_depth.restype = c_uint32
+    lib.emu_max_depth.argtypes = [c_void_p]
+    lib.emu_knn.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p, c_int, c_int, c_void_p]
+    lib.emu_radius_count.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_void_p]
+    lib.emu_radius_fill.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_void_p,
+                                    c_void_p, c_int]
+    lib.emu_morton.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
+    return lib
+
+
+class EmulatedTree:
+    """Builds the flat tree with the PRODUCT builder (host-only libptk handle),
+    encodes it with the product encoder and runs the product kernels on the CPU."""
+
+    def __init__(self, pts, leaf):
+        self.lib = _lib()
+        self.pts = np.ascontiguousarray(pts, dtype=np.float32)
+        self.host = pt.KdTree(self.pts, pt.Metric.L2Squared, leaf, device=pt.PTK_DEVICE_NONE)
+        nodes, idx, self.rmin, self.rmax = self.host.flat()
+        self.h = self.lib.emu_create(self.pts.ctypes.data, len(self.pts), self.pts.shape[1],
+                                     nodes.ctypes.data, len(nodes), idx.ctypes.data)
+        if not self.h:
+            raise RuntimeError(self.lib.emu_last_error().decode())
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.emu_destroy(self.h)
+            self.h = None
+
+    def search_knn(self, q, k, e=None, perm=None, small_stack=False, list_in_lds=True):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.zeros((len(q), k), dtype=pt.NEIGHBOR)
+        rc = self.lib.emu_knn(self.h, q.ctypes.data, len(q), k, e or 1.0,
+                              perm.ctypes.data if perm is not None else None,
+                              int(small_stack), int(list_in_lds), out.ctypes.data)
+        assert rc == 0
+        return out
+
+    def search_radius(self, q, radius, sort=False, e=None, perm=None):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        nq = len(q)
+        p = perm.ctypes.data if perm is not None else None
+        counts = np.zeros(nq + 1, dtype=np.uint64)
+        self.lib.emu_radius_count(self.h, q.ctypes.data, nq, radius, e or 1.0, p, counts.ctypes.data)
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(counts[:nq])
+        out = np.zeros(int(off[-1]), dtype=pt.NEIGHBOR)
+        self.lib.emu_radius_fill(self.h, q.ctypes.data, nq, radius, e or 1.0, p, off.ctypes.data,
+                                 out.ctypes.data, int(sort))
+        return off, out
+
+    def morton_permutation(self, q):
+        """The permutation the device would use (keys from the kernel, stable sort)."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        lo = np.zeros(3, dtype=np.float32)
+        inv = np.zeros(3, dtype=np.float32)
+        d = self.pts.shape[1]
+        lo[:d] = self.rmin
+        ext = self.rmax - self.rmin
+        inv[:d] = np.where(ext > 0, np.float32(1024.0) / ext, 0).astype(np.float32)
+        keys = np.zeros(len(q), dtype=np.uint32)
+        ids = np.zeros(len(q), dtype=np.uint32)
+        self.lib.emu_morton(q.ctypes.data, d, len(q), lo.ctypes.data, inv.ctypes.data,
+                            keys.ctypes.data, ids.ctypes.data)
+        return ids[np.argsort(keys, kind="stable")].astype(np.uint32), keys
