@@ -109,6 +109,7 @@ struct visit_counters {
   std::uint32_t n_branch = 0;
   std::uint32_t n_leaf = 0;
   std::uint32_t n_pts = 0;
+  std::uint32_t n_first = 0;  // branches passed before the first leaf (depth of the home leaf)
 };
 
 struct tree_t {
@@ -296,7 +297,10 @@ struct nearest_search {
 
   void descend(node_t const* node, float node_box_distance) {
     if (node->is_leaf()) {  // :54-59
-      if (counters) ++counters->n_leaf;
+      if (counters) {
+        if (counters->n_leaf == 0) counters->n_first = counters->n_branch;
+        ++counters->n_leaf;
+      }
       for (int i = node->data.leaf.begin_idx; i < node->data.leaf.end_idx; ++i) {
         int const idx = tree.indices[static_cast<size_t>(i)];
         if (counters) ++counters->n_pts;
@@ -503,8 +507,8 @@ void ptkor_set_threads(int threads) {
 int ptkor_max_threads() { return omp_get_max_threads(); }
 
 // kd_tree::search_nn over a batch (kd_tree.hpp:126-129,155-159); approx != 0
-// selects the approximate visitor with ratio e.  counters: optional nq x 3
-// uint32 {n_branch, n_leaf, n_pts}.
+// selects the approximate visitor with ratio e.  counters: optional nq x 4
+// uint32 {n_branch, n_leaf, n_pts, n_first}.
 void ptkor_search_nn(void* handle, float const* q, size_t nq, int approx,
                      float e, void* out, std::uint32_t* counters) {
   auto* t = static_cast<tree_t*>(handle);
@@ -518,9 +522,10 @@ void ptkor_search_nn(void* handle, float const* q, size_t nq, int approx,
                                counters ? &c : nullptr);
     s.run();
     if (counters) {
-      counters[3 * i + 0] = c.n_branch;
-      counters[3 * i + 1] = c.n_leaf;
-      counters[3 * i + 2] = c.n_pts;
+      counters[4 * i + 0] = c.n_branch;
+      counters[4 * i + 1] = c.n_leaf;
+      counters[4 * i + 2] = c.n_pts;
+      counters[4 * i + 3] = c.n_first;
     }
   }
 }
@@ -543,9 +548,10 @@ void ptkor_search_knn(void* handle, float const* q, size_t nq, size_t k,
     nearest_search<visit_knn> s(*t, q + ui * t->dim, v, counters ? &c : nullptr);
     s.run();
     if (counters) {
-      counters[3 * ui + 0] = c.n_branch;
-      counters[3 * ui + 1] = c.n_leaf;
-      counters[3 * ui + 2] = c.n_pts;
+      counters[4 * ui + 0] = c.n_branch;
+      counters[4 * ui + 1] = c.n_leaf;
+      counters[4 * ui + 2] = c.n_pts;
+      counters[4 * ui + 3] = c.n_first;
     }
   }
 }
@@ -575,9 +581,10 @@ void* ptkor_search_radius(void* handle, float const* q, size_t nq, float radius,
                 });
     }
     if (counters) {
-      counters[3 * ui + 0] = c.n_branch;
-      counters[3 * ui + 1] = c.n_leaf;
-      counters[3 * ui + 2] = c.n_pts;
+      counters[4 * ui + 0] = c.n_branch;
+      counters[4 * ui + 1] = c.n_leaf;
+      counters[4 * ui + 2] = c.n_pts;
+      counters[4 * ui + 3] = c.n_first;
     }
   }
   std::uint64_t acc = 0;

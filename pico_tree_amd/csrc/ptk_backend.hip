@@ -317,7 +317,8 @@ template <int S, int OVF, int BLOCK, int LEAFB>
 int launch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                 ptk::Neighbor* d_out, hipStream_t s) {
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  const size_t smem = (size_t)S * BLOCK * 8;
+  // PTK_EXTRA_LDS (bytes): occupancy experiments only -- reserves unused LDS per block.
+  const size_t smem = (size_t)S * BLOCK * 8 + (size_t)env_int("PTK_EXTRA_LDS", 0);
   int rc = allow_lds(ptk::knn1_kernel<S, OVF, BLOCK, LEAFB>, smem);
   if (rc != PTK_OK) return rc;
   Timer timer(t, s);
@@ -368,6 +369,96 @@ int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   return PTK_OK;
 }
 
+// Packs the batch as {x, y, z, bits(index)} records in launch order (perm or identity)
+// for the persistent kernels.  The caller frees *qs with hipFreeAsync.
+int pack_queries(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, hipStream_t s,
+                 float4** qs) {
+  *qs = nullptr;
+  if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
+  Timer timer(t, s);
+  PTK_HIP(hipMallocAsync((void**)qs, nq * sizeof(float4), s));
+  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+  hipLaunchKernelGGL(ptk::pack_queries_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, perm, nq, *qs);
+  PTK_HIP(hipGetLastError());
+  timer.stop(1, 0);
+  return PTK_OK;
+}
+
+uint32_t chunk_size() {
+  const int c = env_int("PTK_CHUNK", 1024);
+  return (uint32_t)(c < 64 ? 64 : c);
+}
+
+template <int S, int OVF, int LEAFB>
+int launch_knn1_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
+                           ptk::Neighbor* d_out, hipStream_t s) {
+  float4* qs = nullptr;
+  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  if (rc != PTK_OK) return rc;
+  const uint32_t chunk = chunk_size();
+  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
+  const size_t smem = (size_t)S * 64 * 8 + (size_t)env_int("PTK_EXTRA_LDS", 0);
+  rc = allow_lds(ptk::knn1_persistent_kernel<S, OVF, LEAFB>, smem);
+  if (rc == PTK_OK) {
+    Timer timer(t, s);
+    hipLaunchKernelGGL((ptk::knn1_persistent_kernel<S, OVF, LEAFB>), dim3(blocks), dim3(64), smem, s, t->dev, qs,
+                       nq, chunk, inv_ratio(e), d_out);
+    if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
+    timer.stop(0, nq);
+  }
+  (void)hipFreeAsync(qs, s);
+  return rc;
+}
+
+template <int S, int OVF, int LEAFB>
+int launch_knn_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k,
+                          float e, ptk::Neighbor* d_out, hipStream_t s) {
+  float4* qs = nullptr;
+  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  if (rc != PTK_OK) return rc;
+  const uint32_t chunk = chunk_size();
+  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
+  const size_t stack_bytes = (size_t)S * 64 * 8;
+  const size_t list_bytes = (size_t)k * 64 * 8;
+  const bool list_lds = stack_bytes + list_bytes <= 40 * 1024;  // <= 1/4 of a CU's LDS per wave
+  Timer timer(t, s);
+  if (list_lds) {
+    hipLaunchKernelGGL((ptk::knn_persistent_kernel<S, OVF, LEAFB, true>), dim3(blocks), dim3(64),
+                       stack_bytes + list_bytes, s, t->dev, qs, nq, chunk, k, inv_ratio(e), d_out);
+  } else {
+    hipLaunchKernelGGL((ptk::knn_persistent_kernel<S, OVF, LEAFB, false>), dim3(blocks), dim3(64), stack_bytes, s,
+                       t->dev, qs, nq, chunk, k, inv_ratio(e), d_out);
+  }
+  if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
+  timer.stop(0, nq);
+  (void)hipFreeAsync(qs, s);
+  return rc;
+}
+
+template <int S, int OVF, int LEAFB>
+int launch_radius_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
+                             float e, bool fill, uint64_t* d_counts, const uint64_t* d_offsets,
+                             ptk::Neighbor* d_out, hipStream_t s) {
+  float4* qs = nullptr;
+  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  if (rc != PTK_OK) return rc;
+  const uint32_t chunk = chunk_size();
+  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
+  const size_t smem = (size_t)S * 64 * 8;
+  Timer timer(t, s);
+  if (!fill) {
+    hipLaunchKernelGGL((ptk::radius_persistent_kernel<S, OVF, LEAFB, false>), dim3(blocks), dim3(64), smem, s,
+                       t->dev, qs, nq, chunk, radius, inv_ratio(e), d_counts, d_offsets, d_out);
+  } else {
+    hipLaunchKernelGGL((ptk::radius_persistent_kernel<S, OVF, LEAFB, true>), dim3(blocks), dim3(64), smem, s,
+                       t->dev, qs, nq, chunk, radius, inv_ratio(e), d_counts, d_offsets, d_out);
+  }
+  if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
+  timer.stop(0, nq);
+  (void)hipFreeAsync(qs, s);
+  return rc;
+}
+
 // Runs CALL with OVF bound to the spill capacity the tree's depth needs.
 #define PTK_WITH_OVF(SLDS, CALL)                                                                            \
   switch (ovf_class(t, SLDS)) {                                                                             \
@@ -394,6 +485,11 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
       case 7: return launch_knn1<8, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
       case 8: return launch_knn1<32, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
       case 9: return launch_knn1<8, 64, 64, 8>(t, d_q, perm, nq, e, d_out, s);
+      case 10: return launch_knn1_persistent<32, 64, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 11: return launch_knn1_persistent<16, 64, 4>(t, d_q, perm, nq, e, d_out, s);
+      case 12: return launch_knn1_persistent<32, 64, 8>(t, d_q, perm, nq, e, d_out, s);
+      case 13: return launch_knn1_persistent<32, 64, 2>(t, d_q, perm, nq, e, d_out, s);
+      case 14: return launch_knn1_persistent<16, 64, 8>(t, d_q, perm, nq, e, d_out, s);
       default: break;
     }
   }

@@ -44,6 +44,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 namespace ptk {
 
 // ---- device tree --------------------------------------------------------------
@@ -75,6 +77,36 @@ struct Neighbor {
   float distance;
 };
 
+// LDS pointers carry their address space explicitly so that every stack / k-list access
+// is a ds_read / ds_write; a generic pointer makes hipcc fall back to flat_* accesses,
+// which go through the vector-memory pipe and cost hundreds of cycles each.
+#define PTK_LDS __attribute__((address_space(3)))
+// (C++ copy-assignment of class types is not defined across address spaces, so LDS
+// slots are plain 64-bit words: one ds_write_b64 / ds_read_b64 each.)
+typedef PTK_LDS unsigned long long LdsWord;
+struct Record {  // one stack entry: {meta, float bits}
+  uint32_t x;
+  uint32_t y;
+};
+__device__ __forceinline__ unsigned long long pack_record(Record r) {
+  return (unsigned long long)r.x | ((unsigned long long)r.y << 32);
+}
+__device__ __forceinline__ Record unpack_record(unsigned long long w) {
+  Record r;
+  r.x = (uint32_t)w;
+  r.y = (uint32_t)(w >> 32);
+  return r;
+}
+__device__ __forceinline__ unsigned long long pack_neighbor(Neighbor n) {
+  return (unsigned long long)(uint32_t)n.index | ((unsigned long long)__float_as_uint(n.distance) << 32);
+}
+__device__ __forceinline__ Neighbor unpack_neighbor(unsigned long long w) {
+  Neighbor n;
+  n.index = (int32_t)(uint32_t)w;
+  n.distance = __uint_as_float((uint32_t)(w >> 32));
+  return n;
+}
+
 __device__ __forceinline__ float f_add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float f_sub(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float f_mul(float a, float b) { return __fmul_rn(a, b); }
@@ -90,28 +122,34 @@ template <int S, int OVF, int BLOCK>
 struct Stack {
   static_assert((S & (S - 1)) == 0 && S >= 4, "S must be a power of two");
   static constexpr int kRefill = S / 2 < 8 ? S / 2 : 8;
-  uint2* lds;  // this lane's column: slot i at lds[i * BLOCK]
-  uint2 ovf[OVF > 0 ? OVF : 1];
+  // The spill array is owned by the kernel body and only referenced here: if it were
+  // a member, the whole struct (top and base included) would live in scratch memory.
+  LdsWord* lds;  // this lane's column: slot i at lds[i * BLOCK]
+  Record* ovf;   // OVF private-scratch slots
   int top;
   int base;
-  __device__ __forceinline__ void init(uint2* block_base, int tid) {
+  __device__ __forceinline__ void init(LdsWord* block_base, int tid, Record* spill) {
     lds = block_base + tid;
+    ovf = spill;
     top = 0;
     base = 0;
   }
   __device__ __forceinline__ bool empty() const { return top == 0; }
   __device__ __forceinline__ void push(uint32_t meta, float val) {
     if (top - base == S) {  // ring full: spill the oldest resident record
-      if (OVF > 0) ovf[base] = lds[(base & (S - 1)) * BLOCK];
+      if (OVF > 0) ovf[base] = unpack_record(lds[(base & (S - 1)) * BLOCK]);
       ++base;
     }
-    lds[(top & (S - 1)) * BLOCK] = make_uint2(meta, __float_as_uint(val));
+    Record rec;
+    rec.x = meta;
+    rec.y = __float_as_uint(val);
+    lds[(top & (S - 1)) * BLOCK] = pack_record(rec);
     ++top;
   }
-  __device__ __forceinline__ uint2 pop() {
+  __device__ __forceinline__ Record pop() {
     if (top == base) {  // ring empty, spilled records remain: refill a batch
       if (OVF > 0) {
-        uint2 r[kRefill];
+        Record r[kRefill];
 #pragma unroll
         for (int i = 0; i < kRefill; ++i) {
           const int idx = base - 1 - i;
@@ -120,13 +158,13 @@ struct Stack {
 #pragma unroll
         for (int i = 0; i < kRefill; ++i) {
           const int idx = base - 1 - i;
-          if (idx >= 0) lds[(idx & (S - 1)) * BLOCK] = r[i];
+          if (idx >= 0) lds[(idx & (S - 1)) * BLOCK] = pack_record(r[i]);
         }
       }
       base = base > kRefill ? base - kRefill : 0;
     }
     --top;
-    return lds[(top & (S - 1)) * BLOCK];
+    return unpack_record(lds[(top & (S - 1)) * BLOCK]);
   }
 };
 
@@ -142,6 +180,17 @@ struct NnPolicy {  // search_visitor.hpp:42-65 / :165-193
   float best_d;
   int32_t best_i;
   float e_inv;
+  Neighbor* out;  // persistent kernels: result rows, indexed by original query
+  __device__ __forceinline__ void begin_query(uint32_t) {
+    best_d = 3.402823466e+38f;
+    best_i = 0;
+  }
+  __device__ __forceinline__ void end_query(uint32_t qi) {
+    Neighbor nb;
+    nb.index = best_i;
+    nb.distance = best_d;
+    out[qi] = nb;
+  }
   __device__ __forceinline__ float max() const { return best_d; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
@@ -152,14 +201,48 @@ struct NnPolicy {  // search_visitor.hpp:42-65 / :165-193
   }
 };
 
-// Sorted k-list, slot j of this lane at list[j * stride]; LDS or global memory.
+// Sorted k-list, slot j of this lane at list[j * stride]; in LDS, or the output row itself.
+template <bool LIST_LDS>
 struct KnnPolicy {  // search_visitor.hpp:83-123 / :198-247
-  Neighbor* list;
+  using ListPtr = typename std::conditional<LIST_LDS, LdsWord*, Neighbor*>::type;
+  ListPtr list;
+  __device__ __forceinline__ Neighbor get(uint32_t j) const {
+    if constexpr (LIST_LDS) {
+      return unpack_neighbor(list[j * stride]);
+    } else {
+      return list[j * stride];
+    }
+  }
+  __device__ __forceinline__ void put(uint32_t j, Neighbor n) {
+    if constexpr (LIST_LDS) {
+      list[j * stride] = pack_neighbor(n);
+    } else {
+      list[j * stride] = n;
+    }
+  }
   uint32_t stride;
   uint32_t k;
   uint32_t filled;
   float worst;  // == max(): FLT_MAX until the list is full, then the k-th distance
   float e_inv;
+  Neighbor* out;      // persistent kernels: all result rows
+  __device__ __forceinline__ void begin_query(uint32_t qi) {
+    filled = 0;
+    worst = 3.402823466e+38f;
+    if constexpr (!LIST_LDS) list = out + (uint64_t)qi * k;
+  }
+  __device__ __forceinline__ void end_query(uint32_t qi) {
+    Neighbor* row = out + (uint64_t)qi * k;
+    if constexpr (LIST_LDS) {
+      for (uint32_t j = 0; j < filled; ++j) row[j] = get(j);
+    }
+    if (filled < k) {  // fewer reachable points than k: the reference's sentinel (:102)
+      Neighbor nb;
+      nb.index = 0;
+      nb.distance = 3.402823466e+38f;
+      row[k - 1] = nb;
+    }
+  }
   __device__ __forceinline__ float max() const { return worst; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
@@ -168,16 +251,16 @@ struct KnnPolicy {  // search_visitor.hpp:83-123 / :198-247
       uint32_t j = filled - 1;
       // insert_sorted (:24-38): shift while strictly smaller => stable on ties.
       while (j > 0) {
-        Neighbor prev = list[(j - 1) * stride];
+        Neighbor prev = get(j - 1);
         if (!(d < prev.distance)) break;
-        list[j * stride] = prev;
+        put(j, prev);
         --j;
       }
       Neighbor nb;
       nb.index = idx;
       nb.distance = d;
-      list[j * stride] = nb;
-      if (filled == k) worst = list[(k - 1) * stride].distance;
+      put(j, nb);
+      if (filled == k) worst = get(k - 1).distance;
     }
   }
 };
@@ -188,6 +271,17 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
   float e_inv;
   uint64_t count;
   Neighbor* out;  // FILL: first record of this query's row
+  // persistent kernels
+  uint64_t* counts;
+  const uint64_t* offsets;
+  Neighbor* rows;
+  __device__ __forceinline__ void begin_query(uint32_t qi) {
+    count = 0;
+    if (FILL) out = rows + offsets[qi];
+  }
+  __device__ __forceinline__ void end_query(uint32_t qi) {
+    if (!FILL) counts[qi] = count;
+  }
   __device__ __forceinline__ float max() const { return radius; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
@@ -260,7 +354,7 @@ __device__ __forceinline__ void traverse(
     // Back up to the next far child still worth entering.
     for (;;) {
       if (st.empty()) return;
-      const uint2 r = st.pop();
+      const Record r = st.pop();
       const float val = __uint_as_float(r.y);
       if (r.x & kRecUndo) {
         if (r.x & kRecSide) {
@@ -289,6 +383,166 @@ __device__ __forceinline__ void traverse(
         nbd = val;
         ref = far_is_right ? nd.w : nd.z;
         break;
+      }
+    }
+  }
+}
+
+// ---- the persistent traversal machine -----------------------------------------------
+//
+// The loop above lets a wavefront idle while its slowest lane finishes: measured on
+// the LiDAR-like cloud, the deepest lane of a wave needs 1.6x (uniform cloud 2.2x)
+// the branch steps of the average lane, and a few queries need 20x.  Here a
+// wavefront is persistent instead: it owns a contiguous chunk of the (spatially
+// sorted) batch and every lane runs the same per-query state machine,
+//
+//     FETCH  -> load the next query of the chunk, start at the root
+//     NODE   -> one branch step (or entering a far child: re-read the parent)
+//     LEAF   -> measure up to LEAFB points; after the last batch, unwind the
+//               record stack (LDS only) to the next far child or finish
+//
+// one state transition per loop iteration, with exactly ONE global-memory round
+// trip per iteration for the whole wave: all loads of an iteration (query, node
+// or point batch, per lane) are issued before any of them is consumed.  A lane
+// that finishes its query takes the next one immediately (ballot + prefix count),
+// so lanes stay busy until the chunk is exhausted.  Each lane still replays its
+// own reference visit order, so results are unchanged.
+template <int LEAFB, class Policy, class StackT>
+__device__ __forceinline__ void run_machine(
+    const DevTree& t, const float4* __restrict__ qs, uint64_t first, uint64_t last, Policy& pol,
+    StackT& st) {
+  const uint4* __restrict__ nodes = t.nodes;
+  const float4* __restrict__ pts = t.pts;
+  const uint64_t lanes_below = (1ull << (threadIdx.x & 63u)) - 1ull;
+
+  uint64_t next = first;  // wave-uniform: first query of the chunk nobody has taken yet
+  bool active = false;
+  bool far_entry = false;
+  uint32_t far_meta = 0;
+  float far_val = 0.0f;
+  uint32_t ref = 0, leaf_j = 0, qi = 0;
+  float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
+  float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+
+  for (;;) {
+    // Hand the next queries of the chunk to the idle lanes.
+    const uint64_t idle = __ballot(!active);
+    bool fetch = false;
+    uint64_t mine = 0;
+    if (idle != 0) {
+      if (next < last) {
+        mine = next + (uint64_t)__popcll(idle & lanes_below);
+        fetch = !active && mine < last;
+        next += (uint64_t)__popcll(idle);
+      } else if (idle == ~0ull) {
+        break;
+      }
+    }
+
+    // Issue this iteration's loads.
+    const bool at_leaf = active && !far_entry && (ref & kLeafBit) != 0;
+    const bool at_node = active && !at_leaf;
+    const uint32_t lv = ref & 0x7FFFFFFFu;
+    const uint32_t begin = lv >> t.cbits;
+    const uint32_t count = lv & t.cmask;
+    const uint32_t node_idx = far_entry ? (far_meta & kRecIdxMask) : (ref & kBranchIdxMask);
+    // Query, node and point records are all 16 bytes: one address per lane.
+    const uint4* addr = fetch ? reinterpret_cast<const uint4*>(qs + mine)
+                              : (at_leaf ? reinterpret_cast<const uint4*>(pts + (begin + leaf_j))
+                                         : nodes + node_idx);
+    uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
+    uint4 rp[LEAFB > 1 ? LEAFB - 1 : 1];
+    if (fetch || active) r0 = *addr;
+    if (at_leaf) {
+#pragma unroll
+      for (int u = 1; u < LEAFB; ++u) rp[u - 1] = addr[u];
+    }
+
+    if (fetch) {
+      qx = __uint_as_float(r0.x);
+      qy = __uint_as_float(r0.y);
+      qz = __uint_as_float(r0.z);
+      qi = r0.w;
+      pol.begin_query(qi);
+      st.top = 0;
+      st.base = 0;
+      nbd = off0 = off1 = off2 = 0.0f;
+      ref = t.root_ref;
+      leaf_j = 0;
+      far_entry = false;
+      active = true;
+    } else if (at_node) {
+      const float left_max = __uint_as_float(r0.x);
+      const float right_min = __uint_as_float(r0.y);
+      if (!far_entry) {
+        const uint32_t axis = (ref >> 29) & 3u;
+        const float v = sel3(axis, qx, qy, qz);
+        const float s = f_sub(f_sub(f_add(left_max, right_min), v), v);
+        const bool go_left = s > 0.0f;
+        const float plane = go_left ? right_min : left_max;
+        const float dv = f_sub(plane, v);
+        const float new_off = f_mul(dv, dv);
+        const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
+        if (pol.max() >= far_nbd) {
+          st.push(node_idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
+        }
+        ref = go_left ? r0.z : r0.w;
+      } else {
+        const uint32_t axis = (far_meta >> 28) & 3u;
+        const bool far_is_right = (far_meta & kRecSide) != 0;
+        const float plane = far_is_right ? right_min : left_max;
+        const float dv = f_sub(plane, sel3(axis, qx, qy, qz));
+        const float new_off = f_mul(dv, dv);
+        st.push(kRecUndo | (axis << 28), sel3(axis, off0, off1, off2));
+        st.push(kRecUndo | kRecSide, nbd);
+        off0 = axis == 0 ? new_off : off0;
+        off1 = axis == 1 ? new_off : off1;
+        off2 = axis == 2 ? new_off : off2;
+        nbd = far_val;
+        ref = far_is_right ? r0.w : r0.z;
+        far_entry = false;
+      }
+      leaf_j = 0;
+    } else if (at_leaf) {
+#pragma unroll
+      for (int u = 0; u < LEAFB; ++u) {
+        const uint4 p = u == 0 ? r0 : rp[u > 0 ? u - 1 : 0];
+        if (leaf_j + u < count) {
+          const float dx = f_sub(qx, __uint_as_float(p.x));
+          const float dy = f_sub(qy, __uint_as_float(p.y));
+          const float dz = f_sub(qz, __uint_as_float(p.z));
+          const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
+          pol.visit((int32_t)p.w, d);
+        }
+      }
+      leaf_j += LEAFB;
+      if (leaf_j >= count) {  // leaf done: unwind to the next far child worth entering
+        for (;;) {
+          if (st.empty()) {
+            pol.end_query(qi);
+            active = false;
+            break;
+          }
+          const Record r = st.pop();
+          const float val = __uint_as_float(r.y);
+          if (r.x & kRecUndo) {
+            if (r.x & kRecSide) {
+              nbd = val;
+            } else {
+              const uint32_t axis = (r.x >> 28) & 3u;
+              off0 = axis == 0 ? val : off0;
+              off1 = axis == 1 ? val : off1;
+              off2 = axis == 2 ? val : off2;
+            }
+            continue;
+          }
+          if (pol.max() >= val) {
+            far_entry = true;
+            far_meta = r.x;
+            far_val = val;
+            break;
+          }
+        }
       }
     }
   }
@@ -326,8 +580,9 @@ __global__ __launch_bounds__(BLOCK) void knn1_kernel(
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
+  Record spill[OVF > 0 ? OVF : 1];
   Stack<S, OVF, BLOCK> st;
-  st.init(reinterpret_cast<uint2*>(ptk_smem), threadIdx.x);
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
   NnPolicy pol;
   pol.best_d = 3.402823466e+38f;
   pol.best_i = 0;
@@ -355,11 +610,12 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
+  Record spill[OVF > 0 ? OVF : 1];
   Stack<S, OVF, BLOCK> st;
-  st.init(reinterpret_cast<uint2*>(ptk_smem), threadIdx.x);
-  KnnPolicy pol;
-  if (LIST_LDS) {
-    pol.list = reinterpret_cast<Neighbor*>(ptk_smem + (size_t)S * BLOCK * 8) + threadIdx.x;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  KnnPolicy<LIST_LDS> pol;
+  if constexpr (LIST_LDS) {
+    pol.list = (LdsWord*)(ptk_smem + (size_t)S * BLOCK * 8) + threadIdx.x;
     pol.stride = BLOCK;
   } else {
     pol.list = out + qi * k;
@@ -373,7 +629,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
 
   if (LIST_LDS) {
     Neighbor* row = out + qi * k;
-    for (uint32_t j = 0; j < pol.filled; ++j) row[j] = pol.list[j * BLOCK];
+    for (uint32_t j = 0; j < pol.filled; ++j) row[j] = pol.get(j);
   }
   if (pol.filled < k) {  // k > reachable points: mirror the reference's sentinel (:102)
     Neighbor nb;
@@ -397,8 +653,9 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
+  Record spill[OVF > 0 ? OVF : 1];
   Stack<S, OVF, BLOCK> st;
-  st.init(reinterpret_cast<uint2*>(ptk_smem), threadIdx.x);
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
   RadiusPolicy<FILL> pol;
   pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
   pol.e_inv = e_inv;
@@ -406,6 +663,84 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   pol.out = FILL ? out + offsets[qi] : nullptr;
   traverse<LEAFB>(t, qx, qy, qz, pol, st);
   if (!FILL) counts[qi] = pol.count;
+}
+
+// ---- persistent kernels: one wavefront per block, one chunk of sorted queries each ------
+// qs: the batch packed as {x, y, z, bits(original index)} in launch order.
+template <int S, int OVF, int LEAFB>
+__global__ __launch_bounds__(64) void knn1_persistent_kernel(
+    DevTree t, const float4* __restrict__ qs, uint64_t nq, uint32_t chunk, float e_inv,
+    Neighbor* __restrict__ out) {
+  const uint64_t first = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * chunk;
+  if (first >= nq) return;
+  const uint64_t last = first + chunk < nq ? first + chunk : nq;
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  NnPolicy pol;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  pol.begin_query(0);
+  run_machine<LEAFB>(t, qs, first, last, pol, st);
+}
+
+template <int S, int OVF, int LEAFB, bool LIST_LDS>
+__global__ __launch_bounds__(64) void knn_persistent_kernel(
+    DevTree t, const float4* __restrict__ qs, uint64_t nq, uint32_t chunk, uint32_t k, float e_inv,
+    Neighbor* __restrict__ out) {
+  const uint64_t first = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * chunk;
+  if (first >= nq) return;
+  const uint64_t last = first + chunk < nq ? first + chunk : nq;
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  KnnPolicy<LIST_LDS> pol;
+  pol.k = k;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  if constexpr (LIST_LDS) {
+    pol.list = (LdsWord*)(ptk_smem + (size_t)S * 64 * 8) + threadIdx.x;
+    pol.stride = 64;
+  } else {
+    pol.list = out;
+    pol.stride = 1;
+  }
+  pol.begin_query(0);
+  run_machine<LEAFB>(t, qs, first, last, pol, st);
+}
+
+template <int S, int OVF, int LEAFB, bool FILL>
+__global__ __launch_bounds__(64) void radius_persistent_kernel(
+    DevTree t, const float4* __restrict__ qs, uint64_t nq, uint32_t chunk, float radius, float e_inv,
+    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out) {
+  const uint64_t first = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * chunk;
+  if (first >= nq) return;
+  const uint64_t last = first + chunk < nq ? first + chunk : nq;
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  RadiusPolicy<FILL> pol;
+  pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
+  pol.e_inv = e_inv;
+  pol.counts = counts;
+  pol.offsets = offsets;
+  pol.rows = out;
+  pol.out = out;
+  pol.count = 0;
+  run_machine<LEAFB>(t, qs, first, last, pol, st);
+}
+
+// Packs the batch for the persistent kernels: qs[i] = {query perm[i], bits(perm[i])}
+// (perm == nullptr: identity).
+__global__ __launch_bounds__(kBlock) void pack_queries_kernel(
+    const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
+    float4* __restrict__ qs) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nq) return;
+  const uint32_t qi = perm ? perm[i] : (uint32_t)i;
+  float x, y, z;
+  load_query(queries, dim, qi, x, y, z);
+  qs[i] = make_float4(x, y, z, __uint_as_float(qi));
 }
 
 // Sorts every row ascending by distance (heap sort, in place, one row per lane).

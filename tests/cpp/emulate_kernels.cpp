@@ -15,6 +15,9 @@ thread_local dim3 blockIdx;
 thread_local dim3 gridDim;
 thread_local dim3 blockDim;
 
+#include <ucontext.h>
+
+#include <functional>
 #include <string>
 #include <vector>
 
@@ -24,6 +27,43 @@ thread_local dim3 blockDim;
 
 namespace ptk {
 unsigned char ptk_smem[192 * 1024] __attribute__((aligned(16)));
+}
+
+// ---- wave-level rendezvous for kernels that use __ballot ---------------------------------
+// The 64 lanes of one wavefront run as 64 cooperative fibers (ucontext) on the calling
+// thread.  A ballot parks the lane; when every live lane has parked, the OR of the
+// predicates is handed to all of them and they resume in lane order.  All lanes of a
+// wave call __ballot the same number of times (the persistent kernels leave their loop
+// on a wave-uniform condition), which the scheduler asserts.
+namespace {
+struct WaveFibers {
+  static constexpr int kLanes = 64;
+  static constexpr size_t kStack = 256 * 1024;
+  ucontext_t scheduler;
+  ucontext_t lane_ctx[kLanes];
+  std::vector<unsigned char> stacks;
+  bool done[kLanes];
+  bool pred[kLanes];
+  unsigned long long result = 0;
+  int current = -1;
+  std::function<void()> body;
+};
+WaveFibers* g_fibers = nullptr;
+
+void fiber_entry() {
+  WaveFibers* w = g_fibers;
+  w->body();
+  w->done[w->current] = true;
+  swapcontext(&w->lane_ctx[w->current], &w->scheduler);
+}
+}  // namespace
+
+unsigned long long emu_ballot(bool pred) {
+  WaveFibers* w = g_fibers;
+  const int lane = w->current;
+  w->pred[lane] = pred;
+  swapcontext(&w->lane_ctx[lane], &w->scheduler);  // park until everyone has voted
+  return w->result;
 }
 
 namespace {
@@ -37,6 +77,7 @@ struct Emu {
   uint32_t dim;
 };
 
+// Kernels whose lanes are independent: every lane of every block, sequentially.
 template <typename F>
 void for_each_lane(uint64_t nq, F&& f, uint32_t block = ptk::kBlock) {
   const uint32_t blocks = (uint32_t)((nq + block - 1) / block);
@@ -49,6 +90,53 @@ void for_each_lane(uint64_t nq, F&& f, uint32_t block = ptk::kBlock) {
       f();
     }
   }
+}
+
+// Runs `blocks` single-wave blocks, one after the other, 64 fibers each.
+template <typename F>
+void for_each_wave(uint32_t blocks, F&& f) {
+  WaveFibers w;
+  w.stacks.resize(WaveFibers::kLanes * WaveFibers::kStack);
+  g_fibers = &w;
+  gridDim.x = blocks;
+  blockDim.x = 64;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    blockIdx.x = b;
+    w.body = [&] { f(); };
+    for (int l = 0; l < WaveFibers::kLanes; ++l) {
+      w.done[l] = false;
+      w.pred[l] = false;
+      getcontext(&w.lane_ctx[l]);
+      w.lane_ctx[l].uc_stack.ss_sp = w.stacks.data() + (size_t)l * WaveFibers::kStack;
+      w.lane_ctx[l].uc_stack.ss_size = WaveFibers::kStack;
+      w.lane_ctx[l].uc_link = &w.scheduler;
+      makecontext(&w.lane_ctx[l], fiber_entry, 0);
+    }
+    for (;;) {
+      // Run every live lane up to its next ballot (or to completion).
+      int live = 0;
+      for (int l = 0; l < WaveFibers::kLanes; ++l) {
+        if (w.done[l]) continue;
+        w.current = l;
+        threadIdx.x = (uint32_t)l;
+        swapcontext(&w.scheduler, &w.lane_ctx[l]);
+        if (!w.done[l]) ++live;
+      }
+      if (live == 0) break;
+      unsigned long long bits = 0;
+      for (int l = 0; l < WaveFibers::kLanes; ++l) {
+        if (!w.done[l] && w.pred[l]) bits |= 1ull << l;
+      }
+      w.result = bits;
+    }
+  }
+  g_fibers = nullptr;
+}
+
+std::vector<float4> pack(const float* q, uint32_t dim, const uint32_t* perm, uint64_t nq) {
+  std::vector<float4> qs(nq ? nq : 1);
+  for_each_lane(nq, [&] { ptk::pack_queries_kernel(q, dim, perm, nq, qs.data()); });
+  return qs;
 }
 
 }  // namespace
@@ -127,6 +215,47 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
     ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o);
   }, 64);
   if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
+  return 0;
+}
+
+// The persistent (state machine + lane refill) kernels.  mode: 0 knn, 1 radius count,
+// 2 radius fill.  small_stack selects a 4-slot ring so that spills happen constantly.
+int emu_persistent(void* h, int mode, const float* q, uint64_t nq, uint32_t k, float radius, float e,
+                   const uint32_t* perm, uint32_t chunk, int small_stack, int list_in_lds, uint64_t* counts,
+                   const uint64_t* offsets, ptk_neighbor* out) {
+  auto* t = static_cast<Emu*>(h);
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  const float e_inv = 1.0f / e;
+  if (2 * t->st.max_depth + 2 > 4 + 2048) return -2;
+  if (nq == 0) return 0;
+  std::vector<float4> qs = pack(q, t->dim, perm, nq);
+  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
+  if (mode == 0 && k == 1) {
+    if (small_stack)
+      for_each_wave(blocks, [&] { ptk::knn1_persistent_kernel<4, 2048, 2>(t->dev, qs.data(), nq, chunk, e_inv, o); });
+    else
+      for_each_wave(blocks, [&] { ptk::knn1_persistent_kernel<32, 2048, 4>(t->dev, qs.data(), nq, chunk, e_inv, o); });
+  } else if (mode == 0) {
+    if ((size_t)(16 + k) * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
+    if (list_in_lds)
+      for_each_wave(blocks, [&] {
+        ptk::knn_persistent_kernel<16, 2048, 4, true>(t->dev, qs.data(), nq, chunk, k, e_inv, o);
+      });
+    else
+      for_each_wave(blocks, [&] {
+        ptk::knn_persistent_kernel<4, 2048, 8, false>(t->dev, qs.data(), nq, chunk, k, e_inv, o);
+      });
+  } else if (mode == 1) {
+    for_each_wave(blocks, [&] {
+      ptk::radius_persistent_kernel<8, 2048, 4, false>(t->dev, qs.data(), nq, chunk, radius, e_inv, counts, nullptr,
+                                                       nullptr);
+    });
+  } else {
+    for_each_wave(blocks, [&] {
+      ptk::radius_persistent_kernel<16, 2048, 4, true>(t->dev, qs.data(), nq, chunk, radius, e_inv, nullptr, offsets,
+                                                       o);
+    });
+  }
   return 0;
 }
 

@@ -23,6 +23,8 @@ struct float4 { float x, y, z, w; };
 struct dim3 { uint32_t x = 1, y = 1, z = 1; };
 
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
+inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
 
 // One rounding per operation; the emulator is built with -ffp-contract=off.
@@ -32,6 +34,12 @@ inline float __fmul_rn(float a, float b) { return a * b; }
 inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); return f; }
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline int32_t __float_as_int(float f) { int32_t i; std::memcpy(&i, &f, 4); return i; }
+
+// Wave-level collectives.  The emulator runs the 64 lanes of a wavefront as 64
+// host threads; __ballot is the rendezvous (see emulate_kernels.cpp).
+unsigned long long emu_ballot(bool pred);
+inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
+inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 
 extern thread_local dim3 threadIdx;
 extern thread_local dim3 blockIdx;

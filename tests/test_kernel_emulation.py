@@ -78,6 +78,30 @@ def test_emulated_kernels_equal_oracle(case):
         assert np.array_equal(gs["distance"], sflat["distance"])
 
 
+@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "lidar", "root-is-leaf", "dim2")],
+                         ids=lambda c: c[0])
+def test_emulated_persistent_machine_equals_oracle(case):
+    """The persistent kernels (per-lane state machine, ballot-based lane refill): the 64
+    lanes of a wavefront run as cooperative fibers so that __ballot is a real rendezvous."""
+    _, pts, q, leaf, radius = case
+    q = q[:700]
+    emu = EmulatedTree(pts, leaf)
+    ref = oracle.Oracle(pts, leaf, "port")
+    perm, _ = emu.morton_permutation(q)
+    for k in (1, 5):
+        if k > len(pts):
+            continue
+        want = ref.search_knn(q, k)
+        for small_stack, list_in_lds, p, chunk in ((False, True, None, 64), (True, False, perm, 200),
+                                                   (False, True, perm, 1024)):
+            got = emu.persistent_knn(q, k, perm=p, chunk=chunk, small_stack=small_stack,
+                                     list_in_lds=list_in_lds)
+            assert got.tobytes() == want.tobytes()
+    off, flat = ref.search_radius(q, radius)
+    goff, gflat = emu.persistent_radius(q, radius, perm=perm, chunk=100)
+    assert np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
+
+
 def test_morton_keys_follow_the_curve():
     pts = ds.uniform_cloud(5_000, 3, 3)
     emu = EmulatedTree(pts, 10)
