@@ -149,22 +149,16 @@ def main():
             f"nodes {info['n_nodes']}, depth {info['max_depth']}, HBM {info['device_bytes'] / 1e6:.1f} MB")
 
     # Shard: contiguous ranges of ceil(nq / world) queries in caller order.
-    per = (nq + world - 1) // world
-    lo, hi = min(rank * per, nq), min((rank + 1) * per, nq)
-    shard = np.zeros((per, dim), dtype=np.float32)
-    shard[:hi - lo] = q[lo:hi]
-    if hi - lo < per:  # pad the last shard with its first query so every rank gathers `per` rows
-        shard[hi - lo:] = q[lo] if hi > lo else q[0]
-    dq = torch.from_numpy(shard).to(dev)
+    from pico_tree_amd.sharded import ShardedSearch, padded_shard, shard_of
+
+    sh = shard_of(nq, world, rank)
+    per, lo, hi = sh.per, sh.lo, sh.hi
+    dq = torch.from_numpy(padded_shard(q, sh)).to(dev)
     out = torch.empty((per, k, 2), dtype=torch.int32, device=dev)
-    gathered = None
-    if world > 1 and rank == 0:
-        gathered = [torch.empty_like(out) for _ in range(world)]
+    sharded = ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw)
 
     def step():
-        tree.search_knn(dq, k, out)
-        if world > 1:
-            dist.gather(out, gathered if rank == 0 else None, dst=0)
+        sharded.step(dq, out)
 
     def fence():
         torch.cuda.synchronize()

@@ -321,9 +321,9 @@ class flat_builder {
       return self;
     }
 
-    Index_* cut;
-    size_t axis;
-    scalar_type plane;
+    Index_* cut = begin;
+    size_t axis = 0;
+    scalar_type plane = scalar_type(0);
     split(begin, end, box, cut, axis, plane);
 
     box_type right = box;

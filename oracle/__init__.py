@@ -137,7 +137,7 @@ class Oracle:
         q = self._queries(q)
         out = np.empty(len(q), dtype=NEIGHBOR)
         if self.kind == "port":
-            cnt = np.zeros((len(q), 4), dtype=np.uint32) if counters else None
+            cnt = np.zeros((len(q), 5), dtype=np.uint32) if counters else None
             self._fn("search_nn", None,
                      [c_void_p, POINTER(c_float), c_size_t, c_int, c_float, c_void_p, c_void_p])(
                 self._h, _fptr(q), len(q), int(e is not None), float(e or 1.0),
@@ -156,7 +156,7 @@ class Oracle:
             raise ValueError("oracle requires 1 <= k <= n")
         out = np.empty((len(q), k), dtype=NEIGHBOR)
         if self.kind == "port":
-            cnt = np.zeros((len(q), 4), dtype=np.uint32) if counters else None
+            cnt = np.zeros((len(q), 5), dtype=np.uint32) if counters else None
             self._fn("search_knn", None,
                      [c_void_p, POINTER(c_float), c_size_t, c_size_t, c_int, c_float,
                       c_void_p, c_void_p])(
@@ -180,7 +180,7 @@ class Oracle:
         q = self._queries(q)
         offsets = np.zeros(len(q) + 1, dtype=np.uint64)
         if self.kind == "port":
-            cnt = np.zeros((len(q), 4), dtype=np.uint32) if counters else None
+            cnt = np.zeros((len(q), 5), dtype=np.uint32) if counters else None
             h = self._fn("search_radius", c_void_p,
                          [c_void_p, POINTER(c_float), c_size_t, c_float, c_int, c_int, c_float,
                           c_void_p, c_void_p])(

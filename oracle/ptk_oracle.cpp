@@ -110,6 +110,10 @@ struct visit_counters {
   std::uint32_t n_leaf = 0;
   std::uint32_t n_pts = 0;
   std::uint32_t n_first = 0;  // branches passed before the first leaf (depth of the home leaf)
+  // Far children of the first descent whose box distance does not exceed the best distance
+  // found in the home leaf: the candidates a two-phase search hands from phase 1 to phase 2.
+  std::uint32_t n_cand = 0;
+  std::vector<float> first_far;  // scratch: far box distances along the first descent
 };
 
 struct tree_t {
@@ -301,10 +305,14 @@ struct nearest_search {
         if (counters->n_leaf == 0) counters->n_first = counters->n_branch;
         ++counters->n_leaf;
       }
+      bool const home_leaf = counters && counters->n_leaf == 1;
       for (int i = node->data.leaf.begin_idx; i < node->data.leaf.end_idx; ++i) {
         int const idx = tree.indices[static_cast<size_t>(i)];
         if (counters) ++counters->n_pts;
         visitor(idx, l2sq(q, tree.point(idx), tree.dim));
+      }
+      if (home_leaf) {
+        for (float f : counters->first_far) counters->n_cand += visitor.max() >= f ? 1u : 0u;
       }
       return;
     }
@@ -326,6 +334,9 @@ struct nearest_search {
       second = node->left;
       float const t = left_max - v;
       new_offset = t * t;  // :84
+    }
+    if (counters && counters->n_leaf == 0) {
+      counters->first_far.push_back(node_box_distance - offset[sd] + new_offset);
     }
     descend(first, node_box_distance);  // :88
 
@@ -507,8 +518,8 @@ void ptkor_set_threads(int threads) {
 int ptkor_max_threads() { return omp_get_max_threads(); }
 
 // kd_tree::search_nn over a batch (kd_tree.hpp:126-129,155-159); approx != 0
-// selects the approximate visitor with ratio e.  counters: optional nq x 4
-// uint32 {n_branch, n_leaf, n_pts, n_first}.
+// selects the approximate visitor with ratio e.  counters: optional nq x 5
+// uint32 {n_branch, n_leaf, n_pts, n_first, n_cand}.
 void ptkor_search_nn(void* handle, float const* q, size_t nq, int approx,
                      float e, void* out, std::uint32_t* counters) {
   auto* t = static_cast<tree_t*>(handle);
@@ -522,10 +533,11 @@ void ptkor_search_nn(void* handle, float const* q, size_t nq, int approx,
                                counters ? &c : nullptr);
     s.run();
     if (counters) {
-      counters[4 * i + 0] = c.n_branch;
-      counters[4 * i + 1] = c.n_leaf;
-      counters[4 * i + 2] = c.n_pts;
-      counters[4 * i + 3] = c.n_first;
+      counters[5 * i + 0] = c.n_branch;
+      counters[5 * i + 1] = c.n_leaf;
+      counters[5 * i + 2] = c.n_pts;
+      counters[5 * i + 3] = c.n_first;
+      counters[5 * i + 4] = c.n_cand;
     }
   }
 }
@@ -548,10 +560,11 @@ void ptkor_search_knn(void* handle, float const* q, size_t nq, size_t k,
     nearest_search<visit_knn> s(*t, q + ui * t->dim, v, counters ? &c : nullptr);
     s.run();
     if (counters) {
-      counters[4 * ui + 0] = c.n_branch;
-      counters[4 * ui + 1] = c.n_leaf;
-      counters[4 * ui + 2] = c.n_pts;
-      counters[4 * ui + 3] = c.n_first;
+      counters[5 * ui + 0] = c.n_branch;
+      counters[5 * ui + 1] = c.n_leaf;
+      counters[5 * ui + 2] = c.n_pts;
+      counters[5 * ui + 3] = c.n_first;
+      counters[5 * ui + 4] = c.n_cand;
     }
   }
 }
@@ -581,10 +594,11 @@ void* ptkor_search_radius(void* handle, float const* q, size_t nq, float radius,
                 });
     }
     if (counters) {
-      counters[4 * ui + 0] = c.n_branch;
-      counters[4 * ui + 1] = c.n_leaf;
-      counters[4 * ui + 2] = c.n_pts;
-      counters[4 * ui + 3] = c.n_first;
+      counters[5 * ui + 0] = c.n_branch;
+      counters[5 * ui + 1] = c.n_leaf;
+      counters[5 * ui + 2] = c.n_pts;
+      counters[5 * ui + 3] = c.n_first;
+      counters[5 * ui + 4] = c.n_cand;
     }
   }
   std::uint64_t acc = 0;

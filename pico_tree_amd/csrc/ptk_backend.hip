@@ -63,7 +63,7 @@ constexpr int kDeviceNone = -2;  // handle without a device replica (host tools,
 
 struct PendingEvent {
   hipEvent_t a, b;
-  int kind;  // 0 search, 1 reorder, 2 other
+  int kind;  // 0 search, 1 reorder, 2 other, 3 search (continuation of the same launch)
   uint64_t queries;
 };
 
@@ -459,6 +459,72 @@ int launch_radius_persistent(const ptk_tree* t, const float* d_q, const uint32_t
   return rc;
 }
 
+// Two-phase k = 1 search (see ptk_kernels.hpp): phase 1 over the whole batch, a 3-bit radix
+// pass over the continuations, phase 2 over the continuations.  All scratch is stream-ordered.
+template <int S1, bool DOUBLE, int S2, int OVF, int LEAFB, bool PERSISTENT2>
+int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
+                          ptk::Neighbor* d_out, hipStream_t s) {
+  float4* qs = nullptr;
+  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  if (rc != PTK_OK) return rc;
+  ptk::Cont cont{};
+  uint8_t* key_out = nullptr;
+  uint32_t* ids_out = nullptr;
+  void* tmp = nullptr;
+  hipError_t he = hipMallocAsync((void**)&cont.rec, nq * ptk::kContSlots * sizeof(ptk::Record), s);
+  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.best, nq * sizeof(uint4), s);
+  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.key, nq, s);
+  if (he == hipSuccess) he = hipMallocAsync((void**)&key_out, nq, s);
+  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.ids, nq * 4, s);
+  if (he == hipSuccess) he = hipMallocAsync((void**)&ids_out, nq * 4, s);
+  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.meta, 16 * 4, s);
+  size_t tmp_bytes = 0;
+  if (he == hipSuccess)
+    he = rocprim::radix_sort_pairs(nullptr, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 3, s);
+  if (he == hipSuccess) he = hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, s);
+  if (he == hipSuccess) {
+    const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+    const float e_inv = inv_ratio(e);
+    {
+      const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
+      Timer timer(t, s);
+      hipLaunchKernelGGL((ptk::knn1_phase1_kernel<S1, OVF, LEAFB, DOUBLE>), dim3(blocks), dim3(64), smem, s, t->dev,
+                         qs, nq, e_inv, d_out, cont);
+      timer.stop(0, nq);
+    }
+    {
+      Timer timer(t, s);
+      he = rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 3, s);
+      hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont);
+      timer.stop(2, 0);
+    }
+    if (he == hipSuccess) {
+      Timer timer(t, s);
+      if (PERSISTENT2) {
+        const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
+        hipLaunchKernelGGL((ptk::knn1_phase2_persistent_kernel<S2, OVF>), dim3(chunks), dim3(64),
+                           (size_t)S2 * 64 * 8 + ptk::kP2Chunk * 4, s, t->dev, qs, e_inv, d_out, cont, ids_out);
+      } else {
+        hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1), dim3(64),
+                           (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out);
+      }
+      timer.stop(3, 0);
+    }
+    if (he == hipSuccess) he = hipGetLastError();
+  }
+  if (tmp) (void)hipFreeAsync(tmp, s);
+  if (ids_out) (void)hipFreeAsync(ids_out, s);
+  if (key_out) (void)hipFreeAsync(key_out, s);
+  if (cont.meta) (void)hipFreeAsync(cont.meta, s);
+  if (cont.ids) (void)hipFreeAsync(cont.ids, s);
+  if (cont.key) (void)hipFreeAsync(cont.key, s);
+  if (cont.rec) (void)hipFreeAsync(cont.rec, s);
+  if (cont.best) (void)hipFreeAsync(cont.best, s);
+  (void)hipFreeAsync(qs, s);
+  if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error in the two-phase search: %s", hipGetErrorString(he));
+  return PTK_OK;
+}
+
 // Runs CALL with OVF bound to the spill capacity the tree's depth needs.
 #define PTK_WITH_OVF(SLDS, CALL)                                                                            \
   switch (ovf_class(t, SLDS)) {                                                                             \
@@ -474,12 +540,11 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
                   ptk::Neighbor* d_out, hipStream_t s) {
   const int variant = env_int("PTK_KNN1_VARIANT", 0);
   int rc = PTK_OK;
-  if (variant != 0 && ovf_class(t, 8) == 0) {
+  if (variant != 0 && variant != 4 && ovf_class(t, 8) == 0) {
     switch (variant) {
       case 1: return launch_knn1<32, 64, 256, 1>(t, d_q, perm, nq, e, d_out, s);
       case 2: return launch_knn1<32, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
       case 3: return launch_knn1<16, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 4: return launch_knn1<16, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
       case 5: return launch_knn1<8, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
       case 6: return launch_knn1<16, 64, 64, 8>(t, d_q, perm, nq, e, d_out, s);
       case 7: return launch_knn1<8, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
@@ -490,10 +555,21 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
       case 12: return launch_knn1_persistent<32, 64, 8>(t, d_q, perm, nq, e, d_out, s);
       case 13: return launch_knn1_persistent<32, 64, 2>(t, d_q, perm, nq, e, d_out, s);
       case 14: return launch_knn1_persistent<16, 64, 8>(t, d_q, perm, nq, e, d_out, s);
+      case 20: return launch_knn1_two_phase<32, false, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s);
+      case 21: return launch_knn1_two_phase<32, true, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s);
+      case 23: return launch_knn1_two_phase<32, true, 8, 64, 4, false>(t, d_q, perm, nq, e, d_out, s);
+      case 30: return launch_knn1_two_phase<32, true, 16, 64, 4, true>(t, d_q, perm, nq, e, d_out, s);
+      case 31: return launch_knn1_two_phase<32, true, 8, 64, 4, true>(t, d_q, perm, nq, e, d_out, s);
+      case 32: return launch_knn1_two_phase<32, true, 32, 64, 4, true>(t, d_q, perm, nq, e, d_out, s);
       default: break;
     }
   }
-  PTK_WITH_OVF(16, (launch_knn1<16, OVF, 64, 4>(t, d_q, perm, nq, e, d_out, s)));
+  if (variant == 4) {  // the single-kernel search
+    PTK_WITH_OVF(16, (launch_knn1<16, OVF, 64, 4>(t, d_q, perm, nq, e, d_out, s)));
+    return rc;
+  }
+  // Default: two-phase search, register-only phase 1.
+  PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false>(t, d_q, perm, nq, e, d_out, s)));
   return rc;
 }
 
@@ -859,6 +935,8 @@ int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
         t->profile.acc.search_ms += ms;
         t->profile.acc.launches += 1;
         t->profile.acc.queries += p.queries;
+      } else if (p.kind == 3) {  // second traversal kernel of the same search
+        t->profile.acc.search_ms += ms;
       } else if (p.kind == 1) {
         t->profile.acc.reorder_ms += ms;
       } else {

@@ -298,12 +298,14 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
 };
 
 // ---- the traversal ----------------------------------------------------------------
-template <int LEAFB, class Policy, class StackT>
+// RESUME: the stack already holds the pending records of a finished first descent (phase 2
+// of the two-phase k = 1 search): start by unwinding instead of descending from the root.
+template <int LEAFB, bool RESUME = false, class Policy, class StackT>
 __device__ __forceinline__ void traverse(
     const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st) {
   const uint4* __restrict__ nodes = t.nodes;
   const float4* __restrict__ pts = t.pts;
-  uint32_t ref = t.root_ref;
+  uint32_t ref = RESUME ? kLeafBit : t.root_ref;  // RESUME: an empty leaf, falls through to the unwind
   float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
 
   for (;;) {
@@ -663,6 +665,455 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   pol.out = FILL ? out + offsets[qi] : nullptr;
   traverse<LEAFB>(t, qx, qy, qz, pol, st);
   if (!FILL) counts[qi] = pol.count;
+}
+
+// ---- two-phase k = 1 search ---------------------------------------------------------------
+//
+// Measured on BASELINE config 2 (profiles/r01b_*): in the single kernel above a wavefront
+// spends two thirds of its memory round trips in far-child work that only a few of its 64
+// lanes need (the average query enters 2.3 far leaves, the worst lane of a wave 8-15), and
+// a few "monster" queries -- e.g. at the centre of the scanner's blind disc, 600 leaves --
+// hold a whole wave for milliseconds.  The first descent, by contrast, is the same ~22
+// steps for every lane.  So the k = 1 search is split where the work stops being uniform:
+//
+//   phase 1  every query: root -> home leaf, best = nearest point of that leaf.  The far
+//            children passed on the way that can still matter (box distance <= best; the
+//            pop-time test of the reference can only reject more) are written out as a
+//            CONTINUATION: at most kContSlots records, typically 1-3, none for ~20 % of the
+//            queries, whose answer is then already final.
+//   sort     continuations are ordered by how many records they carry (one 3-bit radix
+//            pass), so that a phase-2 wavefront holds queries with similar amounts of far
+//            work, the heaviest start first, and spatial neighbours among the heaviest are
+//            dealt to different wavefronts (the monsters come in clusters).
+//   phase 2  the records are pushed back and the reference traversal resumes exactly where
+//            it left off (state: box distance 0, all offsets 0, best = home-leaf best).
+//
+// The visit order of each query is unchanged, so results stay bit-identical.
+constexpr int kContSlots = 6;           // records a continuation can carry
+constexpr uint32_t kContOverflow = 7;   // class of a query with more: redone from the root
+constexpr uint32_t kHeavyClass = 4;     // classes >= this are dealt across wavefronts
+
+// Continuations are indexed by the query's slot in the (Morton-ordered) packed batch, so
+// phase 1 needs no allocation and no atomics; the class sort doubles as the compaction.
+struct Cont {
+  uint4* best;          // [nq]  {best index, bits(best distance), class, 0} after phase 1
+  Record* rec;          // [nq * kContSlots]  pending records of slot i, shallowest first
+  uint8_t* key;         // [nq]  7 - class (class = record count, 7 = overflow); 7 = nothing to do
+  uint32_t* ids;        // [nq]  slot index (sorted together with key)
+  uint32_t* meta;       // [0] continuations  [1] heavy continuations  [2] heavy wavefronts
+};
+
+// Phase 1.  DOUBLE = false: one descent, every far child kept in the LDS ring, filtered
+// against the home-leaf best afterwards.  DOUBLE = true: no LDS at all -- a first descent
+// finds the home-leaf best, a second (cache-hot) descent keeps only the far children that
+// pass, in registers.
+template <int S, int OVF, int LEAFB, bool DOUBLE>
+__global__ __launch_bounds__(64) void knn1_phase1_kernel(
+    DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
+    Cont cont) {
+  const uint64_t i = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint4* __restrict__ nodes = t.nodes;
+  const float4* __restrict__ pts = t.pts;
+  const float4 qrec = qs[i];
+  const float qx = qrec.x, qy = qrec.y, qz = qrec.z;
+  const uint32_t qi = __float_as_uint(qrec.w);
+
+  NnPolicy pol;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  pol.begin_query(qi);
+
+  Record spill[(!DOUBLE && OVF > 0) ? OVF : 1];
+  Stack<S, DOUBLE ? 0 : OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+
+  // First descent: the state is trivial (box distance 0, offsets 0), so a far child's box
+  // distance is just its new offset: (0 - 0) + new_off, exactly as the reference computes it.
+  uint32_t ref = t.root_ref;
+  while (!(ref & kLeafBit)) {
+    const uint32_t idx = ref & kBranchIdxMask;
+    const uint32_t axis = (ref >> 29) & 3u;
+    const uint4 nd = nodes[idx];
+    const float left_max = __uint_as_float(nd.x);
+    const float right_min = __uint_as_float(nd.y);
+    const float v = sel3(axis, qx, qy, qz);
+    const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+    if (!DOUBLE) {
+      const float dv = f_sub(go_left ? right_min : left_max, v);
+      const float far_nbd = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
+      st.push(idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
+    }
+    ref = go_left ? nd.z : nd.w;
+  }
+  {
+    const uint32_t lv = ref & 0x7FFFFFFFu;
+    const uint32_t begin = lv >> t.cbits;
+    const uint32_t count = lv & t.cmask;
+    for (uint32_t j = 0; j < count; j += LEAFB) {
+      float4 p[LEAFB];
+#pragma unroll
+      for (int u = 0; u < LEAFB; ++u) p[u] = pts[begin + j + u];
+#pragma unroll
+      for (int u = 0; u < LEAFB; ++u) {
+        if (j + u < count) {
+          const float dx = f_sub(qx, p[u].x);
+          const float dy = f_sub(qy, p[u].y);
+          const float dz = f_sub(qz, p[u].z);
+          pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
+        }
+      }
+    }
+  }
+  // Collect the far children that can still matter, shallowest first.
+  Record keep[kContSlots];
+  uint32_t c = 0;
+  if (DOUBLE) {
+    uint32_t r2 = t.root_ref;
+    while (!(r2 & kLeafBit)) {
+      const uint32_t idx = r2 & kBranchIdxMask;
+      const uint32_t axis = (r2 >> 29) & 3u;
+      const uint4 nd = nodes[idx];
+      const float left_max = __uint_as_float(nd.x);
+      const float right_min = __uint_as_float(nd.y);
+      const float v = sel3(axis, qx, qy, qz);
+      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+      const float dv = f_sub(go_left ? right_min : left_max, v);
+      const float far_nbd = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
+      if (pol.max() >= far_nbd) {
+        Record r;
+        r.x = idx | (axis << 28) | (go_left ? kRecSide : 0u);
+        r.y = __float_as_uint(far_nbd);
+#pragma unroll
+        for (int s = 0; s < kContSlots; ++s) {
+          if (c == (uint32_t)s) keep[s] = r;
+        }
+        ++c;
+      }
+      r2 = go_left ? nd.z : nd.w;
+    }
+  } else {
+    // Unwind the ring deepest-first; slot (n - 1 - c) keeps the shallowest-first order.
+    uint32_t passed = 0;
+    const int total = st.top;
+    for (int n = 0; n < total; ++n) {
+      const Record r = st.pop();
+      if (pol.max() >= __uint_as_float(r.y)) {
+#pragma unroll
+        for (int s = 0; s < kContSlots; ++s) {
+          if (passed == (uint32_t)s) keep[s] = r;  // deepest first for now
+        }
+        ++passed;
+      }
+    }
+    c = passed;
+  }
+  const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
+  const uint32_t e = (uint32_t)i;
+  cont.key[e] = (uint8_t)(7u - cls);  // class 0 -> key 7: sorts behind every continuation
+  cont.ids[e] = e;
+  if (cls == 0) {
+    pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
+  } else {
+    cont.best[e] = make_uint4((uint32_t)pol.best_i, __float_as_uint(pol.best_d), cls, 0u);
+  }
+  if (cls != 0 && cls != kContOverflow) {
+#pragma unroll
+    for (int s = 0; s < kContSlots; ++s) {
+      if ((uint32_t)s < c) {
+        // DOUBLE collected shallowest-first already; the ring unwind collected deepest-first.
+        const int src = DOUBLE ? s : (int)c - 1 - s;
+        Record r = keep[0];
+#pragma unroll
+        for (int u = 1; u < kContSlots; ++u) {
+          if (src == u) r = keep[u];
+        }
+        cont.rec[(uint64_t)e * kContSlots + s] = r;
+      }
+    }
+  }
+}
+
+// One thread, after the class sort: where the continuations and the heavy classes end.
+__global__ void knn1_phase_meta_kernel(const uint8_t* __restrict__ sorted_key, uint32_t nq, Cont cont) {
+  auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
+    uint32_t lo = 0, hi = nq;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (sorted_key[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const uint32_t n2 = first_at_least(7u);
+  const uint32_t heavy = first_at_least(7u - kHeavyClass + 1u);  // classes >= kHeavyClass
+  cont.meta[0] = n2;
+  cont.meta[1] = heavy;
+  cont.meta[2] = (heavy + 63u) / 64u;
+}
+
+// Phase 2: one continuation per lane, taken from the class-sorted entry list.
+template <int S, int OVF, int LEAFB>
+__global__ __launch_bounds__(64) void knn1_phase2_kernel(
+    DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
+    const uint32_t* __restrict__ sorted_ids) {
+  const uint32_t n2 = cont.meta[0];
+  const uint32_t heavy = cont.meta[1];
+  const uint32_t heavy_waves = cont.meta[2];
+  const uint32_t wave = blockIdx.x;
+  const uint32_t lane = threadIdx.x;
+  // Heavy classes: lane l of wave w takes sorted entry l * heavy_waves + w, so consecutive
+  // (spatially adjacent, equally expensive) entries land in different wavefronts.
+  uint32_t s;
+  bool valid;
+  if (wave < heavy_waves) {
+    s = lane * heavy_waves + wave;
+    valid = s < heavy;
+  } else {
+    s = heavy + (wave - heavy_waves) * 64u + lane;
+    valid = s < n2;
+  }
+  if (!valid) return;
+  const uint32_t e = sorted_ids[s];
+  const float4 qrec = qs[e];
+  const float qx = qrec.x, qy = qrec.y, qz = qrec.z;
+  const uint32_t qi = __float_as_uint(qrec.w);
+  const uint32_t cls = 7u - cont.key[e];
+
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  NnPolicy pol;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  if (cls == kContOverflow) {
+    pol.begin_query(qi);
+    traverse<LEAFB, false>(t, qx, qy, qz, pol, st);
+  } else {
+    const uint4 start = cont.best[e];
+    pol.best_i = (int32_t)start.x;
+    pol.best_d = __uint_as_float(start.y);
+    for (uint32_t j = 0; j < cls; ++j) {
+      const Record r = cont.rec[(uint64_t)e * kContSlots + j];
+      st.push(r.x, __uint_as_float(r.y));
+    }
+    traverse<LEAFB, true>(t, qx, qy, qz, pol, st);
+  }
+  pol.end_query(qi);
+}
+
+// Phase 2, persistent form.  Continuations differ wildly in cost (most need one far leaf,
+// the worst six hundred) and no cheap key predicts it, so here a wavefront does not wait
+// for its slowest lane: it owns kP2Chunk consecutive slots of the class-sorted list and a
+// lane that finishes its continuation takes the next slot at once (ballot + prefix count).
+// Every lane runs the same small state machine -- FETCH a continuation, NODE step (branch or
+// far-child entry), LEAF batch followed by the LDS-only unwind -- one transition per loop
+// iteration, and all global loads of an iteration (five 16-byte loads per lane, redirected
+// to the lane's first address when a state needs fewer) are issued back to back before any
+// is consumed: one memory round trip per iteration for the whole wavefront.
+constexpr uint32_t kP2Chunk = 256;
+constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
+
+template <int S, int OVF>
+__global__ __launch_bounds__(64) void knn1_phase2_persistent_kernel(
+    DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
+    const uint32_t* __restrict__ sorted_ids) {
+  const uint32_t n2 = cont.meta[0];
+  const uint32_t heavy = cont.meta[1];
+  const uint32_t heavy_waves = cont.meta[2];
+  const uint32_t total_slots = heavy_waves * 64u + (n2 - heavy);
+  const uint32_t chunk_base = xcd_tile(blockIdx.x, gridDim.x) * kP2Chunk;
+  if (chunk_base >= total_slots) return;
+  const uint32_t lane = threadIdx.x;
+  const uint4* __restrict__ nodes = t.nodes;
+  const float4* __restrict__ pts = t.pts;
+
+  // The chunk's entry ids, staged in LDS behind the record ring.
+  PTK_LDS uint32_t* ids = (PTK_LDS uint32_t*)(ptk_smem + (size_t)S * 64 * 8);
+  for (uint32_t j = 0; j < kP2Chunk / 64; ++j) {
+    const uint32_t slot = chunk_base + j * 64u + lane;
+    const uint32_t wave = slot >> 6;
+    uint32_t s;
+    bool valid;
+    if (wave < heavy_waves) {  // heavy classes: dealt across wavefront-sized groups
+      s = (slot & 63u) * heavy_waves + wave;
+      valid = s < heavy;
+    } else {
+      s = heavy + (slot - heavy_waves * 64u);
+      valid = s < n2;
+    }
+    ids[j * 64u + lane] = valid ? sorted_ids[s] : kNoEntry;
+  }
+  __syncthreads();  // one wavefront per block: orders the staging writes before the reads below
+
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, lane, spill);
+  NnPolicy pol;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  pol.begin_query(0);
+
+  enum : uint32_t { IDLE = 0, FETCH = 1, NODE = 2, LEAF = 3 };
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
+  uint32_t next = 0;  // wave-uniform: first slot of the chunk nobody has taken
+  uint32_t state = IDLE;
+  uint32_t e = 0, qi = 0, ref = 0, leaf_j = 0, far_meta = 0;
+  bool far_entry = false;
+  float far_val = 0.0f, nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
+  float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+
+  for (;;) {
+    const uint64_t idle = __ballot(state == IDLE);
+    if (idle != 0) {
+      if (next < kP2Chunk) {
+        const uint32_t mine = next + (uint32_t)__popcll(idle & lanes_below);
+        if (state == IDLE && mine < kP2Chunk) {
+          e = ids[mine];
+          if (e != kNoEntry) state = FETCH;
+        }
+        next += (uint32_t)__popcll(idle);
+      } else if (idle == ~0ull) {
+        break;
+      }
+    }
+
+    // ---- this iteration's loads: five 16-byte records per lane ----
+    const uint32_t lv = ref & 0x7FFFFFFFu;
+    const uint32_t begin = lv >> t.cbits;
+    const uint32_t count = lv & t.cmask;
+    const uint32_t node_idx = far_entry ? (far_meta & kRecIdxMask) : (ref & kBranchIdxMask);
+    const uint4* a0;
+    const uint4* a1;
+    const uint4* a2;
+    const uint4* a3;
+    const uint4* a4;
+    if (state == FETCH) {
+      a0 = reinterpret_cast<const uint4*>(qs + e);
+      a1 = cont.best + e;
+      a2 = reinterpret_cast<const uint4*>(cont.rec + (uint64_t)e * kContSlots);
+      a3 = a2 + 1;
+      a4 = a2 + 2;
+    } else if (state == LEAF) {
+      a0 = reinterpret_cast<const uint4*>(pts + (begin + leaf_j));
+      a1 = a0 + 1;
+      a2 = a0 + 2;
+      a3 = a0 + 3;
+      a4 = a0;
+    } else {  // NODE, or IDLE (any readable address)
+      a0 = nodes + (state == NODE ? node_idx : 0u);
+      a1 = a0;
+      a2 = a0;
+      a3 = a0;
+      a4 = a0;
+    }
+    const uint4 r0 = *a0;
+    const uint4 r1 = *a1;
+    const uint4 r2 = *a2;
+    const uint4 r3 = *a3;
+    const uint4 r4 = *a4;
+
+    bool unwind = false;
+    if (state == FETCH) {
+      qx = __uint_as_float(r0.x);
+      qy = __uint_as_float(r0.y);
+      qz = __uint_as_float(r0.z);
+      qi = r0.w;
+      st.top = 0;
+      st.base = 0;
+      nbd = off0 = off1 = off2 = 0.0f;
+      far_entry = false;
+      leaf_j = 0;
+      const uint32_t cls = r1.z;
+      if (cls == kContOverflow) {  // too many candidates to carry: the whole search, from the root
+        pol.begin_query(qi);
+        ref = t.root_ref;
+        state = (ref & kLeafBit) ? LEAF : NODE;
+      } else {
+        pol.best_i = (int32_t)r1.x;
+        pol.best_d = __uint_as_float(r1.y);
+        if (cls > 0) st.push(r2.x, __uint_as_float(r2.y));
+        if (cls > 1) st.push(r2.z, __uint_as_float(r2.w));
+        if (cls > 2) st.push(r3.x, __uint_as_float(r3.y));
+        if (cls > 3) st.push(r3.z, __uint_as_float(r3.w));
+        if (cls > 4) st.push(r4.x, __uint_as_float(r4.y));
+        if (cls > 5) st.push(r4.z, __uint_as_float(r4.w));
+        unwind = true;
+      }
+    } else if (state == NODE) {
+      const float left_max = __uint_as_float(r0.x);
+      const float right_min = __uint_as_float(r0.y);
+      if (!far_entry) {
+        const uint32_t axis = (ref >> 29) & 3u;
+        const float v = sel3(axis, qx, qy, qz);
+        const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+        const float dv = f_sub(go_left ? right_min : left_max, v);
+        const float new_off = f_mul(dv, dv);
+        const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
+        if (pol.max() >= far_nbd) {
+          st.push(node_idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
+        }
+        ref = go_left ? r0.z : r0.w;
+      } else {
+        const uint32_t axis = (far_meta >> 28) & 3u;
+        const bool far_is_right = (far_meta & kRecSide) != 0;
+        const float dv = f_sub(far_is_right ? right_min : left_max, sel3(axis, qx, qy, qz));
+        const float new_off = f_mul(dv, dv);
+        st.push(kRecUndo | (axis << 28), sel3(axis, off0, off1, off2));
+        st.push(kRecUndo | kRecSide, nbd);
+        off0 = axis == 0 ? new_off : off0;
+        off1 = axis == 1 ? new_off : off1;
+        off2 = axis == 2 ? new_off : off2;
+        nbd = far_val;
+        ref = far_is_right ? r0.w : r0.z;
+        far_entry = false;
+      }
+      leaf_j = 0;
+      state = (ref & kLeafBit) ? LEAF : NODE;
+    } else if (state == LEAF) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint4 p = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
+        if (leaf_j + u < count) {
+          const float dx = f_sub(qx, __uint_as_float(p.x));
+          const float dy = f_sub(qy, __uint_as_float(p.y));
+          const float dz = f_sub(qz, __uint_as_float(p.z));
+          pol.visit((int32_t)p.w, f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
+        }
+      }
+      leaf_j += 4;
+      unwind = leaf_j >= count;
+    }
+
+    if (unwind) {  // LDS only: back up to the next far child worth entering, or finish
+      for (;;) {
+        if (st.empty()) {
+          pol.end_query(qi);
+          state = IDLE;
+          break;
+        }
+        const Record r = st.pop();
+        const float val = __uint_as_float(r.y);
+        if (r.x & kRecUndo) {
+          if (r.x & kRecSide) {
+            nbd = val;
+          } else {
+            const uint32_t axis = (r.x >> 28) & 3u;
+            off0 = axis == 0 ? val : off0;
+            off1 = axis == 1 ? val : off1;
+            off2 = axis == 2 ? val : off2;
+          }
+          continue;
+        }
+        if (pol.max() >= val) {
+          far_entry = true;
+          far_meta = r.x;
+          far_val = val;
+          state = NODE;
+          break;
+        }
+      }
+    }
+  }
 }
 
 // ---- persistent kernels: one wavefront per block, one chunk of sorted queries each ------

@@ -17,6 +17,7 @@ thread_local dim3 blockDim;
 
 #include <ucontext.h>
 
+#include <algorithm>
 #include <functional>
 #include <string>
 #include <vector>
@@ -257,6 +258,72 @@ int emu_persistent(void* h, int mode, const float* q, uint64_t nq, uint32_t k, f
     });
   }
   return 0;
+}
+
+// The two-phase k = 1 search: phase 1, class sort (stable counting sort standing in for the
+// device radix pass), phase 2.  variant: 0 = LDS ring phase 1, 1 = double-descent phase 1,
+// 2 = tiny rings everywhere (spill paths), 3 / 4 = persistent phase 2 (normal / tiny ring).
+int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint32_t* perm, int variant,
+                       ptk_neighbor* out) {
+  auto* t = static_cast<Emu*>(h);
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  const float e_inv = 1.0f / e;
+  if (nq == 0) return 0;
+  if (2 * t->st.max_depth + 2 > 4 + 2048) return -2;
+  std::vector<float4> qs = pack(q, t->dim, perm, nq);
+  std::vector<ptk::Record> crec(nq * ptk::kContSlots + 8);
+  std::vector<uint4> cbest(nq);
+  std::vector<uint8_t> ckey(nq, 0xEE);
+  std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(16, 0);
+  ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data()};
+  if (variant == 0)
+    for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
+  else if (variant == 1 || variant >= 3)
+    for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
+  else
+    for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<4, 2048, 1, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
+  // stable sort by key (what the device's radix pass does)
+  std::vector<uint32_t> sorted(nq);
+  std::vector<uint8_t> sorted_key(nq);
+  {
+    std::vector<uint32_t> order(nq);
+    for (uint64_t i = 0; i < nq; ++i) order[i] = (uint32_t)i;
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ckey[a] < ckey[b]; });
+    for (uint64_t i = 0; i < nq; ++i) {
+      sorted[i] = cids[order[i]];
+      sorted_key[i] = ckey[order[i]];
+    }
+  }
+  gridDim.x = 1;
+  blockIdx.x = 0;
+  threadIdx.x = 0;
+  ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont);
+  if (variant >= 3) {  // persistent phase 2 (variant 4: tiny ring)
+    const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
+    if (variant == 3)
+      for_each_wave(chunks, [&] {
+        ptk::knn1_phase2_persistent_kernel<16, 2048>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+      });
+    else
+      for_each_wave(chunks, [&] {
+        ptk::knn1_phase2_persistent_kernel<4, 2048>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+      });
+    return (int)meta[0];
+  }
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1;
+  gridDim.x = blocks;
+  blockDim.x = 64;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    blockIdx.x = b;
+    for (uint32_t l = 0; l < 64; ++l) {
+      threadIdx.x = l;
+      if (variant == 2)
+        ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+      else
+        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+    }
+  }
+  return (int)meta[0];
 }
 
 // Morton keys + identity ids exactly as the device computes them.

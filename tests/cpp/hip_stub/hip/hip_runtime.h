@@ -40,6 +40,15 @@ inline int32_t __float_as_int(float f) { int32_t i; std::memcpy(&i, &f, 4); retu
 unsigned long long emu_ballot(bool pred);
 inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+inline void __syncthreads() { (void)emu_ballot(false); }  // single-wave blocks only
+
+// Lanes run one after the other (or as cooperative fibers), so a plain read-modify-write is atomic.
+template <typename T>
+inline T atomicAdd(T* p, T v) {
+  T old = *p;
+  *p = old + v;
+  return old;
+}
 
 extern thread_local dim3 threadIdx;
 extern thread_local dim3 blockIdx;

@@ -1,0 +1,245 @@
+// tests/cpp/host_api_main.cpp -- TEST PROGRAM for the header-only C++ API in include/pico_tree.
+//
+//   host_api_main host  <dir>   per-query members on the host (no libptk needed at run time)
+//   host_api_main batch <dir>   batched members through the C ABI (needs a GPU)
+//
+// <dir> holds points.bin / queries.bin (float32 row-major, 3-D) written by the pytest
+// driver (tests/test_cpp_api.py); results are written back as .bin files which the driver
+// compares bit-for-bit with the oracle.  The calls mirror how the reference's own examples
+// use the API (examples/kd_tree/kd_tree_search.cpp, kd_tree_creation.cpp,
+// kd_tree_custom_search_visitor.cpp, kd_tree_dynamic_arrays.cpp, kd_tree_save_and_load.cpp).
+
+#include <array>
+#include <cstdint>
+#include <cstdio>
+#include <fstream>
+#include <functional>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include <pico_tree/array_traits.hpp>
+#include <pico_tree/kd_tree.hpp>
+#include <pico_tree/map_traits.hpp>
+#include <pico_tree/vector_traits.hpp>
+
+using point3 = std::array<float, 3>;
+using space3 = std::vector<point3>;
+using neighbor = pico_tree::neighbor<int, float>;
+
+static std::vector<float> read_floats(std::string const& path) {
+  std::ifstream f(path, std::ios::binary | std::ios::ate);
+  if (!f) throw std::runtime_error("cannot open " + path);
+  std::streamsize bytes = f.tellg();
+  f.seekg(0);
+  std::vector<float> v(static_cast<size_t>(bytes) / sizeof(float));
+  f.read(reinterpret_cast<char*>(v.data()), bytes);
+  return v;
+}
+
+template <typename T>
+static void write_raw(std::string const& path, T const* data, size_t count) {
+  std::ofstream f(path, std::ios::binary);
+  f.write(reinterpret_cast<char const*>(data), static_cast<std::streamsize>(count * sizeof(T)));
+}
+
+static space3 to_space(std::vector<float> const& v) {
+  space3 s(v.size() / 3);
+  for (size_t i = 0; i < s.size(); ++i) s[i] = {v[3 * i], v[3 * i + 1], v[3 * i + 2]};
+  return s;
+}
+
+// A user-defined visitor (concept: operator()(index, distance) + max()).
+struct counting_nn {
+  neighbor& nn;
+  int count = 0;
+  explicit counting_nn(neighbor& n) : nn(n) { nn.distance = std::numeric_limits<float>::max(); }
+  void operator()(int idx, float d) {
+    if (max() > d) nn = {idx, d};
+    ++count;
+  }
+  float const& max() const { return nn.distance; }
+};
+
+static int run_host(std::string const& dir) {
+  std::vector<float> pv = read_floats(dir + "/points.bin");
+  std::vector<float> qv = read_floats(dir + "/queries.bin");
+  space3 pts = to_space(pv);
+  space3 qs = to_space(qv);
+  size_t const nq = qs.size();
+  size_t const k = 7;
+  float const radius = 0.0009f;
+
+  // (1) borrow the space, CTAD, default rule = sliding midpoint.
+  pico_tree::kd_tree tree(std::ref(pts), pico_tree::max_leaf_size_t(10));
+  static_assert(std::is_same_v<decltype(tree), pico_tree::kd_tree<std::reference_wrapper<space3>>>);
+
+  std::vector<neighbor> nn(nq), knn(nq * k), aknn(nq * k);
+  std::vector<int> visits(nq);
+  std::vector<std::uint64_t> roff(nq + 1, 0), boff(nq + 1, 0);
+  std::vector<neighbor> rflat, rsorted;
+  std::vector<int> bflat;
+  std::vector<neighbor> tmp;
+  std::vector<int> idxs;
+  for (size_t i = 0; i < nq; ++i) {
+    tree.search_nn(qs[i], nn[i]);
+    tree.search_knn(qs[i], knn.begin() + i * k, knn.begin() + (i + 1) * k);  // iterator form
+    tree.search_knn(qs[i], k, 1.44f, tmp);                                    // approximate, vector form
+    std::copy(tmp.begin(), tmp.end(), aknn.begin() + i * k);
+    neighbor cn{-1, 0.0f};
+    counting_nn v(cn);
+    tree.search_nearest(qs[i], v);
+    visits[i] = (cn.index == nn[i].index && cn.distance == nn[i].distance) ? v.count : -1;
+    tree.search_radius(qs[i], radius, tmp);
+    rflat.insert(rflat.end(), tmp.begin(), tmp.end());
+    roff[i + 1] = rflat.size();
+    tree.search_radius(qs[i], radius, tmp, true);
+    rsorted.insert(rsorted.end(), tmp.begin(), tmp.end());
+    point3 lo = {qs[i][0] - 0.02f, qs[i][1] - 0.02f, qs[i][2] - 0.02f};
+    point3 hi = {qs[i][0] + 0.02f, qs[i][1] + 0.02f, qs[i][2] + 0.02f};
+    tree.search_box(lo, hi, idxs);
+    bflat.insert(bflat.end(), idxs.begin(), idxs.end());
+    boff[i + 1] = bflat.size();
+  }
+  write_raw(dir + "/nn.bin", nn.data(), nn.size());
+  write_raw(dir + "/knn.bin", knn.data(), knn.size());
+  write_raw(dir + "/aknn.bin", aknn.data(), aknn.size());
+  write_raw(dir + "/visits.bin", visits.data(), visits.size());
+  write_raw(dir + "/radius_off.bin", roff.data(), roff.size());
+  write_raw(dir + "/radius_flat.bin", rflat.data(), rflat.size());
+  write_raw(dir + "/radius_sorted.bin", rsorted.data(), rsorted.size());
+  write_raw(dir + "/box_off.bin", boff.data(), boff.size());
+  write_raw(dir + "/box_flat.bin", bflat.data(), bflat.size());
+
+  // (2) save in the reference's byte format, reload, same answers.
+  {
+    std::stringstream ss(std::ios::in | std::ios::out | std::ios::binary);
+    decltype(tree)::save(tree, ss);
+    std::string bytes = ss.str();
+    write_raw(dir + "/save.bin", bytes.data(), bytes.size());
+    auto loaded = decltype(tree)::load(std::ref(pts), ss);
+    for (size_t i = 0; i < nq; i += 17) {
+      neighbor a;
+      loaded.search_nn(qs[i], a);
+      if (a.index != nn[i].index || a.distance != nn[i].distance) return 10;
+    }
+    if (loaded.leaf_ranges().size() != tree.leaf_ranges().size()) return 11;
+  }
+
+  // (3) run-time dimension through space_map / point_map, owning move, raw float[3] query.
+  {
+    using dyn_point = pico_tree::point_map<float const, pico_tree::dynamic_extent>;
+    pico_tree::space_map<dyn_point> dyn(pv.data(), pts.size(), 3);
+    pico_tree::kd_tree<pico_tree::space_map<dyn_point>> dtree(dyn, pico_tree::max_leaf_size_t(10));
+    for (size_t i = 0; i < nq; i += 13) {
+      float raw[3] = {qs[i][0], qs[i][1], qs[i][2]};
+      neighbor a{-1, 0.0f};
+      dtree.search_nn(raw, a);
+      if (a.index != nn[i].index || a.distance != nn[i].distance) return 20;
+    }
+  }
+
+  // (4) the other build parameters and metrics: properties against brute force.
+  {
+    auto brute = [&](point3 const& q, auto metric) {
+      float best = std::numeric_limits<float>::max();
+      for (auto const& p : pts) best = std::min(best, metric(q.begin(), q.end(), p.begin()));
+      return best;
+    };
+    pico_tree::kd_tree<space3> median(pts, pico_tree::max_leaf_size_t(4), pico_tree::bounds_from_space,
+                                      pico_tree::median_max_side);
+    pico_tree::kd_tree<space3> midpoint(pts, pico_tree::max_leaf_depth_t(9),
+                                        pico_tree::bounds_t(point3{-1, -1, -1}, point3{2, 2, 2}),
+                                        pico_tree::midpoint_max_side);
+    auto l1 = pico_tree::make_kd_tree<pico_tree::metric_l1>(std::ref(pts), pico_tree::max_leaf_size_t(6));
+    auto linf = pico_tree::make_kd_tree<pico_tree::metric_lpinf>(std::ref(pts), pico_tree::max_leaf_size_t(6));
+    for (size_t i = 0; i < nq; i += 29) {
+      neighbor a, b, c, d;
+      median.search_nn(qs[i], a);
+      midpoint.search_nn(qs[i], b);
+      l1.search_nn(qs[i], c);
+      linf.search_nn(qs[i], d);
+      if (a.distance != nn[i].distance || b.distance != nn[i].distance) return 30;
+      if (c.distance != brute(qs[i], pico_tree::metric_l1())) return 31;
+      // L-infinity: the incremental box distance is a SUM of per-axis terms (as in the
+      // reference, kd_tree_search.hpp:91-94), which over-estimates a max-norm, so the result
+      // is only guaranteed to be no closer than the brute-force optimum.
+      if (d.distance < brute(qs[i], pico_tree::metric_lpinf())) return 32;
+    }
+    // double precision instantiation
+    std::vector<std::array<double, 3>> dp(pts.size());
+    for (size_t i = 0; i < pts.size(); ++i) dp[i] = {pts[i][0], pts[i][1], pts[i][2]};
+    pico_tree::kd_tree dtree(std::ref(dp), pico_tree::max_leaf_size_t(10));
+    pico_tree::neighbor<int, double> dn;
+    dtree.search_nn(dp[5], dn);
+    if (dn.distance != 0.0) return 33;
+  }
+  std::printf("host ok\n");
+  return 0;
+}
+
+#ifndef PTK_TEST_HOST_ONLY
+static int run_batch(std::string const& dir) {
+  std::vector<float> pv = read_floats(dir + "/points.bin");
+  std::vector<float> qv = read_floats(dir + "/queries.bin");
+  space3 pts = to_space(pv);
+  space3 qs = to_space(qv);
+  size_t const nq = qs.size();
+  size_t const k = 7;
+  float const radius = 0.0009f;
+  pico_tree::kd_tree<space3> tree(std::move(pts), pico_tree::max_leaf_size_t(10));
+  tree.prepare_device();
+
+  std::vector<neighbor> nn(nq), knn(nq * k), aknn(nq * k);
+  tree.search_nn(qs, nn.data());                  // vector<array> query space (zero copy)
+  pico_tree::space_map<pico_tree::point_map<float const, 3>> qmap(qv.data(), nq);
+  tree.search_knn(qmap, k, knn.data());           // raw-pointer query space
+  tree.search_knn(std::cref(qs), k, 1.44f, aknn.data());
+  std::vector<std::vector<neighbor>> rows;
+  tree.search_radius(qs, radius, rows);
+  std::vector<std::uint64_t> roff(nq + 1, 0);
+  std::vector<neighbor> rflat;
+  for (size_t i = 0; i < nq; ++i) {
+    rflat.insert(rflat.end(), rows[i].begin(), rows[i].end());
+    roff[i + 1] = rflat.size();
+  }
+  std::vector<std::uint64_t> soff;
+  std::vector<neighbor> sflat;
+  tree.search_radius(qs, radius, soff, sflat, true);
+  write_raw(dir + "/b_nn.bin", nn.data(), nn.size());
+  write_raw(dir + "/b_knn.bin", knn.data(), knn.size());
+  write_raw(dir + "/b_aknn.bin", aknn.data(), aknn.size());
+  write_raw(dir + "/b_radius_off.bin", roff.data(), roff.size());
+  write_raw(dir + "/b_radius_flat.bin", rflat.data(), rflat.size());
+  write_raw(dir + "/b_radius_sorted.bin", sflat.data(), sflat.size());
+  // wrong dimension must throw, not crash
+  try {
+    std::vector<std::array<float, 2>> bad(4);
+    tree.search_nn(bad, nn.data());
+    return 40;
+  } catch (std::invalid_argument const&) {
+  }
+  std::printf("batch ok\n");
+  return 0;
+}
+
+#else
+static int run_batch(std::string const&) {
+  std::fprintf(stderr, "built without the batched members\n");
+  return 4;
+}
+#endif
+
+int main(int argc, char** argv) {
+  if (argc != 3) {
+    std::fprintf(stderr, "usage: %s host|batch <dir>\n", argv[0]);
+    return 2;
+  }
+  try {
+    return std::string(argv[1]) == "host" ? run_host(argv[2]) : run_batch(argv[2]);
+  } catch (std::exception const& e) {
+    std::fprintf(stderr, "exception: %s\n", e.what());
+    return 3;
+  }
+}

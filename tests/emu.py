@@ -28,6 +28,7 @@ def _lib():
                                     c_void_p, c_int]
     lib.emu_persistent.argtypes = [c_void_p, c_int, c_void_p, c_uint64, c_uint32, c_float, c_float, c_void_p,
                                    c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p]
+    lib.emu_knn1_two_phase.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_int, c_void_p]
     lib.emu_morton.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
     return lib
 
@@ -96,6 +97,16 @@ class EmulatedTree:
         self.lib.emu_persistent(self.h, 2, q.ctypes.data, nq, 0, radius, e or 1.0, p, chunk, 0, 0,
                                 None, off.ctypes.data, out.ctypes.data)
         return off, out
+
+    def two_phase_knn1(self, q, e=None, perm=None, variant=0):
+        """Returns (result (nq,1), number of continuations handed to phase 2)."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.zeros((len(q), 1), dtype=pt.NEIGHBOR)
+        n2 = self.lib.emu_knn1_two_phase(self.h, q.ctypes.data, len(q), e or 1.0,
+                                         perm.ctypes.data if perm is not None else None, variant,
+                                         out.ctypes.data)
+        assert n2 >= 0
+        return out, n2
 
     def morton_permutation(self, q):
         """The permutation the device would use (keys from the kernel, stable sort)."""

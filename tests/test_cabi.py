@@ -1,0 +1,112 @@
+"""CPU tier: libptk.so loads, exports exactly what include/ptk.h declares, and behaves on a
+machine without a GPU the way the boundary promises: structure queries work on a host-only
+handle, every search fails LOUDLY (no CPU fallback), bad arguments are rejected."""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+import pico_tree_amd as pt
+from pico_tree_amd import datasets as ds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "ptk.h")
+
+
+def declared_functions():
+    text = open(HEADER).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(ptk_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_is_plain_c():
+    """The boundary must compile as C (no C++ types leak through)."""
+    src = '#include "ptk.h"\nint main(void){ptk_tree_desc d; (void)d; return sizeof(ptk_neighbor)==8?0:1;}\n'
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"),
+                    "-x", "c", "-", "-fsyntax-only"], input=src.encode(), check=True)
+
+
+def test_library_exports_every_declared_symbol():
+    lib = ctypes.CDLL(pt.library_path())
+    names = declared_functions()
+    assert len(names) >= 20
+    for name in names:
+        assert hasattr(lib, name), f"{name} is declared in ptk.h but not exported"
+    assert set(pt.EXPORTED_SYMBOLS) == set(names), "Python binding table out of date"
+    assert pt._load().ptk_version() == 100
+
+
+def test_host_only_handle_and_loud_failures():
+    pts = ds.uniform_cloud(5000, 3, seed=1)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+    info = tree.info()
+    assert info["n_points"] == 5000 and info["dim"] == 3 and info["device"] == pt.PTK_DEVICE_NONE
+    assert info["n_nodes"] == 2 * info["n_leaves"] - 1 and info["max_leaf_count"] <= 10
+    nodes, idx, rmin, rmax = tree.flat()
+    assert sorted(idx.tolist()) == list(range(5000))
+    assert np.array_equal(rmin, pts.min(0)) and np.array_equal(rmax, pts.max(0))
+    q = ds.uniform_cloud(10, 3, seed=2)
+    with pytest.raises(pt.PtkError) as e:
+        tree.search_knn(q, 1)
+    assert e.value.status == -3 and "no device replica" in str(e.value)
+    with pytest.raises(pt.PtkError):
+        tree.search_radius(q, 0.1)
+
+
+def test_argument_validation():
+    lib = pt._load()
+    h = ctypes.c_void_p()
+    pts = ds.uniform_cloud(100, 3, seed=1)
+    assert lib.ptk_tree_create_from_points(None, 100, 3, 10, pt.PTK_DEVICE_NONE, ctypes.byref(h)) == -1
+    assert lib.ptk_tree_create_from_points(pts.ctypes.data, 0, 3, 10, pt.PTK_DEVICE_NONE, ctypes.byref(h)) == -1
+    assert lib.ptk_tree_create_from_points(pts.ctypes.data, 100, 0, 10, pt.PTK_DEVICE_NONE, ctypes.byref(h)) == -1
+    assert lib.ptk_tree_create_from_points(pts.ctypes.data, 100, 3, 0, pt.PTK_DEVICE_NONE, ctypes.byref(h)) == -1
+    assert b"positive" in lib.ptk_last_error()
+    with pytest.raises(ValueError):
+        pt.KdTree(pts.astype(np.float64))
+    with pytest.raises(ValueError):
+        pt.KdTree(pts[::2])
+    with pytest.raises(ValueError):
+        pt.KdTree(pts, pt.Metric.L1)
+    # F-ordered (sdim, npts) input is the same memory as C-ordered (npts, sdim): accepted
+    t = pt.KdTree(np.asfortranarray(pts.T), pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+    assert t.npts == 100 and t.sdim == 3 and t.metric(-2.0) == 4.0
+
+
+def test_rejects_malformed_flat_trees():
+    """ptk_tree_create validates the node stream instead of trusting it."""
+    from ctypes import POINTER, Structure, c_float, c_int32, c_uint32, c_uint64, c_void_p
+
+    class Desc(Structure):
+        _fields_ = [("dim", c_uint32), ("n_points", c_uint64), ("points", c_void_p), ("n_nodes", c_uint64),
+                    ("nodes", c_void_p), ("indices", c_void_p), ("root_min", c_void_p), ("root_max", c_void_p),
+                    ("max_depth", c_uint32), ("device", c_int32)]
+
+    lib = pt._load()
+    pts = ds.uniform_cloud(64, 3, seed=3)
+    good = pt.KdTree(pts, pt.Metric.L2Squared, 8, device=pt.PTK_DEVICE_NONE)
+    nodes, idx, _, _ = good.flat()
+
+    def create(n, i):
+        d = Desc(3, 64, pts.ctypes.data, len(n), n.ctypes.data, i.ctypes.data, None, None, 0, pt.PTK_DEVICE_NONE)
+        h = c_void_p()
+        rc = lib.ptk_tree_create(ctypes.byref(d), ctypes.byref(h))
+        if rc == 0:
+            lib.ptk_tree_destroy(h)
+        return rc
+
+    assert create(nodes, idx) == 0
+    bad = nodes.copy(); bad[0, 2] = 1                      # right child must lie after the left subtree
+    assert create(bad, idx) == -1
+    bad = nodes.copy(); bad[0, 3] = 7                      # split axis >= dim
+    assert create(bad, idx) == -1
+    assert create(nodes[:-1].copy(), idx) == -1            # truncated stream
+    leaf = np.flatnonzero(nodes[:, 2] == 0xFFFFFFFF)[0]
+    bad = nodes.copy(); bad[leaf, 1] = 1000                # leaf range past the end
+    assert create(bad, idx) == -1

@@ -1,0 +1,75 @@
+"""Multi-process path on CPU: two ranks over gloo run the shard / search / gather
+bookkeeping of pico_tree_amd.sharded (the same code bench.py drives over RCCL), with the
+oracle standing in for the per-shard GPU search, and rank 0 must end up with exactly the
+unsharded answer in caller order."""
+
+from __future__ import annotations
+
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from pico_tree_amd.sharded import padded_shard, shard_of
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_ranges_cover_every_row_once():
+    for nq in (0, 1, 7, 64, 1000, 7_200_863):
+        for world in (1, 2, 3, 8):
+            shards = [shard_of(nq, world, r) for r in range(world)]
+            assert shards[0].lo == 0 and shards[-1].hi == nq
+            for a, b in zip(shards, shards[1:]):
+                assert a.hi == b.lo
+            assert all(s.rows <= s.per for s in shards)
+            assert sum(s.rows for s in shards) == nq
+    sh = shard_of(10, 4, 3)
+    q = np.arange(30, dtype=np.float32).reshape(10, 3)
+    p = padded_shard(q, sh)
+    assert p.shape == (3, 3) and np.array_equal(p[0], q[9]) and np.array_equal(p[2], q[9])
+
+
+def _worker(rank, world, port, nq, k, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import oracle
+    from pico_tree_amd import datasets as ds
+    from pico_tree_amd.sharded import ShardedSearch, padded_shard, shard_of
+
+    pts = ds.uniform_cloud(20_000, 3, seed=5)   # every rank builds the same replica
+    q = ds.uniform_cloud(nq, 3, seed=6)
+    ref = oracle.Oracle(pts, 10, "port")
+
+    def search(q_local):  # stand-in for tree.search_knn(q_local, k).raw on the GPU
+        res = ref.search_knn(q_local.numpy(), k)
+        return torch.from_numpy(res.view(np.int32).reshape(len(res), k, 2).copy())
+
+    sh = shard_of(nq, world, rank)
+    ss = ShardedSearch(sh, search)
+    local = ss.step(torch.from_numpy(padded_shard(q, sh)))
+    dist.barrier()
+    full = ss.result(local)
+    if rank == 0:
+        want = ref.search_knn(q, k).view(np.int32).reshape(nq, k, 2)
+        np.save(os.path.join(tmp, "ok.npy"), np.array([int(np.array_equal(full.numpy(), want))]))
+    else:
+        assert full is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nq,k", [(1001, 1), (4096, 3)])
+def test_two_ranks_gather_matches_unsharded(tmp_path, nq, k):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_worker, args=(2, port, nq, k, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(os.path.join(tmp_path, "ok.npy"))[0] == 1

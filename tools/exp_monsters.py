@@ -28,7 +28,7 @@ def run(sel, label, variant="4"):
         ts.append(tree.profile(enable=False, reset=True)["search_ms"])
     print(f"{label:40s} n={len(sel):8d} variant {variant}: kernel ms {min(ts):.4f}  (max cost {cost[sel].max()}, mean {cost[sel].mean():.1f})", flush=True)
 
-for v in ("4", "8"):
+for v in ("0", "4"):
     run(order[:1], "the single worst query", v)
     run(order[:64], "worst 64 (one wave)", v)
     run(order[:1024], "worst 1024", v)

@@ -72,10 +72,29 @@ def pmc(paths) -> None:
             print(line)
 
 
+def timeline(path: str) -> None:
+    """Kernel sequence of ONE bench step (between the last two launches of the top kernel)."""
+    db = sqlite3.connect(path)
+    rows = db.cursor().execute("select name, start, end from kernels order by start").fetchall()
+    top = db.cursor().execute(
+        "select name from kernels group by name order by sum(end-start) desc limit 1").fetchone()[0]
+    idx = [i for i, r in enumerate(rows) if r[0] == top]
+    if len(idx) < 2:
+        return
+    i0, i1 = idx[-2], idx[-1]
+    t0 = rows[i0][2]
+    print(f"# one step of {path}: t = 0 at the end of the previous step's dominant kernel")
+    print(f"{'start_us':>10s} {'dur_us':>10s}  kernel")
+    for r in rows[i0 + 1:i1 + 1]:
+        print(f"{(r[1] - t0) / 1e3:10.1f} {(r[2] - r[1]) / 1e3:10.1f}  {short(r[0])}")
+
+
 if __name__ == "__main__":
-    if len(sys.argv) < 3 or sys.argv[1] not in ("stats", "pmc"):
+    if len(sys.argv) < 3 or sys.argv[1] not in ("stats", "pmc", "timeline"):
         raise SystemExit(__doc__)
     if sys.argv[1] == "stats":
         stats(sys.argv[2])
+    elif sys.argv[1] == "timeline":
+        timeline(sys.argv[2])
     else:
         pmc(sys.argv[2:])
