@@ -72,6 +72,24 @@ struct Profile {
   bool enabled = false;
   ptk_profile acc{};
   std::vector<PendingEvent> pending;  // recorded, not yet read back
+  std::vector<hipEvent_t> idle;       // events ready for reuse (hipEventCreate is slow)
+};
+
+// Device scratch of a handle: ONE grow-only HBM block, bump-allocated per search call.
+// A batch of BASELINE config 2 needs ~0.8 GB of transient arrays (packed queries, sort
+// double buffers, continuation records); asking the runtime for them on every call left
+// the GPU idle for ~0.6 ms per step (profiles/r01c_two_phase_timeline.txt), so they are
+// kept.  Calls on one handle enqueue under `mutex`; the block is reused in stream order,
+// and a call that arrives on a different stream first waits for `done` (recorded when the
+// previous call finished enqueueing).
+struct Workspace {
+  std::mutex mutex;
+  char* base = nullptr;
+  size_t capacity = 0;
+  size_t used = 0;
+  hipStream_t last_stream = nullptr;
+  hipEvent_t done = nullptr;
+  bool has_work = false;
 };
 
 }  // namespace
@@ -97,6 +115,7 @@ struct ptk_tree {
 
   std::atomic<int> reorder{PTK_REORDER_AUTO};
   mutable Profile profile;
+  mutable Workspace ws;
 };
 
 namespace {
@@ -213,7 +232,17 @@ struct Timer {
   Timer(const ptk_tree* tree, hipStream_t stream) : t(tree), s(stream) {
     on = tree->profile.enabled;
     if (on) {
-      on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+      {
+        std::lock_guard<std::mutex> lock(t->profile.mutex);
+        std::vector<hipEvent_t>& idle = t->profile.idle;
+        if (idle.size() >= 2) {
+          a = idle.back();
+          idle.pop_back();
+          b = idle.back();
+          idle.pop_back();
+        }
+      }
+      if (a == nullptr) on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
       if (on) (void)hipEventRecord(a, s);
     }
   }
@@ -228,6 +257,58 @@ struct Timer {
     if (a) (void)hipEventDestroy(a);
     if (b) (void)hipEventDestroy(b);
   }
+};
+
+// One search call's view of the handle's scratch block (see Workspace).
+class Scratch {
+ public:
+  Scratch(const ptk_tree* t, hipStream_t s) : ws_(t->ws), lock_(t->ws.mutex), s_(s) {}
+  ~Scratch() {
+    if (!reserved_) return;
+    if (ws_.done == nullptr && hipEventCreateWithFlags(&ws_.done, hipEventDisableTiming) != hipSuccess) {
+      ws_.done = nullptr;
+      (void)hipStreamSynchronize(s_);  // cannot order the next call: drain instead
+      ws_.has_work = false;
+      return;
+    }
+    (void)hipEventRecord(ws_.done, s_);
+    ws_.last_stream = s_;
+    ws_.has_work = true;
+  }
+  // Room for `bytes` in total over all take() calls of this search; orders the call
+  // after the previous user of the block.
+  int reserve(size_t bytes) {
+    bytes += 64 * kAlign;  // alignment slack of the individual arrays
+    if (bytes > ws_.capacity) {
+      if (ws_.has_work) (void)hipEventSynchronize(ws_.done);
+      if (ws_.base) (void)hipFree(ws_.base);
+      ws_.base = nullptr;
+      ws_.capacity = 0;
+      ws_.has_work = false;
+      const size_t want = (bytes + (size_t(32) << 20)) & ~((size_t(32) << 20) - 1);
+      PTK_HIP(hipMalloc((void**)&ws_.base, want));
+      ws_.capacity = want;
+    }
+    if (ws_.has_work && ws_.last_stream != s_) PTK_HIP(hipStreamWaitEvent(s_, ws_.done, 0));
+    ws_.used = 0;
+    reserved_ = true;
+    return PTK_OK;
+  }
+  template <class T>
+  T* take(size_t count) {
+    const size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
+    if (!reserved_ || ws_.used + bytes > ws_.capacity) return nullptr;  // reserve() was too small: a bug
+    T* p = reinterpret_cast<T*>(ws_.base + ws_.used);
+    ws_.used += bytes;
+    return p;
+  }
+  static constexpr size_t kAlign = 256;
+
+ private:
+  Workspace& ws_;
+  std::unique_lock<std::mutex> lock_;
+  hipStream_t s_;
+  bool reserved_ = false;
 };
 
 // Stack geometry: the newest S records of a lane live in an LDS ring, older ones
@@ -266,18 +347,39 @@ bool want_reorder(const ptk_tree* t, uint64_t nq) {
   return nq >= 8192;
 }
 
-// Device-side Morton ordering of a batch: returns a permutation (device, nq
-// uint32) in *perm; the caller frees it with hipFreeAsync on the same stream.
-int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, uint32_t** perm) {
+// Bits of the Morton key the batch is sorted by (3 axes interleaved, 10 bits each at most).
+// The search only needs neighbouring lanes to walk neighbouring leaves, so the low bits of
+// the full 30-bit key buy nothing: 24 bits (cells of 1/256 of the root box per axis) is one
+// 8-bit radix pass less.  PTK_MORTON_BITS overrides it for A/B runs.
+int morton_bits() {
+  const int b = env_int("PTK_MORTON_BITS", 24);
+  return b < 3 ? 3 : (b > 30 ? 30 : b);
+}
+
+size_t sort_tmp_bytes(uint64_t nq, int bits) {
+  size_t tmp_bytes = 0;
+  uint32_t* k32 = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k32, k32, k32, k32, nq, 0, bits, (hipStream_t) nullptr);
+  return tmp_bytes + 256;
+}
+
+size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, morton_bits()); }
+
+// Device-side Morton ordering of a batch: *perm (device, nq uint32, in `scratch`) lists the
+// query rows in launch order.
+int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch,
+                     uint32_t** perm) {
   *perm = nullptr;
   if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
   Timer timer(t, s);
-  uint32_t *keys = nullptr, *keys_out = nullptr, *ids = nullptr, *ids_out = nullptr;
-  void* tmp = nullptr;
-  PTK_HIP(hipMallocAsync((void**)&keys, nq * 4, s));
-  PTK_HIP(hipMallocAsync((void**)&keys_out, nq * 4, s));
-  PTK_HIP(hipMallocAsync((void**)&ids, nq * 4, s));
-  PTK_HIP(hipMallocAsync((void**)&ids_out, nq * 4, s));
+  const int bits = morton_bits();
+  size_t tmp_bytes = sort_tmp_bytes(nq, bits);
+  uint32_t* keys = scratch.take<uint32_t>(nq);
+  uint32_t* keys_out = scratch.take<uint32_t>(nq);
+  uint32_t* ids = scratch.take<uint32_t>(nq);
+  uint32_t* ids_out = scratch.take<uint32_t>(nq);
+  void* tmp = scratch.take<char>(tmp_bytes);
+  if (!keys || !keys_out || !ids || !ids_out || !tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
   float3 lo, inv;
   float lo_[3] = {0, 0, 0}, inv_[3] = {0, 0, 0};
   for (uint32_t d = 0; d < t->dim && d < 3; ++d) {
@@ -288,15 +390,9 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   lo = make_float3(lo_[0], lo_[1], lo_[2]);
   inv = make_float3(inv_[0], inv_[1], inv_[2]);
   const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
-  hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq, lo, inv, keys, ids);
-  size_t tmp_bytes = 0;
-  PTK_HIP(rocprim::radix_sort_pairs(nullptr, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, 30, s));
-  PTK_HIP(hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, s));
-  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, 30, s));
-  PTK_HIP(hipFreeAsync(tmp, s));
-  PTK_HIP(hipFreeAsync(keys, s));
-  PTK_HIP(hipFreeAsync(keys_out, s));
-  PTK_HIP(hipFreeAsync(ids, s));
+  hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq, lo, inv,
+                     (uint32_t)(30 - bits), keys, ids);
+  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
   *perm = ids_out;
   timer.stop(1, 0);
   return PTK_OK;
@@ -369,14 +465,14 @@ int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   return PTK_OK;
 }
 
-// Packs the batch as {x, y, z, bits(index)} records in launch order (perm or identity)
-// for the persistent kernels.  The caller frees *qs with hipFreeAsync.
+// Packs the batch as {x, y, z, bits(index)} records in launch order (perm or identity).
 int pack_queries(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, hipStream_t s,
-                 float4** qs) {
+                 Scratch& scratch, float4** qs) {
   *qs = nullptr;
   if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
   Timer timer(t, s);
-  PTK_HIP(hipMallocAsync((void**)qs, nq * sizeof(float4), s));
+  *qs = scratch.take<float4>(nq);
+  if (*qs == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
   const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
   hipLaunchKernelGGL(ptk::pack_queries_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, perm, nq, *qs);
   PTK_HIP(hipGetLastError());
@@ -391,9 +487,9 @@ uint32_t chunk_size() {
 
 template <int S, int OVF, int LEAFB>
 int launch_knn1_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
-                           ptk::Neighbor* d_out, hipStream_t s) {
+                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
   if (rc != PTK_OK) return rc;
   const uint32_t chunk = chunk_size();
   const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
@@ -406,15 +502,14 @@ int launch_knn1_persistent(const ptk_tree* t, const float* d_q, const uint32_t* 
     if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
     timer.stop(0, nq);
   }
-  (void)hipFreeAsync(qs, s);
   return rc;
 }
 
 template <int S, int OVF, int LEAFB>
 int launch_knn_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k,
-                          float e, ptk::Neighbor* d_out, hipStream_t s) {
+                          float e, ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
   if (rc != PTK_OK) return rc;
   const uint32_t chunk = chunk_size();
   const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
@@ -431,16 +526,15 @@ int launch_knn_persistent(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
   timer.stop(0, nq);
-  (void)hipFreeAsync(qs, s);
   return rc;
 }
 
 template <int S, int OVF, int LEAFB>
 int launch_radius_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
                              float e, bool fill, uint64_t* d_counts, const uint64_t* d_offsets,
-                             ptk::Neighbor* d_out, hipStream_t s) {
+                             ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
   if (rc != PTK_OK) return rc;
   const uint32_t chunk = chunk_size();
   const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
@@ -455,73 +549,70 @@ int launch_radius_persistent(const ptk_tree* t, const float* d_q, const uint32_t
   }
   if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
   timer.stop(0, nq);
-  (void)hipFreeAsync(qs, s);
   return rc;
 }
 
 // Two-phase k = 1 search (see ptk_kernels.hpp): phase 1 over the whole batch, a 3-bit radix
-// pass over the continuations, phase 2 over the continuations.  All scratch is stream-ordered.
+// pass over the continuations, phase 2 over the continuations.
+size_t class_sort_tmp_bytes(uint64_t nq) {
+  size_t tmp_bytes = 0;
+  uint8_t* k8 = nullptr;
+  uint32_t* v32 = nullptr;
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k8, k8, v32, v32, nq, 0, 3, (hipStream_t) nullptr);
+  return tmp_bytes + 256;
+}
+
+size_t two_phase_scratch_bytes(uint64_t nq) {
+  return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 2 * nq +
+         2 * (nq * 4) + 64 + class_sort_tmp_bytes(nq);
+}
+
 template <int S1, bool DOUBLE, int S2, int OVF, int LEAFB, bool PERSISTENT2>
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
-                          ptk::Neighbor* d_out, hipStream_t s) {
+                          ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, &qs);
+  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
   if (rc != PTK_OK) return rc;
   ptk::Cont cont{};
-  uint8_t* key_out = nullptr;
-  uint32_t* ids_out = nullptr;
-  void* tmp = nullptr;
-  hipError_t he = hipMallocAsync((void**)&cont.rec, nq * ptk::kContSlots * sizeof(ptk::Record), s);
-  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.best, nq * sizeof(uint4), s);
-  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.key, nq, s);
-  if (he == hipSuccess) he = hipMallocAsync((void**)&key_out, nq, s);
-  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.ids, nq * 4, s);
-  if (he == hipSuccess) he = hipMallocAsync((void**)&ids_out, nq * 4, s);
-  if (he == hipSuccess) he = hipMallocAsync((void**)&cont.meta, 16 * 4, s);
-  size_t tmp_bytes = 0;
-  if (he == hipSuccess)
-    he = rocprim::radix_sort_pairs(nullptr, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 3, s);
-  if (he == hipSuccess) he = hipMallocAsync(&tmp, tmp_bytes ? tmp_bytes : 16, s);
-  if (he == hipSuccess) {
-    const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-    const float e_inv = inv_ratio(e);
-    {
-      const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
-      Timer timer(t, s);
-      hipLaunchKernelGGL((ptk::knn1_phase1_kernel<S1, OVF, LEAFB, DOUBLE>), dim3(blocks), dim3(64), smem, s, t->dev,
-                         qs, nq, e_inv, d_out, cont);
-      timer.stop(0, nq);
-    }
-    {
-      Timer timer(t, s);
-      he = rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 3, s);
-      hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont);
-      timer.stop(2, 0);
-    }
-    if (he == hipSuccess) {
-      Timer timer(t, s);
-      if (PERSISTENT2) {
-        const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
-        hipLaunchKernelGGL((ptk::knn1_phase2_persistent_kernel<S2, OVF>), dim3(chunks), dim3(64),
-                           (size_t)S2 * 64 * 8 + ptk::kP2Chunk * 4, s, t->dev, qs, e_inv, d_out, cont, ids_out);
-      } else {
-        hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1), dim3(64),
-                           (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out);
-      }
-      timer.stop(3, 0);
-    }
-    if (he == hipSuccess) he = hipGetLastError();
+  size_t tmp_bytes = class_sort_tmp_bytes(nq);
+  cont.rec = scratch.take<ptk::Record>(nq * ptk::kContSlots);
+  cont.best = scratch.take<uint4>(nq);
+  cont.key = scratch.take<uint8_t>(nq);
+  uint8_t* key_out = scratch.take<uint8_t>(nq);
+  cont.ids = scratch.take<uint32_t>(nq);
+  uint32_t* ids_out = scratch.take<uint32_t>(nq);
+  cont.meta = scratch.take<uint32_t>(16);
+  void* tmp = scratch.take<char>(tmp_bytes);
+  if (!cont.rec || !cont.best || !cont.key || !key_out || !cont.ids || !ids_out || !cont.meta || !tmp)
+    return fail(PTK_ERR_NOMEM, "scratch block too small");
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+  const float e_inv = inv_ratio(e);
+  {
+    const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
+    Timer timer(t, s);
+    hipLaunchKernelGGL((ptk::knn1_phase1_kernel<S1, OVF, LEAFB, DOUBLE>), dim3(blocks), dim3(64), smem, s, t->dev,
+                       qs, nq, e_inv, d_out, cont);
+    timer.stop(0, nq);
   }
-  if (tmp) (void)hipFreeAsync(tmp, s);
-  if (ids_out) (void)hipFreeAsync(ids_out, s);
-  if (key_out) (void)hipFreeAsync(key_out, s);
-  if (cont.meta) (void)hipFreeAsync(cont.meta, s);
-  if (cont.ids) (void)hipFreeAsync(cont.ids, s);
-  if (cont.key) (void)hipFreeAsync(cont.key, s);
-  if (cont.rec) (void)hipFreeAsync(cont.rec, s);
-  if (cont.best) (void)hipFreeAsync(cont.best, s);
-  (void)hipFreeAsync(qs, s);
-  if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error in the two-phase search: %s", hipGetErrorString(he));
+  {
+    Timer timer(t, s);
+    PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 3, s));
+    hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont);
+    timer.stop(2, 0);
+  }
+  {
+    Timer timer(t, s);
+    if (PERSISTENT2) {
+      const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
+      hipLaunchKernelGGL((ptk::knn1_phase2_persistent_kernel<S2, OVF>), dim3(chunks), dim3(64),
+                         (size_t)S2 * 64 * 8 + ptk::kP2Chunk * 4, s, t->dev, qs, e_inv, d_out, cont, ids_out);
+    } else {
+      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1), dim3(64),
+                         (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out);
+    }
+    timer.stop(3, 0);
+  }
+  PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
 
@@ -537,7 +628,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
 // k = 1 geometries.  Variant 0 is the default; the others exist for A/B runs and
 // only for the shallow spill class (OVF = 64).
 int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
-                  ptk::Neighbor* d_out, hipStream_t s) {
+                  ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   const int variant = env_int("PTK_KNN1_VARIANT", 0);
   int rc = PTK_OK;
   if (variant != 0 && variant != 4 && ovf_class(t, 8) == 0) {
@@ -550,17 +641,17 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
       case 7: return launch_knn1<8, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
       case 8: return launch_knn1<32, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
       case 9: return launch_knn1<8, 64, 64, 8>(t, d_q, perm, nq, e, d_out, s);
-      case 10: return launch_knn1_persistent<32, 64, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 11: return launch_knn1_persistent<16, 64, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 12: return launch_knn1_persistent<32, 64, 8>(t, d_q, perm, nq, e, d_out, s);
-      case 13: return launch_knn1_persistent<32, 64, 2>(t, d_q, perm, nq, e, d_out, s);
-      case 14: return launch_knn1_persistent<16, 64, 8>(t, d_q, perm, nq, e, d_out, s);
-      case 20: return launch_knn1_two_phase<32, false, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s);
-      case 21: return launch_knn1_two_phase<32, true, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s);
-      case 23: return launch_knn1_two_phase<32, true, 8, 64, 4, false>(t, d_q, perm, nq, e, d_out, s);
-      case 30: return launch_knn1_two_phase<32, true, 16, 64, 4, true>(t, d_q, perm, nq, e, d_out, s);
-      case 31: return launch_knn1_two_phase<32, true, 8, 64, 4, true>(t, d_q, perm, nq, e, d_out, s);
-      case 32: return launch_knn1_two_phase<32, true, 32, 64, 4, true>(t, d_q, perm, nq, e, d_out, s);
+      case 10: return launch_knn1_persistent<32, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 11: return launch_knn1_persistent<16, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 12: return launch_knn1_persistent<32, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 13: return launch_knn1_persistent<32, 64, 2>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 14: return launch_knn1_persistent<16, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 20: return launch_knn1_two_phase<32, false, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 21: return launch_knn1_two_phase<32, true, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 23: return launch_knn1_two_phase<32, true, 8, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 30: return launch_knn1_two_phase<32, true, 16, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 31: return launch_knn1_two_phase<32, true, 8, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 32: return launch_knn1_two_phase<32, true, 32, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
       default: break;
     }
   }
@@ -569,7 +660,7 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
     return rc;
   }
   // Default: two-phase search, register-only phase 1.
-  PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false>(t, d_q, perm, nq, e, d_out, s)));
+  PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch)));
   return rc;
 }
 
@@ -654,6 +745,10 @@ void ptk_tree_destroy(ptk_tree* t) {
       (void)hipEventDestroy(p.a);
       (void)hipEventDestroy(p.b);
     }
+    for (hipEvent_t e : t->profile.idle) (void)hipEventDestroy(e);
+    if (t->ws.has_work) (void)hipEventSynchronize(t->ws.done);
+    if (t->ws.done) (void)hipEventDestroy(t->ws.done);
+    if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
     if (t->d_pts) (void)hipFree(t->d_pts);
   }
@@ -704,17 +799,20 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   hipStream_t s = static_cast<hipStream_t>(stream);
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  const bool reorder = want_reorder(t, nq);
+  Scratch scratch(t, s);
+  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) + (k == 1 ? two_phase_scratch_bytes(nq) : 0));
+  if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
-  if (want_reorder(t, nq)) {
-    rc = make_permutation(t, d_q, nq, s, &perm);
+  if (reorder) {
+    rc = make_permutation(t, d_q, nq, s, scratch, &perm);
     if (rc != PTK_OK) return rc;
   }
   if (k == 1) {
-    rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s);
+    rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else {
     PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
   }
-  if (perm) (void)hipFreeAsync(perm, s);
   return rc;
 }
 
@@ -759,14 +857,17 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
   if (nq == 0) return PTK_OK;
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  const bool reorder = want_reorder(t, nq);
+  Scratch scratch(t, s);
+  rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
+  if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
-  if (want_reorder(t, nq)) {
-    rc = make_permutation(t, d_q, nq, s, &perm);
+  if (reorder) {
+    rc = make_permutation(t, d_q, nq, s, scratch, &perm);
     if (rc != PTK_OK) return rc;
   }
   PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4>(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
                                                   reinterpret_cast<ptk::Neighbor*>(d_out), s)));
-  if (perm) (void)hipFreeAsync(perm, s);
   if (rc == PTK_OK && fill && sort) {
     Timer timer(t, s);
     const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
@@ -943,8 +1044,8 @@ int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
         t->profile.acc.other_ms += ms;
       }
     }
-    (void)hipEventDestroy(p.a);
-    (void)hipEventDestroy(p.b);
+    t->profile.idle.push_back(p.a);
+    t->profile.idle.push_back(p.b);
   }
   t->profile.pending.clear();
   *out = t->profile.acc;

@@ -1238,7 +1238,7 @@ __device__ __forceinline__ uint32_t spread10(uint32_t x) {
 }
 
 __global__ __launch_bounds__(kBlock) void morton_kernel(
-    const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv,
+    const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv, uint32_t drop,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nq) return;
@@ -1247,7 +1247,8 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(
   const float fx = fminf(fmaxf((x - lo.x) * inv.x, 0.0f), 1023.0f);
   const float fy = fminf(fmaxf((y - lo.y) * inv.y, 0.0f), 1023.0f);
   const float fz = fminf(fmaxf((z - lo.z) * inv.z, 0.0f), 1023.0f);
-  keys[i] = spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2);
+  // `drop` low bits of the 30-bit key are not worth a radix pass (see morton_bits()).
+  keys[i] = (spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2)) >> drop;
   ids[i] = (uint32_t)i;
 }
 

@@ -331,7 +331,7 @@ void emu_morton(const float* q, uint32_t dim, uint64_t nq, const float* lo, cons
                 uint32_t* ids) {
   float3 l = make_float3(lo[0], lo[1], lo[2]);
   float3 i = make_float3(inv[0], inv[1], inv[2]);
-  for_each_lane(nq, [&] { ptk::morton_kernel(q, dim, nq, l, i, keys, ids); });
+  for_each_lane(nq, [&] { ptk::morton_kernel(q, dim, nq, l, i, 0u, keys, ids); });
 }
 
 }  // extern "C"

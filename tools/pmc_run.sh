@@ -20,5 +20,6 @@ done
 # Summarise on the box and drop the (large) databases: gpurun copies back at most 64 MiB.
 python $R/tools/rocprof_summary.py stats $R/gpurun_out/prof_$TAG/trace_results.db > $R/gpurun_out/${TAG}_stats.txt 2>&1
 python $R/tools/rocprof_summary.py pmc $R/gpurun_out/pmc_${TAG}_*/pmc_results.db > $R/gpurun_out/${TAG}_pmc.txt 2>&1
+python $R/tools/rocprof_summary.py traffic $R/gpurun_out/pmc_${TAG}_1/pmc_results.db $R/gpurun_out/pmc_${TAG}_2/pmc_results.db > $R/gpurun_out/${TAG}_traffic.json 2>&1
 python $R/tools/rocprof_summary.py timeline $R/gpurun_out/prof_$TAG/trace_results.db > $R/gpurun_out/${TAG}_timeline.txt 2>&1
 rm -rf $R/gpurun_out/prof_$TAG $R/gpurun_out/pmc_${TAG}_*
