@@ -33,6 +33,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
+#: The k = 1 traversal is two kernels; the algorithmic bytes cover both.
+TRAVERSAL_KERNELS = ("ptk::knn1_phase1", "ptk::knn1_phase2")
 
 
 def log(*a):
@@ -69,6 +71,29 @@ def algorithmic_bytes(ref, q_sample, k, dim):
     mean = cnt.astype(np.float64).mean(axis=0)
     b = 4 * dim + 8 * k + 16 * mean[0] + 8 * mean[1] + (4 * dim + 4) * mean[2]
     return float(b), {"n_branch": float(mean[0]), "n_leaf": float(mean[1]), "n_pts": float(mean[2])}
+
+
+def measured_traffic(prefixes):
+    """HBM bytes per launch of the traversal kernels from the newest committed
+    ``profiles/*_traffic.json`` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
+    command, tools/pmc_run.sh; 2 x FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes).
+    Counters cannot be collected from inside the process, hence the file; None if absent."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    total, seen = 0.0, 0
+    for name, rec in kernels.items():
+        if any(name.startswith(p) for p in prefixes) and "hbm_bytes_per_dispatch" in rec:
+            total += rec["hbm_bytes_per_dispatch"]
+            seen += 1
+    return (total, os.path.basename(files[-1])) if seen else (None, None)
 
 
 def cpu_baseline(pts, q, k, leaf, seconds):
@@ -205,9 +230,16 @@ def main():
         kernel_ms = prof["search_ms"] / launches
         q_per_launch = prof["queries"] / launches if prof["launches"] else per
         achieved = (b_per_q * q_per_launch) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+        traffic, traffic_src = (None, None)
+        if k == 1 and not args.n and not args.nq and args.cloud == "L" and world == 1:
+            traffic, traffic_src = measured_traffic(TRAVERSAL_KERNELS)
         roofline = {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "kernel": "knn1_kernel" if k == 1 else "knn_kernel",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5),
+                    "traffic": None if traffic is None else round(traffic / 1e9, 3),
+                    "traffic_unit": "GB per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
+                    "traffic_source": traffic_src,
+                    "algorithmic_gb_per_launch": round(b_per_q * q_per_launch / 1e9, 3),
+                    "kernel": "+".join(TRAVERSAL_KERNELS) if k == 1 else "ptk::knn_kernel",
                     "kernel_ms": round(kernel_ms, 4), "reorder_ms": round(prof["reorder_ms"] / launches, 4),
                     "bytes_per_query": round(b_per_q, 1), "queries_per_launch": int(q_per_launch),
                     "visits_per_query": {kk: round(v, 2) for kk, v in visits.items()}}
