@@ -567,13 +567,15 @@ size_t two_phase_scratch_bytes(uint64_t nq) {
          2 * (nq * 4) + 64 + class_sort_tmp_bytes(nq);
 }
 
-template <int S1, bool DOUBLE, int S2, int OVF, int LEAFB, bool PERSISTENT2>
+template <int S1, bool DOUBLE, int S2, int OVF, int LEAFB, bool PERSISTENT2, bool UNIFORM1 = false,
+          int LEAFB1 = LEAFB>
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   float4* qs = nullptr;
   int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
   if (rc != PTK_OK) return rc;
   ptk::Cont cont{};
+  cont.nq = nq;
   size_t tmp_bytes = class_sort_tmp_bytes(nq);
   cont.rec = scratch.take<ptk::Record>(nq * ptk::kContSlots);
   cont.best = scratch.take<uint4>(nq);
@@ -587,17 +589,28 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     return fail(PTK_ERR_NOMEM, "scratch block too small");
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
+  // Heavy continuations run `heavy_lanes` per wavefront; the grid has room for 1/8 of the batch
+  // being heavy at that width (the meta kernel falls back to full waves beyond that).
+  uint32_t heavy_lanes = (uint32_t)env_int("PTK_HEAVY_LANES", 64);
+  if (heavy_lanes < 1 || heavy_lanes > 64) heavy_lanes = 64;
+  const uint32_t extra_waves = heavy_lanes == 64 ? 0xFFFFFFFFu : (uint32_t)(nq / 8 / heavy_lanes) + 2u;
   {
     const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
     Timer timer(t, s);
-    hipLaunchKernelGGL((ptk::knn1_phase1_kernel<S1, OVF, LEAFB, DOUBLE>), dim3(blocks), dim3(64), smem, s, t->dev,
-                       qs, nq, e_inv, d_out, cont);
+    if (UNIFORM1) {
+      hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB1>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq, e_inv,
+                         d_out, cont, (uint32_t)env_int("PTK_DEBUG_PHASE1", 0));
+    } else {
+      hipLaunchKernelGGL((ptk::knn1_phase1_kernel<S1, OVF, LEAFB, DOUBLE>), dim3(blocks), dim3(64), smem, s, t->dev,
+                         qs, nq, e_inv, d_out, cont);
+    }
     timer.stop(0, nq);
   }
   {
     Timer timer(t, s);
     PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 3, s));
-    hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont);
+    hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont,
+                       (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass), heavy_lanes, extra_waves);
     timer.stop(2, 0);
   }
   {
@@ -607,9 +620,79 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
       hipLaunchKernelGGL((ptk::knn1_phase2_persistent_kernel<S2, OVF>), dim3(chunks), dim3(64),
                          (size_t)S2 * 64 * 8 + ptk::kP2Chunk * 4, s, t->dev, qs, e_inv, d_out, cont, ids_out);
     } else {
-      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1), dim3(64),
-                         (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out);
+      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>),
+                         dim3(blocks + 1 + (heavy_lanes == 64 ? 0u : extra_waves)), dim3(64),
+                         (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out,
+                         (uint32_t)env_int("PTK_DEBUG_PHASE2", 0));
     }
+    timer.stop(3, 0);
+  }
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+
+// Two-phase k = 1 search with the refill phase 2 (the shipped form): phase 1 over the whole batch,
+// then a persistent grid of single-wave blocks that pull continuations from the batch in Morton
+// order -- no class sort.
+int persistent_blocks(const ptk_tree* t, const void* kernel, size_t smem) {
+  int per_cu = 0;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, smem) != hipSuccess || per_cu <= 0) per_cu = 8;
+  hipDeviceProp_t prop;
+  int cus = 256;
+  if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0)
+    cus = prop.multiProcessorCount;
+  const int cap = env_int("PTK_REFILL_WAVES_PER_CU", 0);
+  if (cap > 0 && cap < per_cu) per_cu = cap;
+  return per_cu * cus;
+}
+
+template <int S2, int OVF, int LEAFB>
+int launch_knn1_refill(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
+                       ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
+  float4* qs = nullptr;
+  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
+  if (rc != PTK_OK) return rc;
+  ptk::Cont cont{};
+  cont.nq = nq;
+  cont.rec = scratch.take<ptk::Record>(nq * ptk::kContSlots);
+  cont.best = scratch.take<uint4>(nq);
+  cont.key = scratch.take<uint8_t>(nq);
+  cont.ids = scratch.take<uint32_t>(nq);
+  cont.meta = scratch.take<uint32_t>(16);
+  if (!cont.rec || !cont.best || !cont.key || !cont.ids || !cont.meta)
+    return fail(PTK_ERR_NOMEM, "scratch block too small");
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+  const float e_inv = inv_ratio(e);
+  PTK_HIP(hipMemsetAsync(cont.meta, 0, 16 * 4, s));
+  {
+    Timer timer(t, s);
+    hipLaunchKernelGGL((ptk::knn1_phase1_kernel<32, OVF, 4, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
+                       e_inv, d_out, cont);
+    timer.stop(0, nq);
+  }
+  {
+    const size_t smem = (size_t)S2 * 64 * 8 + ptk::kQueueSlots * 4;
+    auto kernel = ptk::knn1_phase2_refill_kernel<S2, OVF, LEAFB>;
+    static thread_local int grid_cache = 0;  // per (thread, instantiation); the device set is homogeneous
+    if (grid_cache == 0) grid_cache = persistent_blocks(t, reinterpret_cast<const void*>(kernel), smem);
+    uint32_t grid = (uint32_t)grid_cache;
+    if (grid > blocks) grid = blocks;
+    const uint32_t min_idle = (uint32_t)env_int("PTK_REFILL_MIN_IDLE", 16);
+    if (env_int("PTK_DEBUG_STATS", 0)) {  // debugging aid: instrumented build of the same kernel
+      hipLaunchKernelGGL((ptk::knn1_phase2_refill_kernel<S2, OVF, LEAFB, true>), dim3(grid), dim3(64), smem, s,
+                         t->dev, qs, (uint32_t)nq, e_inv, d_out, cont, cont.meta, min_idle < 1 ? 1u : min_idle);
+      uint32_t h[16];
+      PTK_HIP(hipMemcpyAsync(h, cont.meta, sizeof(h), hipMemcpyDeviceToHost, s));
+      PTK_HIP(hipStreamSynchronize(s));
+      fprintf(stderr, "[refill S=%d LEAFB=%d grid=%u min_idle=%u] wave-iterations %u, active lane-iterations %u "
+              "(%.1f%% of lanes), refills %u, leaf lane-iterations %u, pops %u, max iterations of a wave %u\n",
+              S2, LEAFB, grid, min_idle, h[8], h[9], 100.0 * h[9] / (64.0 * (h[8] ? h[8] : 1)), h[10], h[11], h[12],
+              h[13]);
+      return PTK_OK;
+    }
+    Timer timer(t, s);
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), smem, s, t->dev, qs, (uint32_t)nq, e_inv, d_out, cont,
+                       cont.meta, min_idle < 1 ? 1u : (min_idle > 64 ? 64u : min_idle));
     timer.stop(3, 0);
   }
   PTK_HIP(hipGetLastError());
@@ -648,7 +731,16 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
       case 14: return launch_knn1_persistent<16, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 20: return launch_knn1_two_phase<32, false, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 21: return launch_knn1_two_phase<32, true, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 22: PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch))); return rc;
       case 23: return launch_knn1_two_phase<32, true, 8, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 50: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 51: return launch_knn1_two_phase<32, true, 16, 64, 8, false, true>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 52: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 40: return launch_knn1_refill<16, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 41: return launch_knn1_refill<8, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 42: return launch_knn1_refill<16, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 43: return launch_knn1_refill<16, 64, 2>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 44: return launch_knn1_refill<32, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 30: return launch_knn1_two_phase<32, true, 16, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 31: return launch_knn1_two_phase<32, true, 8, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 32: return launch_knn1_two_phase<32, true, 32, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
@@ -659,8 +751,8 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
     PTK_WITH_OVF(16, (launch_knn1<16, OVF, 64, 4>(t, d_q, perm, nq, e, d_out, s)));
     return rc;
   }
-  // Default: two-phase search, register-only phase 1.
-  PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch)));
+  // Default: two-phase search, wave-uniform-prefix phase 1 (scalar node loads while the lanes agree).
+  PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false, true>(t, d_q, perm, nq, e, d_out, s, scratch)));
   return rc;
 }
 

@@ -11,7 +11,9 @@
 //           extra dependent load.
 //         * points copied into LEAF ORDER as 16-byte records {x, y, z, index}
 //           (z = 0 when dim < 3; y = z = 0 when dim == 1), so a leaf is one
-//           contiguous run of 16-byte loads and needs no index indirection.
+//           contiguous run of 16-byte loads and needs no index indirection;
+//           `begin` counts records of this array (leaves may be padded apart,
+//           see kEncLeafAlign), not positions of `indices`.
 //         Reference encoding (32 bits):
 //             bit 31 = 1: leaf,   bits 30:0  = (begin << cbits) | count
 //             bit 31 = 0: branch, bits 30:29 = split axis OF THE CHILD,
@@ -45,7 +47,11 @@ struct EncPoint {
 static_assert(sizeof(EncNode) == 16 && sizeof(EncPoint) == 16, "device record sizes");
 
 constexpr uint32_t kEncLeafBit = 0x80000000u;
-constexpr uint32_t kEncLeafPad = 8;  // readable records past the last point (== kLeafPad)
+constexpr uint32_t kEncLeafPad = 8;    // readable records past the last point (== kLeafPad)
+// Leaves start on multiples of this many 16-byte records.  8 (one leaf = one 128-byte line) was
+// measured on BASELINE config 2 and is NOT worth it: +25 % point bytes, traversal 3 % slower
+// (profiles/r01e_notes.txt) -- the divergent-gather rate, not line straddling, bounds the leaf scan.
+constexpr uint64_t kEncLeafAlign = 1;
 
 struct TreeStats {
   uint64_t n_leaves = 0;
@@ -124,9 +130,19 @@ inline std::string encode_tree(
   std::string err = analyse_stream(dim, n_points, nodes, n_nodes, st, &branch_id);
   if (!err.empty()) return err;
 
+  // Device positions of the leaves (kEncLeafAlign records apart at least; gaps, if any, repeat
+  // the leaf's last point and are never visited: the count bounds every scan).
+  std::vector<uint64_t> leaf_pos(n_nodes, 0);
+  uint64_t n_slots = 0;
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    const ptk_node& nd = nodes[i];
+    if (nd.right != PTK_LEAF) continue;
+    leaf_pos[i] = n_slots;
+    n_slots += ((uint64_t)(nd.b - nd.a) + kEncLeafAlign - 1) / kEncLeafAlign * kEncLeafAlign;
+  }
   const uint64_t n_branch = n_nodes - st.n_leaves;
   const uint32_t cbits = bits_for(st.max_leaf_count);
-  const uint32_t bbits = bits_for(n_points);
+  const uint32_t bbits = bits_for(n_slots);
   if (cbits + bbits > 31) {
     unsupported = true;
     return "leaf reference needs " + std::to_string(bbits) + " + " + std::to_string(cbits) +
@@ -139,7 +155,7 @@ inline std::string encode_tree(
 
   auto ref_of = [&](uint64_t i) -> uint32_t {
     const ptk_node& nd = nodes[i];
-    if (nd.right == PTK_LEAF) return kEncLeafBit | (nd.a << cbits) | (nd.b - nd.a);
+    if (nd.right == PTK_LEAF) return kEncLeafBit | ((uint32_t)leaf_pos[i] << cbits) | (nd.b - nd.a);
     return (nd.split_dim << 29) | branch_id[i];
   };
 
@@ -154,19 +170,27 @@ inline std::string encode_tree(
     r.right_ref = ref_of(nd.right);
     out.nodes[branch_id[i]] = r;
   }
-  out.points.resize(n_points + kEncLeafPad);
-  for (uint64_t pos = 0; pos < n_points; ++pos) {
-    const int32_t idx = indices[pos];
-    if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
-    const float* p = points + (uint64_t)idx * dim;
-    EncPoint v;
-    v.x = p[0];
-    v.y = dim > 1 ? p[1] : 0.0f;
-    v.z = dim > 2 ? p[2] : 0.0f;
-    v.index = idx;
-    out.points[pos] = v;
+  out.points.assign(n_slots + kEncLeafPad, EncPoint{0.0f, 0.0f, 0.0f, 0});
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    const ptk_node& nd = nodes[i];
+    if (nd.right != PTK_LEAF) continue;
+    const uint64_t count = nd.b - nd.a;
+    const uint64_t slots = (count + kEncLeafAlign - 1) / kEncLeafAlign * kEncLeafAlign;
+    EncPoint v{0.0f, 0.0f, 0.0f, 0};
+    for (uint64_t j = 0; j < slots; ++j) {
+      if (j < count) {
+        const int32_t idx = indices[nd.a + j];
+        if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
+        const float* p = points + (uint64_t)idx * dim;
+        v.x = p[0];
+        v.y = dim > 1 ? p[1] : 0.0f;
+        v.z = dim > 2 ? p[2] : 0.0f;
+        v.index = idx;
+      }
+      out.points[leaf_pos[i] + j] = v;
+    }
   }
-  for (uint32_t i = 0; i < kEncLeafPad; ++i) out.points[n_points + i] = out.points[n_points - 1];
+  for (uint32_t i = 0; i < kEncLeafPad; ++i) out.points[n_slots + i] = out.points[n_slots ? n_slots - 1 : 0];
   out.root_ref = ref_of(0);
   out.cbits = cbits;
   return std::string();

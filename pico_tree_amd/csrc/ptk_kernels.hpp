@@ -697,10 +697,13 @@ constexpr uint32_t kHeavyClass = 4;     // classes >= this are dealt across wave
 // phase 1 needs no allocation and no atomics; the class sort doubles as the compaction.
 struct Cont {
   uint4* best;          // [nq]  {best index, bits(best distance), class, 0} after phase 1
-  Record* rec;          // [nq * kContSlots]  pending records of slot i, shallowest first
+  Record* rec;          // [kContSlots][nq]  record s of slot i at rec[s * nq + i] (a wave stores and
+                        //                   loads one record index as one coalesced run), shallowest first
   uint8_t* key;         // [nq]  7 - class (class = record count, 7 = overflow); 7 = nothing to do
   uint32_t* ids;        // [nq]  slot index (sorted together with key)
   uint32_t* meta;       // [0] continuations  [1] heavy continuations  [2] heavy wavefronts
+  uint64_t nq;          // slots (= queries of the batch)
+  __device__ __forceinline__ Record& record(uint32_t slot, uint32_t s) const { return rec[(uint64_t)s * nq + slot]; }
 };
 
 // Phase 1.  DOUBLE = false: one descent, every far child kept in the LDS ring, filtered
@@ -828,14 +831,165 @@ __global__ __launch_bounds__(64) void knn1_phase1_kernel(
         for (int u = 1; u < kContSlots; ++u) {
           if (src == u) r = keep[u];
         }
-        cont.rec[(uint64_t)e * kContSlots + s] = r;
+        cont.record(e, (uint32_t)s) = r;
       }
     }
   }
 }
 
+// Phase 1 with a wave-uniform prefix (the shipped form).  The batch is spatially sorted, so the 64
+// queries of a wavefront walk the SAME branches for most of the way down (measured: they part
+// ways 4-6 levels above the leaves).  profiles/r01d: phase 1 is bound by the rate at which the
+// vector-memory pipe takes divergent 16-byte loads (59 per wave, ~48 cycles each per CU), so while
+// all lanes agree the node is fetched ONCE, through the scalar cache (s_load_dwordx4 on a
+// readfirstlane'd index), and only the per-lane arithmetic stays on the vector unit.  A ballot
+// after each step tells whether the lanes still agree.  Same two descents as the DOUBLE form
+// above (first: home leaf and its best; second: the far children that pass), same arithmetic,
+// same records -- only where the node bytes come from differs.
+__device__ __forceinline__ uint32_t uniform_value(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+}
+
+template <int LEAFB>
+__global__ __launch_bounds__(64) void knn1_phase1u_kernel(
+    DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
+    Cont cont, uint32_t debug_skip = 0) {
+  // debug_skip (timing experiments only, results incomplete): 1 = no second descent, 2 = no stores, 4 = no leaf.
+  const uint64_t i0 = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  const bool valid = i0 < nq;
+  const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
+  const uint4* __restrict__ nodes = t.nodes;
+  const float4* __restrict__ pts = t.pts;
+  const float4 qrec = qs[i];
+  const float qx = qrec.x, qy = qrec.y, qz = qrec.z;
+  const uint32_t qi = __float_as_uint(qrec.w);
+
+  NnPolicy pol;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  pol.begin_query(qi);
+
+  // ---- first descent: home leaf ----
+  uint32_t ref = t.root_ref;
+  uint32_t shared_levels = 0;  // branches every lane of the wave passed together
+  {
+    bool together = true;
+    while (together && !(ref & kLeafBit)) {
+      const uint32_t uref = uniform_value(ref);
+      const uint4 nd = nodes[uref & kBranchIdxMask];
+      const uint32_t axis = (uref >> 29) & 3u;
+      const float left_max = __uint_as_float(nd.x);
+      const float right_min = __uint_as_float(nd.y);
+      const float v = sel3(axis, qx, qy, qz);
+      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+      ref = go_left ? nd.z : nd.w;
+      const uint64_t b = __ballot(go_left);
+      together = b == 0ull || b == ~0ull;
+      ++shared_levels;
+    }
+    while (!(ref & kLeafBit)) {
+      const uint4 nd = nodes[ref & kBranchIdxMask];
+      const uint32_t axis = (ref >> 29) & 3u;
+      const float left_max = __uint_as_float(nd.x);
+      const float right_min = __uint_as_float(nd.y);
+      const float v = sel3(axis, qx, qy, qz);
+      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+      ref = go_left ? nd.z : nd.w;
+    }
+  }
+  if (!(debug_skip & 4u)) {
+    const uint32_t lv = ref & 0x7FFFFFFFu;
+    const uint32_t begin = lv >> t.cbits;
+    const uint32_t count = lv & t.cmask;
+    for (uint32_t j = 0; j < count; j += LEAFB) {
+      float4 p[LEAFB];
+#pragma unroll
+      for (int u = 0; u < LEAFB; ++u) p[u] = pts[begin + j + u];
+#pragma unroll
+      for (int u = 0; u < LEAFB; ++u) {
+        if (j + u < count) {
+          const float dx = f_sub(qx, p[u].x);
+          const float dy = f_sub(qy, p[u].y);
+          const float dz = f_sub(qz, p[u].z);
+          pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
+        }
+      }
+    }
+  }
+
+  // ---- second descent: the far children that can still matter, shallowest first ----
+  Record keep[kContSlots];
+  uint32_t c = 0;
+  auto consider = [&](uint32_t idx, uint32_t axis, float left_max, float right_min, bool go_left) {
+    const float v = sel3(axis, qx, qy, qz);
+    const float dv = f_sub(go_left ? right_min : left_max, v);
+    // First descent state: box distance 0, offsets 0 => (0 - 0) + new_off, as the reference computes it.
+    const float far_nbd = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
+    if (pol.max() >= far_nbd) {
+      Record r;
+      r.x = idx | (axis << 28) | (go_left ? kRecSide : 0u);
+      r.y = __float_as_uint(far_nbd);
+#pragma unroll
+      for (int s = 0; s < kContSlots; ++s) {
+        if (c == (uint32_t)s) keep[s] = r;
+      }
+      ++c;
+    }
+  };
+  if (!(debug_skip & 1u)) {
+    uint32_t r2 = t.root_ref;
+    // The lanes agreed on exactly the first `shared_levels` steps of the first descent (the last of
+    // which is where they parted); the same holds here because the steps are the same.
+    for (uint32_t l = 0; l < shared_levels; ++l) {
+      const uint32_t uref = uniform_value(r2);
+      const uint32_t idx = uref & kBranchIdxMask;
+      const uint4 nd = nodes[idx];
+      const uint32_t axis = (uref >> 29) & 3u;
+      const float left_max = __uint_as_float(nd.x);
+      const float right_min = __uint_as_float(nd.y);
+      const float v = sel3(axis, qx, qy, qz);
+      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+      consider(idx, axis, left_max, right_min, go_left);
+      r2 = go_left ? nd.z : nd.w;
+    }
+    while (!(r2 & kLeafBit)) {
+      const uint32_t idx = r2 & kBranchIdxMask;
+      const uint32_t axis = (r2 >> 29) & 3u;
+      const uint4 nd = nodes[idx];
+      const float left_max = __uint_as_float(nd.x);
+      const float right_min = __uint_as_float(nd.y);
+      const float v = sel3(axis, qx, qy, qz);
+      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+      consider(idx, axis, left_max, right_min, go_left);
+      r2 = go_left ? nd.z : nd.w;
+    }
+  }
+  if (!valid) return;
+  const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
+  const uint32_t e = (uint32_t)i;
+  if ((debug_skip & 2u) && pol.best_d >= 0.0f) {
+    if (e == 0xFFFFFFFFu) cont.key[0] = (uint8_t)(cls + c + ref);  // keeps the work alive
+    return;
+  }
+  cont.key[e] = (uint8_t)(7u - cls);  // class 0 -> key 7: sorts behind every continuation
+  cont.ids[e] = e;
+  if (cls == 0) {
+    pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
+  } else {
+    cont.best[e] = make_uint4((uint32_t)pol.best_i, __float_as_uint(pol.best_d), cls, 0u);
+  }
+  if (cls != 0 && cls != kContOverflow) {
+#pragma unroll
+    for (int s = 0; s < kContSlots; ++s) {
+      if ((uint32_t)s < c) cont.record(e, (uint32_t)s) = keep[s];
+    }
+  }
+}
+
 // One thread, after the class sort: where the continuations and the heavy classes end.
-__global__ void knn1_phase_meta_kernel(const uint8_t* __restrict__ sorted_key, uint32_t nq, Cont cont) {
+__global__ void knn1_phase_meta_kernel(const uint8_t* __restrict__ sorted_key, uint32_t nq, Cont cont,
+                                       uint32_t heavy_class = kHeavyClass, uint32_t heavy_lanes = 64u,
+                                       uint32_t max_heavy_waves = 0xFFFFFFFFu) {
   auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
     uint32_t lo = 0, hi = nq;
     while (lo < hi) {
@@ -845,29 +999,37 @@ __global__ void knn1_phase_meta_kernel(const uint8_t* __restrict__ sorted_key, u
     return lo;
   };
   const uint32_t n2 = first_at_least(7u);
-  const uint32_t heavy = first_at_least(7u - kHeavyClass + 1u);  // classes >= kHeavyClass
+  const uint32_t heavy = heavy_class > 7u ? 0u : first_at_least(7u - heavy_class + 1u);  // classes >= heavy_class
   cont.meta[0] = n2;
   cont.meta[1] = heavy;
-  cont.meta[2] = (heavy + 63u) / 64u;
+  // Heavy wavefronts run with `heavy_lanes` lanes each (fewer lanes: shorter rounds on the
+  // critical path); if the launch was not sized for that many waves, fall back to full waves.
+  uint32_t hl = heavy_lanes;
+  if ((heavy + hl - 1u) / hl > max_heavy_waves) hl = 64u;
+  cont.meta[2] = (heavy + hl - 1u) / hl;
+  cont.meta[3] = hl;
 }
 
 // Phase 2: one continuation per lane, taken from the class-sorted entry list.
 template <int S, int OVF, int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
-    const uint32_t* __restrict__ sorted_ids) {
+    const uint32_t* __restrict__ sorted_ids, uint32_t debug_mode = 0) {
   const uint32_t n2 = cont.meta[0];
   const uint32_t heavy = cont.meta[1];
   const uint32_t heavy_waves = cont.meta[2];
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
+  // Timing experiments only (results are incomplete): 1 = skip the heavy waves, 2 = only them.
+  if (debug_mode == 1 && wave < heavy_waves) return;
+  if (debug_mode == 2 && wave >= heavy_waves) return;
   // Heavy classes: lane l of wave w takes sorted entry l * heavy_waves + w, so consecutive
   // (spatially adjacent, equally expensive) entries land in different wavefronts.
   uint32_t s;
   bool valid;
   if (wave < heavy_waves) {
     s = lane * heavy_waves + wave;
-    valid = s < heavy;
+    valid = s < heavy && lane < cont.meta[3];
   } else {
     s = heavy + (wave - heavy_waves) * 64u + lane;
     valid = s < n2;
@@ -893,7 +1055,7 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     pol.best_i = (int32_t)start.x;
     pol.best_d = __uint_as_float(start.y);
     for (uint32_t j = 0; j < cls; ++j) {
-      const Record r = cont.rec[(uint64_t)e * kContSlots + j];
+      const Record r = cont.record(e, j);
       st.push(r.x, __uint_as_float(r.y));
     }
     traverse<LEAFB, true>(t, qx, qy, qz, pol, st);
@@ -990,9 +1152,9 @@ __global__ __launch_bounds__(64) void knn1_phase2_persistent_kernel(
     if (state == FETCH) {
       a0 = reinterpret_cast<const uint4*>(qs + e);
       a1 = cont.best + e;
-      a2 = reinterpret_cast<const uint4*>(cont.rec + (uint64_t)e * kContSlots);
-      a3 = a2 + 1;
-      a4 = a2 + 2;
+      a2 = a1;  // the records are fetched below (one 8-byte load each)
+      a3 = a1;
+      a4 = a1;
     } else if (state == LEAF) {
       a0 = reinterpret_cast<const uint4*>(pts + (begin + leaf_j));
       a1 = a0 + 1;
@@ -1031,12 +1193,11 @@ __global__ __launch_bounds__(64) void knn1_phase2_persistent_kernel(
       } else {
         pol.best_i = (int32_t)r1.x;
         pol.best_d = __uint_as_float(r1.y);
-        if (cls > 0) st.push(r2.x, __uint_as_float(r2.y));
-        if (cls > 1) st.push(r2.z, __uint_as_float(r2.w));
-        if (cls > 2) st.push(r3.x, __uint_as_float(r3.y));
-        if (cls > 3) st.push(r3.z, __uint_as_float(r3.w));
-        if (cls > 4) st.push(r4.x, __uint_as_float(r4.y));
-        if (cls > 5) st.push(r4.z, __uint_as_float(r4.w));
+        for (uint32_t j = 0; j < cls; ++j) {
+          const Record r = cont.record(e, j);
+          st.push(r.x, __uint_as_float(r.y));
+        }
+        (void)r2; (void)r3; (void)r4;
         unwind = true;
       }
     } else if (state == NODE) {
@@ -1113,6 +1274,244 @@ __global__ __launch_bounds__(64) void knn1_phase2_persistent_kernel(
         }
       }
     }
+  }
+}
+
+// Phase 2, refill form (the shipped one).  profiles/r01d_*: in knn1_phase2_kernel a wavefront
+// issues 36 M vector loads per launch where ~3 M would do if its lanes were evenly loaded --
+// far-side work per query is wildly uneven (mean 2.3 far leaves, worst 600) and a wave waits for
+// its slowest lane.  Here the grid is persistent (one wave per block, as many blocks as fit on
+// the chip) and a lane that finishes its continuation takes the next one:
+//
+//   * work is handed out in groups of 64 consecutive slots of the Morton-ordered batch through
+//     8 global counters, one per eighth of the batch; a block starts on the eighth of "its" XCD
+//     (blockIdx & 7 -- a locality hint only) and moves on to the others when it runs dry;
+//   * a group's slots that still need work (class != 0) are compacted with a ballot into a small
+//     LDS queue; idle lanes pop from it by prefix rank.  No class sort is needed any more;
+//   * every lane runs one small state machine -- a NODE step (branch, or entering a far child),
+//     or one LEAF batch of LEAFB points followed, after the last batch, by the LDS-only unwind --
+//     one transition per loop iteration with one memory round trip per iteration for the wave.
+//     A lane only ever issues the loads its own state needs (exec-masked), so the vector-memory
+//     pipe sees no padding traffic;
+//   * the queue is only topped up when at least `min_idle` lanes are idle, so the fetch cost
+//     (5 loads per continuation) is amortised.
+//
+// Each lane still replays its own query's reference visit order; results are unchanged.
+constexpr uint32_t kQueueSlots = 128;   // >= 63 + 64
+constexpr uint32_t kNoGroup = 0xFFFFFFFFu;
+
+__device__ __forceinline__ uint32_t wave_broadcast0(uint32_t v) {
+  return (uint32_t)__shfl((int)v, 0);
+}
+
+template <int S, int OVF, int LEAFB, bool STATS = false>
+__global__ __launch_bounds__(64) void knn1_phase2_refill_kernel(
+    DevTree t, const float4* __restrict__ qs, uint32_t nq, float e_inv, Neighbor* __restrict__ out,
+    Cont cont, uint32_t* __restrict__ counters, uint32_t min_idle) {
+  // STATS (debug builds of the launcher only): counters[8..] += {iterations, active lane-iterations,
+  // refills, leaf lane-iterations, unwind pops}, counters[13] = max iterations of one wave.
+  uint32_t s_iter = 0, s_active = 0, s_refill = 0, s_leaf = 0, s_pops = 0;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t lanes_below = (1ull << lane) - 1ull;
+  const uint4* __restrict__ nodes = t.nodes;
+  const float4* __restrict__ pts = t.pts;
+  PTK_LDS uint32_t* queue = (PTK_LDS uint32_t*)(ptk_smem + (size_t)S * 64 * 8);
+
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, lane, spill);
+  NnPolicy pol;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  pol.begin_query(0);
+
+  // Work distribution (all wave-uniform except `tries`, which only lane 0 uses).
+  const uint32_t groups = (nq + 63u) / 64u;
+  const uint32_t per = (groups + 7u) / 8u;  // groups per eighth
+  const uint32_t home = blockIdx.x & 7u;
+  uint32_t tries = 0;
+  bool exhausted = false;
+  uint32_t q_head = 0, q_tail = 0;
+
+  bool active = false, far = false;
+  uint32_t qi = 0, ref = 0, leaf_j = 0, far_meta = 0;
+  float far_val = 0.0f, nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
+  float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+
+  for (;;) {
+    bool unwind = false;
+    bool fresh = false;
+    const uint64_t idle_mask = __ballot(!active);
+    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
+    if (STATS) {
+      ++s_iter;
+      s_active += 64u - n_idle;
+    }
+    if (n_idle >= min_idle || idle_mask == ~0ull) {
+      if (STATS) ++s_refill;
+      // Top up the queue until every idle lane can be served (or the batch is exhausted).
+      while (q_tail - q_head < n_idle && !exhausted) {
+        uint32_t g = kNoGroup;
+        if (lane == 0) {
+          while (tries < 8u) {
+            const uint32_t r = (home + tries) & 7u;
+            const uint32_t first = r * per;
+            const uint32_t len = first >= groups ? 0u : (groups - first < per ? groups - first : per);
+            const uint32_t got = len ? atomicAdd(&counters[r], 1u) : len;
+            if (got < len) {
+              g = first + got;
+              break;
+            }
+            ++tries;
+          }
+        }
+        g = wave_broadcast0(g);
+        if (g == kNoGroup) {
+          exhausted = true;
+          break;
+        }
+        const uint32_t slot = g * 64u + lane;
+        const bool has = slot < nq && cont.key[slot] != 7u;  // key = 7 - class; class 0 is final already
+        const uint64_t m = __ballot(has);
+        if (has) queue[(q_tail + (uint32_t)__popcll(m & lanes_below)) & (kQueueSlots - 1u)] = slot;
+        q_tail += (uint32_t)__popcll(m);
+      }
+      __syncthreads();  // one wavefront per block: orders the queue writes before the reads below
+      const uint32_t avail = q_tail - q_head;
+      if (avail == 0u && idle_mask == ~0ull) break;  // nothing running, nothing left
+      const uint32_t rank = (uint32_t)__popcll(idle_mask & lanes_below);
+      if (!active && rank < avail) {
+        const uint32_t e = queue[(q_head + rank) & (kQueueSlots - 1u)];
+        const float4 qrec = qs[e];
+        const uint4 start = cont.best[e];
+        const uint32_t cls = start.z;
+        Record rr[kContSlots];
+#pragma unroll
+        for (int j = 0; j < kContSlots; ++j) {
+          rr[j].x = 0u;
+          rr[j].y = 0u;
+          if (cls != kContOverflow && (uint32_t)j < cls) rr[j] = cont.record(e, (uint32_t)j);
+        }
+        qx = qrec.x;
+        qy = qrec.y;
+        qz = qrec.z;
+        qi = __float_as_uint(qrec.w);
+        st.top = 0;
+        st.base = 0;
+        nbd = off0 = off1 = off2 = 0.0f;
+        far = false;
+        leaf_j = 0;
+        active = true;
+        fresh = true;
+        if (cls == kContOverflow) {  // too many candidates to carry: the whole search, from the root
+          pol.begin_query(qi);
+          ref = t.root_ref;
+        } else {
+          pol.best_i = (int32_t)start.x;
+          pol.best_d = __uint_as_float(start.y);
+#pragma unroll
+          for (int j = 0; j < kContSlots; ++j) {
+            if ((uint32_t)j < cls) st.push(rr[j].x, __uint_as_float(rr[j].y));
+          }
+          unwind = true;
+        }
+      }
+      q_head += n_idle < avail ? n_idle : avail;
+    }
+
+    // ---- one state transition per lane ----
+    if (active && !fresh) {
+      const bool at_leaf = !far && (ref & kLeafBit) != 0;
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      const uint32_t begin = lv >> t.cbits;
+      const uint32_t count = lv & t.cmask;
+      const uint32_t node_idx = far ? (far_meta & kRecIdxMask) : (ref & kBranchIdxMask);
+      const uint4* addr = at_leaf ? reinterpret_cast<const uint4*>(pts + (begin + leaf_j)) : nodes + node_idx;
+      const uint4 r0 = addr[0];
+      if (!at_leaf) {
+        const float left_max = __uint_as_float(r0.x);
+        const float right_min = __uint_as_float(r0.y);
+        if (!far) {
+          const uint32_t axis = (ref >> 29) & 3u;
+          const float v = sel3(axis, qx, qy, qz);
+          const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+          const float dv = f_sub(go_left ? right_min : left_max, v);
+          const float new_off = f_mul(dv, dv);
+          const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
+          if (pol.max() >= far_nbd) st.push(node_idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
+          ref = go_left ? r0.z : r0.w;
+        } else {
+          const uint32_t axis = (far_meta >> 28) & 3u;
+          const bool far_is_right = (far_meta & kRecSide) != 0;
+          const float dv = f_sub(far_is_right ? right_min : left_max, sel3(axis, qx, qy, qz));
+          const float new_off = f_mul(dv, dv);
+          st.push(kRecUndo | (axis << 28), sel3(axis, off0, off1, off2));
+          st.push(kRecUndo | kRecSide, nbd);
+          off0 = axis == 0 ? new_off : off0;
+          off1 = axis == 1 ? new_off : off1;
+          off2 = axis == 2 ? new_off : off2;
+          nbd = far_val;
+          ref = far_is_right ? r0.w : r0.z;
+          far = false;
+        }
+        leaf_j = 0;
+      } else {
+        uint4 rp[LEAFB > 1 ? LEAFB - 1 : 1];
+#pragma unroll
+        for (int u = 1; u < LEAFB; ++u) rp[u - 1] = addr[u];
+#pragma unroll
+        for (int u = 0; u < LEAFB; ++u) {
+          const uint4 p = u == 0 ? r0 : rp[u > 0 ? u - 1 : 0];
+          if (leaf_j + u < count) {
+            const float dx = f_sub(qx, __uint_as_float(p.x));
+            const float dy = f_sub(qy, __uint_as_float(p.y));
+            const float dz = f_sub(qz, __uint_as_float(p.z));
+            pol.visit((int32_t)p.w, f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
+          }
+        }
+        leaf_j += LEAFB;
+        unwind = leaf_j >= count;
+        if (STATS) ++s_leaf;
+      }
+    }
+
+    if (unwind) {  // LDS only: back up to the next far child worth entering, or finish
+      for (;;) {
+        if (st.empty()) {
+          pol.end_query(qi);
+          active = false;
+          break;
+        }
+        if (STATS) ++s_pops;
+        const Record r = st.pop();
+        const float val = __uint_as_float(r.y);
+        if (r.x & kRecUndo) {
+          if (r.x & kRecSide) {
+            nbd = val;
+          } else {
+            const uint32_t axis = (r.x >> 28) & 3u;
+            off0 = axis == 0 ? val : off0;
+            off1 = axis == 1 ? val : off1;
+            off2 = axis == 2 ? val : off2;
+          }
+          continue;
+        }
+        if (pol.max() >= val) {
+          far = true;
+          far_meta = r.x;
+          far_val = val;
+          break;
+        }
+      }
+    }
+  }
+  if (STATS) {
+    atomicAdd(&counters[10], lane == 0 ? s_refill : 0u);
+    atomicAdd(&counters[8], lane == 0 ? s_iter : 0u);
+    atomicAdd(&counters[9], lane == 0 ? s_active : 0u);
+    atomicAdd(&counters[11], s_leaf);
+    atomicAdd(&counters[12], s_pops);
+    if (lane == 0) atomicMax(&counters[13], s_iter);
   }
 }
 

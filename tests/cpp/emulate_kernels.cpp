@@ -45,6 +45,8 @@ struct WaveFibers {
   std::vector<unsigned char> stacks;
   bool done[kLanes];
   bool pred[kLanes];
+  int value[kLanes];     // deposited by __shfl before parking
+  int snapshot[kLanes];  // the values of the last rendezvous (stable until everyone parks again)
   unsigned long long result = 0;
   int current = -1;
   std::function<void()> body;
@@ -65,6 +67,17 @@ unsigned long long emu_ballot(bool pred) {
   w->pred[lane] = pred;
   swapcontext(&w->lane_ctx[lane], &w->scheduler);  // park until everyone has voted
   return w->result;
+}
+
+// A shuffle is a rendezvous too: every live lane deposits its value, parks, and reads the
+// source lane's value from the snapshot taken when all had parked.
+int emu_shfl(int v, int src_lane) {
+  WaveFibers* w = g_fibers;
+  const int lane = w->current;
+  w->value[lane] = v;
+  w->pred[lane] = false;
+  swapcontext(&w->lane_ctx[lane], &w->scheduler);
+  return w->snapshot[src_lane & 63];
 }
 
 namespace {
@@ -107,6 +120,7 @@ void for_each_wave(uint32_t blocks, F&& f) {
     for (int l = 0; l < WaveFibers::kLanes; ++l) {
       w.done[l] = false;
       w.pred[l] = false;
+      w.value[l] = 0;
       getcontext(&w.lane_ctx[l]);
       w.lane_ctx[l].uc_stack.ss_sp = w.stacks.data() + (size_t)l * WaveFibers::kStack;
       w.lane_ctx[l].uc_stack.ss_size = WaveFibers::kStack;
@@ -129,6 +143,7 @@ void for_each_wave(uint32_t blocks, F&& f) {
         if (!w.done[l] && w.pred[l]) bits |= 1ull << l;
       }
       w.result = bits;
+      for (int l = 0; l < WaveFibers::kLanes; ++l) w.snapshot[l] = w.value[l];
     }
   }
   g_fibers = nullptr;
@@ -262,7 +277,9 @@ int emu_persistent(void* h, int mode, const float* q, uint64_t nq, uint32_t k, f
 
 // The two-phase k = 1 search: phase 1, class sort (stable counting sort standing in for the
 // device radix pass), phase 2.  variant: 0 = LDS ring phase 1, 1 = double-descent phase 1,
-// 2 = tiny rings everywhere (spill paths), 3 / 4 = persistent phase 2 (normal / tiny ring).
+// 2 = tiny rings everywhere (spill paths), 3 / 4 = persistent phase 2 (normal / tiny ring),
+// 5 / 6 = refill phase 2 (shipped geometry / tiny ring with eager refill),
+// 7 / 8 = wave-uniform-prefix phase 1 followed by the refill / the class-sorted phase 2.
 int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint32_t* perm, int variant,
                        ptk_neighbor* out) {
   auto* t = static_cast<Emu*>(h);
@@ -275,13 +292,35 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   std::vector<uint4> cbest(nq);
   std::vector<uint8_t> ckey(nq, 0xEE);
   std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(16, 0);
-  ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data()};
-  if (variant == 0)
+  ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
+  if (variant == 7 || variant == 8)  // wave-uniform prefix phase 1 (ballots: lanes run as fibers)
+    for_each_wave((uint32_t)((nq + 63) / 64), [&] {
+      if (variant == 7) ptk::knn1_phase1u_kernel<4>(t->dev, qs.data(), nq, e_inv, o, cont);
+      else ptk::knn1_phase1u_kernel<1>(t->dev, qs.data(), nq, e_inv, o, cont);
+    });
+  else if (variant == 0)
     for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
   else if (variant == 1 || variant >= 3)
     for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
   else
     for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<4, 2048, 1, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
+  if (variant >= 5 && variant <= 7) {  // refill phase 2: no class sort (5, 7: shipped ring, 6: tiny ring + eager refill)
+    std::vector<uint32_t> counters(8, 0);
+    const uint32_t waves = 3;  // the first wave drains the batch; the others find it exhausted
+    if (variant != 6)
+      for_each_wave(waves, [&] {
+        ptk::knn1_phase2_refill_kernel<16, 2048, 4>(t->dev, qs.data(), (uint32_t)nq, e_inv, o, cont, counters.data(),
+                                                   16u);
+      });
+    else
+      for_each_wave(waves, [&] {
+        ptk::knn1_phase2_refill_kernel<4, 2048, 1>(t->dev, qs.data(), (uint32_t)nq, e_inv, o, cont, counters.data(),
+                                                  1u);
+      });
+    int todo = 0;
+    for (uint64_t i = 0; i < nq; ++i) todo += ckey[i] != 7;
+    return todo;
+  }
   // stable sort by key (what the device's radix pass does)
   std::vector<uint32_t> sorted(nq);
   std::vector<uint8_t> sorted_key(nq);
@@ -298,7 +337,7 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   blockIdx.x = 0;
   threadIdx.x = 0;
   ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont);
-  if (variant >= 3) {  // persistent phase 2 (variant 4: tiny ring)
+  if (variant == 3 || variant == 4) {  // persistent phase 2 (variant 4: tiny ring)
     const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
     if (variant == 3)
       for_each_wave(chunks, [&] {
@@ -324,6 +363,25 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     }
   }
   return (int)meta[0];
+}
+
+// Phase 1 only: the class (0..7) and the home-leaf best distance of every query (analysis tools).
+int emu_phase1(void* h, const float* q, uint64_t nq, uint8_t* cls_out, float* best_out) {
+  auto* t = static_cast<Emu*>(h);
+  if (nq == 0) return 0;
+  std::vector<float4> qs = pack(q, t->dim, nullptr, nq);
+  std::vector<ptk::Record> crec(nq * ptk::kContSlots + 8);
+  std::vector<uint4> cbest(nq);
+  std::vector<uint8_t> ckey(nq, 0xEE);
+  std::vector<uint32_t> cids(nq), meta(16, 0);
+  std::vector<ptk::Neighbor> o(nq);
+  ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
+  for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, 1.0f, o.data(), cont); }, 64);
+  for (uint64_t i = 0; i < nq; ++i) {
+    cls_out[i] = (uint8_t)(7 - ckey[i]);
+    best_out[i] = ckey[i] == 7 ? o[i].distance : __uint_as_float(cbest[i].y);
+  }
+  return 0;
 }
 
 // Morton keys + identity ids exactly as the device computes them.

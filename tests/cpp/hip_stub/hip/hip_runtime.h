@@ -40,6 +40,9 @@ inline int32_t __float_as_int(float f) { int32_t i; std::memcpy(&i, &f, 4); retu
 unsigned long long emu_ballot(bool pred);
 inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
+int emu_shfl(int v, int src_lane);
+inline int __shfl(int v, int src_lane) { return emu_shfl(v, src_lane); }
+inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl(v, 0); }  // all lanes alive where it is used
 inline void __syncthreads() { (void)emu_ballot(false); }  // single-wave blocks only
 
 // Lanes run one after the other (or as cooperative fibers), so a plain read-modify-write is atomic.
@@ -47,6 +50,13 @@ template <typename T>
 inline T atomicAdd(T* p, T v) {
   T old = *p;
   *p = old + v;
+  return old;
+}
+
+template <typename T>
+inline T atomicMax(T* p, T v) {
+  T old = *p;
+  if (v > old) *p = v;
   return old;
 }
 

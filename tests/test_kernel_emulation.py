@@ -113,3 +113,24 @@ def test_morton_keys_follow_the_curve():
     jump = lambda o: float(np.linalg.norm(np.diff(q[o], axis=0), axis=1).mean())  # noqa: E731
     assert jump(perm) < 0.25 * jump(np.arange(len(q)))
     del host
+
+
+@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "self", "lidar", "root-is-leaf",
+                                                                  "dim2", "leaf1")],
+                         ids=lambda c: c[0])
+def test_emulated_refill_phase2_equals_oracle(case):
+    """Two-phase k = 1 search with the refill phase 2 (persistent waves, ballot-compacted work
+    queue, per-lane state machine): variant 5 = shipped geometry, 6 = 4-slot ring (every record
+    takes the spill path), one-point leaf batches and a refill whenever a single lane is idle."""
+    _, pts, q, leaf, _ = case
+    q = q[:1500]
+    emu = EmulatedTree(pts, leaf)
+    ref = oracle.Oracle(pts, leaf, "port")
+    perm, _ = emu.morton_permutation(q)
+    want = ref.search_knn(q, 1)
+    for variant in (5, 6, 7, 8):  # 7 / 8: wave-uniform-prefix phase 1 + refill / class-sorted phase 2
+        for p in (None, perm):
+            got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
+            assert got.tobytes() == want.tobytes()
+    got, _ = emu.two_phase_knn1(q, e=1.4, perm=perm, variant=5)
+    assert got.tobytes() == ref.search_knn(q, 1, e=1.4).tobytes()
