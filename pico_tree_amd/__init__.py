@@ -150,11 +150,22 @@ def _is_torch(x) -> bool:
 class DArray:
     """Ragged result of a radius (or box) search: a sequence of numpy arrays.
 
-    Same role as the reference's ``DArray`` (``_pyco_tree/darray.hpp:31-288``)
-    but stored flat: row ``i`` is ``flat[offsets[i]:offsets[i + 1]]``.
+    Same role and constructor as the reference's ``DArray``
+    (``_pyco_tree/darray.hpp:31-288``, ``def_darray.cpp``): ``DArray(dtype)`` makes an
+    empty one to be filled by ``search_radius(..., nns)``; it is a sequence (``len``,
+    indexing incl. negative indices and slices, iteration, truthiness).  Stored flat:
+    row ``i`` is ``flat[offsets[i]:offsets[i + 1]]`` (a view, no copy).
     """
 
-    def __init__(self, offsets: np.ndarray, flat: np.ndarray):
+    def __init__(self, dtype=None, flat=None, *, offsets=None):
+        if isinstance(dtype, np.ndarray) and isinstance(flat, np.ndarray):
+            offsets, dtype = dtype, None  # DArray(offsets, flat): the internal form
+        if flat is None:
+            dt = np.dtype(dtype if dtype is not None else NEIGHBOR)
+            if dt != NEIGHBOR and dt != np.dtype(np.int32):
+                raise ValueError("unexpected dtype for DArray")
+            flat = np.empty(0, dtype=dt)
+            offsets = np.zeros(1, dtype=np.uint64)
         self.offsets = offsets
         self.flat = flat
 
@@ -168,8 +179,15 @@ class DArray:
     def __bool__(self) -> bool:
         return len(self) > 0
 
-    def __getitem__(self, i: int) -> np.ndarray:
+    def __getitem__(self, i):
         n = len(self)
+        if isinstance(i, slice):
+            rows = [self[j] for j in range(*i.indices(n))]
+            off = np.zeros(len(rows) + 1, dtype=np.uint64)
+            if rows:
+                off[1:] = np.cumsum([len(r) for r in rows])
+            flat = np.concatenate(rows) if rows else np.empty(0, dtype=self.dtype)
+            return DArray(off, flat.astype(self.dtype, copy=False))
         if i < 0:
             i += n
         if not 0 <= i < n:
@@ -179,6 +197,17 @@ class DArray:
     def __iter__(self):
         for i in range(len(self)):
             yield self[i]
+
+    def _assign(self, offsets: np.ndarray, flat: np.ndarray) -> None:
+        """Takes a new result; storage is kept when the total size is unchanged (the
+        reference re-uses each row's memory when its size allows, darray.hpp)."""
+        if flat.dtype != self.flat.dtype:
+            raise ValueError("unexpected dtype_neighbor for data")
+        if len(flat) == len(self.flat) and len(flat) > 0:
+            np.copyto(self.flat, flat)
+        else:
+            self.flat = flat
+        self.offsets = offsets
 
 
 class DeviceNeighbors:
@@ -394,7 +423,7 @@ class KdTree:
         lib.ptk_free(rows)
         if nns is None:
             return DArray(offsets, flat)
-        nns.offsets, nns.flat = offsets, flat
+        nns._assign(offsets, flat)
         return nns
 
     def search_radius_device(self, q, radius: float, e: float = 1.0, sort: bool = False):

@@ -27,6 +27,7 @@
 #include "ptk.h"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#include "ptk_kernels_nd.hpp"
 
 // Host-side builder: the product's own header-only flat-tree builder.
 #include "pico_tree/internal/flat_tree.hpp"
@@ -110,8 +111,11 @@ struct ptk_tree {
   ptk::DevTree dev{};
   void* d_nodes = nullptr;
   void* d_pts = nullptr;
+  void* d_axes = nullptr;   // dim > 3 only
+  void* d_index = nullptr;  // dim > 3 only
+  ptk::DevTreeND dev_nd{};
   uint64_t device_bytes = 0;
-  bool gpu_layout = false;  // false: dim > 3 (not yet on the device)
+  bool gpu_layout = false;
 
   std::atomic<int> reorder{PTK_REORDER_AUTO};
   mutable Profile profile;
@@ -145,8 +149,33 @@ int analyse(ptk_tree& t) {
 int upload(ptk_tree& t, const float* points) {
   int rc = analyse(t);
   if (rc != PTK_OK) return rc;
-  if (t.dim > 3) {
-    t.gpu_layout = false;  // generic-dimension kernels are not built yet
+  if (t.dim > 3) {  // any-dimension layout (ptk_kernels_nd.hpp)
+    ptk::TreeStats st;
+    ptk::EncodedTreeND enc;
+    bool unsupported = false;
+    std::string err = ptk::encode_tree_nd(t.dim, t.n_points, points, t.nodes.data(), t.nodes.size(),
+                                          t.indices.data(), st, enc, unsupported);
+    if (!err.empty()) return fail(unsupported ? PTK_ERR_UNSUPPORTED : PTK_ERR_INVALID, "%s", err.c_str());
+    const size_t nb = enc.nodes.size() * sizeof(uint4), ab = enc.axes.size() * 4, pb = enc.points.size() * 4,
+                 ib = enc.index.size() * 4;
+    PTK_HIP(hipMalloc(&t.d_nodes, nb));
+    PTK_HIP(hipMalloc(&t.d_axes, ab));
+    PTK_HIP(hipMalloc(&t.d_pts, pb));
+    PTK_HIP(hipMalloc(&t.d_index, ib));
+    PTK_HIP(hipMemcpy(t.d_nodes, enc.nodes.data(), nb, hipMemcpyHostToDevice));
+    PTK_HIP(hipMemcpy(t.d_axes, enc.axes.data(), ab, hipMemcpyHostToDevice));
+    PTK_HIP(hipMemcpy(t.d_pts, enc.points.data(), pb, hipMemcpyHostToDevice));
+    PTK_HIP(hipMemcpy(t.d_index, enc.index.data(), ib, hipMemcpyHostToDevice));
+    t.device_bytes = nb + ab + pb + ib;
+    t.dev_nd.nodes = static_cast<const uint4*>(t.d_nodes);
+    t.dev_nd.axes = static_cast<const uint32_t*>(t.d_axes);
+    t.dev_nd.pts = static_cast<const float*>(t.d_pts);
+    t.dev_nd.index = static_cast<const int32_t*>(t.d_index);
+    t.dev_nd.root_ref = enc.root_ref;
+    t.dev_nd.cbits = enc.cbits;
+    t.dev_nd.cmask = (1u << enc.cbits) - 1u;
+    t.dev_nd.dim = t.dim;
+    t.gpu_layout = true;
     return PTK_OK;
   }
   ptk::TreeStats st;
@@ -402,8 +431,7 @@ int check_search(const ptk_tree* t, const void* q, uint64_t nq) {
   if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
   if (nq > 0 && q == nullptr) return fail(PTK_ERR_INVALID, "null query buffer");
   if (t->device == kDeviceNone) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
-  if (!t->gpu_layout)
-    return fail(PTK_ERR_UNSUPPORTED, "dimension %u: only dim <= 3 runs on the device in this build", t->dim);
+  if (!t->gpu_layout) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
   return PTK_OK;
 }
 
@@ -699,6 +727,61 @@ int launch_knn1_refill(const ptk_tree* t, const float* d_q, const uint32_t* perm
   return PTK_OK;
 }
 
+// ---- any dimension (dim > 3) -----------------------------------------------------------------
+// LDS per 64-lane block: record ring + q[dim] + off[dim] (+ the k-list while it fits).
+constexpr size_t kMaxLdsBytes = 160 * 1024;
+
+template <int OVF>
+int launch_knn_nd(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t k, float e, ptk::Neighbor* d_out,
+                  hipStream_t s) {
+  constexpr int S = 16;
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+  const size_t base = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
+  if (base > kMaxLdsBytes)
+    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
+  const size_t list_bytes = (size_t)k * 64 * 8;
+  const bool list_lds = base + list_bytes <= 64 * 1024;
+  const size_t smem = base + (list_lds ? list_bytes : 0);
+  Timer timer(t, s);
+  if (list_lds) {
+    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, true>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
+                       inv_ratio(e), d_out);
+  } else {
+    int rc = allow_lds(ptk::knn_nd_kernel<S, OVF, false>, smem);
+    if (rc != PTK_OK) return rc;
+    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, false>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
+                       inv_ratio(e), d_out);
+  }
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
+template <int OVF>
+int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e, bool fill,
+                     uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out, hipStream_t s) {
+  constexpr int S = 16;
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+  const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
+  if (smem > kMaxLdsBytes)
+    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
+  Timer timer(t, s);
+  if (!fill) {
+    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, false>, smem);
+    if (rc != PTK_OK) return rc;
+    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, false>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
+                       radius, inv_ratio(e), d_counts, d_offsets, d_out);
+  } else {
+    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, true>, smem);
+    if (rc != PTK_OK) return rc;
+    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, true>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
+                       radius, inv_ratio(e), d_counts, d_offsets, d_out);
+  }
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
 // Runs CALL with OVF bound to the spill capacity the tree's depth needs.
 #define PTK_WITH_OVF(SLDS, CALL)                                                                            \
   switch (ovf_class(t, SLDS)) {                                                                             \
@@ -843,6 +926,8 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
     if (t->d_pts) (void)hipFree(t->d_pts);
+    if (t->d_axes) (void)hipFree(t->d_axes);
+    if (t->d_index) (void)hipFree(t->d_index);
   }
   delete t;
 }
@@ -891,6 +976,10 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   hipStream_t s = static_cast<hipStream_t>(stream);
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  if (t->dim > 3) {
+    PTK_WITH_OVF(16, (launch_knn_nd<OVF>(t, d_q, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    return rc;
+  }
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) + (k == 1 ? two_phase_scratch_bytes(nq) : 0));
@@ -949,6 +1038,17 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
   if (nq == 0) return PTK_OK;
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  if (t->dim > 3) {
+    PTK_WITH_OVF(16, (launch_radius_nd<OVF>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
+                                            reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    if (rc == PTK_OK && fill && sort) {
+      const uint32_t sort_blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+      hipLaunchKernelGGL(ptk::sort_rows_kernel, dim3(sort_blocks), dim3(ptk::kBlock), 0, s, nq, d_offsets,
+                         reinterpret_cast<ptk::Neighbor*>(d_out));
+      PTK_HIP(hipGetLastError());
+    }
+    return rc;
+  }
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s);
   rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);

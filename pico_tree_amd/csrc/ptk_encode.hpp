@@ -196,4 +196,57 @@ inline std::string encode_tree(
   return std::string();
 }
 
+// ---- any dimension (dim > 3): see ptk_kernels_nd.hpp -----------------------------------------
+struct EncodedTreeND {
+  std::vector<EncNode> nodes;     // per branch; refs carry no axis
+  std::vector<uint32_t> axes;     // per branch
+  std::vector<float> points;      // leaf order, row-major (n_points x dim)
+  std::vector<int32_t> index;     // leaf order: original index
+  uint32_t root_ref = 0;
+  uint32_t cbits = 0;
+};
+
+inline std::string encode_tree_nd(
+    uint32_t dim, uint64_t n_points, const float* points, const ptk_node* nodes, uint64_t n_nodes,
+    const int32_t* indices, TreeStats& st, EncodedTreeND& out, bool& unsupported) {
+  unsupported = false;
+  std::vector<uint32_t> branch_id;
+  std::string err = analyse_stream(dim, n_points, nodes, n_nodes, st, &branch_id);
+  if (!err.empty()) return err;
+  const uint64_t n_branch = n_nodes - st.n_leaves;
+  const uint32_t cbits = bits_for(st.max_leaf_count);
+  if (cbits + bits_for(n_points) > 31) {
+    unsupported = true;
+    return "leaf reference does not fit 31 bits: n_points x max leaf size too large";
+  }
+  if (n_branch >= (1ull << 30)) {
+    unsupported = true;
+    return "more than 2^30 branch nodes";
+  }
+  auto ref_of = [&](uint64_t i) -> uint32_t {
+    const ptk_node& nd = nodes[i];
+    if (nd.right == PTK_LEAF) return kEncLeafBit | (nd.a << cbits) | (nd.b - nd.a);
+    return branch_id[i];
+  };
+  out.nodes.assign(n_branch > 0 ? n_branch : 1, EncNode{0, 0, 0, 0});
+  out.axes.assign(n_branch > 0 ? n_branch : 1, 0u);
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    const ptk_node& nd = nodes[i];
+    if (nd.right == PTK_LEAF) continue;
+    out.nodes[branch_id[i]] = EncNode{nd.a, nd.b, ref_of(i + 1), ref_of(nd.right)};
+    out.axes[branch_id[i]] = nd.split_dim;
+  }
+  out.points.resize(n_points * dim);
+  out.index.resize(n_points);
+  for (uint64_t pos = 0; pos < n_points; ++pos) {
+    const int32_t idx = indices[pos];
+    if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
+    std::memcpy(&out.points[pos * dim], points + (uint64_t)idx * dim, dim * sizeof(float));
+    out.index[pos] = idx;
+  }
+  out.root_ref = ref_of(0);
+  out.cbits = cbits;
+  return std::string();
+}
+
 }  // namespace ptk

@@ -1,0 +1,175 @@
+// ptk_kernels_nd.hpp -- gfx950 device code for trees of any dimension (dim > 3).
+//
+// Same algorithm and the same per-lane replay of the reference visit order as the 3-D
+// kernels of ptk_kernels.hpp (see the header there): one query per lane, near child first,
+// far child iff `visitor.max() >= node_box_distance`
+// (/root/reference/src/pico_tree/pico_tree/internal/kd_tree_search.hpp:52-105), one LIFO of
+// 8-byte records per lane (pending / undo_off / undo_nbd).  What changes with the dimension
+// is where the per-lane vectors live: the query q[dim] and the per-axis offsets off[dim]
+// (search.hpp:111) cannot sit in registers for a run-time dim, so they are staged in LDS,
+// laid out [axis][lane] (a wave's access to one axis is one conflict-free ds_read_b32).
+// Point coordinates stream from HBM in leaf order (row-major, `dim` floats per point, no
+// index indirection) and are accumulated left to right from d = 0 exactly like
+// internal::sum (metric.hpp:36-51): d = (((0 + t0) + t1) + ...) with t = (q - p) * (q - p).
+//
+// Layouts (ptk_encode.hpp, encode_tree_nd):
+//   nodes : 16 B per branch {left_max, right_min, left_ref, right_ref}
+//   axes  : 4 B per branch, the split axis
+//   ref   : bit 31 = leaf; leaf = (begin << cbits) | count; branch = branch index
+//   record: x = bit 31 undo | bit 30 (pending: far child is the right one; undo: nbd) |
+//               bits 29:0 (pending: branch index; undo_off: axis),  y = float bits
+
+#pragma once
+
+#include "ptk_kernels.hpp"
+
+namespace ptk {
+
+struct DevTreeND {
+  const uint4* nodes;
+  const uint32_t* axes;
+  const float* pts;     // leaf order, row-major
+  const int32_t* index; // leaf order: original index of each point
+  uint32_t root_ref;
+  uint32_t cbits;
+  uint32_t cmask;
+  uint32_t dim;
+};
+
+constexpr uint32_t kNdIdxMask = 0x3FFFFFFFu;
+
+typedef PTK_LDS float LdsFloat;
+
+template <class Policy, class StackT>
+__device__ __forceinline__ void traverse_nd(
+    const DevTreeND& t, LdsFloat* q, LdsFloat* off, uint32_t stride, Policy& pol, StackT& st) {
+  const uint4* __restrict__ nodes = t.nodes;
+  const uint32_t* __restrict__ axes = t.axes;
+  const float* __restrict__ pts = t.pts;
+  const int32_t* __restrict__ index = t.index;
+  const uint32_t dim = t.dim;
+  uint32_t ref = t.root_ref;
+  float nbd = 0.0f;
+
+  for (;;) {
+    while (!(ref & kLeafBit)) {
+      const uint4 nd = nodes[ref];
+      const uint32_t axis = axes[ref];
+      const float left_max = __uint_as_float(nd.x);
+      const float right_min = __uint_as_float(nd.y);
+      const float v = q[axis * stride];
+      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;  // search.hpp:76
+      const float dv = f_sub(go_left ? right_min : left_max, v);
+      const float new_off = f_mul(dv, dv);                                          // :80,84
+      const float far_nbd = f_add(f_sub(nbd, off[axis * stride]), new_off);         // :94
+      if (pol.max() >= far_nbd) st.push(ref | (go_left ? kRecSide : 0u), far_nbd);
+      ref = go_left ? nd.z : nd.w;
+    }
+    {
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      const uint32_t begin = lv >> t.cbits;
+      const uint32_t count = lv & t.cmask;
+      for (uint32_t j = 0; j < count; ++j) {
+        const float* p = pts + (uint64_t)(begin + j) * dim;
+        float d = 0.0f;
+        for (uint32_t a = 0; a < dim; ++a) {
+          const float diff = f_sub(q[a * stride], p[a]);
+          d = f_add(d, f_mul(diff, diff));
+        }
+        pol.visit(index[begin + j], d);
+      }
+    }
+    for (;;) {
+      if (st.empty()) return;
+      const Record r = st.pop();
+      const float val = __uint_as_float(r.y);
+      if (r.x & kRecUndo) {
+        if (r.x & kRecSide) {
+          nbd = val;
+        } else {
+          off[(r.x & kNdIdxMask) * stride] = val;
+        }
+        continue;
+      }
+      if (pol.max() >= val) {  // the authoritative test of search.hpp:99
+        const uint32_t idx = r.x & kNdIdxMask;
+        const bool far_is_right = (r.x & kRecSide) != 0;
+        const uint4 nd = nodes[idx];
+        const uint32_t axis = axes[idx];
+        const float plane = far_is_right ? __uint_as_float(nd.y) : __uint_as_float(nd.x);
+        const float dv = f_sub(plane, q[axis * stride]);
+        const float new_off = f_mul(dv, dv);
+        st.push(kRecUndo | axis, off[axis * stride]);
+        st.push(kRecUndo | kRecSide, nbd);
+        off[axis * stride] = new_off;
+        nbd = val;
+        ref = far_is_right ? nd.w : nd.z;
+        break;
+      }
+    }
+  }
+}
+
+// LDS of a block: [record ring S][q dim][off dim][k-list k], all [slot][lane].
+template <int S>
+__device__ __forceinline__ void stage_query_nd(
+    const float* __restrict__ queries, uint32_t dim, uint64_t qi, LdsFloat*& q, LdsFloat*& off) {
+  LdsFloat* base = (LdsFloat*)(ptk_smem + (size_t)S * 64 * 8);
+  q = base + threadIdx.x;
+  off = base + (size_t)dim * 64 + threadIdx.x;
+  const float* row = queries + qi * dim;
+  for (uint32_t a = 0; a < dim; ++a) {
+    q[a * 64] = row[a];
+    off[a * 64] = 0.0f;  // search.hpp:47
+  }
+}
+
+template <int S, int OVF, bool LIST_LDS>
+__global__ __launch_bounds__(64) void knn_nd_kernel(
+    DevTreeND t, const float* __restrict__ queries, uint64_t nq, uint32_t k, float e_inv,
+    Neighbor* __restrict__ out) {
+  const uint64_t qi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (qi >= nq) return;
+  LdsFloat *q, *off;
+  stage_query_nd<S>(queries, t.dim, qi, q, off);
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  KnnPolicy<LIST_LDS> pol;
+  if constexpr (LIST_LDS) {
+    pol.list = (LdsWord*)(ptk_smem + (size_t)S * 64 * 8 + (size_t)t.dim * 64 * 8) + threadIdx.x;
+    pol.stride = 64;
+  } else {
+    pol.list = out + qi * k;
+    pol.stride = 1;
+  }
+  pol.k = k;
+  pol.filled = 0;
+  pol.worst = 3.402823466e+38f;
+  pol.e_inv = e_inv;
+  pol.out = out;
+  traverse_nd(t, q, off, 64u, pol, st);
+  pol.end_query((uint32_t)qi);
+}
+
+template <int S, int OVF, bool FILL>
+__global__ __launch_bounds__(64) void radius_nd_kernel(
+    DevTreeND t, const float* __restrict__ queries, uint64_t nq, float radius, float e_inv,
+    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out) {
+  const uint64_t qi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (qi >= nq) return;
+  LdsFloat *q, *off;
+  stage_query_nd<S>(queries, t.dim, qi, q, off);
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  RadiusPolicy<FILL> pol;
+  pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
+  pol.e_inv = e_inv;
+  pol.count = 0;
+  pol.out = FILL ? out + offsets[qi] : nullptr;
+  traverse_nd(t, q, off, 64u, pol, st);
+  if (!FILL) counts[qi] = pol.count;
+}
+
+}  // namespace ptk

@@ -25,6 +25,7 @@ thread_local dim3 blockDim;
 #include "ptk.h"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#include "ptk_kernels_nd.hpp"
 
 namespace ptk {
 unsigned char ptk_smem[192 * 1024] __attribute__((aligned(16)));
@@ -86,8 +87,10 @@ thread_local std::string g_err;
 
 struct Emu {
   ptk::EncodedTree enc;
+  ptk::EncodedTreeND enc_nd;  // dim > 3
   ptk::TreeStats st;
   ptk::DevTree dev;
+  ptk::DevTreeND dev_nd;
   uint32_t dim;
 };
 
@@ -165,6 +168,23 @@ void* emu_create(const float* points, uint64_t n, uint32_t dim, const ptk_node* 
                  const int32_t* indices) {
   auto* e = new Emu;
   bool unsupported = false;
+  if (dim > 3) {
+    g_err = ptk::encode_tree_nd(dim, n, points, nodes, n_nodes, indices, e->st, e->enc_nd, unsupported);
+    if (!g_err.empty()) {
+      delete e;
+      return nullptr;
+    }
+    e->dim = dim;
+    e->dev_nd.nodes = reinterpret_cast<const uint4*>(e->enc_nd.nodes.data());
+    e->dev_nd.axes = e->enc_nd.axes.data();
+    e->dev_nd.pts = e->enc_nd.points.data();
+    e->dev_nd.index = e->enc_nd.index.data();
+    e->dev_nd.root_ref = e->enc_nd.root_ref;
+    e->dev_nd.cbits = e->enc_nd.cbits;
+    e->dev_nd.cmask = (1u << e->enc_nd.cbits) - 1u;
+    e->dev_nd.dim = dim;
+    return e;
+  }
   g_err = ptk::encode_tree(dim, n, points, nodes, n_nodes, indices, e->st, e->enc, unsupported);
   if (!g_err.empty()) {
     delete e;
@@ -193,6 +213,20 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
   const float e_inv = 1.0f / e;
   const uint32_t need = 2 * t->st.max_depth + 2;
   if (need > 4 + 2048) return -2;
+  if (t->dim > 3) {  // any-dimension kernels (no launch permutation)
+    if (perm != nullptr) return -3;
+    const size_t base = (size_t)(small_stack ? 4 : 16) * 64 * 8 + (size_t)t->dim * 64 * 8;
+    if (base + (list_in_lds ? (size_t)k * 64 * 8 : 0) > sizeof(ptk::ptk_smem)) return -2;
+    if (small_stack && list_in_lds)
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, true>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+    else if (small_stack)
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, false>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+    else if (list_in_lds)
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, true>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+    else
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, false>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+    return 0;
+  }
   if (k == 1) {
     if (small_stack)
       for_each_lane(nq, [&] { ptk::knn1_kernel<4, 2048, 64, 1>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 64);
@@ -216,6 +250,12 @@ int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e
                      uint64_t* counts) {
   auto* t = static_cast<Emu*>(h);
   const float e_inv = 1.0f / e;
+  if (t->dim > 3) {
+    for_each_lane(nq, [&] {
+      ptk::radius_nd_kernel<8, 2048, false>(t->dev_nd, q, nq, radius, e_inv, counts, nullptr, nullptr);
+    }, 64);
+    return 0;
+  }
   for_each_lane(nq, [&] {
     ptk::radius_kernel<8, 2048, 64, 4, false>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, nullptr, nullptr);
   }, 64);
@@ -227,6 +267,13 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   auto* t = static_cast<Emu*>(h);
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
   const float e_inv = 1.0f / e;
+  if (t->dim > 3) {
+    for_each_lane(nq, [&] {
+      ptk::radius_nd_kernel<16, 2048, true>(t->dev_nd, q, nq, radius, e_inv, nullptr, offsets, o);
+    }, 64);
+    if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
+    return 0;
+  }
   for_each_lane(nq, [&] {
     ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o);
   }, 64);

@@ -120,6 +120,47 @@ def test_low_dimensions(gpu, dim):
     assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
 
 
+@pytest.mark.parametrize("dim,n,nq,radius", [(4, 30_000, 8_000, 0.01), (5, 30_000, 8_000, 0.03), (8, 20_000, 4_000, 0.15),
+                                             (16, 20_000, 2_000, 0.9), (64, 5_000, 500, 8.0),
+                                             (128, 4_000, 300, 18.0)])
+def test_any_dimension(gpu, dim, n, nq, radius):
+    """dim > 3 runs the any-dimension kernels (query and offsets staged in LDS)."""
+    pts, q = ds.uniform_cloud(n, dim, 3), ds.uniform_cloud(nq, dim, 4)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 9, device=gpu)
+    ref = oracle.Oracle(pts, 9, "port")
+    assert tree.search_knn(q, 1).tobytes() == ref.search_knn(q, 1)[:, 0].tobytes()
+    for k in (6, 40):
+        assert tree.search_knn(q, k).tobytes() == ref.search_knn(q, k).tobytes()
+    assert tree.search_knn(q, 5, 1.3).tobytes() == ref.search_knn(q, 5, e=1.3).tobytes()
+    got = tree.search_radius(q, radius)
+    off, flat = ref.search_radius(q, radius)
+    assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+    assert off[-1] > 0
+
+
+@pytest.mark.parametrize("name", ["g_small_3d", "g_small_2d", "g_small_5d", "g_ties_3d"])
+def test_golden_vectors_on_the_device(gpu, name):
+    """The committed fixtures (outputs of the compiled reference) through the HIP path."""
+    from tests.test_oracle import check_against_golden, load
+
+    g = load(name)
+
+    class Adaptor:
+        def __init__(self):
+            self.tree = pt.KdTree(np.ascontiguousarray(g["points"]), pt.Metric.L2Squared, int(g["max_leaf_size"]),
+                                  device=gpu)
+
+        def search_knn(self, q, k, e=None):
+            r = self.tree.search_knn(np.ascontiguousarray(q), k, *(() if e is None else (e,)))
+            return r[:, None] if k == 1 else r
+
+        def search_radius(self, q, radius, sort=False, e=None):
+            r = self.tree.search_radius(np.ascontiguousarray(q), radius, *(() if e is None else (e,)), sort=sort)
+            return r.offsets, r.flat
+
+    check_against_golden(Adaptor(), g)
+
+
 def test_deep_tree_uses_scratch_overflow(gpu):
     """Heavy duplication makes the sliding-midpoint tree > 100 levels deep."""
     pts = (np.round(ds.uniform_cloud(40_000, 3, 9) * 4) / 4).astype(np.float32)

@@ -78,6 +78,25 @@ def test_emulated_kernels_equal_oracle(case):
         assert np.array_equal(gs["distance"], sflat["distance"])
 
 
+@pytest.mark.parametrize("dim,n,nq,radius", [(4, 6_000, 1_500, 0.02), (5, 6_000, 1_500, 0.05), (16, 4_000, 600, 1.0),
+                                             (100, 1_500, 150, 13.0)])
+def test_emulated_any_dimension_kernels_equal_oracle(dim, n, nq, radius):
+    """dim > 3: the any-dimension kernels (query / offset vectors in LDS)."""
+    pts, q = ds.uniform_cloud(n, dim, 1), ds.uniform_cloud(nq, dim, 2)
+    emu = EmulatedTree(pts, 8)
+    ref = oracle.Oracle(pts, 8, "port")
+    for k in (1, 7):
+        want = ref.search_knn(q, k)
+        for small_stack in (False, True):
+            for list_in_lds in (False, True):
+                got = emu.search_knn(q, k, small_stack=small_stack, list_in_lds=list_in_lds)
+                assert got.tobytes() == want.tobytes()
+    assert emu.search_knn(q, 4, e=1.25).tobytes() == ref.search_knn(q, 4, e=1.25).tobytes()
+    off, flat = ref.search_radius(q, radius)
+    goff, gflat = emu.search_radius(q, radius)
+    assert off[-1] > 0 and np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
+
+
 @pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "lidar", "root-is-leaf", "dim2")],
                          ids=lambda c: c[0])
 def test_emulated_persistent_machine_equals_oracle(case):
