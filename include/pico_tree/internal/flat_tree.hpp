@@ -217,6 +217,12 @@ struct flat_tree {
   std::uint32_t max_depth = 0;   //!< depth of the deepest node (root = 0)
   size_t leaf_count = 0;
   size_t max_leaf_points = 0;
+  //! Optional (keep_outer_bounds): per node, for branches, {left_min, right_max} on the
+  //! split axis -- with left_max / right_min these are the four bounds of the reference's
+  //! kd_tree_node_topological (internal/kd_tree_node.hpp:56-67, :99-117), which the
+  //! kd_forest's priority search needs.
+  bool keep_outer_bounds = false;
+  std::vector<std::array<Scalar_, 2>> outer_bounds;
 };
 
 //! Builds a flat_tree over a space_view.
@@ -301,6 +307,7 @@ class flat_builder {
   std::uint32_t grow(std::uint32_t depth, Index_* begin, Index_* end, box_type& box) {
     std::uint32_t const self = static_cast<std::uint32_t>(tree_.nodes.size());
     tree_.nodes.emplace_back();
+    if (tree_.keep_outer_bounds) tree_.outer_bounds.push_back({scalar_type(0), scalar_type(0)});
     if (depth > tree_.max_depth) tree_.max_depth = depth;
 
     if (stops(depth, begin, end)) {
@@ -338,6 +345,7 @@ class flat_builder {
     branch.right_min = right.min(axis);
     branch.right = r;
     branch.split_dim = static_cast<std::uint32_t>(axis);
+    if (tree_.keep_outer_bounds) tree_.outer_bounds[self] = {box.min(axis), right.max(axis)};
 
     box.fit(right);  // parent box = union of the children
     return self;
@@ -354,7 +362,8 @@ flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_
     SpaceView_ const& space,
     splitter_stop_condition_t<Stop_> const& stop,
     splitter_start_bounds_t<Bounds_> const& bounds,
-    splitter_rule_t<Rule_> const&) {
+    splitter_rule_t<Rule_> const&,
+    bool keep_outer_bounds = false) {
   using scalar_type = typename SpaceView_::scalar_type;
   using tree_type = flat_tree<Index_, scalar_type, SpaceView_::dim>;
   using box_type = typename tree_type::box_type;
@@ -371,6 +380,7 @@ flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_
   }
 
   tree_type tree(sdim);
+  tree.keep_outer_bounds = keep_outer_bounds;
   flat_builder<SpaceView_, Index_, Rule_, Stop_>(space, stop.derived().value, tree).run(start);
   return tree;
 }

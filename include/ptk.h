@@ -198,6 +198,39 @@ int ptk_search_box(const ptk_tree* tree, const float* mins, const float* maxs,
 
 void ptk_free(void* p);
 
+/* ---- randomised kd-forest (approximate k-NN in high dimensions) -------- */
+/* Replaces the per-query loop over pico_tree::kd_forest::search_nearest /
+ * search_nn (examples/pico_understory/pico_understory/kd_forest.hpp:70-85, as
+ * driven by examples/kd_forest/kd_forest.cpp:60-100): forest_size trees over
+ * Householder-reflected copies of the points (internal/rkd_tree_hh_data.hpp),
+ * best-bin-first search bounded by max_leaves_visited per tree
+ * (internal/kd_tree_priority_search.hpp:48-63), one k-list shared by the trees.
+ * Differences from the reference, both deliberate (see ptk_forest.hpp): the
+ * k-list is de-duplicated by index and distances are measured in the original
+ * space; reflection vectors derive from `seed` instead of std::random_device.
+ * Results are approximate by design; quality is recall against the exact
+ * kd_tree, not bit-identity with the reference. */
+typedef struct ptk_forest ptk_forest; /* opaque */
+
+int ptk_forest_create(const float* points, uint64_t n_points, uint32_t dim,
+                      uint64_t max_leaf_size, uint32_t forest_size,
+                      uint64_t seed, int32_t device, ptk_forest** out);
+void ptk_forest_destroy(ptk_forest* forest);
+
+/* The unit reflection vectors in use: forest_size x dim floats. */
+int ptk_forest_get_rotations(const ptk_forest* forest, float* out);
+
+/* Host buffers.  out: nq x k, row i ascending; rows with fewer than k distinct
+ * points found are padded with {index -1, distance FLT_MAX}.  k <= 64. */
+int ptk_forest_search_knn(const ptk_forest* forest, const float* queries,
+                          uint64_t nq, uint32_t k, uint64_t max_leaves_visited,
+                          ptk_neighbor* out);
+/* Device buffers, asynchronous on `stream`. */
+int ptk_forest_search_knn_device(const ptk_forest* forest, const float* d_queries,
+                                 uint64_t nq, uint32_t k,
+                                 uint64_t max_leaves_visited,
+                                 ptk_neighbor* d_out, void* stream);
+
 /* ---- measurement ------------------------------------------------------ */
 /* When enabled, every internal kernel launch of this handle is bracketed by HIP
  * events recorded on its stream (no host synchronisation at launch time, so it

@@ -25,6 +25,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_LIB = os.path.join(_HERE, "liboracle.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libptk_ref.so")
+REF_FOREST_LIB = os.path.join(_HERE, "_ref", "libptk_ref_forest.so")
 
 #: Structured dtype of one result record; identical to the reference binding's
 #: ``[('index','<i4'),('distance','<f4')]`` (_pyco_tree/def_core.hpp:17-18).
@@ -33,12 +34,13 @@ NEIGHBOR = np.dtype([("index", "<i4"), ("distance", "<f4")])
 
 def build(force: bool = False) -> None:
     """Compile the oracle (and the reference driver when the sources exist)."""
-    need = force or not os.path.exists(PORT_LIB)
-    ref_src = "/root/reference/src/pico_tree/pico_tree/kd_tree.hpp"
-    if os.path.exists(ref_src) and not os.path.exists(REF_LIB):
-        need = True
-    if need:
-        subprocess.check_call(["make", "-C", _HERE] + (["-B"] if force else []))
+    # make decides what is stale; the reference targets only exist where /root/reference does.
+    if os.path.exists(os.path.join(_HERE, "Makefile")) and (force or _sources_present()):
+        subprocess.check_call(["make", "-s", "-C", _HERE] + (["-B"] if force else []))
+
+
+def _sources_present() -> bool:
+    return os.path.exists(os.path.join(_HERE, "ptk_oracle.cpp"))
 
 
 def have_reference() -> bool:
@@ -260,3 +262,87 @@ def l2sq_scalar(x: float) -> float:
     lib.ptkor_l2sq_scalar.restype = c_float
     lib.ptkor_l2sq_scalar.argtypes = [c_float]
     return float(lib.ptkor_l2sq_scalar(x))
+
+
+# ---- kd_forest ------------------------------------------------------------------------------
+
+class ForestOracle:
+    """CPU restatement of the forest search the product implements (oracle/ptk_oracle.cpp,
+    section kd_forest): same reflections (passed in), same de-duplicated k-list, distances in the
+    original space.  The GPU result must equal this bit for bit."""
+
+    def __init__(self, points: np.ndarray, max_leaf_size: int, rotations: np.ndarray):
+        build()
+        self._lib = ctypes.CDLL(PORT_LIB)
+        self._pts = np.ascontiguousarray(points, dtype=np.float32)
+        rot = np.ascontiguousarray(rotations, dtype=np.float32)
+        n, dim = self._pts.shape
+        assert rot.ndim == 2 and rot.shape[1] == dim
+        self._dim = dim
+        fn = self._lib.ptkor_forest_create
+        fn.restype = c_void_p
+        fn.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]
+        self._h = fn(self._pts.ctypes.data, n, dim, int(max_leaf_size), rot.shape[0], rot.ctypes.data)
+        assert self._h
+
+    def search_knn(self, q: np.ndarray, k: int, max_leaves_visited: int) -> np.ndarray:
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.empty((len(q), k), dtype=NEIGHBOR)
+        fn = self._lib.ptkor_forest_search_knn
+        fn.restype = None
+        fn.argtypes = [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_void_p]
+        fn(self._h, q.ctypes.data, len(q), int(k), int(max_leaves_visited), out.ctypes.data)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ptkor_forest_destroy.argtypes = [c_void_p]
+            self._lib.ptkor_forest_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def have_reference_forest() -> bool:
+    return os.path.exists(REF_FOREST_LIB)
+
+
+class ReferenceForest:
+    """The compiled reference kd_forest (oracle/ref_forest_driver.cpp).  Its reflections come
+    from std::random_device, so only statistics (recall, speed) are comparable."""
+
+    def __init__(self, points: np.ndarray, max_leaf_size: int, forest_size: int):
+        self._lib = ctypes.CDLL(REF_FOREST_LIB)
+        self._pts = np.ascontiguousarray(points, dtype=np.float32)
+        n, dim = self._pts.shape
+        self._dim = dim
+        fn = self._lib.ptkref_forest_create
+        fn.restype = c_void_p
+        fn.argtypes = [c_void_p, c_size_t, c_size_t, c_size_t, c_size_t]
+        self._h = fn(self._pts.ctypes.data, n, dim, int(max_leaf_size), int(forest_size))
+        assert self._h
+
+    def search_knn(self, q: np.ndarray, k: int, max_leaves_visited: int) -> np.ndarray:
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.zeros((len(q), k), dtype=NEIGHBOR)
+        fn = self._lib.ptkref_forest_search_knn
+        fn.restype = None
+        fn.argtypes = [c_void_p, c_void_p, c_size_t, c_size_t, c_size_t, c_size_t, c_void_p]
+        fn(self._h, q.ctypes.data, len(q), self._dim, int(k), int(max_leaves_visited), out.ctypes.data)
+        return out
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.ptkref_forest_destroy.argtypes = [c_void_p]
+            self._lib.ptkref_forest_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -30,7 +30,7 @@ import numpy as np
 
 from . import datasets  # noqa: F401  (re-export)
 
-__all__ = ["KdTree", "Metric", "NEIGHBOR", "DArray", "DeviceNeighbors", "PtkError",
+__all__ = ["KdTree", "KdForest", "Metric", "NEIGHBOR", "DArray", "DeviceNeighbors", "PtkError",
            "library_path", "device_count", "datasets"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -92,6 +92,13 @@ _SIGNATURES = {
     "ptk_search_box": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p,
                                POINTER(c_void_p)]),
     "ptk_free": (None, [c_void_p]),
+    "ptk_forest_create": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_uint32, c_uint64, c_int32,
+                                  POINTER(c_void_p)]),
+    "ptk_forest_destroy": (None, [c_void_p]),
+    "ptk_forest_get_rotations": (c_int, [c_void_p, c_void_p]),
+    "ptk_forest_search_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint64, c_void_p]),
+    "ptk_forest_search_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint64, c_void_p,
+                                             c_void_p]),
     "ptk_profile_enable": (c_int, [c_void_p, c_int]),
     "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
 }
@@ -478,3 +485,81 @@ class KdTree:
         if not e > 0:
             raise ValueError("e must be positive")
         return e, nns, sort
+
+
+class KdForest:
+    """Randomised kd-forest for approximate nearest neighbours in high dimensions, searched on
+    the MI355X (one query per wavefront; ``pico_tree_amd/csrc/ptk_forest.hpp``).
+
+    Mirrors ``pico_tree::kd_forest`` of the reference's pico_understory
+    (``/root/reference/examples/pico_understory/pico_understory/kd_forest.hpp:42-85``):
+    ``KdForest(pts, max_leaf_size, forest_size)``, ``search_nn(pts, max_leaves_visited)`` and, for
+    k > 1, ``search_knn(pts, k, max_leaves_visited)`` (the reference's generic
+    ``search_nearest`` with a k-list visitor, de-duplicated by index here).  ``seed`` fixes the
+    Householder reflections, which the reference draws from ``std::random_device``.
+    """
+
+    def __init__(self, pts, max_leaf_size: int, forest_size: int, seed: int = 0, device: int | None = None):
+        pts = KdTree._as_matrix(pts, None, "pts")
+        if int(max_leaf_size) <= 0 or int(forest_size) <= 0:
+            raise ValueError("max_leaf_size and forest_size must be positive")
+        self._pts = pts
+        self._npts, self._sdim = pts.shape
+        self._forest_size = int(forest_size)
+        handle = c_void_p()
+        dev = PTK_DEVICE_CURRENT if device is None else int(device)
+        _check(_load().ptk_forest_create(pts.ctypes.data, self._npts, self._sdim, int(max_leaf_size),
+                                         self._forest_size, int(seed), dev, byref(handle)))
+        self._h = handle
+
+    @property
+    def npts(self) -> int:
+        return self._npts
+
+    @property
+    def sdim(self) -> int:
+        return self._sdim
+
+    @property
+    def rotations(self) -> np.ndarray:
+        """The unit reflection vectors, ``(forest_size, sdim)``."""
+        out = np.empty((self._forest_size, self._sdim), dtype=np.float32)
+        _check(_load().ptk_forest_get_rotations(self._h, out.ctypes.data))
+        return out
+
+    def search_knn(self, pts, k: int, max_leaves_visited: int):
+        """Host array -> ``(nq, k)`` :data:`NEIGHBOR` array; torch CUDA tensor -> :class:`DeviceNeighbors`.
+        Rows are ascending; slots beyond the distinct points found hold ``(-1, FLT_MAX)``."""
+        k = int(k)
+        if _is_torch(pts):
+            import torch
+            if pts.dtype != torch.float32 or pts.dim() != 2 or pts.shape[1] != self._sdim \
+                    or not pts.is_cuda or not pts.is_contiguous():
+                raise ValueError("queries must be a contiguous float32 (nq, sdim) CUDA tensor")
+            out = torch.empty((pts.shape[0], k, 2), dtype=torch.int32, device=pts.device)
+            stream = torch.cuda.current_stream(pts.device).cuda_stream
+            _check(_load().ptk_forest_search_knn_device(self._h, pts.data_ptr(), pts.shape[0], k,
+                                                        int(max_leaves_visited), out.data_ptr(), stream))
+            return DeviceNeighbors(out)
+        q = KdTree._as_matrix(pts, self._sdim, "pts")
+        out = np.empty((q.shape[0], k), dtype=NEIGHBOR)
+        _check(_load().ptk_forest_search_knn(self._h, q.ctypes.data, q.shape[0], k, int(max_leaves_visited),
+                                             out.ctypes.data))
+        return out
+
+    def search_nn(self, pts, max_leaves_visited: int):
+        """``(nq,)`` nearest neighbours (kd_forest.hpp:78-85)."""
+        res = self.search_knn(pts, 1, max_leaves_visited)
+        return res if isinstance(res, DeviceNeighbors) else res[:, 0]
+
+    def close(self) -> None:
+        h = getattr(self, "_h", None)
+        if h is not None and h.value:
+            _load().ptk_forest_destroy(h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -20,6 +20,8 @@ SOURCES = [os.path.join(CSRC, "ptk_backend.hip")]
 HEADERS = [
     os.path.join(CSRC, "ptk_kernels.hpp"),
     os.path.join(CSRC, "ptk_kernels_nd.hpp"),
+    os.path.join(CSRC, "ptk_forest.hpp"),
+    os.path.join(CSRC, "ptk_forest_host.hpp"),
     os.path.join(CSRC, "ptk_encode.hpp"),
     os.path.join(ROOT, "include", "ptk.h"),
     os.path.join(ROOT, "include", "pico_tree", "internal", "flat_tree.hpp"),

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <new>
 #include <string>
+#include <random>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -28,6 +29,7 @@
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_nd.hpp"
+#include "ptk_forest.hpp"
 
 // Host-side builder: the product's own header-only flat-tree builder.
 #include "pico_tree/internal/flat_tree.hpp"
@@ -1242,6 +1244,167 @@ int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
   t->profile.pending.clear();
   *out = t->profile.acc;
   if (reset) t->profile.acc = ptk_profile{};
+  return PTK_OK;
+}
+
+
+// ---- kd-forest -----------------------------------------------------------------------------
+
+}  // extern "C"
+
+struct ptk_forest {
+  uint32_t dim = 0;
+  uint64_t n_points = 0;
+  uint32_t n_trees = 0;
+  int device = kDeviceNone;
+  std::vector<float> rotations;       // n_trees x dim
+  std::vector<void*> allocations;     // everything to hipFree
+  ptk::ForestDev dev{};
+  uint32_t* d_dropped = nullptr;
+};
+
+namespace {
+
+template <class T>
+int forest_upload(ptk_forest* f, const std::vector<T>& host, const T** dev) {
+  void* p = nullptr;
+  PTK_HIP(hipMalloc(&p, std::max<size_t>(host.size(), 1) * sizeof(T)));
+  f->allocations.push_back(p);
+  if (!host.empty()) PTK_HIP(hipMemcpy(p, host.data(), host.size() * sizeof(T), hipMemcpyHostToDevice));
+  *dev = static_cast<const T*>(p);
+  return PTK_OK;
+}
+
+int forest_build(ptk_forest* f, const float* points, uint64_t max_leaf_size, uint64_t seed) {
+  const uint64_t n = f->n_points;
+  const uint32_t dim = f->dim;
+  std::vector<ptk::ForestTreeDev> trees(f->n_trees);
+  std::vector<float> rotated;
+  for (uint32_t ti = 0; ti < f->n_trees; ++ti) {
+    float* r = f->rotations.data() + (size_t)ti * dim;
+    ptk::reflection_vector(seed, ti, dim, r);
+    ptk::ForestTreeHost host;
+    std::string err = ptk::build_forest_tree(points, n, dim, max_leaf_size, r, rotated, host);
+    if (!err.empty()) return fail(PTK_ERR_UNSUPPORTED, "tree %u: %s", ti, err.c_str());
+    std::vector<float> rot(r, r + dim);
+    int rc = forest_upload(f, host.nodes, &trees[ti].nodes);
+    if (rc == PTK_OK) rc = forest_upload(f, host.indices, &trees[ti].indices);
+    if (rc == PTK_OK) rc = forest_upload(f, rot, &trees[ti].rotation);
+    if (rc != PTK_OK) return rc;
+    trees[ti].root_ref = host.root_ref;
+    trees[ti].cbits = host.cbits;
+    trees[ti].cmask = (1u << host.cbits) - 1u;
+    trees[ti].pad = 0;
+  }
+  std::vector<float> pts(points, points + n * dim);
+  int rc = forest_upload(f, pts, &f->dev.points);
+  if (rc == PTK_OK) rc = forest_upload(f, trees, &f->dev.trees);
+  if (rc != PTK_OK) return rc;
+  void* d = nullptr;
+  PTK_HIP(hipMalloc(&d, 4));
+  f->allocations.push_back(d);
+  PTK_HIP(hipMemset(d, 0, 4));
+  f->d_dropped = static_cast<uint32_t*>(d);
+  f->dev.n_trees = f->n_trees;
+  f->dev.dim = dim;
+  return PTK_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptk_forest_create(const float* points, uint64_t n_points, uint32_t dim, uint64_t max_leaf_size,
+                      uint32_t forest_size, uint64_t seed, int32_t device, ptk_forest** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (points == nullptr) return fail(PTK_ERR_INVALID, "null points");
+  if (dim == 0 || n_points == 0 || max_leaf_size == 0 || forest_size == 0)
+    return fail(PTK_ERR_INVALID, "dim, n_points, max_leaf_size and forest_size must be positive");
+  if (n_points >= (1ull << 31)) return fail(PTK_ERR_INVALID, "n_points must be < 2^31");
+  const size_t lds = ((size_t)2 * dim + 3 * ptk::kForestQueue + 3 * ptk::kForestPath) * 4;
+  if (lds > 64 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the forest kernel's LDS", dim);
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PTK_ERR_DEVICE, "no HIP device is visible");
+  int dev = device;
+  if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  if (dev >= count) return fail(PTK_ERR_INVALID, "device %d out of range (%d visible)", dev, count);
+  ptk_forest* f = new (std::nothrow) ptk_forest;
+  if (f == nullptr) return fail(PTK_ERR_NOMEM, "out of memory");
+  f->dim = dim;
+  f->n_points = n_points;
+  f->n_trees = forest_size;
+  f->device = dev;
+  int rc = PTK_OK;
+  try {
+    f->rotations.resize((size_t)forest_size * dim);
+    DeviceGuard guard(dev);
+    rc = guard.ok ? forest_build(f, points, max_leaf_size, seed) : fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", dev);
+  } catch (const std::bad_alloc&) {
+    rc = fail(PTK_ERR_NOMEM, "out of memory");
+  }
+  if (rc != PTK_OK) {
+    ptk_forest_destroy(f);
+    return rc;
+  }
+  *out = f;
+  return PTK_OK;
+}
+
+void ptk_forest_destroy(ptk_forest* f) {
+  if (f == nullptr) return;
+  if (f->device >= 0) {
+    DeviceGuard guard(f->device);
+    for (void* p : f->allocations) (void)hipFree(p);
+  }
+  delete f;
+}
+
+int ptk_forest_get_rotations(const ptk_forest* f, float* out) {
+  if (f == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  std::memcpy(out, f->rotations.data(), f->rotations.size() * sizeof(float));
+  return PTK_OK;
+}
+
+int ptk_forest_search_knn_device(const ptk_forest* f, const float* d_q, uint64_t nq, uint32_t k,
+                                 uint64_t max_leaves_visited, ptk_neighbor* d_out, void* stream) {
+  if (f == nullptr) return fail(PTK_ERR_INVALID, "null forest");
+  if (k == 0 || k > 64) return fail(PTK_ERR_INVALID, "k must be in 1..64");
+  if (nq == 0) return PTK_OK;
+  if (d_q == nullptr || d_out == nullptr) return fail(PTK_ERR_INVALID, "null buffer");
+  if (nq >= (1ull << 31)) return fail(PTK_ERR_UNSUPPORTED, "too many queries for one launch");
+  DeviceGuard guard(f->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", f->device);
+  const size_t lds = ((size_t)2 * f->dim + 3 * ptk::kForestQueue + 3 * ptk::kForestPath) * 4;
+  const uint32_t leaves = max_leaves_visited > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_leaves_visited;
+  hipLaunchKernelGGL((ptk::forest_knn_kernel<64>), dim3((uint32_t)nq), dim3(64), lds, static_cast<hipStream_t>(stream),
+                     f->dev, d_q, nq, k, leaves, reinterpret_cast<ptk::Neighbor*>(d_out), f->d_dropped);
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+
+int ptk_forest_search_knn(const ptk_forest* f, const float* q, uint64_t nq, uint32_t k, uint64_t max_leaves_visited,
+                          ptk_neighbor* out) {
+  if (f == nullptr) return fail(PTK_ERR_INVALID, "null forest");
+  if (nq == 0) return PTK_OK;
+  if (q == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null buffer");
+  DeviceGuard guard(f->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", f->device);
+  float* d_q = nullptr;
+  ptk_neighbor* d_out = nullptr;
+  const size_t qb = (size_t)nq * f->dim * 4, ob = (size_t)nq * (k ? k : 1) * sizeof(ptk_neighbor);
+  hipError_t he = hipMalloc((void**)&d_q, qb);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_out, ob);
+  if (he == hipSuccess) he = hipMemcpy(d_q, q, qb, hipMemcpyHostToDevice);
+  int rc = PTK_OK;
+  if (he == hipSuccess) {
+    rc = ptk_forest_search_knn_device(f, d_q, nq, k, max_leaves_visited, d_out, nullptr);
+    if (rc == PTK_OK) he = hipMemcpy(out, d_out, ob, hipMemcpyDeviceToHost);
+  }
+  if (d_q) (void)hipFree(d_q);
+  if (d_out) (void)hipFree(d_out);
+  if (rc != PTK_OK) return rc;
+  if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
   return PTK_OK;
 }
 

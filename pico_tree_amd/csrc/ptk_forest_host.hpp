@@ -1,0 +1,121 @@
+// ptk_forest_host.hpp -- host side of the kd-forest: reflection vectors, per-tree build and
+// encoding (plain C++17, no HIP types; shared by ptk_backend.hip and the CPU kernel emulator).
+
+#pragma once
+
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <random>
+#include <string>
+#include <vector>
+
+#include "pico_tree/internal/flat_tree.hpp"
+#include "pico_tree/map.hpp"
+#include "ptk_encode.hpp"
+
+namespace ptk {
+
+// One node of a forest tree, 32 bytes.  Branch: bounds of both children on the split axis
+// (the reference's kd_tree_node_topological, internal/kd_tree_node.hpp:56-67).
+struct ForestNode {
+  float left_min, left_max, right_min, right_max;
+  uint32_t left_ref, right_ref;  // bit 31 = leaf: (begin << cbits) | count; else branch index
+  uint32_t split_dim;
+  uint32_t right_id;             // DFS-stream position of the right child (left = self + 1)
+};
+static_assert(sizeof(ForestNode) == 32, "forest node layout");
+
+constexpr uint32_t kForestQueue = 1024;   // queued nodes per query and tree
+constexpr uint32_t kForestPath = 96;      // deepest descent recorded (tree depth limit)
+
+struct ForestTreeHost {
+  std::vector<ForestNode> nodes;
+  std::vector<int32_t> indices;
+  uint32_t root_ref = 0;
+  uint32_t cbits = 0;
+  uint32_t max_depth = 0;
+};
+
+// Unit vector with independent N(0,1) components before normalisation: std::mt19937 words
+// through Box-Muller in double (the reference: std::normal_distribution on a
+// std::random_device seed, rkd_tree_hh_data.hpp:14-29).
+inline void reflection_vector(uint64_t seed, uint32_t tree, uint32_t dim, float* out) {
+  std::mt19937 gen(static_cast<uint32_t>(seed * 1000003ull + tree * 7919ull + 12345ull));
+  double norm2 = 0.0;
+  std::vector<double> v(dim);
+  for (uint32_t i = 0; i < dim; ++i) {
+    const double u1 = ((gen() >> 8) + 0.5) * (1.0 / 16777216.0);
+    const double u2 = ((gen() >> 8) + 0.5) * (1.0 / 16777216.0);
+    v[i] = std::sqrt(-2.0 * std::log(u1)) * std::cos(6.283185307179586 * u2);
+    norm2 += v[i] * v[i];
+  }
+  const double inv = 1.0 / std::sqrt(norm2 > 0 ? norm2 : 1.0);
+  for (uint32_t i = 0; i < dim; ++i) out[i] = static_cast<float>(v[i] * inv);
+}
+
+// Builds one tree over the points reflected by r (`rotated` is scratch of n * dim floats).
+// Returns an empty string or an error message.
+inline std::string build_forest_tree(const float* points, uint64_t n, uint32_t dim, uint64_t max_leaf_size,
+                                     const float* r, std::vector<float>& rotated, ForestTreeHost& out) {
+  using namespace pico_tree;
+  using space_t = space_map<point_map<float const, dynamic_extent>>;
+  rotated.resize(n * dim);
+  // y = x - (2 (r.x)) r, the dot product summed left to right (rkd_tree_hh_data.hpp:80-90).
+  for (uint64_t i = 0; i < n; ++i) {
+    const float* x = points + i * dim;
+    float* y = rotated.data() + i * dim;
+    float dot = 0.0f;
+    for (uint32_t a = 0; a < dim; ++a) dot += r[a] * x[a];
+    dot *= 2.0f;
+    for (uint32_t a = 0; a < dim; ++a) y[a] = x[a] - (dot * r[a]);
+  }
+  space_t space(rotated.data(), n, dim);
+  internal::space_view<space_t> view(space);
+  auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
+                                             sliding_midpoint_max_side, /*keep_outer_bounds=*/true);
+  if (flat.max_depth >= kForestPath)
+    return "forest tree is " + std::to_string(flat.max_depth) + " levels deep (limit " +
+           std::to_string(kForestPath - 1) + ")";
+  // Encode: branches only, children as references (a leaf's range is packed into the reference).
+  const size_t n_nodes = flat.nodes.size();
+  std::vector<uint32_t> branch_id(n_nodes, 0);
+  uint32_t n_branch = 0, max_count = 0;
+  for (size_t i = 0; i < n_nodes; ++i) {
+    if (flat.nodes[i].right == internal::flat_leaf_tag) {
+      max_count = std::max<uint32_t>(max_count, (uint32_t)(flat.nodes[i].end - flat.nodes[i].begin));
+    } else {
+      branch_id[i] = n_branch++;
+    }
+  }
+  const uint32_t cbits = bits_for(max_count);
+  if (cbits + bits_for(n) > 31) return "forest leaf reference does not fit 31 bits";
+  auto ref_of = [&](size_t i) -> uint32_t {
+    const auto& nd = flat.nodes[i];
+    if (nd.right == internal::flat_leaf_tag)
+      return kEncLeafBit | ((uint32_t)nd.begin << cbits) | (uint32_t)(nd.end - nd.begin);
+    return branch_id[i];
+  };
+  out.nodes.assign(std::max<uint32_t>(n_branch, 1), ForestNode{});
+  for (size_t i = 0; i < n_nodes; ++i) {
+    const auto& nd = flat.nodes[i];
+    if (nd.right == internal::flat_leaf_tag) continue;
+    ForestNode o;
+    o.left_min = flat.outer_bounds[i][0];
+    o.left_max = nd.left_max;
+    o.right_min = nd.right_min;
+    o.right_max = flat.outer_bounds[i][1];
+    o.left_ref = ref_of(i + 1);
+    o.right_ref = ref_of(nd.right);
+    o.split_dim = nd.split_dim;
+    o.right_id = nd.right;
+    out.nodes[branch_id[i]] = o;
+  }
+  out.indices.assign(flat.indices.begin(), flat.indices.end());
+  out.root_ref = ref_of(0);
+  out.cbits = cbits;
+  out.max_depth = flat.max_depth;
+  return std::string();
+}
+
+}  // namespace ptk

@@ -112,3 +112,17 @@ def config2_clouds(cloud: str = "L", n: int = CONFIG2_N, nq: int = CONFIG2_NQ):
         return (lidar_cloud(n, seed=1, pose=(0.0, 0.0), unit_scale=20.0),
                 lidar_cloud(nq, seed=2, pose=(3.0, 1.5), unit_scale=20.0))
     raise ValueError("cloud must be 'U' or 'L'")
+
+
+def sift_like_cloud(n: int, dim: int = 128, seed: int = 1, centres: int = 1000, centre_seed: int = 77,
+                    sigma: float = 30.0) -> np.ndarray:
+    """Synthetic stand-in for SIFT descriptors (BASELINE config 5; SIFT-1M cannot be downloaded
+    here): a mixture of ``centres`` Gaussians (centres uniform in [40, 180]^dim, sigma 30), clipped
+    to [0, 218] and rounded to integers like SIFT bytes.  ``centre_seed`` is shared by the point
+    and query clouds so they come from the same mixture."""
+    crng = np.random.Generator(np.random.PCG64(centre_seed))
+    c = crng.uniform(40.0, 180.0, size=(centres, dim)).astype(np.float32)
+    rng = np.random.Generator(np.random.PCG64(seed))
+    which = rng.integers(0, centres, size=n)
+    x = c[which] + rng.normal(0.0, sigma, size=(n, dim)).astype(np.float32)
+    return np.ascontiguousarray(np.rint(np.clip(x, 0.0, 218.0)).astype(np.float32))

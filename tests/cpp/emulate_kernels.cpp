@@ -26,6 +26,7 @@ thread_local dim3 blockDim;
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_nd.hpp"
+#include "ptk_forest.hpp"
 
 namespace ptk {
 unsigned char ptk_smem[192 * 1024] __attribute__((aligned(16)));
@@ -80,6 +81,8 @@ int emu_shfl(int v, int src_lane) {
   swapcontext(&w->lane_ctx[lane], &w->scheduler);
   return w->snapshot[src_lane & 63];
 }
+
+int emu_lane() { return g_fibers->current; }
 
 namespace {
 
@@ -428,6 +431,33 @@ int emu_phase1(void* h, const float* q, uint64_t nq, uint8_t* cls_out, float* be
     cls_out[i] = (uint8_t)(7 - ckey[i]);
     best_out[i] = ckey[i] == 7 ? o[i].distance : __uint_as_float(cbest[i].y);
   }
+  return 0;
+}
+
+// The forest: the product's host build (ptk_forest_host.hpp) + the kernel, one wave per query.
+// rotations_out receives the reflection vectors in use (n_trees x dim).
+int emu_forest_knn(const float* points, uint64_t n, uint32_t dim, uint64_t max_leaf, uint32_t n_trees, uint64_t seed,
+                   const float* q, uint64_t nq, uint32_t k, uint32_t max_leaves, float* rotations_out,
+                   ptk_neighbor* out, uint32_t* dropped) {
+  std::vector<ptk::ForestTreeHost> host(n_trees);
+  std::vector<ptk::ForestTreeDev> trees(n_trees);
+  std::vector<float> rotated;
+  for (uint32_t i = 0; i < n_trees; ++i) {
+    float* r = rotations_out + (size_t)i * dim;
+    ptk::reflection_vector(seed, i, dim, r);
+    g_err = ptk::build_forest_tree(points, n, dim, max_leaf, r, rotated, host[i]);
+    if (!g_err.empty()) return -1;
+    trees[i].nodes = host[i].nodes.data();
+    trees[i].indices = host[i].indices.data();
+    trees[i].rotation = r;
+    trees[i].root_ref = host[i].root_ref;
+    trees[i].cbits = host[i].cbits;
+    trees[i].cmask = (1u << host[i].cbits) - 1u;
+  }
+  ptk::ForestDev f{trees.data(), points, n_trees, dim};
+  for_each_wave((uint32_t)nq, [&] {
+    ptk::forest_knn_kernel<64>(f, q, nq, k, max_leaves, reinterpret_cast<ptk::Neighbor*>(out), dropped);
+  });
   return 0;
 }
 

@@ -42,6 +42,18 @@ inline unsigned long long __ballot(bool pred) { return emu_ballot(pred); }
 inline int __popcll(unsigned long long v) { return __builtin_popcountll(v); }
 int emu_shfl(int v, int src_lane);
 inline int __shfl(int v, int src_lane) { return emu_shfl(v, src_lane); }
+inline float __shfl(float v, int src_lane) {
+  int i;
+  std::memcpy(&i, &v, 4);
+  i = emu_shfl(i, src_lane);
+  std::memcpy(&v, &i, 4);
+  return v;
+}
+int emu_lane();
+inline int __shfl_up(int v, int delta) { const int l = emu_lane(); return emu_shfl(v, l >= delta ? l - delta : l); }
+inline float __shfl_up(float v, int delta) { const int l = emu_lane(); return __shfl(v, l >= delta ? l - delta : l); }
+inline int __shfl_xor(int v, int mask) { return emu_shfl(v, emu_lane() ^ mask); }
+inline float __shfl_xor(float v, int mask) { return __shfl(v, emu_lane() ^ mask); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl(v, 0); }  // all lanes alive where it is used
 inline void __syncthreads() { (void)emu_ballot(false); }  // single-wave blocks only
 

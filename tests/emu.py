@@ -122,3 +122,22 @@ class EmulatedTree:
         self.lib.emu_morton(q.ctypes.data, d, len(q), lo.ctypes.data, inv.ctypes.data,
                             keys.ctypes.data, ids.ctypes.data)
         return ids[np.argsort(keys, kind="stable")].astype(np.uint32), keys
+
+
+def emulated_forest_knn(pts, max_leaf, n_trees, seed, q, k, max_leaves):
+    """Host build (product code) + forest kernel under the CPU emulator.
+    Returns (result (nq, k), rotations (n_trees, dim), dropped queue entries)."""
+    from ctypes import c_uint32, c_uint64, c_void_p
+    lib = _lib()
+    pts = np.ascontiguousarray(pts, dtype=np.float32)
+    q = np.ascontiguousarray(q, dtype=np.float32)
+    n, dim = pts.shape
+    rot = np.zeros((n_trees, dim), dtype=np.float32)
+    out = np.zeros((len(q), k), dtype=pt.NEIGHBOR)
+    dropped = np.zeros(1, dtype=np.uint32)
+    lib.emu_forest_knn.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64, c_uint32, c_uint64, c_void_p, c_uint64,
+                                   c_uint32, c_uint32, c_void_p, c_void_p, c_void_p]
+    rc = lib.emu_forest_knn(pts.ctypes.data, n, dim, max_leaf, n_trees, seed, q.ctypes.data, len(q), k, max_leaves,
+                            rot.ctypes.data, out.ctypes.data, dropped.ctypes.data)
+    assert rc == 0, lib.emu_last_error()
+    return out, rot, int(dropped[0])

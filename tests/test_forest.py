@@ -1,0 +1,96 @@
+"""kd_forest (BASELINE config 5): the product's forest search against
+
+* its CPU restatement (oracle.ForestOracle) -- bit for bit, since both use the same reflection
+  vectors, the same de-duplicated k-list and original-space distances;
+* the exact kd_tree -- recall, the quality measure the reference itself reports
+  (/root/reference/examples/kd_forest/kd_forest.cpp:113-123);
+* the compiled reference kd_forest -- recall of both against the same exact answers (the
+  reference draws its reflections from std::random_device, so only statistics compare).
+
+The CPU tier runs the real kernel source under the emulator; the `gpu` tier runs libptk.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import pytest
+
+import oracle
+import pico_tree_amd as pt
+from pico_tree_amd import datasets as ds
+from tests.emu import emulated_forest_knn
+
+
+def _recall(found, exact):
+    """Mean fraction of the exact k nearest that appear in the found rows."""
+    hits = [len(set(f["index"].tolist()) & set(e["index"].tolist())) / len(e) for f, e in zip(found, exact)]
+    return float(np.mean(hits))
+
+
+def _clouds(n, nq, dim):
+    return ds.sift_like_cloud(n, dim, seed=1, centres=60), ds.sift_like_cloud(nq, dim, seed=2, centres=60)
+
+
+@pytest.mark.parametrize("dim,n,nq,leaf,trees,k,leaves", [(16, 4_000, 96, 8, 3, 5, 6), (32, 3_000, 64, 16, 4, 10, 8),
+                                                          (128, 2_500, 48, 32, 2, 1, 4), (5, 3_000, 64, 4, 5, 64, 3)])
+def test_emulated_forest_kernel_equals_oracle(dim, n, nq, leaf, trees, k, leaves):
+    pts, q = _clouds(n, nq, dim)
+    got, rot, dropped = emulated_forest_knn(pts, leaf, trees, 7, q, k, leaves)
+    assert dropped == 0
+    assert np.allclose(np.linalg.norm(rot, axis=1), 1.0, atol=1e-6)
+    want = oracle.ForestOracle(pts, leaf, rot).search_knn(q, k, leaves)
+    assert got.tobytes() == want.tobytes()
+    # rows ascending, indices distinct
+    for row in got:
+        real = row[row["index"] >= 0]
+        assert np.all(np.diff(real["distance"]) >= 0) and len(set(real["index"].tolist())) == len(real)
+
+
+def test_forest_oracle_recall_matches_the_compiled_reference():
+    """Same data, same (trees, leaf, leaves): recall@1 of the restated forest and of the actual
+    reference forest against the exact kd_tree agree within sampling noise."""
+    if not oracle.have_reference_forest():
+        pytest.skip("oracle/_ref/libptk_ref_forest.so is only built where /root/reference exists")
+    pts, q = _clouds(20_000, 400, 32)
+    exact = oracle.Oracle(pts, 10, "port").search_knn(q, 1)
+    trees, leaf, leaves = 4, 16, 8
+    rot = np.stack([emulated_forest_knn(pts[:64], 4, trees, 3, q[:1], 1, 1)[1][i] for i in range(trees)])
+    ours = oracle.ForestOracle(pts, leaf, rot).search_knn(q, 1, leaves)
+    ref = oracle.ReferenceForest(pts, leaf, trees).search_knn(q, 1, leaves)
+    r_ours, r_ref = _recall(ours, exact), _recall(ref, exact)
+    assert r_ours > 0.5 and abs(r_ours - r_ref) < 0.08, (r_ours, r_ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,n,nq,leaf,trees,k,leaves", [(128, 30_000, 700, 32, 8, 10, 64), (128, 30_000, 700, 32, 8, 1, 64),
+                                                          (16, 50_000, 2_000, 8, 4, 5, 10), (64, 20_000, 500, 16, 3, 64, 16),
+                                                          (7, 20_000, 1_000, 4, 6, 3, 5)])
+def test_forest_bit_exact_against_the_oracle(gpu, dim, n, nq, leaf, trees, k, leaves):
+    pts, q = _clouds(n, nq, dim)
+    forest = pt.KdForest(pts, leaf, trees, seed=11, device=gpu)
+    got = forest.search_knn(q, k, leaves)
+    want = oracle.ForestOracle(pts, leaf, forest.rotations).search_knn(q, k, leaves)
+    assert got.tobytes() == want.tobytes()
+    if k == 1:
+        assert forest.search_nn(q, leaves).tobytes() == want[:, 0].tobytes()
+
+
+@pytest.mark.gpu
+def test_forest_recall_and_device_buffers(gpu):
+    import torch
+
+    pts, q = _clouds(60_000, 1_000, 128)
+    forest = pt.KdForest(pts, 32, 8, seed=5, device=gpu)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    exact = tree.search_knn(q, 10)
+    got = forest.search_knn(q, 10, 64)
+    assert _recall(got[:, :1], exact[:, :1]) > 0.9
+    assert _recall(got, exact) > 0.8
+    # more leaves never hurt; one leaf per tree is much worse
+    assert _recall(forest.search_knn(q, 10, 2), exact) < _recall(got, exact)
+    dq = torch.from_numpy(q).to(f"cuda:{gpu}")
+    assert forest.search_knn(dq, 10, 64).numpy().tobytes() == got.tobytes()
+    # distances are true squared distances in the original space
+    i = got["index"][:, 0]
+    d = ((q - pts[i]) ** 2).sum(1)
+    assert np.allclose(d, got["distance"][:, 0], rtol=1e-5)
