@@ -422,7 +422,11 @@ void write_node(node_t const* node, byte_sink& out) {
     out.put(node->data.leaf);
   } else {
     out.put(false);
-    out.put(node->data.branch);
+    // kd_tree_branch_single (kd_tree_node.hpp:43-50) is {int split_dim; float left_max; float
+    // right_min}: 12 bytes; the forest's outer bounds are not part of the euclidean stream.
+    out.put(node->data.branch.split_dim);
+    out.put(node->data.branch.left_max);
+    out.put(node->data.branch.right_min);
     write_node(node->left, out);
     write_node(node->right, out);
   }

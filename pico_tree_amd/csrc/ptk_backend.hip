@@ -93,6 +93,9 @@ struct Workspace {
   hipStream_t last_stream = nullptr;
   hipEvent_t done = nullptr;
   bool has_work = false;
+  // Second stream for the heavy continuations of the two-phase search (fork / join by events).
+  hipStream_t aux = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
 };
 
 }  // namespace
@@ -586,19 +589,19 @@ int launch_radius_persistent(const ptk_tree* t, const float* d_q, const uint32_t
 // pass over the continuations, phase 2 over the continuations.
 size_t class_sort_tmp_bytes(uint64_t nq) {
   size_t tmp_bytes = 0;
-  uint8_t* k8 = nullptr;
+  ptk::ContKey* k16 = nullptr;
   uint32_t* v32 = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k8, k8, v32, v32, nq, 0, 3, (hipStream_t) nullptr);
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k16, k16, v32, v32, nq, 0, 16, (hipStream_t) nullptr);
   return tmp_bytes + 256;
 }
 
 size_t two_phase_scratch_bytes(uint64_t nq) {
-  return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 2 * nq +
+  return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 4 * nq +
          2 * (nq * 4) + 64 + class_sort_tmp_bytes(nq);
 }
 
 template <int S1, bool DOUBLE, int S2, int OVF, int LEAFB, bool PERSISTENT2, bool UNIFORM1 = false,
-          int LEAFB1 = LEAFB>
+          int LEAFB1 = LEAFB, int SH = 0, int LEAFBH = 4>
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   float4* qs = nullptr;
@@ -609,8 +612,8 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   size_t tmp_bytes = class_sort_tmp_bytes(nq);
   cont.rec = scratch.take<ptk::Record>(nq * ptk::kContSlots);
   cont.best = scratch.take<uint4>(nq);
-  cont.key = scratch.take<uint8_t>(nq);
-  uint8_t* key_out = scratch.take<uint8_t>(nq);
+  cont.key = scratch.take<ptk::ContKey>(nq);
+  ptk::ContKey* key_out = scratch.take<ptk::ContKey>(nq);
   cont.ids = scratch.take<uint32_t>(nq);
   uint32_t* ids_out = scratch.take<uint32_t>(nq);
   cont.meta = scratch.take<uint32_t>(16);
@@ -619,11 +622,12 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     return fail(PTK_ERR_NOMEM, "scratch block too small");
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
-  // Heavy continuations run `heavy_lanes` per wavefront; the grid has room for 1/8 of the batch
-  // being heavy at that width (the meta kernel falls back to full waves beyond that).
-  uint32_t heavy_lanes = (uint32_t)env_int("PTK_HEAVY_LANES", 64);
+  // The top tier (head of the ranked classes) runs `heavy_lanes` per wavefront; the grid has
+  // room for 1/32 of the batch in that tier (the meta kernel clamps the tier to what fits).
+  uint32_t heavy_lanes = (uint32_t)env_int("PTK_TOP_LANES", 4);
   if (heavy_lanes < 1 || heavy_lanes > 64) heavy_lanes = 64;
-  const uint32_t extra_waves = heavy_lanes == 64 ? 0xFFFFFFFFu : (uint32_t)(nq / 8 / heavy_lanes) + 2u;
+  const uint32_t top_permille = (uint32_t)env_int("PTK_TOP_PERMILLE", 60);
+  const uint32_t extra_waves = top_permille == 0 ? 0u : (uint32_t)(nq / 32 / heavy_lanes) + 2u;
   {
     const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
     Timer timer(t, s);
@@ -638,9 +642,10 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   {
     Timer timer(t, s);
-    PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 3, s));
+    PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 16, s));
     hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont,
-                       (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass), heavy_lanes, extra_waves);
+                       (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass), heavy_lanes, top_permille,
+                       extra_waves, (uint32_t)env_int("PTK_DEAL", 1));
     timer.stop(2, 0);
   }
   {
@@ -649,9 +654,31 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
       const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
       hipLaunchKernelGGL((ptk::knn1_phase2_persistent_kernel<S2, OVF>), dim3(chunks), dim3(64),
                          (size_t)S2 * 64 * 8 + ptk::kP2Chunk * 4, s, t->dev, qs, e_inv, d_out, cont, ids_out);
+    } else if (SH > 0) {
+      // Heavy continuations (the first wavefronts of the class-sorted list) run concurrently on a
+      // second stream with their own geometry: a ring deep enough that nothing spills to scratch
+      // and whole-leaf batches -- their waves are few and sit on the critical path.
+      Workspace& ws = t->ws;
+      if (ws.aux == nullptr) {
+        PTK_HIP(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
+        PTK_HIP(hipEventCreateWithFlags(&ws.fork, hipEventDisableTiming));
+        PTK_HIP(hipEventCreateWithFlags(&ws.join, hipEventDisableTiming));
+      }
+      constexpr int SHS = SH > 0 ? SH : 16;
+      int rc2 = allow_lds(ptk::knn1_phase2_kernel<SHS, OVF, LEAFBH>, (size_t)SHS * 64 * 8);
+      if (rc2 != PTK_OK) return rc2;
+      PTK_HIP(hipEventRecord(ws.fork, s));
+      PTK_HIP(hipStreamWaitEvent(ws.aux, ws.fork, 0));
+      const uint32_t heavy_grid = (uint32_t)(nq / 8 / 64) + 2u + extra_waves;
+      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<SHS, OVF, LEAFBH>), dim3(heavy_grid), dim3(64),
+                         (size_t)SHS * 64 * 8, ws.aux, t->dev, qs, e_inv, d_out, cont, ids_out, 2u);
+      PTK_HIP(hipEventRecord(ws.join, ws.aux));
+      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1 + extra_waves), dim3(64),
+                         (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out, 1u);
+      PTK_HIP(hipStreamWaitEvent(s, ws.join, 0));
     } else {
       hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>),
-                         dim3(blocks + 1 + (heavy_lanes == 64 ? 0u : extra_waves)), dim3(64),
+                         dim3(blocks + 1 + extra_waves), dim3(64),
                          (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out,
                          (uint32_t)env_int("PTK_DEBUG_PHASE2", 0));
     }
@@ -686,7 +713,7 @@ int launch_knn1_refill(const ptk_tree* t, const float* d_q, const uint32_t* perm
   cont.nq = nq;
   cont.rec = scratch.take<ptk::Record>(nq * ptk::kContSlots);
   cont.best = scratch.take<uint4>(nq);
-  cont.key = scratch.take<uint8_t>(nq);
+  cont.key = scratch.take<ptk::ContKey>(nq);
   cont.ids = scratch.take<uint32_t>(nq);
   cont.meta = scratch.take<uint32_t>(16);
   if (!cont.rec || !cont.best || !cont.key || !cont.ids || !cont.meta)
@@ -821,6 +848,13 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
       case 50: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 51: return launch_knn1_two_phase<32, true, 16, 64, 8, false, true>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 52: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 60: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 61: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 32, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 62: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 63: return launch_knn1_two_phase<32, true, 8, 64, 4, false, true, 4, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 64: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 16, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 65: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 8, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
+      case 66: return launch_knn1_two_phase<32, true, 8, 64, 4, false, true, 4, 8, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 40: return launch_knn1_refill<16, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 41: return launch_knn1_refill<8, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
       case 42: return launch_knn1_refill<16, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
@@ -925,6 +959,9 @@ void ptk_tree_destroy(ptk_tree* t) {
     for (hipEvent_t e : t->profile.idle) (void)hipEventDestroy(e);
     if (t->ws.has_work) (void)hipEventSynchronize(t->ws.done);
     if (t->ws.done) (void)hipEventDestroy(t->ws.done);
+    if (t->ws.fork) (void)hipEventDestroy(t->ws.fork);
+    if (t->ws.join) (void)hipEventDestroy(t->ws.join);
+    if (t->ws.aux) (void)hipStreamDestroy(t->ws.aux);
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
     if (t->d_pts) (void)hipFree(t->d_pts);

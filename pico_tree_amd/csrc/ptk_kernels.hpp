@@ -693,13 +693,27 @@ constexpr int kContSlots = 6;           // records a continuation can carry
 constexpr uint32_t kContOverflow = 7;   // class of a query with more: redone from the root
 constexpr uint32_t kHeavyClass = 4;     // classes >= this are dealt across wavefronts
 
+// Sort key of a continuation (16 bits, ascending = processed first):
+//   classes >= kRankedClass ("ranked"): 0 .. 0x1FFF, smaller for a LARGER home-leaf best distance.
+//     tools/analyse_cost.py: these 2 % of the queries hold every expensive one, and how far the
+//     home-leaf best is predicts the cost (every query with > 500 phase-2 steps is in the top half);
+//   classes 4 .. 1: (7 - class) << 13, low bits 0 so the stable sort keeps their Morton order;
+//   class 0 (final after phase 1): 7 << 13, sorts behind everything.
+typedef uint16_t ContKey;
+constexpr uint32_t kRankedClass = 5;
+__device__ __forceinline__ ContKey make_cont_key(uint32_t cls, float best_d) {
+  if (cls >= kRankedClass) return (ContKey)(0x1FFFu - ((__float_as_uint(best_d) >> 18) & 0x1FFFu));
+  return (ContKey)((7u - cls) << 13);
+}
+__device__ __forceinline__ bool cont_key_is_final(ContKey k) { return (k >> 13) == 7u; }
+
 // Continuations are indexed by the query's slot in the (Morton-ordered) packed batch, so
 // phase 1 needs no allocation and no atomics; the class sort doubles as the compaction.
 struct Cont {
   uint4* best;          // [nq]  {best index, bits(best distance), class, 0} after phase 1
   Record* rec;          // [kContSlots][nq]  record s of slot i at rec[s * nq + i] (a wave stores and
                         //                   loads one record index as one coalesced run), shallowest first
-  uint8_t* key;         // [nq]  7 - class (class = record count, 7 = overflow); 7 = nothing to do
+  ContKey* key;         // [nq]  sort key of the slot, see make_cont_key()
   uint32_t* ids;        // [nq]  slot index (sorted together with key)
   uint32_t* meta;       // [0] continuations  [1] heavy continuations  [2] heavy wavefronts
   uint64_t nq;          // slots (= queries of the batch)
@@ -813,7 +827,7 @@ __global__ __launch_bounds__(64) void knn1_phase1_kernel(
   }
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
   const uint32_t e = (uint32_t)i;
-  cont.key[e] = (uint8_t)(7u - cls);  // class 0 -> key 7: sorts behind every continuation
+  cont.key[e] = make_cont_key(cls, pol.best_d);
   cont.ids[e] = e;
   if (cls == 0) {
     pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
@@ -968,10 +982,10 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
   const uint32_t e = (uint32_t)i;
   if ((debug_skip & 2u) && pol.best_d >= 0.0f) {
-    if (e == 0xFFFFFFFFu) cont.key[0] = (uint8_t)(cls + c + ref);  // keeps the work alive
+    if (e == 0xFFFFFFFFu) cont.key[0] = (ContKey)(cls + c + ref);  // keeps the work alive
     return;
   }
-  cont.key[e] = (uint8_t)(7u - cls);  // class 0 -> key 7: sorts behind every continuation
+  cont.key[e] = make_cont_key(cls, pol.best_d);
   cont.ids[e] = e;
   if (cls == 0) {
     pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
@@ -986,10 +1000,16 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   }
 }
 
-// One thread, after the class sort: where the continuations and the heavy classes end.
-__global__ void knn1_phase_meta_kernel(const uint8_t* __restrict__ sorted_key, uint32_t nq, Cont cont,
-                                       uint32_t heavy_class = kHeavyClass, uint32_t heavy_lanes = 64u,
-                                       uint32_t max_heavy_waves = 0xFFFFFFFFu) {
+// One thread, after the sort: where the tiers of the sorted list end.
+//   meta[0] n2      continuations (everything before class 0)
+//   meta[1] heavy   end of the dealt tier (classes >= heavy_class)
+//   meta[2] waves of the dealt tier     meta[3] lanes per wave of the TOP tier
+//   meta[4] t3      end of the top tier (the first `top_permille` of the ranked classes)
+//   meta[5] waves of the top tier
+__global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, uint32_t nq, Cont cont,
+                                       uint32_t heavy_class = kHeavyClass, uint32_t top_lanes = 64u,
+                                       uint32_t top_permille = 0u, uint32_t max_top_waves = 0u,
+                                       uint32_t deal = 1u) {
   auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
     uint32_t lo = 0, hi = nq;
     while (lo < hi) {
@@ -998,16 +1018,22 @@ __global__ void knn1_phase_meta_kernel(const uint8_t* __restrict__ sorted_key, u
     }
     return lo;
   };
-  const uint32_t n2 = first_at_least(7u);
-  const uint32_t heavy = heavy_class > 7u ? 0u : first_at_least(7u - heavy_class + 1u);  // classes >= heavy_class
+  const uint32_t n2 = first_at_least(7u << 13);
+  const uint32_t ranked = first_at_least(1u << 13);  // classes >= kRankedClass
+  uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
+  uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : first_at_least((7u - hc + 1u) << 13));
+  if (hc > kRankedClass && hc <= 7u) heavy = ranked;  // the ranked classes are one group
+  uint32_t hl = top_lanes < 1u || top_lanes > 64u ? 64u : top_lanes;
+  uint32_t t3 = (uint32_t)(((uint64_t)ranked * top_permille) / 1000u);
+  if (t3 > heavy) t3 = heavy;
+  if ((t3 + hl - 1u) / hl > max_top_waves) t3 = max_top_waves * hl < t3 ? max_top_waves * hl : t3;
   cont.meta[0] = n2;
   cont.meta[1] = heavy;
-  // Heavy wavefronts run with `heavy_lanes` lanes each (fewer lanes: shorter rounds on the
-  // critical path); if the launch was not sized for that many waves, fall back to full waves.
-  uint32_t hl = heavy_lanes;
-  if ((heavy + hl - 1u) / hl > max_heavy_waves) hl = 64u;
-  cont.meta[2] = (heavy + hl - 1u) / hl;
+  cont.meta[2] = (heavy - t3 + 63u) / 64u;
   cont.meta[3] = hl;
+  cont.meta[4] = t3;
+  cont.meta[5] = (t3 + hl - 1u) / hl;
+  cont.meta[6] = deal;
 }
 
 // Phase 2: one continuation per lane, taken from the class-sorted entry list.
@@ -1018,20 +1044,31 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   const uint32_t n2 = cont.meta[0];
   const uint32_t heavy = cont.meta[1];
   const uint32_t heavy_waves = cont.meta[2];
+  const uint32_t top = cont.meta[4];
+  const uint32_t top_waves = cont.meta[5];
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   // Timing experiments only (results are incomplete): 1 = skip the heavy waves, 2 = only them.
-  if (debug_mode == 1 && wave < heavy_waves) return;
-  if (debug_mode == 2 && wave >= heavy_waves) return;
-  // Heavy classes: lane l of wave w takes sorted entry l * heavy_waves + w, so consecutive
-  // (spatially adjacent, equally expensive) entries land in different wavefronts.
+  if (debug_mode == 1 && wave < top_waves + heavy_waves) return;
+  if (debug_mode == 2 && wave >= top_waves + heavy_waves) return;
+  // Three tiers of the sorted list, most expensive first (blocks are dispatched in order):
+  //   top    the head of the ranked classes, few lanes per wavefront: these queries are long
+  //          dependent chains (hundreds of leaves); a wave's round costs the maximum over its
+  //          lanes, so fewer lanes = shorter rounds on what is the critical path of the launch;
+  //   dealt  the other heavy classes: lane l of wave w takes entry l * waves + w, so neighbours in
+  //          the list (similar cost, spatially adjacent) land in different wavefronts;
+  //   light  64 consecutive entries per wavefront (Morton order within a class).
   uint32_t s;
   bool valid;
-  if (wave < heavy_waves) {
-    s = lane * heavy_waves + wave;
-    valid = s < heavy && lane < cont.meta[3];
+  if (wave < top_waves) {
+    const uint32_t hl = cont.meta[3];
+    s = wave * hl + lane;
+    valid = lane < hl && s < top;
+  } else if (wave < top_waves + heavy_waves) {
+    s = cont.meta[6] ? top + lane * heavy_waves + (wave - top_waves) : top + (wave - top_waves) * 64u + lane;
+    valid = s < heavy;
   } else {
-    s = heavy + (wave - heavy_waves) * 64u + lane;
+    s = heavy + (wave - top_waves - heavy_waves) * 64u + lane;
     valid = s < n2;
   }
   if (!valid) return;
@@ -1039,7 +1076,8 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   const float4 qrec = qs[e];
   const float qx = qrec.x, qy = qrec.y, qz = qrec.z;
   const uint32_t qi = __float_as_uint(qrec.w);
-  const uint32_t cls = 7u - cont.key[e];
+  const uint4 start = cont.best[e];
+  const uint32_t cls = start.z;
 
   Record spill[OVF > 0 ? OVF : 1];
   Stack<S, OVF, 64> st;
@@ -1051,7 +1089,6 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     pol.begin_query(qi);
     traverse<LEAFB, false>(t, qx, qy, qz, pol, st);
   } else {
-    const uint4 start = cont.best[e];
     pol.best_i = (int32_t)start.x;
     pol.best_d = __uint_as_float(start.y);
     for (uint32_t j = 0; j < cls; ++j) {
@@ -1371,7 +1408,7 @@ __global__ __launch_bounds__(64) void knn1_phase2_refill_kernel(
           break;
         }
         const uint32_t slot = g * 64u + lane;
-        const bool has = slot < nq && cont.key[slot] != 7u;  // key = 7 - class; class 0 is final already
+        const bool has = slot < nq && !cont_key_is_final(cont.key[slot]);  // class 0 is final already
         const uint64_t m = __ballot(has);
         if (has) queue[(q_tail + (uint32_t)__popcll(m & lanes_below)) & (kQueueSlots - 1u)] = slot;
         q_tail += (uint32_t)__popcll(m);

@@ -340,7 +340,7 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   std::vector<float4> qs = pack(q, t->dim, perm, nq);
   std::vector<ptk::Record> crec(nq * ptk::kContSlots + 8);
   std::vector<uint4> cbest(nq);
-  std::vector<uint8_t> ckey(nq, 0xEE);
+  std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
   std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(16, 0);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
   if (variant == 7 || variant == 8)  // wave-uniform prefix phase 1 (ballots: lanes run as fibers)
@@ -368,12 +368,12 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
                                                   1u);
       });
     int todo = 0;
-    for (uint64_t i = 0; i < nq; ++i) todo += ckey[i] != 7;
+    for (uint64_t i = 0; i < nq; ++i) todo += (ckey[i] >> 13) != 7;
     return todo;
   }
   // stable sort by key (what the device's radix pass does)
   std::vector<uint32_t> sorted(nq);
-  std::vector<uint8_t> sorted_key(nq);
+  std::vector<ptk::ContKey> sorted_key(nq);
   {
     std::vector<uint32_t> order(nq);
     for (uint64_t i = 0; i < nq; ++i) order[i] = (uint32_t)i;
@@ -386,7 +386,12 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   gridDim.x = 1;
   blockIdx.x = 0;
   threadIdx.x = 0;
-  ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont);
+  // variant 8 also exercises the top tier: half of the ranked classes, 4 lanes per wavefront.
+  const uint32_t top_extra = variant == 8 ? (uint32_t)(nq / 4) + 2u : 0u;
+  if (variant == 8)
+    ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, 4u, 500u, top_extra);
+  else
+    ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont);
   if (variant == 3 || variant == 4) {  // persistent phase 2 (variant 4: tiny ring)
     const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
     if (variant == 3)
@@ -399,7 +404,7 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
       });
     return (int)meta[0];
   }
-  const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1;
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
   gridDim.x = blocks;
   blockDim.x = 64;
   for (uint32_t b = 0; b < blocks; ++b) {
@@ -422,14 +427,15 @@ int emu_phase1(void* h, const float* q, uint64_t nq, uint8_t* cls_out, float* be
   std::vector<float4> qs = pack(q, t->dim, nullptr, nq);
   std::vector<ptk::Record> crec(nq * ptk::kContSlots + 8);
   std::vector<uint4> cbest(nq);
-  std::vector<uint8_t> ckey(nq, 0xEE);
+  std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
   std::vector<uint32_t> cids(nq), meta(16, 0);
   std::vector<ptk::Neighbor> o(nq);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
   for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, 1.0f, o.data(), cont); }, 64);
   for (uint64_t i = 0; i < nq; ++i) {
-    cls_out[i] = (uint8_t)(7 - ckey[i]);
-    best_out[i] = ckey[i] == 7 ? o[i].distance : __uint_as_float(cbest[i].y);
+    const bool final_ = (ckey[i] >> 13) == 7;
+    cls_out[i] = final_ ? 0 : (uint8_t)cbest[i].z;
+    best_out[i] = final_ ? o[i].distance : __uint_as_float(cbest[i].y);
   }
   return 0;
 }
