@@ -605,7 +605,14 @@ template <int S1, bool DOUBLE, int S2, int OVF, int LEAFB, bool PERSISTENT2, boo
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
+  int rc = PTK_OK;
+  if (UNIFORM1) {  // phase 1 packs the launch-order records itself
+    if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
+    qs = scratch.take<float4>(nq);
+    if (qs == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
+  } else {
+    rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
+  }
   if (rc != PTK_OK) return rc;
   ptk::Cont cont{};
   cont.nq = nq;
@@ -632,8 +639,8 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
     Timer timer(t, s);
     if (UNIFORM1) {
-      hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB1>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq, e_inv,
-                         d_out, cont, (uint32_t)env_int("PTK_DEBUG_PHASE1", 0));
+      hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB1, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
+                         e_inv, d_out, cont, (uint32_t)env_int("PTK_DEBUG_PHASE1", 0), d_q, t->dim, perm, qs);
     } else {
       hipLaunchKernelGGL((ptk::knn1_phase1_kernel<S1, OVF, LEAFB, DOUBLE>), dim3(blocks), dim3(64), smem, s, t->dev,
                          qs, nq, e_inv, d_out, cont);

@@ -864,19 +864,32 @@ __device__ __forceinline__ uint32_t uniform_value(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-template <int LEAFB>
+// PACK: the launch-order query records are made here (gather through `perm` + one coalesced
+// 16-byte store for phase 2) instead of by a separate pack_queries_kernel pass.
+template <int LEAFB, bool PACK = false>
 __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
-    Cont cont, uint32_t debug_skip = 0) {
+    Cont cont, uint32_t debug_skip = 0, const float* __restrict__ queries = nullptr, uint32_t dim = 3,
+    const uint32_t* __restrict__ perm = nullptr, float4* __restrict__ qs_out = nullptr) {
   // debug_skip (timing experiments only, results incomplete): 1 = no second descent, 2 = no stores, 4 = no leaf.
   const uint64_t i0 = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
   const uint4* __restrict__ nodes = t.nodes;
   const float4* __restrict__ pts = t.pts;
-  const float4 qrec = qs[i];
-  const float qx = qrec.x, qy = qrec.y, qz = qrec.z;
-  const uint32_t qi = __float_as_uint(qrec.w);
+  float qx, qy, qz;
+  uint32_t qi;
+  if constexpr (PACK) {
+    qi = perm ? perm[i] : (uint32_t)i;
+    load_query(queries, dim, qi, qx, qy, qz);
+    if (valid) qs_out[i] = make_float4(qx, qy, qz, __uint_as_float(qi));
+  } else {
+    const float4 qrec = qs[i];
+    qx = qrec.x;
+    qy = qrec.y;
+    qz = qrec.z;
+    qi = __float_as_uint(qrec.w);
+  }
 
   NnPolicy pol;
   pol.e_inv = e_inv;
