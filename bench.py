@@ -10,10 +10,14 @@ timed region; the tree is built and uploaded once, outside it.
 
     python bench.py --gpus N --steps K --warmup W
 
-For N > 1 the driver launches this file under ``torch.distributed.run``; the
-batch is split into N contiguous shards (strong scaling: the total stays
-7.2 M queries), each rank searches its shard against its own replica of the
-tree, and rank 0 gathers the results.
+For N > 1 the driver launches this file under ``torch.distributed.run``, one rank per GPU,
+tree replicated on every GPU, queries independent (no data-path collective).  Default
+``--scaling weak``: every rank searches its own full config-2 batch (7.2 M queries drawn from the
+same cloud with a different seed), so per-GPU work is fixed and ``value`` = N x 7.2 M queries / step;
+rank 0 still collects every rank's (index, distance) rows with one RCCL gather per step, issued
+asynchronously so that it overlaps the next step's search (all gathers complete inside the timed
+region).  ``--scaling strong`` is BASELINE configs[3] literally: ONE 7.2 M batch cut into N
+contiguous shards.
 
 Rank 0 prints ONE JSON line; see README.md / DESIGN.md for the field meanings.
 """
@@ -55,6 +59,8 @@ def parse_args():
     ap.add_argument("--nq", type=int, default=None, help="queries (default: config 2)")
     ap.add_argument("--leaf", type=int, default=10)
     ap.add_argument("--reorder", choices=["auto", "on", "off"], default="auto")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="N > 1: weak = a full batch per GPU, strong = one batch cut into N shards")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="approximate budget of the OpenMP CPU baseline sample")
@@ -158,8 +164,12 @@ def main():
     k = args.k
     dim = 3
 
+    weak = args.scaling == "weak" and world > 1
     t0 = time.perf_counter()
     pts, q = ds.config2_clouds(args.cloud, n, nq)
+    if weak and rank > 0:  # this rank's own batch: same cloud, different seed
+        q = (ds.lidar_cloud(nq, seed=2 + rank, pose=(3.0, 1.5), unit_scale=20.0) if args.cloud == "L"
+             else ds.uniform_cloud(nq, 3, seed=2 + rank, scale=100.0))
     if args.order == "morton":
         q = np.ascontiguousarray(q[ds.morton_order(q)])
     gen_s = time.perf_counter() - t0
@@ -173,19 +183,25 @@ def main():
         log(f"[bench] clouds {args.cloud}/{args.order}: gen {gen_s:.1f}s, host build+upload {build_s:.1f}s, "
             f"nodes {info['n_nodes']}, depth {info['max_depth']}, HBM {info['device_bytes'] / 1e6:.1f} MB")
 
-    # Shard: contiguous ranges of ceil(nq / world) queries in caller order.
     from pico_tree_amd.sharded import ShardedSearch, padded_shard, shard_of
 
-    sh = shard_of(nq, world, rank)
-    per, lo, hi = sh.per, sh.lo, sh.hi
-    dq = torch.from_numpy(padded_shard(q, sh)).to(dev)
-    out = torch.empty((per, k, 2), dtype=torch.int32, device=dev)
-    sharded = ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw)
+    if weak:  # every rank: its whole batch
+        sh = shard_of(nq * world, world, rank)
+        per, lo, hi = nq, 0, nq
+        dq = torch.from_numpy(q).to(dev)
+    else:     # contiguous ranges of ceil(nq / world) rows of ONE batch, in caller order
+        sh = shard_of(nq, world, rank)
+        per, lo, hi = sh.per, sh.lo, sh.hi
+        dq = torch.from_numpy(padded_shard(q, sh)).to(dev)
+    total_queries = nq * world if weak else nq
+    sharded = ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw,
+                            lambda: torch.empty((per, k, 2), dtype=torch.int32, device=dev))
 
     def step():
-        sharded.step(dq, out)
+        return sharded.step(dq)
 
     def fence():
+        sharded.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -197,7 +213,7 @@ def main():
     tree.profile(enable=True, reset=True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        out = step()
     fence()
     elapsed = time.perf_counter() - t0
     prof = tree.profile(enable=False, reset=True)
@@ -207,7 +223,7 @@ def main():
         elapsed = float(tmax.item())
 
     ms_per_step = elapsed / args.steps * 1e3
-    value = nq / (elapsed / args.steps) / 1e6
+    value = total_queries / (elapsed / args.steps) / 1e6
 
     result = None
     if rank == 0:
@@ -220,6 +236,22 @@ def main():
         want = ref_small.search_knn(q[lo:hi][sample], k)
         got = res[sample] if k > 1 else res[sample][:, None]
         parity_ok = bool(got.tobytes() == want.tobytes())
+        if world > 1:  # and the rows rank 0 gathered from rank 1 (last step)
+            rows = sharded.result(rows_per_rank=per if weak else None)
+            if weak:
+                q1 = (ds.lidar_cloud(nq, seed=3, pose=(3.0, 1.5), unit_scale=20.0) if args.cloud == "L"
+                      else ds.uniform_cloud(nq, 3, seed=3, scale=100.0))
+                if args.order == "morton":
+                    q1 = np.ascontiguousarray(q1[ds.morton_order(q1)])
+                got1 = pt.DeviceNeighbors(rows[per:2 * per]).numpy()[sample]
+                want1 = ref_small.search_knn(q1[sample], k)
+            else:
+                sh1 = shard_of(nq, world, 1)
+                s1 = np.linspace(sh1.lo, sh1.hi - 1, num=min(4096, sh1.rows), dtype=np.int64)
+                got1 = pt.DeviceNeighbors(rows).numpy()[s1]
+                want1 = ref_small.search_knn(q[s1], k)
+            got1 = got1 if k > 1 else got1[:, None]
+            parity_ok = parity_ok and bool(got1.tobytes() == want1.tobytes())
 
         rng = np.random.default_rng(7)
         cs = rng.choice(nq, size=min(args.counter_sample, nq), replace=False)
@@ -253,14 +285,18 @@ def main():
                       else f"Mqueries/sec, knn={k} 3D L2",
             "value": round(value, 3), "unit": "Mqueries/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[1]: cloud {args.cloud} "
                                    f"({'LiDAR-like room scan' if args.cloud == 'L' else 'uniform cube'}), "
                                    f"{n} tree points / {nq} queries, knn={k}, max_leaf_size={args.leaf}, "
                                    f"sliding midpoint",
                        "query_order": args.order, "reorder": args.reorder,
-                       "parallelism": f"queries sharded x{world}, tree replicated"
-                                      + (", RCCL gather to rank 0" if world > 1 else ""),
+                       "parallelism": (f"{world} x {nq} queries (one full batch per GPU), tree replicated"
+                                       if weak else f"one batch of {nq} queries cut into {world} shards, "
+                                                    f"tree replicated")
+                                      + (", (index, distance) rows gathered on rank 0 over RCCL, "
+                                         "overlapped with the next step" if world > 1 else ""),
+                       "queries_per_step": int(total_queries),
                        "tree_nodes": int(info["n_nodes"]), "tree_depth": int(info["max_depth"]),
                        "host_build_upload_s": round(build_s, 2)},
             "parity_sample_ok": parity_ok,

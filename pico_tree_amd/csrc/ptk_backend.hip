@@ -587,6 +587,24 @@ int launch_radius_persistent(const ptk_tree* t, const float* d_q, const uint32_t
 
 // Two-phase k = 1 search (see ptk_kernels.hpp): phase 1 over the whole batch, a 3-bit radix
 // pass over the continuations, phase 2 over the continuations.
+// PTK_TIERS="60:4" (default): the first 60 per mille of the ranked classes at 4 lanes per wave.
+ptk::TierSpec parse_tiers() {
+  ptk::TierSpec t{};
+  const char* v = std::getenv("PTK_TIERS");
+  std::string spec = v ? v : "60:4";
+  size_t pos = 0;
+  for (uint32_t i = 0; i < ptk::kMaxTiers && pos < spec.size(); ++i) {
+    unsigned pm = 0, lanes = 0;
+    int used = 0;
+    if (std::sscanf(spec.c_str() + pos, "%u:%u%n", &pm, &lanes, &used) < 2) break;
+    t.permille[i] = pm > 1000 ? 1000 : pm;
+    t.lanes[i] = lanes;
+    pos += (size_t)used;
+    if (pos < spec.size() && spec[pos] == ',') ++pos;
+  }
+  return t;
+}
+
 size_t class_sort_tmp_bytes(uint64_t nq) {
   size_t tmp_bytes = 0;
   ptk::ContKey* k16 = nullptr;
@@ -629,12 +647,10 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     return fail(PTK_ERR_NOMEM, "scratch block too small");
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
-  // The top tier (head of the ranked classes) runs `heavy_lanes` per wavefront; the grid has
-  // room for 1/32 of the batch in that tier (the meta kernel clamps the tier to what fits).
-  uint32_t heavy_lanes = (uint32_t)env_int("PTK_TOP_LANES", 4);
-  if (heavy_lanes < 1 || heavy_lanes > 64) heavy_lanes = 64;
-  const uint32_t top_permille = (uint32_t)env_int("PTK_TOP_PERMILLE", 60);
-  const uint32_t extra_waves = top_permille == 0 ? 0u : (uint32_t)(nq / 32 / heavy_lanes) + 2u;
+  // Narrow tiers at the head of the ranked classes: "permille:lanes,..." (cumulative marks).  The
+  // grid has room for nq / 64 extra waves there; the meta kernel cuts the tiers to what fits.
+  ptk::TierSpec tiers = parse_tiers();
+  const uint32_t extra_waves = tiers.permille[0] == 0 ? 0u : (uint32_t)(nq / 64) + 2u;
   {
     const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
     Timer timer(t, s);
@@ -651,8 +667,8 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     Timer timer(t, s);
     PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 16, s));
     hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont,
-                       (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass), heavy_lanes, top_permille,
-                       extra_waves, (uint32_t)env_int("PTK_DEAL", 1));
+                       (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass), tiers, extra_waves,
+                       (uint32_t)env_int("PTK_DEAL", 1));
     timer.stop(2, 0);
   }
   {

@@ -1016,13 +1016,19 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 // One thread, after the sort: where the tiers of the sorted list end.
 //   meta[0] n2      continuations (everything before class 0)
 //   meta[1] heavy   end of the dealt tier (classes >= heavy_class)
-//   meta[2] waves of the dealt tier     meta[3] lanes per wave of the TOP tier
-//   meta[4] t3      end of the top tier (the first `top_permille` of the ranked classes)
-//   meta[5] waves of the top tier
+//   meta[2] waves of the dealt tier     meta[6] dealt (1) or consecutive (0) middle tier
+//   meta[4] end of the narrow tiers     meta[5] their waves in total
+//   meta[8 + 4 i ..]  narrow tier i: {first entry, end entry, lanes per wave, first wave}
+// The narrow tiers cut the head of the ranked classes at cumulative per-mille marks.
+constexpr uint32_t kMaxTiers = 4;
+struct TierSpec {
+  uint32_t permille[kMaxTiers];  // cumulative share of the ranked group where tier i ends (0 = unused)
+  uint32_t lanes[kMaxTiers];
+};
+
 __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, uint32_t nq, Cont cont,
-                                       uint32_t heavy_class = kHeavyClass, uint32_t top_lanes = 64u,
-                                       uint32_t top_permille = 0u, uint32_t max_top_waves = 0u,
-                                       uint32_t deal = 1u) {
+                                       uint32_t heavy_class, TierSpec tiers, uint32_t max_narrow_waves,
+                                       uint32_t deal) {
   auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
     uint32_t lo = 0, hi = nq;
     while (lo < hi) {
@@ -1033,19 +1039,31 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
   };
   const uint32_t n2 = first_at_least(7u << 13);
   const uint32_t ranked = first_at_least(1u << 13);  // classes >= kRankedClass
-  uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
-  uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : first_at_least((7u - hc + 1u) << 13));
-  if (hc > kRankedClass && hc <= 7u) heavy = ranked;  // the ranked classes are one group
-  uint32_t hl = top_lanes < 1u || top_lanes > 64u ? 64u : top_lanes;
-  uint32_t t3 = (uint32_t)(((uint64_t)ranked * top_permille) / 1000u);
-  if (t3 > heavy) t3 = heavy;
-  if ((t3 + hl - 1u) / hl > max_top_waves) t3 = max_top_waves * hl < t3 ? max_top_waves * hl : t3;
+  const uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
+  const uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : first_at_least((7u - hc + 1u) << 13));
+  uint32_t begin = 0, wave = 0;
+  for (uint32_t i = 0; i < kMaxTiers; ++i) {
+    uint32_t end = (uint32_t)(((uint64_t)ranked * tiers.permille[i]) / 1000u);
+    if (end > heavy) end = heavy;
+    if (end < begin) end = begin;
+    uint32_t hl = tiers.lanes[i] < 1u || tiers.lanes[i] > 64u ? 64u : tiers.lanes[i];
+    uint32_t waves = (end - begin + hl - 1u) / hl;
+    if (wave + waves > max_narrow_waves) {  // the launch has no room: this tier ends early
+      waves = max_narrow_waves - wave;
+      end = begin + waves * hl;
+    }
+    cont.meta[8 + 4 * i + 0] = begin;
+    cont.meta[8 + 4 * i + 1] = end;
+    cont.meta[8 + 4 * i + 2] = hl;
+    cont.meta[8 + 4 * i + 3] = wave;
+    begin = end;
+    wave += waves;
+  }
   cont.meta[0] = n2;
   cont.meta[1] = heavy;
-  cont.meta[2] = (heavy - t3 + 63u) / 64u;
-  cont.meta[3] = hl;
-  cont.meta[4] = t3;
-  cont.meta[5] = (t3 + hl - 1u) / hl;
+  cont.meta[2] = (heavy - begin + 63u) / 64u;
+  cont.meta[4] = begin;
+  cont.meta[5] = wave;
   cont.meta[6] = deal;
 }
 
@@ -1062,21 +1080,31 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   // Timing experiments only (results are incomplete): 1 = skip the heavy waves, 2 = only them.
+  // 3 / 4 / 5 = only the top / dealt / light tier.
   if (debug_mode == 1 && wave < top_waves + heavy_waves) return;
   if (debug_mode == 2 && wave >= top_waves + heavy_waves) return;
+  if (debug_mode == 3 && wave >= top_waves) return;
+  if (debug_mode == 4 && (wave < top_waves || wave >= top_waves + heavy_waves)) return;
+  if (debug_mode == 5 && wave < top_waves + heavy_waves) return;
   // Three tiers of the sorted list, most expensive first (blocks are dispatched in order):
-  //   top    the head of the ranked classes, few lanes per wavefront: these queries are long
-  //          dependent chains (hundreds of leaves); a wave's round costs the maximum over its
-  //          lanes, so fewer lanes = shorter rounds on what is the critical path of the launch;
+  //   narrow the head of the ranked classes in up to kMaxTiers tiers of few lanes per wavefront:
+  //          these queries are long dependent chains (hundreds of leaves); a wave's round costs
+  //          the maximum over its lanes, so fewer lanes = shorter rounds on what is the critical
+  //          path of the launch (empty tiers have first wave == the next tier's first wave);
   //   dealt  the other heavy classes: lane l of wave w takes entry l * waves + w, so neighbours in
   //          the list (similar cost, spatially adjacent) land in different wavefronts;
   //   light  64 consecutive entries per wavefront (Morton order within a class).
   uint32_t s;
   bool valid;
   if (wave < top_waves) {
-    const uint32_t hl = cont.meta[3];
-    s = wave * hl + lane;
-    valid = lane < hl && s < top;
+    uint32_t tier = 0;
+#pragma unroll
+    for (uint32_t i = 1; i < kMaxTiers; ++i) {
+      if (wave >= cont.meta[8 + 4 * i + 3]) tier = i;
+    }
+    const uint32_t hl = cont.meta[8 + 4 * tier + 2];
+    s = cont.meta[8 + 4 * tier + 0] + (wave - cont.meta[8 + 4 * tier + 3]) * hl + lane;
+    valid = lane < hl && s < cont.meta[8 + 4 * tier + 1];
   } else if (wave < top_waves + heavy_waves) {
     s = cont.meta[6] ? top + lane * heavy_waves + (wave - top_waves) : top + (wave - top_waves) * 64u + lane;
     valid = s < heavy;

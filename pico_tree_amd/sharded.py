@@ -9,9 +9,9 @@ rank 0 collects the ``(index, distance)`` records with ONE gather over RCCL/xGMI
 k = 1, so no ring or tree is needed).  Rows keep the caller's order: shard ``r``
 owns rows ``[r * per, min((r + 1) * per, nq))``.
 
-Nothing here touches the search itself -- ``search`` is any callable mapping a
-``(per, dim)`` float32 tensor to a ``(per, k, 2)`` int32 tensor (on the GPU:
-``lambda q: tree.search_knn(q, k).raw``), which is what lets the 2-process gloo
+Nothing here touches the search itself -- ``search`` is any callable filling a
+``(per, k, 2)`` int32 tensor from a ``(per, dim)`` float32 tensor (on the GPU:
+``lambda q, out: tree.search_knn(q, k, out).raw``), which is what lets the 2-process gloo
 test exercise the bookkeeping on CPU.
 """
 
@@ -58,35 +58,66 @@ def padded_shard(queries: np.ndarray, shard: Shard) -> np.ndarray:
 
 
 class ShardedSearch:
-    """Search the local shard, then gather every shard's rows on rank 0."""
+    """Search the local rows, then gather every rank's rows on rank 0.
 
-    def __init__(self, shard: Shard, search, group=None):
+    ``search(q, out)`` must fill (and return) the preallocated ``out``.  The gather of step i is
+    issued asynchronously and overlaps the search of step i + 1: ``depth`` output buffers are used
+    in rotation and a buffer is only handed to a new search after the gather that reads it has been
+    waited for (``work.wait()`` orders the current stream behind the collective; on RCCL it does
+    not block the host).  ``finish()`` waits for everything still in flight -- call it before
+    stopping a clock.
+    """
+
+    def __init__(self, shard: Shard, search, make_out, group=None, depth: int = 2):
         self.shard = shard
         self.search = search
         self.group = group
-        self._gathered = None
+        self.depth = max(1, int(depth))
+        self._out = [make_out() for _ in range(self.depth)]
+        self._recv = [None] * self.depth     # rank 0: list of world tensors per buffer
+        self._work = [None] * self.depth
+        self._step = 0
+        self._last = None
 
-    def step(self, q_local, out=None):
-        """One pass: returns the local result tensor; rank 0 also refreshes ``gathered``."""
+    def step(self, q_local):
+        """One pass: returns the local result tensor of this step."""
         import torch.distributed as dist
 
-        res = self.search(q_local) if out is None else self.search(q_local, out)
+        b = self._step % self.depth
+        self._step += 1
+        if self._work[b] is not None:  # the gather that still reads this buffer
+            self._work[b].wait()
+            self._work[b] = None
+        res = self.search(q_local, self._out[b])
         if self.shard.world > 1:
             if self.shard.rank == 0:
-                if self._gathered is None:
+                if self._recv[b] is None:
                     import torch
-                    self._gathered = [torch.empty_like(res) for _ in range(self.shard.world)]
-                dist.gather(res, self._gathered, dst=0, group=self.group)
+                    self._recv[b] = [torch.empty_like(res) for _ in range(self.shard.world)]
+                self._work[b] = dist.gather(res, self._recv[b], dst=0, group=self.group, async_op=True)
             else:
-                dist.gather(res, None, dst=0, group=self.group)
+                self._work[b] = dist.gather(res, None, dst=0, group=self.group, async_op=True)
+        self._last = b
         return res
 
-    def result(self, local):
-        """Rank 0: all ``nq`` rows in caller order, ``(nq, k, 2)``; other ranks: ``None``."""
+    def finish(self) -> None:
+        for b in range(self.depth):
+            if self._work[b] is not None:
+                self._work[b].wait()
+                self._work[b] = None
+
+    def result(self, rows_per_rank=None):
+        """Rank 0: the rows of the LAST step from every rank, concatenated in rank order and cut to
+        ``shard.nq`` rows (contiguous sharding) or to ``rows_per_rank`` rows each (replicated
+        batches); other ranks: ``None``."""
         import torch
 
+        self.finish()
+        b = self._last
         if self.shard.world == 1:
-            return local[:self.shard.nq]
+            return self._out[b][:self.shard.nq]
         if self.shard.rank != 0:
             return None
-        return torch.cat(self._gathered, dim=0)[:self.shard.nq]
+        if rows_per_rank is not None:
+            return torch.cat([t[:rows_per_rank] for t in self._recv[b]], dim=0)
+        return torch.cat(self._recv[b], dim=0)[:self.shard.nq]

@@ -387,11 +387,14 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   blockIdx.x = 0;
   threadIdx.x = 0;
   // variant 8 also exercises the top tier: half of the ranked classes, 4 lanes per wavefront.
-  const uint32_t top_extra = variant == 8 ? (uint32_t)(nq / 4) + 2u : 0u;
-  if (variant == 8)
-    ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, 4u, 500u, top_extra);
-  else
-    ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont);
+  const uint32_t top_extra = variant == 8 ? (uint32_t)nq + 2u : 0u;
+  ptk::TierSpec tiers{};
+  if (variant == 8) {  // three narrow tiers: 1, 4 and 16 lanes per wave
+    tiers.permille[0] = 200; tiers.lanes[0] = 1;
+    tiers.permille[1] = 500; tiers.lanes[1] = 4;
+    tiers.permille[2] = 800; tiers.lanes[2] = 16;
+  }
+  ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
   if (variant == 3 || variant == 4) {  // persistent phase 2 (variant 4: tiny ring)
     const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
     if (variant == 3)

@@ -45,23 +45,38 @@ def _worker(rank, world, port, nq, k, tmp):
     from pico_tree_amd.sharded import ShardedSearch, padded_shard, shard_of
 
     pts = ds.uniform_cloud(20_000, 3, seed=5)   # every rank builds the same replica
-    q = ds.uniform_cloud(nq, 3, seed=6)
     ref = oracle.Oracle(pts, 10, "port")
 
-    def search(q_local):  # stand-in for tree.search_knn(q_local, k).raw on the GPU
+    def search(q_local, out):  # stand-in for tree.search_knn(q_local, k, out).raw on the GPU
         res = ref.search_knn(q_local.numpy(), k)
-        return torch.from_numpy(res.view(np.int32).reshape(len(res), k, 2).copy())
+        out.copy_(torch.from_numpy(res.view(np.int32).reshape(len(res), k, 2).copy()))
+        return out
 
     sh = shard_of(nq, world, rank)
-    ss = ShardedSearch(sh, search)
-    local = ss.step(torch.from_numpy(padded_shard(q, sh)))
-    dist.barrier()
-    full = ss.result(local)
+    ss = ShardedSearch(sh, search, lambda: torch.empty((sh.per, k, 2), dtype=torch.int32), depth=2)
+    ok = True
+    # Several steps with DIFFERENT batches: the gather of one step overlaps the next search, and the
+    # rotating buffers must never be overwritten while a gather still reads them.
+    for step in range(5):
+        q = ds.uniform_cloud(nq, 3, seed=6 + step)
+        ss.step(torch.from_numpy(padded_shard(q, sh)))
+        if step in (0, 3, 4):
+            full = ss.result()
+            if rank == 0:
+                want = ref.search_knn(q, k).view(np.int32).reshape(nq, k, 2)
+                ok = ok and bool(np.array_equal(full.numpy(), want))
+            else:
+                assert full is None
+    # Replicated batches (weak scaling): every rank searches its own nq rows, rank 0 gets world * nq.
+    sh1 = shard_of(nq * world, world, rank)
+    ss2 = ShardedSearch(sh1, search, lambda: torch.empty((nq, k, 2), dtype=torch.int32))
+    mine = ds.uniform_cloud(nq, 3, seed=100 + rank)
+    ss2.step(torch.from_numpy(mine))
+    both = ss2.result(rows_per_rank=nq)
     if rank == 0:
-        want = ref.search_knn(q, k).view(np.int32).reshape(nq, k, 2)
-        np.save(os.path.join(tmp, "ok.npy"), np.array([int(np.array_equal(full.numpy(), want))]))
-    else:
-        assert full is None
+        want = np.concatenate([ref.search_knn(ds.uniform_cloud(nq, 3, seed=100 + r), k) for r in range(world)])
+        ok = ok and bool(np.array_equal(both.numpy(), want.view(np.int32).reshape(nq * world, k, 2)))
+        np.save(os.path.join(tmp, "ok.npy"), np.array([int(ok)]))
     dist.barrier()
     dist.destroy_process_group()
 
