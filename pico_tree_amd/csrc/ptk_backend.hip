@@ -641,7 +641,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   ptk::ContKey* key_out = scratch.take<ptk::ContKey>(nq);
   cont.ids = scratch.take<uint32_t>(nq);
   uint32_t* ids_out = scratch.take<uint32_t>(nq);
-  cont.meta = scratch.take<uint32_t>(16);
+  cont.meta = scratch.take<uint32_t>(ptk::kMetaWords);
   void* tmp = scratch.take<char>(tmp_bytes);
   if (!cont.rec || !cont.best || !cont.key || !key_out || !cont.ids || !ids_out || !cont.meta || !tmp)
     return fail(PTK_ERR_NOMEM, "scratch block too small");
@@ -738,12 +738,12 @@ int launch_knn1_refill(const ptk_tree* t, const float* d_q, const uint32_t* perm
   cont.best = scratch.take<uint4>(nq);
   cont.key = scratch.take<ptk::ContKey>(nq);
   cont.ids = scratch.take<uint32_t>(nq);
-  cont.meta = scratch.take<uint32_t>(16);
+  cont.meta = scratch.take<uint32_t>(ptk::kMetaWords);
   if (!cont.rec || !cont.best || !cont.key || !cont.ids || !cont.meta)
     return fail(PTK_ERR_NOMEM, "scratch block too small");
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
-  PTK_HIP(hipMemsetAsync(cont.meta, 0, 16 * 4, s));
+  PTK_HIP(hipMemsetAsync(cont.meta, 0, ptk::kMetaWords * 4, s));
   {
     Timer timer(t, s);
     hipLaunchKernelGGL((ptk::knn1_phase1_kernel<32, OVF, 4, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,

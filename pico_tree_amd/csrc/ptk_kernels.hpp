@@ -715,7 +715,7 @@ struct Cont {
                         //                   loads one record index as one coalesced run), shallowest first
   ContKey* key;         // [nq]  sort key of the slot, see make_cont_key()
   uint32_t* ids;        // [nq]  slot index (sorted together with key)
-  uint32_t* meta;       // [0] continuations  [1] heavy continuations  [2] heavy wavefronts
+  uint32_t* meta;       // [kMetaWords], written by knn1_phase_meta_kernel (layout there)
   uint64_t nq;          // slots (= queries of the batch)
   __device__ __forceinline__ Record& record(uint32_t slot, uint32_t s) const { return rec[(uint64_t)s * nq + slot]; }
 };
@@ -1021,6 +1021,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 //   meta[8 + 4 i ..]  narrow tier i: {first entry, end entry, lanes per wave, first wave}
 // The narrow tiers cut the head of the ranked classes at cumulative per-mille marks.
 constexpr uint32_t kMaxTiers = 4;
+constexpr uint32_t kMetaWords = 32;  // size of Cont::meta (8 fixed words + 4 per narrow tier, rounded up)
 struct TierSpec {
   uint32_t permille[kMaxTiers];  // cumulative share of the ranked group where tier i ends (0 = unused)
   uint32_t lanes[kMaxTiers];

@@ -341,7 +341,7 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   std::vector<ptk::Record> crec(nq * ptk::kContSlots + 8);
   std::vector<uint4> cbest(nq);
   std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
-  std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(16, 0);
+  std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(ptk::kMetaWords, 0);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
   if (variant == 7 || variant == 8)  // wave-uniform prefix phase 1 (ballots: lanes run as fibers)
     for_each_wave((uint32_t)((nq + 63) / 64), [&] {
@@ -431,7 +431,7 @@ int emu_phase1(void* h, const float* q, uint64_t nq, uint8_t* cls_out, float* be
   std::vector<ptk::Record> crec(nq * ptk::kContSlots + 8);
   std::vector<uint4> cbest(nq);
   std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
-  std::vector<uint32_t> cids(nq), meta(16, 0);
+  std::vector<uint32_t> cids(nq), meta(ptk::kMetaWords, 0);
   std::vector<ptk::Neighbor> o(nq);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
   for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, 1.0f, o.data(), cont); }, 64);
