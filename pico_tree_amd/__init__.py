@@ -433,6 +433,36 @@ class KdTree:
         nns._assign(offsets, flat)
         return nns
 
+    # -- box ------------------------------------------------------------------------------
+    def search_box(self, boxes, nns=None):
+        """``search_box(boxes[, nns])`` -> :class:`DArray` of int32 index arrays.
+
+        ``boxes`` is ``(2 * nbox, sdim)``: rows ``2 i`` and ``2 i + 1`` are the min and max corner
+        of box ``i`` (``_pyco_tree/kd_tree.hpp:245-268``).  Row ``i`` of the result lists the points
+        inside the closed box in the reference's traversal order."""
+        b = self._as_matrix(boxes, self._sdim, "boxes")
+        if b.shape[0] % 2 != 0:
+            raise ValueError("query min and max don't have equal size")
+        nb = b.shape[0] // 2
+        mins = np.ascontiguousarray(b[0::2])
+        maxs = np.ascontiguousarray(b[1::2])
+        if nns is not None and (not isinstance(nns, DArray) or nns.dtype != np.dtype(np.int32)):
+            raise ValueError("unexpected dtype_index for data")
+        offsets = np.zeros(nb + 1, dtype=np.uint64)
+        rows = c_void_p()
+        lib = _load()
+        _check(lib.ptk_search_box(self._h, mins.ctypes.data, maxs.ctypes.data, nb, offsets.ctypes.data,
+                                  byref(rows)))
+        total = int(offsets[-1])
+        flat = np.empty(total, dtype=np.int32)
+        if total:
+            ctypes.memmove(flat.ctypes.data, rows.value, total * 4)
+        lib.ptk_free(rows)
+        if nns is None:
+            return DArray(offsets, flat)
+        nns._assign(offsets, flat)
+        return nns
+
     def search_radius_device(self, q, radius: float, e: float = 1.0, sort: bool = False):
         """Device form: returns (offsets int64 tensor [nq + 1], raw int32 tensor [total, 2])."""
         import torch

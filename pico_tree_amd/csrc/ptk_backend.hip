@@ -116,6 +116,7 @@ struct ptk_tree {
   ptk::DevTree dev{};
   void* d_nodes = nullptr;
   void* d_pts = nullptr;
+  void* d_ranges = nullptr; // dim <= 3: subtree ranges for the box search
   void* d_axes = nullptr;   // dim > 3 only
   void* d_index = nullptr;  // dim > 3 only
   ptk::DevTreeND dev_nd{};
@@ -195,7 +196,10 @@ int upload(ptk_tree& t, const float* points) {
   PTK_HIP(hipMalloc(&t.d_pts, enc.points.size() * sizeof(float4)));
   PTK_HIP(hipMemcpy(t.d_nodes, enc.nodes.data(), enc.nodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
   PTK_HIP(hipMemcpy(t.d_pts, enc.points.data(), enc.points.size() * sizeof(float4), hipMemcpyHostToDevice));
-  t.device_bytes = enc.nodes.size() * sizeof(uint4) + enc.points.size() * sizeof(float4);
+  PTK_HIP(hipMalloc(&t.d_ranges, enc.ranges.size() * sizeof(ptk::EncRange)));
+  PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), enc.ranges.size() * sizeof(ptk::EncRange), hipMemcpyHostToDevice));
+  t.device_bytes = enc.nodes.size() * sizeof(uint4) + enc.points.size() * sizeof(float4) +
+                   enc.ranges.size() * sizeof(ptk::EncRange);
   t.dev.nodes = static_cast<const uint4*>(t.d_nodes);
   t.dev.pts = static_cast<const float4*>(t.d_pts);
   t.dev.root_ref = enc.root_ref;
@@ -988,6 +992,7 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
     if (t->d_pts) (void)hipFree(t->d_pts);
+    if (t->d_ranges) (void)hipFree(t->d_ranges);
     if (t->d_axes) (void)hipFree(t->d_axes);
     if (t->d_index) (void)hipFree(t->d_index);
   }
@@ -1265,10 +1270,88 @@ int ptk_search_radius(const ptk_tree* t, const float* q, uint64_t nq, float radi
 
 int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint64_t nb, uint64_t* offsets,
                    int32_t** out) {
-  (void)mins; (void)maxs; (void)nb; (void)offsets;
-  if (out) *out = nullptr;
-  if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
-  return fail(PTK_ERR_UNSUPPORTED, "search_box is not on the device yet");
+  if (out == nullptr || offsets == nullptr) return fail(PTK_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  int rc = check_search(t, mins, nb);
+  if (rc != PTK_OK) return rc;
+  if (nb > 0 && maxs == nullptr) return fail(PTK_ERR_INVALID, "null box buffer");
+  if (t->dim > 3) return fail(PTK_ERR_UNSUPPORTED, "search_box runs on the device for dim <= 3 only");
+  offsets[0] = 0;
+  if (nb == 0) return PTK_OK;
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  ptk::BoxState root{0, 0, 0, 0, 0, 0};
+  {
+    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (uint32_t d = 0; d < t->dim; ++d) {
+      mn[d] = t->root_min[d];
+      mx[d] = t->root_max[d];
+    }
+    root = ptk::BoxState{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
+  }
+  float *d_mn = nullptr, *d_mx = nullptr;
+  uint64_t *d_c = nullptr, *d_o = nullptr;
+  int32_t* d_out = nullptr;
+  void* tmp = nullptr;
+  const size_t bbytes = (size_t)nb * t->dim * sizeof(float);
+  hipError_t he = hipMalloc((void**)&d_mn, bbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_mx, bbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_c, (nb + 1) * 8);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nb + 1) * 8);
+  if (he == hipSuccess) he = hipMemset(d_c, 0, (nb + 1) * 8);
+  if (he == hipSuccess) he = hipMemcpy(d_mn, mins, bbytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(d_mx, maxs, bbytes, hipMemcpyHostToDevice);
+  uint64_t total = 0;
+  const uint32_t blocks = (uint32_t)((nb + 63) / 64);
+  const auto* ranges = static_cast<const uint2*>(t->d_ranges);
+  if (he == hipSuccess) {
+    PTK_WITH_OVF(16, ([&]() -> int {
+                   hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
+                                      t->dev, ranges, root, d_mn, d_mx, t->dim, nb, d_c, nullptr, nullptr);
+                   return PTK_OK;
+                 }()));
+    if (rc == PTK_OK) {
+      size_t tmp_bytes = 0;
+      he = rocprim::exclusive_scan(nullptr, tmp_bytes, d_c, d_o, (uint64_t)0, nb + 1, rocprim::plus<uint64_t>(),
+                                   (hipStream_t) nullptr);
+      if (he == hipSuccess) he = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+      if (he == hipSuccess)
+        he = rocprim::exclusive_scan(tmp, tmp_bytes, d_c, d_o, (uint64_t)0, nb + 1, rocprim::plus<uint64_t>(),
+                                     (hipStream_t) nullptr);
+      if (he == hipSuccess) he = hipMemcpy(offsets, d_o, (nb + 1) * 8, hipMemcpyDeviceToHost);
+      if (he == hipSuccess) {
+        total = offsets[nb];
+        he = hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * 4);
+      }
+      if (he == hipSuccess) {
+        PTK_WITH_OVF(16, ([&]() -> int {
+                       hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
+                                          t->dev, ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_o, d_out);
+                       return PTK_OK;
+                     }()));
+      }
+      if (he == hipSuccess && rc == PTK_OK) {
+        *out = static_cast<int32_t*>(std::malloc(std::max<uint64_t>(total, 1) * 4));
+        if (*out == nullptr) {
+          rc = fail(PTK_ERR_NOMEM, "out of memory");
+        } else if (total > 0) {
+          he = hipMemcpy(*out, d_out, total * 4, hipMemcpyDeviceToHost);
+        }
+      }
+    }
+  }
+  if (tmp) (void)hipFree(tmp);
+  if (d_mn) (void)hipFree(d_mn);
+  if (d_mx) (void)hipFree(d_mx);
+  if (d_c) (void)hipFree(d_c);
+  if (d_o) (void)hipFree(d_o);
+  if (d_out) (void)hipFree(d_out);
+  if (rc == PTK_OK && he != hipSuccess) rc = fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  if (rc != PTK_OK && *out) {
+    std::free(*out);
+    *out = nullptr;
+  }
+  return rc;
 }
 
 void ptk_free(void* p) { std::free(p); }

@@ -59,8 +59,13 @@ struct TreeStats {
   uint32_t max_depth = 0;
 };
 
+struct EncRange {
+  uint32_t begin, end;
+};
+
 struct EncodedTree {
   std::vector<EncNode> nodes;   // at least one element (dummy when the root is a leaf)
+  std::vector<EncRange> ranges; // per branch: record range [begin, end) of its whole subtree (box search)
   std::vector<EncPoint> points; // n_points + kEncLeafPad (the tail repeats the last point)
   uint32_t root_ref = 0;
   uint32_t cbits = 0;
@@ -191,6 +196,22 @@ inline std::string encode_tree(
     }
   }
   for (uint32_t i = 0; i < kEncLeafPad; ++i) out.points[n_slots + i] = out.points[n_slots ? n_slots - 1 : 0];
+  // Subtree ranges: children come later in the stream, so one backward pass suffices.
+  static_assert(kEncLeafAlign == 1, "subtree ranges assume leaves are packed without gaps");
+  {
+    std::vector<EncRange> of_node(n_nodes);
+    for (uint64_t i = n_nodes; i-- > 0;) {
+      const ptk_node& nd = nodes[i];
+      if (nd.right == PTK_LEAF) {
+        of_node[i] = EncRange{(uint32_t)leaf_pos[i], (uint32_t)leaf_pos[i] + (nd.b - nd.a)};
+      } else {
+        of_node[i] = EncRange{of_node[i + 1].begin, of_node[nd.right].end};
+      }
+    }
+    out.ranges.assign(n_branch > 0 ? n_branch : 1, EncRange{0, 0});
+    for (uint64_t i = 0; i < n_nodes; ++i)
+      if (nodes[i].right != PTK_LEAF) out.ranges[branch_id[i]] = of_node[i];
+  }
   out.root_ref = ref_of(0);
   out.cbits = cbits;
   return std::string();

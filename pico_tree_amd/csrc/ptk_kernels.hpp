@@ -1672,6 +1672,131 @@ __global__ __launch_bounds__(kBlock) void pack_queries_kernel(
   qs[i] = make_float4(x, y, z, __uint_as_float(qi));
 }
 
+// ---- box search ---------------------------------------------------------------------------
+// search_box (/root/reference/src/pico_tree/pico_tree/internal/kd_tree_search.hpp:238-381): a
+// left-then-right depth-first walk with a RUNNING node box; a child whose box lies inside the
+// query box is reported wholesale (its whole index range, :321-337), a child that merely
+// intersects is entered, a leaf is filtered point by point (closed interval test, box.hpp:31-42).
+// One query box per lane.  Records on the lane's LIFO:
+//   right  {node | axis << 28, val = max[axis] to restore}  the right child of `node` is still to do
+//   undo   {kRecUndo | axis << 28, val = min[axis] to restore}
+// `ranges[branch] = {begin, end}` is the index range of the whole subtree (what report_left /
+// report_right find by walking to the outermost leaves, :339-353).  Unused axes (dim < 3) carry
+// the box [0, 0] against a query of (-inf, +inf).  COUNT pass: counts[i]; FILL pass: indices.
+struct BoxState {
+  float mn0, mn1, mn2, mx0, mx1, mx2;
+};
+__device__ __forceinline__ void set_axis(float& a0, float& a1, float& a2, uint32_t axis, float v) {
+  a0 = axis == 0 ? v : a0;
+  a1 = axis == 1 ? v : a1;
+  a2 = axis == 2 ? v : a2;
+}
+
+template <int S, int OVF, bool FILL>
+__global__ __launch_bounds__(64) void box_kernel(
+    DevTree t, const uint2* __restrict__ ranges, BoxState root, const float* __restrict__ mins,
+    const float* __restrict__ maxs, uint32_t dim, uint64_t nb, uint64_t* __restrict__ counts,
+    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out) {
+  const uint64_t bi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (bi >= nb) return;
+  const float inf = __uint_as_float(0x7F800000u);
+  float qn0, qn1, qn2, qx0, qx1, qx2;
+  load_query(mins, dim, bi, qn0, qn1, qn2);
+  load_query(maxs, dim, bi, qx0, qx1, qx2);
+  if (dim < 2) { qn1 = -inf; qx1 = inf; }
+  if (dim < 3) { qn2 = -inf; qx2 = inf; }
+  BoxState b = root;
+  const uint4* __restrict__ nodes = t.nodes;
+  const float4* __restrict__ pts = t.pts;
+  uint64_t count = 0;
+  int32_t* row = FILL ? out + offsets[bi] : nullptr;
+
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+
+  auto inside = [&]() {  // query_.contains(box_): both corners inside the closed query box
+    return qn0 <= b.mn0 && b.mn0 <= qx0 && qn0 <= b.mx0 && b.mx0 <= qx0 &&
+           qn1 <= b.mn1 && b.mn1 <= qx1 && qn1 <= b.mx1 && b.mx1 <= qx1 &&
+           qn2 <= b.mn2 && b.mn2 <= qx2 && qn2 <= b.mx2 && b.mx2 <= qx2;
+  };
+  auto report_range = [&](uint32_t begin, uint32_t end) {
+    if (FILL) {
+      for (uint32_t p = begin; p < end; ++p) row[count + (p - begin)] = __float_as_int(pts[p].w);
+    }
+    count += end - begin;
+  };
+  auto report = [&](uint32_t ref) {  // report_node: the whole subtree
+    if (ref & kLeafBit) {
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      report_range(lv >> t.cbits, (lv >> t.cbits) + (lv & t.cmask));
+    } else {
+      const uint2 r = ranges[ref & kBranchIdxMask];
+      report_range(r.x, r.y);
+    }
+  };
+  auto scan_leaf = [&](uint32_t ref) {
+    const uint32_t lv = ref & 0x7FFFFFFFu;
+    const uint32_t begin = lv >> t.cbits;
+    const uint32_t n = lv & t.cmask;
+    for (uint32_t j = 0; j < n; ++j) {
+      const float4 p = pts[begin + j];
+      if (qn0 <= p.x && p.x <= qx0 && qn1 <= p.y && p.y <= qx1 && qn2 <= p.z && p.z <= qx2) {
+        if (FILL) row[count] = __float_as_int(p.w);
+        ++count;
+      }
+    }
+  };
+
+  uint32_t ref = t.root_ref;  // the subtree to walk next (kLeafBit | 0x7FFFFFFF... is never produced)
+  bool have = true;
+  for (;;) {
+    if (have) {
+      if (ref & kLeafBit) {
+        scan_leaf(ref);
+        have = false;
+      } else {
+        const uint32_t idx = ref & kBranchIdxMask;
+        const uint32_t axis = (ref >> 29) & 3u;
+        const uint4 nd = nodes[idx];
+        const float left_max = __uint_as_float(nd.x);
+        st.push(idx | (axis << 28), sel3(axis, b.mx0, b.mx1, b.mx2));  // the right child comes later
+        set_axis(b.mx0, b.mx1, b.mx2, axis, left_max);
+        if (inside()) {
+          report(nd.z);
+          have = false;
+        } else if (sel3(axis, qn0, qn1, qn2) <= left_max) {  // intersects_left
+          ref = nd.z;
+        } else {
+          have = false;
+        }
+      }
+      continue;
+    }
+    if (st.empty()) break;
+    const Record r = st.pop();
+    const uint32_t axis = (r.x >> 28) & 3u;
+    const float val = __uint_as_float(r.y);
+    if (r.x & kRecUndo) {
+      set_axis(b.mn0, b.mn1, b.mn2, axis, val);
+      continue;
+    }
+    // Left side of node r.x is done: restore max, narrow min, do the right side.
+    set_axis(b.mx0, b.mx1, b.mx2, axis, val);
+    const uint4 nd = nodes[r.x & kRecIdxMask];
+    const float right_min = __uint_as_float(nd.y);
+    st.push(kRecUndo | (axis << 28), sel3(axis, b.mn0, b.mn1, b.mn2));
+    set_axis(b.mn0, b.mn1, b.mn2, axis, right_min);
+    if (inside()) {
+      report(nd.w);
+    } else if (sel3(axis, qx0, qx1, qx2) >= right_min) {  // intersects_right
+      ref = nd.w;
+      have = true;
+    }
+  }
+  if (!FILL) counts[bi] = count;
+}
+
 // Sorts every row ascending by distance (heap sort, in place, one row per lane).
 // std::sort in the reference is unstable, so the order among equal distances is
 // unspecified on both sides.

@@ -423,6 +423,34 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   return (int)meta[0];
 }
 
+// Box search: count pass then fill pass; offsets must hold nb + 1 entries, out is resized by the caller
+// through a second call (pass out == nullptr to get the counts / offsets only).
+int emu_box(void* h, const float* mins, const float* maxs, uint64_t nb, const float* root_min, const float* root_max,
+            uint64_t* offsets, int32_t* out) {
+  auto* t = static_cast<Emu*>(h);
+  if (t->dim > 3) return -2;
+  float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+  for (uint32_t d = 0; d < t->dim; ++d) {
+    mn[d] = root_min[d];
+    mx[d] = root_max[d];
+  }
+  const ptk::BoxState root{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
+  const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
+  if (out == nullptr) {
+    std::vector<uint64_t> counts(nb + 1, 0);
+    for_each_lane(nb, [&] {
+      ptk::box_kernel<4, 2048, false>(t->dev, ranges, root, mins, maxs, t->dim, nb, counts.data(), nullptr, nullptr);
+    }, 64);
+    offsets[0] = 0;
+    for (uint64_t i = 0; i < nb; ++i) offsets[i + 1] = offsets[i] + counts[i];
+    return 0;
+  }
+  for_each_lane(nb, [&] {
+    ptk::box_kernel<16, 2048, true>(t->dev, ranges, root, mins, maxs, t->dim, nb, nullptr, offsets, out);
+  }, 64);
+  return 0;
+}
+
 // Phase 1 only: the class (0..7) and the home-leaf best distance of every query (analysis tools).
 int emu_phase1(void* h, const float* q, uint64_t nq, uint8_t* cls_out, float* best_out) {
   auto* t = static_cast<Emu*>(h);

@@ -98,6 +98,22 @@ class EmulatedTree:
                                 None, off.ctypes.data, out.ctypes.data)
         return off, out
 
+    def search_box(self, mins, maxs):
+        from ctypes import c_uint64, c_void_p
+        mins = np.ascontiguousarray(mins, dtype=np.float32)
+        maxs = np.ascontiguousarray(maxs, dtype=np.float32)
+        nb = len(mins)
+        rmin = np.ascontiguousarray(self.pts.min(0), dtype=np.float32)
+        rmax = np.ascontiguousarray(self.pts.max(0), dtype=np.float32)
+        off = np.zeros(nb + 1, dtype=np.uint64)
+        self.lib.emu_box.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
+        assert self.lib.emu_box(self.h, mins.ctypes.data, maxs.ctypes.data, nb, rmin.ctypes.data, rmax.ctypes.data,
+                                off.ctypes.data, None) == 0
+        out = np.zeros(max(int(off[-1]), 1), dtype=np.int32)
+        assert self.lib.emu_box(self.h, mins.ctypes.data, maxs.ctypes.data, nb, rmin.ctypes.data, rmax.ctypes.data,
+                                off.ctypes.data, out.ctypes.data) == 0
+        return off, out[:int(off[-1])]
+
     def two_phase_knn1(self, q, e=None, perm=None, variant=0):
         """Returns (result (nq,1), number of continuations handed to phase 2)."""
         q = np.ascontiguousarray(q, dtype=np.float32)

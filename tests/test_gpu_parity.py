@@ -161,6 +161,32 @@ def test_golden_vectors_on_the_device(gpu, name):
     check_against_golden(Adaptor(), g)
 
 
+@pytest.mark.parametrize("cloud,dim,half", [("uniform", 3, 0.03), ("lidar", 3, 1.5), ("ties", 3, 0.125), ("u2", 2, 0.02),
+                                            ("u1", 1, 0.001)])
+def test_box_search_traversal_order(gpu, cloud, dim, half):
+    """search_box on the device: rows equal the reference's traversal-order index lists
+    (kd_tree_search.hpp:238-381), including wholesale-reported subtrees and closed bounds."""
+    if cloud in ("uniform", "lidar", "ties"):
+        pts, q = _clouds(cloud, 60_000, 6_000)
+    else:
+        pts, q = ds.uniform_cloud(40_000, dim, 3), ds.uniform_cloud(4_000, dim, 4)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    ref = oracle.Oracle(pts, 10, "port")
+    rng = np.random.default_rng(5)
+    h = (rng.uniform(0.2, 1.0, size=q.shape) * half).astype(np.float32)
+    mins, maxs = q - h, q + h
+    mins[::50] = pts.min(0) - 1  # a few boxes swallow the whole cloud or large subtrees
+    maxs[::50] = pts.max(0) + 1
+    maxs[1::50] = mins[1::50]    # and a few are degenerate (min == max)
+    boxes = np.empty((2 * len(q), dim), dtype=np.float32)
+    boxes[0::2], boxes[1::2] = mins, maxs
+    got = tree.search_box(boxes)
+    off, flat = ref.search_box(mins, maxs)
+    assert np.array_equal(got.offsets, off)
+    assert np.array_equal(got.flat, flat)
+    assert off[-1] > len(pts)
+
+
 def test_deep_tree_uses_scratch_overflow(gpu):
     """Heavy duplication makes the sliding-midpoint tree > 100 levels deep."""
     pts = (np.round(ds.uniform_cloud(40_000, 3, 9) * 4) / 4).astype(np.float32)

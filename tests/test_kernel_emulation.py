@@ -153,3 +153,23 @@ def test_emulated_refill_phase2_equals_oracle(case):
             assert got.tobytes() == want.tobytes()
     got, _ = emu.two_phase_knn1(q, e=1.4, perm=perm, variant=5)
     assert got.tobytes() == ref.search_knn(q, 1, e=1.4).tobytes()
+
+
+@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "dim2", "dim1", "ties", "lidar", "root-is-leaf",
+                                                                  "leaf1")], ids=lambda c: c[0])
+def test_emulated_box_search_equals_oracle(case):
+    """search_box: running node box, wholesale-reported subtrees, closed bounds, traversal order."""
+    _, pts, q, leaf, radius = case
+    emu = EmulatedTree(pts, leaf)
+    ref = oracle.Oracle(pts, leaf, "port")
+    rng = np.random.default_rng(3)
+    span = (pts.max(0) - pts.min(0)).astype(np.float32)
+    h = (rng.uniform(0.01, 0.2, size=q.shape) * span).astype(np.float32)
+    mins, maxs = (q - h).astype(np.float32), (q + h).astype(np.float32)
+    mins[::20] = pts.min(0)  # boxes touching the root bounds exactly (closed interval)
+    maxs[::20] = pts.max(0)
+    maxs[1::20] = mins[1::20]
+    off, flat = ref.search_box(mins, maxs)
+    goff, gflat = emu.search_box(mins, maxs)
+    assert np.array_equal(goff, off) and np.array_equal(gflat, flat)
+    assert off[-1] > 0

@@ -1,7 +1,7 @@
 """The reference's Python unit tests (/root/reference/test/pyco_tree/kd_tree_test.py)
 restated against ``pico_tree_amd.KdTree`` for the path this repository builds (float32,
 Metric.L2Squared): same calls, same assertions.  Cases that need the parts listed as out of
-scope in DESIGN.md (float64, L1, search_box on the device, file I/O) are restated as the
+scope in DESIGN.md (float64, L1, file I/O) are restated as the
 behaviour this build promises instead: a loud error, never a silent CPU fallback.
 """
 
@@ -117,7 +117,24 @@ def test_column_major_queries_give_transposed_output(gpu):  # _pyco_tree/kd_tree
     assert col.reshape(-1).tobytes() == row.reshape(-1).tobytes()
 
 
-def test_search_box_is_a_loud_error_until_built(gpu):
+def test_search_box(gpu):  # kd_tree_test.py:155-201
     a = np.array(A, dtype=np.float32)
     t = pt.KdTree(a, pt.Metric.L2Squared, 10, device=gpu)
-    assert not hasattr(t, "search_box") or pytest.raises(pt.PtkError)
+    boxes = np.array([[0, 0], [3, 3], [2, 2], [3, 3], [0, 0], [9, 9], [6, 6], [9, 9]], dtype=np.float32)
+    nns = t.search_box(boxes)
+    assert len(nns) == 4
+    assert nns.dtype == t.dtype_index
+    assert nns
+
+    def addresses(rows):
+        return [copy.deepcopy(x.ctypes.data) if len(x) else 0 for x in rows]
+
+    datas = addresses(nns)
+    t.search_box(boxes, nns)
+    assert addresses(nns) == datas
+    assert [len(n) for n in nns] == [1, 0, 3, 1]
+    sub = nns[0:4:2]
+    assert len(sub) == 2 and [len(n) for n in sub] == [1, 3]
+    assert len(sub[-1]) == 3
+    with pytest.raises(ValueError):
+        t.search_box(boxes[:3])
