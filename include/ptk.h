@@ -146,6 +146,18 @@ int ptk_tree_get_flat(const ptk_tree* tree, ptk_node* nodes, int32_t* indices,
 
 int ptk_tree_set_reorder(ptk_tree* tree, int mode);
 
+/* The tree in the reference's own binary format (kd_tree::save / kd_tree::load,
+ * kd_tree.hpp:336-370, internal/kd_tree_data.hpp:43-58,90-135): sdim, indices,
+ * root box, nodes depth-first.  Files written by the reference load here and
+ * vice versa (the Python module's PKD header, _pyco_tree/kd_tree.hpp:547-614,
+ * is added by the binding).  ptk_tree_serialize: pass buf == NULL to get the
+ * size; PTK_ERR_INVALID if cap is too small.  Like the reference, loading does
+ * not check that the stream belongs to the points (kd_tree.hpp:346-351). */
+int ptk_tree_serialize(const ptk_tree* tree, void* buf, uint64_t cap, uint64_t* size);
+int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t dim,
+                                const void* stream, uint64_t stream_bytes,
+                                int32_t device, ptk_tree** out);
+
 /* ---- k nearest neighbours --------------------------------------------- */
 
 /* Host buffers.  queries: nq x dim row-major.  out: nq x k row-major; row i is

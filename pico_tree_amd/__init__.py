@@ -30,7 +30,7 @@ import numpy as np
 
 from . import datasets  # noqa: F401  (re-export)
 
-__all__ = ["KdTree", "KdForest", "Metric", "NEIGHBOR", "DArray", "DeviceNeighbors", "PtkError",
+__all__ = ["KdTree", "KdForest", "save_kd_tree", "load_kd_tree", "Metric", "NEIGHBOR", "DArray", "DeviceNeighbors", "PtkError",
            "library_path", "device_count", "datasets"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -77,6 +77,9 @@ _SIGNATURES = {
     "ptk_tree_get_info": (c_int, [c_void_p, POINTER(_Info)]),
     "ptk_tree_get_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ptk_tree_set_reorder": (c_int, [c_void_p, c_int]),
+    "ptk_tree_serialize": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
+    "ptk_tree_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
+                                            POINTER(c_void_p)]),
     "ptk_search_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p]),
     "ptk_search_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p,
                                       c_void_p]),
@@ -249,7 +252,7 @@ class KdTree:
     """
 
     def __init__(self, pts, metric: Metric = Metric.L2Squared, max_leaf_size: int = 10,
-                 device: int | None = None):
+                 device: int | None = None, _stream: bytes | None = None):
         if metric is not Metric.L2Squared:
             raise ValueError("only Metric.L2Squared is available in this build")
         pts = self._as_matrix(pts, None, "pts")
@@ -261,9 +264,22 @@ class KdTree:
         lib = _load()
         handle = c_void_p()
         dev = PTK_DEVICE_CURRENT if device is None else int(device)
-        _check(lib.ptk_tree_create_from_points(pts.ctypes.data, self._npts, self._sdim,
-                                               self._max_leaf_size, dev, byref(handle)))
+        if _stream is None:
+            _check(lib.ptk_tree_create_from_points(pts.ctypes.data, self._npts, self._sdim,
+                                                   self._max_leaf_size, dev, byref(handle)))
+        else:  # load_kd_tree: the tree comes from a saved stream
+            buf = ctypes.create_string_buffer(_stream, len(_stream))
+            _check(lib.ptk_tree_create_from_stream(pts.ctypes.data, self._npts, self._sdim, buf, len(_stream),
+                                                   dev, byref(handle)))
         self._h = handle
+
+    def _serialize(self) -> bytes:
+        size = c_uint64()
+        lib = _load()
+        _check(lib.ptk_tree_serialize(self._h, None, 0, byref(size)))
+        buf = ctypes.create_string_buffer(size.value)
+        _check(lib.ptk_tree_serialize(self._h, buf, size.value, byref(size)))
+        return buf.raw[:size.value]
 
     # -- helpers ---------------------------------------------------------------
     @staticmethod
@@ -297,9 +313,8 @@ class KdTree:
         except Exception:
             pass
 
-    def __repr__(self) -> str:
-        return (f"KdTree(metric=L2Squared, max_leaf_size={self._max_leaf_size}, "
-                f"dtype=float32, sdim={self._sdim}, npts={self._npts})")
+    def __repr__(self) -> str:  # _pyco_tree/kd_tree.hpp:321-326
+        return f"KdTree(metric=L2Squared, dtype=float32, sdim={self._sdim}, npts={self._npts})"
 
     # -- properties (names of the reference binding) ----------------------------------
     @property
@@ -593,3 +608,37 @@ class KdForest:
             self.close()
         except Exception:
             pass
+
+
+# ---- file I/O (the reference's PKD container, _pyco_tree/kd_tree.hpp:546-614) -------------------
+_PKD_SIGNATURE = b"\x89PKD"
+_PKD_VERSION = 1
+
+
+def save_kd_tree(tree: KdTree, filename: str) -> None:
+    """``pico_tree.save_kd_tree``: PKD header (signature, version, metric string) followed by the
+    tree in the reference's kd_tree::save format.  The points are not stored."""
+    metric = b"L2Squared"
+    with open(filename, "wb") as f:
+        f.write(_PKD_SIGNATURE)
+        f.write(np.uint32(_PKD_VERSION).tobytes())
+        f.write(np.uint64(len(metric)).tobytes())
+        f.write(metric)
+        f.write(tree._serialize())
+
+
+def load_kd_tree(pts, filename: str, device: int | None = None) -> KdTree:
+    """``pico_tree.load_kd_tree``: rebuilds a :class:`KdTree` over ``pts`` from a file written by
+    :func:`save_kd_tree` or by the reference's own ``save_kd_tree`` (float32, L2Squared)."""
+    with open(filename, "rb") as f:
+        data = f.read()
+    if data[:4] != _PKD_SIGNATURE:
+        raise RuntimeError("unexpected header signature")
+    if int(np.frombuffer(data, dtype=np.uint32, count=1, offset=4)[0]) != _PKD_VERSION:
+        raise RuntimeError("unsupported header version")
+    n = int(np.frombuffer(data, dtype=np.uint64, count=1, offset=8)[0])
+    metric = data[16:16 + n].decode("ascii", "replace")
+    if metric != "L2Squared":
+        raise RuntimeError("unexpected metric string" if metric not in ("L1", "LPInf")
+                           else f"metric {metric} is not available in this build")
+    return KdTree(pts, Metric.L2Squared, 1, device=device, _stream=data[16 + n:])

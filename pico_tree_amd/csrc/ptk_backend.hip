@@ -20,6 +20,7 @@
 #include <new>
 #include <string>
 #include <random>
+#include <sstream>
 #include <vector>
 
 #include <rocprim/device/device_radix_sort.hpp>
@@ -33,6 +34,7 @@
 
 // Host-side builder: the product's own header-only flat-tree builder.
 #include "pico_tree/internal/flat_tree.hpp"
+#include "pico_tree/internal/stream.hpp"
 #include "pico_tree/map.hpp"
 
 static_assert(sizeof(ptk_neighbor) == 8 && sizeof(ptk::Neighbor) == 8, "neighbor layout");
@@ -1019,6 +1021,64 @@ int ptk_tree_get_flat(const ptk_tree* t, ptk_node* nodes, int32_t* indices, floa
   if (root_min) std::memcpy(root_min, t->root_min.data(), t->dim * sizeof(float));
   if (root_max) std::memcpy(root_max, t->root_max.data(), t->dim * sizeof(float));
   return PTK_OK;
+}
+
+int ptk_tree_serialize(const ptk_tree* t, void* buf, uint64_t cap, uint64_t* size) {
+  if (t == nullptr || size == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  try {
+    using tree_t = pico_tree::internal::flat_tree<int, float, pico_tree::dynamic_extent>;
+    tree_t flat(t->dim);
+    flat.indices.assign(t->indices.begin(), t->indices.end());
+    std::memcpy(flat.root_box.min(), t->root_min.data(), t->dim * sizeof(float));
+    std::memcpy(flat.root_box.max(), t->root_max.data(), t->dim * sizeof(float));
+    flat.nodes.resize(t->nodes.size());
+    std::memcpy(static_cast<void*>(flat.nodes.data()), t->nodes.data(), t->nodes.size() * sizeof(ptk_node));
+    std::ostringstream os(std::ios::out | std::ios::binary);
+    pico_tree::internal::write_flat_tree(flat, os);
+    const std::string bytes = os.str();
+    *size = bytes.size();
+    if (buf == nullptr) return PTK_OK;
+    if (cap < bytes.size()) return fail(PTK_ERR_INVALID, "buffer of %llu bytes, stream needs %llu",
+                                        (unsigned long long)cap, (unsigned long long)bytes.size());
+    std::memcpy(buf, bytes.data(), bytes.size());
+    return PTK_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  }
+}
+
+int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t dim, const void* stream,
+                                uint64_t stream_bytes, int32_t device, ptk_tree** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (points == nullptr || stream == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (dim == 0 || n_points == 0) return fail(PTK_ERR_INVALID, "dim and n_points must be positive");
+  ptk_tree* t = nullptr;
+  try {
+    using tree_t = pico_tree::internal::flat_tree<int, float, pico_tree::dynamic_extent>;
+    std::istringstream is(std::string(static_cast<const char*>(stream), stream_bytes), std::ios::in | std::ios::binary);
+    tree_t flat = pico_tree::internal::read_flat_tree<tree_t>(is);
+    if (flat.root_box.size() != dim) return fail(PTK_ERR_INVALID, "stream is %zu-dimensional, points are %u-dimensional",
+                                                 (size_t)flat.root_box.size(), dim);
+    if (flat.indices.size() != n_points)
+      return fail(PTK_ERR_INVALID, "stream indexes %zu points, %llu were given", flat.indices.size(),
+                  (unsigned long long)n_points);
+    t = new ptk_tree;
+    t->dim = dim;
+    t->n_points = n_points;
+    t->nodes.resize(flat.nodes.size());
+    std::memcpy(t->nodes.data(), flat.nodes.data(), flat.nodes.size() * sizeof(ptk_node));
+    t->indices.assign(flat.indices.begin(), flat.indices.end());
+    t->root_min.assign(flat.root_box.min(), flat.root_box.min() + dim);
+    t->root_max.assign(flat.root_box.max(), flat.root_box.max() + dim);
+  } catch (const std::bad_alloc&) {
+    delete t;
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  } catch (const std::exception& e) {
+    delete t;
+    return fail(PTK_ERR_INVALID, "bad kd_tree stream: %s", e.what());
+  }
+  return finish_create(t, points, device, out);
 }
 
 int ptk_tree_set_reorder(ptk_tree* t, int mode) {

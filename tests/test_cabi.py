@@ -110,3 +110,38 @@ def test_rejects_malformed_flat_trees():
     leaf = np.flatnonzero(nodes[:, 2] == 0xFFFFFFFF)[0]
     bad = nodes.copy(); bad[leaf, 1] = 1000                # leaf range past the end
     assert create(bad, idx) == -1
+
+
+def test_tree_stream_round_trip_on_a_host_only_handle():
+    """ptk_tree_serialize writes the reference's kd_tree::save format (equal to the oracle's
+    stream, which test_oracle.py pins against the compiled reference) and
+    ptk_tree_create_from_stream reads it back to the same flat tree; bad streams fail loudly."""
+    import ctypes
+    from ctypes import byref, c_uint64, c_void_p
+
+    import oracle
+    from pico_tree_amd import datasets as ds
+
+    lib = pt._load()
+    pts = ds.uniform_cloud(3_000, 3, 4)
+    h = c_void_p()
+    assert lib.ptk_tree_create_from_points(pts.ctypes.data, len(pts), 3, 9, pt.PTK_DEVICE_NONE, byref(h)) == 0
+    size = c_uint64()
+    assert lib.ptk_tree_serialize(h, None, 0, byref(size)) == 0
+    buf = ctypes.create_string_buffer(size.value)
+    assert lib.ptk_tree_serialize(h, buf, size.value - 1, byref(size)) == -1  # too small
+    assert lib.ptk_tree_serialize(h, buf, size.value, byref(size)) == 0
+    assert buf.raw[:size.value] == oracle.Oracle(pts, 9, "port").save_bytes()
+    h2 = c_void_p()
+    assert lib.ptk_tree_create_from_stream(pts.ctypes.data, len(pts), 3, buf, size.value, pt.PTK_DEVICE_NONE,
+                                           byref(h2)) == 0
+    size2 = c_uint64()
+    buf2 = ctypes.create_string_buffer(size.value)
+    assert lib.ptk_tree_serialize(h2, buf2, size.value, byref(size2)) == 0 and buf2.raw == buf.raw
+    h3 = c_void_p()
+    assert lib.ptk_tree_create_from_stream(pts.ctypes.data, len(pts) - 1, 3, buf, size.value, pt.PTK_DEVICE_NONE,
+                                           byref(h3)) == -1  # wrong point count
+    assert lib.ptk_tree_create_from_stream(pts.ctypes.data, len(pts), 3, buf, 100, pt.PTK_DEVICE_NONE,
+                                           byref(h3)) == -1  # truncated
+    for x in (h, h2):
+        lib.ptk_tree_destroy(x)
