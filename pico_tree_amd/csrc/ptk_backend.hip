@@ -485,6 +485,26 @@ int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64
   return PTK_OK;
 }
 
+// k <= 32: the k-list in registers (K = 4 / 8 / 16 / 32 slots compiled).
+template <int S, int OVF, int BLOCK, int LEAFB>
+int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
+                   ptk::Neighbor* d_out, hipStream_t s) {
+  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
+  const size_t smem = (size_t)S * BLOCK * 8;
+  Timer timer(t, s);
+#define PTK_LAUNCH_REG(KK)                                                                                          \
+  hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q, \
+                     t->dim, perm, nq, k, inv_ratio(e), d_out)
+  if (k <= 4) PTK_LAUNCH_REG(4);
+  else if (k <= 8) PTK_LAUNCH_REG(8);
+  else if (k <= 16) PTK_LAUNCH_REG(16);
+  else PTK_LAUNCH_REG(32);
+#undef PTK_LAUNCH_REG
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
 template <int S, int OVF, int BLOCK, int LEAFB>
 int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
                   bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out,
@@ -1118,6 +1138,8 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   }
   if (k == 1) {
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
+  } else if (k <= 32 && env_int("PTK_KNN_LIST", 0) == 0) {
+    PTK_WITH_OVF(16, (launch_knn_reg<16, OVF, 64, 4>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
   } else {
     PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
   }

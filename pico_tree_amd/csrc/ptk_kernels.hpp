@@ -265,6 +265,66 @@ struct KnnPolicy {  // search_visitor.hpp:83-123 / :198-247
   }
 };
 
+// Sorted k-list in REGISTERS for k <= K <= 32 (profiles/r01f_config3_*: the LDS list above
+// makes knn = 16 seven times slower per query than knn = 1 -- every accepted candidate walks a
+// divergent shift loop of ds_read / ds_write pairs).  Here an insertion is K branch-free
+// compare / select steps on registers:
+//   new[j] = d < old[j-1] ? old[j-1] : (d < old[j] ? d : old[j])
+// which is insert_sorted (search_visitor.hpp:24-38) exactly: strict `<` keeps the new entry
+// BEHIND equal distances.  Slots start at FLT_MAX (the reference's sentinel, :102), so max() =
+// slot k-1 needs no fill counter; k <= n_points is enforced by the caller (kd_tree.hpp:193), hence
+// every slot below k is a real point when the search ends.
+template <int K>
+struct KnnRegPolicy {
+  float ld[K];
+  int32_t li[K];
+  uint32_t k;
+  float worst;
+  float e_inv;
+  __device__ __forceinline__ void init(uint32_t k_, float e_inv_) {
+    k = k_;
+    e_inv = e_inv_;
+    worst = 3.402823466e+38f;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ld[j] = 3.402823466e+38f;
+      li[j] = 0;
+    }
+  }
+  __device__ __forceinline__ float max() const { return worst; }
+  __device__ __forceinline__ void visit(int32_t idx, float d) {
+    d = f_mul(d, e_inv);
+    if (worst > d) {
+#pragma unroll
+      for (int j = K - 1; j >= 1; --j) {
+        const bool shift = d < ld[j - 1];
+        const bool here = d < ld[j];
+        li[j] = shift ? li[j - 1] : (here ? idx : li[j]);
+        ld[j] = shift ? ld[j - 1] : (here ? d : ld[j]);
+      }
+      if (d < ld[0]) {
+        ld[0] = d;
+        li[0] = idx;
+      }
+      float w = ld[0];
+#pragma unroll
+      for (int j = 1; j < K; ++j) w = (uint32_t)j < k ? ld[j] : w;  // slot k - 1
+      worst = w;
+    }
+  }
+  __device__ __forceinline__ void store(Neighbor* row) const {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if ((uint32_t)j < k) {
+        Neighbor nb;
+        nb.index = li[j];
+        nb.distance = ld[j];
+        row[j] = nb;
+      }
+    }
+  }
+};
+
 template <bool FILL>
 struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
   float radius;  // already scaled by 1/e for the approximate search (:265)
@@ -639,6 +699,26 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
     nb.distance = 3.402823466e+38f;
     out[qi * k + (k - 1)] = nb;
   }
+}
+
+template <int K, int S, int OVF, int BLOCK, int LEAFB>
+__global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
+    DevTree t, const float* __restrict__ queries, uint32_t dim,
+    const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
+    Neighbor* __restrict__ out) {
+  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[i] : i;
+  float qx, qy, qz;
+  load_query(queries, dim, qi, qx, qy, qz);
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, BLOCK> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  KnnRegPolicy<K> pol;
+  pol.init(k, e_inv);
+  traverse<LEAFB>(t, qx, qy, qz, pol, st);
+  pol.store(out + qi * k);
 }
 
 // ---- radius: count pass and fill pass ------------------------------------------------------

@@ -237,6 +237,17 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
       for_each_lane(nq, [&] { ptk::knn1_kernel<16, 64, 64, 4>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 64);
     else
       for_each_lane(nq, [&] { ptk::knn1_kernel<32, 2048, 256, 8>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 256);
+  } else if (list_in_lds == 2) {  // k-list in registers (k <= 32)
+    if (k > 32) return -2;
+    if (small_stack) {
+      if (k <= 4) for_each_lane(nq, [&] { ptk::knn_reg_kernel<4, 4, 2048, 64, 1>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+      else if (k <= 16) for_each_lane(nq, [&] { ptk::knn_reg_kernel<16, 4, 2048, 64, 1>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+      else for_each_lane(nq, [&] { ptk::knn_reg_kernel<32, 4, 2048, 64, 1>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+    } else {
+      if (k <= 8) for_each_lane(nq, [&] { ptk::knn_reg_kernel<8, 16, 2048, 64, 4>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+      else if (k <= 16) for_each_lane(nq, [&] { ptk::knn_reg_kernel<16, 16, 2048, 64, 4>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+      else for_each_lane(nq, [&] { ptk::knn_reg_kernel<32, 16, 2048, 64, 4>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+    }
   } else if (list_in_lds) {
     if ((size_t)(16 + k) * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
     if (small_stack)

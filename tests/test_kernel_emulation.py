@@ -64,7 +64,7 @@ def test_emulated_kernels_equal_oracle(case):
             continue
         want = ref.search_knn(q, k)
         for small_stack in (False, True):       # True: records spill to the scratch half
-            for list_in_lds in (False, True):   # k-list in LDS vs in the output row
+            for list_in_lds in (False, True, 2):  # k-list in the output row / in LDS / in registers
                 for p in (None, perm):          # identity vs Morton launch order
                     got = emu.search_knn(q, k, perm=p, small_stack=small_stack, list_in_lds=list_in_lds)
                     assert got.tobytes() == want.tobytes()
