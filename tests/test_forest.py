@@ -94,3 +94,33 @@ def test_forest_recall_and_device_buffers(gpu):
     i = got["index"][:, 0]
     d = ((q - pts[i]) ** 2).sum(1)
     assert np.allclose(d, got["distance"][:, 0], rtol=1e-5)
+
+
+@pytest.mark.gpu
+def test_cpp_kd_forest_header(gpu, tmp_path):
+    """include/pico_understory/kd_forest.hpp (the reference's class shape) through the C ABI:
+    per-query search_nn, batched search_nn / search_knn, all equal to the Python binding and
+    therefore to the oracle."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pts, q = _clouds(20_000, 300, 16)
+    pts.tofile(tmp_path / "points.bin")
+    q.tofile(tmp_path / "queries.bin")
+    exe = str(tmp_path / "forest_main")
+    libdir = os.path.join(root, "pico_tree_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", "-Wall", "-I" + os.path.join(root, "include"),
+                           os.path.join(root, "tests", "cpp", "forest_main.cpp"), "-o", exe,
+                           "-L" + libdir, "-lptk", "-Wl,-rpath," + libdir])
+    env = dict(os.environ, HIP_VISIBLE_DEVICES=str(gpu)) if gpu else None
+    subprocess.check_call([exe, str(tmp_path)], env=env)
+    forest = pt.KdForest(pts, 8, 4, seed=11, device=gpu)
+    want1 = forest.search_nn(q, 10)
+    want5 = forest.search_knn(q, 5, 10)
+    one = np.fromfile(tmp_path / "f_one.bin", dtype=pt.NEIGHBOR)
+    batch = np.fromfile(tmp_path / "f_batch.bin", dtype=pt.NEIGHBOR)
+    knn = np.fromfile(tmp_path / "f_knn.bin", dtype=pt.NEIGHBOR).reshape(len(q), 5)
+    assert one.tobytes() == want1.tobytes() and batch.tobytes() == want1.tobytes()
+    assert knn.tobytes() == want5.tobytes()
+    assert want5.tobytes() == oracle.ForestOracle(pts, 8, forest.rotations).search_knn(q, 5, 10).tobytes()
