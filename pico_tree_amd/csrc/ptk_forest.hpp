@@ -191,7 +191,25 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
             const float4* row = reinterpret_cast<const float4*>(f.points + (uint64_t)idx * dim);
             float acc = 0.0f;
             uint32_t a = 0;
-            if ((dim & 3u) == 0u) {
+            if ((dim & 31u) == 0u) {
+              // 8 x 16 bytes in flight per lane (a row is a stream of independent loads; issued one
+              // at a time each would pay the full memory latency).  Summation stays left to right.
+              for (; a < dim; a += 32) {
+                float4 p[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) p[u] = row[(a >> 2) + u];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                  const uint32_t b = a + 4u * u;
+                  const float d0 = f_sub(q[b], p[u].x), d1 = f_sub(q[b + 1], p[u].y);
+                  const float d2 = f_sub(q[b + 2], p[u].z), d3 = f_sub(q[b + 3], p[u].w);
+                  acc = f_add(acc, f_mul(d0, d0));
+                  acc = f_add(acc, f_mul(d1, d1));
+                  acc = f_add(acc, f_mul(d2, d2));
+                  acc = f_add(acc, f_mul(d3, d3));
+                }
+              }
+            } else if ((dim & 3u) == 0u) {
               for (; a < dim; a += 4) {
                 const float4 p = row[a >> 2];
                 const float d0 = f_sub(q[a], p.x), d1 = f_sub(q[a + 1], p.y);
