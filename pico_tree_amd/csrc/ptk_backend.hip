@@ -95,9 +95,6 @@ struct Workspace {
   hipStream_t last_stream = nullptr;
   hipEvent_t done = nullptr;
   bool has_work = false;
-  // Second stream for the heavy continuations of the two-phase search (fork / join by events).
-  hipStream_t aux = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
 };
 
 }  // namespace
@@ -452,8 +449,7 @@ template <int S, int OVF, int BLOCK, int LEAFB>
 int launch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                 ptk::Neighbor* d_out, hipStream_t s) {
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  // PTK_EXTRA_LDS (bytes): occupancy experiments only -- reserves unused LDS per block.
-  const size_t smem = (size_t)S * BLOCK * 8 + (size_t)env_int("PTK_EXTRA_LDS", 0);
+  const size_t smem = (size_t)S * BLOCK * 8;
   int rc = allow_lds(ptk::knn1_kernel<S, OVF, BLOCK, LEAFB>, smem);
   if (rc != PTK_OK) return rc;
   Timer timer(t, s);
@@ -539,80 +535,6 @@ int pack_queries(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint
   return PTK_OK;
 }
 
-uint32_t chunk_size() {
-  const int c = env_int("PTK_CHUNK", 1024);
-  return (uint32_t)(c < 64 ? 64 : c);
-}
-
-template <int S, int OVF, int LEAFB>
-int launch_knn1_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
-                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
-  float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
-  if (rc != PTK_OK) return rc;
-  const uint32_t chunk = chunk_size();
-  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
-  const size_t smem = (size_t)S * 64 * 8 + (size_t)env_int("PTK_EXTRA_LDS", 0);
-  rc = allow_lds(ptk::knn1_persistent_kernel<S, OVF, LEAFB>, smem);
-  if (rc == PTK_OK) {
-    Timer timer(t, s);
-    hipLaunchKernelGGL((ptk::knn1_persistent_kernel<S, OVF, LEAFB>), dim3(blocks), dim3(64), smem, s, t->dev, qs,
-                       nq, chunk, inv_ratio(e), d_out);
-    if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
-    timer.stop(0, nq);
-  }
-  return rc;
-}
-
-template <int S, int OVF, int LEAFB>
-int launch_knn_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k,
-                          float e, ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
-  float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
-  if (rc != PTK_OK) return rc;
-  const uint32_t chunk = chunk_size();
-  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
-  const size_t stack_bytes = (size_t)S * 64 * 8;
-  const size_t list_bytes = (size_t)k * 64 * 8;
-  const bool list_lds = stack_bytes + list_bytes <= 40 * 1024;  // <= 1/4 of a CU's LDS per wave
-  Timer timer(t, s);
-  if (list_lds) {
-    hipLaunchKernelGGL((ptk::knn_persistent_kernel<S, OVF, LEAFB, true>), dim3(blocks), dim3(64),
-                       stack_bytes + list_bytes, s, t->dev, qs, nq, chunk, k, inv_ratio(e), d_out);
-  } else {
-    hipLaunchKernelGGL((ptk::knn_persistent_kernel<S, OVF, LEAFB, false>), dim3(blocks), dim3(64), stack_bytes, s,
-                       t->dev, qs, nq, chunk, k, inv_ratio(e), d_out);
-  }
-  if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
-  timer.stop(0, nq);
-  return rc;
-}
-
-template <int S, int OVF, int LEAFB>
-int launch_radius_persistent(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
-                             float e, bool fill, uint64_t* d_counts, const uint64_t* d_offsets,
-                             ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
-  float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
-  if (rc != PTK_OK) return rc;
-  const uint32_t chunk = chunk_size();
-  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
-  const size_t smem = (size_t)S * 64 * 8;
-  Timer timer(t, s);
-  if (!fill) {
-    hipLaunchKernelGGL((ptk::radius_persistent_kernel<S, OVF, LEAFB, false>), dim3(blocks), dim3(64), smem, s,
-                       t->dev, qs, nq, chunk, radius, inv_ratio(e), d_counts, d_offsets, d_out);
-  } else {
-    hipLaunchKernelGGL((ptk::radius_persistent_kernel<S, OVF, LEAFB, true>), dim3(blocks), dim3(64), smem, s,
-                       t->dev, qs, nq, chunk, radius, inv_ratio(e), d_counts, d_offsets, d_out);
-  }
-  if (hipGetLastError() != hipSuccess) rc = fail(PTK_ERR_DEVICE, "kernel launch failed");
-  timer.stop(0, nq);
-  return rc;
-}
-
-// Two-phase k = 1 search (see ptk_kernels.hpp): phase 1 over the whole batch, a 3-bit radix
-// pass over the continuations, phase 2 over the continuations.
 // PTK_TIERS="60:4" (default): the first 60 per mille of the ranked classes at 4 lanes per wave.
 ptk::TierSpec parse_tiers() {
   ptk::TierSpec t{};
@@ -644,13 +566,16 @@ size_t two_phase_scratch_bytes(uint64_t nq) {
          2 * (nq * 4) + 64 + class_sort_tmp_bytes(nq);
 }
 
-template <int S1, bool DOUBLE, int S2, int OVF, int LEAFB, bool PERSISTENT2, bool UNIFORM1 = false,
-          int LEAFB1 = LEAFB, int SH = 0, int LEAFBH = 4>
+// UNIFORM1: phase 1 with the wave-uniform prefix, which also packs the launch-order records (the
+// shipped form); otherwise the plain double-descent phase 1 behind pack_queries_kernel (A/B).
+template <int OVF, bool UNIFORM1>
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
+  constexpr int S2 = 16;    // LDS ring of phase 2 (8 KB per wave: 20 waves per CU)
+  constexpr int LEAFB = 4;  // points fetched per round trip
   float4* qs = nullptr;
   int rc = PTK_OK;
-  if (UNIFORM1) {  // phase 1 packs the launch-order records itself
+  if (UNIFORM1) {
     if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
     qs = scratch.take<float4>(nq);
     if (qs == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
@@ -678,14 +603,13 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   ptk::TierSpec tiers = parse_tiers();
   const uint32_t extra_waves = tiers.permille[0] == 0 ? 0u : (uint32_t)(nq / 64) + 2u;
   {
-    const size_t smem = DOUBLE ? 0 : (size_t)S1 * 64 * 8;
     Timer timer(t, s);
     if (UNIFORM1) {
-      hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB1, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
+      hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
                          e_inv, d_out, cont, (uint32_t)env_int("PTK_DEBUG_PHASE1", 0), d_q, t->dim, perm, qs);
     } else {
-      hipLaunchKernelGGL((ptk::knn1_phase1_kernel<S1, OVF, LEAFB, DOUBLE>), dim3(blocks), dim3(64), smem, s, t->dev,
-                         qs, nq, e_inv, d_out, cont);
+      hipLaunchKernelGGL((ptk::knn1_phase1_kernel<32, OVF, LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs,
+                         nq, e_inv, d_out, cont);
     }
     timer.stop(0, nq);
   }
@@ -699,106 +623,9 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   {
     Timer timer(t, s);
-    if (PERSISTENT2) {
-      const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
-      hipLaunchKernelGGL((ptk::knn1_phase2_persistent_kernel<S2, OVF>), dim3(chunks), dim3(64),
-                         (size_t)S2 * 64 * 8 + ptk::kP2Chunk * 4, s, t->dev, qs, e_inv, d_out, cont, ids_out);
-    } else if (SH > 0) {
-      // Heavy continuations (the first wavefronts of the class-sorted list) run concurrently on a
-      // second stream with their own geometry: a ring deep enough that nothing spills to scratch
-      // and whole-leaf batches -- their waves are few and sit on the critical path.
-      Workspace& ws = t->ws;
-      if (ws.aux == nullptr) {
-        PTK_HIP(hipStreamCreateWithFlags(&ws.aux, hipStreamNonBlocking));
-        PTK_HIP(hipEventCreateWithFlags(&ws.fork, hipEventDisableTiming));
-        PTK_HIP(hipEventCreateWithFlags(&ws.join, hipEventDisableTiming));
-      }
-      constexpr int SHS = SH > 0 ? SH : 16;
-      int rc2 = allow_lds(ptk::knn1_phase2_kernel<SHS, OVF, LEAFBH>, (size_t)SHS * 64 * 8);
-      if (rc2 != PTK_OK) return rc2;
-      PTK_HIP(hipEventRecord(ws.fork, s));
-      PTK_HIP(hipStreamWaitEvent(ws.aux, ws.fork, 0));
-      const uint32_t heavy_grid = (uint32_t)(nq / 8 / 64) + 2u + extra_waves;
-      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<SHS, OVF, LEAFBH>), dim3(heavy_grid), dim3(64),
-                         (size_t)SHS * 64 * 8, ws.aux, t->dev, qs, e_inv, d_out, cont, ids_out, 2u);
-      PTK_HIP(hipEventRecord(ws.join, ws.aux));
-      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1 + extra_waves), dim3(64),
-                         (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out, 1u);
-      PTK_HIP(hipStreamWaitEvent(s, ws.join, 0));
-    } else {
-      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>),
-                         dim3(blocks + 1 + extra_waves), dim3(64),
-                         (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out,
-                         (uint32_t)env_int("PTK_DEBUG_PHASE2", 0));
-    }
-    timer.stop(3, 0);
-  }
-  PTK_HIP(hipGetLastError());
-  return PTK_OK;
-}
-
-// Two-phase k = 1 search with the refill phase 2 (the shipped form): phase 1 over the whole batch,
-// then a persistent grid of single-wave blocks that pull continuations from the batch in Morton
-// order -- no class sort.
-int persistent_blocks(const ptk_tree* t, const void* kernel, size_t smem) {
-  int per_cu = 0;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, 64, smem) != hipSuccess || per_cu <= 0) per_cu = 8;
-  hipDeviceProp_t prop;
-  int cus = 256;
-  if (hipGetDeviceProperties(&prop, t->device) == hipSuccess && prop.multiProcessorCount > 0)
-    cus = prop.multiProcessorCount;
-  const int cap = env_int("PTK_REFILL_WAVES_PER_CU", 0);
-  if (cap > 0 && cap < per_cu) per_cu = cap;
-  return per_cu * cus;
-}
-
-template <int S2, int OVF, int LEAFB>
-int launch_knn1_refill(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
-                       ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
-  float4* qs = nullptr;
-  int rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
-  if (rc != PTK_OK) return rc;
-  ptk::Cont cont{};
-  cont.nq = nq;
-  cont.rec = scratch.take<ptk::Record>(nq * ptk::kContSlots);
-  cont.best = scratch.take<uint4>(nq);
-  cont.key = scratch.take<ptk::ContKey>(nq);
-  cont.ids = scratch.take<uint32_t>(nq);
-  cont.meta = scratch.take<uint32_t>(ptk::kMetaWords);
-  if (!cont.rec || !cont.best || !cont.key || !cont.ids || !cont.meta)
-    return fail(PTK_ERR_NOMEM, "scratch block too small");
-  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-  const float e_inv = inv_ratio(e);
-  PTK_HIP(hipMemsetAsync(cont.meta, 0, ptk::kMetaWords * 4, s));
-  {
-    Timer timer(t, s);
-    hipLaunchKernelGGL((ptk::knn1_phase1_kernel<32, OVF, 4, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
-                       e_inv, d_out, cont);
-    timer.stop(0, nq);
-  }
-  {
-    const size_t smem = (size_t)S2 * 64 * 8 + ptk::kQueueSlots * 4;
-    auto kernel = ptk::knn1_phase2_refill_kernel<S2, OVF, LEAFB>;
-    static thread_local int grid_cache = 0;  // per (thread, instantiation); the device set is homogeneous
-    if (grid_cache == 0) grid_cache = persistent_blocks(t, reinterpret_cast<const void*>(kernel), smem);
-    uint32_t grid = (uint32_t)grid_cache;
-    if (grid > blocks) grid = blocks;
-    const uint32_t min_idle = (uint32_t)env_int("PTK_REFILL_MIN_IDLE", 16);
-    if (env_int("PTK_DEBUG_STATS", 0)) {  // debugging aid: instrumented build of the same kernel
-      hipLaunchKernelGGL((ptk::knn1_phase2_refill_kernel<S2, OVF, LEAFB, true>), dim3(grid), dim3(64), smem, s,
-                         t->dev, qs, (uint32_t)nq, e_inv, d_out, cont, cont.meta, min_idle < 1 ? 1u : min_idle);
-      uint32_t h[16];
-      PTK_HIP(hipMemcpyAsync(h, cont.meta, sizeof(h), hipMemcpyDeviceToHost, s));
-      PTK_HIP(hipStreamSynchronize(s));
-      fprintf(stderr, "[refill S=%d LEAFB=%d grid=%u min_idle=%u] wave-iterations %u, active lane-iterations %u "
-              "(%.1f%% of lanes), refills %u, leaf lane-iterations %u, pops %u, max iterations of a wave %u\n",
-              S2, LEAFB, grid, min_idle, h[8], h[9], 100.0 * h[9] / (64.0 * (h[8] ? h[8] : 1)), h[10], h[11], h[12],
-              h[13]);
-      return PTK_OK;
-    }
-    Timer timer(t, s);
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(64), smem, s, t->dev, qs, (uint32_t)nq, e_inv, d_out, cont,
-                       cont.meta, min_idle < 1 ? 1u : (min_idle > 64 ? 64u : min_idle));
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1 + extra_waves), dim3(64),
+                       (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out,
+                       (uint32_t)env_int("PTK_DEBUG_PHASE2", 0));
     timer.stop(3, 0);
   }
   PTK_HIP(hipGetLastError());
@@ -869,58 +696,22 @@ int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float rad
     default: rc = fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth); \
   }
 
-// k = 1 geometries.  Variant 0 is the default; the others exist for A/B runs and
-// only for the shallow spill class (OVF = 64).
+// k = 1.  PTK_KNN1_VARIANT selects an A/B form (tools/ab_knn1.py): 0 = the shipped two-phase
+// search, 22 = the same behind the plain phase 1 (no wave-uniform prefix, separate packing pass),
+// 4 = the single-kernel search every query of which runs to completion in its lane.  The forms
+// measured and rejected on the way (persistent / refill state machines, deeper rings on a second
+// stream, ...) are described in profiles/r01e_notes.txt and live in the git history only.
 int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                   ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   const int variant = env_int("PTK_KNN1_VARIANT", 0);
   int rc = PTK_OK;
-  if (variant != 0 && variant != 4 && ovf_class(t, 8) == 0) {
-    switch (variant) {
-      case 1: return launch_knn1<32, 64, 256, 1>(t, d_q, perm, nq, e, d_out, s);
-      case 2: return launch_knn1<32, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 3: return launch_knn1<16, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 5: return launch_knn1<8, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 6: return launch_knn1<16, 64, 64, 8>(t, d_q, perm, nq, e, d_out, s);
-      case 7: return launch_knn1<8, 64, 256, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 8: return launch_knn1<32, 64, 64, 4>(t, d_q, perm, nq, e, d_out, s);
-      case 9: return launch_knn1<8, 64, 64, 8>(t, d_q, perm, nq, e, d_out, s);
-      case 10: return launch_knn1_persistent<32, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 11: return launch_knn1_persistent<16, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 12: return launch_knn1_persistent<32, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 13: return launch_knn1_persistent<32, 64, 2>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 14: return launch_knn1_persistent<16, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 20: return launch_knn1_two_phase<32, false, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 21: return launch_knn1_two_phase<32, true, 16, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 22: PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch))); return rc;
-      case 23: return launch_knn1_two_phase<32, true, 8, 64, 4, false>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 50: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 51: return launch_knn1_two_phase<32, true, 16, 64, 8, false, true>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 52: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 60: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 61: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 32, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 62: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 63: return launch_knn1_two_phase<32, true, 8, 64, 4, false, true, 4, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 64: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 16, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 65: return launch_knn1_two_phase<32, true, 16, 64, 4, false, true, 4, 8, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 66: return launch_knn1_two_phase<32, true, 8, 64, 4, false, true, 4, 8, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 40: return launch_knn1_refill<16, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 41: return launch_knn1_refill<8, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 42: return launch_knn1_refill<16, 64, 8>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 43: return launch_knn1_refill<16, 64, 2>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 44: return launch_knn1_refill<32, 64, 4>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 30: return launch_knn1_two_phase<32, true, 16, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 31: return launch_knn1_two_phase<32, true, 8, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
-      case 32: return launch_knn1_two_phase<32, true, 32, 64, 4, true>(t, d_q, perm, nq, e, d_out, s, scratch);
-      default: break;
-    }
-  }
-  if (variant == 4) {  // the single-kernel search
+  if (variant == 4) {
     PTK_WITH_OVF(16, (launch_knn1<16, OVF, 64, 4>(t, d_q, perm, nq, e, d_out, s)));
-    return rc;
+  } else if (variant == 22) {
+    PTK_WITH_OVF(16, (launch_knn1_two_phase<OVF, false>(t, d_q, perm, nq, e, d_out, s, scratch)));
+  } else {
+    PTK_WITH_OVF(16, (launch_knn1_two_phase<OVF, true>(t, d_q, perm, nq, e, d_out, s, scratch)));
   }
-  // Default: two-phase search, wave-uniform-prefix phase 1 (scalar node loads while the lanes agree).
-  PTK_WITH_OVF(16, (launch_knn1_two_phase<32, true, 16, OVF, 4, false, true>(t, d_q, perm, nq, e, d_out, s, scratch)));
   return rc;
 }
 
@@ -1008,9 +799,6 @@ void ptk_tree_destroy(ptk_tree* t) {
     for (hipEvent_t e : t->profile.idle) (void)hipEventDestroy(e);
     if (t->ws.has_work) (void)hipEventSynchronize(t->ws.done);
     if (t->ws.done) (void)hipEventDestroy(t->ws.done);
-    if (t->ws.fork) (void)hipEventDestroy(t->ws.fork);
-    if (t->ws.join) (void)hipEventDestroy(t->ws.join);
-    if (t->ws.aux) (void)hipStreamDestroy(t->ws.aux);
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
     if (t->d_pts) (void)hipFree(t->d_pts);

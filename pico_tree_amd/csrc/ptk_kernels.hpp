@@ -450,166 +450,6 @@ __device__ __forceinline__ void traverse(
   }
 }
 
-// ---- the persistent traversal machine -----------------------------------------------
-//
-// The loop above lets a wavefront idle while its slowest lane finishes: measured on
-// the LiDAR-like cloud, the deepest lane of a wave needs 1.6x (uniform cloud 2.2x)
-// the branch steps of the average lane, and a few queries need 20x.  Here a
-// wavefront is persistent instead: it owns a contiguous chunk of the (spatially
-// sorted) batch and every lane runs the same per-query state machine,
-//
-//     FETCH  -> load the next query of the chunk, start at the root
-//     NODE   -> one branch step (or entering a far child: re-read the parent)
-//     LEAF   -> measure up to LEAFB points; after the last batch, unwind the
-//               record stack (LDS only) to the next far child or finish
-//
-// one state transition per loop iteration, with exactly ONE global-memory round
-// trip per iteration for the whole wave: all loads of an iteration (query, node
-// or point batch, per lane) are issued before any of them is consumed.  A lane
-// that finishes its query takes the next one immediately (ballot + prefix count),
-// so lanes stay busy until the chunk is exhausted.  Each lane still replays its
-// own reference visit order, so results are unchanged.
-template <int LEAFB, class Policy, class StackT>
-__device__ __forceinline__ void run_machine(
-    const DevTree& t, const float4* __restrict__ qs, uint64_t first, uint64_t last, Policy& pol,
-    StackT& st) {
-  const uint4* __restrict__ nodes = t.nodes;
-  const float4* __restrict__ pts = t.pts;
-  const uint64_t lanes_below = (1ull << (threadIdx.x & 63u)) - 1ull;
-
-  uint64_t next = first;  // wave-uniform: first query of the chunk nobody has taken yet
-  bool active = false;
-  bool far_entry = false;
-  uint32_t far_meta = 0;
-  float far_val = 0.0f;
-  uint32_t ref = 0, leaf_j = 0, qi = 0;
-  float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
-  float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-
-  for (;;) {
-    // Hand the next queries of the chunk to the idle lanes.
-    const uint64_t idle = __ballot(!active);
-    bool fetch = false;
-    uint64_t mine = 0;
-    if (idle != 0) {
-      if (next < last) {
-        mine = next + (uint64_t)__popcll(idle & lanes_below);
-        fetch = !active && mine < last;
-        next += (uint64_t)__popcll(idle);
-      } else if (idle == ~0ull) {
-        break;
-      }
-    }
-
-    // Issue this iteration's loads.
-    const bool at_leaf = active && !far_entry && (ref & kLeafBit) != 0;
-    const bool at_node = active && !at_leaf;
-    const uint32_t lv = ref & 0x7FFFFFFFu;
-    const uint32_t begin = lv >> t.cbits;
-    const uint32_t count = lv & t.cmask;
-    const uint32_t node_idx = far_entry ? (far_meta & kRecIdxMask) : (ref & kBranchIdxMask);
-    // Query, node and point records are all 16 bytes: one address per lane.
-    const uint4* addr = fetch ? reinterpret_cast<const uint4*>(qs + mine)
-                              : (at_leaf ? reinterpret_cast<const uint4*>(pts + (begin + leaf_j))
-                                         : nodes + node_idx);
-    uint4 r0 = make_uint4(0u, 0u, 0u, 0u);
-    uint4 rp[LEAFB > 1 ? LEAFB - 1 : 1];
-    if (fetch || active) r0 = *addr;
-    if (at_leaf) {
-#pragma unroll
-      for (int u = 1; u < LEAFB; ++u) rp[u - 1] = addr[u];
-    }
-
-    if (fetch) {
-      qx = __uint_as_float(r0.x);
-      qy = __uint_as_float(r0.y);
-      qz = __uint_as_float(r0.z);
-      qi = r0.w;
-      pol.begin_query(qi);
-      st.top = 0;
-      st.base = 0;
-      nbd = off0 = off1 = off2 = 0.0f;
-      ref = t.root_ref;
-      leaf_j = 0;
-      far_entry = false;
-      active = true;
-    } else if (at_node) {
-      const float left_max = __uint_as_float(r0.x);
-      const float right_min = __uint_as_float(r0.y);
-      if (!far_entry) {
-        const uint32_t axis = (ref >> 29) & 3u;
-        const float v = sel3(axis, qx, qy, qz);
-        const float s = f_sub(f_sub(f_add(left_max, right_min), v), v);
-        const bool go_left = s > 0.0f;
-        const float plane = go_left ? right_min : left_max;
-        const float dv = f_sub(plane, v);
-        const float new_off = f_mul(dv, dv);
-        const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
-        if (pol.max() >= far_nbd) {
-          st.push(node_idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
-        }
-        ref = go_left ? r0.z : r0.w;
-      } else {
-        const uint32_t axis = (far_meta >> 28) & 3u;
-        const bool far_is_right = (far_meta & kRecSide) != 0;
-        const float plane = far_is_right ? right_min : left_max;
-        const float dv = f_sub(plane, sel3(axis, qx, qy, qz));
-        const float new_off = f_mul(dv, dv);
-        st.push(kRecUndo | (axis << 28), sel3(axis, off0, off1, off2));
-        st.push(kRecUndo | kRecSide, nbd);
-        off0 = axis == 0 ? new_off : off0;
-        off1 = axis == 1 ? new_off : off1;
-        off2 = axis == 2 ? new_off : off2;
-        nbd = far_val;
-        ref = far_is_right ? r0.w : r0.z;
-        far_entry = false;
-      }
-      leaf_j = 0;
-    } else if (at_leaf) {
-#pragma unroll
-      for (int u = 0; u < LEAFB; ++u) {
-        const uint4 p = u == 0 ? r0 : rp[u > 0 ? u - 1 : 0];
-        if (leaf_j + u < count) {
-          const float dx = f_sub(qx, __uint_as_float(p.x));
-          const float dy = f_sub(qy, __uint_as_float(p.y));
-          const float dz = f_sub(qz, __uint_as_float(p.z));
-          const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
-          pol.visit((int32_t)p.w, d);
-        }
-      }
-      leaf_j += LEAFB;
-      if (leaf_j >= count) {  // leaf done: unwind to the next far child worth entering
-        for (;;) {
-          if (st.empty()) {
-            pol.end_query(qi);
-            active = false;
-            break;
-          }
-          const Record r = st.pop();
-          const float val = __uint_as_float(r.y);
-          if (r.x & kRecUndo) {
-            if (r.x & kRecSide) {
-              nbd = val;
-            } else {
-              const uint32_t axis = (r.x >> 28) & 3u;
-              off0 = axis == 0 ? val : off0;
-              off1 = axis == 1 ? val : off1;
-              off2 = axis == 2 ? val : off2;
-            }
-            continue;
-          }
-          if (pol.max() >= val) {
-            far_entry = true;
-            far_meta = r.x;
-            far_val = val;
-            break;
-          }
-        }
-      }
-    }
-  }
-}
-
 // Blocks are dealt round-robin to the 8 XCDs; give each XCD one contiguous
 // eighth of the (spatially sorted) batch so its private L2 only ever sees one
 // region of the tree.  Pure performance: any mapping is correct.
@@ -1222,524 +1062,7 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   pol.end_query(qi);
 }
 
-// Phase 2, persistent form.  Continuations differ wildly in cost (most need one far leaf,
-// the worst six hundred) and no cheap key predicts it, so here a wavefront does not wait
-// for its slowest lane: it owns kP2Chunk consecutive slots of the class-sorted list and a
-// lane that finishes its continuation takes the next slot at once (ballot + prefix count).
-// Every lane runs the same small state machine -- FETCH a continuation, NODE step (branch or
-// far-child entry), LEAF batch followed by the LDS-only unwind -- one transition per loop
-// iteration, and all global loads of an iteration (five 16-byte loads per lane, redirected
-// to the lane's first address when a state needs fewer) are issued back to back before any
-// is consumed: one memory round trip per iteration for the whole wavefront.
-constexpr uint32_t kP2Chunk = 256;
-constexpr uint32_t kNoEntry = 0xFFFFFFFFu;
-
-template <int S, int OVF>
-__global__ __launch_bounds__(64) void knn1_phase2_persistent_kernel(
-    DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
-    const uint32_t* __restrict__ sorted_ids) {
-  const uint32_t n2 = cont.meta[0];
-  const uint32_t heavy = cont.meta[1];
-  const uint32_t heavy_waves = cont.meta[2];
-  const uint32_t total_slots = heavy_waves * 64u + (n2 - heavy);
-  const uint32_t chunk_base = xcd_tile(blockIdx.x, gridDim.x) * kP2Chunk;
-  if (chunk_base >= total_slots) return;
-  const uint32_t lane = threadIdx.x;
-  const uint4* __restrict__ nodes = t.nodes;
-  const float4* __restrict__ pts = t.pts;
-
-  // The chunk's entry ids, staged in LDS behind the record ring.
-  PTK_LDS uint32_t* ids = (PTK_LDS uint32_t*)(ptk_smem + (size_t)S * 64 * 8);
-  for (uint32_t j = 0; j < kP2Chunk / 64; ++j) {
-    const uint32_t slot = chunk_base + j * 64u + lane;
-    const uint32_t wave = slot >> 6;
-    uint32_t s;
-    bool valid;
-    if (wave < heavy_waves) {  // heavy classes: dealt across wavefront-sized groups
-      s = (slot & 63u) * heavy_waves + wave;
-      valid = s < heavy;
-    } else {
-      s = heavy + (slot - heavy_waves * 64u);
-      valid = s < n2;
-    }
-    ids[j * 64u + lane] = valid ? sorted_ids[s] : kNoEntry;
-  }
-  __syncthreads();  // one wavefront per block: orders the staging writes before the reads below
-
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, lane, spill);
-  NnPolicy pol;
-  pol.e_inv = e_inv;
-  pol.out = out;
-  pol.begin_query(0);
-
-  enum : uint32_t { IDLE = 0, FETCH = 1, NODE = 2, LEAF = 3 };
-  const uint64_t lanes_below = (1ull << lane) - 1ull;
-  uint32_t next = 0;  // wave-uniform: first slot of the chunk nobody has taken
-  uint32_t state = IDLE;
-  uint32_t e = 0, qi = 0, ref = 0, leaf_j = 0, far_meta = 0;
-  bool far_entry = false;
-  float far_val = 0.0f, nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
-  float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-
-  for (;;) {
-    const uint64_t idle = __ballot(state == IDLE);
-    if (idle != 0) {
-      if (next < kP2Chunk) {
-        const uint32_t mine = next + (uint32_t)__popcll(idle & lanes_below);
-        if (state == IDLE && mine < kP2Chunk) {
-          e = ids[mine];
-          if (e != kNoEntry) state = FETCH;
-        }
-        next += (uint32_t)__popcll(idle);
-      } else if (idle == ~0ull) {
-        break;
-      }
-    }
-
-    // ---- this iteration's loads: five 16-byte records per lane ----
-    const uint32_t lv = ref & 0x7FFFFFFFu;
-    const uint32_t begin = lv >> t.cbits;
-    const uint32_t count = lv & t.cmask;
-    const uint32_t node_idx = far_entry ? (far_meta & kRecIdxMask) : (ref & kBranchIdxMask);
-    const uint4* a0;
-    const uint4* a1;
-    const uint4* a2;
-    const uint4* a3;
-    const uint4* a4;
-    if (state == FETCH) {
-      a0 = reinterpret_cast<const uint4*>(qs + e);
-      a1 = cont.best + e;
-      a2 = a1;  // the records are fetched below (one 8-byte load each)
-      a3 = a1;
-      a4 = a1;
-    } else if (state == LEAF) {
-      a0 = reinterpret_cast<const uint4*>(pts + (begin + leaf_j));
-      a1 = a0 + 1;
-      a2 = a0 + 2;
-      a3 = a0 + 3;
-      a4 = a0;
-    } else {  // NODE, or IDLE (any readable address)
-      a0 = nodes + (state == NODE ? node_idx : 0u);
-      a1 = a0;
-      a2 = a0;
-      a3 = a0;
-      a4 = a0;
-    }
-    const uint4 r0 = *a0;
-    const uint4 r1 = *a1;
-    const uint4 r2 = *a2;
-    const uint4 r3 = *a3;
-    const uint4 r4 = *a4;
-
-    bool unwind = false;
-    if (state == FETCH) {
-      qx = __uint_as_float(r0.x);
-      qy = __uint_as_float(r0.y);
-      qz = __uint_as_float(r0.z);
-      qi = r0.w;
-      st.top = 0;
-      st.base = 0;
-      nbd = off0 = off1 = off2 = 0.0f;
-      far_entry = false;
-      leaf_j = 0;
-      const uint32_t cls = r1.z;
-      if (cls == kContOverflow) {  // too many candidates to carry: the whole search, from the root
-        pol.begin_query(qi);
-        ref = t.root_ref;
-        state = (ref & kLeafBit) ? LEAF : NODE;
-      } else {
-        pol.best_i = (int32_t)r1.x;
-        pol.best_d = __uint_as_float(r1.y);
-        for (uint32_t j = 0; j < cls; ++j) {
-          const Record r = cont.record(e, j);
-          st.push(r.x, __uint_as_float(r.y));
-        }
-        (void)r2; (void)r3; (void)r4;
-        unwind = true;
-      }
-    } else if (state == NODE) {
-      const float left_max = __uint_as_float(r0.x);
-      const float right_min = __uint_as_float(r0.y);
-      if (!far_entry) {
-        const uint32_t axis = (ref >> 29) & 3u;
-        const float v = sel3(axis, qx, qy, qz);
-        const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
-        const float dv = f_sub(go_left ? right_min : left_max, v);
-        const float new_off = f_mul(dv, dv);
-        const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
-        if (pol.max() >= far_nbd) {
-          st.push(node_idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
-        }
-        ref = go_left ? r0.z : r0.w;
-      } else {
-        const uint32_t axis = (far_meta >> 28) & 3u;
-        const bool far_is_right = (far_meta & kRecSide) != 0;
-        const float dv = f_sub(far_is_right ? right_min : left_max, sel3(axis, qx, qy, qz));
-        const float new_off = f_mul(dv, dv);
-        st.push(kRecUndo | (axis << 28), sel3(axis, off0, off1, off2));
-        st.push(kRecUndo | kRecSide, nbd);
-        off0 = axis == 0 ? new_off : off0;
-        off1 = axis == 1 ? new_off : off1;
-        off2 = axis == 2 ? new_off : off2;
-        nbd = far_val;
-        ref = far_is_right ? r0.w : r0.z;
-        far_entry = false;
-      }
-      leaf_j = 0;
-      state = (ref & kLeafBit) ? LEAF : NODE;
-    } else if (state == LEAF) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const uint4 p = u == 0 ? r0 : (u == 1 ? r1 : (u == 2 ? r2 : r3));
-        if (leaf_j + u < count) {
-          const float dx = f_sub(qx, __uint_as_float(p.x));
-          const float dy = f_sub(qy, __uint_as_float(p.y));
-          const float dz = f_sub(qz, __uint_as_float(p.z));
-          pol.visit((int32_t)p.w, f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
-        }
-      }
-      leaf_j += 4;
-      unwind = leaf_j >= count;
-    }
-
-    if (unwind) {  // LDS only: back up to the next far child worth entering, or finish
-      for (;;) {
-        if (st.empty()) {
-          pol.end_query(qi);
-          state = IDLE;
-          break;
-        }
-        const Record r = st.pop();
-        const float val = __uint_as_float(r.y);
-        if (r.x & kRecUndo) {
-          if (r.x & kRecSide) {
-            nbd = val;
-          } else {
-            const uint32_t axis = (r.x >> 28) & 3u;
-            off0 = axis == 0 ? val : off0;
-            off1 = axis == 1 ? val : off1;
-            off2 = axis == 2 ? val : off2;
-          }
-          continue;
-        }
-        if (pol.max() >= val) {
-          far_entry = true;
-          far_meta = r.x;
-          far_val = val;
-          state = NODE;
-          break;
-        }
-      }
-    }
-  }
-}
-
-// Phase 2, refill form (the shipped one).  profiles/r01d_*: in knn1_phase2_kernel a wavefront
-// issues 36 M vector loads per launch where ~3 M would do if its lanes were evenly loaded --
-// far-side work per query is wildly uneven (mean 2.3 far leaves, worst 600) and a wave waits for
-// its slowest lane.  Here the grid is persistent (one wave per block, as many blocks as fit on
-// the chip) and a lane that finishes its continuation takes the next one:
-//
-//   * work is handed out in groups of 64 consecutive slots of the Morton-ordered batch through
-//     8 global counters, one per eighth of the batch; a block starts on the eighth of "its" XCD
-//     (blockIdx & 7 -- a locality hint only) and moves on to the others when it runs dry;
-//   * a group's slots that still need work (class != 0) are compacted with a ballot into a small
-//     LDS queue; idle lanes pop from it by prefix rank.  No class sort is needed any more;
-//   * every lane runs one small state machine -- a NODE step (branch, or entering a far child),
-//     or one LEAF batch of LEAFB points followed, after the last batch, by the LDS-only unwind --
-//     one transition per loop iteration with one memory round trip per iteration for the wave.
-//     A lane only ever issues the loads its own state needs (exec-masked), so the vector-memory
-//     pipe sees no padding traffic;
-//   * the queue is only topped up when at least `min_idle` lanes are idle, so the fetch cost
-//     (5 loads per continuation) is amortised.
-//
-// Each lane still replays its own query's reference visit order; results are unchanged.
-constexpr uint32_t kQueueSlots = 128;   // >= 63 + 64
-constexpr uint32_t kNoGroup = 0xFFFFFFFFu;
-
-__device__ __forceinline__ uint32_t wave_broadcast0(uint32_t v) {
-  return (uint32_t)__shfl((int)v, 0);
-}
-
-template <int S, int OVF, int LEAFB, bool STATS = false>
-__global__ __launch_bounds__(64) void knn1_phase2_refill_kernel(
-    DevTree t, const float4* __restrict__ qs, uint32_t nq, float e_inv, Neighbor* __restrict__ out,
-    Cont cont, uint32_t* __restrict__ counters, uint32_t min_idle) {
-  // STATS (debug builds of the launcher only): counters[8..] += {iterations, active lane-iterations,
-  // refills, leaf lane-iterations, unwind pops}, counters[13] = max iterations of one wave.
-  uint32_t s_iter = 0, s_active = 0, s_refill = 0, s_leaf = 0, s_pops = 0;
-  const uint32_t lane = threadIdx.x;
-  const uint64_t lanes_below = (1ull << lane) - 1ull;
-  const uint4* __restrict__ nodes = t.nodes;
-  const float4* __restrict__ pts = t.pts;
-  PTK_LDS uint32_t* queue = (PTK_LDS uint32_t*)(ptk_smem + (size_t)S * 64 * 8);
-
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, lane, spill);
-  NnPolicy pol;
-  pol.e_inv = e_inv;
-  pol.out = out;
-  pol.begin_query(0);
-
-  // Work distribution (all wave-uniform except `tries`, which only lane 0 uses).
-  const uint32_t groups = (nq + 63u) / 64u;
-  const uint32_t per = (groups + 7u) / 8u;  // groups per eighth
-  const uint32_t home = blockIdx.x & 7u;
-  uint32_t tries = 0;
-  bool exhausted = false;
-  uint32_t q_head = 0, q_tail = 0;
-
-  bool active = false, far = false;
-  uint32_t qi = 0, ref = 0, leaf_j = 0, far_meta = 0;
-  float far_val = 0.0f, nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
-  float qx = 0.0f, qy = 0.0f, qz = 0.0f;
-
-  for (;;) {
-    bool unwind = false;
-    bool fresh = false;
-    const uint64_t idle_mask = __ballot(!active);
-    const uint32_t n_idle = (uint32_t)__popcll(idle_mask);
-    if (STATS) {
-      ++s_iter;
-      s_active += 64u - n_idle;
-    }
-    if (n_idle >= min_idle || idle_mask == ~0ull) {
-      if (STATS) ++s_refill;
-      // Top up the queue until every idle lane can be served (or the batch is exhausted).
-      while (q_tail - q_head < n_idle && !exhausted) {
-        uint32_t g = kNoGroup;
-        if (lane == 0) {
-          while (tries < 8u) {
-            const uint32_t r = (home + tries) & 7u;
-            const uint32_t first = r * per;
-            const uint32_t len = first >= groups ? 0u : (groups - first < per ? groups - first : per);
-            const uint32_t got = len ? atomicAdd(&counters[r], 1u) : len;
-            if (got < len) {
-              g = first + got;
-              break;
-            }
-            ++tries;
-          }
-        }
-        g = wave_broadcast0(g);
-        if (g == kNoGroup) {
-          exhausted = true;
-          break;
-        }
-        const uint32_t slot = g * 64u + lane;
-        const bool has = slot < nq && !cont_key_is_final(cont.key[slot]);  // class 0 is final already
-        const uint64_t m = __ballot(has);
-        if (has) queue[(q_tail + (uint32_t)__popcll(m & lanes_below)) & (kQueueSlots - 1u)] = slot;
-        q_tail += (uint32_t)__popcll(m);
-      }
-      __syncthreads();  // one wavefront per block: orders the queue writes before the reads below
-      const uint32_t avail = q_tail - q_head;
-      if (avail == 0u && idle_mask == ~0ull) break;  // nothing running, nothing left
-      const uint32_t rank = (uint32_t)__popcll(idle_mask & lanes_below);
-      if (!active && rank < avail) {
-        const uint32_t e = queue[(q_head + rank) & (kQueueSlots - 1u)];
-        const float4 qrec = qs[e];
-        const uint4 start = cont.best[e];
-        const uint32_t cls = start.z;
-        Record rr[kContSlots];
-#pragma unroll
-        for (int j = 0; j < kContSlots; ++j) {
-          rr[j].x = 0u;
-          rr[j].y = 0u;
-          if (cls != kContOverflow && (uint32_t)j < cls) rr[j] = cont.record(e, (uint32_t)j);
-        }
-        qx = qrec.x;
-        qy = qrec.y;
-        qz = qrec.z;
-        qi = __float_as_uint(qrec.w);
-        st.top = 0;
-        st.base = 0;
-        nbd = off0 = off1 = off2 = 0.0f;
-        far = false;
-        leaf_j = 0;
-        active = true;
-        fresh = true;
-        if (cls == kContOverflow) {  // too many candidates to carry: the whole search, from the root
-          pol.begin_query(qi);
-          ref = t.root_ref;
-        } else {
-          pol.best_i = (int32_t)start.x;
-          pol.best_d = __uint_as_float(start.y);
-#pragma unroll
-          for (int j = 0; j < kContSlots; ++j) {
-            if ((uint32_t)j < cls) st.push(rr[j].x, __uint_as_float(rr[j].y));
-          }
-          unwind = true;
-        }
-      }
-      q_head += n_idle < avail ? n_idle : avail;
-    }
-
-    // ---- one state transition per lane ----
-    if (active && !fresh) {
-      const bool at_leaf = !far && (ref & kLeafBit) != 0;
-      const uint32_t lv = ref & 0x7FFFFFFFu;
-      const uint32_t begin = lv >> t.cbits;
-      const uint32_t count = lv & t.cmask;
-      const uint32_t node_idx = far ? (far_meta & kRecIdxMask) : (ref & kBranchIdxMask);
-      const uint4* addr = at_leaf ? reinterpret_cast<const uint4*>(pts + (begin + leaf_j)) : nodes + node_idx;
-      const uint4 r0 = addr[0];
-      if (!at_leaf) {
-        const float left_max = __uint_as_float(r0.x);
-        const float right_min = __uint_as_float(r0.y);
-        if (!far) {
-          const uint32_t axis = (ref >> 29) & 3u;
-          const float v = sel3(axis, qx, qy, qz);
-          const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
-          const float dv = f_sub(go_left ? right_min : left_max, v);
-          const float new_off = f_mul(dv, dv);
-          const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
-          if (pol.max() >= far_nbd) st.push(node_idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
-          ref = go_left ? r0.z : r0.w;
-        } else {
-          const uint32_t axis = (far_meta >> 28) & 3u;
-          const bool far_is_right = (far_meta & kRecSide) != 0;
-          const float dv = f_sub(far_is_right ? right_min : left_max, sel3(axis, qx, qy, qz));
-          const float new_off = f_mul(dv, dv);
-          st.push(kRecUndo | (axis << 28), sel3(axis, off0, off1, off2));
-          st.push(kRecUndo | kRecSide, nbd);
-          off0 = axis == 0 ? new_off : off0;
-          off1 = axis == 1 ? new_off : off1;
-          off2 = axis == 2 ? new_off : off2;
-          nbd = far_val;
-          ref = far_is_right ? r0.w : r0.z;
-          far = false;
-        }
-        leaf_j = 0;
-      } else {
-        uint4 rp[LEAFB > 1 ? LEAFB - 1 : 1];
-#pragma unroll
-        for (int u = 1; u < LEAFB; ++u) rp[u - 1] = addr[u];
-#pragma unroll
-        for (int u = 0; u < LEAFB; ++u) {
-          const uint4 p = u == 0 ? r0 : rp[u > 0 ? u - 1 : 0];
-          if (leaf_j + u < count) {
-            const float dx = f_sub(qx, __uint_as_float(p.x));
-            const float dy = f_sub(qy, __uint_as_float(p.y));
-            const float dz = f_sub(qz, __uint_as_float(p.z));
-            pol.visit((int32_t)p.w, f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
-          }
-        }
-        leaf_j += LEAFB;
-        unwind = leaf_j >= count;
-        if (STATS) ++s_leaf;
-      }
-    }
-
-    if (unwind) {  // LDS only: back up to the next far child worth entering, or finish
-      for (;;) {
-        if (st.empty()) {
-          pol.end_query(qi);
-          active = false;
-          break;
-        }
-        if (STATS) ++s_pops;
-        const Record r = st.pop();
-        const float val = __uint_as_float(r.y);
-        if (r.x & kRecUndo) {
-          if (r.x & kRecSide) {
-            nbd = val;
-          } else {
-            const uint32_t axis = (r.x >> 28) & 3u;
-            off0 = axis == 0 ? val : off0;
-            off1 = axis == 1 ? val : off1;
-            off2 = axis == 2 ? val : off2;
-          }
-          continue;
-        }
-        if (pol.max() >= val) {
-          far = true;
-          far_meta = r.x;
-          far_val = val;
-          break;
-        }
-      }
-    }
-  }
-  if (STATS) {
-    atomicAdd(&counters[10], lane == 0 ? s_refill : 0u);
-    atomicAdd(&counters[8], lane == 0 ? s_iter : 0u);
-    atomicAdd(&counters[9], lane == 0 ? s_active : 0u);
-    atomicAdd(&counters[11], s_leaf);
-    atomicAdd(&counters[12], s_pops);
-    if (lane == 0) atomicMax(&counters[13], s_iter);
-  }
-}
-
-// ---- persistent kernels: one wavefront per block, one chunk of sorted queries each ------
-// qs: the batch packed as {x, y, z, bits(original index)} in launch order.
-template <int S, int OVF, int LEAFB>
-__global__ __launch_bounds__(64) void knn1_persistent_kernel(
-    DevTree t, const float4* __restrict__ qs, uint64_t nq, uint32_t chunk, float e_inv,
-    Neighbor* __restrict__ out) {
-  const uint64_t first = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * chunk;
-  if (first >= nq) return;
-  const uint64_t last = first + chunk < nq ? first + chunk : nq;
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
-  NnPolicy pol;
-  pol.e_inv = e_inv;
-  pol.out = out;
-  pol.begin_query(0);
-  run_machine<LEAFB>(t, qs, first, last, pol, st);
-}
-
-template <int S, int OVF, int LEAFB, bool LIST_LDS>
-__global__ __launch_bounds__(64) void knn_persistent_kernel(
-    DevTree t, const float4* __restrict__ qs, uint64_t nq, uint32_t chunk, uint32_t k, float e_inv,
-    Neighbor* __restrict__ out) {
-  const uint64_t first = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * chunk;
-  if (first >= nq) return;
-  const uint64_t last = first + chunk < nq ? first + chunk : nq;
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
-  KnnPolicy<LIST_LDS> pol;
-  pol.k = k;
-  pol.e_inv = e_inv;
-  pol.out = out;
-  if constexpr (LIST_LDS) {
-    pol.list = (LdsWord*)(ptk_smem + (size_t)S * 64 * 8) + threadIdx.x;
-    pol.stride = 64;
-  } else {
-    pol.list = out;
-    pol.stride = 1;
-  }
-  pol.begin_query(0);
-  run_machine<LEAFB>(t, qs, first, last, pol, st);
-}
-
-template <int S, int OVF, int LEAFB, bool FILL>
-__global__ __launch_bounds__(64) void radius_persistent_kernel(
-    DevTree t, const float4* __restrict__ qs, uint64_t nq, uint32_t chunk, float radius, float e_inv,
-    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out) {
-  const uint64_t first = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * chunk;
-  if (first >= nq) return;
-  const uint64_t last = first + chunk < nq ? first + chunk : nq;
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
-  RadiusPolicy<FILL> pol;
-  pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
-  pol.e_inv = e_inv;
-  pol.counts = counts;
-  pol.offsets = offsets;
-  pol.rows = out;
-  pol.out = out;
-  pol.count = 0;
-  run_machine<LEAFB>(t, qs, first, last, pol, st);
-}
-
-// Packs the batch for the persistent kernels: qs[i] = {query perm[i], bits(perm[i])}
+// Packs the batch in launch order: qs[i] = {query perm[i], bits(perm[i])}
 // (perm == nullptr: identity).
 __global__ __launch_bounds__(kBlock) void pack_queries_kernel(
     const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,

@@ -295,52 +295,13 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   return 0;
 }
 
-// The persistent (state machine + lane refill) kernels.  mode: 0 knn, 1 radius count,
-// 2 radius fill.  small_stack selects a 4-slot ring so that spills happen constantly.
-int emu_persistent(void* h, int mode, const float* q, uint64_t nq, uint32_t k, float radius, float e,
-                   const uint32_t* perm, uint32_t chunk, int small_stack, int list_in_lds, uint64_t* counts,
-                   const uint64_t* offsets, ptk_neighbor* out) {
-  auto* t = static_cast<Emu*>(h);
-  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
-  const float e_inv = 1.0f / e;
-  if (2 * t->st.max_depth + 2 > 4 + 2048) return -2;
-  if (nq == 0) return 0;
-  std::vector<float4> qs = pack(q, t->dim, perm, nq);
-  const uint32_t blocks = (uint32_t)((nq + chunk - 1) / chunk);
-  if (mode == 0 && k == 1) {
-    if (small_stack)
-      for_each_wave(blocks, [&] { ptk::knn1_persistent_kernel<4, 2048, 2>(t->dev, qs.data(), nq, chunk, e_inv, o); });
-    else
-      for_each_wave(blocks, [&] { ptk::knn1_persistent_kernel<32, 2048, 4>(t->dev, qs.data(), nq, chunk, e_inv, o); });
-  } else if (mode == 0) {
-    if ((size_t)(16 + k) * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
-    if (list_in_lds)
-      for_each_wave(blocks, [&] {
-        ptk::knn_persistent_kernel<16, 2048, 4, true>(t->dev, qs.data(), nq, chunk, k, e_inv, o);
-      });
-    else
-      for_each_wave(blocks, [&] {
-        ptk::knn_persistent_kernel<4, 2048, 8, false>(t->dev, qs.data(), nq, chunk, k, e_inv, o);
-      });
-  } else if (mode == 1) {
-    for_each_wave(blocks, [&] {
-      ptk::radius_persistent_kernel<8, 2048, 4, false>(t->dev, qs.data(), nq, chunk, radius, e_inv, counts, nullptr,
-                                                       nullptr);
-    });
-  } else {
-    for_each_wave(blocks, [&] {
-      ptk::radius_persistent_kernel<16, 2048, 4, true>(t->dev, qs.data(), nq, chunk, radius, e_inv, nullptr, offsets,
-                                                       o);
-    });
-  }
-  return 0;
-}
-
-// The two-phase k = 1 search: phase 1, class sort (stable counting sort standing in for the
-// device radix pass), phase 2.  variant: 0 = LDS ring phase 1, 1 = double-descent phase 1,
-// 2 = tiny rings everywhere (spill paths), 3 / 4 = persistent phase 2 (normal / tiny ring),
-// 5 / 6 = refill phase 2 (shipped geometry / tiny ring with eager refill),
-// 7 / 8 = wave-uniform-prefix phase 1 followed by the refill / the class-sorted phase 2.
+// The two-phase k = 1 search: phase 1, sort by continuation key (stable sort standing in for the
+// device radix pass), phase 2.  variant:
+//   0  LDS-ring phase 1            1  double-descent phase 1
+//   2  tiny rings everywhere (spill paths)
+//   3  wave-uniform-prefix phase 1 that also packs the records (the shipped form; ballots: lanes
+//      run as fibers), default phase 2
+//   4  as 3 with one-point leaf batches and three narrow tiers (1, 4 and 16 lanes per wave)
 int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint32_t* perm, int variant,
                        ptk_neighbor* out) {
   auto* t = static_cast<Emu*>(h);
@@ -354,33 +315,23 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
   std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(ptk::kMetaWords, 0);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
-  if (variant == 7 || variant == 8)  // wave-uniform prefix phase 1 (ballots: lanes run as fibers)
+  if (variant == 3 || variant == 4) {
+    std::vector<float4> packed(nq);  // written by the kernel itself (PACK)
     for_each_wave((uint32_t)((nq + 63) / 64), [&] {
-      if (variant == 7) ptk::knn1_phase1u_kernel<4>(t->dev, qs.data(), nq, e_inv, o, cont);
-      else ptk::knn1_phase1u_kernel<1>(t->dev, qs.data(), nq, e_inv, o, cont);
+      if (variant == 3)
+        ptk::knn1_phase1u_kernel<4, true>(t->dev, nullptr, nq, e_inv, o, cont, 0u, q, t->dim, perm, packed.data());
+      else
+        ptk::knn1_phase1u_kernel<1, true>(t->dev, nullptr, nq, e_inv, o, cont, 0u, q, t->dim, perm, packed.data());
     });
-  else if (variant == 0)
+    for (uint64_t i = 0; i < nq; ++i) {
+      if (std::memcmp(&packed[i], &qs[i], sizeof(float4)) != 0) return -4;  // same records as pack_queries_kernel
+    }
+  } else if (variant == 0) {
     for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
-  else if (variant == 1 || variant >= 3)
+  } else if (variant == 1) {
     for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
-  else
+  } else {
     for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<4, 2048, 1, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
-  if (variant >= 5 && variant <= 7) {  // refill phase 2: no class sort (5, 7: shipped ring, 6: tiny ring + eager refill)
-    std::vector<uint32_t> counters(8, 0);
-    const uint32_t waves = 3;  // the first wave drains the batch; the others find it exhausted
-    if (variant != 6)
-      for_each_wave(waves, [&] {
-        ptk::knn1_phase2_refill_kernel<16, 2048, 4>(t->dev, qs.data(), (uint32_t)nq, e_inv, o, cont, counters.data(),
-                                                   16u);
-      });
-    else
-      for_each_wave(waves, [&] {
-        ptk::knn1_phase2_refill_kernel<4, 2048, 1>(t->dev, qs.data(), (uint32_t)nq, e_inv, o, cont, counters.data(),
-                                                  1u);
-      });
-    int todo = 0;
-    for (uint64_t i = 0; i < nq; ++i) todo += (ckey[i] >> 13) != 7;
-    return todo;
   }
   // stable sort by key (what the device's radix pass does)
   std::vector<uint32_t> sorted(nq);
@@ -397,27 +348,16 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   gridDim.x = 1;
   blockIdx.x = 0;
   threadIdx.x = 0;
-  // variant 8 also exercises the top tier: half of the ranked classes, 4 lanes per wavefront.
-  const uint32_t top_extra = variant == 8 ? (uint32_t)nq + 2u : 0u;
+  const uint32_t top_extra = variant == 4 ? (uint32_t)nq + 2u : (uint32_t)(nq / 64) + 2u;
   ptk::TierSpec tiers{};
-  if (variant == 8) {  // three narrow tiers: 1, 4 and 16 lanes per wave
+  if (variant == 4) {
     tiers.permille[0] = 200; tiers.lanes[0] = 1;
     tiers.permille[1] = 500; tiers.lanes[1] = 4;
     tiers.permille[2] = 800; tiers.lanes[2] = 16;
+  } else {  // the shipped default
+    tiers.permille[0] = 60; tiers.lanes[0] = 4;
   }
   ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
-  if (variant == 3 || variant == 4) {  // persistent phase 2 (variant 4: tiny ring)
-    const uint32_t chunks = (uint32_t)((nq + 64 + ptk::kP2Chunk - 1) / ptk::kP2Chunk) + 1;
-    if (variant == 3)
-      for_each_wave(chunks, [&] {
-        ptk::knn1_phase2_persistent_kernel<16, 2048>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
-      });
-    else
-      for_each_wave(chunks, [&] {
-        ptk::knn1_phase2_persistent_kernel<4, 2048>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
-      });
-    return (int)meta[0];
-  }
   const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
   gridDim.x = blocks;
   blockDim.x = 64;
@@ -425,7 +365,7 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     blockIdx.x = b;
     for (uint32_t l = 0; l < 64; ++l) {
       threadIdx.x = l;
-      if (variant == 2)
+      if (variant == 2 || variant == 4)
         ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
       else
         ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data());

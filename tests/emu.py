@@ -26,8 +26,6 @@ def _lib():
     lib.emu_radius_count.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_void_p]
     lib.emu_radius_fill.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_void_p,
                                     c_void_p, c_int]
-    lib.emu_persistent.argtypes = [c_void_p, c_int, c_void_p, c_uint64, c_uint32, c_float, c_float, c_void_p,
-                                   c_uint32, c_int, c_int, c_void_p, c_void_p, c_void_p]
     lib.emu_knn1_two_phase.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_int, c_void_p]
     lib.emu_morton.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
     return lib
@@ -75,29 +73,6 @@ class EmulatedTree:
         return off, out
 
     # -- persistent (state machine + lane refill) kernels: 64 host threads per wavefront --
-    def persistent_knn(self, q, k, e=None, perm=None, chunk=256, small_stack=False, list_in_lds=True):
-        q = np.ascontiguousarray(q, dtype=np.float32)
-        out = np.zeros((len(q), k), dtype=pt.NEIGHBOR)
-        rc = self.lib.emu_persistent(self.h, 0, q.ctypes.data, len(q), k, 0.0, e or 1.0,
-                                     perm.ctypes.data if perm is not None else None, chunk,
-                                     int(small_stack), int(list_in_lds), None, None, out.ctypes.data)
-        assert rc == 0
-        return out
-
-    def persistent_radius(self, q, radius, sort=False, e=None, perm=None, chunk=256):
-        q = np.ascontiguousarray(q, dtype=np.float32)
-        nq = len(q)
-        p = perm.ctypes.data if perm is not None else None
-        counts = np.zeros(nq + 1, dtype=np.uint64)
-        self.lib.emu_persistent(self.h, 1, q.ctypes.data, nq, 0, radius, e or 1.0, p, chunk, 0, 0,
-                                counts.ctypes.data, None, None)
-        off = np.zeros(nq + 1, dtype=np.uint64)
-        off[1:] = np.cumsum(counts[:nq])
-        out = np.zeros(int(off[-1]), dtype=pt.NEIGHBOR)
-        self.lib.emu_persistent(self.h, 2, q.ctypes.data, nq, 0, radius, e or 1.0, p, chunk, 0, 0,
-                                None, off.ctypes.data, out.ctypes.data)
-        return off, out
-
     def search_box(self, mins, maxs):
         from ctypes import c_uint64, c_void_p
         mins = np.ascontiguousarray(mins, dtype=np.float32)

@@ -97,30 +97,6 @@ def test_emulated_any_dimension_kernels_equal_oracle(dim, n, nq, radius):
     assert off[-1] > 0 and np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
 
 
-@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "lidar", "root-is-leaf", "dim2")],
-                         ids=lambda c: c[0])
-def test_emulated_persistent_machine_equals_oracle(case):
-    """The persistent kernels (per-lane state machine, ballot-based lane refill): the 64
-    lanes of a wavefront run as cooperative fibers so that __ballot is a real rendezvous."""
-    _, pts, q, leaf, radius = case
-    q = q[:700]
-    emu = EmulatedTree(pts, leaf)
-    ref = oracle.Oracle(pts, leaf, "port")
-    perm, _ = emu.morton_permutation(q)
-    for k in (1, 5):
-        if k > len(pts):
-            continue
-        want = ref.search_knn(q, k)
-        for small_stack, list_in_lds, p, chunk in ((False, True, None, 64), (True, False, perm, 200),
-                                                   (False, True, perm, 1024)):
-            got = emu.persistent_knn(q, k, perm=p, chunk=chunk, small_stack=small_stack,
-                                     list_in_lds=list_in_lds)
-            assert got.tobytes() == want.tobytes()
-    off, flat = ref.search_radius(q, radius)
-    goff, gflat = emu.persistent_radius(q, radius, perm=perm, chunk=100)
-    assert np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
-
-
 def test_morton_keys_follow_the_curve():
     pts = ds.uniform_cloud(5_000, 3, 3)
     emu = EmulatedTree(pts, 10)
@@ -137,21 +113,22 @@ def test_morton_keys_follow_the_curve():
 @pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "self", "lidar", "root-is-leaf",
                                                                   "dim2", "leaf1")],
                          ids=lambda c: c[0])
-def test_emulated_refill_phase2_equals_oracle(case):
-    """Two-phase k = 1 search with the refill phase 2 (persistent waves, ballot-compacted work
-    queue, per-lane state machine): variant 5 = shipped geometry, 6 = 4-slot ring (every record
-    takes the spill path), one-point leaf batches and a refill whenever a single lane is idle."""
+def test_emulated_two_phase_knn1_equals_oracle(case):
+    """The two-phase k = 1 search in every compiled form: LDS-ring / double-descent / tiny-ring
+    phase 1 (variants 0-2), the shipped wave-uniform-prefix phase 1 that packs the records itself
+    (3), and that form with one-point leaf batches, 4-slot rings and three narrow tiers of 1, 4 and
+    16 lanes per wavefront (4)."""
     _, pts, q, leaf, _ = case
     q = q[:1500]
     emu = EmulatedTree(pts, leaf)
     ref = oracle.Oracle(pts, leaf, "port")
     perm, _ = emu.morton_permutation(q)
     want = ref.search_knn(q, 1)
-    for variant in (5, 6, 7, 8):  # 7 / 8: wave-uniform-prefix phase 1 + refill / class-sorted phase 2
+    for variant in (0, 1, 2, 3, 4):
         for p in (None, perm):
             got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
             assert got.tobytes() == want.tobytes()
-    got, _ = emu.two_phase_knn1(q, e=1.4, perm=perm, variant=5)
+    got, _ = emu.two_phase_knn1(q, e=1.4, perm=perm, variant=3)
     assert got.tobytes() == ref.search_knn(q, 1, e=1.4).tobytes()
 
 
