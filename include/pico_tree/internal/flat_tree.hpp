@@ -23,6 +23,7 @@
 #include <array>
 #include <cassert>
 #include <cstdint>
+#include <future>
 #include <limits>
 #include <type_traits>
 #include <vector>
@@ -237,7 +238,10 @@ class flat_builder {
   flat_builder(SpaceView_ const& space, size_t stop_value, tree_type& out)
       : space_(space), stop_(static_cast<Index_>(stop_value)), tree_(out) {}
 
-  void run(box_type const& start_bounds) {
+  //! \param threads > 1: the two subtrees of the top levels are built concurrently (each into
+  //! its own node array, spliced back in depth-first order).  The result does not depend on it:
+  //! every std::partition / std::nth_element call sees the same range in the same state.
+  void run(box_type const& start_bounds, unsigned threads = 1) {
     size_t const n = space_.size();
     assert(n > 0);
     tree_.indices.resize(n);
@@ -249,8 +253,10 @@ class flat_builder {
                             ? 4 * n / static_cast<size_t>(stop_ > 0 ? stop_ : 1) + 16
                             : 1024);
     box_type work = start_bounds;
-    Index_* const base = tree_.indices.data();
-    grow(0, base, base + n, work);
+    index_base_ = tree_.indices.data();
+    int levels = 0;  // levels of the tree whose children are separate tasks: 2^levels >= 2 * threads
+    while (threads > 1 && (1u << levels) < 2 * threads && levels < 12) ++levels;
+    grow(0, index_base_, index_base_ + n, work, levels);
   }
 
  private:
@@ -304,7 +310,26 @@ class flat_builder {
     }
   }
 
-  std::uint32_t grow(std::uint32_t depth, Index_* begin, Index_* end, box_type& box) {
+  //! Ranges below this many points are not worth a task.
+  static constexpr std::ptrdiff_t kParallelMin = 20000;
+
+  //! Appends the nodes of a separately built subtree; its right-child links are relative to its
+  //! own first node.
+  void splice(tree_type const& sub) {
+    std::uint32_t const base = static_cast<std::uint32_t>(tree_.nodes.size());
+    for (auto nd : sub.nodes) {
+      if (nd.right != flat_leaf_tag) nd.right += base;
+      tree_.nodes.push_back(nd);
+    }
+    if (tree_.keep_outer_bounds)
+      tree_.outer_bounds.insert(tree_.outer_bounds.end(), sub.outer_bounds.begin(), sub.outer_bounds.end());
+    tree_.max_depth = std::max(tree_.max_depth, sub.max_depth);
+    tree_.leaf_count += sub.leaf_count;
+    tree_.max_leaf_points = std::max(tree_.max_leaf_points, sub.max_leaf_points);
+  }
+
+  std::uint32_t grow(
+      std::uint32_t depth, Index_* begin, Index_* end, box_type& box, int task_levels = 0) {
     std::uint32_t const self = static_cast<std::uint32_t>(tree_.nodes.size());
     tree_.nodes.emplace_back();
     if (tree_.keep_outer_bounds) tree_.outer_bounds.push_back({scalar_type(0), scalar_type(0)});
@@ -312,8 +337,8 @@ class flat_builder {
 
     if (stops(depth, begin, end)) {
       auto& leaf = tree_.nodes[self];
-      leaf.begin = static_cast<Index_>(begin - tree_.indices.data());
-      leaf.end = static_cast<Index_>(end - tree_.indices.data());
+      leaf.begin = static_cast<Index_>(begin - index_base_);
+      leaf.end = static_cast<Index_>(end - index_base_);
       leaf.right = flat_leaf_tag;
       leaf.split_dim = 0;
       ++tree_.leaf_count;
@@ -337,8 +362,26 @@ class flat_builder {
     box.max(axis) = plane;    // `box` now bounds the left child
     right.min(axis) = plane;
 
-    grow(depth + 1, begin, cut, box);  // lands at self + 1
-    std::uint32_t const r = grow(depth + 1, cut, end, right);
+    std::uint32_t r;
+    if (task_levels > 0 && (end - begin) >= kParallelMin) {
+      // Left subtree in another thread, right subtree here, each into its own tree object.
+      size_t const sdim = tree_.root_box.size();
+      tree_type lt(sdim), rt(sdim);
+      lt.keep_outer_bounds = rt.keep_outer_bounds = tree_.keep_outer_bounds;
+      flat_builder lb(space_, static_cast<size_t>(stop_), lt), rb(space_, static_cast<size_t>(stop_), rt);
+      lb.index_base_ = rb.index_base_ = index_base_;
+      auto left_done = std::async(std::launch::async, [&] {
+        lb.grow(depth + 1, begin, cut, box, task_levels - 1);
+      });
+      rb.grow(depth + 1, cut, end, right, task_levels - 1);
+      left_done.get();
+      splice(lt);  // lands at self + 1
+      r = static_cast<std::uint32_t>(tree_.nodes.size());
+      splice(rt);
+    } else {
+      grow(depth + 1, begin, cut, box);  // lands at self + 1
+      r = grow(depth + 1, cut, end, right);
+    }
 
     auto& branch = tree_.nodes[self];  // taken after the recursion: vector may grow
     branch.left_max = box.max(axis);   // both tightened by the children
@@ -354,6 +397,7 @@ class flat_builder {
   SpaceView_ const& space_;
   Index_ stop_;
   tree_type& tree_;
+  Index_* index_base_ = nullptr;  //!< first element of the (shared) index permutation
 };
 
 //! Entry point: build with the given parameters.
@@ -363,7 +407,8 @@ flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_
     splitter_stop_condition_t<Stop_> const& stop,
     splitter_start_bounds_t<Bounds_> const& bounds,
     splitter_rule_t<Rule_> const&,
-    bool keep_outer_bounds = false) {
+    bool keep_outer_bounds = false,
+    unsigned threads = 1) {
   using scalar_type = typename SpaceView_::scalar_type;
   using tree_type = flat_tree<Index_, scalar_type, SpaceView_::dim>;
   using box_type = typename tree_type::box_type;
@@ -381,7 +426,7 @@ flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_
 
   tree_type tree(sdim);
   tree.keep_outer_bounds = keep_outer_bounds;
-  flat_builder<SpaceView_, Index_, Rule_, Stop_>(space, stop.derived().value, tree).run(start);
+  flat_builder<SpaceView_, Index_, Rule_, Stop_>(space, stop.derived().value, tree).run(start, threads);
   return tree;
 }
 

@@ -141,6 +141,17 @@ struct DeviceGuard {
   }
 };
 
+int env_int(const char* name, int fallback);  // defined with the launch helpers below
+
+// Host threads for the tree build (the result does not depend on it): PTK_BUILD_THREADS, else the
+// hardware concurrency capped at 32.
+unsigned build_threads() {
+  const int v = env_int("PTK_BUILD_THREADS", 0);
+  if (v > 0) return (unsigned)v;
+  const unsigned hc = std::thread::hardware_concurrency();
+  return hc == 0 ? 1u : (hc > 32u ? 32u : hc);
+}
+
 int analyse(ptk_tree& t) {
   ptk::TreeStats st;
   std::string err = ptk::analyse_stream(t.dim, t.n_points, t.nodes.data(), t.nodes.size(), st, nullptr);
@@ -186,18 +197,41 @@ int upload(ptk_tree& t, const float* points) {
   ptk::TreeStats st;
   ptk::EncodedTree enc;
   bool unsupported = false;
-  std::string err = ptk::encode_tree(t.dim, t.n_points, points, t.nodes.data(), t.nodes.size(),
-                                     t.indices.data(), st, enc, unsupported);
+  // Branch records and references on the host; the 16-byte point records are gathered on the
+  // device from the raw points and the leaf-order permutation (no host pass over the points).
+  static_assert(ptk::kEncLeafAlign == 1, "encode_points_kernel assumes packed leaves");
+  std::string err = ptk::encode_tree(t.dim, t.n_points, nullptr, t.nodes.data(), t.nodes.size(),
+                                     t.indices.data(), st, enc, unsupported, /*with_points=*/false);
   if (!err.empty()) return fail(unsupported ? PTK_ERR_UNSUPPORTED : PTK_ERR_INVALID, "%s", err.c_str());
+  for (int32_t idx : t.indices)
+    if (idx < 0 || (uint64_t)idx >= t.n_points) return fail(PTK_ERR_INVALID, "index out of range in the permutation");
 
   static_assert(sizeof(ptk::EncNode) == sizeof(uint4) && sizeof(ptk::EncPoint) == sizeof(float4), "records");
+  const size_t n_records = t.n_points + ptk::kEncLeafPad;
   PTK_HIP(hipMalloc(&t.d_nodes, enc.nodes.size() * sizeof(uint4)));
-  PTK_HIP(hipMalloc(&t.d_pts, enc.points.size() * sizeof(float4)));
+  PTK_HIP(hipMalloc(&t.d_pts, n_records * sizeof(float4)));
   PTK_HIP(hipMemcpy(t.d_nodes, enc.nodes.data(), enc.nodes.size() * sizeof(uint4), hipMemcpyHostToDevice));
-  PTK_HIP(hipMemcpy(t.d_pts, enc.points.data(), enc.points.size() * sizeof(float4), hipMemcpyHostToDevice));
+  {
+    float* d_raw = nullptr;
+    int32_t* d_idx = nullptr;
+    const size_t raw_bytes = (size_t)t.n_points * t.dim * sizeof(float);
+    hipError_t he = hipMalloc((void**)&d_raw, raw_bytes);
+    if (he == hipSuccess) he = hipMalloc((void**)&d_idx, t.n_points * sizeof(int32_t));
+    if (he == hipSuccess) he = hipMemcpy(d_raw, points, raw_bytes, hipMemcpyHostToDevice);
+    if (he == hipSuccess) he = hipMemcpy(d_idx, t.indices.data(), t.n_points * sizeof(int32_t), hipMemcpyHostToDevice);
+    if (he == hipSuccess) {
+      const uint32_t blocks = (uint32_t)((n_records + ptk::kBlock - 1) / ptk::kBlock);
+      hipLaunchKernelGGL(ptk::encode_points_kernel, dim3(blocks), dim3(ptk::kBlock), 0, nullptr, d_raw, t.dim, d_idx,
+                         t.n_points, static_cast<float4*>(t.d_pts));
+      he = hipDeviceSynchronize();
+    }
+    if (d_raw) (void)hipFree(d_raw);
+    if (d_idx) (void)hipFree(d_idx);
+    if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error while encoding the points: %s", hipGetErrorString(he));
+  }
   PTK_HIP(hipMalloc(&t.d_ranges, enc.ranges.size() * sizeof(ptk::EncRange)));
   PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), enc.ranges.size() * sizeof(ptk::EncRange), hipMemcpyHostToDevice));
-  t.device_bytes = enc.nodes.size() * sizeof(uint4) + enc.points.size() * sizeof(float4) +
+  t.device_bytes = enc.nodes.size() * sizeof(uint4) + n_records * sizeof(float4) +
                    enc.ranges.size() * sizeof(ptk::EncRange);
   t.dev.nodes = static_cast<const uint4*>(t.d_nodes);
   t.dev.pts = static_cast<const float4*>(t.d_pts);
@@ -773,7 +807,7 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
     space_t space(points, n_points, dim);
     internal::space_view<space_t> view(space);
     auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
-                                               sliding_midpoint_max_side);
+                                               sliding_midpoint_max_side, false, build_threads());
     t->dim = dim;
     t->n_points = n_points;
     t->nodes.resize(flat.nodes.size());
@@ -1297,7 +1331,7 @@ int forest_build(ptk_forest* f, const float* points, uint64_t max_leaf_size, uin
     float* r = f->rotations.data() + (size_t)ti * dim;
     ptk::reflection_vector(seed, ti, dim, r);
     ptk::ForestTreeHost host;
-    std::string err = ptk::build_forest_tree(points, n, dim, max_leaf_size, r, rotated, host);
+    std::string err = ptk::build_forest_tree(points, n, dim, max_leaf_size, r, rotated, host, build_threads());
     if (!err.empty()) return fail(PTK_ERR_UNSUPPORTED, "tree %u: %s", ti, err.c_str());
     std::vector<float> rot(r, r + dim);
     int rc = forest_upload(f, host.nodes, &trees[ti].nodes);

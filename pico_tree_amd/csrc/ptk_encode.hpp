@@ -125,7 +125,9 @@ inline std::string analyse_stream(
 // does not fit the 32-bit reference encoding.
 inline std::string encode_tree(
     uint32_t dim, uint64_t n_points, const float* points, const ptk_node* nodes, uint64_t n_nodes,
-    const int32_t* indices, TreeStats& st, EncodedTree& out, bool& unsupported) {
+    const int32_t* indices, TreeStats& st, EncodedTree& out, bool& unsupported, bool with_points = true) {
+  // with_points = false: the caller fills the point records itself (the backend gathers them on
+  // the device: encode_points_kernel); `points` may then be null.
   unsupported = false;
   if (dim == 0 || dim > 3) {
     unsupported = true;
@@ -175,8 +177,9 @@ inline std::string encode_tree(
     r.right_ref = ref_of(nd.right);
     out.nodes[branch_id[i]] = r;
   }
-  out.points.assign(n_slots + kEncLeafPad, EncPoint{0.0f, 0.0f, 0.0f, 0});
-  for (uint64_t i = 0; i < n_nodes; ++i) {
+  out.points.clear();
+  if (with_points) out.points.assign(n_slots + kEncLeafPad, EncPoint{0.0f, 0.0f, 0.0f, 0});
+  for (uint64_t i = 0; i < n_nodes && with_points; ++i) {
     const ptk_node& nd = nodes[i];
     if (nd.right != PTK_LEAF) continue;
     const uint64_t count = nd.b - nd.a;
@@ -195,7 +198,7 @@ inline std::string encode_tree(
       out.points[leaf_pos[i] + j] = v;
     }
   }
-  for (uint32_t i = 0; i < kEncLeafPad; ++i) out.points[n_slots + i] = out.points[n_slots ? n_slots - 1 : 0];
+  for (uint32_t i = 0; i < kEncLeafPad && with_points; ++i) out.points[n_slots + i] = out.points[n_slots ? n_slots - 1 : 0];
   // Subtree ranges: children come later in the stream, so one backward pass suffices.
   static_assert(kEncLeafAlign == 1, "subtree ranges assume leaves are packed without gaps");
   {

@@ -57,7 +57,8 @@ inline void reflection_vector(uint64_t seed, uint32_t tree, uint32_t dim, float*
 // Builds one tree over the points reflected by r (`rotated` is scratch of n * dim floats).
 // Returns an empty string or an error message.
 inline std::string build_forest_tree(const float* points, uint64_t n, uint32_t dim, uint64_t max_leaf_size,
-                                     const float* r, std::vector<float>& rotated, ForestTreeHost& out) {
+                                     const float* r, std::vector<float>& rotated, ForestTreeHost& out,
+                                     unsigned threads = 1) {
   using namespace pico_tree;
   using space_t = space_map<point_map<float const, dynamic_extent>>;
   rotated.resize(n * dim);
@@ -73,7 +74,7 @@ inline std::string build_forest_tree(const float* points, uint64_t n, uint32_t d
   space_t space(rotated.data(), n, dim);
   internal::space_view<space_t> view(space);
   auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
-                                             sliding_midpoint_max_side, /*keep_outer_bounds=*/true);
+                                             sliding_midpoint_max_side, /*keep_outer_bounds=*/true, threads);
   if (flat.max_depth >= kForestPath)
     return "forest tree is " + std::to_string(flat.max_depth) + " levels deep (limit " +
            std::to_string(kForestPath - 1) + ")";

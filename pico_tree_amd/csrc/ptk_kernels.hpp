@@ -1231,6 +1231,19 @@ __global__ __launch_bounds__(kBlock) void sort_rows_kernel(
   }
 }
 
+// Point records of the device tree: pts[pos] = {point indices[pos], bits(indices[pos])} in leaf
+// order, the kLeafPad records behind the last point repeat it (see ptk_encode.hpp).
+__global__ __launch_bounds__(kBlock) void encode_points_kernel(
+    const float* __restrict__ points, uint32_t dim, const int32_t* __restrict__ indices, uint64_t n,
+    float4* __restrict__ pts) {
+  const uint64_t pos = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (pos >= n + kLeafPad) return;
+  const int32_t idx = indices[pos < n ? pos : n - 1];
+  float x, y, z;
+  load_query(points, dim, (uint64_t)idx, x, y, z);
+  pts[pos] = make_float4(x, y, z, __int_as_float(idx));
+}
+
 // ---- batch ordering ------------------------------------------------------------------------
 // 30-bit Morton key of each query inside the tree's root box (clamped), plus the
 // identity permutation to be sorted along with it.

@@ -145,3 +145,28 @@ def test_tree_stream_round_trip_on_a_host_only_handle():
                                            byref(h3)) == -1  # truncated
     for x in (h, h2):
         lib.ptk_tree_destroy(x)
+
+
+def test_threaded_build_gives_the_identical_tree(monkeypatch):
+    """PTK_BUILD_THREADS only changes who builds which subtree: same nodes, same permutation."""
+    from ctypes import byref, c_void_p
+
+    from pico_tree_amd import datasets as ds
+
+    lib = pt._load()
+    pts = np.concatenate([ds.lidar_cloud(150_000, 1), ds.lidar_cloud(50_000, 1)])  # with exact duplicates
+    flats = []
+    for threads in ("1", "3", "8"):
+        monkeypatch.setenv("PTK_BUILD_THREADS", threads)
+        h = c_void_p()
+        assert lib.ptk_tree_create_from_points(pts.ctypes.data, len(pts), 3, 10, pt.PTK_DEVICE_NONE, byref(h)) == 0
+        inf = pt._Info()
+        assert lib.ptk_tree_get_info(h, byref(inf)) == 0
+        nodes = np.empty((inf.n_nodes, 4), dtype=np.uint32)
+        idx = np.empty(len(pts), dtype=np.int32)
+        assert lib.ptk_tree_get_flat(h, nodes.ctypes.data, idx.ctypes.data, None, None) == 0
+        flats.append((nodes, idx, inf.max_depth, inf.n_leaves))
+        lib.ptk_tree_destroy(h)
+    for other in flats[1:]:
+        assert np.array_equal(other[0], flats[0][0]) and np.array_equal(other[1], flats[0][1])
+        assert other[2:] == flats[0][2:]
