@@ -229,6 +229,10 @@ int ptk_forest_create(const float* points, uint64_t n_points, uint32_t dim,
                       uint64_t seed, int32_t device, ptk_forest** out);
 void ptk_forest_destroy(ptk_forest* forest);
 
+/* Queue entries dropped so far because a query's per-tree queue (1024 nodes) was full: a
+ * dropped node is simply never searched (the result stays a valid approximate answer). */
+int ptk_forest_get_dropped(const ptk_forest* forest, uint64_t* dropped);
+
 /* The unit reflection vectors in use: forest_size x dim floats. */
 int ptk_forest_get_rotations(const ptk_forest* forest, float* out);
 

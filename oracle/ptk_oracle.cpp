@@ -708,7 +708,8 @@ float ptkor_l2sq_scalar(float x) { return x * x; }
 //   .../internal/rkd_tree_hh_data.hpp:56-90 (Householder reflection)
 // with the two differences the product documents (pico_tree_amd/csrc/ptk_forest.hpp): the shared
 // k-list is de-duplicated by index and point distances are measured in the original space; the
-// queue orders equal distances by DFS stream position and holds at most kForestQueue nodes.
+// queue orders equal distances by (branch before leaf, DFS stream position) and holds at most
+// kForestQueue nodes.
 // Reflection vectors are INPUTS (the product reports the ones it drew).
 }  // extern "C"
 
@@ -798,7 +799,9 @@ struct forest_query {
     while (!queue.empty()) {
       size_t best = 0;
       for (size_t i = 1; i < queue.size(); ++i) {
-        if (queue[i].d < queue[best].d || (queue[i].d == queue[best].d && queue[i].node->id < queue[best].node->id))
+        // Equal distances: branches before leaves, then depth-first (stream) order.
+        auto const rank = [](node_t const* n) { return std::make_pair(n->is_leaf(), n->id); };
+        if (queue[i].d < queue[best].d || (queue[i].d == queue[best].d && rank(queue[i].node) < rank(queue[best].node)))
           best = i;
       }
       entry const top = queue[best];

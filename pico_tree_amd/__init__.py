@@ -99,6 +99,7 @@ _SIGNATURES = {
                                   POINTER(c_void_p)]),
     "ptk_forest_destroy": (None, [c_void_p]),
     "ptk_forest_get_rotations": (c_int, [c_void_p, c_void_p]),
+    "ptk_forest_get_dropped": (c_int, [c_void_p, POINTER(c_uint64)]),
     "ptk_forest_search_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint64, c_void_p]),
     "ptk_forest_search_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_uint64, c_void_p,
                                              c_void_p]),
@@ -591,6 +592,13 @@ class KdForest:
         _check(_load().ptk_forest_search_knn(self._h, q.ctypes.data, q.shape[0], k, int(max_leaves_visited),
                                              out.ctypes.data))
         return out
+
+    @property
+    def dropped(self) -> int:
+        """Queue entries dropped so far because a per-tree queue was full (0 in normal use)."""
+        v = c_uint64()
+        _check(_load().ptk_forest_get_dropped(self._h, byref(v)))
+        return int(v.value)
 
     def search_nn(self, pts, max_leaves_visited: int):
         """``(nq,)`` nearest neighbours (kd_forest.hpp:78-85)."""

@@ -1369,7 +1369,7 @@ int ptk_forest_create(const float* points, uint64_t n_points, uint32_t dim, uint
   if (dim == 0 || n_points == 0 || max_leaf_size == 0 || forest_size == 0)
     return fail(PTK_ERR_INVALID, "dim, n_points, max_leaf_size and forest_size must be positive");
   if (n_points >= (1ull << 31)) return fail(PTK_ERR_INVALID, "n_points must be < 2^31");
-  const size_t lds = ((size_t)2 * dim + 3 * ptk::kForestQueue + 3 * ptk::kForestPath) * 4;
+  const size_t lds = ((size_t)2 * dim + 2 * ptk::kForestQueue + 2 * ptk::kForestPath) * 4;
   if (lds > 64 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the forest kernel's LDS", dim);
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PTK_ERR_DEVICE, "no HIP device is visible");
@@ -1407,6 +1407,15 @@ void ptk_forest_destroy(ptk_forest* f) {
   delete f;
 }
 
+int ptk_forest_get_dropped(const ptk_forest* f, uint64_t* dropped) {
+  if (f == nullptr || dropped == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  DeviceGuard guard(f->device);
+  uint32_t v = 0;
+  PTK_HIP(hipMemcpy(&v, f->d_dropped, 4, hipMemcpyDeviceToHost));
+  *dropped = v;
+  return PTK_OK;
+}
+
 int ptk_forest_get_rotations(const ptk_forest* f, float* out) {
   if (f == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   std::memcpy(out, f->rotations.data(), f->rotations.size() * sizeof(float));
@@ -1422,7 +1431,7 @@ int ptk_forest_search_knn_device(const ptk_forest* f, const float* d_q, uint64_t
   if (nq >= (1ull << 31)) return fail(PTK_ERR_UNSUPPORTED, "too many queries for one launch");
   DeviceGuard guard(f->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", f->device);
-  const size_t lds = ((size_t)2 * f->dim + 3 * ptk::kForestQueue + 3 * ptk::kForestPath) * 4;
+  const size_t lds = ((size_t)2 * f->dim + 2 * ptk::kForestQueue + 2 * ptk::kForestPath) * 4;
   const uint32_t leaves = max_leaves_visited > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)max_leaves_visited;
   hipLaunchKernelGGL((ptk::forest_knn_kernel<64>), dim3((uint32_t)nq), dim3(64), lds, static_cast<hipStream_t>(stream),
                      f->dev, d_q, nq, k, leaves, reinterpret_cast<ptk::Neighbor*>(d_out), f->d_dropped);

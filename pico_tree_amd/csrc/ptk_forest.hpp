@@ -17,8 +17,8 @@
 //     the same quantity without the per-tree rounding noise) -- which also means only ONE copy of
 //     the points is kept in HBM (512 MB for SIFT-1M) instead of one rotated copy per tree (4.1 GB):
 //     the trees keep their split bounds in reflected coordinates plus an index permutation.
-// Ties between queued nodes of equal distance are broken by the node's position in the DFS
-// stream (the reference compares node addresses there, which is unspecified).
+// Ties between queued nodes of equal distance are broken by the node reference (branches before
+// leaves, then depth-first order; the reference compares node addresses there, which is unspecified).
 // The reference draws its reflection vectors from std::random_device; here they are given by the
 // caller (libptk derives them from a seed), so a forest is reproducible.
 //
@@ -60,7 +60,7 @@ constexpr float kFltMax = 3.402823466e+38f;
 
 __device__ __forceinline__ float wave_shfl(float v, int lane) { return __shfl(v, lane); }
 
-// LDS of a block: q[dim] | qr[dim] | queue_d[Q] | queue_ref[Q] | queue_id[Q] | path_d[P] | path_ref[P] | path_id[P]
+// LDS of a block: q[dim] | qr[dim] | queue_d[Q] | queue_ref[Q] | path_d[P] | path_ref[P]
 template <int KMAX>
 __global__ __launch_bounds__(64) void forest_knn_kernel(
     ForestDev f, const float* __restrict__ queries, uint64_t nq, uint32_t k, uint32_t max_leaves,
@@ -74,10 +74,8 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
   PTK_LDS float* qr = q + dim;
   PTK_LDS float* queue_d = qr + dim;
   PTK_LDS uint32_t* queue_ref = (PTK_LDS uint32_t*)(queue_d + kForestQueue);
-  PTK_LDS uint32_t* queue_id = queue_ref + kForestQueue;
-  PTK_LDS float* path_d = (PTK_LDS float*)(queue_id + kForestQueue);
+  PTK_LDS float* path_d = (PTK_LDS float*)(queue_ref + kForestQueue);
   PTK_LDS uint32_t* path_ref = (PTK_LDS uint32_t*)(path_d + kForestPath);
-  PTK_LDS uint32_t* path_id = path_ref + kForestPath;
 
   for (uint32_t a = lane; a < dim; a += 64) q[a] = queries[qi * dim + a];
   __syncthreads();
@@ -101,45 +99,42 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
     if (lane == 0) {
       queue_d[0] = 0.0f;
       queue_ref[0] = t.root_ref;
-      queue_id[0] = 0u;
     }
     __syncthreads();
     uint32_t leaves_visited = 0;
 
     while (qn > 0) {
-      // ---- extract-min over (distance, stream id) ----
+      // ---- extract-min over (distance, reference) ----
       float bd = kFltMax;
-      uint32_t bid = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
+      uint32_t bref = 0xFFFFFFFFu, bpos = 0xFFFFFFFFu;
       for (uint32_t p = lane; p < qn; p += 64) {
         const float d = queue_d[p];
-        const uint32_t id = queue_id[p];
-        if (d < bd || (d == bd && id < bid)) {
+        const uint32_t r = queue_ref[p];
+        if (d < bd || (d == bd && r < bref)) {
           bd = d;
-          bid = id;
+          bref = r;
           bpos = p;
         }
       }
 #pragma unroll
       for (int off = 32; off >= 1; off >>= 1) {
         const float od = __shfl_xor(bd, off);
-        const uint32_t oid = (uint32_t)__shfl_xor((int)bid, off);
+        const uint32_t oref = (uint32_t)__shfl_xor((int)bref, off);
         const uint32_t opos = (uint32_t)__shfl_xor((int)bpos, off);
-        if (od < bd || (od == bd && oid < bid)) {
+        if (od < bd || (od == bd && oref < bref)) {
           bd = od;
-          bid = oid;
+          bref = oref;
           bpos = opos;
         }
       }
       if (leaves_visited >= max_leaves || worst < bd) break;  // priority_search:55-58
-      uint32_t ref = queue_ref[bpos];
-      uint32_t id = bid;
+      uint32_t ref = bref;
       float nbd = bd;
       __syncthreads();
       --qn;
       if (lane == 0 && bpos != qn) {  // fill the hole with the last entry
         queue_d[bpos] = queue_d[qn];
         queue_ref[bpos] = queue_ref[qn];
-        queue_id[bpos] = queue_id[qn];
       }
       __syncthreads();
 
@@ -149,30 +144,25 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
         const ForestNode nd = t.nodes[uniform_value(ref)];
         const float v = qr[nd.split_dim];
         float old_off, new_off;
-        uint32_t far_ref, far_id;
+        uint32_t far_ref;
         if (f_sub(f_sub(f_add(nd.left_max, nd.right_min), v), v) > 0.0f) {  // priority_search:97
           far_ref = nd.right_ref;
-          far_id = nd.right_id;
           const float a = f_sub(nd.left_min, v);
           old_off = v > nd.left_min ? 0.0f : f_mul(a, a);
           const float b = f_sub(nd.right_min, v);
           new_off = f_mul(b, b);
           ref = nd.left_ref;
-          id = id + 1u;
         } else {
           far_ref = nd.left_ref;
-          far_id = id + 1u;
           const float a = f_sub(nd.right_max, v);
           old_off = v < nd.right_max ? 0.0f : f_mul(a, a);
           const float b = f_sub(nd.left_max, v);
           new_off = f_mul(b, b);
           ref = nd.right_ref;
-          id = nd.right_id;
         }
         if (depth < kForestPath && lane == 0) {
           path_d[depth] = f_add(f_sub(nbd, old_off), new_off);  // :123
           path_ref[depth] = far_ref;
-          path_id[depth] = far_id;
         }
         ++depth;
       }
@@ -265,7 +255,6 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
             if (lane == 0) {
               queue_d[qn] = d;
               queue_ref[qn] = path_ref[l];
-              queue_id[qn] = path_id[l];
             }
             ++qn;
           } else if (lane == 0 && dropped) {

@@ -22,7 +22,7 @@ struct ForestNode {
   float left_min, left_max, right_min, right_max;
   uint32_t left_ref, right_ref;  // bit 31 = leaf: (begin << cbits) | count; else branch index
   uint32_t split_dim;
-  uint32_t right_id;             // DFS-stream position of the right child (left = self + 1)
+  uint32_t reserved;
 };
 static_assert(sizeof(ForestNode) == 32, "forest node layout");
 
@@ -109,7 +109,7 @@ inline std::string build_forest_tree(const float* points, uint64_t n, uint32_t d
     o.left_ref = ref_of(i + 1);
     o.right_ref = ref_of(nd.right);
     o.split_dim = nd.split_dim;
-    o.right_id = nd.right;
+    o.reserved = 0;
     out.nodes[branch_id[i]] = o;
   }
   out.indices.assign(flat.indices.begin(), flat.indices.end());

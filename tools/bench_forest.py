@@ -83,7 +83,8 @@ def main():
            f"recall_at_{args.k}": round(recall(got["index"].reshape(args.nq, -1), exact, args.k), 4),
            "data": "synthetic (mixture of 1000 Gaussians, SIFT-like range)", "gen_s": round(gen_s, 1),
            "host_build_upload_s": round(build_s, 1),
-           "leaf_bytes_read_per_query": args.trees * args.leaves * args.leaf * args.dim * 4}
+           "leaf_bytes_read_per_query": args.trees * args.leaves * args.leaf * args.dim * 4,
+           "queue_entries_dropped": forest.dropped}
     out["hbm_gbs_leaf_scans"] = round(out["leaf_bytes_read_per_query"] * args.nq / (ms * 1e-3) / 1e9, 1)
     import oracle
     if oracle.have_reference_forest():
