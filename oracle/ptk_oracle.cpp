@@ -740,6 +740,29 @@ void reflect(std::vector<float> const& r, float const* x, float* y, size_t dim) 
   for (size_t i = 0; i < dim; ++i) y[i] = x[i] - (dot * r[i]);
 }
 
+// Point distance of the forest search, in the original space.  For dimensions that are a multiple
+// of 128 the product's wavefront reads a row with 64 lanes (lane l: elements 2l, 2l + 1 of every
+// 128-float segment) and adds the 64 partial sums in a fixed tree: pairs of lanes differing in
+// bit 5, then bit 4, ... bit 0.  Other dimensions: left to right like l2sq.
+inline float forest_l2sq(float const* q, float const* p, size_t dim) {
+  if (dim % 128 != 0) return l2sq(q, p, dim);
+  float s[64];
+  for (size_t l = 0; l < 64; ++l) {
+    float acc = 0.0f;
+    for (size_t m = 0; m < dim / 128; ++m) {
+      float const d0 = q[128 * m + 2 * l] - p[128 * m + 2 * l];
+      float const d1 = q[128 * m + 2 * l + 1] - p[128 * m + 2 * l + 1];
+      acc = acc + d0 * d0;
+      acc = acc + d1 * d1;
+    }
+    s[l] = acc;
+  }
+  for (size_t bit = 32; bit >= 1; bit >>= 1)
+    for (size_t l = 0; l < 64; ++l)
+      if ((l & bit) == 0) s[l] = s[l] + s[l | bit];
+  return s[0];
+}
+
 struct forest_query {
   forest_t const& f;
   float const* q;   // original space
@@ -768,7 +791,7 @@ struct forest_query {
     if (node->is_leaf()) {
       for (int i = node->data.leaf.begin_idx; i < node->data.leaf.end_idx; ++i) {
         int const idx = t.indices[static_cast<size_t>(i)];
-        visit(idx, l2sq(q, f.pts.data() + static_cast<size_t>(idx) * f.dim, f.dim));
+        visit(idx, forest_l2sq(q, f.pts.data() + static_cast<size_t>(idx) * f.dim, f.dim));
       }
       return;
     }

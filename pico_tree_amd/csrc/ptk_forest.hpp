@@ -24,8 +24,10 @@
 //
 // Mapping: ONE QUERY PER WAVEFRONT.  10 000 queries of 128 dimensions cannot feed one query per
 // lane (157 waves, a 10 KB queue per lane); the work is the leaf scans (32 points x 128 floats,
-// 512 leaves per query), so the 64 lanes measure one leaf together -- lane j takes point j and
-// streams its 512-byte row -- while the descent, the queue and the k-list are wave-uniform:
+// 512 leaves per query), so the 64 lanes measure one leaf together -- rows of 128 floats are read
+// by the whole wave, one coalesced 512-byte read per row, 16 rows in flight, and summed with a
+// transposing butterfly; other dimensions: lane j streams the row of point j -- while the
+// descent, the queue and the k-list are wave-uniform:
 //   * node records come through the scalar cache (uniform index -> s_load_dwordx8);
 //   * the queue lives in LDS; extract-min is a strided scan + a 6-step wave reduction;
 //   * the sorted k-list lives in REGISTERS, entry j in lane j (k <= 64): a candidate's rank is a
@@ -59,6 +61,12 @@ struct ForestDev {
 constexpr float kFltMax = 3.402823466e+38f;
 
 __device__ __forceinline__ float wave_shfl(float v, int lane) { return __shfl(v, lane); }
+// Value of `v` in lane `src`, for a wave-uniform `src`: one v_readlane instead of a trip through the
+// LDS crossbar (ds_bpermute).
+__device__ __forceinline__ int32_t lane_value(int32_t v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float lane_value(float v, int src) {
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
 
 // LDS of a block: q[dim] | qr[dim] | queue_d[Q] | queue_ref[Q] | path_d[P] | path_ref[P]
 template <int KMAX>
@@ -172,6 +180,76 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
         const uint32_t lv = ref & 0x7FFFFFFFu;
         const uint32_t begin = lv >> t.cbits;
         const uint32_t count = lv & t.cmask;
+        if ((dim & 127u) == 0u) {
+          // Rows of 128 * M floats: the WAVE reads one row at a time, lane l the two floats
+          // 2l, 2l + 1 of every 128-float segment (one coalesced 512-byte read per segment), 16
+          // rows in flight.  The 64 partial sums of a row are added in a fixed tree -- lanes
+          // pair up by bit 5 of the lane number, then bit 4, ... bit 0 -- which for 16 rows at
+          // once is a transposing butterfly: after the steps for bits 5..2 lane l holds the
+          // partial of row (l >> 2) & 15 only, so 17 shuffles serve 16 rows.  (The oracle adds in
+          // the same tree; see ptk_oracle.cpp, forest_l2sq.)
+          const uint32_t segs = dim >> 7;
+          for (uint32_t base = 0; base < count; base += 16) {
+            const uint32_t rows = count - base < 16u ? count - base : 16u;
+            const int32_t my_idx = lane < rows ? t.indices[begin + base + lane] : -1;
+            float part[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) part[r] = 0.0f;
+            for (uint32_t m = 0; m < segs; ++m) {
+              const float qa = q[128u * m + 2u * lane], qb = q[128u * m + 2u * lane + 1u];
+              float2 p[16];
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const int32_t ir = __shfl(my_idx, r);
+                p[r] = ir >= 0 ? *reinterpret_cast<const float2*>(f.points + (uint64_t)ir * dim + 128u * m + 2u * lane)
+                               : make_float2(qa, qb);
+              }
+#pragma unroll
+              for (int r = 0; r < 16; ++r) {
+                const float d0 = f_sub(qa, p[r].x), d1 = f_sub(qb, p[r].y);
+                part[r] = f_add(part[r], f_mul(d0, d0));
+                part[r] = f_add(part[r], f_mul(d1, d1));
+              }
+            }
+            const bool b5 = (lane & 32u) != 0, b4 = (lane & 16u) != 0, b3 = (lane & 8u) != 0, b2 = (lane & 4u) != 0;
+            float v8[8], v4[4], v2[2];
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+              v8[j] = f_add(b5 ? part[j + 8] : part[j], __shfl_xor(b5 ? part[j] : part[j + 8], 32));
+#pragma unroll
+            for (int j = 0; j < 4; ++j) v4[j] = f_add(b4 ? v8[j + 4] : v8[j], __shfl_xor(b4 ? v8[j] : v8[j + 4], 16));
+#pragma unroll
+            for (int j = 0; j < 2; ++j) v2[j] = f_add(b3 ? v4[j + 2] : v4[j], __shfl_xor(b3 ? v4[j] : v4[j + 2], 8));
+            float dist = f_add(b2 ? v2[1] : v2[0], __shfl_xor(b2 ? v2[0] : v2[1], 4));
+            dist = f_add(dist, __shfl_xor(dist, 2));
+            dist = f_add(dist, __shfl_xor(dist, 1));
+            // Row r of the chunk is now in lanes 4r .. 4r + 3; candidates enter in leaf order.  Only
+            // the rows that still beat max() cost an iteration (the test is re-evaluated after every
+            // insertion, as the reference's visitor does point by point).
+            bool pending = (lane & 3u) == 0u && (lane >> 2) < rows;
+            for (;;) {
+              const uint64_t m = __ballot(pending && worst > dist);  // search_visitor.hpp:107
+              if (m == 0ull) break;
+              const int src = __builtin_ctzll(m);
+              const float cd = lane_value(dist, src);
+              const int32_t ci = lane_value(my_idx, src >> 2);
+              if ((int)lane == src) pending = false;
+              if (__ballot(lane < filled && li == ci) != 0ull) continue;  // already listed
+              const uint32_t pos = (uint32_t)__popcll(__ballot(lane < filled && !(cd < ld)));
+              const float up_d = __shfl_up(ld, 1);
+              const int32_t up_i = __shfl_up(li, 1);
+              if (filled < k) ++filled;
+              if (lane > pos && lane < filled) {
+                ld = up_d;
+                li = up_i;
+              } else if (lane == pos && lane < filled) {
+                ld = cd;
+                li = ci;
+              }
+              worst = filled == k ? lane_value(ld, (int)k - 1) : kFltMax;
+            }
+          }
+        } else
         for (uint32_t base = 0; base < count; base += 64) {
           const bool has = base + lane < count;
           int32_t idx = -1;
@@ -223,8 +301,8 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
             const uint64_t m = __ballot(pending && worst > d);  // search_visitor.hpp:107
             if (m == 0ull) break;
             const int src = __builtin_ctzll(m);
-            const float cd = wave_shfl(d, src);
-            const int32_t ci = __shfl(idx, src);
+            const float cd = lane_value(d, src);
+            const int32_t ci = lane_value(idx, src);
             if ((int)lane == src) pending = false;
             if (__ballot(lane < filled && li == ci) != 0ull) continue;  // already listed
             // insert_sorted (search_visitor.hpp:24-38): behind every entry that is not larger.
@@ -239,7 +317,7 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
               ld = cd;
               li = ci;
             }
-            worst = filled == k ? wave_shfl(ld, (int)k - 1) : kFltMax;
+            worst = filled == k ? lane_value(ld, (int)k - 1) : kFltMax;
           }
         }
       }

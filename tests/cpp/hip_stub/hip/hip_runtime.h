@@ -18,6 +18,7 @@
 
 struct uint2 { uint32_t x, y; };
 struct uint4 { uint32_t x, y, z, w; };
+struct float2 { float x, y; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 struct dim3 { uint32_t x = 1, y = 1, z = 1; };
@@ -25,6 +26,7 @@ struct dim3 { uint32_t x = 1, y = 1, z = 1; };
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
 inline float3 make_float3(float x, float y, float z) { return float3{x, y, z}; }
 
 // One rounding per operation; the emulator is built with -ffp-contract=off.
@@ -55,6 +57,7 @@ inline int __shfl_up(int v, int delta) { const int l = emu_lane(); return emu_sh
 inline float __shfl_up(float v, int delta) { const int l = emu_lane(); return __shfl(v, l >= delta ? l - delta : l); }
 inline int __shfl_xor(int v, int mask) { return emu_shfl(v, emu_lane() ^ mask); }
 inline float __shfl_xor(float v, int mask) { return __shfl(v, emu_lane() ^ mask); }
+inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_shfl(v, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl(v, 0); }  // all lanes alive where it is used
 inline void __syncthreads() { (void)emu_ballot(false); }  // single-wave blocks only
 
