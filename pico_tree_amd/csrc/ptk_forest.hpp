@@ -68,6 +68,14 @@ __device__ __forceinline__ float lane_value(float v, int src) {
   return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+// Order of two queued nodes at EQUAL distance: branches before leaves, then depth-first stream
+// order (leaf references grow with it; branch records carry their stream position, fetched only
+// in this rare case).
+__device__ __forceinline__ bool queued_before(const ForestNode* nodes, uint32_t a, uint32_t b) {
+  if ((a | b) & kLeafBit) return a < b;
+  return a != b && nodes[a].stream_id < nodes[b].stream_id;
+}
+
 // LDS of a block: q[dim] | qr[dim] | queue_d[Q] | queue_ref[Q] | path_d[P] | path_ref[P]
 template <int KMAX>
 __global__ __launch_bounds__(64) void forest_knn_kernel(
@@ -118,7 +126,7 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
       for (uint32_t p = lane; p < qn; p += 64) {
         const float d = queue_d[p];
         const uint32_t r = queue_ref[p];
-        if (d < bd || (d == bd && r < bref)) {
+        if (d < bd || (d == bd && (bpos == 0xFFFFFFFFu || queued_before(t.nodes, r, bref)))) {
           bd = d;
           bref = r;
           bpos = p;
@@ -129,7 +137,8 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
         const float od = __shfl_xor(bd, off);
         const uint32_t oref = (uint32_t)__shfl_xor((int)bref, off);
         const uint32_t opos = (uint32_t)__shfl_xor((int)bpos, off);
-        if (od < bd || (od == bd && oref < bref)) {
+        if (opos != 0xFFFFFFFFu &&
+            (od < bd || (od == bd && (bpos == 0xFFFFFFFFu || queued_before(t.nodes, oref, bref))))) {
           bd = od;
           bref = oref;
           bpos = opos;
@@ -149,30 +158,44 @@ __global__ __launch_bounds__(64) void forest_knn_kernel(
       // ---- near-first descent to one leaf, recording the far children ----
       uint32_t depth = 0;
       while (!(ref & kLeafBit)) {
-        const ForestNode nd = t.nodes[uniform_value(ref)];
-        const float v = qr[nd.split_dim];
-        float old_off, new_off;
-        uint32_t far_ref;
-        if (f_sub(f_sub(f_add(nd.left_max, nd.right_min), v), v) > 0.0f) {  // priority_search:97
-          far_ref = nd.right_ref;
-          const float a = f_sub(nd.left_min, v);
-          old_off = v > nd.left_min ? 0.0f : f_mul(a, a);
-          const float b = f_sub(nd.right_min, v);
-          new_off = f_mul(b, b);
-          ref = nd.left_ref;
-        } else {
-          far_ref = nd.left_ref;
-          const float a = f_sub(nd.right_max, v);
-          old_off = v < nd.right_max ? 0.0f : f_mul(a, a);
-          const float b = f_sub(nd.left_max, v);
-          new_off = f_mul(b, b);
-          ref = nd.right_ref;
+        // One fetch per BLOCK of three levels (ptk_forest_host.hpp): lane s holds slot s, the steps
+        // inside the block read their record with v_readlane.
+        const uint32_t blk = uniform_value(ref) >> 3;
+        const ForestNode mine = t.nodes[blk * 8u + (lane & 7u)];
+        while (!(ref & kLeafBit) && (ref >> 3) == blk) {
+          const int slot = (int)(ref & 7u);
+          ForestNode nd;
+          nd.left_min = lane_value(mine.left_min, slot);
+          nd.left_max = lane_value(mine.left_max, slot);
+          nd.right_min = lane_value(mine.right_min, slot);
+          nd.right_max = lane_value(mine.right_max, slot);
+          nd.left_ref = (uint32_t)lane_value((int32_t)mine.left_ref, slot);
+          nd.right_ref = (uint32_t)lane_value((int32_t)mine.right_ref, slot);
+          nd.split_dim = (uint32_t)lane_value((int32_t)mine.split_dim, slot);
+          const float v = qr[nd.split_dim];
+          float old_off, new_off;
+          uint32_t far_ref;
+          if (f_sub(f_sub(f_add(nd.left_max, nd.right_min), v), v) > 0.0f) {  // priority_search:97
+            far_ref = nd.right_ref;
+            const float a = f_sub(nd.left_min, v);
+            old_off = v > nd.left_min ? 0.0f : f_mul(a, a);
+            const float b = f_sub(nd.right_min, v);
+            new_off = f_mul(b, b);
+            ref = nd.left_ref;
+          } else {
+            far_ref = nd.left_ref;
+            const float a = f_sub(nd.right_max, v);
+            old_off = v < nd.right_max ? 0.0f : f_mul(a, a);
+            const float b = f_sub(nd.left_max, v);
+            new_off = f_mul(b, b);
+            ref = nd.right_ref;
+          }
+          if (depth < kForestPath && lane == 0) {
+            path_d[depth] = f_add(f_sub(nbd, old_off), new_off);  // :123
+            path_ref[depth] = far_ref;
+          }
+          ++depth;
         }
-        if (depth < kForestPath && lane == 0) {
-          path_d[depth] = f_add(f_sub(nbd, old_off), new_off);  // :123
-          path_ref[depth] = far_ref;
-        }
-        ++depth;
       }
 
       // ---- the leaf: lane j measures point j, candidates enter the list in leaf order ----
