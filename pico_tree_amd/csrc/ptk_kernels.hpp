@@ -180,7 +180,7 @@ struct NnPolicy {  // search_visitor.hpp:42-65 / :165-193
   float best_d;
   int32_t best_i;
   float e_inv;
-  Neighbor* out;  // persistent kernels: result rows, indexed by original query
+  Neighbor* out;  // result rows, indexed by original query (end_query)
   __device__ __forceinline__ void begin_query(uint32_t) {
     best_d = 3.402823466e+38f;
     best_i = 0;
@@ -225,7 +225,7 @@ struct KnnPolicy {  // search_visitor.hpp:83-123 / :198-247
   uint32_t filled;
   float worst;  // == max(): FLT_MAX until the list is full, then the k-th distance
   float e_inv;
-  Neighbor* out;      // persistent kernels: all result rows
+  Neighbor* out;      // all result rows (end_query)
   __device__ __forceinline__ void begin_query(uint32_t qi) {
     filled = 0;
     worst = 3.402823466e+38f;
@@ -331,17 +331,6 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
   float e_inv;
   uint64_t count;
   Neighbor* out;  // FILL: first record of this query's row
-  // persistent kernels
-  uint64_t* counts;
-  const uint64_t* offsets;
-  Neighbor* rows;
-  __device__ __forceinline__ void begin_query(uint32_t qi) {
-    count = 0;
-    if (FILL) out = rows + offsets[qi];
-  }
-  __device__ __forceinline__ void end_query(uint32_t qi) {
-    if (!FILL) counts[qi] = count;
-  }
   __device__ __forceinline__ float max() const { return radius; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
@@ -601,10 +590,10 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
 //            pop-time test of the reference can only reject more) are written out as a
 //            CONTINUATION: at most kContSlots records, typically 1-3, none for ~20 % of the
 //            queries, whose answer is then already final.
-//   sort     continuations are ordered by how many records they carry (one 3-bit radix
-//            pass), so that a phase-2 wavefront holds queries with similar amounts of far
-//            work, the heaviest start first, and spatial neighbours among the heaviest are
-//            dealt to different wavefronts (the monsters come in clusters).
+//   sort     continuations are ordered by a 16-bit key (make_cont_key): the classes that hold
+//            every expensive query first, ranked by how far their home-leaf best is (which
+//            predicts the cost), then the light classes by record count in Morton order; the
+//            heaviest start first, in three tiers (knn1_phase2_kernel).
 //   phase 2  the records are pushed back and the reference traversal resumes exactly where
 //            it left off (state: box distance 0, all offsets 0, best = home-leaf best).
 //
