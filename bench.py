@@ -129,8 +129,19 @@ def cpu_baseline(pts, q, k, leaf, seconds):
     t0 = time.perf_counter()
     cpu.search_knn(q[:n1], k)
     st = n1 / (time.perf_counter() - t0) / 1e6
+    # The same loop on a spatially sorted copy of a sample (scan-ordered real data looks like this;
+    # order alone moves the CPU figure several times): context, not `value`.
+    from pico_tree_amd import datasets as ds
+    cpu.set_threads(cores)
+    ns = min(len(q), 2_000_000)
+    qs = np.ascontiguousarray(q[:ns][ds.morton_order(q[:ns])])
+    t0 = time.perf_counter()
+    cpu.search_knn(qs, k)
+    omp_sorted = ns / (time.perf_counter() - t0) / 1e6
     cpu.close()
     return {"value": round(omp, 4), "unit": "Mqueries/s", "cores": cores, "kind": kind,
+            "morton_sorted_queries_value": round(omp_sorted, 4),
+            "morton_sorted_queries_sample": f"first {ns} queries, Morton-sorted",
             "sample": f"first {done} of {len(q)} queries, same order as the GPU run, "
                       f"OpenMP schedule(dynamic,128) on {cores} threads",
             "single_thread_value": round(st, 4), "single_thread_sample": f"first {n1} queries",
