@@ -146,6 +146,32 @@ struct Stack {
     lds[(top & (S - 1)) * BLOCK] = pack_record(rec);
     ++top;
   }
+  static constexpr int kUnwind = 8;
+  // The newest records, rr[0] the newest; returns how many are valid (>= 1 unless empty).  They
+  // stay on the stack until drop().
+  __device__ __forceinline__ int peek(Record (&rr)[kUnwind]) {
+    if (top == base) {  // ring empty, spilled records remain: bring a batch back
+      if (OVF > 0) {
+        Record r[kRefill];
+#pragma unroll
+        for (int i = 0; i < kRefill; ++i) {
+          const int idx = base - 1 - i;
+          r[i] = ovf[idx >= 0 ? idx : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < kRefill; ++i) {
+          const int idx = base - 1 - i;
+          if (idx >= 0) lds[(idx & (S - 1)) * BLOCK] = pack_record(r[i]);
+        }
+      }
+      base = base > kRefill ? base - kRefill : 0;
+    }
+#pragma unroll
+    for (int i = 0; i < kUnwind; ++i) rr[i] = unpack_record(lds[((top - 1 - i) & (S - 1)) * BLOCK]);
+    const int resident = top - base;
+    return resident < kUnwind ? resident : kUnwind;
+  }
+  __device__ __forceinline__ void drop(int n) { top -= n; }
   __device__ __forceinline__ Record pop() {
     if (top == base) {  // ring empty, spilled records remain: refill a batch
       if (OVF > 0) {
@@ -402,26 +428,45 @@ __device__ __forceinline__ void traverse(
       }
     }
 
-    // Back up to the next far child still worth entering.
+    // Back up to the next far child still worth entering.  The records are consumed kUnwind at a
+    // time: that many independent LDS reads are issued together and then examined in order from
+    // registers (measured: popping them one by one, each ds_read waiting for the branch on the
+    // previous record, was the largest part of a round of the expensive queries, ~2.5 k cycles).
+    uint32_t enter_meta = 0;
+    float enter_val = 0.0f;
     for (;;) {
       if (st.empty()) return;
-      const Record r = st.pop();
-      const float val = __uint_as_float(r.y);
-      if (r.x & kRecUndo) {
-        if (r.x & kRecSide) {
-          nbd = val;
-        } else {
-          const uint32_t axis = (r.x >> 28) & 3u;
-          off0 = axis == 0 ? val : off0;
-          off1 = axis == 1 ? val : off1;
-          off2 = axis == 2 ? val : off2;
+      Record rr[StackT::kUnwind];
+      const int got = st.peek(rr);  // 1 .. kUnwind records, newest first (refills the ring if needed)
+      int used = 0;
+      bool enter = false;
+#pragma unroll
+      for (int i = 0; i < StackT::kUnwind; ++i) {
+        if (!enter && i < got) {
+          used = i + 1;
+          const float val = __uint_as_float(rr[i].y);
+          if (rr[i].x & kRecUndo) {
+            if (rr[i].x & kRecSide) {
+              nbd = val;
+            } else {
+              const uint32_t axis = (rr[i].x >> 28) & 3u;
+              off0 = axis == 0 ? val : off0;
+              off1 = axis == 1 ? val : off1;
+              off2 = axis == 2 ? val : off2;
+            }
+          } else if (pol.max() >= val) {  // the authoritative test of search.hpp:99
+            enter = true;
+            enter_meta = rr[i].x;
+            enter_val = val;
+          }
         }
-        continue;
       }
-      if (pol.max() >= val) {
-        const uint32_t idx = r.x & kRecIdxMask;
-        const uint32_t axis = (r.x >> 28) & 3u;
-        const bool far_is_right = (r.x & kRecSide) != 0;
+      st.drop(used);
+      if (enter) {
+        const float val = enter_val;
+        const uint32_t idx = enter_meta & kRecIdxMask;
+        const uint32_t axis = (enter_meta >> 28) & 3u;
+        const bool far_is_right = (enter_meta & kRecSide) != 0;
         const uint4 nd = nodes[idx];
         const float plane = far_is_right ? __uint_as_float(nd.y) : __uint_as_float(nd.x);
         const float dv = f_sub(plane, sel3(axis, qx, qy, qz));
