@@ -943,6 +943,17 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   if (nq == 0) return PTK_OK;
   if (d_out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // Very large batches go through in pieces of at most 2^25 queries: the scratch of a piece stays
+  // at a few GB and every 32-bit index in the kernels holds (PTK_MAX_BATCH shrinks it for tests).
+  const uint64_t piece = (uint64_t)std::max(1, env_int("PTK_MAX_BATCH", 1 << 25));
+  if (nq > piece) {
+    for (uint64_t done = 0; done < nq; done += piece) {
+      const uint64_t n = std::min(piece, nq - done);
+      rc = ptk_search_knn_device(t, d_q + done * t->dim, n, k, e, d_out + done * k, stream);
+      if (rc != PTK_OK) return rc;
+    }
+    return PTK_OK;
+  }
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   if (t->dim > 3) {

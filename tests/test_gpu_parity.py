@@ -225,6 +225,14 @@ def test_device_buffers_and_streams(trees, gpu):
     assert raw.cpu().numpy().tobytes() == flat.tobytes()
 
 
+def test_large_batches_go_through_in_pieces(trees, monkeypatch):
+    """ptk_search_knn_device cuts batches above PTK_MAX_BATCH (default 2^25) into pieces."""
+    tree, ref, _, q = trees("lidar")
+    monkeypatch.setenv("PTK_MAX_BATCH", "3001")
+    assert tree.search_knn(q, 1).tobytes() == ref.search_knn(q, 1)[:, 0].tobytes()
+    assert tree.search_knn(q, 6).tobytes() == ref.search_knn(q, 6).tobytes()
+
+
 def test_empty_batch_and_errors(trees):
     tree, _, pts, q = trees("uniform")
     assert tree.search_knn(q[:0], 3).shape == (0, 3)
