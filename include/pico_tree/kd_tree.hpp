@@ -285,6 +285,27 @@ class kd_tree {
     ptk_free(rows);
   }
 
+  //! Batched box search: row i (flat[offsets[i] .. offsets[i + 1])) lists the indices inside the
+  //! closed box [mins[i], maxs[i]], in the traversal order of the per-query search_box.
+  template <typename BoxSpace_>
+  inline void search_box(
+      BoxSpace_ const& mins,
+      BoxSpace_ const& maxs,
+      std::vector<std::uint64_t>& offsets,
+      std::vector<index_type>& flat) const {
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    internal::dense_rows<internal::unwrap_ref_t<BoxSpace_>> lo(unwrap(mins)), hi(unwrap(maxs));
+    check_query_dim(lo.cols());
+    check_query_dim(hi.cols());
+    if (lo.rows() != hi.rows()) throw std::invalid_argument("query min and max don't have equal size");
+    offsets.assign(lo.rows() + 1, 0);
+    std::int32_t* rows = nullptr;
+    internal::ptk_check(
+        ptk_search_box(device(), lo.data(), hi.data(), lo.rows(), offsets.data(), &rows), "ptk_search_box");
+    flat.assign(rows, rows + offsets.back());
+    ptk_free(rows);
+  }
+
   //! Uploads the tree to the device now instead of at the first batched call.
   inline void prepare_device() const {
     static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");

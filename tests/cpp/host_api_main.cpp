@@ -213,6 +213,19 @@ static int run_batch(std::string const& dir) {
   write_raw(dir + "/b_radius_off.bin", roff.data(), roff.size());
   write_raw(dir + "/b_radius_flat.bin", rflat.data(), rflat.size());
   write_raw(dir + "/b_radius_sorted.bin", sflat.data(), sflat.size());
+  {  // batched box search: a small box around every query
+    space3 lo = qs, hi = qs;
+    for (size_t i = 0; i < nq; ++i)
+      for (int d = 0; d < 3; ++d) {
+        lo[i][d] -= 0.02f;
+        hi[i][d] += 0.02f;
+      }
+    std::vector<std::uint64_t> boff;
+    std::vector<int> bflat;
+    tree.search_box(lo, hi, boff, bflat);
+    write_raw(dir + "/b_box_off.bin", boff.data(), boff.size());
+    write_raw(dir + "/b_box_flat.bin", bflat.data(), bflat.size());
+  }
   // wrong dimension must throw, not crash
   try {
     std::vector<std::array<float, 2>> bad(4);

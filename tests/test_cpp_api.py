@@ -112,3 +112,6 @@ def test_batched_members_match_oracle(workdir, gpu):
     assert _load(d, "b_radius_flat.bin", pt.NEIGHBOR).tobytes() == flat.tobytes()
     _, sflat = ref.search_radius(q, RADIUS, sort=True)
     assert np.array_equal(_load(d, "b_radius_sorted.bin", pt.NEIGHBOR)["distance"], sflat["distance"])
+    boff, bflat = ref.search_box(q - np.float32(0.02), q + np.float32(0.02))
+    assert np.array_equal(_load(d, "b_box_off.bin", np.uint64), boff)
+    assert np.array_equal(_load(d, "b_box_flat.bin", np.int32), bflat)
