@@ -31,10 +31,17 @@ inline void ptk_check(int status, char const* what) {
   }
 }
 
+//! PTK_METRIC_* of a metric type the backend knows; -1 otherwise.
+template <typename Metric_>
+inline constexpr int ptk_metric_v = std::is_same_v<Metric_, metric_l2_squared> ? PTK_METRIC_L2_SQUARED
+                                    : std::is_same_v<Metric_, metric_l1>       ? PTK_METRIC_L1
+                                    : std::is_same_v<Metric_, metric_lpinf>    ? PTK_METRIC_LPINF
+                                                                               : -1;
+
 //! Which kd_tree instantiations run on the GPU.
 template <typename Metric_, typename Scalar_, typename Index_>
 inline constexpr bool is_accelerated_v =
-    std::is_same_v<Metric_, metric_l2_squared> && std::is_same_v<Scalar_, float> &&
+    ptk_metric_v<Metric_> >= 0 && std::is_same_v<Scalar_, float> &&
     std::is_same_v<Index_, int> && sizeof(int) == 4;
 
 //! True for space types whose points are known to be one contiguous row-major
@@ -84,7 +91,7 @@ class device_tree {
   device_tree() : state_(std::make_shared<state>()) {}
 
   template <typename Tree_, typename SpaceView_>
-  ptk_tree* get(Tree_ const& tree, SpaceView_ const& space) const {
+  ptk_tree* get(Tree_ const& tree, SpaceView_ const& space, int metric = PTK_METRIC_L2_SQUARED) const {
     static_assert(sizeof(typename Tree_::node_type) == sizeof(ptk_node), "node layout");
     std::lock_guard<std::mutex> lock(state_->mutex);
     if (state_->handle == nullptr) {
@@ -108,6 +115,11 @@ class device_tree {
       desc.device = PTK_DEVICE_CURRENT;
       ptk_tree* h = nullptr;
       ptk_check(ptk_tree_create(&desc, &h), "ptk_tree_create");
+      if (metric != PTK_METRIC_L2_SQUARED) {
+        int const rc = ptk_tree_set_metric(h, metric);
+        if (rc != PTK_OK) ptk_tree_destroy(h);
+        ptk_check(rc, "ptk_tree_set_metric");
+      }
       state_->handle = h;
       state_->destroy = &ptk_tree_destroy;
     }

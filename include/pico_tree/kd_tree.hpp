@@ -11,8 +11,8 @@
 //!  2. A family of BATCHED members takes a whole query space at once -- the
 //!     shape of the reference's only batched caller, the OpenMP loops of its
 //!     Python binding (src/pyco_tree/pico_tree/_pyco_tree/kd_tree.hpp:117-268).
-//!     For kd_tree<Space, metric_l2_squared, int> over float they run on the
-//!     MI355X through the C ABI of include/ptk.h (link with -lptk).  They have
+//!     For kd_tree<Space, metric_l2_squared | metric_l1 | metric_lpinf, int> over
+//!     float they run on the MI355X through the C ABI of include/ptk.h (-lptk).  They have
 //!     no host fallback: without a usable backend they throw.
 //!
 //! The per-query members (search_nn(x, nn), search_knn(x, k, knn), custom
@@ -270,7 +270,7 @@ class kd_tree {
       std::vector<std::uint64_t>& offsets,
       std::vector<neighbor_type>& flat,
       bool const sort = false) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
     internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
     check_query_dim(q.cols());
     offsets.assign(q.rows() + 1, 0);
@@ -293,7 +293,7 @@ class kd_tree {
       BoxSpace_ const& maxs,
       std::vector<std::uint64_t>& offsets,
       std::vector<index_type>& flat) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
     internal::dense_rows<internal::unwrap_ref_t<BoxSpace_>> lo(unwrap(mins)), hi(unwrap(maxs));
     check_query_dim(lo.cols());
     check_query_dim(hi.cols());
@@ -308,7 +308,7 @@ class kd_tree {
 
   //! Uploads the tree to the device now instead of at the first batched call.
   inline void prepare_device() const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
     (void)device();
   }
 
@@ -367,7 +367,9 @@ class kd_tree {
     return space_view_type(unwrap(space_));
   }
 
-  ptk_tree* device() const { return device_.get(tree_, view()); }
+  ptk_tree* device() const {
+    return device_.get(tree_, view(), accelerated ? internal::ptk_metric_v<Metric_> : 0);
+  }
 
   void check_query_dim(size_type qdim) const {
     if (qdim != view().sdim()) {
@@ -378,7 +380,7 @@ class kd_tree {
   template <typename QuerySpace_>
   void batched_knn(
       QuerySpace_ const& queries, size_type k, scalar_type e, neighbor_type* out) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
     static_assert(sizeof(neighbor_type) == sizeof(ptk_neighbor), "neighbor layout");
     internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
     check_query_dim(q.cols());
@@ -396,7 +398,7 @@ class kd_tree {
       scalar_type e,
       std::vector<std::vector<neighbor_type>>& out,
       bool sort) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_METRIC_L2_SQUARED_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
     internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
     check_query_dim(q.cols());
     std::vector<std::uint64_t> offsets(q.rows() + 1, 0);

@@ -45,7 +45,7 @@ class kd_forest {
   using neighbor_type = neighbor<index_type, scalar_type>;
 
   static_assert(
-      internal::is_accelerated_v<Metric_, scalar_type, Index_>,
+      internal::is_accelerated_v<Metric_, scalar_type, Index_> && std::is_same_v<Metric_, metric_l2_squared>,
       "kd_forest is built for metric_l2_squared over float points with int indices");
 
   kd_forest(space_type space, size_type max_leaf_size, size_type forest_size, std::uint64_t seed = 0)

@@ -146,6 +146,15 @@ int ptk_tree_get_flat(const ptk_tree* tree, ptk_node* nodes, int32_t* indices,
 
 int ptk_tree_set_reorder(ptk_tree* tree, int mode);
 
+/* Metric of the searches on this handle (the tree itself does not depend on it).  The
+ * reference's euclidean search is generic over the metric (kd_tree.hpp:23, metric.hpp:72-150):
+ *   PTK_METRIC_L2_SQUARED  metric_l2_squared (default): squared distances, radius squared
+ *   PTK_METRIC_L1          metric_l1:    sum of |differences|
+ *   PTK_METRIC_LPINF       metric_lpinf: max of |differences|
+ * Set once, before the first search. */
+enum { PTK_METRIC_L2_SQUARED = 0, PTK_METRIC_L1 = 1, PTK_METRIC_LPINF = 2 };
+int ptk_tree_set_metric(ptk_tree* tree, int metric);
+
 /* The tree in the reference's own binary format (kd_tree::save / kd_tree::load,
  * kd_tree.hpp:336-370, internal/kd_tree_data.hpp:43-58,90-135): sdim, indices,
  * root box, nodes depth-first.  Files written by the reference load here and

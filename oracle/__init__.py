@@ -59,10 +59,15 @@ class Oracle:
     ``(offsets[nq+1], flat)`` pairs.
     """
 
-    def __init__(self, points: np.ndarray, max_leaf_size: int = 10, kind: str = "port"):
+    METRICS = {"L2Squared": 0, "L1": 1, "LPInf": 2}
+
+    def __init__(self, points: np.ndarray, max_leaf_size: int = 10, kind: str = "port",
+                 metric: str = "L2Squared"):
         if kind not in ("port", "reference"):
             raise ValueError(kind)
         self.kind = kind
+        self.metric = metric
+        mid = self.METRICS[metric]
         path = PORT_LIB if kind == "port" else REF_LIB
         if not os.path.exists(path):
             raise RuntimeError(f"oracle library missing: {path} (run oracle.build())")
@@ -74,10 +79,17 @@ class Oracle:
         self.n, self.dim = pts.shape
         self.max_leaf_size = int(max_leaf_size)
         self._pts = pts
-        create = self._fn("create", c_void_p, [POINTER(c_float), c_size_t, c_size_t, c_size_t])
-        self._h = create(_fptr(pts), self.n, self.dim, self.max_leaf_size)
+        if kind == "reference" and mid != 0:  # another instantiation of the reference's kd_tree
+            create = self._fn("create_metric", c_void_p, [POINTER(c_float), c_size_t, c_size_t, c_size_t, c_int])
+            self._h = create(_fptr(pts), self.n, self.dim, self.max_leaf_size, mid)
+        else:
+            create = self._fn("create", c_void_p, [POINTER(c_float), c_size_t, c_size_t, c_size_t])
+            self._h = create(_fptr(pts), self.n, self.dim, self.max_leaf_size)
         if not self._h:
             raise RuntimeError("oracle create failed")
+        if kind == "port" and mid != 0:
+            if self._fn("set_metric", c_int, [c_void_p, c_int])(self._h, mid) != 0:
+                raise RuntimeError("oracle set_metric failed")
 
     def _fn(self, name, restype, argtypes):
         f = getattr(self._lib, self._p + name)
@@ -255,6 +267,22 @@ def l2sq(a, b) -> float:
     a = np.ascontiguousarray(a, dtype=np.float32)
     b = np.ascontiguousarray(b, dtype=np.float32)
     return float(lib.ptkor_l2sq(_fptr(a), _fptr(b), len(a)))
+
+
+def distance(metric: str, a, b) -> float:
+    lib = ctypes.CDLL(PORT_LIB)
+    lib.ptkor_distance.restype = c_float
+    lib.ptkor_distance.argtypes = [c_int, POINTER(c_float), POINTER(c_float), c_size_t]
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    b = np.ascontiguousarray(b, dtype=np.float32)
+    return float(lib.ptkor_distance(Oracle.METRICS[metric], _fptr(a), _fptr(b), len(a)))
+
+
+def distance_scalar(metric: str, x: float) -> float:
+    lib = ctypes.CDLL(PORT_LIB)
+    lib.ptkor_distance_scalar.restype = c_float
+    lib.ptkor_distance_scalar.argtypes = [c_int, c_float]
+    return float(lib.ptkor_distance_scalar(Oracle.METRICS[metric], x))
 
 
 def l2sq_scalar(x: float) -> float:

@@ -125,6 +125,7 @@ struct tree_t {
   size_t dim = 0;
   size_t n = 0;
   size_t max_leaf = 0;
+  int metric = 0;                  // 0 metric_l2_squared, 1 metric_l1, 2 metric_lpinf (searches only)
   std::vector<float> pts;          // n x dim row-major, original order
   std::vector<int> indices;        // kd_tree_data.hpp:67
   box_t root_box{1};               // kd_tree_data.hpp:69
@@ -231,6 +232,24 @@ inline float l2sq(float const* a, float const* b, size_t dim) {
   return d;
 }
 
+// metric_l1 (metric.hpp:78-99: sum of r1_distance = |x - y|, distance.hpp:23-27) and
+// metric_lpinf (metric.hpp:126-152: d = std::max(d, |x - y|), d from 0).
+inline float l1(float const* a, float const* b, size_t dim) {
+  float d = 0.0f;
+  for (size_t i = 0; i < dim; ++i) d += std::abs(a[i] - b[i]);
+  return d;
+}
+inline float lpinf(float const* a, float const* b, size_t dim) {
+  float d = 0.0f;
+  for (size_t i = 0; i < dim; ++i) d = std::max(d, std::abs(a[i] - b[i]));
+  return d;
+}
+inline float point_distance(int metric, float const* a, float const* b, size_t dim) {
+  return metric == 1 ? l1(a, b, dim) : metric == 2 ? lpinf(a, b, dim) : l2sq(a, b, dim);
+}
+// The one-dimensional form the searches apply to a split offset (metric.hpp:95-98, :120-123, :147-150).
+inline float scalar_distance(int metric, float x) { return metric == 0 ? x * x : std::abs(x); }
+
 // ---- visitors: search_visitor.hpp ------------------------------------------
 
 struct visit_nn {  // :42-65 (exact) and :165-193 (approximate: scale by 1/e)
@@ -316,7 +335,7 @@ struct nearest_search {
       for (int i = node->data.leaf.begin_idx; i < node->data.leaf.end_idx; ++i) {
         int const idx = tree.indices[static_cast<size_t>(i)];
         if (counters) ++counters->n_pts;
-        visitor(idx, l2sq(q, tree.point(idx), tree.dim));
+        visitor(idx, point_distance(tree.metric, q, tree.point(idx), tree.dim));
       }
       if (home_leaf) {
         for (float f : counters->first_far) counters->n_cand += visitor.max() >= f ? 1u : 0u;
@@ -334,13 +353,11 @@ struct nearest_search {
     if ((left_max + right_min - v - v) > 0) {  // :76 (left-assoc: ((a+b)-v)-v)
       first = node->left;
       second = node->right;
-      float const t = right_min - v;
-      new_offset = t * t;  // :80, metric.hpp:120-123
+      new_offset = scalar_distance(tree.metric, right_min - v);  // :80, metric.hpp:120-123
     } else {
       first = node->right;
       second = node->left;
-      float const t = left_max - v;
-      new_offset = t * t;  // :84
+      new_offset = scalar_distance(tree.metric, left_max - v);  // :84
     }
     if (counters && counters->n_leaf == 0) {
       counters->first_far.push_back(node_box_distance - offset[sd] + new_offset);
@@ -699,6 +716,16 @@ float ptkor_l2sq(float const* a, float const* b, size_t dim) {
   return l2sq(a, b, dim);
 }
 float ptkor_l2sq_scalar(float x) { return x * x; }
+// metric_l1 / metric_lpinf known answers (metric_test.cpp:27-35, :47-55) and the search metric.
+float ptkor_distance(int metric, float const* a, float const* b, size_t dim) {
+  return point_distance(metric, a, b, dim);
+}
+float ptkor_distance_scalar(int metric, float x) { return scalar_distance(metric, x); }
+int ptkor_set_metric(void* tree, int metric) {
+  if (tree == nullptr || metric < 0 || metric > 2) return -1;
+  static_cast<tree_t*>(tree)->metric = metric;
+  return 0;
+}
 
 
 // =====================================================================================

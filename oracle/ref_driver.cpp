@@ -80,11 +80,11 @@ struct tree_base {
   size_t n = 0;
 };
 
-template <size_t Dim_>
+template <size_t Dim_, typename Metric_ = pico_tree::metric_l2_squared>
 struct tree_impl final : tree_base {
   using point_t = pico_tree::point_map<float const, Dim_>;
   using space_t = pico_tree::space_map<point_t>;
-  using kd_t = pico_tree::kd_tree<space_t>;
+  using kd_t = pico_tree::kd_tree<space_t, Metric_>;
 
   std::vector<float> pts;  // the driver owns a copy so callers may free theirs
   std::unique_ptr<kd_t> tree;
@@ -191,6 +191,24 @@ void* ptkref_create(float const* pts, size_t n, size_t dim, size_t max_leaf) {
   return dispatch_dim(dim, [&](auto d) -> void* {
     return static_cast<tree_base*>(
         new tree_impl<decltype(d)::value>(pts, n, dim, max_leaf));
+  });
+}
+
+// The same tree searched under another of the reference's metrics
+// (0 metric_l2_squared, 1 metric_l1, 2 metric_lpinf; metric.hpp:78-152).
+void* ptkref_create_metric(float const* pts, size_t n, size_t dim,
+                           size_t max_leaf, int metric) {
+  if (n == 0 || dim == 0 || max_leaf == 0) return nullptr;
+  if (metric == 0) return ptkref_create(pts, n, dim, max_leaf);
+  return dispatch_dim(dim, [&](auto d) -> void* {
+    constexpr size_t kDim = decltype(d)::value;
+    if (metric == 1)
+      return static_cast<tree_base*>(
+          new tree_impl<kDim, pico_tree::metric_l1>(pts, n, dim, max_leaf));
+    if (metric == 2)
+      return static_cast<tree_base*>(
+          new tree_impl<kDim, pico_tree::metric_lpinf>(pts, n, dim, max_leaf));
+    return nullptr;
   });
 }
 

@@ -77,6 +77,7 @@ _SIGNATURES = {
     "ptk_tree_get_info": (c_int, [c_void_p, POINTER(_Info)]),
     "ptk_tree_get_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ptk_tree_set_reorder": (c_int, [c_void_p, c_int]),
+    "ptk_tree_set_metric": (c_int, [c_void_p, c_int]),
     "ptk_tree_serialize": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
     "ptk_tree_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
                                             POINTER(c_void_p)]),
@@ -148,10 +149,14 @@ def device_count() -> int:
 
 
 class Metric(enum.Enum):
-    """Metrics of the reference binding; only ``L2Squared`` is built here."""
+    """Metrics of the reference binding (``def_kd_tree.cpp:14-17``).  ``L2Squared`` takes the
+    tuned kernels; ``L1`` and ``LPInf`` run the generic kernels with the metric swapped in."""
     L1 = 1
     L2Squared = 2
     LPInf = 3
+
+
+_PTK_METRIC = {Metric.L2Squared: 0, Metric.L1: 1, Metric.LPInf: 2}  # PTK_METRIC_* of ptk.h
 
 
 def _is_torch(x) -> bool:
@@ -254,8 +259,9 @@ class KdTree:
 
     def __init__(self, pts, metric: Metric = Metric.L2Squared, max_leaf_size: int = 10,
                  device: int | None = None, _stream: bytes | None = None):
-        if metric is not Metric.L2Squared:
-            raise ValueError("only Metric.L2Squared is available in this build")
+        if not isinstance(metric, Metric):
+            raise TypeError("metric must be a pico_tree_amd.Metric")
+        self._metric = metric
         pts = self._as_matrix(pts, None, "pts")
         if int(max_leaf_size) <= 0:
             raise ValueError("max_leaf_size must be positive")
@@ -273,6 +279,12 @@ class KdTree:
             _check(lib.ptk_tree_create_from_stream(pts.ctypes.data, self._npts, self._sdim, buf, len(_stream),
                                                    dev, byref(handle)))
         self._h = handle
+        if metric is not Metric.L2Squared:
+            _check(lib.ptk_tree_set_metric(handle, _PTK_METRIC[metric]))
+
+    @property
+    def metric_string(self) -> str:  # core.hpp:24-38
+        return self._metric.name
 
     def _serialize(self) -> bytes:
         size = c_uint64()
@@ -315,7 +327,7 @@ class KdTree:
             pass
 
     def __repr__(self) -> str:  # _pyco_tree/kd_tree.hpp:321-326
-        return f"KdTree(metric=L2Squared, dtype=float32, sdim={self._sdim}, npts={self._npts})"
+        return f"KdTree(metric={self._metric.name}, dtype=float32, sdim={self._sdim}, npts={self._npts})"
 
     # -- properties (names of the reference binding) ----------------------------------
     @property
@@ -339,9 +351,10 @@ class KdTree:
         return NEIGHBOR
 
     def metric(self, scalar: float) -> float:
-        """metric_l2_squared's one-dimensional form: ``x * x`` in float32."""
+        """The metric's one-dimensional form in float32: ``x * x`` for L2Squared, ``|x|`` for L1 and
+        LPInf (metric.hpp:95-98, :120-123, :147-150)."""
         x = np.float32(scalar)
-        return float(x * x)
+        return float(x * x) if self._metric is Metric.L2Squared else float(abs(x))
 
     def info(self) -> dict:
         inf = _Info()
@@ -626,7 +639,7 @@ _PKD_VERSION = 1
 def save_kd_tree(tree: KdTree, filename: str) -> None:
     """``pico_tree.save_kd_tree``: PKD header (signature, version, metric string) followed by the
     tree in the reference's kd_tree::save format.  The points are not stored."""
-    metric = b"L2Squared"
+    metric = tree.metric_string.encode("ascii")
     with open(filename, "wb") as f:
         f.write(_PKD_SIGNATURE)
         f.write(np.uint32(_PKD_VERSION).tobytes())
@@ -637,7 +650,7 @@ def save_kd_tree(tree: KdTree, filename: str) -> None:
 
 def load_kd_tree(pts, filename: str, device: int | None = None) -> KdTree:
     """``pico_tree.load_kd_tree``: rebuilds a :class:`KdTree` over ``pts`` from a file written by
-    :func:`save_kd_tree` or by the reference's own ``save_kd_tree`` (float32, L2Squared)."""
+    :func:`save_kd_tree` or by the reference's own ``save_kd_tree`` (float32, any of its metrics)."""
     with open(filename, "rb") as f:
         data = f.read()
     if data[:4] != _PKD_SIGNATURE:
@@ -646,7 +659,6 @@ def load_kd_tree(pts, filename: str, device: int | None = None) -> KdTree:
         raise RuntimeError("unsupported header version")
     n = int(np.frombuffer(data, dtype=np.uint64, count=1, offset=8)[0])
     metric = data[16:16 + n].decode("ascii", "replace")
-    if metric != "L2Squared":
-        raise RuntimeError("unexpected metric string" if metric not in ("L1", "LPInf")
-                           else f"metric {metric} is not available in this build")
-    return KdTree(pts, Metric.L2Squared, 1, device=device, _stream=data[16 + n:])
+    if metric not in Metric.__members__:  # kd_tree.hpp:588-598
+        raise RuntimeError("unexpected metric string")
+    return KdTree(pts, Metric[metric], 1, device=device, _stream=data[16 + n:])

@@ -123,6 +123,7 @@ struct ptk_tree {
   bool gpu_layout = false;
 
   std::atomic<int> reorder{PTK_REORDER_AUTO};
+  std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
   mutable Profile profile;
   mutable Workspace ws;
 };
@@ -494,7 +495,7 @@ int launch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint6
   return PTK_OK;
 }
 
-template <int S, int OVF, int BLOCK, int LEAFB>
+template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
                ptk::Neighbor* d_out, hipStream_t s) {
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
@@ -504,10 +505,10 @@ int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64
   const bool list_lds = stack_bytes + list_bytes <= 40 * 1024;
   Timer timer(t, s);
   if (list_lds) {
-    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, true>), dim3(blocks), dim3(BLOCK),
+    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK),
                        stack_bytes + list_bytes, s, t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out);
   } else {
-    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, false>), dim3(blocks), dim3(BLOCK), stack_bytes, s,
+    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, false, M>), dim3(blocks), dim3(BLOCK), stack_bytes, s,
                        t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out);
   }
   PTK_HIP(hipGetLastError());
@@ -516,14 +517,14 @@ int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64
 }
 
 // k <= 32: the k-list in registers (K = 4 / 8 / 16 / 32 slots compiled).
-template <int S, int OVF, int BLOCK, int LEAFB>
+template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
                    ptk::Neighbor* d_out, hipStream_t s) {
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
 #define PTK_LAUNCH_REG(KK)                                                                                          \
-  hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q, \
+  hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q, \
                      t->dim, perm, nq, k, inv_ratio(e), d_out)
   if (k <= 4) PTK_LAUNCH_REG(4);
   else if (k <= 8) PTK_LAUNCH_REG(8);
@@ -535,7 +536,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
   return PTK_OK;
 }
 
-template <int S, int OVF, int BLOCK, int LEAFB>
+template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
                   bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out,
                   hipStream_t s) {
@@ -543,10 +544,10 @@ int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
   if (!fill) {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, false>), dim3(blocks), dim3(BLOCK), smem, s,
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, false, M>), dim3(blocks), dim3(BLOCK), smem, s,
                        t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
   } else {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true>), dim3(blocks), dim3(BLOCK), smem, s,
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK), smem, s,
                        t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
   }
   PTK_HIP(hipGetLastError());
@@ -670,7 +671,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
 // LDS per 64-lane block: record ring + q[dim] + off[dim] (+ the k-list while it fits).
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 
-template <int OVF>
+template <int OVF, class M = ptk::MetricL2>
 int launch_knn_nd(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t k, float e, ptk::Neighbor* d_out,
                   hipStream_t s) {
   constexpr int S = 16;
@@ -683,12 +684,12 @@ int launch_knn_nd(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t k, 
   const size_t smem = base + (list_lds ? list_bytes : 0);
   Timer timer(t, s);
   if (list_lds) {
-    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, true>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
+    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, true, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
                        inv_ratio(e), d_out);
   } else {
-    int rc = allow_lds(ptk::knn_nd_kernel<S, OVF, false>, smem);
+    int rc = allow_lds(ptk::knn_nd_kernel<S, OVF, false, M>, smem);
     if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, false>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
+    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, false, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
                        inv_ratio(e), d_out);
   }
   PTK_HIP(hipGetLastError());
@@ -696,7 +697,7 @@ int launch_knn_nd(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t k, 
   return PTK_OK;
 }
 
-template <int OVF>
+template <int OVF, class M = ptk::MetricL2>
 int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e, bool fill,
                      uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out, hipStream_t s) {
   constexpr int S = 16;
@@ -706,14 +707,14 @@ int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float rad
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
   Timer timer(t, s);
   if (!fill) {
-    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, false>, smem);
+    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, false, M>, smem);
     if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, false>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
+    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, false, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
                        radius, inv_ratio(e), d_counts, d_offsets, d_out);
   } else {
-    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, true>, smem);
+    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, true, M>, smem);
     if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, true>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
+    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, true, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
                        radius, inv_ratio(e), d_counts, d_offsets, d_out);
   }
   PTK_HIP(hipGetLastError());
@@ -728,6 +729,14 @@ int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float rad
     case 1: { constexpr int OVF = 256; rc = CALL; } break;                                                  \
     case 2: { constexpr int OVF = 2048; rc = CALL; } break;                                                 \
     default: rc = fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth); \
+  }
+
+// Runs CALL with M bound to the metric of the handle (other than L2 squared).
+#define PTK_WITH_METRIC(CALL)                                              \
+  switch (t->metric.load()) {                                             \
+    case PTK_METRIC_L1: { using M = ptk::MetricL1; CALL; } break;         \
+    case PTK_METRIC_LPINF: { using M = ptk::MetricLInf; CALL; } break;    \
+    default: { using M = ptk::MetricL2; CALL; } break;                    \
   }
 
 // k = 1.  PTK_KNN1_VARIANT selects an A/B form (tools/ab_knn1.py): 0 = the shipped two-phase
@@ -923,6 +932,13 @@ int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t
   return finish_create(t, points, device, out);
 }
 
+int ptk_tree_set_metric(ptk_tree* t, int metric) {
+  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LPINF)
+    return fail(PTK_ERR_INVALID, "bad metric");
+  t->metric.store(metric);
+  return PTK_OK;
+}
+
 int ptk_tree_set_reorder(ptk_tree* t, int mode) {
   if (t == nullptr || mode < PTK_REORDER_AUTO || mode > PTK_REORDER_OFF)
     return fail(PTK_ERR_INVALID, "bad reorder mode");
@@ -956,25 +972,26 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   }
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  const bool l2 = t->metric.load() == PTK_METRIC_L2_SQUARED;
   if (t->dim > 3) {
-    PTK_WITH_OVF(16, (launch_knn_nd<OVF>(t, d_q, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_nd<OVF, M>(t, d_q, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
     return rc;
   }
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s);
-  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) + (k == 1 ? two_phase_scratch_bytes(nq) : 0));
+  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) + (k == 1 && l2 ? two_phase_scratch_bytes(nq) : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
   if (reorder) {
     rc = make_permutation(t, d_q, nq, s, scratch, &perm);
     if (rc != PTK_OK) return rc;
   }
-  if (k == 1) {
+  if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else if (k <= 32 && env_int("PTK_KNN_LIST", 0) == 0) {
-    PTK_WITH_OVF(16, (launch_knn_reg<16, OVF, 64, 4>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_reg<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   } else {
-    PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   }
   return rc;
 }
@@ -1021,8 +1038,8 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   if (t->dim > 3) {
-    PTK_WITH_OVF(16, (launch_radius_nd<OVF>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
-                                            reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
+                                                               reinterpret_cast<ptk::Neighbor*>(d_out), s))));
     if (rc == PTK_OK && fill && sort) {
       const uint32_t sort_blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
       hipLaunchKernelGGL(ptk::sort_rows_kernel, dim3(sort_blocks), dim3(ptk::kBlock), 0, s, nq, d_offsets,
@@ -1040,8 +1057,8 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     rc = make_permutation(t, d_q, nq, s, scratch, &perm);
     if (rc != PTK_OK) return rc;
   }
-  PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4>(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
-                                                  reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+  PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
+                                                                     d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   if (rc == PTK_OK && fill && sort) {
     Timer timer(t, s);
     const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);

@@ -114,6 +114,31 @@ __device__ __forceinline__ float sel3(uint32_t axis, float a0, float a1, float a
   return axis == 0 ? a0 : (axis == 1 ? a1 : a2);
 }
 
+// ---- metrics ---------------------------------------------------------------------------------
+// The reference's euclidean search is generic over the metric (metric.hpp:72-150): `one(x)` is the
+// one-dimensional form used for the box offsets (search.hpp:80,84), `acc` adds one coordinate to a
+// point distance that starts at 0 (internal::sum, metric.hpp:36-51; metric_lpinf: std::max from 0).
+struct MetricL2 {  // metric_l2_squared
+  __device__ __forceinline__ static float one(float x) { return f_mul(x, x); }
+  __device__ __forceinline__ static float acc(float d, float diff) { return f_add(d, f_mul(diff, diff)); }
+};
+struct MetricL1 {  // metric_l1
+  __device__ __forceinline__ static float one(float x) { return fabsf(x); }
+  __device__ __forceinline__ static float acc(float d, float diff) { return f_add(d, fabsf(diff)); }
+};
+struct MetricLInf {  // metric_lpinf
+  __device__ __forceinline__ static float one(float x) { return fabsf(x); }
+  __device__ __forceinline__ static float acc(float d, float diff) {
+    const float a = fabsf(diff);
+    return d < a ? a : d;  // std::max(d, a)
+  }
+};
+// Three coordinates at once: acc(acc(acc(0, dx), dy), dz) without the exact no-op 0 + x.
+template <class M>
+__device__ __forceinline__ float point_distance3(float dx, float dy, float dz) {
+  return M::acc(M::acc(M::one(dx), dy), dz);
+}
+
 // ---- record stack: ring of S slots in LDS + OVF spill slots in private scratch ----
 // Records are numbered 0, 1, 2, ... in push order.  [base, top) is resident in the
 // ring (record i at slot i mod S); [0, base) has been spilled (record i at
@@ -375,7 +400,7 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
 // ---- the traversal ----------------------------------------------------------------
 // RESUME: the stack already holds the pending records of a finished first descent (phase 2
 // of the two-phase k = 1 search): start by unwinding instead of descending from the root.
-template <int LEAFB, bool RESUME = false, class Policy, class StackT>
+template <int LEAFB, bool RESUME = false, class M = MetricL2, class Policy, class StackT>
 __device__ __forceinline__ void traverse(
     const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st) {
   const uint4* __restrict__ nodes = t.nodes;
@@ -396,7 +421,7 @@ __device__ __forceinline__ void traverse(
       const bool go_left = s > 0.0f;
       const float plane = go_left ? right_min : left_max;  // the far child's face
       const float dv = f_sub(plane, v);
-      const float new_off = f_mul(dv, dv);
+      const float new_off = M::one(dv);
       const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
       if (pol.max() >= far_nbd) {
         st.push(idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
@@ -421,8 +446,7 @@ __device__ __forceinline__ void traverse(
             const float dx = f_sub(qx, p[u].x);
             const float dy = f_sub(qy, p[u].y);
             const float dz = f_sub(qz, p[u].z);
-            const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
-            pol.visit(__float_as_int(p[u].w), d);
+            pol.visit(__float_as_int(p[u].w), point_distance3<M>(dx, dy, dz));
           }
         }
       }
@@ -470,7 +494,7 @@ __device__ __forceinline__ void traverse(
         const uint4 nd = nodes[idx];
         const float plane = far_is_right ? __uint_as_float(nd.y) : __uint_as_float(nd.x);
         const float dv = f_sub(plane, sel3(axis, qx, qy, qz));
-        const float new_off = f_mul(dv, dv);
+        const float new_off = M::one(dv);
         st.push(kRecUndo | (axis << 28), sel3(axis, off0, off1, off2));
         st.push(kRecUndo | kRecSide, nbd);
         off0 = axis == 0 ? new_off : off0;
@@ -534,7 +558,7 @@ __global__ __launch_bounds__(BLOCK) void knn1_kernel(
 // ---- general k -------------------------------------------------------------------------
 // LIST_LDS: the k-list lives in LDS behind the stack ([slot][lane]) and is copied
 // to the output row at the end; otherwise the output row itself is the list.
-template <int S, int OVF, int BLOCK, int LEAFB, bool LIST_LDS>
+template <int S, int OVF, int BLOCK, int LEAFB, bool LIST_LDS, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void knn_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
@@ -561,7 +585,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   pol.filled = 0;
   pol.worst = 3.402823466e+38f;
   pol.e_inv = e_inv;
-  traverse<LEAFB>(t, qx, qy, qz, pol, st);
+  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
 
   if (LIST_LDS) {
     Neighbor* row = out + qi * k;
@@ -575,7 +599,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   }
 }
 
-template <int K, int S, int OVF, int BLOCK, int LEAFB>
+template <int K, int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
@@ -591,12 +615,12 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
   st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
   KnnRegPolicy<K> pol;
   pol.init(k, e_inv);
-  traverse<LEAFB>(t, qx, qy, qz, pol, st);
+  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   pol.store(out + qi * k);
 }
 
 // ---- radius: count pass and fill pass ------------------------------------------------------
-template <int S, int OVF, int BLOCK, int LEAFB, bool FILL>
+template <int S, int OVF, int BLOCK, int LEAFB, bool FILL, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void radius_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
@@ -617,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   pol.e_inv = e_inv;
   pol.count = 0;
   pol.out = FILL ? out + offsets[qi] : nullptr;
-  traverse<LEAFB>(t, qx, qy, qz, pol, st);
+  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   if (!FILL) counts[qi] = pol.count;
 }
 

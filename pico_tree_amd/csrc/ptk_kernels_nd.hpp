@@ -40,7 +40,7 @@ constexpr uint32_t kNdIdxMask = 0x3FFFFFFFu;
 
 typedef PTK_LDS float LdsFloat;
 
-template <class Policy, class StackT>
+template <class M = MetricL2, class Policy, class StackT>
 __device__ __forceinline__ void traverse_nd(
     const DevTreeND& t, LdsFloat* q, LdsFloat* off, uint32_t stride, Policy& pol, StackT& st) {
   const uint4* __restrict__ nodes = t.nodes;
@@ -60,7 +60,7 @@ __device__ __forceinline__ void traverse_nd(
       const float v = q[axis * stride];
       const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;  // search.hpp:76
       const float dv = f_sub(go_left ? right_min : left_max, v);
-      const float new_off = f_mul(dv, dv);                                          // :80,84
+      const float new_off = M::one(dv);                                             // :80,84
       const float far_nbd = f_add(f_sub(nbd, off[axis * stride]), new_off);         // :94
       if (pol.max() >= far_nbd) st.push(ref | (go_left ? kRecSide : 0u), far_nbd);
       ref = go_left ? nd.z : nd.w;
@@ -74,7 +74,7 @@ __device__ __forceinline__ void traverse_nd(
         float d = 0.0f;
         for (uint32_t a = 0; a < dim; ++a) {
           const float diff = f_sub(q[a * stride], p[a]);
-          d = f_add(d, f_mul(diff, diff));
+          d = M::acc(d, diff);
         }
         pol.visit(index[begin + j], d);
       }
@@ -98,7 +98,7 @@ __device__ __forceinline__ void traverse_nd(
         const uint32_t axis = axes[idx];
         const float plane = far_is_right ? __uint_as_float(nd.y) : __uint_as_float(nd.x);
         const float dv = f_sub(plane, q[axis * stride]);
-        const float new_off = f_mul(dv, dv);
+        const float new_off = M::one(dv);
         st.push(kRecUndo | axis, off[axis * stride]);
         st.push(kRecUndo | kRecSide, nbd);
         off[axis * stride] = new_off;
@@ -124,7 +124,7 @@ __device__ __forceinline__ void stage_query_nd(
   }
 }
 
-template <int S, int OVF, bool LIST_LDS>
+template <int S, int OVF, bool LIST_LDS, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn_nd_kernel(
     DevTreeND t, const float* __restrict__ queries, uint64_t nq, uint32_t k, float e_inv,
     Neighbor* __restrict__ out) {
@@ -148,11 +148,11 @@ __global__ __launch_bounds__(64) void knn_nd_kernel(
   pol.worst = 3.402823466e+38f;
   pol.e_inv = e_inv;
   pol.out = out;
-  traverse_nd(t, q, off, 64u, pol, st);
+  traverse_nd<M>(t, q, off, 64u, pol, st);
   pol.end_query((uint32_t)qi);
 }
 
-template <int S, int OVF, bool FILL>
+template <int S, int OVF, bool FILL, class M = MetricL2>
 __global__ __launch_bounds__(64) void radius_nd_kernel(
     DevTreeND t, const float* __restrict__ queries, uint64_t nq, float radius, float e_inv,
     uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out) {
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(64) void radius_nd_kernel(
   pol.e_inv = e_inv;
   pol.count = 0;
   pol.out = FILL ? out + offsets[qi] : nullptr;
-  traverse_nd(t, q, off, 64u, pol, st);
+  traverse_nd<M>(t, q, off, 64u, pol, st);
   if (!FILL) counts[qi] = pol.count;
 }
 

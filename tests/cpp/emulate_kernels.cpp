@@ -95,6 +95,7 @@ struct Emu {
   ptk::DevTree dev;
   ptk::DevTreeND dev_nd;
   uint32_t dim;
+  int metric = 0;
 };
 
 // Kernels whose lanes are independent: every lane of every block, sequentially.
@@ -163,6 +164,49 @@ std::vector<float4> pack(const float* q, uint32_t dim, const uint32_t* perm, uin
 
 }  // namespace
 
+// The launches the backend makes for a metric other than L2 squared: register k-list for k <= 32
+// (k = 1 included -- the two-phase search is L2 only), LDS k-list above, any-dimension kernels.
+template <class M>
+int emu_knn_metric(Emu* t, const float* q, uint64_t nq, uint32_t k, float e_inv, const uint32_t* perm,
+                   int small_stack, ptk::Neighbor* o) {
+  if (t->dim > 3) {
+    if (perm != nullptr) return -3;
+    if (small_stack)
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, true, M>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+    else
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, true, M>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+    return 0;
+  }
+  if (k <= 32) {
+    if (small_stack) {
+      if (k <= 4) for_each_lane(nq, [&] { ptk::knn_reg_kernel<4, 4, 2048, 64, 1, M>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+      else for_each_lane(nq, [&] { ptk::knn_reg_kernel<32, 4, 2048, 64, 1, M>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+    } else {
+      if (k <= 8) for_each_lane(nq, [&] { ptk::knn_reg_kernel<8, 16, 2048, 64, 4, M>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+      else for_each_lane(nq, [&] { ptk::knn_reg_kernel<32, 16, 2048, 64, 4, M>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+    }
+  } else {
+    for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, 64, 4, true, M>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+  }
+  return 0;
+}
+
+template <class M>
+void emu_radius_metric(Emu* t, const float* q, uint64_t nq, float radius, float e_inv, const uint32_t* perm,
+                       uint64_t* counts, const uint64_t* offsets, ptk::Neighbor* o) {
+  if (t->dim > 3) {
+    if (o == nullptr)
+      for_each_lane(nq, [&] { ptk::radius_nd_kernel<8, 2048, false, M>(t->dev_nd, q, nq, radius, e_inv, counts, nullptr, nullptr); }, 64);
+    else
+      for_each_lane(nq, [&] { ptk::radius_nd_kernel<16, 2048, true, M>(t->dev_nd, q, nq, radius, e_inv, nullptr, offsets, o); }, 64);
+    return;
+  }
+  if (o == nullptr)
+    for_each_lane(nq, [&] { ptk::radius_kernel<8, 2048, 64, 4, false, M>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, nullptr, nullptr); }, 64);
+  else
+    for_each_lane(nq, [&] { ptk::radius_kernel<16, 2048, 64, 4, true, M>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o); }, 64);
+}
+
 extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
@@ -205,6 +249,9 @@ void* emu_create(const float* points, uint64_t n, uint32_t dim, const ptk_node* 
 
 void emu_destroy(void* h) { delete static_cast<Emu*>(h); }
 
+// 0 L2 squared (default), 1 L1, 2 LPInf: the metric of the searches that follow (ptk_tree_set_metric).
+void emu_set_metric(void* h, int metric) { static_cast<Emu*>(h)->metric = metric; }
+
 uint32_t emu_max_depth(void* h) { return static_cast<Emu*>(h)->st.max_depth; }
 
 // small_stack != 0 runs the smallest LDS ring (4 slots), so nearly every record
@@ -216,6 +263,8 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
   const float e_inv = 1.0f / e;
   const uint32_t need = 2 * t->st.max_depth + 2;
   if (need > 4 + 2048) return -2;
+  if (t->metric == 1) return emu_knn_metric<ptk::MetricL1>(t, q, nq, k, e_inv, perm, small_stack, o);
+  if (t->metric == 2) return emu_knn_metric<ptk::MetricLInf>(t, q, nq, k, e_inv, perm, small_stack, o);
   if (t->dim > 3) {  // any-dimension kernels (no launch permutation)
     if (perm != nullptr) return -3;
     const size_t base = (size_t)(small_stack ? 4 : 16) * 64 * 8 + (size_t)t->dim * 64 * 8;
@@ -264,6 +313,11 @@ int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e
                      uint64_t* counts) {
   auto* t = static_cast<Emu*>(h);
   const float e_inv = 1.0f / e;
+  if (t->metric != 0) {
+    if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
+    else emu_radius_metric<ptk::MetricLInf>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
+    return 0;
+  }
   if (t->dim > 3) {
     for_each_lane(nq, [&] {
       ptk::radius_nd_kernel<8, 2048, false>(t->dev_nd, q, nq, radius, e_inv, counts, nullptr, nullptr);
@@ -281,6 +335,12 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   auto* t = static_cast<Emu*>(h);
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
   const float e_inv = 1.0f / e;
+  if (t->metric != 0) {
+    if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
+    else emu_radius_metric<ptk::MetricLInf>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
+    if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
+    return 0;
+  }
   if (t->dim > 3) {
     for_each_lane(nq, [&] {
       ptk::radius_nd_kernel<16, 2048, true>(t->dev_nd, q, nq, radius, e_inv, nullptr, offsets, o);

@@ -226,6 +226,20 @@ static int run_batch(std::string const& dir) {
     write_raw(dir + "/b_box_off.bin", boff.data(), boff.size());
     write_raw(dir + "/b_box_flat.bin", bflat.data(), bflat.size());
   }
+  {  // the same batched members under metric_l1 / metric_lpinf (ptk_tree_set_metric)
+    auto l1 = pico_tree::make_kd_tree<pico_tree::metric_l1>(std::cref(qs), pico_tree::max_leaf_size_t(10));
+    auto linf = pico_tree::make_kd_tree<pico_tree::metric_lpinf>(std::cref(qs), pico_tree::max_leaf_size_t(10));
+    std::vector<neighbor> a(nq * k), b(nq * k);
+    l1.search_knn(qmap, k, a.data());
+    linf.search_knn(qmap, k, b.data());
+    write_raw(dir + "/b_l1_knn.bin", a.data(), a.size());
+    write_raw(dir + "/b_linf_knn.bin", b.data(), b.size());
+    std::vector<std::uint64_t> off;
+    std::vector<neighbor> flat;
+    l1.search_radius(qs, 0.03f, off, flat, false);
+    write_raw(dir + "/b_l1_radius_off.bin", off.data(), off.size());
+    write_raw(dir + "/b_l1_radius_flat.bin", flat.data(), flat.size());
+  }
   // wrong dimension must throw, not crash
   try {
     std::vector<std::array<float, 2>> bad(4);

@@ -35,15 +35,18 @@ class EmulatedTree:
     """Builds the flat tree with the PRODUCT builder (host-only libptk handle),
     encodes it with the product encoder and runs the product kernels on the CPU."""
 
-    def __init__(self, pts, leaf):
+    def __init__(self, pts, leaf, metric=pt.Metric.L2Squared):
         self.lib = _lib()
         self.pts = np.ascontiguousarray(pts, dtype=np.float32)
-        self.host = pt.KdTree(self.pts, pt.Metric.L2Squared, leaf, device=pt.PTK_DEVICE_NONE)
+        self.host = pt.KdTree(self.pts, metric, leaf, device=pt.PTK_DEVICE_NONE)
         nodes, idx, self.rmin, self.rmax = self.host.flat()
         self.h = self.lib.emu_create(self.pts.ctypes.data, len(self.pts), self.pts.shape[1],
                                      nodes.ctypes.data, len(nodes), idx.ctypes.data)
         if not self.h:
             raise RuntimeError(self.lib.emu_last_error().decode())
+        self.lib.emu_set_metric.argtypes = [c_void_p, ctypes.c_int]
+        self.lib.emu_set_metric.restype = None
+        self.lib.emu_set_metric(self.h, {"L2Squared": 0, "L1": 1, "LPInf": 2}[metric.name])
 
     def __del__(self):
         if getattr(self, "h", None):

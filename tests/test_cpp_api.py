@@ -115,3 +115,10 @@ def test_batched_members_match_oracle(workdir, gpu):
     boff, bflat = ref.search_box(q - np.float32(0.02), q + np.float32(0.02))
     assert np.array_equal(_load(d, "b_box_off.bin", np.uint64), boff)
     assert np.array_equal(_load(d, "b_box_flat.bin", np.int32), bflat)
+    # other metrics: trees over the QUERY cloud, searched with itself
+    l1, linf = oracle.Oracle(q, 10, "port", "L1"), oracle.Oracle(q, 10, "port", "LPInf")
+    assert _load(d, "b_l1_knn.bin", pt.NEIGHBOR).tobytes() == l1.search_knn(q, K).tobytes()
+    assert _load(d, "b_linf_knn.bin", pt.NEIGHBOR).tobytes() == linf.search_knn(q, K).tobytes()
+    off, flat = l1.search_radius(q, 0.03)
+    assert np.array_equal(_load(d, "b_l1_radius_off.bin", np.uint64), off)
+    assert _load(d, "b_l1_radius_flat.bin", pt.NEIGHBOR).tobytes() == flat.tobytes()

@@ -258,3 +258,51 @@ def test_subnormal_and_huge_coordinates(gpu):
         tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
         ref = oracle.Oracle(pts, 10, "port")
         assert tree.search_knn(q, 3).tobytes() == ref.search_knn(q, 3).tobytes()
+
+
+@pytest.mark.parametrize("metric", ["L1", "LPInf"])
+@pytest.mark.parametrize("cloud,dim", [("uniform", 3), ("lidar", 3), ("ties", 3), ("u2", 2), ("u6", 6), ("u32", 32)])
+def test_other_metrics_bit_exact(gpu, cloud, dim, metric):
+    """metric_l1 / metric_lpinf (metric.hpp:78-152) through ptk_tree_set_metric: same tree, the
+    generic kernels with the metric swapped in; the oracle under the same metric is pinned against
+    kd_tree<space, metric_l1|metric_lpinf> of the compiled reference (tests/test_oracle.py)."""
+    if dim == 3:
+        pts, q = _clouds(cloud, 50_000, 12_000)
+    else:
+        n, nq = (40_000, 8_000) if dim <= 6 else (8_000, 1_000)
+        pts, q = ds.uniform_cloud(n, dim, 71), ds.uniform_cloud(nq, dim, 72)
+    tree = pt.KdTree(pts, pt.Metric[metric], 10, device=gpu)
+    ref = oracle.Oracle(pts, 10, "port", metric)
+    assert tree.search_knn(q, 1).tobytes() == ref.search_knn(q, 1)[:, 0].tobytes()
+    for k in (5, 16, 40):
+        assert tree.search_knn(q, k).tobytes() == ref.search_knn(q, k).tobytes()
+    assert tree.search_knn(q, 6, 1.25).tobytes() == ref.search_knn(q, 6, e=1.25).tobytes()
+    scale = float(np.ptp(pts, axis=0).max())
+    radius = scale * {("L1", 2): 0.01, ("L1", 3): 0.02, ("L1", 6): 0.45, ("L1", 32): 7.0,
+                      ("LPInf", 2): 0.01, ("LPInf", 3): 0.02, ("LPInf", 6): 0.15, ("LPInf", 32): 0.5}[(metric, dim)]
+    got = tree.search_radius(q, radius)
+    off, flat = ref.search_radius(q, radius)
+    assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+    assert off[-1] > 0
+    got = tree.search_radius(q, radius, 1.5, sort=True)
+    off, flat = ref.search_radius(q, radius, e=1.5, sort=True)
+    assert np.array_equal(got.offsets, off) and np.array_equal(got.flat["distance"], flat["distance"])
+    # the same handle keeps answering box queries (metric-free)
+    if dim == 3:
+        half = np.float32(0.02 * scale)
+        boxes = np.empty((4000, 3), dtype=np.float32)
+        boxes[0::2], boxes[1::2] = q[:2000] - half, q[:2000] + half
+        b = tree.search_box(boxes)
+        boff, bflat = ref.search_box(q[:2000] - half, q[:2000] + half)
+        assert np.array_equal(b.offsets, boff) and np.array_equal(b.flat, bflat)
+
+
+def test_metric_round_trips_through_saved_file(gpu, tmp_path):
+    pts, q = ds.uniform_cloud(20_000, 3, 81), ds.uniform_cloud(3_000, 3, 82)
+    tree = pt.KdTree(pts, pt.Metric.L1, 8, device=gpu)
+    path = str(tmp_path / "l1.pkd")
+    pt.save_kd_tree(tree, path)
+    again = pt.load_kd_tree(pts, path, device=gpu)
+    assert "metric=L1" in repr(again)
+    assert again.search_knn(q, 4).tobytes() == tree.search_knn(q, 4).tobytes()
+    assert again.search_knn(q, 4).tobytes() == oracle.Oracle(pts, 8, "port", "L1").search_knn(q, 4).tobytes()

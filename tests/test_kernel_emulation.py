@@ -150,3 +150,35 @@ def test_emulated_box_search_equals_oracle(case):
     goff, gflat = emu.search_box(mins, maxs)
     assert np.array_equal(goff, off) and np.array_equal(gflat, flat)
     assert off[-1] > 0
+
+
+@pytest.mark.parametrize("metric", ["L1", "LPInf"])
+@pytest.mark.parametrize("case", ["uniform3", "ties3", "dim2", "dim5"])
+def test_emulated_kernels_other_metrics(case, metric):
+    """metric_l1 / metric_lpinf swapped into the generic kernels (the launches the backend makes
+    for ptk_tree_set_metric != L2 squared), against the oracle under the same metric."""
+    import pico_tree_amd as pt
+    if case == "uniform3":
+        pts, q, leaf = ds.uniform_cloud(20_000, 3, 31), ds.uniform_cloud(2_000, 3, 32), 10
+    elif case == "ties3":
+        pts = (np.round(ds.uniform_cloud(20_000, 3, 33) * 8) / 8).astype(np.float32)
+        q, leaf = (np.round(ds.uniform_cloud(2_000, 3, 34) * 16) / 16).astype(np.float32), 10
+    elif case == "dim2":
+        pts, q, leaf = ds.uniform_cloud(8_000, 2, 35), ds.uniform_cloud(1_500, 2, 36), 5
+    else:
+        pts, q, leaf = ds.uniform_cloud(8_000, 5, 37), ds.uniform_cloud(800, 5, 38), 8
+    emu = EmulatedTree(pts, leaf, pt.Metric[metric])
+    ref = oracle.Oracle(pts, leaf, "port", metric)
+    perm = emu.morton_permutation(q)[0] if pts.shape[1] <= 3 else None
+    for k, small in ((1, False), (1, True), (4, True), (12, False), (40, False)):
+        want = ref.search_knn(q, k)
+        assert emu.search_knn(q, k, small_stack=small).tobytes() == want.tobytes(), (k, small)
+        if perm is not None:
+            assert emu.search_knn(q, k, perm=perm, small_stack=small).tobytes() == want.tobytes(), (k, small)
+    assert emu.search_knn(q, 5, e=1.4).tobytes() == ref.search_knn(q, 5, e=1.4).tobytes()
+    radius = 0.04 * float(np.ptp(pts, axis=0).max()) * (2.0 if pts.shape[1] > 3 else 1.0)
+    for kw in ({}, {"e": 1.5}):
+        a, b = emu.search_radius(q, radius, **kw), ref.search_radius(q, radius, **kw)
+        assert np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()
+    a, b = emu.search_radius(q, radius, sort=True), ref.search_radius(q, radius, sort=True)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1]["distance"], b[1]["distance"])

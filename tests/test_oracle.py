@@ -140,6 +140,15 @@ def test_kat_metric_l2_squared():
     assert oracle.l2sq_scalar(np.float32(-3.1)) == float(np.float32(-3.1) * np.float32(-3.1))
 
 
+def test_kat_metric_l1_lpinf():
+    """metric_test.cpp:16-24 (L1) and :47-55 (LPInf)."""
+    assert oracle.distance("L1", [2, 4], [10, 1]) == 11.0
+    assert oracle.distance("LPInf", [2, 4], [10, 1]) == 8.0
+    assert oracle.distance("L2Squared", [2, 4], [10, 1]) == 73.0
+    for m in ("L1", "LPInf"):
+        assert oracle.distance_scalar(m, -3.1) == float(np.float32(3.1))
+
+
 def test_kat_python_three_points():
     """kd_tree_test.py:53-69 (knn), :90-118 (radius), :151-192 (box)."""
     a = np.array([[2, 1], [4, 3], [8, 7]], dtype=np.float32)
@@ -220,6 +229,40 @@ def test_port_equals_compiled_reference(case):
     half = np.float32(0.03 * scale)
     a, b = port.search_box(q - half, q + half), ref.search_box(q - half, q + half)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+
+
+@needs_ref
+@pytest.mark.parametrize("metric", ["L1", "LPInf"])
+@pytest.mark.parametrize("case", ["uniform3", "ties3", "lidar3", "dim2", "dim6"])
+def test_port_equals_compiled_reference_other_metrics(case, metric):
+    """The same kd_tree searched under metric_l1 / metric_lpinf (metric.hpp:78-152): the port against
+    kd_tree<space, metric_l1|metric_lpinf> of the reference, bit for bit."""
+    n, nq, leaf = 30_000, 5_000, 10
+    if case == "uniform3":
+        pts, q = ds.uniform_cloud(n, 3, 161), ds.uniform_cloud(nq, 3, 162)
+    elif case == "ties3":
+        pts = (np.round(ds.uniform_cloud(n, 3, 163) * 8) / 8).astype(np.float32)
+        q = (np.round(ds.uniform_cloud(nq, 3, 164) * 16) / 16).astype(np.float32)
+    elif case == "lidar3":
+        pts, q = ds.lidar_cloud(n, 161), ds.lidar_cloud(nq, 162, pose=(3.0, 1.5))
+    elif case == "dim2":
+        pts, q, leaf = ds.uniform_cloud(n, 2, 166), ds.uniform_cloud(nq, 2, 167), 7
+    else:
+        pts, q, leaf = ds.uniform_cloud(n, 6, 168), ds.uniform_cloud(nq, 6, 169), 12
+    port, ref = oracle.Oracle(pts, leaf, "port", metric), oracle.Oracle(pts, leaf, "reference", metric)
+    assert port.save_bytes() == ref.save_bytes()  # the tree does not depend on the metric
+    for k in (1, 7, 40):
+        assert port.search_knn(q, k).tobytes() == ref.search_knn(q, k).tobytes()
+    assert port.search_nn(q).tobytes() == ref.search_nn(q).tobytes()
+    assert port.search_knn(q, 6, e=1.3).tobytes() == ref.search_knn(q, 6, e=1.3).tobytes()
+    radius = 0.03 * float(np.ptp(pts, axis=0).max())
+    for kw in ({}, {"e": 1.5}, {"sort": True}):
+        a, b = port.search_radius(q, radius, **kw), ref.search_radius(q, radius, **kw)
+        assert np.array_equal(a[0], b[0])
+        if kw.get("sort"):
+            assert np.array_equal(a[1]["distance"], b[1]["distance"])
+        else:
+            assert a[1].tobytes() == b[1].tobytes()
 
 
 @needs_ref

@@ -39,8 +39,11 @@ def test_metric(gpu):  # kd_tree_test.py:44-51
     a = np.array(A, dtype=np.float32)
     t = pt.KdTree(a, pt.Metric.L2Squared, 10, device=gpu)
     assert t.metric(-2.0) == 4
-    with pytest.raises(ValueError):
-        pt.KdTree(a, pt.Metric.L1, 10, device=gpu)
+    t = pt.KdTree(a, pt.Metric.L1, 10, device=gpu)
+    assert t.metric(-2.0) == 2
+    assert "metric=L1" in repr(t)
+    t = pt.KdTree(a, pt.Metric.LPInf, 10, device=gpu)
+    assert t.metric(-2.0) == 2
 
 
 @pytest.mark.parametrize("e", [None, 1.0])  # kd_tree_test.py:53-89 (exact and approximate)
