@@ -197,6 +197,13 @@ int ptk_search_radius_fill(const ptk_tree* tree, const float* queries,
                            const uint64_t* offsets, ptk_neighbor* out,
                            int sort);
 
+/* Device forms.  The count pass keeps the rows it finds in a block of device
+ * memory owned by the handle (dim <= 3; PTK_RADIUS_CAPTURE_MB, default 16384,
+ * 0 = off).  A fill call whose (d_queries, nq, radius, e, stream) repeat the
+ * LAST count call on the handle -- the normal sequence -- copies them out
+ * instead of searching again; any other fill call searches again.  The
+ * contents of d_queries must not change between the two calls (they must not
+ * in the two-pass form either: d_offsets would no longer fit). */
 int ptk_search_radius_count_device(const ptk_tree* tree, const float* d_queries,
                                    uint64_t nq, float radius, float e,
                                    uint64_t* d_counts, void* stream);

@@ -56,7 +56,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     if not force and not _stale():
         return LIB
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + FLAGS + [
+    cmd = [hipcc] + FLAGS + os.environ.get("PTK_EXTRA_FLAGS", "").split() + [  # -D... of kernel experiments
         "-I" + os.path.join(ROOT, "include"),
         "-I" + CSRC,
         "-o", LIB,

@@ -95,6 +95,19 @@ struct Workspace {
   hipStream_t last_stream = nullptr;
   hipEvent_t done = nullptr;
   bool has_work = false;
+
+  // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
+  // it must survive until the fill pass of the same batch while other searches reuse `base`.
+  // The key is what the fill pass must repeat to be served from it.
+  char* cap_base = nullptr;
+  size_t cap_capacity = 0;
+  bool cap_valid = false;
+  ptk::RadiusCapture cap{};
+  const float* cap_q = nullptr;
+  uint64_t cap_nq = 0;
+  float cap_radius = 0.0f, cap_e = 0.0f;
+  int cap_metric = 0;
+  hipStream_t cap_stream = nullptr;
 };
 
 }  // namespace
@@ -539,7 +552,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
 template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
                   bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out,
-                  hipStream_t s) {
+                  hipStream_t s, const uint32_t* n_dev = nullptr) {
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
@@ -548,11 +561,70 @@ int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
                        t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
   } else {
     hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK), smem, s,
-                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
+                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out, n_dev);
   }
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, n_dev ? 0 : nq);
+  return PTK_OK;
+}
+
+// The count pass that also captures the rows.
+template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
+int launch_radius_capture(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
+                          float e, uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
+  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
+  const size_t smem = (size_t)S * BLOCK * 8;
+  Timer timer(t, s);
+  PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
+  hipLaunchKernelGGL((ptk::radius_capture_kernel<S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s,
+                     t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, cap);
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
   return PTK_OK;
+}
+
+// PTK_RADIUS_CAPTURE_MB: the most device memory the captured rows of a radius batch may take
+// (default 16384; 0 switches the capture off and every fill pass repeats the traversal).
+size_t capture_budget_bytes() {
+  const int mb = env_int("PTK_RADIUS_CAPTURE_MB", 16384);
+  return mb <= 0 ? 0 : (size_t)mb << 20;
+}
+
+// Sizes (and if needed allocates) the capture block for a batch of nq rows; false = no capture.
+// Layout: counters | captured flags | chunks.  The dynamic pool is 8 chunks (248 hits) per row
+// when the budget allows; PTK_RADIUS_CAPTURE_CHUNKS overrides chunks per sub-pool (tests).
+bool prepare_capture(uint64_t nq, Workspace& ws) {
+  const size_t budget = capture_budget_bytes();
+  if (budget == 0 || nq == 0 || nq >= (1ull << 31)) return false;
+  const size_t chunk_bytes = (size_t)ptk::kCapChunk * sizeof(ptk::Neighbor);
+  const size_t head = (size_t)ptk::kCapSubPools * ptk::kCapCounterStride * 4 + ((nq + 255) & ~(size_t)255);
+  if (head + nq * chunk_bytes > budget) return false;
+  const size_t dyn = std::min<size_t>((budget - head - nq * chunk_bytes) / chunk_bytes, nq * 8);
+  const int forced = env_int("PTK_RADIUS_CAPTURE_CHUNKS", -1);
+  size_t sub_cap = forced >= 0 ? (size_t)forced : dyn / ptk::kCapSubPools;
+  if (nq + sub_cap * ptk::kCapSubPools >= (1ull << 32)) sub_cap = ((1ull << 32) - 1 - nq) / ptk::kCapSubPools;
+  const size_t bytes = head + (nq + sub_cap * ptk::kCapSubPools) * chunk_bytes;
+  if (bytes > ws.cap_capacity) {
+    if (ws.has_work) (void)hipEventSynchronize(ws.done);
+    if (ws.cap_base) (void)hipFree(ws.cap_base);
+    ws.cap_base = nullptr;
+    ws.cap_capacity = 0;
+    ws.cap_valid = false;
+    size_t free_b = 0, total_b = 0;
+    if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || bytes > free_b / 2) return false;
+    if (hipMalloc((void**)&ws.cap_base, bytes) != hipSuccess) {
+      (void)hipGetLastError();
+      ws.cap_base = nullptr;
+      return false;
+    }
+    ws.cap_capacity = bytes;
+  }
+  ws.cap.counters = reinterpret_cast<uint32_t*>(ws.cap_base);
+  ws.cap.captured = reinterpret_cast<uint8_t*>(ws.cap_base + (size_t)ptk::kCapSubPools * ptk::kCapCounterStride * 4);
+  ws.cap.chunks = reinterpret_cast<ptk::Neighbor*>(ws.cap_base + head);
+  ws.cap.n_static = (uint32_t)nq;
+  ws.cap.sub_cap = (uint32_t)sub_cap;
+  return true;
 }
 
 // Packs the batch as {x, y, z, bits(index)} records in launch order (perm or identity).
@@ -843,6 +915,7 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->ws.has_work) (void)hipEventSynchronize(t->ws.done);
     if (t->ws.done) (void)hipEventDestroy(t->ws.done);
     if (t->ws.base) (void)hipFree(t->ws.base);
+    if (t->ws.cap_base) (void)hipFree(t->ws.cap_base);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
     if (t->d_pts) (void)hipFree(t->d_pts);
     if (t->d_ranges) (void)hipFree(t->d_ranges);
@@ -1049,16 +1122,59 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     return rc;
   }
   const bool reorder = want_reorder(t, nq);
+  const int metric = t->metric.load();
   Scratch scratch(t, s);
-  rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
-  if (rc != PTK_OK) return rc;
-  uint32_t* perm = nullptr;
-  if (reorder) {
-    rc = make_permutation(t, d_q, nq, s, scratch, &perm);
+  Workspace& ws = t->ws;  // locked by `scratch` for the duration of this call
+  // A fill pass that repeats the arguments of the last count pass is served from its capture.
+  const bool from_capture = fill && ws.cap_valid && ws.cap_q == d_q && ws.cap_nq == nq && ws.cap_radius == radius &&
+                            ws.cap_e == e && ws.cap_metric == metric && ws.cap_stream == s;
+  if (from_capture) {
+    rc = scratch.reserve(nq * 4 + 256);
     if (rc != PTK_OK) return rc;
+    uint32_t* over_list = scratch.take<uint32_t>(nq);
+    uint32_t* n_over = scratch.take<uint32_t>(1);
+    if (over_list == nullptr || n_over == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
+    {
+      Timer timer(t, s);
+      PTK_HIP(hipMemsetAsync(n_over, 0, 4, s));
+      constexpr int G = 32;
+      const uint64_t threads = nq * G;
+      hipLaunchKernelGGL((ptk::radius_scatter_kernel<G>), dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s,
+                         ws.cap, nq, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over);
+      PTK_HIP(hipGetLastError());
+      timer.stop(0, 0);
+    }
+    // Rows the capture could not hold (possibly none: the blocks then leave at once).
+    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
+                                                                       d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
+                                                                       s, n_over))));
+  } else {
+    const bool capture = !fill && prepare_capture(nq, ws);
+    if (!fill) ws.cap_valid = false;
+    rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
+    if (rc != PTK_OK) return rc;
+    uint32_t* perm = nullptr;
+    if (reorder) {
+      rc = make_permutation(t, d_q, nq, s, scratch, &perm);
+      if (rc != PTK_OK) return rc;
+    }
+    if (capture) {
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_capture<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, d_counts,
+                                                                                 ws.cap, s))));
+      if (rc == PTK_OK) {
+        ws.cap_valid = true;
+        ws.cap_q = d_q;
+        ws.cap_nq = nq;
+        ws.cap_radius = radius;
+        ws.cap_e = e;
+        ws.cap_metric = metric;
+        ws.cap_stream = s;
+      }
+    } else {
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
+                                                                         d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    }
   }
-  PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
-                                                                     d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   if (rc == PTK_OK && fill && sort) {
     Timer timer(t, s);
     const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);

@@ -77,6 +77,13 @@ struct Neighbor {
   float distance;
 };
 
+// "All four words of this float4 are used here" (no instruction): keeps a 16-byte record load whole.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define PTK_KEEP4(P) asm volatile("" ::"v"((P).x), "v"((P).y), "v"((P).z), "v"((P).w))
+#else
+#define PTK_KEEP4(P) ((void)0)
+#endif
+
 // LDS pointers carry their address space explicitly so that every stack / k-list access
 // is a ds_read / ds_write; a generic pointer makes hipcc fall back to flat_* accesses,
 // which go through the vector-memory pipe and cost hundreds of cycles each.
@@ -376,21 +383,70 @@ struct KnnRegPolicy {
   }
 };
 
-template <bool FILL>
+// Rows captured during the count pass.  The radius search is a count pass, a scan and a fill pass;
+// the fill pass repeats the whole traversal only to learn where each hit goes.  With a capture the
+// count pass also writes every hit into a chain of 256-byte chunks -- chunk qi is the first chunk
+// of row qi, later ones come from kCapSubPools bump allocators (one atomic per 31 hits, the
+// counters on separate cache lines, a wavefront staying with the pool of its block: atomics of
+// one wavefront on many lines were measured 1.6x slower for the whole pass) -- and the fill pass
+// becomes a copy (radius_scatter_kernel).  The next chunk is claimed when the current one is half
+// full and the answer is only looked at when it is needed.  A row whose chain could not grow is
+// marked and searched again by the ordinary fill kernel: a small pool costs time, never
+// correctness.  Entry 0 of a chunk is its header: .index = next chunk.
+// (Measured and rejected, profiles/r01l_notes.txt: a per-wavefront log of hits in LDS flushed 64
+// entries at a time with full-width stores -- every KB of LDS per wavefront costs more occupancy
+// than the stores give back.)
+constexpr uint32_t kCapChunk = 32;           // 8-byte entries per chunk, header included
+constexpr uint32_t kCapSubPools = 256;
+constexpr uint32_t kCapCounterStride = 16;   // words between counters: one 64-byte line each
+
+struct RadiusCapture {
+  Neighbor* chunks;     // (n_static + kCapSubPools * sub_cap) * kCapChunk entries
+  uint32_t* counters;   // kCapSubPools * kCapCounterStride words, zero before the count pass
+  uint8_t* captured;    // per query: 1 = the whole row is in its chain
+  uint32_t n_static;    // queries of the batch
+  uint32_t sub_cap;     // chunks per sub-pool
+};
+
+constexpr int kRadiusCount = 0, kRadiusFill = 1, kRadiusCapture = 2;
+
+template <int MODE>
 struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
   float radius;  // already scaled by 1/e for the approximate search (:265)
   float e_inv;
   uint64_t count;
-  Neighbor* out;  // FILL: first record of this query's row
+  Neighbor* out;  // fill: first record of this query's row; capture: the chunk array
+  // capture only
+  uint32_t* counters;
+  uint32_t cur, pos, next, sub, sub_cap, n_static;
+  bool capturing;
   __device__ __forceinline__ float max() const { return radius; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
     if (radius > d) {  // strict
-      if (FILL) {
-        Neighbor nb;
-        nb.index = idx;
-        nb.distance = d;
-        out[count] = nb;
+      Neighbor nb;
+      nb.index = idx;
+      nb.distance = d;
+      if (MODE == kRadiusFill) out[count] = nb;
+      if (MODE == kRadiusCapture && capturing) {
+        if (pos == kCapChunk) {  // the chunk claimed half a chunk ago: was there room?
+          if (next < sub_cap) {
+            const uint32_t id = n_static + sub * sub_cap + next;
+            Neighbor link;
+            link.index = (int32_t)id;
+            link.distance = 0.0f;
+            out[(uint64_t)cur * kCapChunk] = link;
+            cur = id;
+            pos = 1;
+          } else {
+            capturing = false;
+          }
+        }
+        if (capturing) {
+          out[(uint64_t)cur * kCapChunk + pos] = nb;
+          ++pos;
+          if (pos == kCapChunk / 2) next = atomicAdd(&counters[sub * kCapCounterStride], 1u);
+        }
       }
       ++count;
     }
@@ -443,6 +499,10 @@ __device__ __forceinline__ void traverse(
 #pragma unroll
         for (int u = 0; u < LEAFB; ++u) {
           if (j + u < count) {
+            // All four words of the record are needed HERE: without this the compiler narrows the
+            // 16-byte load to 12 bytes and fetches the index with a second, dependent load inside
+            // the branch that stores a hit (radius fill pass: +10 ms of 27 on BASELINE config 3).
+            PTK_KEEP4(p[u]);
             const float dx = f_sub(qx, p[u].x);
             const float dy = f_sub(qy, p[u].y);
             const float dz = f_sub(qz, p[u].z);
@@ -620,12 +680,15 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
 }
 
 // ---- radius: count pass and fill pass ------------------------------------------------------
+// n_dev (fill pass only): the batch is the first *n_dev entries of perm -- the rows a capture
+// could not hold, listed on the device (no host round trip to size the launch).
 template <int S, int OVF, int BLOCK, int LEAFB, bool FILL, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void radius_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
     uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
-    Neighbor* __restrict__ out) {
+    Neighbor* __restrict__ out, const uint32_t* __restrict__ n_dev = nullptr) {
+  if (n_dev != nullptr) nq = *n_dev;
   const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
@@ -636,13 +699,78 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   Record spill[OVF > 0 ? OVF : 1];
   Stack<S, OVF, BLOCK> st;
   st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
-  RadiusPolicy<FILL> pol;
+  RadiusPolicy<FILL ? kRadiusFill : kRadiusCount> pol;
   pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
   pol.e_inv = e_inv;
   pol.count = 0;
   pol.out = FILL ? out + offsets[qi] : nullptr;
   traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   if (!FILL) counts[qi] = pol.count;
+}
+
+// The count pass that also captures the rows (see RadiusCapture).
+template <int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2>
+__global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
+    DevTree t, const float* __restrict__ queries, uint32_t dim,
+    const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
+    uint64_t* __restrict__ counts, RadiusCapture cap) {
+  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[i] : i;
+  float qx, qy, qz;
+  load_query(queries, dim, qi, qx, qy, qz);
+
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, BLOCK> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  RadiusPolicy<kRadiusCapture> pol;
+  pol.radius = f_mul(radius, e_inv);
+  pol.e_inv = e_inv;
+  pol.count = 0;
+  pol.out = cap.chunks;
+  pol.counters = cap.counters;
+  pol.cur = (uint32_t)qi;
+  pol.pos = 1;
+  pol.next = 0xFFFFFFFFu;
+  pol.sub = (blockIdx.x * 0x9E3779B1u) >> 24;  // kCapSubPools = 256: the top byte of a hash of the block
+  pol.sub_cap = cap.sub_cap;
+  pol.n_static = cap.n_static;
+  pol.capturing = true;
+  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
+  counts[qi] = pol.count;
+  cap.captured[qi] = pol.capturing ? 1 : 0;
+}
+
+// The fill pass of a captured batch: G lanes copy one row out of its chain, one chunk per step at
+// G = 32 (lane j moves entry j; the header rides along and gives the next chunk).  Rows of up to
+// 31 hits -- most -- lie in the static chunks, which are in row order like the output: for them
+// this is a coalesced stream compaction.  Rows that were not captured are listed for
+// radius_kernel<FILL>.
+template <int G>
+__global__ __launch_bounds__(256) void radius_scatter_kernel(
+    RadiusCapture cap, uint64_t nq, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out,
+    uint32_t* __restrict__ over_list, uint32_t* __restrict__ n_over) {
+  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t qi = tid / G;
+  const uint32_t sub = (uint32_t)(tid % G);
+  if (qi >= nq) return;
+  const uint64_t o = offsets[qi];
+  const uint64_t c = offsets[qi + 1] - o;
+  if (!cap.captured[qi]) {
+    if (sub == 0) over_list[atomicAdd(n_over, 1u)] = (uint32_t)qi;
+    return;
+  }
+  uint32_t chunk = (uint32_t)qi;
+  for (uint64_t done = 0; done < c;) {
+    const Neighbor* base = cap.chunks + (uint64_t)chunk * kCapChunk;
+    const uint64_t left = c - done;
+    const uint32_t n = left < kCapChunk - 1 ? (uint32_t)left : kCapChunk - 1;
+    const uint32_t link = left > kCapChunk - 1 ? (uint32_t)base[0].index : 0u;  // same address in all G lanes
+    for (uint32_t j = sub; j < n; j += G) out[o + done + j] = base[1 + j];
+    done += n;
+    chunk = link;
+  }
 }
 
 // ---- two-phase k = 1 search ---------------------------------------------------------------

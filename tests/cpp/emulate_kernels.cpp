@@ -96,6 +96,11 @@ struct Emu {
   ptk::DevTreeND dev_nd;
   uint32_t dim;
   int metric = 0;
+  // rows captured by emu_radius_capture (ptk::RadiusCapture)
+  std::vector<ptk::Neighbor> cap_chunks;
+  std::vector<uint32_t> cap_counters;
+  std::vector<uint8_t> cap_flags;
+  ptk::RadiusCapture cap{};
 };
 
 // Kernels whose lanes are independent: every lane of every block, sequentially.
@@ -353,6 +358,46 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   }, 64);
   if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
   return 0;
+}
+
+// The capturing count pass (dim <= 3, L2): sub_cap dynamic chunks per sub-pool -- 0 leaves only
+// the static first chunk of every row, so rows above 31 hits take the re-traversal path.
+int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
+                       uint64_t* counts, uint32_t sub_cap) {
+  auto* t = static_cast<Emu*>(h);
+  if (t->dim > 3 || t->metric != 0) return -3;
+  t->cap_chunks.assign(((size_t)nq + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kCapChunk, ptk::Neighbor{-1, -1.0f});
+  t->cap_counters.assign(ptk::kCapSubPools * ptk::kCapCounterStride, 0u);
+  t->cap_flags.assign(nq, 2);
+  t->cap.chunks = t->cap_chunks.data();
+  t->cap.counters = t->cap_counters.data();
+  t->cap.captured = t->cap_flags.data();
+  t->cap.n_static = (uint32_t)nq;
+  t->cap.sub_cap = sub_cap;
+  const float e_inv = 1.0f / e;
+  for_each_lane(nq, [&] {
+    ptk::radius_capture_kernel<8, 2048, 64, 4>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
+  }, 64);
+  return 0;
+}
+
+// The fill pass of a captured batch: copy, then the ordinary fill kernel over the listed rows.
+// Returns the number of rows that had to be searched again (or a negative status).
+int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float radius, float e,
+                                 const uint64_t* offsets, ptk_neighbor* out, int sort) {
+  auto* t = static_cast<Emu*>(h);
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  if (t->cap_flags.size() != nq) return -1;
+  std::vector<uint32_t> over(nq + 1, 0u);
+  uint32_t n_over = 0;
+  const float e_inv = 1.0f / e;
+  for_each_lane(nq * 32, [&] { ptk::radius_scatter_kernel<32>(t->cap, nq, offsets, o, over.data(), &n_over); }, 256);
+  for_each_lane(nq, [&] {
+    ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o,
+                                              &n_over);
+  }, 64);
+  if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
+  return (int64_t)n_over;
 }
 
 // The two-phase k = 1 search: phase 1, sort by continuation key (stable sort standing in for the

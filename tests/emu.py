@@ -38,6 +38,7 @@ class EmulatedTree:
     def __init__(self, pts, leaf, metric=pt.Metric.L2Squared):
         self.lib = _lib()
         self.pts = np.ascontiguousarray(pts, dtype=np.float32)
+        self.leaf = int(leaf)
         self.host = pt.KdTree(self.pts, metric, leaf, device=pt.PTK_DEVICE_NONE)
         nodes, idx, self.rmin, self.rmax = self.host.flat()
         self.h = self.lib.emu_create(self.pts.ctypes.data, len(self.pts), self.pts.shape[1],
@@ -74,6 +75,27 @@ class EmulatedTree:
         self.lib.emu_radius_fill(self.h, q.ctypes.data, nq, radius, e or 1.0, p, off.ctypes.data,
                                  out.ctypes.data, int(sort))
         return off, out
+
+    def search_radius_captured(self, q, radius, sort=False, e=None, perm=None, sub_cap=64):
+        """Count pass with capture, then the copy (+ re-traversal of rows that did not fit)."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        nq = len(q)
+        p = perm.ctypes.data if perm is not None else None
+        counts = np.zeros(nq + 1, dtype=np.uint64)
+        self.lib.emu_radius_capture.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_void_p,
+                                                c_uint32]
+        assert self.lib.emu_radius_capture(self.h, q.ctypes.data, nq, radius, e or 1.0, p, counts.ctypes.data,
+                                           sub_cap) == 0
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(counts[:nq])
+        out = np.zeros(int(off[-1]), dtype=pt.NEIGHBOR)
+        self.lib.emu_radius_fill_captured.restype = ctypes.c_int64
+        self.lib.emu_radius_fill_captured.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p,
+                                                      c_void_p, c_int]
+        redone = self.lib.emu_radius_fill_captured(self.h, q.ctypes.data, nq, radius, e or 1.0, off.ctypes.data,
+                                                   out.ctypes.data, int(sort))
+        assert redone >= 0
+        return off, out, int(redone)
 
     # -- persistent (state machine + lane refill) kernels: 64 host threads per wavefront --
     def search_box(self, mins, maxs):

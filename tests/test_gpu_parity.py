@@ -306,3 +306,58 @@ def test_metric_round_trips_through_saved_file(gpu, tmp_path):
     assert "metric=L1" in repr(again)
     assert again.search_knn(q, 4).tobytes() == tree.search_knn(q, 4).tobytes()
     assert again.search_knn(q, 4).tobytes() == oracle.Oracle(pts, 8, "port", "L1").search_knn(q, 4).tobytes()
+
+
+@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "40"},
+                                 {"PTK_RADIUS_CAPTURE_MB": "0"}, {"PTK_RADIUS_CAPTURE_MB": "2"}],
+                         ids=["default", "static-chunk-only", "pool-runs-dry", "capture-off", "budget-too-small"])
+@pytest.mark.parametrize("cloud,radius", [("lidar", 1.0), ("ties", 0.03)])
+def test_radius_rows_captured_in_the_count_pass(trees, monkeypatch, env, cloud, radius):
+    """The count pass captures the rows and the fill pass copies them (RadiusCapture in
+    ptk_kernels.hpp); rows that did not fit are searched again.  Same bytes in every regime."""
+    import torch
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    tree, ref, _, q = trees(cloud)
+    want_off, want = ref.search_radius(q, radius)
+    got = tree.search_radius(q, radius)
+    assert np.array_equal(got.offsets, want_off) and got.flat.tobytes() == want.tobytes()
+    dq = torch.from_numpy(q).cuda()
+    off, raw = tree.search_radius_device(dq, radius)
+    assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+    assert raw.cpu().numpy().tobytes() == want.tobytes()
+    want_off, want = ref.search_radius(q, radius, e=1.5, sort=True)
+    off, raw = tree.search_radius_device(dq, radius, 1.5, sort=True)
+    assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+    assert np.array_equal(raw.cpu().numpy()[:, 1].view(np.float32), want["distance"])
+
+
+def test_radius_fill_that_does_not_match_the_last_count(trees):
+    """count(A), count(B), fill(A): the capture belongs to B, so A's fill must search again."""
+    import ctypes
+    import torch
+    tree, ref, _, q = trees("uniform")
+    lib = pt._load()
+    radius = 0.0015
+    a, b = torch.from_numpy(q[:9000]).cuda(), torch.from_numpy(q[9000:18000].copy()).cuda()
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def count(t):
+        c = torch.zeros(len(t) + 1, dtype=torch.int64, device="cuda")
+        assert lib.ptk_search_radius_count_device(tree._h, t.data_ptr(), len(t), ctypes.c_float(radius),
+                                                  ctypes.c_float(1.0), c.data_ptr(), stream) == 0
+        off = torch.zeros(len(t) + 1, dtype=torch.int64, device="cuda")
+        off[1:] = torch.cumsum(c[:len(t)], 0)
+        return off
+
+    def fill(t, off):
+        out = torch.empty((max(int(off[-1].item()), 1), 2), dtype=torch.int32, device="cuda")
+        assert lib.ptk_search_radius_fill_device(tree._h, t.data_ptr(), len(t), ctypes.c_float(radius),
+                                                 ctypes.c_float(1.0), off.data_ptr(), out.data_ptr(), 0, stream) == 0
+        return out[:int(off[-1].item())].cpu().numpy()
+
+    off_a, off_b = count(a), count(b)
+    for t, off, rows in ((a, off_a, q[:9000]), (b, off_b, q[9000:18000]), (a, off_a, q[:9000])):
+        want_off, want = ref.search_radius(rows, radius)
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+        assert fill(t, off).tobytes() == want.tobytes()

@@ -182,3 +182,30 @@ def test_emulated_kernels_other_metrics(case, metric):
         assert np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()
     a, b = emu.search_radius(q, radius, sort=True), ref.search_radius(q, radius, sort=True)
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1]["distance"], b[1]["distance"])
+
+
+@pytest.mark.parametrize("sub_cap", [1024, 0, 8])
+def test_emulated_radius_capture(sub_cap):
+    """The capturing count pass + copy (RadiusCapture): rows equal the two-pass result whether the
+    chunk pool is ample, absent (static chunk only) or runs dry (chains break off midway)."""
+    pts, q = ds.uniform_cloud(20_000, 3, 41), ds.uniform_cloud(3_000, 3, 42)
+    q[:200] = pts[:200]  # dense spots: a few long rows
+    q = q[:2_990]        # the last wavefront is partly empty
+    emu = EmulatedTree(pts, 10)
+    ref = oracle.Oracle(pts, 10, "port")
+    perm, _ = emu.morton_permutation(q)
+    for radius, e in ((0.0004, None), (0.01, None), (0.03, None), (0.02, 1.6)):
+        want_off, want = ref.search_radius(q, radius, e=e)
+        long_rows = int((np.diff(want_off.astype(np.int64)) > 31).sum())
+        for pm in (None, perm):
+            off, got, redone = emu.search_radius_captured(q, radius, e=e, perm=pm, sub_cap=sub_cap)
+            assert np.array_equal(off, want_off) and got.tobytes() == want.tobytes()
+            if sub_cap == 1024:
+                assert redone == 0
+            elif sub_cap == 0:
+                assert redone == long_rows
+            else:
+                assert redone <= long_rows and (radius < 0.03 or redone > 0)
+    off, got, _ = emu.search_radius_captured(q, 0.03, sort=True, sub_cap=1024)
+    _, want = ref.search_radius(q, 0.03, sort=True)
+    assert np.array_equal(got["distance"], want["distance"])
