@@ -25,6 +25,7 @@
 #include <cstdint>
 #include <future>
 #include <limits>
+#include <stdexcept>
 #include <type_traits>
 #include <vector>
 
@@ -312,6 +313,7 @@ class flat_builder {
 
   //! Ranges below this many points are not worth a task.
   static constexpr std::ptrdiff_t kParallelMin = 20000;
+  static constexpr std::uint32_t kMaxBuildDepth = 8192;
 
   //! Appends the nodes of a separately built subtree; its right-child links are relative to its
   //! own first node.
@@ -330,6 +332,10 @@ class flat_builder {
 
   std::uint32_t grow(
       std::uint32_t depth, Index_* begin, Index_* end, box_type& box, int task_levels = 0) {
+    // Degenerate input (thousands of identical points with a small leaf size) makes the sliding
+    // midpoint peel off one point per level; the reference recurses until its stack overflows.
+    if (depth > kMaxBuildDepth)
+      throw std::length_error("kd_tree: the tree is deeper than 8192 levels (degenerate point set?)");
     std::uint32_t const self = static_cast<std::uint32_t>(tree_.nodes.size());
     tree_.nodes.emplace_back();
     if (tree_.keep_outer_bounds) tree_.outer_bounds.push_back({scalar_type(0), scalar_type(0)});

@@ -899,6 +899,9 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
   } catch (const std::bad_alloc&) {
     delete t;
     return fail(PTK_ERR_NOMEM, "out of memory");
+  } catch (const std::length_error& err) {  // degenerate point set: see flat_builder::grow
+    delete t;
+    return fail(PTK_ERR_UNSUPPORTED, "%s", err.what());
   }
   return finish_create(t, points, device, out);
 }
@@ -1533,6 +1536,8 @@ int ptk_forest_create(const float* points, uint64_t n_points, uint32_t dim, uint
     rc = guard.ok ? forest_build(f, points, max_leaf_size, seed) : fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", dev);
   } catch (const std::bad_alloc&) {
     rc = fail(PTK_ERR_NOMEM, "out of memory");
+  } catch (const std::length_error& err) {
+    rc = fail(PTK_ERR_UNSUPPORTED, "%s", err.what());
   }
   if (rc != PTK_OK) {
     ptk_forest_destroy(f);

@@ -173,3 +173,14 @@ def test_threaded_build_gives_the_identical_tree(monkeypatch):
     for other in flats[1:]:
         assert np.array_equal(other[0], flats[0][0]) and np.array_equal(other[1], flats[0][1])
         assert other[2:] == flats[0][2:]
+
+
+def test_degenerate_point_set_is_refused_not_crashed():
+    """Thousands of identical points with a small leaf size make the sliding midpoint peel one
+    point per level: the reference recurses until its stack overflows; the build here stops at
+    8192 levels with PTK_ERR_UNSUPPORTED."""
+    pts = np.full((60_000, 1), 0.5e-6, dtype=np.float32)
+    with pytest.raises(pt.PtkError, match="deeper than 8192"):
+        pt.KdTree(pts, pt.Metric.L2Squared, 5, device=pt.PTK_DEVICE_NONE)
+    t = pt.KdTree(np.full((6_000, 3), 1.5, dtype=np.float32), pt.Metric.L2Squared, 2, device=pt.PTK_DEVICE_NONE)
+    assert len(t.flat()[0]) == 11_997  # deep (2 999 levels) but built

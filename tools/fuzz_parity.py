@@ -1,0 +1,129 @@
+#!/usr/bin/env python3
+"""Randomised differential test on the GPU: libptk (through the Python host / C ABI) against the
+oracle's CPU restatement on random trees, batches and search parameters.  Bit-exact comparison
+(indices and float32 distance bits); radius rows in traversal order.  Prints one line per failing
+case with everything needed to replay it (--seed S --case I), and a summary.
+
+    python tools/fuzz_parity.py --cases 200 --seed 1
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+VERBOSE = False
+
+
+def make_cloud(rng, kind, n, dim):
+    if kind == "uniform":
+        p = rng.random((n, dim))
+    elif kind == "clustered":
+        c = rng.random((max(1, n // 200), dim))
+        p = c[rng.integers(0, len(c), n)] + rng.normal(0, 0.01, (n, dim))
+    elif kind == "lattice":
+        p = np.round(rng.random((n, dim)) * 6) / 6
+    elif kind == "duplicates":
+        base = rng.random((max(1, n // 3), dim))
+        p = base[rng.integers(0, len(base), n)]
+    elif kind == "line":
+        t = rng.random((n, 1))
+        p = t * rng.random((1, dim)) + 0.25
+    elif kind == "plane":
+        p = rng.random((n, dim))
+        p[:, -1] = 0.5
+    else:
+        raise ValueError(kind)
+    return p
+
+
+def one_case(rng, pt, oracle, torch, case):
+    dim = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7]))
+    n = int(rng.choice([1, 2, 9, 100, 3000, 20000, 60000]))
+    nq = int(rng.choice([1, 63, 64, 65, 1000, 5000]))
+    leaf = int(rng.choice([1, 2, 5, 10, 16, 24]))
+    kind = str(rng.choice(["uniform", "clustered", "lattice", "duplicates", "line", "plane"]))
+    scale = float(rng.choice([1.0, 1.0, 1e-6, 1e6, 37.5]))
+    shift = float(rng.choice([0.0, 0.0, -0.5, 100.0]))
+    metric = str(rng.choice(["L2Squared", "L2Squared", "L1", "LPInf"]))
+    pts = ((make_cloud(rng, kind, n, dim) + shift) * scale).astype(np.float32)
+    if rng.random() < 0.5:
+        q = ((make_cloud(rng, kind, nq, dim) + shift) * scale).astype(np.float32)
+    else:  # queries near / on tree points
+        q = pts[rng.integers(0, n, nq)] + (rng.normal(0, 1e-3, (nq, dim)) * scale * (rng.random() < 0.7)).astype(np.float32)
+        q = q.astype(np.float32)
+    desc = f"case {case}: dim {dim} n {n} nq {nq} leaf {leaf} {kind} scale {scale} shift {shift} {metric}"
+    if VERBOSE:
+        print(desc, flush=True)
+    tree = pt.KdTree(pts, pt.Metric[metric], leaf, device=0)
+    tree.set_reorder(int(rng.choice([pt.REORDER_AUTO, pt.REORDER_ON, pt.REORDER_OFF])))
+    ref = oracle.Oracle(pts, leaf, "port", metric)
+    bad = []
+    for k in {1, int(rng.integers(1, min(n, 48) + 1)), min(n, int(rng.choice([2, 8, 33, 64])))}:
+        e = float(rng.choice([1.0, 1.0, 1.3, 4.0]))
+        want = ref.search_knn(q, k, e=None if e == 1.0 else e)
+        got = tree.search_knn(q, k) if e == 1.0 else tree.search_knn(q, k, e)
+        if got.reshape(want.shape).tobytes() != want.tobytes():
+            bad.append(f"knn k={k} e={e}")
+    nn = ref.search_knn(q, min(n, 4))["distance"][:, -1]
+    radius = float(np.quantile(nn, rng.choice([0.1, 0.5, 0.9])) * rng.choice([1.0, 4.0])) or float(scale * 0.01)
+    e = float(rng.choice([1.0, 1.0, 2.0]))
+    off, flat = ref.search_radius(q, radius, e=None if e == 1.0 else e)
+    got = tree.search_radius(q, radius) if e == 1.0 else tree.search_radius(q, radius, e)
+    if not np.array_equal(got.offsets, off) or got.flat.tobytes() != flat.tobytes():
+        bad.append(f"radius r={radius} e={e}")
+    dq = torch.from_numpy(q).cuda()
+    doff, draw = tree.search_radius_device(dq, radius, e)
+    if not np.array_equal(doff.cpu().numpy().astype(np.uint64), off) or draw.cpu().numpy().tobytes() != flat.tobytes():
+        bad.append(f"radius (device buffers) r={radius} e={e}")
+    if dim <= 3:
+        half = (rng.random((nq, dim)) * scale * 0.05).astype(np.float32)
+        boxes = np.empty((2 * nq, dim), dtype=np.float32)
+        boxes[0::2], boxes[1::2] = q - half, q + half
+        boff, bflat = ref.search_box(boxes[0::2].copy(), boxes[1::2].copy())
+        b = tree.search_box(boxes)
+        if not np.array_equal(b.offsets, boff) or not np.array_equal(b.flat, bflat):
+            bad.append("box")
+    tree.close()
+    return desc, bad
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cases", type=int, default=100)
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--case", type=int, default=-1, help="replay only this case")
+    ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
+    args = ap.parse_args()
+    import torch
+    import oracle
+    import pico_tree_amd as pt
+    global VERBOSE
+    VERBOSE = args.verbose
+    failures = unsupported = 0
+    for case in range(args.cases):
+        rng = np.random.default_rng([args.seed, case])
+        if args.case >= 0 and case != args.case:
+            continue
+        try:
+            desc, bad = one_case(rng, pt, oracle, torch, case)
+        except pt.PtkError as err:  # the one documented limit: degenerate trees deeper than the device stack
+            if "too deep" not in str(err) and "deeper than" not in str(err):
+                raise
+            unsupported += 1
+            continue
+        if bad:
+            failures += 1
+            print("FAIL", desc, "->", "; ".join(bad), flush=True)
+    print(f"fuzz: {args.cases} cases, seed {args.seed}, {failures} failing, "
+          f"{unsupported} refused (degenerate tree deeper than the device stack / the build limit)", flush=True)
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
