@@ -110,6 +110,19 @@ struct Workspace {
   hipStream_t cap_stream = nullptr;
 };
 
+// Device-side staging of the host-buffer entry points (ptk_search_knn with host pointers): kept
+// with the handle so that a call costs two copies and a search, not two hipMalloc / hipFree pairs
+// (hipFree synchronises the device) and a stream.  Calls that use it are serialised by `mutex`.
+struct HostIo {
+  std::mutex mutex;
+  hipStream_t stream = nullptr;       // uploads and searches
+  hipStream_t down_stream = nullptr;  // downloads, behind `searched`
+  hipEvent_t searched[2] = {nullptr, nullptr};
+  char* d_in = nullptr;
+  char* d_out = nullptr;
+  size_t in_capacity = 0, out_capacity = 0;
+};
+
 }  // namespace
 
 struct ptk_tree {
@@ -139,6 +152,7 @@ struct ptk_tree {
   std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
   mutable Profile profile;
   mutable Workspace ws;
+  mutable HostIo io;
 };
 
 namespace {
@@ -919,6 +933,12 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->ws.done) (void)hipEventDestroy(t->ws.done);
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->ws.cap_base) (void)hipFree(t->ws.cap_base);
+    if (t->io.d_in) (void)hipFree(t->io.d_in);
+    if (t->io.d_out) (void)hipFree(t->io.d_out);
+    if (t->io.stream) (void)hipStreamDestroy(t->io.stream);
+    if (t->io.down_stream) (void)hipStreamDestroy(t->io.down_stream);
+    for (hipEvent_t ev : t->io.searched)
+      if (ev) (void)hipEventDestroy(ev);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
     if (t->d_pts) (void)hipFree(t->d_pts);
     if (t->d_ranges) (void)hipFree(t->d_ranges);
@@ -1072,6 +1092,22 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   return rc;
 }
 
+// Grow-only device block of the host-buffer entry points (rounded up to 1 MiB; the old contents are dropped).
+static int grow_device_block(char** p, size_t* capacity, size_t bytes) {
+  if (bytes <= *capacity) return PTK_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr;
+  *capacity = 0;
+  const size_t want = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+  if (hipMalloc((void**)p, want) != hipSuccess) {
+    (void)hipGetLastError();
+    *p = nullptr;
+    return fail(PTK_ERR_NOMEM, "out of device memory (%zu bytes)", want);
+  }
+  *capacity = want;
+  return PTK_OK;
+}
+
 int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, float e, ptk_neighbor* out) {
   int rc = check_search(t, q, nq);
   if (rc != PTK_OK) return rc;
@@ -1079,26 +1115,56 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
   if (out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
-  hipStream_t s = nullptr;
-  PTK_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  float* d_q = nullptr;
-  ptk_neighbor* d_out = nullptr;
   const size_t qbytes = (size_t)nq * t->dim * sizeof(float);
   const size_t obytes = (size_t)nq * (k ? k : 1) * sizeof(ptk_neighbor);
-  hipError_t he = hipMalloc((void**)&d_q, qbytes);
-  if (he == hipSuccess) he = hipMalloc((void**)&d_out, obytes);
-  if (he == hipSuccess) he = hipMemcpyAsync(d_q, q, qbytes, hipMemcpyHostToDevice, s);
-  if (he == hipSuccess) {
-    rc = ptk_search_knn_device(t, d_q, nq, k, e, d_out, s);
-    if (rc == PTK_OK) he = hipMemcpyAsync(out, d_out, obytes, hipMemcpyDeviceToHost, s);
+  HostIo& io = t->io;
+  std::lock_guard<std::mutex> lock(io.mutex);
+  if (io.stream == nullptr) PTK_HIP(hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking));
+  rc = grow_device_block(&io.d_in, &io.in_capacity, qbytes);
+  if (rc == PTK_OK) rc = grow_device_block(&io.d_out, &io.out_capacity, obytes);
+  if (rc != PTK_OK) return rc;
+  if (io.down_stream == nullptr) PTK_HIP(hipStreamCreateWithFlags(&io.down_stream, hipStreamNonBlocking));
+  for (hipEvent_t& ev : io.searched)
+    if (ev == nullptr) PTK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  float* d_q = reinterpret_cast<float*>(io.d_in);
+  ptk_neighbor* d_out = reinterpret_cast<ptk_neighbor*>(io.d_out);
+  // Large results go down in pieces while the next piece is searched (the link is full duplex and
+  // the download of k = 16 rows takes twice as long as the search): piece c + 1 is uploaded and
+  // enqueued BEFORE the download of piece c is issued, because a copy to pageable memory keeps the
+  // calling thread until it is done.
+  // (Measured on BASELINE config 3, knn = 16, 922 MB of rows: 1 / 2 / 3 / 4 pieces 27.3 / 24.5 / 23.6 / 25.3 ms
+  // on cloud L -- every piece pays the slowest queries of its own -- and 24.6 / 21.6 / 20.7 / 20.1 on cloud U.)
+  const int forced_pieces = env_int("PTK_HOST_PIECES", 0);
+  const uint64_t pieces = forced_pieces > 0 ? (uint64_t)forced_pieces
+                                            : std::min<uint64_t>(std::max<uint64_t>(obytes / (size_t(256) << 20), 1), 3);
+  const uint64_t per = (nq + pieces - 1) / pieces;
+  const size_t row_out = (size_t)(k ? k : 1) * sizeof(ptk_neighbor);
+  hipError_t he = hipSuccess;
+  uint64_t down_lo = 0, down_n = 0;  // the piece waiting for its download
+  for (uint64_t c = 0, lo = 0; lo < nq && he == hipSuccess && rc == PTK_OK; ++c, lo += per) {
+    const uint64_t n = std::min<uint64_t>(per, nq - lo);
+    he = hipMemcpyAsync(d_q + lo * t->dim, q + lo * t->dim, (size_t)n * t->dim * sizeof(float), hipMemcpyHostToDevice,
+                        io.stream);
+    if (he != hipSuccess) break;
+    rc = ptk_search_knn_device(t, d_q + lo * t->dim, n, k, e, d_out + lo * (k ? k : 1), io.stream);
+    if (rc != PTK_OK) break;
+    he = hipEventRecord(io.searched[c & 1], io.stream);
+    if (he == hipSuccess && down_n > 0)
+      he = hipMemcpyAsync(reinterpret_cast<char*>(out) + down_lo * row_out, io.d_out + down_lo * row_out,
+                          (size_t)down_n * row_out, hipMemcpyDeviceToHost, io.down_stream);
+    if (he == hipSuccess) he = hipStreamWaitEvent(io.down_stream, io.searched[c & 1], 0);
+    down_lo = lo;
+    down_n = n;
   }
-  hipError_t hs = hipStreamSynchronize(s);
-  if (d_q) (void)hipFree(d_q);
-  if (d_out) (void)hipFree(d_out);
-  (void)hipStreamDestroy(s);
+  if (he == hipSuccess && rc == PTK_OK && down_n > 0)
+    he = hipMemcpyAsync(reinterpret_cast<char*>(out) + down_lo * row_out, io.d_out + down_lo * row_out,
+                        (size_t)down_n * row_out, hipMemcpyDeviceToHost, io.down_stream);
+  hipError_t hs = hipStreamSynchronize(io.stream);
+  hipError_t hd = hipStreamSynchronize(io.down_stream);
   if (rc != PTK_OK) return rc;
   if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
   if (hs != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(hs));
+  if (hd != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(hd));
   return PTK_OK;
 }
 
