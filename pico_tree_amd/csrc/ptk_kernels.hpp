@@ -152,8 +152,12 @@ __device__ __forceinline__ float point_distance3(float dx, float dy, float dz) {
 // ovf[i]).  S is a power of two.
 template <int S, int OVF, int BLOCK>
 struct Stack {
-  static_assert((S & (S - 1)) == 0 && S >= 4, "S must be a power of two");
+  static_assert(S >= 4, "ring too small");
   static constexpr int kRefill = S / 2 < 8 ? S / 2 : 8;
+  // Ring slot of record i (a power of two is a mask; other sizes a multiply-shift).
+  static __device__ __forceinline__ int slot(int i) {
+    return (S & (S - 1)) == 0 ? (i & (S - 1)) : (int)((uint32_t)i % (uint32_t)S);
+  }
   // The spill array is owned by the kernel body and only referenced here: if it were
   // a member, the whole struct (top and base included) would live in scratch memory.
   LdsWord* lds;  // this lane's column: slot i at lds[i * BLOCK]
@@ -169,13 +173,13 @@ struct Stack {
   __device__ __forceinline__ bool empty() const { return top == 0; }
   __device__ __forceinline__ void push(uint32_t meta, float val) {
     if (top - base == S) {  // ring full: spill the oldest resident record
-      if (OVF > 0) ovf[base] = unpack_record(lds[(base & (S - 1)) * BLOCK]);
+      if (OVF > 0) ovf[base] = unpack_record(lds[slot(base) * BLOCK]);
       ++base;
     }
     Record rec;
     rec.x = meta;
     rec.y = __float_as_uint(val);
-    lds[(top & (S - 1)) * BLOCK] = pack_record(rec);
+    lds[slot(top) * BLOCK] = pack_record(rec);
     ++top;
   }
   static constexpr int kUnwind = 8;
@@ -193,13 +197,13 @@ struct Stack {
 #pragma unroll
         for (int i = 0; i < kRefill; ++i) {
           const int idx = base - 1 - i;
-          if (idx >= 0) lds[(idx & (S - 1)) * BLOCK] = pack_record(r[i]);
+          if (idx >= 0) lds[slot(idx) * BLOCK] = pack_record(r[i]);
         }
       }
       base = base > kRefill ? base - kRefill : 0;
     }
 #pragma unroll
-    for (int i = 0; i < kUnwind; ++i) rr[i] = unpack_record(lds[((top - 1 - i) & (S - 1)) * BLOCK]);
+    for (int i = 0; i < kUnwind; ++i) rr[i] = unpack_record(lds[slot(top - 1 - i) * BLOCK]);
     const int resident = top - base;
     return resident < kUnwind ? resident : kUnwind;
   }
@@ -216,13 +220,13 @@ struct Stack {
 #pragma unroll
         for (int i = 0; i < kRefill; ++i) {
           const int idx = base - 1 - i;
-          if (idx >= 0) lds[(idx & (S - 1)) * BLOCK] = pack_record(r[i]);
+          if (idx >= 0) lds[slot(idx) * BLOCK] = pack_record(r[i]);
         }
       }
       base = base > kRefill ? base - kRefill : 0;
     }
     --top;
-    return unpack_record(lds[(top & (S - 1)) * BLOCK]);
+    return unpack_record(lds[slot(top) * BLOCK]);
   }
 };
 
