@@ -692,7 +692,7 @@ size_t two_phase_scratch_bytes(uint64_t nq) {
 template <int OVF, bool UNIFORM1>
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
-  constexpr int S2 = 16;    // LDS ring of phase 2 (8 KB per wave: 20 waves per CU)
+  constexpr int S2 = 16;    // LDS ring of phase 2 (8 KB per wave: 20 waves per CU; 12 / 8 slots: r01l_notes item 8)
   constexpr int LEAFB = 4;  // points fetched per round trip
   float4* qs = nullptr;
   int rc = PTK_OK;
