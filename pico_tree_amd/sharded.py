@@ -121,3 +121,50 @@ class ShardedSearch:
         if rows_per_rank is not None:
             return torch.cat([t[:rows_per_rank] for t in self._recv[b]], dim=0)
         return torch.cat(self._recv[b], dim=0)[:self.shard.nq]
+
+
+def sharded_radius(shard: Shard, search, q_local, group=None):
+    """Radius search of a sharded batch: ragged rows, so the gather is two-step.
+
+    ``search(q_local)`` returns this rank's ``(offsets, rows)`` -- ``offsets`` an int64 tensor of
+    ``rows_local + 1`` entries, ``rows`` an int32 ``(total, 2)`` tensor of (index, distance bits) in
+    the reference's traversal order (on the GPU: ``tree.search_radius_device``).  ``q_local`` holds
+    ``shard.per`` rows (``padded_shard``); the padding rows are cut before anything is sent.
+
+    Step 1 gathers the per-row counts (fixed size: ``shard.per`` per rank) on rank 0, which gives it
+    every rank's payload size; step 2 moves each payload with one point-to-point transfer into its
+    place of the final buffer (shards are contiguous row ranges, so rank order is row order).
+    Returns ``(offsets[nq + 1], rows)`` on rank 0 and ``None`` elsewhere."""
+    import torch
+    import torch.distributed as dist
+
+    offsets, rows = search(q_local)
+    n_local = shard.rows
+    counts = (offsets[1:n_local + 1] - offsets[:n_local]).to(torch.int64)
+    rows = rows[:int(offsets[n_local].item())].contiguous()
+    if shard.world == 1:
+        out_off = torch.zeros(shard.nq + 1, dtype=torch.int64, device=counts.device)
+        out_off[1:] = torch.cumsum(counts, 0)
+        return out_off, rows
+    padded = torch.zeros(shard.per, dtype=torch.int64, device=counts.device)
+    padded[:n_local] = counts
+    if shard.rank == 0:
+        parts = [torch.empty_like(padded) for _ in range(shard.world)]
+        dist.gather(padded, parts, dst=0, group=group)
+        all_counts = torch.cat(parts)[:shard.nq]
+        out_off = torch.zeros(shard.nq + 1, dtype=torch.int64, device=counts.device)
+        out_off[1:] = torch.cumsum(all_counts, 0)
+        total = int(out_off[-1].item())
+        out = torch.empty((total, 2), dtype=torch.int32, device=rows.device)
+        out[:rows.shape[0]] = rows
+        for r in range(1, shard.world):
+            lo = min(r * shard.per, shard.nq)
+            hi = min(lo + shard.per, shard.nq)
+            a, b = int(out_off[lo].item()), int(out_off[hi].item())
+            if b > a:
+                dist.recv(out[a:b], src=r, group=group)
+        return out_off, out
+    dist.gather(padded, None, dst=0, group=group)
+    if rows.shape[0] > 0:
+        dist.send(rows, dst=0, group=group)
+    return None

@@ -77,6 +77,26 @@ def _worker(rank, world, port, nq, k, tmp):
         want = np.concatenate([ref.search_knn(ds.uniform_cloud(nq, 3, seed=100 + r), k) for r in range(world)])
         ok = ok and bool(np.array_equal(both.numpy(), want.view(np.int32).reshape(nq * world, k, 2)))
         np.save(os.path.join(tmp, "ok.npy"), np.array([int(ok)]))
+    # Ragged results: radius rows gathered in two steps (counts, then one transfer per rank).
+    from pico_tree_amd.sharded import sharded_radius
+    radius = 0.0012
+    for nq_r in (nq, 3):  # 3 rows over 2 ranks: the last shard is short, and may be empty of hits
+        q = ds.uniform_cloud(nq_r, 3, seed=50)
+        shr = shard_of(nq_r, world, rank)
+
+        def search_radius(q_local):  # stand-in for tree.search_radius_device on the GPU
+            off, flat = ref.search_radius(q_local.numpy(), radius)
+            return (torch.from_numpy(off.astype(np.int64)),
+                    torch.from_numpy(flat.view(np.int32).reshape(-1, 2).copy()))
+
+        res = sharded_radius(shr, search_radius, torch.from_numpy(padded_shard(q, shr)))
+        if rank == 0:
+            want_off, want = ref.search_radius(q, radius)
+            ok = ok and bool(np.array_equal(res[0].numpy().astype(np.uint64), want_off))
+            ok = ok and res[1].numpy().tobytes() == want.tobytes()
+            np.save(os.path.join(tmp, "ok.npy"), np.array([int(ok)]))
+        else:
+            assert res is None
     dist.barrier()
     dist.destroy_process_group()
 
