@@ -210,7 +210,10 @@ int upload(ptk_tree& t, const float* points) {
     PTK_HIP(hipMemcpy(t.d_axes, enc.axes.data(), ab, hipMemcpyHostToDevice));
     PTK_HIP(hipMemcpy(t.d_pts, enc.points.data(), pb, hipMemcpyHostToDevice));
     PTK_HIP(hipMemcpy(t.d_index, enc.index.data(), ib, hipMemcpyHostToDevice));
-    t.device_bytes = nb + ab + pb + ib;
+    const size_t rb = enc.ranges.size() * sizeof(ptk::EncRange);
+    PTK_HIP(hipMalloc(&t.d_ranges, rb));
+    PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), rb, hipMemcpyHostToDevice));
+    t.device_bytes = nb + ab + pb + ib + rb;
     t.dev_nd.nodes = static_cast<const uint4*>(t.d_nodes);
     t.dev_nd.axes = static_cast<const uint32_t*>(t.d_axes);
     t.dev_nd.pts = static_cast<const float*>(t.d_pts);
@@ -1392,7 +1395,9 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   int rc = check_search(t, mins, nb);
   if (rc != PTK_OK) return rc;
   if (nb > 0 && maxs == nullptr) return fail(PTK_ERR_INVALID, "null box buffer");
-  if (t->dim > 3) return fail(PTK_ERR_UNSUPPORTED, "search_box runs on the device for dim <= 3 only");
+  const size_t nd_smem = (size_t)16 * 64 * 8 + (size_t)4 * t->dim * 64 * 4;
+  if (t->dim > 3 && nd_smem > kMaxLdsBytes)
+    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device box search", t->dim);
   offsets[0] = 0;
   if (nb == 0) return PTK_OK;
   DeviceGuard guard(t->device);
@@ -1400,18 +1405,24 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   ptk::BoxState root{0, 0, 0, 0, 0, 0};
   {
     float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-    for (uint32_t d = 0; d < t->dim; ++d) {
+    for (uint32_t d = 0; d < t->dim && d < 3; ++d) {  // dim > 3 hands its root box over in d_root
       mn[d] = t->root_min[d];
       mx[d] = t->root_max[d];
     }
     root = ptk::BoxState{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
   }
-  float *d_mn = nullptr, *d_mx = nullptr;
+  float *d_mn = nullptr, *d_mx = nullptr, *d_root = nullptr;
   uint64_t *d_c = nullptr, *d_o = nullptr;
   int32_t* d_out = nullptr;
   void* tmp = nullptr;
   const size_t bbytes = (size_t)nb * t->dim * sizeof(float);
   hipError_t he = hipMalloc((void**)&d_mn, bbytes);
+  if (he == hipSuccess && t->dim > 3) {  // the root box of the any-dimension kernel: min[dim], max[dim]
+    he = hipMalloc((void**)&d_root, (size_t)2 * t->dim * sizeof(float));
+    if (he == hipSuccess) he = hipMemcpy(d_root, t->root_min.data(), t->dim * sizeof(float), hipMemcpyHostToDevice);
+    if (he == hipSuccess)
+      he = hipMemcpy(d_root + t->dim, t->root_max.data(), t->dim * sizeof(float), hipMemcpyHostToDevice);
+  }
   if (he == hipSuccess) he = hipMalloc((void**)&d_mx, bbytes);
   if (he == hipSuccess) he = hipMalloc((void**)&d_c, (nb + 1) * 8);
   if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nb + 1) * 8);
@@ -1423,6 +1434,13 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   const auto* ranges = static_cast<const uint2*>(t->d_ranges);
   if (he == hipSuccess) {
     PTK_WITH_OVF(16, ([&]() -> int {
+                   if (t->dim > 3) {
+                     int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, false>, nd_smem);
+                     if (lrc != PTK_OK) return lrc;
+                     hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, false>), dim3(blocks), dim3(64), nd_smem, nullptr,
+                                        t->dev_nd, ranges, d_root, d_mn, d_mx, nb, d_c, nullptr, nullptr);
+                     return PTK_OK;
+                   }
                    hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
                                       t->dev, ranges, root, d_mn, d_mx, t->dim, nb, d_c, nullptr, nullptr);
                    return PTK_OK;
@@ -1442,6 +1460,13 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
       }
       if (he == hipSuccess) {
         PTK_WITH_OVF(16, ([&]() -> int {
+                       if (t->dim > 3) {
+                         int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, true>, nd_smem);
+                         if (lrc != PTK_OK) return lrc;
+                         hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, true>), dim3(blocks), dim3(64), nd_smem, nullptr,
+                                            t->dev_nd, ranges, d_root, d_mn, d_mx, nb, nullptr, d_o, d_out);
+                         return PTK_OK;
+                       }
                        hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
                                           t->dev, ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_o, d_out);
                        return PTK_OK;
@@ -1460,6 +1485,7 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   if (tmp) (void)hipFree(tmp);
   if (d_mn) (void)hipFree(d_mn);
   if (d_mx) (void)hipFree(d_mx);
+  if (d_root) (void)hipFree(d_root);
   if (d_c) (void)hipFree(d_c);
   if (d_o) (void)hipFree(d_o);
   if (d_out) (void)hipFree(d_out);

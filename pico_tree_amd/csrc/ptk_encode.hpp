@@ -226,6 +226,7 @@ struct EncodedTreeND {
   std::vector<uint32_t> axes;     // per branch
   std::vector<float> points;      // leaf order, row-major (n_points x dim)
   std::vector<int32_t> index;     // leaf order: original index
+  std::vector<EncRange> ranges;   // per branch: position range [begin, end) of its whole subtree (box search)
   uint32_t root_ref = 0;
   uint32_t cbits = 0;
 };
@@ -267,6 +268,16 @@ inline std::string encode_tree_nd(
     if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
     std::memcpy(&out.points[pos * dim], points + (uint64_t)idx * dim, dim * sizeof(float));
     out.index[pos] = idx;
+  }
+  {  // subtree ranges: children come later in the stream, so one backward pass suffices
+    std::vector<EncRange> of_node(n_nodes);
+    for (uint64_t i = n_nodes; i-- > 0;) {
+      const ptk_node& nd = nodes[i];
+      of_node[i] = nd.right == PTK_LEAF ? EncRange{nd.a, nd.b} : EncRange{of_node[i + 1].begin, of_node[nd.right].end};
+    }
+    out.ranges.assign(n_branch > 0 ? n_branch : 1, EncRange{0, 0});
+    for (uint64_t i = 0; i < n_nodes; ++i)
+      if (nodes[i].right != PTK_LEAF) out.ranges[branch_id[i]] = of_node[i];
   }
   out.root_ref = ref_of(0);
   out.cbits = cbits;

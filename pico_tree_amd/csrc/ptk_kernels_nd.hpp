@@ -172,4 +172,124 @@ __global__ __launch_bounds__(64) void radius_nd_kernel(
   if (!FILL) counts[qi] = pol.count;
 }
 
+// ---- box search, any dimension ------------------------------------------------------------
+// The walk of box_kernel (ptk_kernels.hpp; kd_tree_search.hpp:238-381) with the four per-lane
+// vectors -- query min / max and the running node box min / max -- staged in LDS [axis][lane].
+// `root` holds the root box (min[dim], max[dim]).  Records: pending-right {branch, val = box max
+// of the axis to restore}, undo {kRecUndo | axis, val = box min to restore}.
+template <int S, int OVF, bool FILL>
+__global__ __launch_bounds__(64) void box_nd_kernel(
+    DevTreeND t, const uint2* __restrict__ ranges, const float* __restrict__ root,
+    const float* __restrict__ mins, const float* __restrict__ maxs, uint64_t nb,
+    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, int32_t* __restrict__ out) {
+  const uint64_t bi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (bi >= nb) return;
+  const uint32_t dim = t.dim;
+  LdsFloat* base = (LdsFloat*)(ptk_smem + (size_t)S * 64 * 8);
+  LdsFloat* qn = base + threadIdx.x;
+  LdsFloat* qx = qn + (size_t)dim * 64;
+  LdsFloat* mn = qx + (size_t)dim * 64;
+  LdsFloat* mx = mn + (size_t)dim * 64;
+  for (uint32_t a = 0; a < dim; ++a) {
+    qn[a * 64] = mins[bi * dim + a];
+    qx[a * 64] = maxs[bi * dim + a];
+    mn[a * 64] = root[a];
+    mx[a * 64] = root[dim + a];
+  }
+  const uint4* __restrict__ nodes = t.nodes;
+  const uint32_t* __restrict__ axes = t.axes;
+  uint64_t count = 0;
+  int32_t* row = FILL ? out + offsets[bi] : nullptr;
+
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+
+  auto inside = [&]() {  // query_.contains(box_), box.hpp: both corners inside the closed query box
+    bool in = true;
+    for (uint32_t a = 0; a < dim; ++a) {
+      const float lo = qn[a * 64], hi = qx[a * 64], bl = mn[a * 64], bh = mx[a * 64];
+      in = in && lo <= bl && bl <= hi && lo <= bh && bh <= hi;
+    }
+    return in;
+  };
+  auto report_range = [&](uint32_t begin, uint32_t end) {
+    if (FILL) {
+      for (uint32_t p = begin; p < end; ++p) row[count + (p - begin)] = t.index[p];
+    }
+    count += end - begin;
+  };
+  auto report = [&](uint32_t ref) {
+    if (ref & kLeafBit) {
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      report_range(lv >> t.cbits, (lv >> t.cbits) + (lv & t.cmask));
+    } else {
+      const uint2 r = ranges[ref];
+      report_range(r.x, r.y);
+    }
+  };
+  auto scan_leaf = [&](uint32_t ref) {
+    const uint32_t lv = ref & 0x7FFFFFFFu;
+    const uint32_t begin = lv >> t.cbits;
+    const uint32_t n = lv & t.cmask;
+    for (uint32_t j = 0; j < n; ++j) {
+      const float* p = t.pts + (uint64_t)(begin + j) * dim;
+      bool in = true;
+      for (uint32_t a = 0; a < dim; ++a) in = in && qn[a * 64] <= p[a] && p[a] <= qx[a * 64];
+      if (in) {
+        if (FILL) row[count] = t.index[begin + j];
+        ++count;
+      }
+    }
+  };
+
+  uint32_t ref = t.root_ref;
+  bool have = true;
+  for (;;) {
+    if (have) {
+      if (ref & kLeafBit) {
+        scan_leaf(ref);
+        have = false;
+      } else {
+        const uint4 nd = nodes[ref];
+        const uint32_t axis = axes[ref];
+        const float left_max = __uint_as_float(nd.x);
+        st.push(ref, mx[axis * 64]);  // the right child comes later
+        mx[axis * 64] = left_max;
+        if (inside()) {
+          report(nd.z);
+          have = false;
+        } else if (qn[axis * 64] <= left_max) {  // intersects_left
+          ref = nd.z;
+        } else {
+          have = false;
+        }
+      }
+      continue;
+    }
+    if (st.empty()) break;
+    const Record r = st.pop();
+    const float val = __uint_as_float(r.y);
+    if (r.x & kRecUndo) {
+      mn[(r.x & kNdIdxMask) * 64] = val;
+      continue;
+    }
+    // Left side of branch r.x is done: restore max, narrow min, do the right side.
+    const uint32_t idx = r.x & kNdIdxMask;
+    const uint4 nd = nodes[idx];
+    const uint32_t axis = axes[idx];
+    mx[axis * 64] = val;
+    const float right_min = __uint_as_float(nd.y);
+    st.push(kRecUndo | axis, mn[axis * 64]);
+    mn[axis * 64] = right_min;
+    if (inside()) {
+      report(nd.w);
+    } else if (qx[axis * 64] >= right_min) {  // intersects_right
+      ref = nd.w;
+      have = true;
+    }
+  }
+  if (!FILL) counts[bi] = count;
+}
+
 }  // namespace ptk

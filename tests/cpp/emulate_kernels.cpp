@@ -484,7 +484,29 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
 int emu_box(void* h, const float* mins, const float* maxs, uint64_t nb, const float* root_min, const float* root_max,
             uint64_t* offsets, int32_t* out) {
   auto* t = static_cast<Emu*>(h);
-  if (t->dim > 3) return -2;
+  if (t->dim > 3) {  // any-dimension kernel
+    std::vector<float> root(2 * (size_t)t->dim);
+    for (uint32_t d = 0; d < t->dim; ++d) {
+      root[d] = root_min[d];
+      root[t->dim + d] = root_max[d];
+    }
+    const auto* nd_ranges = reinterpret_cast<const uint2*>(t->enc_nd.ranges.data());
+    if ((size_t)16 * 64 * 8 + (size_t)4 * t->dim * 64 * 4 > sizeof(ptk::ptk_smem)) return -2;
+    if (out == nullptr) {
+      std::vector<uint64_t> counts(nb + 1, 0);
+      for_each_lane(nb, [&] {
+        ptk::box_nd_kernel<4, 2048, false>(t->dev_nd, nd_ranges, root.data(), mins, maxs, nb, counts.data(), nullptr,
+                                           nullptr);
+      }, 64);
+      offsets[0] = 0;
+      for (uint64_t i = 0; i < nb; ++i) offsets[i + 1] = offsets[i] + counts[i];
+      return 0;
+    }
+    for_each_lane(nb, [&] {
+      ptk::box_nd_kernel<16, 2048, true>(t->dev_nd, nd_ranges, root.data(), mins, maxs, nb, nullptr, offsets, out);
+    }, 64);
+    return 0;
+  }
   float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
   for (uint32_t d = 0; d < t->dim; ++d) {
     mn[d] = root_min[d];

@@ -162,7 +162,7 @@ def test_golden_vectors_on_the_device(gpu, name):
 
 
 @pytest.mark.parametrize("cloud,dim,half", [("uniform", 3, 0.03), ("lidar", 3, 1.5), ("ties", 3, 0.125), ("u2", 2, 0.02),
-                                            ("u1", 1, 0.001)])
+                                            ("u1", 1, 0.001), ("u4", 4, 0.15), ("u7", 7, 0.35), ("u24", 24, 0.6)])
 def test_box_search_traversal_order(gpu, cloud, dim, half):
     """search_box on the device: rows equal the reference's traversal-order index lists
     (kd_tree_search.hpp:238-381), including wholesale-reported subtrees and closed bounds."""

@@ -152,6 +152,27 @@ def test_emulated_box_search_equals_oracle(case):
     assert off[-1] > 0
 
 
+@pytest.mark.parametrize("dim,leaf", [(4, 7), (6, 10), (17, 3)])
+def test_emulated_box_search_any_dimension(dim, leaf):
+    """box_nd_kernel (dim > 3): the same walk with the four per-lane vectors staged in LDS."""
+    pts = ds.uniform_cloud(12_000, dim, 51)
+    if dim == 4:
+        pts = (np.round(pts * 6) / 6).astype(np.float32)  # lattice: points ON box faces
+    q = ds.uniform_cloud(600, dim, 52)
+    emu = EmulatedTree(pts, leaf)
+    ref = oracle.Oracle(pts, leaf, "port")
+    rng = np.random.default_rng(4)
+    h = (rng.uniform(0.2, 0.6, size=q.shape)).astype(np.float32)
+    mins, maxs = (q - h).astype(np.float32), (q + h).astype(np.float32)
+    mins[::20] = pts.min(0)
+    maxs[::20] = pts.max(0)
+    maxs[1::20] = mins[1::20]
+    off, flat = ref.search_box(mins, maxs)
+    goff, gflat = emu.search_box(mins, maxs)
+    assert np.array_equal(goff, off) and np.array_equal(gflat, flat)
+    assert off[-1] > len(pts)
+
+
 @pytest.mark.parametrize("metric", ["L1", "LPInf"])
 @pytest.mark.parametrize("case", ["uniform3", "ties3", "dim2", "dim5"])
 def test_emulated_kernels_other_metrics(case, metric):
