@@ -198,7 +198,7 @@ int ptk_search_radius_fill(const ptk_tree* tree, const float* queries,
                            int sort);
 
 /* Device forms.  The count pass keeps the rows it finds in a block of device
- * memory owned by the handle (dim <= 3; PTK_RADIUS_CAPTURE_MB, default 16384,
+ * memory owned by the handle (PTK_RADIUS_CAPTURE_MB, default 16384,
  * 0 = off).  A fill call whose (d_queries, nq, radius, e, stream) repeat the
  * LAST count call on the handle -- the normal sequence -- copies them out
  * instead of searching again; any other fill call searches again.  The

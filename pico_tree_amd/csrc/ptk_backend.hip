@@ -788,7 +788,8 @@ int launch_knn_nd(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t k, 
 
 template <int OVF, class M = ptk::MetricL2>
 int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e, bool fill,
-                     uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out, hipStream_t s) {
+                     uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out, hipStream_t s,
+                     const uint32_t* perm = nullptr, const uint32_t* n_dev = nullptr) {
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
@@ -804,8 +805,27 @@ int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float rad
     int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, true, M>, smem);
     if (rc != PTK_OK) return rc;
     hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, true, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
-                       radius, inv_ratio(e), d_counts, d_offsets, d_out);
+                       radius, inv_ratio(e), d_counts, d_offsets, d_out, perm, n_dev);
   }
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, n_dev ? 0 : nq);
+  return PTK_OK;
+}
+
+template <int OVF, class M = ptk::MetricL2>
+int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e,
+                             uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
+  constexpr int S = 16;
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+  const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
+  if (smem > kMaxLdsBytes)
+    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
+  Timer timer(t, s);
+  int rc = allow_lds(ptk::radius_nd_capture_kernel<S, OVF, M>, smem);
+  if (rc != PTK_OK) return rc;
+  PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
+  hipLaunchKernelGGL((ptk::radius_nd_capture_kernel<S, OVF, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
+                     radius, inv_ratio(e), d_counts, cap);
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
   return PTK_OK;
@@ -1182,18 +1202,8 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
   if (nq == 0) return PTK_OK;
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
-  if (t->dim > 3) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
-                                                               reinterpret_cast<ptk::Neighbor*>(d_out), s))));
-    if (rc == PTK_OK && fill && sort) {
-      const uint32_t sort_blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
-      hipLaunchKernelGGL(ptk::sort_rows_kernel, dim3(sort_blocks), dim3(ptk::kBlock), 0, s, nq, d_offsets,
-                         reinterpret_cast<ptk::Neighbor*>(d_out));
-      PTK_HIP(hipGetLastError());
-    }
-    return rc;
-  }
-  const bool reorder = want_reorder(t, nq);
+  const bool nd = t->dim > 3;  // the any-dimension kernels take the batch in caller order
+  const bool reorder = !nd && want_reorder(t, nq);
   const int metric = t->metric.load();
   Scratch scratch(t, s);
   Workspace& ws = t->ws;  // locked by `scratch` for the duration of this call
@@ -1217,9 +1227,15 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       timer.stop(0, 0);
     }
     // Rows the capture could not hold (possibly none: the blocks then leave at once).
-    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
-                                                                       d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
-                                                                       s, n_over))));
+    if (nd) {
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, true, nullptr, d_offsets,
+                                                                 reinterpret_cast<ptk::Neighbor*>(d_out), s, over_list,
+                                                                 n_over))));
+    } else {
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
+                                                                         d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
+                                                                         s, n_over))));
+    }
   } else {
     const bool capture = !fill && prepare_capture(nq, ws);
     if (!fill) ws.cap_valid = false;
@@ -1231,8 +1247,12 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       if (rc != PTK_OK) return rc;
     }
     if (capture) {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_capture<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, d_counts,
-                                                                                 ws.cap, s))));
+      if (nd) {
+        PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd_capture<OVF, M>(t, d_q, nq, radius, e, d_counts, ws.cap, s))));
+      } else {
+        PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_capture<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, d_counts,
+                                                                                   ws.cap, s))));
+      }
       if (rc == PTK_OK) {
         ws.cap_valid = true;
         ws.cap_q = d_q;
@@ -1242,6 +1262,9 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
         ws.cap_metric = metric;
         ws.cap_stream = s;
       }
+    } else if (nd) {
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
+                                                                 reinterpret_cast<ptk::Neighbor*>(d_out), s))));
     } else {
       PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));

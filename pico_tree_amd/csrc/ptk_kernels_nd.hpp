@@ -152,12 +152,17 @@ __global__ __launch_bounds__(64) void knn_nd_kernel(
   pol.end_query((uint32_t)qi);
 }
 
+// perm / n_dev (fill pass only): the batch is the first *n_dev rows listed in perm -- the rows a
+// capture could not hold (see radius_kernel in ptk_kernels.hpp).
 template <int S, int OVF, bool FILL, class M = MetricL2>
 __global__ __launch_bounds__(64) void radius_nd_kernel(
     DevTreeND t, const float* __restrict__ queries, uint64_t nq, float radius, float e_inv,
-    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out) {
-  const uint64_t qi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (qi >= nq) return;
+    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out,
+    const uint32_t* __restrict__ perm = nullptr, const uint32_t* __restrict__ n_dev = nullptr) {
+  if (n_dev != nullptr) nq = *n_dev;
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[i] : i;
   LdsFloat *q, *off;
   stage_query_nd<S>(queries, t.dim, qi, q, off);
   Record spill[OVF > 0 ? OVF : 1];
@@ -170,6 +175,36 @@ __global__ __launch_bounds__(64) void radius_nd_kernel(
   pol.out = FILL ? out + offsets[qi] : nullptr;
   traverse_nd<M>(t, q, off, 64u, pol, st);
   if (!FILL) counts[qi] = pol.count;
+}
+
+// The count pass that also captures the rows (RadiusCapture, ptk_kernels.hpp).
+template <int S, int OVF, class M = MetricL2>
+__global__ __launch_bounds__(64) void radius_nd_capture_kernel(
+    DevTreeND t, const float* __restrict__ queries, uint64_t nq, float radius, float e_inv,
+    uint64_t* __restrict__ counts, RadiusCapture cap) {
+  const uint64_t qi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (qi >= nq) return;
+  LdsFloat *q, *off;
+  stage_query_nd<S>(queries, t.dim, qi, q, off);
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  RadiusPolicy<kRadiusCapture> pol;
+  pol.radius = f_mul(radius, e_inv);
+  pol.e_inv = e_inv;
+  pol.count = 0;
+  pol.out = cap.chunks;
+  pol.counters = cap.counters;
+  pol.cur = (uint32_t)qi;
+  pol.pos = 1;
+  pol.next = 0xFFFFFFFFu;
+  pol.sub = (blockIdx.x * 0x9E3779B1u) >> 24;
+  pol.sub_cap = cap.sub_cap;
+  pol.n_static = cap.n_static;
+  pol.capturing = true;
+  traverse_nd<M>(t, q, off, 64u, pol, st);
+  counts[qi] = pol.count;
+  cap.captured[qi] = pol.capturing ? 1 : 0;
 }
 
 // ---- box search, any dimension ------------------------------------------------------------

@@ -365,7 +365,7 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
 int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
                        uint64_t* counts, uint32_t sub_cap) {
   auto* t = static_cast<Emu*>(h);
-  if (t->dim > 3 || t->metric != 0) return -3;
+  if (t->metric != 0 || (t->dim > 3 && perm != nullptr)) return -3;
   t->cap_chunks.assign(((size_t)nq + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kCapChunk, ptk::Neighbor{-1, -1.0f});
   t->cap_counters.assign(ptk::kCapSubPools * ptk::kCapCounterStride, 0u);
   t->cap_flags.assign(nq, 2);
@@ -375,6 +375,12 @@ int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float
   t->cap.n_static = (uint32_t)nq;
   t->cap.sub_cap = sub_cap;
   const float e_inv = 1.0f / e;
+  if (t->dim > 3) {
+    for_each_lane(nq, [&] {
+      ptk::radius_nd_capture_kernel<8, 2048>(t->dev_nd, q, nq, radius, e_inv, counts, t->cap);
+    }, 64);
+    return 0;
+  }
   for_each_lane(nq, [&] {
     ptk::radius_capture_kernel<8, 2048, 64, 4>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
   }, 64);
@@ -392,10 +398,16 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
   uint32_t n_over = 0;
   const float e_inv = 1.0f / e;
   for_each_lane(nq * 32, [&] { ptk::radius_scatter_kernel<32>(t->cap, nq, offsets, o, over.data(), &n_over); }, 256);
-  for_each_lane(nq, [&] {
-    ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o,
-                                              &n_over);
-  }, 64);
+  if (t->dim > 3) {
+    for_each_lane(nq, [&] {
+      ptk::radius_nd_kernel<16, 2048, true>(t->dev_nd, q, nq, radius, e_inv, nullptr, offsets, o, over.data(), &n_over);
+    }, 64);
+  } else {
+    for_each_lane(nq, [&] {
+      ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o,
+                                                &n_over);
+    }, 64);
+  }
   if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
   return (int64_t)n_over;
 }

@@ -428,3 +428,19 @@ def test_randomised_differential_sweep(gpu):
             failing.append((desc, bad))
     assert not failing, failing
     assert ran >= 60
+
+
+@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "5"},
+                                 {"PTK_RADIUS_CAPTURE_MB": "0"}], ids=["default", "static-chunk-only", "pool-runs-dry", "off"])
+@pytest.mark.parametrize("dim,radius", [(5, 0.06), (16, 1.1)])
+def test_radius_capture_any_dimension(gpu, monkeypatch, env, dim, radius):
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    pts, q = ds.uniform_cloud(30_000, dim, 91), ds.uniform_cloud(6_000, dim, 92)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 9, device=gpu)
+    ref = oracle.Oracle(pts, 9, "port")
+    for e in (1.0, 1.4):
+        want_off, want = ref.search_radius(q, radius, e=None if e == 1.0 else e)
+        got = tree.search_radius(q, radius, e)
+        assert np.array_equal(got.offsets, want_off) and got.flat.tobytes() == want.tobytes()
+    assert int((np.diff(want_off.astype(np.int64)) > 31).sum()) > 100  # long rows exist: chains grow / break
