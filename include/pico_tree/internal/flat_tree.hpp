@@ -21,6 +21,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <cassert>
 #include <cstdint>
 #include <future>
@@ -78,6 +79,79 @@ struct max_leaf_size_t : splitter_stop_condition_t<max_leaf_size_t> {
   constexpr max_leaf_size_t(size_t v) : value(v) { assert(value > 0); }
   size_t value;
 };
+
+namespace internal {
+
+//! std::partition's result, computed by several threads.
+//! \details libstdc++'s std::partition on bidirectional (and random access) iterators is the
+//! two-pointer scheme: the k-th element from the left that fails the predicate is swapped with
+//! the k-th element from the right that passes it, until the pointers meet at position
+//! m = number of passing elements.  So the permutation is determined by two lists -- the
+//! misplaced positions below m in increasing order and the misplaced positions from m on in
+//! decreasing order -- which threads can build chunk by chunk and swap pairwise.  The result is
+//! element-for-element what the serial call leaves behind (tests/test_cabi.py compares trees
+//! built with 1 and many threads; the oracle pins them to the reference).
+template <typename Index_, typename Pred_>
+Index_* parallel_partition(Index_* begin, Index_* end, Pred_ pred, unsigned threads) {
+  std::ptrdiff_t const n = end - begin;
+  if (threads < 2 || n < (std::ptrdiff_t(1) << 16)) return std::partition(begin, end, pred);
+  unsigned const t_count = threads > 64 ? 64 : threads;
+  std::ptrdiff_t const per = (n + t_count - 1) / t_count;
+  std::vector<unsigned char> pass(static_cast<size_t>(n));
+  std::vector<std::ptrdiff_t> count(t_count + 1, 0);
+  auto for_chunks = [&](auto&& body) {
+    std::vector<std::future<void>> jobs;
+    for (unsigned t = 1; t < t_count; ++t)
+      jobs.push_back(std::async(std::launch::async, [&body, t] { body(t); }));
+    body(0u);
+    for (auto& j : jobs) j.get();
+  };
+  for_chunks([&](unsigned t) {
+    std::ptrdiff_t const lo = std::min<std::ptrdiff_t>(n, per * t), hi = std::min<std::ptrdiff_t>(n, lo + per);
+    std::ptrdiff_t c = 0;
+    for (std::ptrdiff_t i = lo; i < hi; ++i) {
+      bool const ok = pred(begin[i]);
+      pass[static_cast<size_t>(i)] = ok ? 1 : 0;
+      c += ok ? 1 : 0;
+    }
+    count[t + 1] = c;
+  });
+  for (unsigned t = 0; t < t_count; ++t) count[t + 1] += count[t];
+  std::ptrdiff_t const m = count[t_count];
+  if (m == 0 || m == n) return begin + m;  // nothing to move
+  // Misplaced positions per chunk (increasing), then their global ranks.
+  std::vector<std::vector<std::ptrdiff_t>> left(t_count), right(t_count);
+  for_chunks([&](unsigned t) {
+    std::ptrdiff_t const lo = std::min<std::ptrdiff_t>(n, per * t), hi = std::min<std::ptrdiff_t>(n, lo + per);
+    for (std::ptrdiff_t i = lo; i < hi; ++i) {
+      if (i < m) {
+        if (!pass[static_cast<size_t>(i)]) left[t].push_back(i);
+      } else if (pass[static_cast<size_t>(i)]) {
+        right[t].push_back(i);
+      }
+    }
+  });
+  std::vector<std::ptrdiff_t> lbase(t_count + 1, 0), rbase(t_count + 1, 0);
+  for (unsigned t = 0; t < t_count; ++t) {
+    lbase[t + 1] = lbase[t] + static_cast<std::ptrdiff_t>(left[t].size());
+    rbase[t + 1] = rbase[t] + static_cast<std::ptrdiff_t>(right[t].size());
+  }
+  std::ptrdiff_t const swaps = lbase[t_count];  // == rbase[t_count]
+  std::vector<std::ptrdiff_t> rflat(static_cast<size_t>(swaps));
+  for_chunks([&](unsigned t) {
+    for (size_t k = 0; k < right[t].size(); ++k) rflat[static_cast<size_t>(rbase[t]) + k] = right[t][k];
+  });
+  // The k-th misplaced position from the left meets the k-th from the right (rflat read backwards).
+  for_chunks([&](unsigned t) {
+    for (size_t k = 0; k < left[t].size(); ++k) {
+      std::ptrdiff_t const rank = lbase[t] + static_cast<std::ptrdiff_t>(k);
+      std::swap(begin[left[t][k]], begin[rflat[static_cast<size_t>(swaps - 1 - rank)]]);
+    }
+  });
+  return begin + m;
+}
+
+}  // namespace internal
 
 //! A node at this depth becomes a leaf (depth 0 = the root).
 struct max_leaf_depth_t : splitter_stop_condition_t<max_leaf_depth_t> {
@@ -255,9 +329,12 @@ class flat_builder {
                             : 1024);
     box_type work = start_bounds;
     index_base_ = tree_.indices.data();
-    int levels = 0;  // levels of the tree whose children are separate tasks: 2^levels >= 2 * threads
-    while (threads > 1 && (1u << levels) < 2 * threads && levels < 12) ++levels;
-    grow(0, index_base_, index_base_ + n, work, levels);
+    task_pool pool;
+    pool.idle.store(static_cast<int>(threads) - 1);  // this thread is the first worker
+    pool.threads = threads;
+    pool.n_total = n;
+    pool_ = threads > 1 ? &pool : nullptr;
+    grow(0, index_base_, index_base_ + n, work);
   }
 
  private:
@@ -275,7 +352,8 @@ class flat_builder {
       box_type const& box,
       Index_*& cut,
       size_t& axis,
-      scalar_type& plane) const {
+      scalar_type& plane,
+      unsigned threads = 1) const {
     scalar_type extent;
     box.longest_side(axis, extent);
     size_t const a = axis;
@@ -294,9 +372,9 @@ class flat_builder {
         plane = extent / scalar_type(2.0) + box.min(a);
       }
       scalar_type const p = plane;
-      cut = std::partition(begin, end, [this, a, p](Index_ const i) -> bool {
+      cut = parallel_partition(begin, end, [this, a, p](Index_ const i) -> bool {
         return space_[i][a] < p;
-      });
+      }, threads);
       if constexpr (std::is_same_v<Rule_, sliding_midpoint_max_side_t>) {
         if (cut == end) {  // nothing on the right: slide the largest point over
           --cut;
@@ -311,6 +389,25 @@ class flat_builder {
     }
   }
 
+  //! Workers of a threaded build.  Tasks are spawned by SIZE, wherever both children of a node are
+  //! worth one and a worker is idle -- a fixed number of top levels is not enough: on a LiDAR
+  //! cloud the sliding midpoint splits 77 / 23 again and again, and one of 64 equal-depth subtrees
+  //! held a fifth of the points.  A thread that waits for a child it spawned counts as idle.
+  struct task_pool {
+    std::atomic<int> idle{0};
+    unsigned threads = 1;
+    size_t n_total = 0;
+    bool try_acquire() {
+      int v = idle.load(std::memory_order_relaxed);
+      while (v > 0) {
+        if (idle.compare_exchange_weak(v, v - 1, std::memory_order_acq_rel)) return true;
+      }
+      return false;
+    }
+    void release() { idle.fetch_add(1, std::memory_order_acq_rel); }
+    void reclaim() { idle.fetch_sub(1, std::memory_order_acq_rel); }  // may dip below zero for a moment
+  };
+
   //! Ranges below this many points are not worth a task.
   static constexpr std::ptrdiff_t kParallelMin = 20000;
   static constexpr std::uint32_t kMaxBuildDepth = 8192;
@@ -319,9 +416,14 @@ class flat_builder {
   //! own first node.
   void splice(tree_type const& sub) {
     std::uint32_t const base = static_cast<std::uint32_t>(tree_.nodes.size());
-    for (auto nd : sub.nodes) {
+    size_t const count = sub.nodes.size();
+    tree_.nodes.resize(base + count);
+    auto* dst = tree_.nodes.data() + base;
+    auto const* src = sub.nodes.data();
+    for (size_t i = 0; i < count; ++i) {
+      auto nd = src[i];
       if (nd.right != flat_leaf_tag) nd.right += base;
-      tree_.nodes.push_back(nd);
+      dst[i] = nd;
     }
     if (tree_.keep_outer_bounds)
       tree_.outer_bounds.insert(tree_.outer_bounds.end(), sub.outer_bounds.begin(), sub.outer_bounds.end());
@@ -331,7 +433,7 @@ class flat_builder {
   }
 
   std::uint32_t grow(
-      std::uint32_t depth, Index_* begin, Index_* end, box_type& box, int task_levels = 0) {
+      std::uint32_t depth, Index_* begin, Index_* end, box_type& box) {
     // Degenerate input (thousands of identical points with a small leaf size) makes the sliding
     // midpoint peel off one point per level; the reference recurses until its stack overflows.
     if (depth > kMaxBuildDepth)
@@ -362,25 +464,49 @@ class flat_builder {
     Index_* cut = begin;
     size_t axis = 0;
     scalar_type plane = scalar_type(0);
-    split(begin, end, box, cut, axis, plane);
+    // A node's partition gets the share of the workers its share of the points is worth.
+    unsigned split_threads = 1;
+    if (pool_ != nullptr) {
+      size_t const share = static_cast<size_t>(end - begin) * pool_->threads / pool_->n_total;
+      split_threads = share > 64 ? 64u : (share < 1 ? 1u : static_cast<unsigned>(share));
+    }
+    split(begin, end, box, cut, axis, plane, split_threads);
 
     box_type right = box;
     box.max(axis) = plane;    // `box` now bounds the left child
     right.min(axis) = plane;
 
     std::uint32_t r;
-    if (task_levels > 0 && (end - begin) >= kParallelMin) {
+    if (pool_ != nullptr && (cut - begin) >= kParallelMin && (end - cut) >= kParallelMin && pool_->try_acquire()) {
       // Left subtree in another thread, right subtree here, each into its own tree object.
       size_t const sdim = tree_.root_box.size();
       tree_type lt(sdim), rt(sdim);
       lt.keep_outer_bounds = rt.keep_outer_bounds = tree_.keep_outer_bounds;
       flat_builder lb(space_, static_cast<size_t>(stop_), lt), rb(space_, static_cast<size_t>(stop_), rt);
       lb.index_base_ = rb.index_base_ = index_base_;
-      auto left_done = std::async(std::launch::async, [&] {
-        lb.grow(depth + 1, begin, cut, box, task_levels - 1);
+      lb.pool_ = rb.pool_ = pool_;
+      task_pool* const pool = pool_;
+      auto left_done = std::async(std::launch::async, [&lb, &box, pool, depth, begin, cut] {
+        struct on_exit {  // the worker goes idle again, also when the subtree throws
+          task_pool* p;
+          ~on_exit() { p->release(); }
+        } guard{pool};
+        lb.grow(depth + 1, begin, cut, box);
       });
-      rb.grow(depth + 1, cut, end, right, task_levels - 1);
-      left_done.get();
+      try {
+        rb.grow(depth + 1, cut, end, right);
+      } catch (...) {
+        left_done.wait();
+        throw;
+      }
+      pool->release();  // waiting is not working
+      try {
+        left_done.get();
+      } catch (...) {
+        pool->reclaim();
+        throw;
+      }
+      pool->reclaim();
       splice(lt);  // lands at self + 1
       r = static_cast<std::uint32_t>(tree_.nodes.size());
       splice(rt);
@@ -404,6 +530,7 @@ class flat_builder {
   Index_ stop_;
   tree_type& tree_;
   Index_* index_base_ = nullptr;  //!< first element of the (shared) index permutation
+  task_pool* pool_ = nullptr;     //!< shared by the builders of one threaded build
 };
 
 //! Entry point: build with the given parameters.
@@ -423,7 +550,23 @@ flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_
   box_type start(sdim);
   start.invert();
   if constexpr (std::is_same_v<Bounds_, bounds_from_space_t>) {
-    for (size_t i = 0; i < space.size(); ++i) start.fit(space[i]);
+    size_t const n = space.size();
+    if (threads > 1 && n >= (size_t(1) << 18)) {  // min / max are exact: any grouping gives the same box
+      unsigned const t_count = threads > 64 ? 64 : threads;
+      std::vector<box_type> part(t_count, box_type(sdim));
+      std::vector<std::future<void>> jobs;
+      auto body = [&](unsigned t) {
+        part[t].invert();
+        size_t const per = (n + t_count - 1) / t_count, lo = std::min(n, per * t), hi = std::min(n, lo + per);
+        for (size_t i = lo; i < hi; ++i) part[t].fit(space[i]);
+      };
+      for (unsigned t = 1; t < t_count; ++t) jobs.push_back(std::async(std::launch::async, [&body, t] { body(t); }));
+      body(0u);
+      for (auto& j : jobs) j.get();
+      for (unsigned t = 0; t < t_count; ++t) start.fit(part[t]);
+    } else {
+      for (size_t i = 0; i < n; ++i) start.fit(space[i]);
+    }
   } else {
     using bound_point = std::decay_t<decltype(bounds.derived().min())>;
     start.fit(point_view<bound_point>(bounds.derived().min()).data());

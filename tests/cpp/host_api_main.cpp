@@ -9,6 +9,7 @@
 // use the API (examples/kd_tree/kd_tree_search.cpp, kd_tree_creation.cpp,
 // kd_tree_custom_search_visitor.cpp, kd_tree_dynamic_arrays.cpp, kd_tree_save_and_load.cpp).
 
+#include <algorithm>
 #include <array>
 #include <cstdint>
 #include <cstdio>
@@ -62,7 +63,36 @@ struct counting_nn {
   float const& max() const { return nn.distance; }
 };
 
+// parallel_partition must leave exactly what std::partition leaves (flat_tree.hpp).
+static int check_parallel_partition() {
+  std::uint64_t state = 12345;
+  auto next = [&state] {
+    state = state * 6364136223846793005ull + 1442695040888963407ull;
+    return static_cast<std::uint32_t>(state >> 33);
+  };
+  for (int round = 0; round < 24; ++round) {
+    size_t const n = 65536 + next() % 300000;
+    std::uint32_t const cut = round == 0 ? 0u : round == 1 ? 1000u : next() % 1001u;  // per mille that pass
+    std::vector<int> a(n);
+    for (auto& v : a) v = static_cast<int>(next() % 1000000u);
+    if (round == 2) std::sort(a.begin(), a.end());
+    auto pred = [cut](int v) { return static_cast<std::uint32_t>(v) % 1000u < cut; };
+    std::vector<int> want = a;
+    auto wm = std::partition(want.begin(), want.end(), pred);
+    for (unsigned threads : {2u, 5u, 32u}) {
+      std::vector<int> got = a;
+      int* gm = pico_tree::internal::parallel_partition(got.data(), got.data() + n, pred, threads);
+      if (gm - got.data() != wm - want.begin() || got != want) {
+        std::fprintf(stderr, "parallel_partition differs: round %d n %zu cut %u threads %u\n", round, n, cut, threads);
+        return 50;
+      }
+    }
+  }
+  return 0;
+}
+
 static int run_host(std::string const& dir) {
+  if (int rc = check_parallel_partition()) return rc;
   std::vector<float> pv = read_floats(dir + "/points.bin");
   std::vector<float> qv = read_floats(dir + "/queries.bin");
   space3 pts = to_space(pv);
