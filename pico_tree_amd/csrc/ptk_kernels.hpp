@@ -1334,6 +1334,7 @@ __global__ __launch_bounds__(64) void box_kernel(
     const uint32_t n = lv & t.cmask;
     for (uint32_t j = 0; j < n; ++j) {
       const float4 p = pts[begin + j];
+      PTK_KEEP4(p);  // one 16-byte load: the index must not become a dependent load inside the branch
       if (qn0 <= p.x && p.x <= qx0 && qn1 <= p.y && p.y <= qx1 && qn2 <= p.z && p.z <= qx2) {
         if (FILL) row[count] = __float_as_int(p.w);
         ++count;
