@@ -444,3 +444,37 @@ def test_radius_capture_any_dimension(gpu, monkeypatch, env, dim, radius):
         got = tree.search_radius(q, radius, e)
         assert np.array_equal(got.offsets, want_off) and got.flat.tobytes() == want.tobytes()
     assert int((np.diff(want_off.astype(np.int64)) > 31).sum()) > 100  # long rows exist: chains grow / break
+
+
+def test_concurrent_host_threads_on_one_handle(trees):
+    """searches may be issued from several host threads on one handle
+    (ctypes drops the GIL).  Mixed knn / radius / box calls, every result checked."""
+    import threading
+    tree, ref, pts, q = trees("uniform")
+    parts = [q[i * 4000:(i + 1) * 4000].copy() for i in range(4)]
+    want = []
+    for p in parts:
+        off, flat = ref.search_radius(p, 0.0015)
+        want.append((ref.search_knn(p, 1)[:, 0], ref.search_knn(p, 12), off, flat))
+    errors = []
+
+    def worker(i):
+        try:
+            for _ in range(6):
+                p, (w1, w12, woff, wflat) = parts[i], want[i]
+                if tree.search_knn(p, 1).tobytes() != w1.tobytes():
+                    errors.append((i, "knn1"))
+                if tree.search_knn(p, 12).tobytes() != w12.tobytes():
+                    errors.append((i, "knn12"))
+                got = tree.search_radius(p, 0.0015)
+                if not np.array_equal(got.offsets, woff) or got.flat.tobytes() != wflat.tobytes():
+                    errors.append((i, "radius"))
+        except Exception as exc:  # noqa: BLE001
+            errors.append((i, repr(exc)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(4)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
