@@ -13,9 +13,14 @@
 //!     leaf   { Index begin_idx; Index end_idx; }  or
 //!     branch { int split_dim; Scalar left_max; Scalar right_min; }
 //!
+//! Both records are written as whole structs (kd_tree_data.hpp:113,116), so for Scalar = double
+//! the branch carries the 4 bytes of padding the compiler puts after split_dim (24 bytes, not
+//! 20).  The reference writes whatever those bytes hold; this writer zeroes them.
+//!
 //! The flat node array is already in that order, so saving is one linear pass
 //! and loading rebuilds only the right-child indices.
 
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -43,6 +48,14 @@ inline void get_pod(std::istream& s, T_& v) {
   s.read(reinterpret_cast<char*>(&v), sizeof(T_));
 }
 
+// kd_tree_branch_single<Scalar_> (kd_tree_node.hpp:43-50), the layout of a branch on disk.
+template <typename Scalar_>
+struct stream_branch {
+  int split_dim;
+  Scalar_ left_max;
+  Scalar_ right_min;
+};
+
 template <typename Tree_>
 inline void write_flat_tree(Tree_ const& tree, std::ostream& s) {
   using index = typename Tree_::index_type;
@@ -64,10 +77,12 @@ inline void write_flat_tree(Tree_ const& tree, std::ostream& s) {
       put_pod(s, nd.begin);
       put_pod(s, nd.end);
     } else {
-      int const split_dim = static_cast<int>(nd.split_dim);
-      put_pod(s, split_dim);
-      put_pod(s, nd.left_max);
-      put_pod(s, nd.right_min);
+      stream_branch<scalar> b;
+      std::memset(&b, 0, sizeof(b));  // padding included
+      b.split_dim = static_cast<int>(nd.split_dim);
+      b.left_max = nd.left_max;
+      b.right_min = nd.right_min;
+      put_pod(s, b);
     }
   }
 }
@@ -107,12 +122,12 @@ inline Tree_ read_flat_tree(std::istream& s) {
     bool leaf = false;
     get_pod(s, leaf);
     if (!leaf) {
-      int split_dim = 0;
-      get_pod(s, split_dim);
+      stream_branch<scalar> rec{};
+      get_pod(s, rec);
       auto& b = tree.nodes[self];
-      b.split_dim = static_cast<std::uint32_t>(split_dim);
-      get_pod(s, b.left_max);
-      get_pod(s, b.right_min);
+      b.split_dim = static_cast<std::uint32_t>(rec.split_dim);
+      b.left_max = rec.left_max;
+      b.right_min = rec.right_min;
       b.right = 0;
       open.push_back(pending{self, depth, false});
       ++depth;  // next node is the left child

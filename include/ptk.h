@@ -32,6 +32,9 @@
  *   ptk_search_box_*              the batch loop over kd_tree::search_box:
  *                                 _pyco_tree/kd_tree.hpp:245-268, kd_tree.hpp:296-318
  *   ptk_tree_destroy              ~kd_tree
+ *   ptk_tree64_* / ptk_search64_* the same entry points for kd_trees over double
+ *                                 points (_pyco_tree/kd_tree.hpp:383-445 dispatches
+ *                                 on the array dtype)
  *
  * Results contract: neighbour indices are bit-identical to the reference CPU
  * kd_tree on the same inputs, squared distances bit-identical to the reference
@@ -225,6 +228,56 @@ int ptk_search_box(const ptk_tree* tree, const float* mins, const float* maxs,
                    uint64_t nb, uint64_t* offsets, int32_t** out);
 
 void ptk_free(void* p);
+
+/* ---- double precision ---------------------------------------------------- */
+/* The reference's kd_tree is generic over the scalar type and its Python module
+ * builds KdTree objects over float64 arrays too (dispatch on the array dtype:
+ * src/pyco_tree/pico_tree/_pyco_tree/kd_tree.hpp:383-445; neighbor dtype
+ * [('index','<i4'),('distance','<f8')], def_core.hpp:17-18).  These entry points
+ * are that instantiation: kd_tree<space of double points, metric, int>.  Same
+ * meaning, same error behaviour and the same results contract as their float32
+ * counterparts above (bit-identical to the reference built over doubles with
+ * -ffp-contract=off); the tree file format is the reference's for double
+ * scalars (branch records are written as whole structs: 24 bytes). */
+
+/* Layout-identical to pico_tree::neighbor<int, double>: 16 bytes, the distance
+ * at offset 8. */
+typedef struct ptk_neighbor64 {
+  int32_t index;
+  int32_t pad_; /* zero */
+  double distance;
+} ptk_neighbor64;
+
+typedef struct ptk_tree64 ptk_tree64; /* opaque */
+
+int ptk_tree64_create_from_points(const double* points, uint64_t n_points,
+                                  uint32_t dim, uint64_t max_leaf_size,
+                                  int32_t device, ptk_tree64** out);
+int ptk_tree64_create_from_stream(const double* points, uint64_t n_points,
+                                  uint32_t dim, const void* stream,
+                                  uint64_t stream_bytes, int32_t device,
+                                  ptk_tree64** out);
+void ptk_tree64_destroy(ptk_tree64* tree);
+int ptk_tree64_get_info(const ptk_tree64* tree, ptk_tree_info* info);
+int ptk_tree64_set_metric(ptk_tree64* tree, int metric);
+int ptk_tree64_serialize(const ptk_tree64* tree, void* buf, uint64_t cap,
+                         uint64_t* size);
+
+/* As ptk_search_knn / ptk_search_knn_device. */
+int ptk_search64_knn(const ptk_tree64* tree, const double* queries, uint64_t nq,
+                     uint32_t k, double e, ptk_neighbor64* out);
+int ptk_search64_knn_device(const ptk_tree64* tree, const double* d_queries,
+                            uint64_t nq, uint32_t k, double e,
+                            ptk_neighbor64* d_out, void* stream);
+/* As ptk_search_radius: *out is malloc'ed by the library (ptk_free).  With
+ * sort != 0 rows ascend by distance, equal distances by index. */
+int ptk_search64_radius(const ptk_tree64* tree, const double* queries,
+                        uint64_t nq, double radius, double e, int sort,
+                        uint64_t* offsets, ptk_neighbor64** out);
+/* As ptk_search_box. */
+int ptk_search64_box(const ptk_tree64* tree, const double* mins,
+                     const double* maxs, uint64_t nb, uint64_t* offsets,
+                     int32_t** out);
 
 /* ---- randomised kd-forest (approximate k-NN in high dimensions) -------- */
 /* Replaces the per-query loop over pico_tree::kd_forest::search_nearest /

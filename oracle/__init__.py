@@ -18,7 +18,7 @@ from __future__ import annotations
 import ctypes
 import os
 import subprocess
-from ctypes import c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p, POINTER
+from ctypes import c_double, c_float, c_int, c_size_t, c_uint32, c_uint64, c_void_p, POINTER
 
 import numpy as np
 
@@ -26,10 +26,17 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 PORT_LIB = os.path.join(_HERE, "liboracle.so")
 REF_LIB = os.path.join(_HERE, "_ref", "libptk_ref.so")
 REF_FOREST_LIB = os.path.join(_HERE, "_ref", "libptk_ref_forest.so")
+#: The same two libraries over double points (``-DPTKOR_DOUBLE`` / ``-DPTKREF_DOUBLE``).
+PORT_LIB64 = os.path.join(_HERE, "liboracle64.so")
+REF_LIB64 = os.path.join(_HERE, "_ref", "libptk_ref64.so")
 
 #: Structured dtype of one result record; identical to the reference binding's
 #: ``[('index','<i4'),('distance','<f4')]`` (_pyco_tree/def_core.hpp:17-18).
 NEIGHBOR = np.dtype([("index", "<i4"), ("distance", "<f4")])
+#: ``neighbor<int, double>``: 16 bytes, the distance at offset 8 (what pybind11's
+#: PYBIND11_NUMPY_DTYPE yields for that struct, _pyco_tree/def_core.hpp:17-18).
+NEIGHBOR64 = np.dtype({"names": ["index", "distance"], "formats": ["<i4", "<f8"], "offsets": [0, 8],
+                       "itemsize": 16})
 
 
 def build(force: bool = False) -> None:
@@ -47,6 +54,10 @@ def have_reference() -> bool:
     return os.path.exists(REF_LIB)
 
 
+def have_reference64() -> bool:
+    return os.path.exists(REF_LIB64)
+
+
 def _fptr(a: np.ndarray):
     return a.ctypes.data_as(POINTER(c_float))
 
@@ -62,34 +73,45 @@ class Oracle:
     METRICS = {"L2Squared": 0, "L1": 1, "LPInf": 2}
 
     def __init__(self, points: np.ndarray, max_leaf_size: int = 10, kind: str = "port",
-                 metric: str = "L2Squared"):
+                 metric: str = "L2Squared", dtype=np.float32):
         if kind not in ("port", "reference"):
             raise ValueError(kind)
         self.kind = kind
         self.metric = metric
         mid = self.METRICS[metric]
-        path = PORT_LIB if kind == "port" else REF_LIB
+        self.dtype = np.dtype(dtype)
+        if self.dtype == np.float64:
+            path = PORT_LIB64 if kind == "port" else REF_LIB64
+            self._cs, self.neighbor = c_double, NEIGHBOR64
+        elif self.dtype == np.float32:
+            path = PORT_LIB if kind == "port" else REF_LIB
+            self._cs, self.neighbor = c_float, NEIGHBOR
+        else:
+            raise ValueError("dtype must be float32 or float64")
         if not os.path.exists(path):
             raise RuntimeError(f"oracle library missing: {path} (run oracle.build())")
         self._lib = ctypes.CDLL(path)
         self._p = "ptkor_" if kind == "port" else "ptkref_"
-        pts = np.ascontiguousarray(points, dtype=np.float32)
+        pts = np.ascontiguousarray(points, dtype=self.dtype)
         if pts.ndim != 2:
             raise ValueError("points must be (n, dim)")
         self.n, self.dim = pts.shape
         self.max_leaf_size = int(max_leaf_size)
         self._pts = pts
         if kind == "reference" and mid != 0:  # another instantiation of the reference's kd_tree
-            create = self._fn("create_metric", c_void_p, [POINTER(c_float), c_size_t, c_size_t, c_size_t, c_int])
-            self._h = create(_fptr(pts), self.n, self.dim, self.max_leaf_size, mid)
+            create = self._fn("create_metric", c_void_p, [POINTER(self._cs), c_size_t, c_size_t, c_size_t, c_int])
+            self._h = create(self._ptr(pts), self.n, self.dim, self.max_leaf_size, mid)
         else:
-            create = self._fn("create", c_void_p, [POINTER(c_float), c_size_t, c_size_t, c_size_t])
-            self._h = create(_fptr(pts), self.n, self.dim, self.max_leaf_size)
+            create = self._fn("create", c_void_p, [POINTER(self._cs), c_size_t, c_size_t, c_size_t])
+            self._h = create(self._ptr(pts), self.n, self.dim, self.max_leaf_size)
         if not self._h:
             raise RuntimeError("oracle create failed")
         if kind == "port" and mid != 0:
             if self._fn("set_metric", c_int, [c_void_p, c_int])(self._h, mid) != 0:
                 raise RuntimeError("oracle set_metric failed")
+
+    def _ptr(self, a: np.ndarray):
+        return a.ctypes.data_as(POINTER(self._cs))
 
     def _fn(self, name, restype, argtypes):
         f = getattr(self._lib, self._p + name)
@@ -133,8 +155,8 @@ class Oracle:
         count = f(self._h, None, 0, None, None, None, None)
         nodes = np.empty((count, 4), dtype=np.uint32)
         indices = np.empty(self.n, dtype=np.int32)
-        rmin = np.empty(self.dim, dtype=np.float32)
-        rmax = np.empty(self.dim, dtype=np.float32)
+        rmin = np.empty(self.dim, dtype=self.dtype)
+        rmax = np.empty(self.dim, dtype=self.dtype)
         depth = c_uint32(0)
         f(self._h, nodes.ctypes.data, count, indices.ctypes.data, rmin.ctypes.data,
           rmax.ctypes.data, ctypes.byref(depth))
@@ -142,25 +164,25 @@ class Oracle:
 
     # -- queries ------------------------------------------------------------
     def _queries(self, q):
-        q = np.ascontiguousarray(q, dtype=np.float32)
+        q = np.ascontiguousarray(q, dtype=self.dtype)
         if q.ndim != 2 or q.shape[1] != self.dim:
             raise ValueError("queries must be (nq, dim)")
         return q
 
     def search_nn(self, q, e: float | None = None, counters: bool = False):
         q = self._queries(q)
-        out = np.empty(len(q), dtype=NEIGHBOR)
+        out = np.empty(len(q), dtype=self.neighbor)
         if self.kind == "port":
             cnt = np.zeros((len(q), 5), dtype=np.uint32) if counters else None
             self._fn("search_nn", None,
-                     [c_void_p, POINTER(c_float), c_size_t, c_int, c_float, c_void_p, c_void_p])(
-                self._h, _fptr(q), len(q), int(e is not None), float(e or 1.0),
+                     [c_void_p, POINTER(self._cs), c_size_t, c_int, self._cs, c_void_p, c_void_p])(
+                self._h, self._ptr(q), len(q), int(e is not None), float(e or 1.0),
                 out.ctypes.data, cnt.ctypes.data if counters else None)
             return (out, cnt) if counters else out
         if e is not None or counters:
             raise RuntimeError("reference driver: use search_knn(k=1, e) / count_visits")
-        self._fn("search_nn", None, [c_void_p, POINTER(c_float), c_size_t, c_void_p])(
-            self._h, _fptr(q), len(q), out.ctypes.data)
+        self._fn("search_nn", None, [c_void_p, POINTER(self._cs), c_size_t, c_void_p])(
+            self._h, self._ptr(q), len(q), out.ctypes.data)
         return out
 
     def search_knn(self, q, k: int, e: float | None = None, counters: bool = False):
@@ -168,25 +190,25 @@ class Oracle:
         k = int(k)
         if k < 1 or k > self.n:
             raise ValueError("oracle requires 1 <= k <= n")
-        out = np.empty((len(q), k), dtype=NEIGHBOR)
+        out = np.empty((len(q), k), dtype=self.neighbor)
         if self.kind == "port":
             cnt = np.zeros((len(q), 5), dtype=np.uint32) if counters else None
             self._fn("search_knn", None,
-                     [c_void_p, POINTER(c_float), c_size_t, c_size_t, c_int, c_float,
+                     [c_void_p, POINTER(self._cs), c_size_t, c_size_t, c_int, self._cs,
                       c_void_p, c_void_p])(
-                self._h, _fptr(q), len(q), k, int(e is not None), float(e or 1.0),
+                self._h, self._ptr(q), len(q), k, int(e is not None), float(e or 1.0),
                 out.ctypes.data, cnt.ctypes.data if counters else None)
             return (out, cnt) if counters else out
         if counters:
             raise RuntimeError("reference driver: use count_visits")
         if e is None:
             self._fn("search_knn", None,
-                     [c_void_p, POINTER(c_float), c_size_t, c_size_t, c_void_p])(
-                self._h, _fptr(q), len(q), k, out.ctypes.data)
+                     [c_void_p, POINTER(self._cs), c_size_t, c_size_t, c_void_p])(
+                self._h, self._ptr(q), len(q), k, out.ctypes.data)
         else:
             self._fn("search_knn_approx", None,
-                     [c_void_p, POINTER(c_float), c_size_t, c_size_t, c_float, c_void_p])(
-                self._h, _fptr(q), len(q), k, float(e), out.ctypes.data)
+                     [c_void_p, POINTER(self._cs), c_size_t, c_size_t, self._cs, c_void_p])(
+                self._h, self._ptr(q), len(q), k, float(e), out.ctypes.data)
         return out
 
     def search_radius(self, q, radius: float, sort: bool = False, e: float | None = None,
@@ -196,20 +218,20 @@ class Oracle:
         if self.kind == "port":
             cnt = np.zeros((len(q), 5), dtype=np.uint32) if counters else None
             h = self._fn("search_radius", c_void_p,
-                         [c_void_p, POINTER(c_float), c_size_t, c_float, c_int, c_int, c_float,
+                         [c_void_p, POINTER(self._cs), c_size_t, self._cs, c_int, c_int, self._cs,
                           c_void_p, c_void_p])(
-                self._h, _fptr(q), len(q), float(radius), int(sort), int(e is not None),
+                self._h, self._ptr(q), len(q), float(radius), int(sort), int(e is not None),
                 float(e or 1.0), offsets.ctypes.data, cnt.ctypes.data if counters else None)
         else:
             if counters:
                 raise RuntimeError("reference driver has no radius counters")
             cnt = None
             h = self._fn("search_radius", c_void_p,
-                         [c_void_p, POINTER(c_float), c_size_t, c_float, c_int, c_int, c_float,
+                         [c_void_p, POINTER(self._cs), c_size_t, self._cs, c_int, c_int, self._cs,
                           c_void_p])(
-                self._h, _fptr(q), len(q), float(radius), int(sort), int(e is not None),
+                self._h, self._ptr(q), len(q), float(radius), int(sort), int(e is not None),
                 float(e or 1.0), offsets.ctypes.data)
-        flat = np.empty(int(offsets[-1]), dtype=NEIGHBOR)
+        flat = np.empty(int(offsets[-1]), dtype=self.neighbor)
         self._fn("radius_copy", None, [c_void_p, c_void_p])(h, flat.ctypes.data)
         self._fn("radius_free", None, [c_void_p])(h)
         return (offsets, flat, cnt) if counters else (offsets, flat)
@@ -219,8 +241,8 @@ class Oracle:
         maxs = self._queries(maxs)
         offsets = np.zeros(len(mins) + 1, dtype=np.uint64)
         h = self._fn("search_box", c_void_p,
-                     [c_void_p, POINTER(c_float), POINTER(c_float), c_size_t, c_void_p])(
-            self._h, _fptr(mins), _fptr(maxs), len(mins), offsets.ctypes.data)
+                     [c_void_p, POINTER(self._cs), POINTER(self._cs), c_size_t, c_void_p])(
+            self._h, self._ptr(mins), self._ptr(maxs), len(mins), offsets.ctypes.data)
         flat = np.empty(int(offsets[-1]), dtype=np.int32)
         self._fn("box_copy", None, [c_void_p, c_void_p])(h, flat.ctypes.data)
         self._fn("box_free", None, [c_void_p])(h)
@@ -374,3 +396,26 @@ class ReferenceForest:
             self.close()
         except Exception:
             pass
+
+
+def canonical_stream64(stream: bytes) -> bytes:
+    """A double-scalar ``kd_tree::save`` stream with the 4 padding bytes of every branch record
+    zeroed.  The reference writes ``kd_tree_branch_single<double>`` whole
+    (internal/kd_tree_data.hpp:116): {int split_dim; <4 bytes padding>; double; double}, and the
+    padding holds whatever the allocator left there."""
+    import struct
+
+    b = bytearray(stream)
+    sdim, n = struct.unpack_from("<QQ", b, 0)
+    pos = 16 + 4 * n + 16 * sdim
+    while pos < len(b):
+        leaf = b[pos]
+        pos += 1
+        if leaf:
+            pos += 8
+        else:
+            b[pos + 4:pos + 8] = b"\0\0\0\0"
+            pos += 24
+    if pos != len(b):
+        raise ValueError("not a double-scalar kd_tree stream")
+    return bytes(b)

@@ -30,13 +30,22 @@
 #include <string>
 #include <vector>
 
+// The scalar type of the points (the reference's kd_tree is generic over it: point_traits<>::
+// scalar_type).  liboracle.so is the float build; liboracle64.so is this file compiled with
+// -DPTKOR_DOUBLE (no forest section, no 16-byte flat export).
+#ifdef PTKOR_DOUBLE
+typedef double scalar_t;
+#else
+typedef float scalar_t;
+#endif
+
 namespace {
 
 struct neighbor_t {  // core.hpp:24-46
   int index;
-  float distance;
+  scalar_t distance;
 };
-static_assert(sizeof(neighbor_t) == 8, "layout");
+static_assert(sizeof(neighbor_t) == (sizeof(scalar_t) == 4 ? 8 : 16), "layout");
 
 // kd_tree_node.hpp:7-27,31-50: two child pointers + union{leaf, branch}.
 struct node_t {
@@ -49,12 +58,12 @@ struct node_t {
     } leaf;
     struct {
       int split_dim;
-      float left_max;
-      float right_min;
+      scalar_t left_max;
+      scalar_t right_min;
       // The outer bounds of kd_tree_node_topological (kd_tree_node.hpp:56-67,106-113); only the
       // kd_forest's priority search reads them.
-      float left_min;
-      float right_max;
+      scalar_t left_min;
+      scalar_t right_max;
     } branch;
   } data;
   std::uint32_t id = 0;  // position in the DFS pre-order stream (forest queue tie-break)
@@ -63,31 +72,31 @@ struct node_t {
 
 // box.hpp:161-193 with run-time size: min[dim] then max[dim].
 struct box_t {
-  std::vector<float> c;
+  std::vector<scalar_t> c;
   size_t dim;
   explicit box_t(size_t d) : c(2 * d), dim(d) {}
-  float& mn(size_t i) { return c[i]; }
-  float& mx(size_t i) { return c[dim + i]; }
-  float mn(size_t i) const { return c[i]; }
-  float mx(size_t i) const { return c[dim + i]; }
+  scalar_t& mn(size_t i) { return c[i]; }
+  scalar_t& mx(size_t i) { return c[dim + i]; }
+  scalar_t mn(size_t i) const { return c[i]; }
+  scalar_t mx(size_t i) const { return c[dim + i]; }
 
   void fill_inverse_max() {  // box.hpp:54-59
     for (size_t i = 0; i < dim; ++i) {
-      mn(i) = std::numeric_limits<float>::max();
-      mx(i) = std::numeric_limits<float>::lowest();
+      mn(i) = std::numeric_limits<scalar_t>::max();
+      mx(i) = std::numeric_limits<scalar_t>::lowest();
     }
   }
-  void max_side(size_t& idx, float& val) const {  // box.hpp:71-82
-    val = std::numeric_limits<float>::lowest();
+  void max_side(size_t& idx, scalar_t& val) const {  // box.hpp:71-82
+    val = std::numeric_limits<scalar_t>::lowest();
     for (size_t i = 0; i < dim; ++i) {
-      float const delta = mx(i) - mn(i);
+      scalar_t const delta = mx(i) - mn(i);
       if (delta > val) {
         idx = i;
         val = delta;
       }
     }
   }
-  void fit(float const* x) {  // box.hpp:86-95
+  void fit(scalar_t const* x) {  // box.hpp:86-95
     for (size_t i = 0; i < dim; ++i) {
       if (x[i] < mn(i)) mn(i) = x[i];
       if (x[i] > mx(i)) mx(i) = x[i];
@@ -99,7 +108,7 @@ struct box_t {
       if (o.mx(i) > mx(i)) mx(i) = o.mx(i);
     }
   }
-  bool contains(float const* x) const {  // box.hpp:31-40
+  bool contains(scalar_t const* x) const {  // box.hpp:31-40
     for (size_t i = 0; i < dim; ++i) {
       if (mn(i) > x[i] || mx(i) < x[i]) return false;
     }
@@ -118,7 +127,7 @@ struct visit_counters {
   // Far children of the first descent whose box distance does not exceed the best distance
   // found in the home leaf: the candidates a two-phase search hands from phase 1 to phase 2.
   std::uint32_t n_cand = 0;
-  std::vector<float> first_far;  // scratch: far box distances along the first descent
+  std::vector<scalar_t> first_far;  // scratch: far box distances along the first descent
 };
 
 struct tree_t {
@@ -126,14 +135,14 @@ struct tree_t {
   size_t n = 0;
   size_t max_leaf = 0;
   int metric = 0;                  // 0 metric_l2_squared, 1 metric_l1, 2 metric_lpinf (searches only)
-  std::vector<float> pts;          // n x dim row-major, original order
+  std::vector<scalar_t> pts;          // n x dim row-major, original order
   std::vector<int> indices;        // kd_tree_data.hpp:67
   box_t root_box{1};               // kd_tree_data.hpp:69
   std::vector<std::unique_ptr<node_t[]>> chunks;  // stands in for memory.hpp's pool
   size_t chunk_used = 256;
   node_t* root = nullptr;
 
-  float const* point(int idx) const {  // space_wrapper.hpp:30-32
+  scalar_t const* point(int idx) const {  // space_wrapper.hpp:30-32
     return pts.data() + static_cast<size_t>(idx) * dim;
   }
 
@@ -148,13 +157,13 @@ struct tree_t {
   // splitter_sliding_midpoint_max_side::operator(), kd_tree_builder.hpp:229-276.
   void split_sliding_midpoint(int* begin, int* end, box_t const& box,
                               int*& split, size_t& split_dim,
-                              float& split_val) const {
-    float max_delta;
+                              scalar_t& split_val) const {
+    scalar_t max_delta;
     box.max_side(split_dim, max_delta);
     split_val = max_delta / 2.0f + box.mn(split_dim);  // :240 (divide, then add)
 
     size_t const sd = split_dim;
-    float const sv = split_val;
+    scalar_t const sv = split_val;
     split = std::partition(begin, end, [this, sd, sv](int const i) -> bool {
       return point(i)[sd] < sv;  // :243-247
     });
@@ -187,7 +196,7 @@ struct tree_t {
     } else {
       int* split;
       size_t split_dim;
-      float split_val;
+      scalar_t split_val;
       split_sliding_midpoint(begin, end, box, split, split_dim, split_val);
 
       box_t right = box;  // :379-383
@@ -223,10 +232,10 @@ struct tree_t {
 // metric_l2_squared, range form: metric.hpp:107-117 -> internal::sum :36-51 ->
 // squared_r1_distance distance.hpp:38-41.  d starts at 0 and accumulates left to
 // right; every operation rounds to float on its own (no contraction).
-inline float l2sq(float const* a, float const* b, size_t dim) {
-  float d = 0.0f;
+inline scalar_t l2sq(scalar_t const* a, scalar_t const* b, size_t dim) {
+  scalar_t d = 0.0f;
   for (size_t i = 0; i < dim; ++i) {
-    float const t = a[i] - b[i];
+    scalar_t const t = a[i] - b[i];
     d += t * t;
   }
   return d;
@@ -234,33 +243,33 @@ inline float l2sq(float const* a, float const* b, size_t dim) {
 
 // metric_l1 (metric.hpp:78-99: sum of r1_distance = |x - y|, distance.hpp:23-27) and
 // metric_lpinf (metric.hpp:126-152: d = std::max(d, |x - y|), d from 0).
-inline float l1(float const* a, float const* b, size_t dim) {
-  float d = 0.0f;
+inline scalar_t l1(scalar_t const* a, scalar_t const* b, size_t dim) {
+  scalar_t d = 0.0f;
   for (size_t i = 0; i < dim; ++i) d += std::abs(a[i] - b[i]);
   return d;
 }
-inline float lpinf(float const* a, float const* b, size_t dim) {
-  float d = 0.0f;
+inline scalar_t lpinf(scalar_t const* a, scalar_t const* b, size_t dim) {
+  scalar_t d = 0.0f;
   for (size_t i = 0; i < dim; ++i) d = std::max(d, std::abs(a[i] - b[i]));
   return d;
 }
-inline float point_distance(int metric, float const* a, float const* b, size_t dim) {
+inline scalar_t point_distance(int metric, scalar_t const* a, scalar_t const* b, size_t dim) {
   return metric == 1 ? l1(a, b, dim) : metric == 2 ? lpinf(a, b, dim) : l2sq(a, b, dim);
 }
 // The one-dimensional form the searches apply to a split offset (metric.hpp:95-98, :120-123, :147-150).
-inline float scalar_distance(int metric, float x) { return metric == 0 ? x * x : std::abs(x); }
+inline scalar_t scalar_distance(int metric, scalar_t x) { return metric == 0 ? x * x : std::abs(x); }
 
 // ---- visitors: search_visitor.hpp ------------------------------------------
 
 struct visit_nn {  // :42-65 (exact) and :165-193 (approximate: scale by 1/e)
   neighbor_t* nn;
   bool approx;
-  float e_inv;
-  visit_nn(neighbor_t* out, bool a, float e) : nn(out), approx(a), e_inv(1.0f / e) {
-    nn->distance = std::numeric_limits<float>::max();
+  scalar_t e_inv;
+  visit_nn(neighbor_t* out, bool a, scalar_t e) : nn(out), approx(a), e_inv(1.0f / e) {
+    nn->distance = std::numeric_limits<scalar_t>::max();
   }
-  float max() const { return nn->distance; }
-  void operator()(int idx, float dst) {
+  scalar_t max() const { return nn->distance; }
+  void operator()(int idx, scalar_t dst) {
     if (approx) dst = dst * e_inv;
     if (max() > dst) {
       nn->index = idx;
@@ -274,13 +283,13 @@ struct visit_knn {  // :83-123 (exact) and :198-247 (approximate)
   neighbor_t* end;
   neighbor_t* active_end;
   bool approx;
-  float e_inv;
-  visit_knn(neighbor_t* b, neighbor_t* e_, bool a, float e)
+  scalar_t e_inv;
+  visit_knn(neighbor_t* b, neighbor_t* e_, bool a, scalar_t e)
       : begin(b), end(e_), active_end(b), approx(a), e_inv(1.0f / e) {
-    (end - 1)->distance = std::numeric_limits<float>::max();  // :102
+    (end - 1)->distance = std::numeric_limits<scalar_t>::max();  // :102
   }
-  float max() const { return (end - 1)->distance; }
-  void operator()(int idx, float dst) {
+  scalar_t max() const { return (end - 1)->distance; }
+  void operator()(int idx, scalar_t dst) {
     if (approx) dst = dst * e_inv;
     if (max() > dst) {
       if (active_end < end) ++active_end;  // :108-110
@@ -295,16 +304,16 @@ struct visit_knn {  // :83-123 (exact) and :198-247 (approximate)
 
 struct visit_radius {  // :127-156 (exact) and :252-288 (approximate)
   std::vector<neighbor_t>* out;
-  float radius;
+  scalar_t radius;
   bool approx;
-  float e_inv;
-  visit_radius(float r, std::vector<neighbor_t>* o, bool a, float e)
+  scalar_t e_inv;
+  visit_radius(scalar_t r, std::vector<neighbor_t>* o, bool a, scalar_t e)
       : out(o), radius(r), approx(a), e_inv(1.0f / e) {
     if (approx) radius = r * e_inv;  // :265
     out->clear();                    // :136
   }
-  float max() const { return radius; }
-  void operator()(int idx, float dst) {
+  scalar_t max() const { return radius; }
+  void operator()(int idx, scalar_t dst) {
     if (approx) dst = dst * e_inv;
     if (max() > dst) out->push_back(neighbor_t{idx, dst});  // strict, :141
   }
@@ -314,18 +323,18 @@ struct visit_radius {  // :127-156 (exact) and :252-288 (approximate)
 template <typename Visitor>
 struct nearest_search {
   tree_t const& tree;
-  float const* q;
+  scalar_t const* q;
   Visitor& visitor;
-  std::vector<float> offset;  // node_box_offset_, :111, zeroed per query :47
+  std::vector<scalar_t> offset;  // node_box_offset_, :111, zeroed per query :47
   visit_counters* counters;
 
-  nearest_search(tree_t const& t, float const* query, Visitor& v,
+  nearest_search(tree_t const& t, scalar_t const* query, Visitor& v,
                  visit_counters* c)
       : tree(t), q(query), visitor(v), offset(t.dim, 0.0f), counters(c) {}
 
   void run() { descend(tree.root, 0.0f); }
 
-  void descend(node_t const* node, float node_box_distance) {
+  void descend(node_t const* node, scalar_t node_box_distance) {
     if (node->is_leaf()) {  // :54-59
       if (counters) {
         if (counters->n_leaf == 0) counters->n_first = counters->n_branch;
@@ -338,16 +347,16 @@ struct nearest_search {
         visitor(idx, point_distance(tree.metric, q, tree.point(idx), tree.dim));
       }
       if (home_leaf) {
-        for (float f : counters->first_far) counters->n_cand += visitor.max() >= f ? 1u : 0u;
+        for (scalar_t f : counters->first_far) counters->n_cand += visitor.max() >= f ? 1u : 0u;
       }
       return;
     }
     if (counters) ++counters->n_branch;
     size_t const sd = static_cast<size_t>(node->data.branch.split_dim);  // :63
-    float const v = q[sd];
-    float const left_max = node->data.branch.left_max;
-    float const right_min = node->data.branch.right_min;
-    float new_offset;
+    scalar_t const v = q[sd];
+    scalar_t const left_max = node->data.branch.left_max;
+    scalar_t const right_min = node->data.branch.right_min;
+    scalar_t new_offset;
     node_t const* first;
     node_t const* second;
     if ((left_max + right_min - v - v) > 0) {  // :76 (left-assoc: ((a+b)-v)-v)
@@ -364,7 +373,7 @@ struct nearest_search {
     }
     descend(first, node_box_distance);  // :88
 
-    float const old_offset = offset[sd];  // :93
+    scalar_t const old_offset = offset[sd];  // :93
     node_box_distance = node_box_distance - old_offset + new_offset;  // :94
     if (visitor.max() >= node_box_distance) {  // :99
       offset[sd] = new_offset;
@@ -399,7 +408,7 @@ struct box_search {
       return;
     }
     size_t const sd = static_cast<size_t>(node->data.branch.split_dim);
-    float old_value = box.mx(sd);
+    scalar_t old_value = box.mx(sd);
     box.mx(sd) = node->data.branch.left_max;
     if (query.contains(box)) {
       report_all(node->left);
@@ -441,14 +450,24 @@ void write_node(node_t const* node, byte_sink& out) {
     out.put(false);
     // kd_tree_branch_single (kd_tree_node.hpp:43-50) is {int split_dim; float left_max; float
     // right_min}: 12 bytes; the forest's outer bounds are not part of the euclidean stream.
-    out.put(node->data.branch.split_dim);
-    out.put(node->data.branch.left_max);
-    out.put(node->data.branch.right_min);
+    // The reference writes the struct whole (kd_tree_data.hpp:116): with double scalars that
+    // includes 4 bytes of padding after split_dim (indeterminate there, zero here).
+    struct {
+      int split_dim;
+      scalar_t left_max;
+      scalar_t right_min;
+    } rec;
+    std::memset(&rec, 0, sizeof(rec));
+    rec.split_dim = node->data.branch.split_dim;
+    rec.left_max = node->data.branch.left_max;
+    rec.right_min = node->data.branch.right_min;
+    out.put(rec);
     write_node(node->left, out);
     write_node(node->right, out);
   }
 }
 
+#ifndef PTKOR_DOUBLE
 // Flat DFS pre-order export: mirrors the save stream, one 16-byte record per
 // node.  Branch: {left_max, right_min, right_child_index, split_dim};
 // leaf: {begin, end, 0xFFFFFFFF, 0}.  Used by tests to check the product's own
@@ -480,6 +499,8 @@ std::uint32_t flatten(node_t const* node, std::vector<flat_node>& out,
   return self;
 }
 
+#endif  // !PTKOR_DOUBLE
+
 constexpr int kChunk = 128;  // _pyco_tree/kd_tree.hpp:94
 
 struct ragged_nb {
@@ -493,7 +514,7 @@ struct ragged_idx {
 
 extern "C" {
 
-void* ptkor_create(float const* pts, size_t n, size_t dim, size_t max_leaf) {
+void* ptkor_create(scalar_t const* pts, size_t n, size_t dim, size_t max_leaf) {
   if (n == 0 || dim == 0 || max_leaf == 0) return nullptr;  // builder.hpp:93,479
   auto* t = new tree_t;
   t->dim = dim;
@@ -521,9 +542,10 @@ size_t ptkor_save(void* handle, unsigned char* buf, size_t cap) {
   return out.s.size();
 }
 
+#ifndef PTKOR_DOUBLE
 // Flat export. Call with nodes == nullptr to get the node count.
 size_t ptkor_flatten(void* handle, void* nodes, size_t cap, int* indices,
-                     float* root_min, float* root_max,
+                     scalar_t* root_min, scalar_t* root_max,
                      std::uint32_t* max_depth_out) {
   auto* t = static_cast<tree_t*>(handle);
   std::vector<flat_node> out;
@@ -539,6 +561,8 @@ size_t ptkor_flatten(void* handle, void* nodes, size_t cap, int* indices,
   return out.size();
 }
 
+#endif  // !PTKOR_DOUBLE
+
 void ptkor_set_threads(int threads) {
   if (threads > 0) omp_set_num_threads(threads);
 }
@@ -548,8 +572,8 @@ int ptkor_max_threads() { return omp_get_max_threads(); }
 // kd_tree::search_nn over a batch (kd_tree.hpp:126-129,155-159); approx != 0
 // selects the approximate visitor with ratio e.  counters: optional nq x 5
 // uint32 {n_branch, n_leaf, n_pts, n_first, n_cand}.
-void ptkor_search_nn(void* handle, float const* q, size_t nq, int approx,
-                     float e, void* out, std::uint32_t* counters) {
+void ptkor_search_nn(void* handle, scalar_t const* q, size_t nq, int approx,
+                     scalar_t e, void* out, std::uint32_t* counters) {
   auto* t = static_cast<tree_t*>(handle);
   auto* o = static_cast<neighbor_t*>(out);
   std::ptrdiff_t const count = static_cast<std::ptrdiff_t>(nq);
@@ -574,8 +598,8 @@ void ptkor_search_nn(void* handle, float const* q, size_t nq, int approx,
 // row i of out holds k slots.  As in the reference, slots beyond min(k, n) are
 // only meaningful when n >= k (the vector overload clamps, kd_tree.hpp:193);
 // callers pass k <= n.
-void ptkor_search_knn(void* handle, float const* q, size_t nq, size_t k,
-                      int approx, float e, void* out,
+void ptkor_search_knn(void* handle, scalar_t const* q, size_t nq, size_t k,
+                      int approx, scalar_t e, void* out,
                       std::uint32_t* counters) {
   auto* t = static_cast<tree_t*>(handle);
   auto* o = static_cast<neighbor_t*>(out);
@@ -600,8 +624,8 @@ void ptkor_search_knn(void* handle, float const* q, size_t nq, size_t k,
 // kd_tree::search_radius over a batch (kd_tree.hpp:257-290). sort != 0 applies
 // std::sort by distance (search_visitor.hpp:148), which is unstable: rows with
 // equal distances are only comparable as multisets.
-void* ptkor_search_radius(void* handle, float const* q, size_t nq, float radius,
-                          int sort, int approx, float e, std::uint64_t* offsets,
+void* ptkor_search_radius(void* handle, scalar_t const* q, size_t nq, scalar_t radius,
+                          int sort, int approx, scalar_t e, std::uint64_t* offsets,
                           std::uint32_t* counters) {
   auto* t = static_cast<tree_t*>(handle);
   auto* r = new ragged_nb;
@@ -650,7 +674,7 @@ void ptkor_radius_copy(void* h, void* out) {
 void ptkor_radius_free(void* h) { delete static_cast<ragged_nb*>(h); }
 
 // kd_tree::search_box over a batch (kd_tree.hpp:296-318).
-void* ptkor_search_box(void* handle, float const* mins, float const* maxs,
+void* ptkor_search_box(void* handle, scalar_t const* mins, scalar_t const* maxs,
                        size_t nb, std::uint64_t* offsets) {
   auto* t = static_cast<tree_t*>(handle);
   auto* r = new ragged_idx;
@@ -689,10 +713,10 @@ void ptkor_box_copy(void* h, int* out) {
 void ptkor_box_free(void* h) { delete static_cast<ragged_idx*>(h); }
 
 // Known-answer hook mirroring test/pico_tree/kd_tree_builder_test.cpp:134-197.
-void ptkor_sliding_midpoint_2d(float const* pts, size_t n, int* indices,
-                               float const* box_min, float const* box_max,
+void ptkor_sliding_midpoint_2d(scalar_t const* pts, size_t n, int* indices,
+                               scalar_t const* box_min, scalar_t const* box_max,
                                size_t* split_offset, size_t* split_dim,
-                               float* split_val) {
+                               scalar_t* split_val) {
   tree_t t;
   t.dim = 2;
   t.n = n;
@@ -704,7 +728,7 @@ void ptkor_sliding_midpoint_2d(float const* pts, size_t n, int* indices,
   }
   int* split = nullptr;
   size_t sd = 0;
-  float sv = 0;
+  scalar_t sv = 0;
   t.split_sliding_midpoint(indices, indices + n, box, split, sd, sv);
   *split_offset = static_cast<size_t>(split - indices);
   *split_dim = sd;
@@ -712,15 +736,15 @@ void ptkor_sliding_midpoint_2d(float const* pts, size_t n, int* indices,
 }
 
 // metric_l2_squared known answers (test/pico_tree/metric_test.cpp:37-45).
-float ptkor_l2sq(float const* a, float const* b, size_t dim) {
+scalar_t ptkor_l2sq(scalar_t const* a, scalar_t const* b, size_t dim) {
   return l2sq(a, b, dim);
 }
-float ptkor_l2sq_scalar(float x) { return x * x; }
+scalar_t ptkor_l2sq_scalar(scalar_t x) { return x * x; }
 // metric_l1 / metric_lpinf known answers (metric_test.cpp:27-35, :47-55) and the search metric.
-float ptkor_distance(int metric, float const* a, float const* b, size_t dim) {
+scalar_t ptkor_distance(int metric, scalar_t const* a, scalar_t const* b, size_t dim) {
   return point_distance(metric, a, b, dim);
 }
-float ptkor_distance_scalar(int metric, float x) { return scalar_distance(metric, x); }
+scalar_t ptkor_distance_scalar(int metric, scalar_t x) { return scalar_distance(metric, x); }
 int ptkor_set_metric(void* tree, int metric) {
   if (tree == nullptr || metric < 0 || metric > 2) return -1;
   static_cast<tree_t*>(tree)->metric = metric;
@@ -728,6 +752,9 @@ int ptkor_set_metric(void* tree, int metric) {
 }
 
 
+#ifdef PTKOR_DOUBLE
+}  // extern "C"
+#else
 // =====================================================================================
 // kd_forest (BASELINE config 5).  Restates
 //   /root/reference/examples/pico_understory/pico_understory/kd_forest.hpp:70-115
@@ -912,3 +939,5 @@ void ptkor_forest_search_knn(void* handle, float const* q, size_t nq, size_t k, 
 }
 
 }  // extern "C"
+
+#endif  // PTKOR_DOUBLE

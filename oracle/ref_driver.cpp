@@ -35,10 +35,18 @@
 #include <pico_tree/vector_traits.hpp>
 #include <pico_tree/array_traits.hpp>
 
+// Scalar type of the instantiation: _ref/libptk_ref.so is kd_tree over float points,
+// _ref/libptk_ref64.so (-DPTKREF_DOUBLE) the same reference headers over double points.
+#ifdef PTKREF_DOUBLE
+typedef double scalar_t;
+#else
+typedef float scalar_t;
+#endif
+
 namespace {
 
-using neighbor_t = pico_tree::neighbor<int, float>;
-static_assert(sizeof(neighbor_t) == 8, "neighbor layout");
+using neighbor_t = pico_tree::neighbor<int, scalar_t>;
+static_assert(sizeof(neighbor_t) == (sizeof(scalar_t) == 4 ? 8 : 16), "neighbor layout");
 
 constexpr int kChunk = 128;  // _pyco_tree/kd_tree.hpp:94
 
@@ -68,13 +76,13 @@ thread_local std::uint64_t counting_l2::n_pts = 0;
 struct tree_base {
   virtual ~tree_base() = default;
   virtual std::string save() const = 0;
-  virtual void knn(float const* q, size_t nq, size_t k, float e, bool approx,
+  virtual void knn(scalar_t const* q, size_t nq, size_t k, scalar_t e, bool approx,
                    neighbor_t* out) const = 0;
-  virtual void nn(float const* q, size_t nq, neighbor_t* out) const = 0;
-  virtual void radius(float const* q, size_t nq, float r, float e, bool approx,
+  virtual void nn(scalar_t const* q, size_t nq, neighbor_t* out) const = 0;
+  virtual void radius(scalar_t const* q, size_t nq, scalar_t r, scalar_t e, bool approx,
                       bool sort,
                       std::vector<std::vector<neighbor_t>>& out) const = 0;
-  virtual void box(float const* mins, float const* maxs, size_t nb,
+  virtual void box(scalar_t const* mins, scalar_t const* maxs, size_t nb,
                    std::vector<std::vector<int>>& out) const = 0;
   size_t dim = 0;
   size_t n = 0;
@@ -82,14 +90,14 @@ struct tree_base {
 
 template <size_t Dim_, typename Metric_ = pico_tree::metric_l2_squared>
 struct tree_impl final : tree_base {
-  using point_t = pico_tree::point_map<float const, Dim_>;
+  using point_t = pico_tree::point_map<scalar_t const, Dim_>;
   using space_t = pico_tree::space_map<point_t>;
   using kd_t = pico_tree::kd_tree<space_t, Metric_>;
 
-  std::vector<float> pts;  // the driver owns a copy so callers may free theirs
+  std::vector<scalar_t> pts;  // the driver owns a copy so callers may free theirs
   std::unique_ptr<kd_t> tree;
 
-  space_t make_space(float const* p, size_t count) const {
+  space_t make_space(scalar_t const* p, size_t count) const {
     if constexpr (Dim_ == pico_tree::dynamic_extent) {
       return space_t(p, count, dim);
     } else {
@@ -97,7 +105,7 @@ struct tree_impl final : tree_base {
     }
   }
 
-  tree_impl(float const* p, size_t count, size_t d, size_t max_leaf) {
+  tree_impl(scalar_t const* p, size_t count, size_t d, size_t max_leaf) {
     dim = d;
     n = count;
     pts.assign(p, p + count * d);
@@ -111,7 +119,7 @@ struct tree_impl final : tree_base {
     return ss.str();
   }
 
-  void nn(float const* q, size_t nq, neighbor_t* out) const override {
+  void nn(scalar_t const* q, size_t nq, neighbor_t* out) const override {
     auto query = make_space(q, nq);
     std::ptrdiff_t const count = static_cast<std::ptrdiff_t>(nq);
 #pragma omp parallel for schedule(dynamic, kChunk)
@@ -120,7 +128,7 @@ struct tree_impl final : tree_base {
     }
   }
 
-  void knn(float const* q, size_t nq, size_t k, float e, bool approx,
+  void knn(scalar_t const* q, size_t nq, size_t k, scalar_t e, bool approx,
            neighbor_t* out) const override {
     auto query = make_space(q, nq);
     std::ptrdiff_t const count = static_cast<std::ptrdiff_t>(nq);
@@ -135,7 +143,7 @@ struct tree_impl final : tree_base {
     }
   }
 
-  void radius(float const* q, size_t nq, float r, float e, bool approx,
+  void radius(scalar_t const* q, size_t nq, scalar_t r, scalar_t e, bool approx,
               bool sort,
               std::vector<std::vector<neighbor_t>>& out) const override {
     auto query = make_space(q, nq);
@@ -152,7 +160,7 @@ struct tree_impl final : tree_base {
     }
   }
 
-  void box(float const* mins, float const* maxs, size_t nb,
+  void box(scalar_t const* mins, scalar_t const* maxs, size_t nb,
            std::vector<std::vector<int>>& out) const override {
     auto qmin = make_space(mins, nb);
     auto qmax = make_space(maxs, nb);
@@ -186,7 +194,7 @@ struct box_result {
 
 extern "C" {
 
-void* ptkref_create(float const* pts, size_t n, size_t dim, size_t max_leaf) {
+void* ptkref_create(scalar_t const* pts, size_t n, size_t dim, size_t max_leaf) {
   if (n == 0 || dim == 0 || max_leaf == 0) return nullptr;
   return dispatch_dim(dim, [&](auto d) -> void* {
     return static_cast<tree_base*>(
@@ -196,7 +204,7 @@ void* ptkref_create(float const* pts, size_t n, size_t dim, size_t max_leaf) {
 
 // The same tree searched under another of the reference's metrics
 // (0 metric_l2_squared, 1 metric_l1, 2 metric_lpinf; metric.hpp:78-152).
-void* ptkref_create_metric(float const* pts, size_t n, size_t dim,
+void* ptkref_create_metric(scalar_t const* pts, size_t n, size_t dim,
                            size_t max_leaf, int metric) {
   if (n == 0 || dim == 0 || max_leaf == 0) return nullptr;
   if (metric == 0) return ptkref_create(pts, n, dim, max_leaf);
@@ -228,26 +236,26 @@ void ptkref_set_threads(int threads) {
 
 int ptkref_max_threads() { return omp_get_max_threads(); }
 
-void ptkref_search_nn(void* t, float const* q, size_t nq, void* out) {
+void ptkref_search_nn(void* t, scalar_t const* q, size_t nq, void* out) {
   static_cast<tree_base*>(t)->nn(q, nq, static_cast<neighbor_t*>(out));
 }
 
-void ptkref_search_knn(void* t, float const* q, size_t nq, size_t k,
+void ptkref_search_knn(void* t, scalar_t const* q, size_t nq, size_t k,
                        void* out) {
   static_cast<tree_base*>(t)->knn(q, nq, k, 1.0f, false,
                                   static_cast<neighbor_t*>(out));
 }
 
-void ptkref_search_knn_approx(void* t, float const* q, size_t nq, size_t k,
-                              float e, void* out) {
+void ptkref_search_knn_approx(void* t, scalar_t const* q, size_t nq, size_t k,
+                              scalar_t e, void* out) {
   static_cast<tree_base*>(t)->knn(q, nq, k, e, true,
                                   static_cast<neighbor_t*>(out));
 }
 
 // Ragged radius search. offsets has nq + 1 entries. Returns a handle holding
 // the rows; copy them out with ptkref_radius_copy and release it.
-void* ptkref_search_radius(void* t, float const* q, size_t nq, float radius,
-                           int sort, int approx, float e,
+void* ptkref_search_radius(void* t, scalar_t const* q, size_t nq, scalar_t radius,
+                           int sort, int approx, scalar_t e,
                            std::uint64_t* offsets) {
   auto* r = new radius_result;
   static_cast<tree_base*>(t)->radius(q, nq, radius, e, approx != 0, sort != 0,
@@ -272,7 +280,7 @@ void ptkref_radius_copy(void* h, void* out) {
 
 void ptkref_radius_free(void* h) { delete static_cast<radius_result*>(h); }
 
-void* ptkref_search_box(void* t, float const* mins, float const* maxs,
+void* ptkref_search_box(void* t, scalar_t const* mins, scalar_t const* maxs,
                         size_t nb, std::uint64_t* offsets) {
   auto* r = new box_result;
   static_cast<tree_base*>(t)->box(mins, maxs, nb, r->rows);
@@ -299,15 +307,15 @@ void ptkref_box_free(void* h) { delete static_cast<box_result*>(h); }
 // search_knn visitor with a one-element range, which visits exactly what
 // search_nn visits): per query, the number of branch nodes expanded and points
 // measured.  Single-threaded; builds its own tree with the counting metric.
-void ptkref_count_visits(float const* pts, size_t n, size_t dim,
-                         size_t max_leaf, float const* q, size_t nq, size_t k,
+void ptkref_count_visits(scalar_t const* pts, size_t n, size_t dim,
+                         size_t max_leaf, scalar_t const* q, size_t nq, size_t k,
                          std::uint32_t* n_branch, std::uint32_t* n_pts) {
   dispatch_dim(dim, [&](auto d) {
     constexpr size_t D = decltype(d)::value;
-    using point_t = pico_tree::point_map<float const, D>;
+    using point_t = pico_tree::point_map<scalar_t const, D>;
     using space_t = pico_tree::space_map<point_t>;
     using kd_t = pico_tree::kd_tree<space_t, counting_l2>;
-    auto mk = [&](float const* p, size_t c) {
+    auto mk = [&](scalar_t const* p, size_t c) {
       if constexpr (D == pico_tree::dynamic_extent) {
         return space_t(p, c, dim);
       } else {
@@ -331,11 +339,11 @@ void ptkref_count_visits(float const* pts, size_t n, size_t dim,
 // Known-answer hook for the reference's own splitter test
 // (test/pico_tree/kd_tree_builder_test.cpp:134-197): runs
 // splitter_sliding_midpoint_max_side on 2-D points with the given box.
-void ptkref_sliding_midpoint_2d(float const* pts, size_t n, int* indices,
-                                float const* box_min, float const* box_max,
+void ptkref_sliding_midpoint_2d(scalar_t const* pts, size_t n, int* indices,
+                                scalar_t const* box_min, scalar_t const* box_max,
                                 size_t* split_offset, size_t* split_dim,
-                                float* split_val) {
-  using point_t = pico_tree::point_map<float const, 2>;
+                                scalar_t* split_val) {
+  using point_t = pico_tree::point_map<scalar_t const, 2>;
   using space_t = pico_tree::space_map<point_t>;
   using wrapper_t = pico_tree::internal::space_wrapper<space_t>;
   using splitter_t =
@@ -343,7 +351,7 @@ void ptkref_sliding_midpoint_2d(float const* pts, size_t n, int* indices,
   space_t space(pts, n);
   wrapper_t wrapper(space);
   splitter_t splitter(wrapper);
-  pico_tree::internal::box<float, 2> box(2);
+  pico_tree::internal::box<scalar_t, 2> box(2);
   for (size_t i = 0; i < 2; ++i) {
     box.min(i) = box_min[i];
     box.max(i) = box_max[i];
@@ -351,7 +359,7 @@ void ptkref_sliding_midpoint_2d(float const* pts, size_t n, int* indices,
   std::vector<int> idx(indices, indices + n);
   std::vector<int>::iterator split;
   pico_tree::size_t sd = 0;
-  float sv = 0;
+  scalar_t sv = 0;
   splitter(0, idx.begin(), idx.end(), box, split, sd, sv);
   *split_offset = static_cast<size_t>(split - idx.begin());
   *split_dim = sd;

@@ -30,7 +30,7 @@ import numpy as np
 
 from . import datasets  # noqa: F401  (re-export)
 
-__all__ = ["KdTree", "KdForest", "save_kd_tree", "load_kd_tree", "Metric", "NEIGHBOR", "DArray", "DeviceNeighbors", "PtkError",
+__all__ = ["KdTree", "KdForest", "save_kd_tree", "load_kd_tree", "Metric", "NEIGHBOR", "NEIGHBOR64", "DArray", "DeviceNeighbors", "PtkError",
            "library_path", "device_count", "datasets"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
@@ -38,6 +38,11 @@ _LIB_PATH = os.path.join(_HERE, "csrc", "libptk.so")
 
 #: Result record; identical to the reference binding's neighbor dtype.
 NEIGHBOR = np.dtype([("index", "<i4"), ("distance", "<f4")])
+#: The same record of a tree over float64 points: ``neighbor<int, double>`` is 16 bytes with the
+#: distance at offset 8, which is what the reference binding's PYBIND11_NUMPY_DTYPE yields for it
+#: (_pyco_tree/def_core.hpp:17-18).
+NEIGHBOR64 = np.dtype({"names": ["index", "distance"], "formats": ["<i4", "<f8"], "offsets": [0, 8],
+                       "itemsize": 16})
 
 PTK_OK = 0
 PTK_DEVICE_CURRENT = -1
@@ -96,6 +101,18 @@ _SIGNATURES = {
     "ptk_search_box": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p,
                                POINTER(c_void_p)]),
     "ptk_free": (None, [c_void_p]),
+    "ptk_tree64_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_int32, POINTER(c_void_p)]),
+    "ptk_tree64_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
+                                              POINTER(c_void_p)]),
+    "ptk_tree64_destroy": (None, [c_void_p]),
+    "ptk_tree64_get_info": (c_int, [c_void_p, POINTER(_Info)]),
+    "ptk_tree64_set_metric": (c_int, [c_void_p, c_int]),
+    "ptk_tree64_serialize": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
+    "ptk_search64_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_double, c_void_p]),
+    "ptk_search64_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_double, c_void_p, c_void_p]),
+    "ptk_search64_radius": (c_int, [c_void_p, c_void_p, c_uint64, c_double, c_double, c_int, c_void_p,
+                                    POINTER(c_void_p)]),
+    "ptk_search64_box": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, POINTER(c_void_p)]),
     "ptk_forest_create": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_uint32, c_uint64, c_int32,
                                   POINTER(c_void_p)]),
     "ptk_forest_destroy": (None, [c_void_p]),
@@ -178,7 +195,7 @@ class DArray:
             offsets, dtype = dtype, None  # DArray(offsets, flat): the internal form
         if flat is None:
             dt = np.dtype(dtype if dtype is not None else NEIGHBOR)
-            if dt != NEIGHBOR and dt != np.dtype(np.int32):
+            if dt != NEIGHBOR and dt != NEIGHBOR64 and dt != np.dtype(np.int32):
                 raise ValueError("unexpected dtype for DArray")
             flat = np.empty(0, dtype=dt)
             offsets = np.zeros(1, dtype=np.uint64)
@@ -227,7 +244,9 @@ class DArray:
 
 
 class DeviceNeighbors:
-    """k-NN result resident on the device: ``raw`` is int32 ``(nq, k, 2)``."""
+    """k-NN result resident on the device: ``raw`` is int32 ``(nq, k, 2)`` -- (index, bits of the
+    float32 distance) -- for a float32 tree and int64 ``(nq, k, 2)`` -- (index, bits of the float64
+    distance) -- for a float64 tree (the 16-byte ``neighbor<int, double>`` record)."""
 
     def __init__(self, raw):
         self.raw = raw
@@ -239,22 +258,25 @@ class DeviceNeighbors:
     @property
     def distance(self):
         import torch
-        return self.raw[..., 1].view(torch.float32)
+        return self.raw[..., 1].view(torch.float64 if self.raw.dtype == torch.int64 else torch.float32)
 
     def numpy(self) -> np.ndarray:
-        """Host copy with the :data:`NEIGHBOR` dtype, shape ``(nq,)`` or ``(nq, k)``."""
+        """Host copy with the :data:`NEIGHBOR` (or :data:`NEIGHBOR64`) dtype, shape ``(nq,)`` or ``(nq, k)``."""
         a = self.raw.cpu().numpy()
-        out = np.ascontiguousarray(a).view(NEIGHBOR)[..., 0]
+        out = np.ascontiguousarray(a).view(NEIGHBOR64 if a.dtype == np.int64 else NEIGHBOR)[..., 0]
         return out[:, 0] if out.shape[1] == 1 else out
 
 
 class KdTree:
-    """A kd-tree over float32 points, searched on the MI355X.
+    """A kd-tree over float32 or float64 points, searched on the MI355X.
 
     ``KdTree(pts, Metric.L2Squared, max_leaf_size)`` as in the reference.  ``pts``
-    is ``(npts, sdim)`` C-contiguous float32 (an F-contiguous ``(sdim, npts)``
-    array is the same memory and accepted like the reference does).  The tree is
-    built on the host with the sliding-midpoint rule and uploaded once.
+    is ``(npts, sdim)`` C-contiguous (an F-contiguous ``(sdim, npts)`` array is the
+    same memory and accepted like the reference does); its dtype selects the
+    instantiation like the reference's dispatch does (_pyco_tree/kd_tree.hpp:383-445):
+    float32 -> the tuned kernels (``ptk_*``), float64 -> the double-precision
+    kernels (``ptk_tree64_*`` / ``ptk_search64_*``, results ``NEIGHBOR64``).  The tree
+    is built on the host with the sliding-midpoint rule and uploaded once.
     """
 
     def __init__(self, pts, metric: Metric = Metric.L2Squared, max_leaf_size: int = 10,
@@ -262,7 +284,12 @@ class KdTree:
         if not isinstance(metric, Metric):
             raise TypeError("metric must be a pico_tree_amd.Metric")
         self._metric = metric
-        pts = self._as_matrix(pts, None, "pts")
+        if isinstance(pts, np.ndarray) and pts.dtype == np.float64:
+            self._dtype, self._neighbor, self._f64 = np.dtype(np.float64), NEIGHBOR64, True
+        else:
+            self._dtype, self._neighbor, self._f64 = np.dtype(np.float32), NEIGHBOR, False
+        self._real = np.float64 if self._f64 else np.float32
+        pts = self._as_matrix(pts, None, "pts", self._dtype)
         if int(max_leaf_size) <= 0:
             raise ValueError("max_leaf_size must be positive")
         self._pts = pts  # keep alive, like py::keep_alive<1, 2>
@@ -271,16 +298,18 @@ class KdTree:
         lib = _load()
         handle = c_void_p()
         dev = PTK_DEVICE_CURRENT if device is None else int(device)
+        self._fn = (lambda name: getattr(lib, name.replace("ptk_tree_", "ptk_tree64_").replace("ptk_search_", "ptk_search64_"))) \
+            if self._f64 else (lambda name: getattr(lib, name))
         if _stream is None:
-            _check(lib.ptk_tree_create_from_points(pts.ctypes.data, self._npts, self._sdim,
-                                                   self._max_leaf_size, dev, byref(handle)))
+            _check(self._fn("ptk_tree_create_from_points")(pts.ctypes.data, self._npts, self._sdim,
+                                                           self._max_leaf_size, dev, byref(handle)))
         else:  # load_kd_tree: the tree comes from a saved stream
             buf = ctypes.create_string_buffer(_stream, len(_stream))
-            _check(lib.ptk_tree_create_from_stream(pts.ctypes.data, self._npts, self._sdim, buf, len(_stream),
-                                                   dev, byref(handle)))
+            _check(self._fn("ptk_tree_create_from_stream")(pts.ctypes.data, self._npts, self._sdim, buf,
+                                                           len(_stream), dev, byref(handle)))
         self._h = handle
         if metric is not Metric.L2Squared:
-            _check(lib.ptk_tree_set_metric(handle, _PTK_METRIC[metric]))
+            _check(self._fn("ptk_tree_set_metric")(handle, _PTK_METRIC[metric]))
 
     @property
     def metric_string(self) -> str:  # core.hpp:24-38
@@ -288,19 +317,18 @@ class KdTree:
 
     def _serialize(self) -> bytes:
         size = c_uint64()
-        lib = _load()
-        _check(lib.ptk_tree_serialize(self._h, None, 0, byref(size)))
+        _check(self._fn("ptk_tree_serialize")(self._h, None, 0, byref(size)))
         buf = ctypes.create_string_buffer(size.value)
-        _check(lib.ptk_tree_serialize(self._h, buf, size.value, byref(size)))
+        _check(self._fn("ptk_tree_serialize")(self._h, buf, size.value, byref(size)))
         return buf.raw[:size.value]
 
     # -- helpers ---------------------------------------------------------------
     @staticmethod
-    def _as_matrix(a, sdim, what):
+    def _as_matrix(a, sdim, what, dtype=np.float32):
         """Validates like py_array_map.hpp:37-62 and returns a C-order view."""
         if not isinstance(a, np.ndarray):
             raise ValueError(f"{what} must be a numpy array")
-        if a.dtype != np.float32:
+        if a.dtype != dtype:
             raise ValueError("unexpected dtype_scalar for data")
         if a.ndim != 2:
             raise ValueError(f"{what} must have 2 dimensions")
@@ -317,7 +345,7 @@ class KdTree:
     def close(self) -> None:
         h = getattr(self, "_h", None)
         if h is not None and h.value:
-            _load().ptk_tree_destroy(h)
+            self._fn("ptk_tree_destroy")(h)
             self._h = None
 
     def __del__(self):
@@ -327,7 +355,7 @@ class KdTree:
             pass
 
     def __repr__(self) -> str:  # _pyco_tree/kd_tree.hpp:321-326
-        return f"KdTree(metric={self._metric.name}, dtype=float32, sdim={self._sdim}, npts={self._npts})"
+        return f"KdTree(metric={self._metric.name}, dtype={self._dtype.name}, sdim={self._sdim}, npts={self._npts})"
 
     # -- properties (names of the reference binding) ----------------------------------
     @property
@@ -344,25 +372,30 @@ class KdTree:
 
     @property
     def dtype_scalar(self):
-        return np.dtype(np.float32)
+        return self._dtype
 
     @property
     def dtype_neighbor(self):
-        return NEIGHBOR
+        return self._neighbor
 
     def metric(self, scalar: float) -> float:
-        """The metric's one-dimensional form in float32: ``x * x`` for L2Squared, ``|x|`` for L1 and
-        LPInf (metric.hpp:95-98, :120-123, :147-150)."""
-        x = np.float32(scalar)
+        """The metric's one-dimensional form in the tree's scalar type: ``x * x`` for L2Squared, ``|x|``
+        for L1 and LPInf (metric.hpp:95-98, :120-123, :147-150)."""
+        x = self._real(scalar)
         return float(x * x) if self._metric is Metric.L2Squared else float(abs(x))
 
     def info(self) -> dict:
         inf = _Info()
-        _check(_load().ptk_tree_get_info(self._h, byref(inf)))
+        _check(self._fn("ptk_tree_get_info")(self._h, byref(inf)))
         return {name: getattr(inf, name) for name, _ in _Info._fields_}
+
+    def _float32_only(self, what):
+        if self._f64:
+            raise PtkError(-2, f"{what} is available for float32 trees only")
 
     def flat(self):
         """(nodes uint32[n_nodes, 4], indices int32[npts], root_min, root_max)."""
+        self._float32_only("flat()")
         inf = self.info()
         nodes = np.empty((inf["n_nodes"], 4), dtype=np.uint32)
         indices = np.empty(self._npts, dtype=np.int32)
@@ -373,9 +406,12 @@ class KdTree:
         return nodes, indices, rmin, rmax
 
     def set_reorder(self, mode: int) -> None:
+        if self._f64:
+            return  # the double-precision kernels take the batch in the caller's order
         _check(_load().ptk_tree_set_reorder(self._h, int(mode)))
 
     def profile(self, enable: bool | None = None, reset: bool = False) -> dict:
+        self._float32_only("profile()")
         lib = _load()
         if enable is not None:
             _check(lib.ptk_profile_enable(self._h, int(enable)))
@@ -395,67 +431,69 @@ class KdTree:
         k = int(k)
         if _is_torch(pts):
             return self._search_knn_device(pts, k, e, nns)
-        q = self._as_matrix(pts, self._sdim, "pts")
+        q = self._as_matrix(pts, self._sdim, "pts", self._dtype)
         nq = q.shape[0]
         shape = (nq,) if k == 1 else ((nq, k) if pts.flags.c_contiguous else (k, nq))
+        NB = self._neighbor
         if nns is None:
-            nns = np.empty(shape, dtype=NEIGHBOR)
-        elif not isinstance(nns, np.ndarray) or nns.dtype != NEIGHBOR:
+            nns = np.zeros(shape, dtype=NB) if self._f64 else np.empty(shape, dtype=NB)
+        elif not isinstance(nns, np.ndarray) or nns.dtype != NB:
             raise ValueError("unexpected dtype_neighbor for data")
         elif nns.size != nq * k or not nns.flags.c_contiguous:
             # Resized like ensure_size() of the reference (kd_tree.hpp:362-378).
             try:
                 nns.resize(shape, refcheck=False)
             except ValueError:
-                nns = np.empty(shape, dtype=NEIGHBOR)
+                nns = np.empty(shape, dtype=NB)
+        search = self._fn("ptk_search_knn")
         if k > 1 and not pts.flags.c_contiguous:
             # Column-major callers get the transposed (k, npts) layout of the reference
             # (kd_tree.hpp:362-378): row i of the search is column i of the output.
-            tmp = np.empty((nq, k), dtype=NEIGHBOR)
-            _check(_load().ptk_search_knn(self._h, q.ctypes.data, nq, k, np.float32(e),
-                                          tmp.ctypes.data))
+            tmp = np.empty((nq, k), dtype=NB)
+            _check(search(self._h, q.ctypes.data, nq, k, self._real(e), tmp.ctypes.data))
             nns.reshape(-1)[:] = tmp.reshape(-1)
             return nns
-        _check(_load().ptk_search_knn(self._h, q.ctypes.data, nq, k, np.float32(e),
-                                      nns.ctypes.data))
+        _check(search(self._h, q.ctypes.data, nq, k, self._real(e), nns.ctypes.data))
         return nns
 
     def _search_knn_device(self, q, k, e, out):
         import torch
-        if q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != self._sdim:
-            raise ValueError("queries must be a float32 (nq, sdim) tensor")
+        tq, traw = (torch.float64, torch.int64) if self._f64 else (torch.float32, torch.int32)
+        if q.dtype != tq or q.dim() != 2 or q.shape[1] != self._sdim:
+            raise ValueError(f"queries must be a {self._dtype.name} (nq, sdim) tensor")
         if not q.is_cuda or not q.is_contiguous():
             raise ValueError("queries must be a contiguous CUDA tensor")
         nq = q.shape[0]
         if out is None:
-            out = torch.empty((nq, k, 2), dtype=torch.int32, device=q.device)
+            # float64: the records carry 4 bytes of padding, zeroed so that index reads as an int64
+            out = (torch.zeros if self._f64 else torch.empty)((nq, k, 2), dtype=traw, device=q.device)
         elif isinstance(out, DeviceNeighbors):
             out = out.raw
-        if out.dtype != torch.int32 or tuple(out.shape) != (nq, k, 2) or not out.is_contiguous():
-            raise ValueError("nns must be a contiguous int32 (nq, k, 2) tensor")
+        if out.dtype != traw or tuple(out.shape) != (nq, k, 2) or not out.is_contiguous():
+            raise ValueError(f"nns must be a contiguous {traw} (nq, k, 2) tensor")
         stream = torch.cuda.current_stream(q.device).cuda_stream
-        _check(_load().ptk_search_knn_device(self._h, q.data_ptr(), nq, k, np.float32(e),
-                                             out.data_ptr(), stream))
+        _check(self._fn("ptk_search_knn_device")(self._h, q.data_ptr(), nq, k, self._real(e),
+                                                 out.data_ptr(), stream))
         return DeviceNeighbors(out)
 
     # -- radius ---------------------------------------------------------------------------
     def search_radius(self, pts, radius: float, *args, sort: bool = False):
         """``search_radius(pts, radius[, e][, nns], sort=False)`` -> :class:`DArray`."""
         e, nns, sort = self._split_optional_radius(args, sort)
-        q = self._as_matrix(pts, self._sdim, "pts")
+        q = self._as_matrix(pts, self._sdim, "pts", self._dtype)
         nq = q.shape[0]
-        if nns is not None and not isinstance(nns, DArray):
+        if nns is not None and (not isinstance(nns, DArray) or nns.dtype != self._neighbor):
             raise ValueError("unexpected dtype_neighbor for data")
         offsets = np.zeros(nq + 1, dtype=np.uint64)
         rows = c_void_p()
         lib = _load()
-        _check(lib.ptk_search_radius(self._h, q.ctypes.data, nq, np.float32(radius),
-                                     np.float32(e), int(bool(sort)), offsets.ctypes.data,
-                                     byref(rows)))
+        _check(self._fn("ptk_search_radius")(self._h, q.ctypes.data, nq, self._real(radius),
+                                             self._real(e), int(bool(sort)), offsets.ctypes.data,
+                                             byref(rows)))
         total = int(offsets[-1])
-        flat = np.empty(total, dtype=NEIGHBOR)
+        flat = np.empty(total, dtype=self._neighbor)
         if total:
-            ctypes.memmove(flat.ctypes.data, rows.value, total * NEIGHBOR.itemsize)
+            ctypes.memmove(flat.ctypes.data, rows.value, total * self._neighbor.itemsize)
         lib.ptk_free(rows)
         if nns is None:
             return DArray(offsets, flat)
@@ -469,7 +507,7 @@ class KdTree:
         ``boxes`` is ``(2 * nbox, sdim)``: rows ``2 i`` and ``2 i + 1`` are the min and max corner
         of box ``i`` (``_pyco_tree/kd_tree.hpp:245-268``).  Row ``i`` of the result lists the points
         inside the closed box in the reference's traversal order."""
-        b = self._as_matrix(boxes, self._sdim, "boxes")
+        b = self._as_matrix(boxes, self._sdim, "boxes", self._dtype)
         if b.shape[0] % 2 != 0:
             raise ValueError("query min and max don't have equal size")
         nb = b.shape[0] // 2
@@ -480,8 +518,8 @@ class KdTree:
         offsets = np.zeros(nb + 1, dtype=np.uint64)
         rows = c_void_p()
         lib = _load()
-        _check(lib.ptk_search_box(self._h, mins.ctypes.data, maxs.ctypes.data, nb, offsets.ctypes.data,
-                                  byref(rows)))
+        _check(self._fn("ptk_search_box")(self._h, mins.ctypes.data, maxs.ctypes.data, nb, offsets.ctypes.data,
+                                          byref(rows)))
         total = int(offsets[-1])
         flat = np.empty(total, dtype=np.int32)
         if total:
@@ -495,6 +533,7 @@ class KdTree:
     def search_radius_device(self, q, radius: float, e: float = 1.0, sort: bool = False):
         """Device form: returns (offsets int64 tensor [nq + 1], raw int32 tensor [total, 2])."""
         import torch
+        self._float32_only("search_radius_device()")
         if q.dtype != torch.float32 or q.dim() != 2 or q.shape[1] != self._sdim:
             raise ValueError("queries must be a float32 (nq, sdim) tensor")
         if not q.is_cuda or not q.is_contiguous():
@@ -650,7 +689,8 @@ def save_kd_tree(tree: KdTree, filename: str) -> None:
 
 def load_kd_tree(pts, filename: str, device: int | None = None) -> KdTree:
     """``pico_tree.load_kd_tree``: rebuilds a :class:`KdTree` over ``pts`` from a file written by
-    :func:`save_kd_tree` or by the reference's own ``save_kd_tree`` (float32, any of its metrics)."""
+    :func:`save_kd_tree` or by the reference's own ``save_kd_tree`` (any of its metrics; the dtype of
+    ``pts`` -- float32 or float64 -- must be the one the tree was built over)."""
     with open(filename, "rb") as f:
         data = f.read()
     if data[:4] != _PKD_SIGNATURE:

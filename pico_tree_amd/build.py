@@ -20,11 +20,14 @@ SOURCES = [os.path.join(CSRC, "ptk_backend.hip")]
 HEADERS = [
     os.path.join(CSRC, "ptk_kernels.hpp"),
     os.path.join(CSRC, "ptk_kernels_nd.hpp"),
+    os.path.join(CSRC, "ptk_kernels_f64.hpp"),
+    os.path.join(CSRC, "ptk_backend_f64.hpp"),
     os.path.join(CSRC, "ptk_forest.hpp"),
     os.path.join(CSRC, "ptk_forest_host.hpp"),
     os.path.join(CSRC, "ptk_encode.hpp"),
     os.path.join(ROOT, "include", "ptk.h"),
     os.path.join(ROOT, "include", "pico_tree", "internal", "flat_tree.hpp"),
+    os.path.join(ROOT, "include", "pico_tree", "internal", "stream.hpp"),
     os.path.join(ROOT, "include", "pico_tree", "internal", "access.hpp"),
     os.path.join(ROOT, "include", "pico_tree", "map.hpp"),
     os.path.join(ROOT, "include", "pico_tree", "traits.hpp"),

@@ -12,6 +12,7 @@
 #include <atomic>
 #include <cmath>
 #include <cstdarg>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -1729,3 +1730,6 @@ int ptk_forest_search_knn(const ptk_forest* f, const float* q, uint64_t nq, uint
 }
 
 }  // extern "C"
+
+// ---- double precision (ptk_tree64_* / ptk_search64_*) -------------------------------------
+#include "ptk_backend_f64.hpp"

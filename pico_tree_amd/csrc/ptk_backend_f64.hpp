@@ -1,0 +1,535 @@
+// ptk_backend_f64.hpp -- host side of the double-precision entry points of include/ptk.h
+// (ptk_tree64_* / ptk_search64_*).  Included at the end of ptk_backend.hip: one translation
+// unit, so it shares the error channel, the HIP helpers and the host builder set-up.
+//
+// Same responsibilities as the float32 side: build (or load) the flat tree on the host with the
+// product's own builder instantiated over double, re-encode it for the kernels of
+// ptk_kernels_f64.hpp, keep it in HBM, launch, move results.  No CPU search path.
+
+#pragma once
+
+#include "ptk_kernels_f64.hpp"
+
+static_assert(sizeof(ptk_neighbor64) == 16 && offsetof(ptk_neighbor64, distance) == 8, "neighbor<int, double> layout");
+
+struct ptk_tree64 {
+  using flat_t = pico_tree::internal::flat_tree<int, double, pico_tree::dynamic_extent>;
+  uint32_t dim = 0;
+  uint64_t n_points = 0;
+  flat_t flat{1};  // host copy (DFS pre-order stream)
+  uint64_t n_leaves = 0;
+  uint32_t max_depth = 0;
+  uint32_t max_leaf_count = 0;
+
+  int device = kDeviceNone;
+  ptk::DevTree64 dev{};
+  void* d_nodes = nullptr;
+  void* d_pts = nullptr;
+  void* d_index = nullptr;
+  void* d_ranges = nullptr;
+  void* d_root = nullptr;  // root box: min[dim], max[dim]
+  uint64_t device_bytes = 0;
+  uint32_t slots = 0;      // stack records a lane may need: 2 * depth + 4
+  std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
+
+  // The record stacks of a launch live in one grow-only HBM block; calls on one handle enqueue under
+  // `mutex` and the block is reused in stream order (`done` orders a call on another stream).
+  mutable std::mutex mutex;
+  mutable char* stack = nullptr;
+  mutable size_t stack_capacity = 0;
+  mutable hipEvent_t done = nullptr;
+  mutable hipStream_t last_stream = nullptr;
+  mutable bool has_work = false;
+};
+
+namespace {
+
+// Stack block of one launch; larger batches go through in pieces (PTK_STACK64_MB shrinks it for tests).
+size_t stack64_bytes() { return (size_t)std::max(1, env_int("PTK_STACK64_MB", 1024)) << 20; }
+
+int encode64(ptk_tree64& t, const double* points) {
+  ptk::TreeStats st;
+  ptk::EncodedTree64 enc;
+  bool unsupported = false;
+  std::string err = ptk::encode_tree64(t.dim, t.n_points, points, t.flat.nodes.data(), t.flat.nodes.size(),
+                                       t.flat.indices.data(), st, enc, unsupported, t.device != kDeviceNone);
+  if (!err.empty()) return fail(unsupported ? PTK_ERR_UNSUPPORTED : PTK_ERR_INVALID, "%s", err.c_str());
+  t.n_leaves = st.n_leaves;
+  t.max_depth = st.max_depth;
+  t.max_leaf_count = st.max_leaf_count;
+  t.slots = 2 * st.max_depth + 4;
+  if (t.device == kDeviceNone) return PTK_OK;
+
+  static_assert(sizeof(ptk::EncNode64) == sizeof(ptk::Node64), "records");
+  std::vector<double> root(2 * (size_t)t.dim);
+  std::memcpy(root.data(), t.flat.root_box.min(), t.dim * sizeof(double));
+  std::memcpy(root.data() + t.dim, t.flat.root_box.max(), t.dim * sizeof(double));
+  const size_t nb = enc.nodes.size() * sizeof(ptk::Node64), pb = enc.points.size() * sizeof(double),
+               ib = t.flat.indices.size() * sizeof(int32_t), rb = enc.ranges.size() * sizeof(ptk::EncRange),
+               bb = root.size() * sizeof(double);
+  PTK_HIP(hipMalloc(&t.d_nodes, nb));
+  PTK_HIP(hipMalloc(&t.d_pts, pb));
+  PTK_HIP(hipMalloc(&t.d_index, ib));
+  PTK_HIP(hipMalloc(&t.d_ranges, rb));
+  PTK_HIP(hipMalloc(&t.d_root, bb));
+  PTK_HIP(hipMemcpy(t.d_nodes, enc.nodes.data(), nb, hipMemcpyHostToDevice));
+  PTK_HIP(hipMemcpy(t.d_pts, enc.points.data(), pb, hipMemcpyHostToDevice));
+  PTK_HIP(hipMemcpy(t.d_index, t.flat.indices.data(), ib, hipMemcpyHostToDevice));
+  PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), rb, hipMemcpyHostToDevice));
+  PTK_HIP(hipMemcpy(t.d_root, root.data(), bb, hipMemcpyHostToDevice));
+  t.device_bytes = nb + pb + ib + rb + bb;
+  t.dev.nodes = static_cast<const ptk::Node64*>(t.d_nodes);
+  t.dev.pts = static_cast<const double*>(t.d_pts);
+  t.dev.index = static_cast<const int32_t*>(t.d_index);
+  t.dev.ranges = static_cast<const uint2*>(t.d_ranges);
+  t.dev.root_ref = enc.root_ref;
+  t.dev.cbits = enc.cbits;
+  t.dev.cmask = (1u << enc.cbits) - 1u;
+  t.dev.dim = t.dim;
+  return PTK_OK;
+}
+
+int finish_create64(ptk_tree64* t, const double* points, int32_t device, ptk_tree64** out) {
+  int dev = kDeviceNone;
+  if (device != kDeviceNone) {
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+      delete t;
+      return fail(PTK_ERR_DEVICE, "no HIP device is visible");
+    }
+    dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    if (dev >= count) {
+      delete t;
+      return fail(PTK_ERR_INVALID, "device %d out of range (%d visible)", dev, count);
+    }
+  }
+  t->device = dev;
+  int rc;
+  if (dev == kDeviceNone) {
+    rc = encode64(*t, points);
+  } else {
+    DeviceGuard guard(dev);
+    rc = guard.ok ? encode64(*t, points) : fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", dev);
+  }
+  if (rc != PTK_OK) {
+    ptk_tree64_destroy(t);
+    return rc;
+  }
+  *out = t;
+  return PTK_OK;
+}
+
+int check_search64(const ptk_tree64* t, const void* q, uint64_t nq) {
+  if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
+  if (nq > 0 && q == nullptr) return fail(PTK_ERR_INVALID, "null query buffer");
+  if (t->device == kDeviceNone) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
+  return PTK_OK;
+}
+
+// Pieces of a batch that fit the stack block; *stack is valid on `s` after the call.
+struct Stack64Lease {
+  const ptk_tree64* t;
+  std::unique_lock<std::mutex> lock;
+  hipStream_t s;
+  bool armed = false;
+  Stack64Lease(const ptk_tree64* tree, hipStream_t stream) : t(tree), lock(tree->mutex), s(stream) {}
+  uint64_t piece = 0;  // queries per launch
+  int acquire(uint64_t n) {
+    const size_t per_block = (size_t)t->slots * 64 * sizeof(ptk::Rec64);
+    uint64_t blocks = (n + 63) / 64;
+    const uint64_t max_blocks = std::max<uint64_t>(1, stack64_bytes() / per_block);
+    if (blocks > max_blocks) blocks = max_blocks;
+    const size_t bytes = blocks * per_block;
+    if (bytes > t->stack_capacity) {
+      if (t->has_work) (void)hipEventSynchronize(t->done);
+      if (t->stack) (void)hipFree(t->stack);
+      t->stack = nullptr;
+      t->stack_capacity = 0;
+      t->has_work = false;
+      if (hipMalloc((void**)&t->stack, bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        t->stack = nullptr;
+        return fail(PTK_ERR_NOMEM, "out of device memory (%zu bytes of traversal stacks)", bytes);
+      }
+      t->stack_capacity = bytes;
+    }
+    if (t->has_work && t->last_stream != s) PTK_HIP(hipStreamWaitEvent(s, t->done, 0));
+    piece = blocks * 64;
+    armed = true;
+    return PTK_OK;
+  }
+  ~Stack64Lease() {
+    if (!armed) return;
+    if (t->done == nullptr && hipEventCreateWithFlags(&t->done, hipEventDisableTiming) != hipSuccess) {
+      t->done = nullptr;
+      (void)hipStreamSynchronize(s);
+      t->has_work = false;
+      return;
+    }
+    (void)hipEventRecord(t->done, s);
+    t->last_stream = s;
+    t->has_work = true;
+  }
+};
+
+#define PTK_WITH_METRIC64(CALL)                         \
+  do {                                                  \
+    const int metric_ = t->metric.load();               \
+    if (metric_ == PTK_METRIC_L1) {                     \
+      using M = ptk::Metric64L1;                        \
+      CALL;                                             \
+    } else if (metric_ == PTK_METRIC_LPINF) {           \
+      using M = ptk::Metric64LInf;                      \
+      CALL;                                             \
+    } else {                                            \
+      using M = ptk::Metric64L2;                        \
+      CALL;                                             \
+    }                                                   \
+  } while (0)
+
+template <class M>
+int launch_knn64(const ptk_tree64* t, const double* d_q, uint64_t nq, uint32_t k, double e, ptk::Neighbor64* d_out,
+                 hipStream_t s, Stack64Lease& lease) {
+  const size_t smem = (size_t)2 * t->dim * 64 * sizeof(double);
+  if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
+  int rc = allow_lds(ptk::knn64_kernel<M>, smem);
+  if (rc != PTK_OK) return rc;
+  for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {
+    const uint64_t n = std::min(lease.piece, nq - q0);
+    hipLaunchKernelGGL((ptk::knn64_kernel<M>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, d_q, q0, n, k,
+                       1.0 / e, d_out, reinterpret_cast<ptk::Rec64*>(t->stack), t->slots);
+  }
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+
+template <class M, bool FILL>
+int launch_radius64(const ptk_tree64* t, const double* d_q, uint64_t nq, double radius, double e, uint64_t* d_counts,
+                    const uint64_t* d_offsets, ptk::Neighbor64* d_out, hipStream_t s, Stack64Lease& lease) {
+  const size_t smem = (size_t)2 * t->dim * 64 * sizeof(double);
+  if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
+  int rc = allow_lds(ptk::radius64_kernel<M, FILL>, smem);
+  if (rc != PTK_OK) return rc;
+  for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {
+    const uint64_t n = std::min(lease.piece, nq - q0);
+    hipLaunchKernelGGL((ptk::radius64_kernel<M, FILL>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, d_q, q0,
+                       n, radius, 1.0 / e, d_counts, d_offsets, d_out, reinterpret_cast<ptk::Rec64*>(t->stack), t->slots);
+  }
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+
+template <bool FILL>
+int launch_box64(const ptk_tree64* t, const double* d_mins, const double* d_maxs, uint64_t nb, uint64_t* d_counts,
+                 const uint64_t* d_offsets, int32_t* d_out, hipStream_t s, Stack64Lease& lease) {
+  const size_t smem = (size_t)4 * t->dim * 64 * sizeof(double);
+  if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
+  int rc = allow_lds(ptk::box64_kernel<FILL>, smem);
+  if (rc != PTK_OK) return rc;
+  for (uint64_t b0 = 0; b0 < nb; b0 += lease.piece) {
+    const uint64_t n = std::min(lease.piece, nb - b0);
+    hipLaunchKernelGGL((ptk::box64_kernel<FILL>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
+                       static_cast<const double*>(t->d_root), d_mins, d_maxs, b0, n, d_counts, d_offsets, d_out,
+                       reinterpret_cast<ptk::Rec64*>(t->stack), t->slots);
+  }
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+
+// counts (nq + 1, last = 0) -> offsets (nq + 1) on the device, offsets copied to the host.
+int scan_counts64(uint64_t* d_c, uint64_t* d_o, uint64_t nq, uint64_t* offsets) {
+  size_t tmp_bytes = 0;
+  void* tmp = nullptr;
+  hipError_t he = rocprim::exclusive_scan(nullptr, tmp_bytes, d_c, d_o, (uint64_t)0, nq + 1, rocprim::plus<uint64_t>(),
+                                          (hipStream_t) nullptr);
+  if (he == hipSuccess) he = hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 16);
+  if (he == hipSuccess)
+    he = rocprim::exclusive_scan(tmp, tmp_bytes, d_c, d_o, (uint64_t)0, nq + 1, rocprim::plus<uint64_t>(),
+                                 (hipStream_t) nullptr);
+  if (he == hipSuccess) he = hipMemcpy(offsets, d_o, (nq + 1) * 8, hipMemcpyDeviceToHost);
+  if (tmp) (void)hipFree(tmp);
+  if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error in the offsets scan: %s", hipGetErrorString(he));
+  return PTK_OK;
+}
+
+template <class Flat>
+void adopt_flat64(ptk_tree64* t, Flat&& flat, uint32_t dim, uint64_t n_points) {
+  t->dim = dim;
+  t->n_points = n_points;
+  t->flat = std::forward<Flat>(flat);
+}
+
+}  // namespace
+
+extern "C" {
+
+int ptk_tree64_create_from_points(const double* points, uint64_t n_points, uint32_t dim, uint64_t max_leaf_size,
+                                  int32_t device, ptk_tree64** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (points == nullptr) return fail(PTK_ERR_INVALID, "null points");
+  if (dim == 0 || n_points == 0 || max_leaf_size == 0)
+    return fail(PTK_ERR_INVALID, "dim, n_points and max_leaf_size must be positive");
+  if (n_points >= (1ull << 31)) return fail(PTK_ERR_INVALID, "n_points must be < 2^31");
+  ptk_tree64* t = new (std::nothrow) ptk_tree64;
+  if (t == nullptr) return fail(PTK_ERR_NOMEM, "out of memory");
+  try {
+    using namespace pico_tree;
+    using space_t = space_map<point_map<double const, dynamic_extent>>;
+    space_t space(points, n_points, dim);
+    internal::space_view<space_t> view(space);
+    adopt_flat64(t, internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
+                                                   sliding_midpoint_max_side, false, build_threads()),
+                 dim, n_points);
+  } catch (const std::bad_alloc&) {
+    delete t;
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  } catch (const std::length_error& err) {  // degenerate point set: see flat_builder::grow
+    delete t;
+    return fail(PTK_ERR_UNSUPPORTED, "%s", err.what());
+  }
+  return finish_create64(t, points, device, out);
+}
+
+int ptk_tree64_create_from_stream(const double* points, uint64_t n_points, uint32_t dim, const void* stream,
+                                  uint64_t stream_bytes, int32_t device, ptk_tree64** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (points == nullptr || stream == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (dim == 0 || n_points == 0) return fail(PTK_ERR_INVALID, "dim and n_points must be positive");
+  ptk_tree64* t = nullptr;
+  try {
+    std::istringstream is(std::string(static_cast<const char*>(stream), stream_bytes), std::ios::in | std::ios::binary);
+    ptk_tree64::flat_t flat = pico_tree::internal::read_flat_tree<ptk_tree64::flat_t>(is);
+    if (flat.root_box.size() != dim) return fail(PTK_ERR_INVALID, "stream is %zu-dimensional, points are %u-dimensional",
+                                                 (size_t)flat.root_box.size(), dim);
+    if (flat.indices.size() != n_points)
+      return fail(PTK_ERR_INVALID, "stream indexes %zu points, %llu were given", flat.indices.size(),
+                  (unsigned long long)n_points);
+    t = new ptk_tree64;
+    adopt_flat64(t, std::move(flat), dim, n_points);
+  } catch (const std::bad_alloc&) {
+    delete t;
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  } catch (const std::exception& e) {
+    delete t;
+    return fail(PTK_ERR_INVALID, "bad kd_tree stream: %s", e.what());
+  }
+  return finish_create64(t, points, device, out);
+}
+
+void ptk_tree64_destroy(ptk_tree64* t) {
+  if (t == nullptr) return;
+  if (t->device >= 0) {
+    DeviceGuard guard(t->device);
+    if (t->has_work) (void)hipEventSynchronize(t->done);
+    if (t->done) (void)hipEventDestroy(t->done);
+    if (t->stack) (void)hipFree(t->stack);
+    if (t->d_nodes) (void)hipFree(t->d_nodes);
+    if (t->d_pts) (void)hipFree(t->d_pts);
+    if (t->d_index) (void)hipFree(t->d_index);
+    if (t->d_ranges) (void)hipFree(t->d_ranges);
+    if (t->d_root) (void)hipFree(t->d_root);
+  }
+  delete t;
+}
+
+int ptk_tree64_get_info(const ptk_tree64* t, ptk_tree_info* info) {
+  if (t == nullptr || info == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  info->dim = t->dim;
+  info->n_points = t->n_points;
+  info->n_nodes = t->flat.nodes.size();
+  info->n_leaves = t->n_leaves;
+  info->max_depth = t->max_depth;
+  info->max_leaf_count = t->max_leaf_count;
+  info->device_bytes = t->device_bytes;
+  info->device = t->device;
+  return PTK_OK;
+}
+
+int ptk_tree64_set_metric(ptk_tree64* t, int metric) {
+  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LPINF)
+    return fail(PTK_ERR_INVALID, "bad metric");
+  t->metric.store(metric);
+  return PTK_OK;
+}
+
+int ptk_tree64_serialize(const ptk_tree64* t, void* buf, uint64_t cap, uint64_t* size) {
+  if (t == nullptr || size == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  try {
+    std::ostringstream os(std::ios::out | std::ios::binary);
+    pico_tree::internal::write_flat_tree(t->flat, os);
+    const std::string bytes = os.str();
+    *size = bytes.size();
+    if (buf == nullptr) return PTK_OK;
+    if (cap < bytes.size()) return fail(PTK_ERR_INVALID, "buffer of %llu bytes, stream needs %llu",
+                                        (unsigned long long)cap, (unsigned long long)bytes.size());
+    std::memcpy(buf, bytes.data(), bytes.size());
+    return PTK_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  }
+}
+
+int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq, uint32_t k, double e,
+                            ptk_neighbor64* d_out, void* stream) {
+  int rc = check_search64(t, d_q, nq);
+  if (rc != PTK_OK) return rc;
+  if (k == 0) return fail(PTK_ERR_INVALID, "k must be >= 1");
+  if (k > t->n_points) return fail(PTK_ERR_INVALID, "k = %u exceeds the number of points (%llu)", k,
+                                   (unsigned long long)t->n_points);
+  if (!(e > 0.0)) return fail(PTK_ERR_INVALID, "approximation ratio e must be > 0");
+  if (nq == 0) return PTK_OK;
+  if (d_out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  Stack64Lease lease(t, s);
+  rc = lease.acquire(nq);
+  if (rc != PTK_OK) return rc;
+  PTK_WITH_METRIC64(rc = launch_knn64<M>(t, d_q, nq, k, e, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease));
+  return rc;
+}
+
+int ptk_search64_knn(const ptk_tree64* t, const double* q, uint64_t nq, uint32_t k, double e, ptk_neighbor64* out) {
+  int rc = check_search64(t, q, nq);
+  if (rc != PTK_OK) return rc;
+  if (nq == 0) return PTK_OK;
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  double* d_q = nullptr;
+  ptk_neighbor64* d_out = nullptr;
+  const size_t qbytes = (size_t)nq * t->dim * sizeof(double), obytes = (size_t)nq * k * sizeof(ptk_neighbor64);
+  hipError_t he = hipMalloc((void**)&d_q, qbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_out, obytes ? obytes : 16);
+  if (he == hipSuccess) he = hipMemset(d_out, 0, obytes ? obytes : 16);  // padding bytes of the records
+  if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    rc = ptk_search64_knn_device(t, d_q, nq, k, e, d_out, nullptr);
+    if (rc == PTK_OK) he = hipMemcpy(out, d_out, obytes, hipMemcpyDeviceToHost);
+  }
+  if (d_q) (void)hipFree(d_q);
+  if (d_out) (void)hipFree(d_out);
+  if (rc == PTK_OK && he != hipSuccess) rc = fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  return rc;
+}
+
+int ptk_search64_radius(const ptk_tree64* t, const double* q, uint64_t nq, double radius, double e, int sort,
+                        uint64_t* offsets, ptk_neighbor64** out) {
+  if (out == nullptr || offsets == nullptr) return fail(PTK_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  int rc = check_search64(t, q, nq);
+  if (rc != PTK_OK) return rc;
+  if (!(e > 0.0)) return fail(PTK_ERR_INVALID, "approximation ratio e must be > 0");
+  offsets[0] = 0;
+  if (nq == 0) return PTK_OK;
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  double* d_q = nullptr;
+  uint64_t *d_c = nullptr, *d_o = nullptr;
+  ptk_neighbor64* d_out = nullptr;
+  const size_t qbytes = (size_t)nq * t->dim * sizeof(double);
+  hipError_t he = hipMalloc((void**)&d_q, qbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_c, (nq + 1) * 8);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nq + 1) * 8);
+  if (he == hipSuccess) he = hipMemset(d_c, 0, (nq + 1) * 8);
+  if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
+  uint64_t total = 0;
+  if (he == hipSuccess) {
+    Stack64Lease lease(t, nullptr);
+    rc = lease.acquire(nq);
+    if (rc == PTK_OK)
+      PTK_WITH_METRIC64(rc = (launch_radius64<M, false>(t, d_q, nq, radius, e, d_c, nullptr, nullptr, nullptr, lease)));
+    if (rc == PTK_OK) rc = scan_counts64(d_c, d_o, nq, offsets);
+    if (rc == PTK_OK) {
+      total = offsets[nq];
+      const size_t obytes = std::max<uint64_t>(total, 1) * sizeof(ptk_neighbor64);
+      he = hipMalloc((void**)&d_out, obytes);
+      if (he == hipSuccess) he = hipMemset(d_out, 0, obytes);
+      if (he == hipSuccess)
+        PTK_WITH_METRIC64(rc = (launch_radius64<M, true>(t, d_q, nq, radius, e, nullptr, d_o,
+                                                         reinterpret_cast<ptk::Neighbor64*>(d_out), nullptr, lease)));
+      if (he == hipSuccess && rc == PTK_OK && sort) {
+        hipLaunchKernelGGL(ptk::sort_rows64_kernel, dim3((uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock)), dim3(ptk::kBlock),
+                           0, nullptr, d_o, nq, reinterpret_cast<ptk::Neighbor64*>(d_out));
+        he = hipGetLastError();
+      }
+      if (he == hipSuccess && rc == PTK_OK) {
+        *out = static_cast<ptk_neighbor64*>(std::malloc(obytes));
+        if (*out == nullptr) {
+          rc = fail(PTK_ERR_NOMEM, "out of memory");
+        } else {
+          he = hipMemcpy(*out, d_out, obytes, hipMemcpyDeviceToHost);
+        }
+      }
+    }
+  }
+  if (d_q) (void)hipFree(d_q);
+  if (d_c) (void)hipFree(d_c);
+  if (d_o) (void)hipFree(d_o);
+  if (d_out) (void)hipFree(d_out);
+  if (rc == PTK_OK && he != hipSuccess) rc = fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  if (rc != PTK_OK && *out) {
+    std::free(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+int ptk_search64_box(const ptk_tree64* t, const double* mins, const double* maxs, uint64_t nb, uint64_t* offsets,
+                     int32_t** out) {
+  if (out == nullptr || offsets == nullptr) return fail(PTK_ERR_INVALID, "null output pointer");
+  *out = nullptr;
+  int rc = check_search64(t, mins, nb);
+  if (rc != PTK_OK) return rc;
+  if (nb > 0 && maxs == nullptr) return fail(PTK_ERR_INVALID, "null box buffer");
+  offsets[0] = 0;
+  if (nb == 0) return PTK_OK;
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  double *d_mn = nullptr, *d_mx = nullptr;
+  uint64_t *d_c = nullptr, *d_o = nullptr;
+  int32_t* d_out = nullptr;
+  const size_t bbytes = (size_t)nb * t->dim * sizeof(double);
+  hipError_t he = hipMalloc((void**)&d_mn, bbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_mx, bbytes);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_c, (nb + 1) * 8);
+  if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nb + 1) * 8);
+  if (he == hipSuccess) he = hipMemset(d_c, 0, (nb + 1) * 8);
+  if (he == hipSuccess) he = hipMemcpy(d_mn, mins, bbytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) he = hipMemcpy(d_mx, maxs, bbytes, hipMemcpyHostToDevice);
+  if (he == hipSuccess) {
+    Stack64Lease lease(t, nullptr);
+    rc = lease.acquire(nb);
+    if (rc == PTK_OK) rc = launch_box64<false>(t, d_mn, d_mx, nb, d_c, nullptr, nullptr, nullptr, lease);
+    if (rc == PTK_OK) rc = scan_counts64(d_c, d_o, nb, offsets);
+    if (rc == PTK_OK) {
+      const size_t obytes = std::max<uint64_t>(offsets[nb], 1) * sizeof(int32_t);
+      he = hipMalloc((void**)&d_out, obytes);
+      if (he == hipSuccess) rc = launch_box64<true>(t, d_mn, d_mx, nb, nullptr, d_o, d_out, nullptr, lease);
+      if (he == hipSuccess && rc == PTK_OK) {
+        *out = static_cast<int32_t*>(std::malloc(obytes));
+        if (*out == nullptr) {
+          rc = fail(PTK_ERR_NOMEM, "out of memory");
+        } else {
+          he = hipMemcpy(*out, d_out, obytes, hipMemcpyDeviceToHost);
+        }
+      }
+    }
+  }
+  if (d_mn) (void)hipFree(d_mn);
+  if (d_mx) (void)hipFree(d_mx);
+  if (d_c) (void)hipFree(d_c);
+  if (d_o) (void)hipFree(d_o);
+  if (d_out) (void)hipFree(d_out);
+  if (rc == PTK_OK && he != hipSuccess) rc = fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  if (rc != PTK_OK && *out) {
+    std::free(*out);
+    *out = nullptr;
+  }
+  return rc;
+}
+
+}  // extern "C"

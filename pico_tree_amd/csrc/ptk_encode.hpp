@@ -284,4 +284,80 @@ inline std::string encode_tree_nd(
   return std::string();
 }
 
+// ---- double points, any dimension: see ptk_kernels_f64.hpp -------------------------------------
+struct EncNode64 {  // == ptk::Node64
+  double left_max, right_min;
+  uint32_t left_ref, right_ref, axis, pad_;
+};
+static_assert(sizeof(EncNode64) == 32, "device record size");
+
+struct EncodedTree64 {
+  std::vector<EncNode64> nodes;   // per branch
+  std::vector<EncRange> ranges;   // per branch: position range [begin, end) of its whole subtree
+  std::vector<double> points;     // leaf order, row-major (n_points x dim)
+  uint32_t root_ref = 0;
+  uint32_t cbits = 0;
+};
+
+// `fn`: the host builder's DFS pre-order nodes (pico_tree::internal::flat_node<int, double>: members
+// is_leaf(), begin / end, left_max / right_min, right, split_dim).  encode = false only validates
+// the stream and gathers the statistics.
+template <class NodeT>
+inline std::string encode_tree64(
+    uint32_t dim, uint64_t n_points, const double* points, const NodeT* fn, uint64_t n_nodes, const int32_t* indices,
+    TreeStats& st, EncodedTree64& out, bool& unsupported, bool encode = true) {
+  unsupported = false;
+  // analyse_stream works on ptk_node records: hand it the structure (child links, leaf ranges,
+  // split axes); the planes are not part of the check.
+  std::vector<ptk_node> shape(n_nodes);
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    if (fn[i].is_leaf()) {
+      shape[i] = ptk_node{(uint32_t)fn[i].begin, (uint32_t)fn[i].end, PTK_LEAF, 0};
+    } else {
+      shape[i] = ptk_node{0, 0, fn[i].right, fn[i].split_dim};
+    }
+  }
+  std::vector<uint32_t> branch_id;
+  std::string err = analyse_stream(dim, n_points, shape.data(), n_nodes, st, &branch_id);
+  if (!err.empty() || !encode) return err;
+  const uint64_t n_branch = n_nodes - st.n_leaves;
+  const uint32_t cbits = bits_for(st.max_leaf_count);
+  if (cbits + bits_for(n_points) > 31) {
+    unsupported = true;
+    return "leaf reference does not fit 31 bits: n_points x max leaf size too large";
+  }
+  if (n_branch >= (1ull << 30)) {
+    unsupported = true;
+    return "more than 2^30 branch nodes";
+  }
+  auto ref_of = [&](uint64_t i) -> uint32_t {
+    if (fn[i].is_leaf()) return kEncLeafBit | ((uint32_t)fn[i].begin << cbits) | (uint32_t)(fn[i].end - fn[i].begin);
+    return branch_id[i];
+  };
+  out.nodes.assign(n_branch > 0 ? n_branch : 1, EncNode64{0, 0, 0, 0, 0, 0});
+  out.ranges.assign(out.nodes.size(), EncRange{0, 0});
+  {
+    std::vector<EncRange> of_node(n_nodes);  // children come later in the stream: one backward pass
+    for (uint64_t i = n_nodes; i-- > 0;) {
+      of_node[i] = fn[i].is_leaf() ? EncRange{(uint32_t)fn[i].begin, (uint32_t)fn[i].end}
+                                   : EncRange{of_node[i + 1].begin, of_node[fn[i].right].end};
+    }
+    for (uint64_t i = 0; i < n_nodes; ++i) {
+      if (fn[i].is_leaf()) continue;
+      out.nodes[branch_id[i]] =
+          EncNode64{fn[i].left_max, fn[i].right_min, ref_of(i + 1), ref_of(fn[i].right), fn[i].split_dim, 0};
+      out.ranges[branch_id[i]] = of_node[i];
+    }
+  }
+  out.points.resize((size_t)n_points * dim);
+  for (uint64_t pos = 0; pos < n_points; ++pos) {
+    const int32_t idx = indices[pos];
+    if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
+    std::memcpy(&out.points[pos * dim], points + (uint64_t)idx * dim, dim * sizeof(double));
+  }
+  out.root_ref = ref_of(0);
+  out.cbits = cbits;
+  return std::string();
+}
+
 }  // namespace ptk

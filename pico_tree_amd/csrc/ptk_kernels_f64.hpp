@@ -1,0 +1,445 @@
+// ptk_kernels_f64.hpp -- gfx950 device code for kd_trees over DOUBLE points, any dimension.
+//
+// The reference's kd_tree is generic over the scalar type (point_traits<>::scalar_type) and its
+// Python module builds KdTree objects over float64 arrays as readily as over float32 ones
+// (/root/reference/src/pyco_tree/pico_tree/_pyco_tree/kd_tree.hpp:383-445, def_core.hpp:17-18).
+// This file is that instantiation for the device: the same per-lane replay of the reference's
+// visit order as ptk_kernels_nd.hpp -- one query per lane, near child first, far child iff
+// `visitor.max() >= node_box_distance` (internal/kd_tree_search.hpp:52-105) -- with every scalar a
+// double and one IEEE operation per reference operation (__dadd_rn / __dsub_rn / __dmul_rn: no
+// contraction), so indices and distance bits equal the reference compiled with -ffp-contract=off.
+//
+// Where the per-lane state lives:
+//   q[dim], off[dim]  LDS, [axis][lane] (search.hpp:47,111); 16 bytes per axis per lane
+//   record stack      HBM scratch, [block][slot][lane], 16-byte records {meta, double}: a wave's
+//                     push / pop is one coalesced 1 KiB access; 2 * depth + 2 slots always suffice
+//   k-list            the caller's output row itself (neighbor<int, double>, 16 bytes)
+// Layouts (ptk_backend_f64.hpp, encode64):
+//   nodes : 32 B per branch {left_max, right_min, left_ref, right_ref, axis, 0}
+//   ref   : bit 31 = leaf; leaf = (begin << cbits) | count; branch = branch index
+//   pts   : leaf order, row-major (dim doubles per point); index[]: original index per position
+//   record: x = bit 31 undo | bit 30 (pending: far child is the right one; undo: nbd) |
+//               bits 29:0 (pending: branch index; undo_off: axis),  val = double
+
+#pragma once
+
+#include "ptk_kernels.hpp"
+
+namespace ptk {
+
+struct Neighbor64 {  // pico_tree::neighbor<int, double> (core.hpp:24-46): 16 bytes, distance at 8
+  int32_t index;
+  int32_t pad_;
+  double distance;
+};
+struct Node64 {
+  double left_max, right_min;
+  uint32_t left_ref, right_ref, axis, pad_;
+};
+struct Rec64 {
+  uint32_t x, pad_;
+  double val;
+};
+static_assert(sizeof(Neighbor64) == 16 && sizeof(Node64) == 32 && sizeof(Rec64) == 16, "f64 records");
+
+struct DevTree64 {
+  const Node64* nodes;
+  const double* pts;
+  const int32_t* index;
+  const uint2* ranges;  // per branch: position range of its whole subtree (box search)
+  uint32_t root_ref;
+  uint32_t cbits;
+  uint32_t cmask;
+  uint32_t dim;
+};
+
+constexpr double kDblMax = 1.7976931348623157e308;
+typedef PTK_LDS double LdsDouble;
+
+__device__ __forceinline__ double d_add(double a, double b) { return __dadd_rn(a, b); }
+__device__ __forceinline__ double d_sub(double a, double b) { return __dsub_rn(a, b); }
+__device__ __forceinline__ double d_mul(double a, double b) { return __dmul_rn(a, b); }
+
+// metric.hpp:72-150, as MetricL2 / MetricL1 / MetricLInf of ptk_kernels.hpp.
+struct Metric64L2 {
+  __device__ __forceinline__ static double one(double x) { return d_mul(x, x); }
+  __device__ __forceinline__ static double acc(double d, double diff) { return d_add(d, d_mul(diff, diff)); }
+};
+struct Metric64L1 {
+  __device__ __forceinline__ static double one(double x) { return fabs(x); }
+  __device__ __forceinline__ static double acc(double d, double diff) { return d_add(d, fabs(diff)); }
+};
+struct Metric64LInf {
+  __device__ __forceinline__ static double one(double x) { return fabs(x); }
+  __device__ __forceinline__ static double acc(double d, double diff) {
+    const double a = fabs(diff);
+    return d < a ? a : d;  // std::max(d, a)
+  }
+};
+
+struct Stack64 {
+  Rec64* base;  // this lane's column: slot i at base[i * 64]
+  int top;
+  __device__ __forceinline__ void init(Rec64* scratch, uint32_t slots) {
+    base = scratch + (uint64_t)blockIdx.x * slots * 64 + threadIdx.x;
+    top = 0;
+  }
+  __device__ __forceinline__ bool empty() const { return top == 0; }
+  __device__ __forceinline__ void push(uint32_t meta, double val) {
+    Rec64 r;
+    r.x = meta;
+    r.pad_ = 0;
+    r.val = val;
+    base[(uint64_t)top * 64] = r;
+    ++top;
+  }
+  __device__ __forceinline__ Rec64 pop() {
+    --top;
+    return base[(uint64_t)top * 64];
+  }
+};
+
+// ---- result policies (search_visitor.hpp), candidates scaled by 1/e as in ptk_kernels.hpp ----
+struct Knn64Policy {  // :83-123 / :198-247
+  Neighbor64* list;   // the output row
+  uint32_t k;
+  uint32_t filled;
+  double worst;
+  double e_inv;
+  __device__ __forceinline__ double max() const { return worst; }
+  __device__ __forceinline__ void visit(int32_t idx, double d) {
+    d = d_mul(d, e_inv);
+    if (worst > d) {
+      if (filled < k) ++filled;
+      uint32_t j = filled - 1;
+      while (j > 0) {  // insert_sorted (:24-38): shift while strictly smaller => stable on ties
+        const Neighbor64 prev = list[j - 1];
+        if (!(d < prev.distance)) break;
+        list[j] = prev;
+        --j;
+      }
+      Neighbor64 nb;
+      nb.index = idx;
+      nb.pad_ = 0;
+      nb.distance = d;
+      list[j] = nb;
+      if (filled == k) worst = list[k - 1].distance;
+    }
+  }
+  __device__ __forceinline__ void end_query() {
+    if (filled < k) {  // fewer reachable points than k: the reference's sentinel (:102)
+      Neighbor64 nb;
+      nb.index = 0;
+      nb.pad_ = 0;
+      nb.distance = kDblMax;
+      list[k - 1] = nb;
+    }
+  }
+};
+
+struct Nn64Policy {  // :42-65 / :165-193 -- k == 1 keeps the best in registers
+  double best_d;
+  int32_t best_i;
+  double e_inv;
+  __device__ __forceinline__ double max() const { return best_d; }
+  __device__ __forceinline__ void visit(int32_t idx, double d) {
+    d = d_mul(d, e_inv);
+    if (best_d > d) {
+      best_d = d;
+      best_i = idx;
+    }
+  }
+};
+
+template <bool FILL>
+struct Radius64Policy {  // :127-156 / :252-288
+  double radius;  // already scaled by 1/e for the approximate search (:265)
+  double e_inv;
+  uint64_t count;
+  Neighbor64* out;
+  __device__ __forceinline__ double max() const { return radius; }
+  __device__ __forceinline__ void visit(int32_t idx, double d) {
+    d = d_mul(d, e_inv);
+    if (radius > d) {  // strict
+      if (FILL) {
+        Neighbor64 nb;
+        nb.index = idx;
+        nb.pad_ = 0;
+        nb.distance = d;
+        out[count] = nb;
+      }
+      ++count;
+    }
+  }
+};
+
+template <class M, class Policy>
+__device__ __forceinline__ void traverse64(const DevTree64& t, LdsDouble* q, LdsDouble* off, Policy& pol, Stack64& st) {
+  const Node64* __restrict__ nodes = t.nodes;
+  const double* __restrict__ pts = t.pts;
+  const int32_t* __restrict__ index = t.index;
+  const uint32_t dim = t.dim;
+  uint32_t ref = t.root_ref;
+  double nbd = 0.0;
+
+  for (;;) {
+    while (!(ref & kLeafBit)) {
+      const Node64 nd = nodes[ref];
+      const double v = q[nd.axis * 64];
+      const bool go_left = d_sub(d_sub(d_add(nd.left_max, nd.right_min), v), v) > 0.0;  // search.hpp:76
+      const double dv = d_sub(go_left ? nd.right_min : nd.left_max, v);
+      const double new_off = M::one(dv);                                                  // :80,84
+      const double far_nbd = d_add(d_sub(nbd, off[nd.axis * 64]), new_off);               // :94
+      if (pol.max() >= far_nbd) st.push(ref | (go_left ? kRecSide : 0u), far_nbd);
+      ref = go_left ? nd.left_ref : nd.right_ref;
+    }
+    {
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      const uint32_t begin = lv >> t.cbits;
+      const uint32_t count = lv & t.cmask;
+      for (uint32_t j = 0; j < count; ++j) {
+        const double* p = pts + (uint64_t)(begin + j) * dim;
+        double d = 0.0;
+        for (uint32_t a = 0; a < dim; ++a) d = M::acc(d, d_sub(q[a * 64], p[a]));  // internal::sum, metric.hpp:36-51
+        pol.visit(index[begin + j], d);
+      }
+    }
+    for (;;) {
+      if (st.empty()) return;
+      const Rec64 r = st.pop();
+      if (r.x & kRecUndo) {
+        if (r.x & kRecSide) {
+          nbd = r.val;
+        } else {
+          off[(r.x & 0x3FFFFFFFu) * 64] = r.val;
+        }
+        continue;
+      }
+      if (pol.max() >= r.val) {  // the authoritative test of search.hpp:99
+        const uint32_t idx = r.x & 0x3FFFFFFFu;
+        const bool far_is_right = (r.x & kRecSide) != 0;
+        const Node64 nd = nodes[idx];
+        const double dv = d_sub(far_is_right ? nd.right_min : nd.left_max, q[nd.axis * 64]);
+        const double new_off = M::one(dv);
+        st.push(kRecUndo | nd.axis, off[nd.axis * 64]);
+        st.push(kRecUndo | kRecSide, nbd);
+        off[nd.axis * 64] = new_off;
+        nbd = r.val;
+        ref = far_is_right ? nd.right_ref : nd.left_ref;
+        break;
+      }
+    }
+  }
+}
+
+__device__ __forceinline__ void stage_query64(
+    const double* __restrict__ queries, uint32_t dim, uint64_t qi, LdsDouble*& q, LdsDouble*& off) {
+  LdsDouble* base = (LdsDouble*)ptk_smem;
+  q = base + threadIdx.x;
+  off = base + (size_t)dim * 64 + threadIdx.x;
+  const double* row = queries + qi * dim;
+  for (uint32_t a = 0; a < dim; ++a) {
+    q[a * 64] = row[a];
+    off[a * 64] = 0.0;  // search.hpp:47
+  }
+}
+
+// Queries [q0, q0 + nq) of the batch; block b of the launch owns stack columns [b * slots * 64, ...).
+template <class M>
+__global__ __launch_bounds__(64) void knn64_kernel(
+    DevTree64 t, const double* __restrict__ queries, uint64_t q0, uint64_t nq, uint32_t k, double e_inv,
+    Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = q0 + i;
+  LdsDouble *q, *off;
+  stage_query64(queries, t.dim, qi, q, off);
+  Stack64 st;
+  st.init(stack, slots);
+  if (k == 1) {
+    Nn64Policy pol;
+    pol.best_d = kDblMax;  // search_visitor.hpp:50
+    pol.best_i = 0;
+    pol.e_inv = e_inv;
+    traverse64<M>(t, q, off, pol, st);
+    Neighbor64 nb;
+    nb.index = pol.best_i;
+    nb.pad_ = 0;
+    nb.distance = pol.best_d;
+    out[qi] = nb;
+    return;
+  }
+  Knn64Policy pol;
+  pol.list = out + qi * k;
+  pol.k = k;
+  pol.filled = 0;
+  pol.worst = kDblMax;
+  pol.e_inv = e_inv;
+  traverse64<M>(t, q, off, pol, st);
+  pol.end_query();
+}
+
+template <class M, bool FILL>
+__global__ __launch_bounds__(64) void radius64_kernel(
+    DevTree64 t, const double* __restrict__ queries, uint64_t q0, uint64_t nq, double radius, double e_inv,
+    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor64* __restrict__ out,
+    Rec64* __restrict__ stack, uint32_t slots) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = q0 + i;
+  LdsDouble *q, *off;
+  stage_query64(queries, t.dim, qi, q, off);
+  Stack64 st;
+  st.init(stack, slots);
+  Radius64Policy<FILL> pol;
+  pol.radius = d_mul(radius, e_inv);  // search_visitor.hpp:265
+  pol.e_inv = e_inv;
+  pol.count = 0;
+  pol.out = FILL ? out + offsets[qi] : nullptr;
+  traverse64<M>(t, q, off, pol, st);
+  if (!FILL) counts[qi] = pol.count;
+}
+
+// Rows ascending by distance (kd_tree.hpp:263-265: std::sort, ties in unspecified order; here
+// ties go by index so the result is deterministic).  One lane per row, heap sort in place.
+__global__ __launch_bounds__(kBlock) void sort_rows64_kernel(
+    const uint64_t* __restrict__ offsets, uint64_t nq, Neighbor64* __restrict__ out) {
+  const uint64_t qi = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (qi >= nq) return;
+  Neighbor64* a = out + offsets[qi];
+  const uint64_t n = offsets[qi + 1] - offsets[qi];
+  if (n < 2) return;
+  auto less = [](const Neighbor64& x, const Neighbor64& y) {
+    return x.distance < y.distance || (x.distance == y.distance && x.index < y.index);
+  };
+  auto sift = [&](uint64_t root, uint64_t end) {
+    Neighbor64 v = a[root];
+    for (;;) {
+      uint64_t c = 2 * root + 1;
+      if (c >= end) break;
+      if (c + 1 < end && less(a[c], a[c + 1])) ++c;
+      if (!less(v, a[c])) break;
+      a[root] = a[c];
+      root = c;
+    }
+    a[root] = v;
+  };
+  for (uint64_t s = n / 2; s-- > 0;) sift(s, n);
+  for (uint64_t end = n - 1; end > 0; --end) {
+    const Neighbor64 top = a[0];
+    a[0] = a[end];
+    a[end] = top;
+    sift(0, end);
+  }
+}
+
+// ---- box search (kd_tree_search.hpp:238-381), as box_nd_kernel of ptk_kernels_nd.hpp ----------
+// Records: pending-right {branch, val = box max of the axis to restore}, undo {kRecUndo | axis,
+// val = box min to restore}.  LDS: query min / max and the running node box min / max.
+template <bool FILL>
+__global__ __launch_bounds__(64) void box64_kernel(
+    DevTree64 t, const double* __restrict__ root, const double* __restrict__ mins,
+    const double* __restrict__ maxs, uint64_t b0, uint64_t nb, uint64_t* __restrict__ counts,
+    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nb) return;
+  const uint64_t bi = b0 + i;
+  const uint32_t dim = t.dim;
+  LdsDouble* qn = (LdsDouble*)ptk_smem + threadIdx.x;
+  LdsDouble* qx = qn + (size_t)dim * 64;
+  LdsDouble* mn = qx + (size_t)dim * 64;
+  LdsDouble* mx = mn + (size_t)dim * 64;
+  for (uint32_t a = 0; a < dim; ++a) {
+    qn[a * 64] = mins[bi * dim + a];
+    qx[a * 64] = maxs[bi * dim + a];
+    mn[a * 64] = root[a];
+    mx[a * 64] = root[dim + a];
+  }
+  const Node64* __restrict__ nodes = t.nodes;
+  uint64_t count = 0;
+  int32_t* row = FILL ? out + offsets[bi] : nullptr;
+  Stack64 st;
+  st.init(stack, slots);
+
+  auto inside = [&]() {  // query_.contains(box_): both corners inside the closed query box
+    bool in = true;
+    for (uint32_t a = 0; a < dim; ++a) {
+      const double lo = qn[a * 64], hi = qx[a * 64], bl = mn[a * 64], bh = mx[a * 64];
+      in = in && lo <= bl && bl <= hi && lo <= bh && bh <= hi;
+    }
+    return in;
+  };
+  auto report_range = [&](uint32_t begin, uint32_t end) {
+    if (FILL) {
+      for (uint32_t p = begin; p < end; ++p) row[count + (p - begin)] = t.index[p];
+    }
+    count += end - begin;
+  };
+  auto report = [&](uint32_t ref) {
+    if (ref & kLeafBit) {
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      report_range(lv >> t.cbits, (lv >> t.cbits) + (lv & t.cmask));
+    } else {
+      const uint2 r = t.ranges[ref];
+      report_range(r.x, r.y);
+    }
+  };
+  auto scan_leaf = [&](uint32_t ref) {
+    const uint32_t lv = ref & 0x7FFFFFFFu;
+    const uint32_t begin = lv >> t.cbits;
+    const uint32_t n = lv & t.cmask;
+    for (uint32_t j = 0; j < n; ++j) {
+      const double* p = t.pts + (uint64_t)(begin + j) * dim;
+      bool in = true;
+      for (uint32_t a = 0; a < dim; ++a) in = in && qn[a * 64] <= p[a] && p[a] <= qx[a * 64];
+      if (in) {
+        if (FILL) row[count] = t.index[begin + j];
+        ++count;
+      }
+    }
+  };
+
+  uint32_t ref = t.root_ref;
+  bool have = true;
+  for (;;) {
+    if (have) {
+      if (ref & kLeafBit) {
+        scan_leaf(ref);
+        have = false;
+      } else {
+        const Node64 nd = nodes[ref];
+        st.push(ref, mx[nd.axis * 64]);  // the right child comes later
+        mx[nd.axis * 64] = nd.left_max;
+        if (inside()) {
+          report(nd.left_ref);
+          have = false;
+        } else if (qn[nd.axis * 64] <= nd.left_max) {  // intersects_left
+          ref = nd.left_ref;
+        } else {
+          have = false;
+        }
+      }
+      continue;
+    }
+    if (st.empty()) break;
+    const Rec64 r = st.pop();
+    if (r.x & kRecUndo) {
+      mn[(r.x & 0x3FFFFFFFu) * 64] = r.val;
+      continue;
+    }
+    // Left side of branch r.x is done: restore max, narrow min, do the right side.
+    const Node64 nd = nodes[r.x & 0x3FFFFFFFu];
+    mx[nd.axis * 64] = r.val;
+    st.push(kRecUndo | nd.axis, mn[nd.axis * 64]);
+    mn[nd.axis * 64] = nd.right_min;
+    if (inside()) {
+      report(nd.right_ref);
+    } else if (qx[nd.axis * 64] >= nd.right_min) {  // intersects_right
+      ref = nd.right_ref;
+      have = true;
+    }
+  }
+  if (!FILL) counts[bi] = count;
+}
+
+}  // namespace ptk

@@ -19,6 +19,7 @@ thread_local dim3 blockDim;
 
 #include <algorithm>
 #include <functional>
+#include <sstream>
 #include <string>
 #include <vector>
 
@@ -26,6 +27,10 @@ thread_local dim3 blockDim;
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_nd.hpp"
+#include "ptk_kernels_f64.hpp"
+#include "pico_tree/internal/flat_tree.hpp"
+#include "pico_tree/internal/stream.hpp"
+#include "pico_tree/map.hpp"
 #include "ptk_forest.hpp"
 
 namespace ptk {
@@ -594,6 +599,147 @@ void emu_morton(const float* q, uint32_t dim, uint64_t nq, const float* lo, cons
   float3 l = make_float3(lo[0], lo[1], lo[2]);
   float3 i = make_float3(inv[0], inv[1], inv[2]);
   for_each_lane(nq, [&] { ptk::morton_kernel(q, dim, nq, l, i, 0u, keys, ids); });
+}
+
+}  // extern "C"
+
+// ---- double precision (ptk_kernels_f64.hpp) ----------------------------------------------------
+// The tree is built here with the product's host builder instantiated over double (what
+// ptk_tree64_create_from_points does) and encoded with ptk::encode_tree64.
+namespace {
+struct Emu64 {
+  using flat_t = pico_tree::internal::flat_tree<int, double, pico_tree::dynamic_extent>;
+  flat_t flat{1};
+  ptk::EncodedTree64 enc;
+  ptk::TreeStats st;
+  ptk::DevTree64 dev;
+  std::vector<double> root;
+  std::vector<ptk::Rec64> stack;  // one block's worth: blocks run one after the other
+  uint32_t slots = 0;
+  int metric = 0;
+};
+
+template <class F>
+void for_each_lane64(Emu64* t, uint64_t n, F&& f) {
+  // Every block reuses stack columns [0, slots * 64): blockIdx.x stays 0 while the lanes run.
+  gridDim.x = 1;
+  blockDim.x = 64;
+  blockIdx.x = 0;
+  for (uint64_t q0 = 0; q0 < n; q0 += 64) {
+    const uint64_t m = std::min<uint64_t>(64, n - q0);
+    for (uint32_t l = 0; l < 64; ++l) {
+      threadIdx.x = l;
+      f(q0, m);
+    }
+  }
+}
+}  // namespace
+
+extern "C" {
+
+void* emu64_create(const double* points, uint64_t n, uint32_t dim, uint64_t max_leaf) {
+  using namespace pico_tree;
+  auto* e = new Emu64;
+  using space_t = space_map<point_map<double const, dynamic_extent>>;
+  space_t space(points, n, dim);
+  internal::space_view<space_t> view(space);
+  e->flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf), bounds_from_space, sliding_midpoint_max_side,
+                                           false, 1u);
+  bool unsupported = false;
+  g_err = ptk::encode_tree64(dim, n, points, e->flat.nodes.data(), e->flat.nodes.size(), e->flat.indices.data(), e->st,
+                             e->enc, unsupported);
+  if (!g_err.empty()) {
+    delete e;
+    return nullptr;
+  }
+  e->dev.nodes = reinterpret_cast<const ptk::Node64*>(e->enc.nodes.data());
+  e->dev.pts = e->enc.points.data();
+  e->dev.index = e->flat.indices.data();
+  e->dev.ranges = reinterpret_cast<const uint2*>(e->enc.ranges.data());
+  e->dev.root_ref = e->enc.root_ref;
+  e->dev.cbits = e->enc.cbits;
+  e->dev.cmask = (1u << e->enc.cbits) - 1u;
+  e->dev.dim = dim;
+  e->root.assign(e->flat.root_box.min(), e->flat.root_box.min() + dim);
+  e->root.insert(e->root.end(), e->flat.root_box.max(), e->flat.root_box.max() + dim);
+  e->slots = 2 * e->st.max_depth + 4;
+  e->stack.resize((size_t)e->slots * 64);
+  return e;
+}
+void emu64_destroy(void* h) { delete static_cast<Emu64*>(h); }
+void emu64_set_metric(void* h, int metric) { static_cast<Emu64*>(h)->metric = metric; }
+
+// The kd_tree::save stream of the tree (pico_tree/internal/stream.hpp); returns its size.
+uint64_t emu64_save(void* h, void* buf, uint64_t cap) {
+  std::ostringstream os(std::ios::out | std::ios::binary);
+  pico_tree::internal::write_flat_tree(static_cast<Emu64*>(h)->flat, os);
+  const std::string bytes = os.str();
+  if (buf != nullptr && cap >= bytes.size()) std::memcpy(buf, bytes.data(), bytes.size());
+  return bytes.size();
+}
+
+#define EMU64_WITH_METRIC(CALL)                \
+  do {                                         \
+    if (t->metric == 1) {                      \
+      using M = ptk::Metric64L1;               \
+      CALL;                                    \
+    } else if (t->metric == 2) {               \
+      using M = ptk::Metric64LInf;             \
+      CALL;                                    \
+    } else {                                   \
+      using M = ptk::Metric64L2;               \
+      CALL;                                    \
+    }                                          \
+  } while (0)
+
+int emu64_knn(void* h, const double* q, uint64_t nq, uint32_t k, double e, ptk::Neighbor64* out) {
+  auto* t = static_cast<Emu64*>(h);
+  if ((size_t)2 * t->dev.dim * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
+  EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+    ptk::knn64_kernel<M>(t->dev, q, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);
+  }));
+  return 0;
+}
+
+// out == nullptr: count pass (offsets filled); otherwise the fill pass (+ optional row sort).
+int emu64_radius(void* h, const double* q, uint64_t nq, double radius, double e, int sort, uint64_t* offsets,
+                 ptk::Neighbor64* out) {
+  auto* t = static_cast<Emu64*>(h);
+  if ((size_t)2 * t->dev.dim * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
+  if (out == nullptr) {
+    std::vector<uint64_t> counts(nq + 1, 0);
+    EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+      ptk::radius64_kernel<M, false>(t->dev, q, q0, m, radius, 1.0 / e, counts.data(), nullptr, nullptr, t->stack.data(),
+                                     t->slots);
+    }));
+    offsets[0] = 0;
+    for (uint64_t i = 0; i < nq; ++i) offsets[i + 1] = offsets[i] + counts[i];
+    return 0;
+  }
+  EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+    ptk::radius64_kernel<M, true>(t->dev, q, q0, m, radius, 1.0 / e, nullptr, offsets, out, t->stack.data(), t->slots);
+  }));
+  if (sort) for_each_lane(nq, [&] { ptk::sort_rows64_kernel(offsets, nq, out); });
+  return 0;
+}
+
+int emu64_box(void* h, const double* mins, const double* maxs, uint64_t nb, uint64_t* offsets, int32_t* out) {
+  auto* t = static_cast<Emu64*>(h);
+  if ((size_t)4 * t->dev.dim * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
+  if (out == nullptr) {
+    std::vector<uint64_t> counts(nb + 1, 0);
+    for_each_lane64(t, nb, [&](uint64_t b0, uint64_t m) {
+      ptk::box64_kernel<false>(t->dev, t->root.data(), mins, maxs, b0, m, counts.data(), nullptr, nullptr,
+                               t->stack.data(), t->slots);
+    });
+    offsets[0] = 0;
+    for (uint64_t i = 0; i < nb; ++i) offsets[i + 1] = offsets[i] + counts[i];
+    return 0;
+  }
+  for_each_lane64(t, nb, [&](uint64_t b0, uint64_t m) {
+    ptk::box64_kernel<true>(t->dev, t->root.data(), mins, maxs, b0, m, nullptr, offsets, out, t->stack.data(), t->slots);
+  });
+  return 0;
 }
 
 }  // extern "C"

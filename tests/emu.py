@@ -157,3 +157,65 @@ def emulated_forest_knn(pts, max_leaf, n_trees, seed, q, k, max_leaves):
                             rot.ctypes.data, out.ctypes.data, dropped.ctypes.data)
     assert rc == 0, lib.emu_last_error()
     return out, rot, int(dropped[0])
+
+
+class EmulatedTree64:
+    """The double-precision kernels (pico_tree_amd/csrc/ptk_kernels_f64.hpp) run lane by lane on
+    the CPU over a tree built by the product's host builder instantiated over double."""
+
+    def __init__(self, pts, leaf, metric="L2Squared"):
+        import oracle
+
+        self.neighbor = oracle.NEIGHBOR64
+        self.lib = ctypes.CDLL(_LIB)
+        self.lib.emu64_create.restype = c_void_p
+        self.lib.emu64_create.argtypes = [c_void_p, c_uint64, c_uint32, c_uint64]
+        self.lib.emu64_destroy.argtypes = [c_void_p]
+        self.lib.emu64_set_metric.argtypes = [c_void_p, c_int]
+        self.lib.emu64_save.restype = c_uint64
+        self.lib.emu64_save.argtypes = [c_void_p, c_void_p, c_uint64]
+        self.lib.emu64_knn.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, ctypes.c_double, c_void_p]
+        self.lib.emu64_radius.argtypes = [c_void_p, c_void_p, c_uint64, ctypes.c_double, ctypes.c_double, c_int,
+                                          c_void_p, c_void_p]
+        self.lib.emu64_box.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]
+        self.pts = np.ascontiguousarray(pts, dtype=np.float64)
+        self.h = self.lib.emu64_create(self.pts.ctypes.data, len(self.pts), self.pts.shape[1], int(leaf))
+        if not self.h:
+            raise RuntimeError(self.lib.emu_last_error().decode())
+        self.lib.emu64_set_metric(self.h, {"L2Squared": 0, "L1": 1, "LPInf": 2}[metric])
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.lib.emu64_destroy(self.h)
+            self.h = None
+
+    def save_bytes(self) -> bytes:
+        size = self.lib.emu64_save(self.h, None, 0)
+        buf = np.empty(size, dtype=np.uint8)
+        self.lib.emu64_save(self.h, buf.ctypes.data, size)
+        return buf.tobytes()
+
+    def search_knn(self, q, k, e=None):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        out = np.zeros((len(q), k), dtype=self.neighbor)
+        assert self.lib.emu64_knn(self.h, q.ctypes.data, len(q), k, e or 1.0, out.ctypes.data) == 0
+        return out
+
+    def search_radius(self, q, radius, e=None, sort=False):
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        off = np.zeros(len(q) + 1, dtype=np.uint64)
+        assert self.lib.emu64_radius(self.h, q.ctypes.data, len(q), radius, e or 1.0, 0, off.ctypes.data, None) == 0
+        flat = np.zeros(int(off[-1]), dtype=self.neighbor)
+        assert self.lib.emu64_radius(self.h, q.ctypes.data, len(q), radius, e or 1.0, int(sort), off.ctypes.data,
+                                     flat.ctypes.data) == 0
+        return off, flat
+
+    def search_box(self, mins, maxs):
+        mins = np.ascontiguousarray(mins, dtype=np.float64)
+        maxs = np.ascontiguousarray(maxs, dtype=np.float64)
+        off = np.zeros(len(mins) + 1, dtype=np.uint64)
+        assert self.lib.emu64_box(self.h, mins.ctypes.data, maxs.ctypes.data, len(mins), off.ctypes.data, None) == 0
+        flat = np.zeros(int(off[-1]), dtype=np.int32)
+        assert self.lib.emu64_box(self.h, mins.ctypes.data, maxs.ctypes.data, len(mins), off.ctypes.data,
+                                  flat.ctypes.data) == 0
+        return off, flat

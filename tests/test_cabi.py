@@ -69,7 +69,7 @@ def test_argument_validation():
     assert lib.ptk_tree_create_from_points(pts.ctypes.data, 100, 3, 0, pt.PTK_DEVICE_NONE, ctypes.byref(h)) == -1
     assert b"positive" in lib.ptk_last_error()
     with pytest.raises(ValueError):
-        pt.KdTree(pts.astype(np.float64))
+        pt.KdTree(pts.astype(np.float16))
     with pytest.raises(ValueError):
         pt.KdTree(pts[::2])
     with pytest.raises(TypeError):

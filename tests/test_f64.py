@@ -1,0 +1,253 @@
+"""kd_trees over float64 points (ptk_tree64_* / ptk_search64_*, pico_tree_amd.KdTree on float64 arrays).
+
+The reference's Python module dispatches on the array dtype
+(/root/reference/src/pyco_tree/pico_tree/_pyco_tree/kd_tree.hpp:383-445) and its own unit tests
+build float64 trees (test/pyco_tree/kd_tree_test.py:13-18, 209-212, 223-237).
+
+CPU tier: the oracle's double build against the committed goldens (outputs of the COMPILED
+REFERENCE over double, tests/golden/make_golden_f64.py) and against the compiled reference itself;
+the device kernels run lane by lane in the emulator; the host-only handle (build, save stream).
+GPU tier (``-m gpu``): the same checks through the C ABI on the device.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+import pytest
+
+import oracle
+import pico_tree_amd as pt
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SETS = ["g_f64_3d", "g_f64_6d"]
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def same(rows, index, distance):
+    return np.array_equal(rows["index"], index) and rows["distance"].tobytes() == distance.tobytes()
+
+
+def check_against_golden(impl, g, metrics=None):
+    """impl: search_knn(q, k, e=None) / search_radius(q, r, e=None, sort=False) -> (offsets, flat) /
+    search_box(mins, maxs) -> (offsets, flat); distance BITS are compared."""
+    q, k, e, radius = g["queries"], int(g["k"]), float(g["e"]), float(g["radius"])
+    assert same(impl.search_knn(q, 1).reshape(len(q), 1), g["knn1_index"], g["knn1_distance"])
+    assert same(impl.search_knn(q, k), g["knn_index"], g["knn_distance"])
+    assert same(impl.search_knn(q, k, e=e), g["aknn_index"], g["aknn_distance"])
+    off, flat = impl.search_radius(q, radius)
+    assert np.array_equal(off, g["radius_offsets"]) and same(flat, g["radius_index"], g["radius_distance"])
+    off, flat = impl.search_radius(q, radius, sort=True)
+    assert np.array_equal(off, g["radius_offsets"])
+    assert flat["distance"].tobytes() == g["radius_sorted_distance"].tobytes()
+    off, flat = impl.search_radius(q, radius, e=e)
+    assert np.array_equal(off, g["aradius_offsets"]) and same(flat, g["aradius_index"], g["aradius_distance"])
+    off, flat = impl.search_box(g["box_mins"], g["box_maxs"])
+    assert np.array_equal(off, g["box_offsets"]) and np.array_equal(flat, g["box_flat"])
+    for metric in ("L1", "LPInf"):
+        if metrics is not None:
+            assert same(metrics(metric).search_knn(q, k), g[f"knn_{metric}_index"], g[f"knn_{metric}_distance"])
+
+
+# ---- CPU tier ------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("name", SETS)
+def test_oracle_double_reproduces_the_goldens(name):
+    g = load(name)
+    leaf = int(g["max_leaf_size"])
+    port = oracle.Oracle(g["points"], leaf, "port", dtype=np.float64)
+    assert port.save_bytes() == g["save_stream"].tobytes()
+    check_against_golden(port, g, lambda m: oracle.Oracle(g["points"], leaf, "port", m, dtype=np.float64))
+
+
+@pytest.mark.skipif(not oracle.have_reference64(), reason="compiled reference (double) not present")
+@pytest.mark.parametrize("dim", [1, 2, 3, 4, 8])
+def test_oracle_double_equals_compiled_reference(dim):
+    rng = np.random.default_rng(100 + dim)
+    pts, q = rng.random((3000, dim)), rng.random((500, dim))
+    pts[7:19] = pts[7]
+    for metric in ("L2Squared", "L1", "LPInf"):
+        a = oracle.Oracle(pts, 6, "port", metric, dtype=np.float64)
+        b = oracle.Oracle(pts, 6, "reference", metric, dtype=np.float64)
+        assert a.save_bytes() == oracle.canonical_stream64(b.save_bytes())
+        for k, e in ((1, None), (11, None), (4, 1.7)):
+            x, y = a.search_knn(q, k, e=e), b.search_knn(q, k, e=e)
+            assert same(x, y["index"], y["distance"])
+        r = 0.2 * dim ** 0.5 if metric != "L2Squared" else 0.02 * dim
+        (o1, f1), (o2, f2) = a.search_radius(q, r), b.search_radius(q, r)
+        assert np.array_equal(o1, o2) and same(f1, f2["index"], f2["distance"]) and o1[-1] > 0
+    (o1, f1), (o2, f2) = a.search_box(q - 0.2, q + 0.2), b.search_box(q - 0.2, q + 0.2)
+    assert np.array_equal(o1, o2) and np.array_equal(f1, f2)
+
+
+@pytest.mark.parametrize("name", SETS)
+def test_emulated_double_kernels_reproduce_the_goldens(name):
+    """ptk_kernels_f64.hpp compiled for the host, run lane by lane (tests/cpp/emulate_kernels.cpp)."""
+    from tests import emu
+
+    g = load(name)
+    leaf = int(g["max_leaf_size"])
+    t = emu.EmulatedTree64(g["points"], leaf)
+    assert t.save_bytes() == g["save_stream"].tobytes()
+    check_against_golden(t, g, lambda m: emu.EmulatedTree64(g["points"], leaf, m))
+
+
+def test_host_only_double_handle_builds_the_reference_tree(tmp_path):
+    g = load("g_f64_3d")
+    t = pt.KdTree(g["points"], pt.Metric.L2Squared, int(g["max_leaf_size"]), device=pt.PTK_DEVICE_NONE)
+    assert t.dtype_scalar == np.float64 and t.dtype_neighbor == pt.NEIGHBOR64 and "dtype=float64" in repr(t)
+    assert t.dtype_neighbor.itemsize == 16 and t.dtype_neighbor.fields["distance"][1] == 8
+    assert t._serialize() == g["save_stream"].tobytes()
+    assert t.info()["n_points"] == len(g["points"]) and t.metric(-2.0) == 4.0
+    with pytest.raises(pt.PtkError) as err:  # no device replica: loud, no CPU search
+        t.search_knn(g["queries"], 1)
+    assert err.value.status == -3
+    with pytest.raises(ValueError):  # float32 queries on a float64 tree
+        t.search_knn(g["queries"].astype(np.float32), 1)
+    # file round trip (PKD container around the double stream)
+    fn = str(tmp_path / "t64.bin")
+    pt.save_kd_tree(t, fn)
+    t2 = pt.load_kd_tree(g["points"], fn, device=pt.PTK_DEVICE_NONE)
+    assert t2.dtype_scalar == np.float64 and t2._serialize() == t._serialize()
+    with pytest.raises(pt.PtkError):  # a float32 stream is not a float64 one
+        f32 = pt.KdTree(g["points"].astype(np.float32), pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+        pt.save_kd_tree(f32, fn)
+        pt.load_kd_tree(g["points"], fn, device=pt.PTK_DEVICE_NONE)
+
+
+def test_double_entry_points_validate_arguments():
+    lib = pt._load()
+    h = ctypes.c_void_p()
+    pts = np.random.default_rng(1).random((100, 3))
+    none = pt.PTK_DEVICE_NONE
+    assert lib.ptk_tree64_create_from_points(None, 100, 3, 10, none, ctypes.byref(h)) == -1
+    assert lib.ptk_tree64_create_from_points(pts.ctypes.data, 0, 3, 10, none, ctypes.byref(h)) == -1
+    assert lib.ptk_tree64_create_from_points(pts.ctypes.data, 100, 3, 0, none, ctypes.byref(h)) == -1
+    assert lib.ptk_tree64_create_from_points(pts.ctypes.data, 100, 3, 10, none, ctypes.byref(h)) == 0
+    assert lib.ptk_tree64_set_metric(h, 3) == -1 and lib.ptk_tree64_set_metric(h, 1) == 0
+    out = np.zeros(100, dtype=pt.NEIGHBOR64)
+    assert lib.ptk_search64_knn(h, pts.ctypes.data, 100, 1, 1.0, out.ctypes.data) == -3  # no device
+    assert lib.ptk_search64_knn(None, pts.ctypes.data, 100, 1, 1.0, out.ctypes.data) == -1
+    lib.ptk_tree64_destroy(h)
+    garbage = ctypes.create_string_buffer(b"\x03" + b"\0" * 40, 41)
+    assert lib.ptk_tree64_create_from_stream(pts.ctypes.data, 100, 3, garbage, 41, none, ctypes.byref(h)) == -1
+
+
+# ---- GPU tier ------------------------------------------------------------------------------------
+
+class _GpuTree:
+    """Adapts pico_tree_amd.KdTree to the (offsets, flat) interface of check_against_golden."""
+
+    def __init__(self, pts, leaf, metric="L2Squared", device=0):
+        self.t = pt.KdTree(pts, pt.Metric[metric], leaf, device=device)
+
+    def search_knn(self, q, k, e=None):
+        r = self.t.search_knn(q, k) if e is None else self.t.search_knn(q, k, e)
+        return r.reshape(len(q), k)
+
+    def search_radius(self, q, r, e=None, sort=False):
+        d = self.t.search_radius(q, r, sort=sort) if e is None else self.t.search_radius(q, r, e, sort=sort)
+        return d.offsets, d.flat
+
+    def search_box(self, mins, maxs):
+        boxes = np.empty((2 * len(mins), mins.shape[1]), dtype=np.float64)
+        boxes[0::2], boxes[1::2] = mins, maxs
+        d = self.t.search_box(boxes)
+        return d.offsets, d.flat
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", SETS)
+def test_gpu_double_reproduces_the_goldens(gpu, name):
+    g = load(name)
+    leaf = int(g["max_leaf_size"])
+    t = _GpuTree(g["points"], leaf, device=gpu)
+    assert t.t._serialize() == g["save_stream"].tobytes()
+    check_against_golden(t, g, lambda m: _GpuTree(g["points"], leaf, m, device=gpu))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim,n,nq,leaf", [(3, 200_000, 100_000, 10), (2, 50_000, 30_000, 1), (5, 60_000, 20_000, 12),
+                                           (16, 20_000, 4_000, 8), (1, 5_000, 3_000, 3)])
+def test_gpu_double_equals_oracle(gpu, dim, n, nq, leaf):
+    """Seeded clouds at sizes the oracle finishes in seconds; every metric; indices and distance bits."""
+    rng = np.random.default_rng(dim * 7 + 1)
+    pts, q = rng.random((n, dim)) * 50.0, rng.random((nq, dim)) * 50.0
+    pts[100:130] = pts[100]
+    for metric in ("L2Squared", "L1", "LPInf"):
+        ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
+        t = _GpuTree(pts, leaf, metric, device=gpu)
+        for k, e in ((1, None), (16, None), (40, None), (5, 1.5)):
+            want = ref.search_knn(q, k, e=e)
+            assert same(t.search_knn(q, k, e=e), want["index"], want["distance"]), (metric, k, e)
+        if metric == "L2Squared":
+            r = {1: 1e-5, 2: 0.05, 3: 1.0, 5: 60.0, 16: 1500.0}[dim]
+        else:
+            r = {1: 3e-3, 2: 0.2, 3: 1.0, 5: 8.0, 16: 30.0}[dim] * (2.0 if metric == "L1" else 1.0)
+        (o1, f1), (o2, f2) = t.search_radius(q, r), ref.search_radius(q, r)
+        assert np.array_equal(o1, o2) and same(f1, f2["index"], f2["distance"]) and o1[-1] > 0, (metric, "radius")
+        (o1, f1), (o2, f2) = t.search_radius(q[:2000], r, e=1.2, sort=True), ref.search_radius(q[:2000], r, e=1.2, sort=True)
+        assert np.array_equal(o1, o2) and f1["distance"].tobytes() == f2["distance"].tobytes()
+    h = 50.0 * 0.5 * (200.0 / n) ** (1.0 / dim)
+    (o1, f1), (o2, f2) = t.search_box(q[:5000] - h, q[:5000] + h), ref.search_box(q[:5000] - h, q[:5000] + h)
+    assert np.array_equal(o1, o2) and np.array_equal(f1, f2) and o1[-1] > 0
+
+
+@pytest.mark.gpu
+def test_gpu_double_device_tensors_and_python_api(gpu, tmp_path):
+    import torch
+
+    g = load("g_f64_3d")
+    t = pt.KdTree(g["points"], pt.Metric.L2Squared, int(g["max_leaf_size"]), device=gpu)
+    k = int(g["k"])
+    dq = torch.from_numpy(g["queries"]).to(f"cuda:{gpu}")
+    got = t.search_knn(dq, k)
+    torch.cuda.synchronize()
+    assert got.raw.dtype == torch.int64 and tuple(got.raw.shape) == (len(g["queries"]), k, 2)
+    assert same(got.numpy(), g["knn_index"], g["knn_distance"])
+    assert np.array_equal(got.index.cpu().numpy(), g["knn_index"])
+    assert got.distance.cpu().numpy().tobytes() == g["knn_distance"].tobytes()
+    # kd_tree_test.py:203-229 with a float64 tree: DArray of the tree's neighbor dtype, reused
+    d = pt.DArray(dtype=t.dtype_neighbor)
+    assert d.dtype == t.dtype_neighbor and not d
+    t.search_radius(g["queries"], float(g["radius"]), d)
+    assert len(d) == len(g["queries"]) and same(d.flat, g["radius_index"], g["radius_distance"])
+    with pytest.raises(ValueError):
+        t.search_radius(g["queries"], float(g["radius"]), pt.DArray(pt.NEIGHBOR))
+    # kd_tree_test.py:231-248 with float64 points
+    fn = str(tmp_path / "tree64.bin")
+    pt.save_kd_tree(t, fn)
+    t2 = pt.load_kd_tree(g["points"], fn, device=gpu)
+    assert repr(t) == repr(t2) and t.dtype_scalar == t2.dtype_scalar
+    assert same(t2.search_knn(g["queries"], k), g["knn_index"], g["knn_distance"])
+    # a stream written by the reference side (oracle, pinned to the compiled reference) loads too
+    ref = oracle.Oracle(g["points"], int(g["max_leaf_size"]), "port", dtype=np.float64)
+    with open(fn, "wb") as f:
+        f.write(b"\x89PKD" + np.uint32(1).tobytes() + np.uint64(9).tobytes() + b"L2Squared" + ref.save_bytes())
+    t3 = pt.load_kd_tree(g["points"], fn, device=gpu)
+    assert same(t3.search_knn(g["queries"], 1).reshape(-1, 1), g["knn1_index"], g["knn1_distance"])
+    # column-major queries: the transposed (k, nq) result of the reference (kd_tree.hpp:362-378)
+    qf = np.asfortranarray(g["queries"].T)
+    rf = t.search_knn(qf, k)
+    assert rf.shape == (k, len(g["queries"])) and np.array_equal(rf.reshape(-1)["index"], g["knn_index"].reshape(-1))
+
+
+@pytest.mark.gpu
+def test_gpu_double_large_batch_in_pieces(gpu, monkeypatch):
+    """More queries than one launch's stack block holds (deep tree: many slots per lane)."""
+    monkeypatch.setenv("PTK_STACK64_MB", "64")
+    rng = np.random.default_rng(5)
+    pts = np.cumsum(rng.random((40_000, 3)) ** 8, axis=0)  # a drawn-out curve: a deep, skewed tree
+    q = pts[rng.integers(0, len(pts), 600_000)] + rng.normal(0, 1e-3, (600_000, 3))
+    t = pt.KdTree(pts, pt.Metric.L2Squared, 1, device=gpu)
+    ref = oracle.Oracle(pts, 1, "port", dtype=np.float64)
+    ref.set_threads(os.cpu_count() or 1)
+    want = ref.search_knn(q, 1)
+    got = t.search_knn(q, 1)
+    assert t.info()["max_depth"] > 20
+    assert same(got.reshape(-1, 1), want["index"], want["distance"])

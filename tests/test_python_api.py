@@ -31,8 +31,13 @@ def test_creation_kd_tree(gpu):  # kd_tree_test.py:11-42
     assert (f.shape[1], f.shape[0]) == (t.npts, t.sdim)
     with pytest.raises(ValueError):  # must have two dimensions
         pt.KdTree(np.array([[[2, 1]], [[4, 3]], [[8, 7]]], dtype=np.float32), pt.Metric.L2Squared, 10, device=gpu)
-    with pytest.raises(ValueError):  # float64 is not built here: loud, no fallback
-        pt.KdTree(np.array(A, dtype=np.float64), pt.Metric.L2Squared, 10, device=gpu)
+    d = np.array(A, dtype=np.float64, order="C")  # kd_tree_test.py:13-18: the scalar dtype follows the input
+    t = pt.KdTree(d, pt.Metric.L2Squared, 10, device=gpu)
+    assert d.dtype == t.dtype_scalar and (t.npts, t.sdim) == d.shape
+    with pytest.raises(ValueError):  # queries of another dtype than the tree's
+        t.search_knn(a, 1)
+    with pytest.raises(ValueError):  # neither float32 nor float64
+        pt.KdTree(np.array(A, dtype=np.int64), pt.Metric.L2Squared, 10, device=gpu)
 
 
 def test_metric(gpu):  # kd_tree_test.py:44-51
