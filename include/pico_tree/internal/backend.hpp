@@ -10,6 +10,7 @@
 #include <cstdint>
 #include <memory>
 #include <mutex>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 #include <type_traits>
@@ -21,6 +22,7 @@
 #include "../metric.hpp"
 #include "access.hpp"
 #include "flat_tree.hpp"
+#include "stream.hpp"
 
 namespace pico_tree::internal {
 
@@ -38,11 +40,52 @@ inline constexpr int ptk_metric_v = std::is_same_v<Metric_, metric_l2_squared> ?
                                     : std::is_same_v<Metric_, metric_lpinf>    ? PTK_METRIC_LPINF
                                                                                : -1;
 
-//! Which kd_tree instantiations run on the GPU.
+//! Which kd_tree instantiations run on the GPU: float points through ptk_* and double points
+//! through ptk_tree64_* / ptk_search64_* (include/ptk.h).
 template <typename Metric_, typename Scalar_, typename Index_>
 inline constexpr bool is_accelerated_v =
-    ptk_metric_v<Metric_> >= 0 && std::is_same_v<Scalar_, float> &&
+    ptk_metric_v<Metric_> >= 0 && (std::is_same_v<Scalar_, float> || std::is_same_v<Scalar_, double>) &&
     std::is_same_v<Index_, int> && sizeof(int) == 4;
+
+//! The C entry points of one scalar type under one set of names.
+template <typename Scalar_>
+struct ptk_api;
+template <>
+struct ptk_api<float> {
+  using tree = ptk_tree;
+  using neighbor = ptk_neighbor;
+  static void destroy(tree* t) { ptk_tree_destroy(t); }
+  static int set_metric(tree* t, int m) { return ptk_tree_set_metric(t, m); }
+  static int knn(tree const* t, float const* q, std::uint64_t nq, std::uint32_t k, float e, neighbor* out) {
+    return ptk_search_knn(t, q, nq, k, e, out);
+  }
+  static int radius(tree const* t, float const* q, std::uint64_t nq, float r, float e, int sort,
+                    std::uint64_t* offsets, neighbor** out) {
+    return ptk_search_radius(t, q, nq, r, e, sort, offsets, out);
+  }
+  static int box(tree const* t, float const* lo, float const* hi, std::uint64_t nb, std::uint64_t* offsets,
+                 std::int32_t** out) {
+    return ptk_search_box(t, lo, hi, nb, offsets, out);
+  }
+};
+template <>
+struct ptk_api<double> {
+  using tree = ptk_tree64;
+  using neighbor = ptk_neighbor64;
+  static void destroy(tree* t) { ptk_tree64_destroy(t); }
+  static int set_metric(tree* t, int m) { return ptk_tree64_set_metric(t, m); }
+  static int knn(tree const* t, double const* q, std::uint64_t nq, std::uint32_t k, double e, neighbor* out) {
+    return ptk_search64_knn(t, q, nq, k, e, out);
+  }
+  static int radius(tree const* t, double const* q, std::uint64_t nq, double r, double e, int sort,
+                    std::uint64_t* offsets, neighbor** out) {
+    return ptk_search64_radius(t, q, nq, r, e, sort, offsets, out);
+  }
+  static int box(tree const* t, double const* lo, double const* hi, std::uint64_t nb, std::uint64_t* offsets,
+                 std::int32_t** out) {
+    return ptk_search64_box(t, lo, hi, nb, offsets, out);
+  }
+};
 
 //! True for space types whose points are known to be one contiguous row-major
 //! float matrix, so a batch can be handed over without a gather copy.
@@ -53,11 +96,11 @@ struct is_dense_space<space_map<point_map<Scalar_, Dim_>>> : std::true_type {};
 template <typename Scalar_, std::size_t Dim_, typename Alloc_>
 struct is_dense_space<std::vector<std::array<Scalar_, Dim_>, Alloc_>> : std::true_type {};
 
-//! Row-major float matrix view of any space: zero-copy when dense, gathered
-//! otherwise.
+//! Row-major matrix view of any space: zero-copy when dense, gathered otherwise.
 template <typename Space_>
 class dense_rows {
  public:
+  using scalar = typename space_view<Space_>::scalar_type;
   explicit dense_rows(Space_ const& space) {
     space_view<Space_> view(space);
     n_ = view.size();
@@ -67,61 +110,75 @@ class dense_rows {
     } else {
       owned_.resize(n_ * dim_);
       for (size_t i = 0; i < n_; ++i) {
-        float const* p = view[i];
+        scalar const* p = view[i];
         for (size_t d = 0; d < dim_; ++d) owned_[i * dim_ + d] = p[d];
       }
       data_ = owned_.data();
     }
   }
-  float const* data() const { return data_; }
+  scalar const* data() const { return data_; }
   size_t rows() const { return n_; }
   size_t cols() const { return dim_; }
 
  private:
-  std::vector<float> owned_;
-  float const* data_ = nullptr;
+  std::vector<scalar> owned_;
+  scalar const* data_ = nullptr;
   size_t n_ = 0;
   size_t dim_ = 0;
 };
 
 //! Owns the device-side replica of one flat tree; created lazily, shared by
 //! moves of the owning kd_tree.
+template <typename Scalar_>
 class device_tree {
  public:
+  using api = ptk_api<Scalar_>;
+  using handle_type = typename api::tree;
   device_tree() : state_(std::make_shared<state>()) {}
 
   template <typename Tree_, typename SpaceView_>
-  ptk_tree* get(Tree_ const& tree, SpaceView_ const& space, int metric = PTK_METRIC_L2_SQUARED) const {
-    static_assert(sizeof(typename Tree_::node_type) == sizeof(ptk_node), "node layout");
+  handle_type* get(Tree_ const& tree, SpaceView_ const& space, int metric = PTK_METRIC_L2_SQUARED) const {
     std::lock_guard<std::mutex> lock(state_->mutex);
     if (state_->handle == nullptr) {
       size_t const n = space.size();
       size_t const dim = space.sdim();
-      std::vector<float> pts(n * dim);
+      std::vector<Scalar_> pts(n * dim);
       for (size_t i = 0; i < n; ++i) {
-        float const* p = space[i];
+        Scalar_ const* p = space[i];
         for (size_t d = 0; d < dim; ++d) pts[i * dim + d] = p[d];
       }
-      ptk_tree_desc desc{};
-      desc.dim = static_cast<std::uint32_t>(dim);
-      desc.n_points = n;
-      desc.points = pts.data();
-      desc.n_nodes = tree.nodes.size();
-      desc.nodes = reinterpret_cast<ptk_node const*>(tree.nodes.data());
-      desc.indices = tree.indices.data();
-      desc.root_min = tree.root_box.min();
-      desc.root_max = tree.root_box.max();
-      desc.max_depth = tree.max_depth;
-      desc.device = PTK_DEVICE_CURRENT;
-      ptk_tree* h = nullptr;
-      ptk_check(ptk_tree_create(&desc, &h), "ptk_tree_create");
+      handle_type* h = nullptr;
+      if constexpr (std::is_same_v<Scalar_, float>) {
+        static_assert(sizeof(typename Tree_::node_type) == sizeof(ptk_node), "node layout");
+        ptk_tree_desc desc{};
+        desc.dim = static_cast<std::uint32_t>(dim);
+        desc.n_points = n;
+        desc.points = pts.data();
+        desc.n_nodes = tree.nodes.size();
+        desc.nodes = reinterpret_cast<ptk_node const*>(tree.nodes.data());
+        desc.indices = tree.indices.data();
+        desc.root_min = tree.root_box.min();
+        desc.root_max = tree.root_box.max();
+        desc.max_depth = tree.max_depth;
+        desc.device = PTK_DEVICE_CURRENT;
+        ptk_check(ptk_tree_create(&desc, &h), "ptk_tree_create");
+      } else {
+        // The already built tree crosses the boundary in the reference's own stream format.
+        std::ostringstream os(std::ios::out | std::ios::binary);
+        write_flat_tree(tree, os);
+        std::string const bytes = os.str();
+        ptk_check(
+            ptk_tree64_create_from_stream(
+                pts.data(), n, static_cast<std::uint32_t>(dim), bytes.data(), bytes.size(), PTK_DEVICE_CURRENT, &h),
+            "ptk_tree64_create_from_stream");
+      }
       if (metric != PTK_METRIC_L2_SQUARED) {
-        int const rc = ptk_tree_set_metric(h, metric);
-        if (rc != PTK_OK) ptk_tree_destroy(h);
+        int const rc = api::set_metric(h, metric);
+        if (rc != PTK_OK) api::destroy(h);
         ptk_check(rc, "ptk_tree_set_metric");
       }
       state_->handle = h;
-      state_->destroy = &ptk_tree_destroy;
+      state_->destroy = &api::destroy;
     }
     return state_->handle;
   }
@@ -129,10 +186,10 @@ class device_tree {
  private:
   struct state {
     std::mutex mutex;
-    ptk_tree* handle = nullptr;
+    handle_type* handle = nullptr;
     // Set where the handle is made, so that a translation unit that never issues
     // a batched call does not reference (and need not link) libptk.
-    void (*destroy)(ptk_tree*) = nullptr;
+    void (*destroy)(handle_type*) = nullptr;
     ~state() {
       if (handle != nullptr && destroy != nullptr) destroy(handle);
     }

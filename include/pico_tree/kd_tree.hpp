@@ -62,6 +62,7 @@ class kd_tree {
   using tree_type = internal::flat_tree<index_type, scalar_type, dim>;
   static constexpr bool accelerated =
       internal::is_accelerated_v<Metric_, scalar_type, Index_>;
+  using api = internal::ptk_api<std::conditional_t<accelerated, scalar_type, float>>;
 
  public:
   //! Index positions of one leaf: a [begin, end) range into the tree's indices.
@@ -270,18 +271,19 @@ class kd_tree {
       std::vector<std::uint64_t>& offsets,
       std::vector<neighbor_type>& flat,
       bool const sort = false) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_OR_DOUBLE_INT");
     internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
     check_query_dim(q.cols());
     offsets.assign(q.rows() + 1, 0);
-    ptk_neighbor* rows = nullptr;
+    typename api::neighbor* rows = nullptr;
     internal::ptk_check(
-        ptk_search_radius(
-            device(), q.data(), q.rows(), radius, 1.0f, sort ? 1 : 0,
+        api::radius(
+            device(), q.data(), q.rows(), radius, scalar_type(1), sort ? 1 : 0,
             offsets.data(), &rows),
         "ptk_search_radius");
     flat.resize(offsets.back());
-    std::copy(rows, rows + flat.size(), reinterpret_cast<ptk_neighbor*>(flat.data()));
+    auto const* src = reinterpret_cast<neighbor_type const*>(rows);
+    std::copy(src, src + flat.size(), flat.data());
     ptk_free(rows);
   }
 
@@ -293,7 +295,7 @@ class kd_tree {
       BoxSpace_ const& maxs,
       std::vector<std::uint64_t>& offsets,
       std::vector<index_type>& flat) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_OR_DOUBLE_INT");
     internal::dense_rows<internal::unwrap_ref_t<BoxSpace_>> lo(unwrap(mins)), hi(unwrap(maxs));
     check_query_dim(lo.cols());
     check_query_dim(hi.cols());
@@ -301,14 +303,14 @@ class kd_tree {
     offsets.assign(lo.rows() + 1, 0);
     std::int32_t* rows = nullptr;
     internal::ptk_check(
-        ptk_search_box(device(), lo.data(), hi.data(), lo.rows(), offsets.data(), &rows), "ptk_search_box");
+        api::box(device(), lo.data(), hi.data(), lo.rows(), offsets.data(), &rows), "ptk_search_box");
     flat.assign(rows, rows + offsets.back());
     ptk_free(rows);
   }
 
   //! Uploads the tree to the device now instead of at the first batched call.
   inline void prepare_device() const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_OR_DOUBLE_INT");
     (void)device();
   }
 
@@ -367,7 +369,7 @@ class kd_tree {
     return space_view_type(unwrap(space_));
   }
 
-  ptk_tree* device() const {
+  typename api::tree* device() const {
     return device_.get(tree_, view(), accelerated ? internal::ptk_metric_v<Metric_> : 0);
   }
 
@@ -380,14 +382,14 @@ class kd_tree {
   template <typename QuerySpace_>
   void batched_knn(
       QuerySpace_ const& queries, size_type k, scalar_type e, neighbor_type* out) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
-    static_assert(sizeof(neighbor_type) == sizeof(ptk_neighbor), "neighbor layout");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_OR_DOUBLE_INT");
+    static_assert(sizeof(neighbor_type) == sizeof(typename api::neighbor), "neighbor layout");
     internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
     check_query_dim(q.cols());
     internal::ptk_check(
-        ptk_search_knn(
+        api::knn(
             device(), q.data(), q.rows(), static_cast<std::uint32_t>(k), e,
-            reinterpret_cast<ptk_neighbor*>(out)),
+            reinterpret_cast<typename api::neighbor*>(out)),
         "ptk_search_knn");
   }
 
@@ -398,13 +400,13 @@ class kd_tree {
       scalar_type e,
       std::vector<std::vector<neighbor_type>>& out,
       bool sort) const {
-    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_INT");
+    static_assert(accelerated, "BATCHED_SEARCH_NEEDS_A_BACKEND_METRIC_FLOAT_OR_DOUBLE_INT");
     internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
     check_query_dim(q.cols());
     std::vector<std::uint64_t> offsets(q.rows() + 1, 0);
-    ptk_neighbor* rows = nullptr;
+    typename api::neighbor* rows = nullptr;
     internal::ptk_check(
-        ptk_search_radius(
+        api::radius(
             device(), q.data(), q.rows(), radius, e, sort ? 1 : 0, offsets.data(), &rows),
         "ptk_search_radius");
     out.resize(q.rows());
@@ -418,7 +420,7 @@ class kd_tree {
   space_type space_;
   metric_type metric_;
   tree_type tree_;
-  internal::device_tree device_;
+  internal::device_tree<std::conditional_t<accelerated, scalar_type, float>> device_;
 };
 
 template <typename Space_, typename... Args>

@@ -13,6 +13,7 @@
 #include <array>
 #include <cstdint>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <functional>
 #include <iostream>
@@ -269,6 +270,47 @@ static int run_batch(std::string const& dir) {
     l1.search_radius(qs, 0.03f, off, flat, false);
     write_raw(dir + "/b_l1_radius_off.bin", off.data(), off.size());
     write_raw(dir + "/b_l1_radius_flat.bin", flat.data(), flat.size());
+  }
+  {  // double precision: kd_tree over double points takes the ptk_tree64_* / ptk_search64_* entry points
+    using neighbor64 = pico_tree::neighbor<int, double>;
+    std::vector<std::array<double, 3>> dp(tree.space().size()), dq(nq);
+    for (size_t i = 0; i < dp.size(); ++i)
+      for (int d = 0; d < 3; ++d) dp[i][d] = static_cast<double>(tree.space()[i][d]) * 1.0000001;
+    for (size_t i = 0; i < nq; ++i)
+      for (int d = 0; d < 3; ++d) dq[i][d] = static_cast<double>(qs[i][d]) * 1.0000001;
+    pico_tree::kd_tree dtree(std::cref(dp), pico_tree::max_leaf_size_t(10));
+    std::vector<neighbor64> a(nq), b(nq * k);
+    std::memset(static_cast<void*>(b.data()), 0, b.size() * sizeof(neighbor64));
+    dtree.search_nn(dq, a.data());
+    dtree.search_knn(dq, k, b.data());
+    for (size_t i = 0; i < nq; ++i) {  // the batched answer is the per-query member's answer
+      neighbor64 one;
+      dtree.search_nn(dq[i], one);
+      if (one.index != a[i].index || one.distance != a[i].distance) return 41;
+      if (b[i * k].index != one.index || b[i * k].distance != one.distance) return 42;
+    }
+    std::vector<std::uint64_t> off, boff;
+    std::vector<neighbor64> flat;
+    std::vector<int> bflat;
+    dtree.search_radius(dq, 0.0009, off, flat, false);
+    auto lo = dq, hi = dq;
+    for (size_t i = 0; i < nq; ++i)
+      for (int d = 0; d < 3; ++d) {
+        lo[i][d] -= 0.02;
+        hi[i][d] += 0.02;
+      }
+    dtree.search_box(lo, hi, boff, bflat);
+    std::vector<int> idx(b.size()), ridx(flat.size());
+    std::vector<double> dist(b.size()), rdist(flat.size());
+    for (size_t i = 0; i < b.size(); ++i) idx[i] = b[i].index, dist[i] = b[i].distance;
+    for (size_t i = 0; i < flat.size(); ++i) ridx[i] = flat[i].index, rdist[i] = flat[i].distance;
+    write_raw(dir + "/d_knn_idx.bin", idx.data(), idx.size());
+    write_raw(dir + "/d_knn_dist.bin", dist.data(), dist.size());
+    write_raw(dir + "/d_radius_off.bin", off.data(), off.size());
+    write_raw(dir + "/d_radius_idx.bin", ridx.data(), ridx.size());
+    write_raw(dir + "/d_radius_dist.bin", rdist.data(), rdist.size());
+    write_raw(dir + "/d_box_off.bin", boff.data(), boff.size());
+    write_raw(dir + "/d_box_flat.bin", bflat.data(), bflat.size());
   }
   // wrong dimension must throw, not crash
   try {

@@ -122,3 +122,16 @@ def test_batched_members_match_oracle(workdir, gpu):
     off, flat = l1.search_radius(q, 0.03)
     assert np.array_equal(_load(d, "b_l1_radius_off.bin", np.uint64), off)
     assert _load(d, "b_l1_radius_flat.bin", pt.NEIGHBOR).tobytes() == flat.tobytes()
+    # double precision members (ptk_tree64_* / ptk_search64_*): the driver scales the clouds by 1.0000001 in double
+    pd, qd = pts.astype(np.float64) * 1.0000001, q.astype(np.float64) * 1.0000001
+    r64 = oracle.Oracle(pd, 10, "port", dtype=np.float64)
+    want = r64.search_knn(qd, K)
+    assert np.array_equal(_load(d, "d_knn_idx.bin", np.int32).reshape(-1, K), want["index"])
+    assert _load(d, "d_knn_dist.bin", np.float64).tobytes() == np.ascontiguousarray(want["distance"]).tobytes()
+    off, flat = r64.search_radius(qd, 0.0009)
+    assert np.array_equal(_load(d, "d_radius_off.bin", np.uint64), off)
+    assert np.array_equal(_load(d, "d_radius_idx.bin", np.int32), flat["index"])
+    assert _load(d, "d_radius_dist.bin", np.float64).tobytes() == np.ascontiguousarray(flat["distance"]).tobytes()
+    boff, bflat = r64.search_box(qd - 0.02, qd + 0.02)
+    assert np.array_equal(_load(d, "d_box_off.bin", np.uint64), boff)
+    assert np.array_equal(_load(d, "d_box_flat.bin", np.int32), bflat)
