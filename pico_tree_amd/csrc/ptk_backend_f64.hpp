@@ -45,7 +45,10 @@ struct ptk_tree64 {
 namespace {
 
 // Stack block of one launch; larger batches go through in pieces (PTK_STACK64_MB shrinks it for tests).
-size_t stack64_bytes() { return (size_t)std::max(1, env_int("PTK_STACK64_MB", 1024)) << 20; }
+// Default 8 GiB: BASELINE config 2 in one launch (7.2 M queries x 68 slots x 16 B = 7.8 GB; every
+// launch ends with the tail of its slowest queries, so pieces cost time: 8 pieces 442 Mq/s, 1 piece see
+// DESIGN.md).  The block is allocated at the size the largest batch so far needed, not up front.
+size_t stack64_bytes() { return (size_t)std::max(1, env_int("PTK_STACK64_MB", 8192)) << 20; }
 
 int encode64(ptk_tree64& t, const double* points) {
   ptk::TreeStats st;
@@ -86,6 +89,8 @@ int encode64(ptk_tree64& t, const double* points) {
   t.dev.cbits = enc.cbits;
   t.dev.cmask = (1u << enc.cbits) - 1u;
   t.dev.dim = t.dim;
+  t.dev.stride = enc.stride;
+  t.dev.n_points = (uint32_t)t.n_points;
   return PTK_OK;
 }
 
@@ -135,12 +140,15 @@ struct Stack64Lease {
   bool armed = false;
   Stack64Lease(const ptk_tree64* tree, hipStream_t stream) : t(tree), lock(tree->mutex), s(stream) {}
   uint64_t piece = 0;  // queries per launch
-  int acquire(uint64_t n) {
+  char* aux = nullptr; // aux_bytes of scratch for the caller (the launch-order permutation)
+  ptk::Rec64* stack = nullptr;
+  int acquire(uint64_t n, size_t aux_bytes = 0) {
     const size_t per_block = (size_t)t->slots * 64 * sizeof(ptk::Rec64);
     uint64_t blocks = (n + 63) / 64;
     const uint64_t max_blocks = std::max<uint64_t>(1, stack64_bytes() / per_block);
     if (blocks > max_blocks) blocks = max_blocks;
-    const size_t bytes = blocks * per_block;
+    aux_bytes = (aux_bytes + 255) & ~size_t(255);
+    const size_t bytes = blocks * per_block + aux_bytes;
     if (bytes > t->stack_capacity) {
       if (t->has_work) (void)hipEventSynchronize(t->done);
       if (t->stack) (void)hipFree(t->stack);
@@ -156,6 +164,8 @@ struct Stack64Lease {
     }
     if (t->has_work && t->last_stream != s) PTK_HIP(hipStreamWaitEvent(s, t->done, 0));
     piece = blocks * 64;
+    aux = t->stack;
+    stack = reinterpret_cast<ptk::Rec64*>(t->stack + aux_bytes);
     armed = true;
     return PTK_OK;
   }
@@ -173,6 +183,41 @@ struct Stack64Lease {
   }
 };
 
+bool want_reorder64(uint64_t nq) { return nq >= 8192 && nq < (1ull << 32) && env_int("PTK_REORDER64", 1) != 0; }
+size_t permutation64_bytes(uint64_t nq) { return want_reorder64(nq) ? permutation_scratch_bytes(nq) + 5 * 256 : 0; }
+
+// Device-side Morton ordering of a batch (make_permutation of the float32 side): *perm lists the
+// query rows in launch order; it lives in the lease's aux block.
+int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipStream_t s, Stack64Lease& lease,
+                       const uint32_t** perm) {
+  *perm = nullptr;
+  if (!want_reorder64(nq)) return PTK_OK;
+  const int bits = morton_bits();
+  size_t tmp_bytes = sort_tmp_bytes(nq, bits);
+  auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
+  char* p = lease.aux;
+  uint32_t* keys = reinterpret_cast<uint32_t*>(p);
+  p += align(nq * 4);
+  uint32_t* keys_out = reinterpret_cast<uint32_t*>(p);
+  p += align(nq * 4);
+  uint32_t* ids = reinterpret_cast<uint32_t*>(p);
+  p += align(nq * 4);
+  uint32_t* ids_out = reinterpret_cast<uint32_t*>(p);
+  p += align(nq * 4);
+  void* tmp = p;
+  ptk::Morton64Box box{};
+  for (uint32_t d = 0; d < t->dim && d < 3; ++d) {
+    box.lo[d] = t->flat.root_box.min()[d];
+    const double ext = t->flat.root_box.max()[d] - t->flat.root_box.min()[d];
+    box.inv[d] = ext > 0 ? 1024.0 / ext : 0.0;
+  }
+  hipLaunchKernelGGL(ptk::morton64_kernel, dim3((uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock)), dim3(ptk::kBlock), 0, s,
+                     d_q, t->dim, nq, box, (uint32_t)(30 - bits), keys, ids);
+  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
+  *perm = ids_out;
+  return PTK_OK;
+}
+
 #define PTK_WITH_METRIC64(CALL)                         \
   do {                                                  \
     const int metric_ = t->metric.load();               \
@@ -189,32 +234,58 @@ struct Stack64Lease {
   } while (0)
 
 template <class M>
-int launch_knn64(const ptk_tree64* t, const double* d_q, uint64_t nq, uint32_t k, double e, ptk::Neighbor64* d_out,
-                 hipStream_t s, Stack64Lease& lease) {
-  const size_t smem = (size_t)2 * t->dim * 64 * sizeof(double);
+int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, double e,
+                 ptk::Neighbor64* d_out, hipStream_t s, Stack64Lease& lease) {
+  const bool d3 = t->dim <= 3;  // q / off in registers: the LDS holds the record ring only
+  const size_t smem = ptk::lds64_bytes(d3 ? 0 : 2, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
-  int rc = allow_lds(ptk::knn64_kernel<M>, smem);
-  if (rc != PTK_OK) return rc;
-  for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {
-    const uint64_t n = std::min(lease.piece, nq - q0);
-    hipLaunchKernelGGL((ptk::knn64_kernel<M>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, d_q, q0, n, k,
-                       1.0 / e, d_out, reinterpret_cast<ptk::Rec64*>(t->stack), t->slots);
+  int rc = PTK_OK;
+  // k-list in registers for 1 < k <= 16 (PTK_KNN_LIST=1: the list in the output row, for A/B runs).
+  const int reg = (k > 1 && k <= 16 && env_int("PTK_KNN_LIST", 0) == 0) ? (k <= 4 ? 4 : (k <= 8 ? 8 : 16)) : 0;
+#define PTK_LAUNCH64(KERNEL)                                                                                          \
+  do {                                                                                                                \
+    rc = allow_lds(KERNEL, smem);                                                                                     \
+    if (rc != PTK_OK) return rc;                                                                                      \
+    for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {                                                               \
+      const uint64_t n = std::min(lease.piece, nq - q0);                                                              \
+      hipLaunchKernelGGL(KERNEL, dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, d_q, perm, q0, n, k,   \
+                         1.0 / e, d_out, lease.stack, t->slots);                                                     \
+    }                                                                                                                 \
+  } while (0)
+  if (d3) {
+    if (reg == 4) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 4, true>));
+    else if (reg == 8) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 8, true>));
+    else if (reg == 16) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 16, true>));
+    else PTK_LAUNCH64((ptk::knn64_kernel<M, true>));
+  } else {
+    if (reg == 4) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 4, false>));
+    else if (reg == 8) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 8, false>));
+    else if (reg == 16) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 16, false>));
+    else PTK_LAUNCH64((ptk::knn64_kernel<M, false>));
   }
+#undef PTK_LAUNCH64
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
 
 template <class M, bool FILL>
-int launch_radius64(const ptk_tree64* t, const double* d_q, uint64_t nq, double radius, double e, uint64_t* d_counts,
-                    const uint64_t* d_offsets, ptk::Neighbor64* d_out, hipStream_t s, Stack64Lease& lease) {
-  const size_t smem = (size_t)2 * t->dim * 64 * sizeof(double);
+int launch_radius64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, uint64_t nq, double radius, double e,
+                    uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor64* d_out, hipStream_t s,
+                    Stack64Lease& lease) {
+  const bool d3 = t->dim <= 3;
+  const size_t smem = ptk::lds64_bytes(d3 ? 0 : 2, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
-  int rc = allow_lds(ptk::radius64_kernel<M, FILL>, smem);
+  int rc = allow_lds(ptk::radius64_kernel<M, FILL, false>, smem);
   if (rc != PTK_OK) return rc;
   for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {
     const uint64_t n = std::min(lease.piece, nq - q0);
-    hipLaunchKernelGGL((ptk::radius64_kernel<M, FILL>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, d_q, q0,
-                       n, radius, 1.0 / e, d_counts, d_offsets, d_out, reinterpret_cast<ptk::Rec64*>(t->stack), t->slots);
+    if (d3) {
+      hipLaunchKernelGGL((ptk::radius64_kernel<M, FILL, true>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
+                         d_q, perm, q0, n, radius, 1.0 / e, d_counts, d_offsets, d_out, lease.stack, t->slots);
+    } else {
+      hipLaunchKernelGGL((ptk::radius64_kernel<M, FILL, false>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
+                         d_q, perm, q0, n, radius, 1.0 / e, d_counts, d_offsets, d_out, lease.stack, t->slots);
+    }
   }
   PTK_HIP(hipGetLastError());
   return PTK_OK;
@@ -223,7 +294,7 @@ int launch_radius64(const ptk_tree64* t, const double* d_q, uint64_t nq, double 
 template <bool FILL>
 int launch_box64(const ptk_tree64* t, const double* d_mins, const double* d_maxs, uint64_t nb, uint64_t* d_counts,
                  const uint64_t* d_offsets, int32_t* d_out, hipStream_t s, Stack64Lease& lease) {
-  const size_t smem = (size_t)4 * t->dim * 64 * sizeof(double);
+  const size_t smem = ptk::lds64_bytes(4, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
   int rc = allow_lds(ptk::box64_kernel<FILL>, smem);
   if (rc != PTK_OK) return rc;
@@ -231,7 +302,7 @@ int launch_box64(const ptk_tree64* t, const double* d_mins, const double* d_maxs
     const uint64_t n = std::min(lease.piece, nb - b0);
     hipLaunchKernelGGL((ptk::box64_kernel<FILL>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
                        static_cast<const double*>(t->d_root), d_mins, d_maxs, b0, n, d_counts, d_offsets, d_out,
-                       reinterpret_cast<ptk::Rec64*>(t->stack), t->slots);
+                       lease.stack, t->slots);
   }
   PTK_HIP(hipGetLastError());
   return PTK_OK;
@@ -386,9 +457,12 @@ int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq,
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   Stack64Lease lease(t, s);
-  rc = lease.acquire(nq);
+  rc = lease.acquire(nq, permutation64_bytes(nq));
   if (rc != PTK_OK) return rc;
-  PTK_WITH_METRIC64(rc = launch_knn64<M>(t, d_q, nq, k, e, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease));
+  const uint32_t* perm = nullptr;
+  rc = make_permutation64(t, d_q, nq, s, lease, &perm);
+  if (rc != PTK_OK) return rc;
+  PTK_WITH_METRIC64(rc = launch_knn64<M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease));
   return rc;
 }
 
@@ -439,9 +513,11 @@ int ptk_search64_radius(const ptk_tree64* t, const double* q, uint64_t nq, doubl
   uint64_t total = 0;
   if (he == hipSuccess) {
     Stack64Lease lease(t, nullptr);
-    rc = lease.acquire(nq);
+    rc = lease.acquire(nq, permutation64_bytes(nq));
+    const uint32_t* perm = nullptr;
+    if (rc == PTK_OK) rc = make_permutation64(t, d_q, nq, nullptr, lease, &perm);
     if (rc == PTK_OK)
-      PTK_WITH_METRIC64(rc = (launch_radius64<M, false>(t, d_q, nq, radius, e, d_c, nullptr, nullptr, nullptr, lease)));
+      PTK_WITH_METRIC64(rc = (launch_radius64<M, false>(t, d_q, perm, nq, radius, e, d_c, nullptr, nullptr, nullptr, lease)));
     if (rc == PTK_OK) rc = scan_counts64(d_c, d_o, nq, offsets);
     if (rc == PTK_OK) {
       total = offsets[nq];
@@ -449,7 +525,7 @@ int ptk_search64_radius(const ptk_tree64* t, const double* q, uint64_t nq, doubl
       he = hipMalloc((void**)&d_out, obytes);
       if (he == hipSuccess) he = hipMemset(d_out, 0, obytes);
       if (he == hipSuccess)
-        PTK_WITH_METRIC64(rc = (launch_radius64<M, true>(t, d_q, nq, radius, e, nullptr, d_o,
+        PTK_WITH_METRIC64(rc = (launch_radius64<M, true>(t, d_q, perm, nq, radius, e, nullptr, d_o,
                                                          reinterpret_cast<ptk::Neighbor64*>(d_out), nullptr, lease)));
       if (he == hipSuccess && rc == PTK_OK && sort) {
         hipLaunchKernelGGL(ptk::sort_rows64_kernel, dim3((uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock)), dim3(ptk::kBlock),

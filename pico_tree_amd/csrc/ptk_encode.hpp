@@ -294,7 +294,8 @@ static_assert(sizeof(EncNode64) == 32, "device record size");
 struct EncodedTree64 {
   std::vector<EncNode64> nodes;   // per branch
   std::vector<EncRange> ranges;   // per branch: position range [begin, end) of its whole subtree
-  std::vector<double> points;     // leaf order, row-major (n_points x dim)
+  std::vector<double> points;     // leaf order, row-major (n_points x stride)
+  uint32_t stride = 0;            // doubles per point: 3 for dim <= 3 (unused axes zero), else dim
   uint32_t root_ref = 0;
   uint32_t cbits = 0;
 };
@@ -349,11 +350,12 @@ inline std::string encode_tree64(
       out.ranges[branch_id[i]] = of_node[i];
     }
   }
-  out.points.resize((size_t)n_points * dim);
+  out.stride = dim <= 3 ? 3 : dim;
+  out.points.assign((size_t)n_points * out.stride, 0.0);
   for (uint64_t pos = 0; pos < n_points; ++pos) {
     const int32_t idx = indices[pos];
     if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
-    std::memcpy(&out.points[pos * dim], points + (uint64_t)idx * dim, dim * sizeof(double));
+    std::memcpy(&out.points[pos * out.stride], points + (uint64_t)idx * dim, dim * sizeof(double));
   }
   out.root_ref = ref_of(0);
   out.cbits = cbits;

@@ -11,13 +11,22 @@
 //
 // Where the per-lane state lives:
 //   q[dim], off[dim]  LDS, [axis][lane] (search.hpp:47,111); 16 bytes per axis per lane
-//   record stack      HBM scratch, [block][slot][lane], 16-byte records {meta, double}: a wave's
-//                     push / pop is one coalesced 1 KiB access; 2 * depth + 2 slots always suffice
-//   k-list            the caller's output row itself (neighbor<int, double>, 16 bytes)
+//   record stack      the newest S records in an LDS ring ([slot][lane]: a double and a meta word per
+//                     slot), older ones spilled to HBM scratch ([block][slot][lane], 16-byte records:
+//                     a wave's spill / refill is one coalesced 1 KiB access); 2 * depth + 2 slots
+//                     always suffice.  (First version: the whole stack in HBM -- every pop a
+//                     dependent global load; 324 -> see DESIGN.md.)
+//   k-list            registers for k <= 16 (Knn64RegPolicy, as KnnRegPolicy of ptk_kernels.hpp),
+//                     else the caller's output row itself (neighbor<int, double>, 16 bytes)
 // Layouts (ptk_backend_f64.hpp, encode64):
 //   nodes : 32 B per branch {left_max, right_min, left_ref, right_ref, axis, 0}
 //   ref   : bit 31 = leaf; leaf = (begin << cbits) | count; branch = branch index
-//   pts   : leaf order, row-major (dim doubles per point); index[]: original index per position
+//   pts   : leaf order, row-major, `stride` doubles per point (stride = 3 for dim <= 3, the unused
+//           axes zero: they add an exact +0 to every distance; else stride = dim); index[]:
+//           original index per position
+// dim <= 3 takes traverse64_3: q and off in registers, the coordinates of two leaf points loaded
+// before either is used (the run-time-dim loop waits for memory once per coordinate: 324 Mq/s on
+// BASELINE config 2 in double against ... see DESIGN.md).
 //   record: x = bit 31 undo | bit 30 (pending: far child is the right one; undo: nbd) |
 //               bits 29:0 (pending: branch index; undo_off: axis),  val = double
 
@@ -51,6 +60,8 @@ struct DevTree64 {
   uint32_t cbits;
   uint32_t cmask;
   uint32_t dim;
+  uint32_t stride;    // doubles per point in pts
+  uint32_t n_points;
 };
 
 constexpr double kDblMax = 1.7976931348623157e308;
@@ -77,25 +88,69 @@ struct Metric64LInf {
   }
 };
 
+typedef PTK_LDS uint32_t LdsU32;
+constexpr int kRing64 = 8;  // LDS ring slots per lane (12 bytes each)
+
+// LDS of a block: [vectors: nvec * dim doubles][ring values: S doubles][ring meta: S words], all [slot][lane].
+__host__ __device__ constexpr size_t lds64_bytes(uint32_t nvec, uint32_t dim) {
+  return ((size_t)nvec * dim * 8 + (size_t)kRing64 * 12) * 64;
+}
+
+// Records are numbered 0, 1, 2, ... in push order; [base, top) is resident in the ring (record i at
+// slot i mod S), [0, base) has been spilled (record i at ovf[i * 64]).  As Stack of ptk_kernels.hpp.
 struct Stack64 {
-  Rec64* base;  // this lane's column: slot i at base[i * 64]
-  int top;
-  __device__ __forceinline__ void init(Rec64* scratch, uint32_t slots) {
-    base = scratch + (uint64_t)blockIdx.x * slots * 64 + threadIdx.x;
+  static constexpr int S = kRing64;
+  static constexpr int kRefill = S / 2;
+  LdsDouble* rv;  // this lane's column of values
+  LdsU32* rm;     // ... and of meta words
+  Rec64* ovf;     // this lane's spill column
+  int top, base;
+  __device__ __forceinline__ void init(uint32_t nvec, uint32_t dim, Rec64* scratch, uint32_t slots) {
+    LdsDouble* ring = (LdsDouble*)ptk_smem + (size_t)nvec * dim * 64;
+    rv = ring + threadIdx.x;
+    rm = (LdsU32*)(ring + (size_t)S * 64) + threadIdx.x;
+    ovf = scratch + (uint64_t)blockIdx.x * slots * 64 + threadIdx.x;
     top = 0;
+    base = 0;
   }
   __device__ __forceinline__ bool empty() const { return top == 0; }
   __device__ __forceinline__ void push(uint32_t meta, double val) {
-    Rec64 r;
-    r.x = meta;
-    r.pad_ = 0;
-    r.val = val;
-    base[(uint64_t)top * 64] = r;
+    if (top - base == S) {  // ring full: spill the oldest resident record
+      Rec64 r;
+      r.x = rm[(base & (S - 1)) * 64];
+      r.pad_ = 0;
+      r.val = rv[(base & (S - 1)) * 64];
+      ovf[(uint64_t)base * 64] = r;
+      ++base;
+    }
+    rm[(top & (S - 1)) * 64] = meta;
+    rv[(top & (S - 1)) * 64] = val;
     ++top;
   }
   __device__ __forceinline__ Rec64 pop() {
+    if (top == base) {  // ring empty, spilled records remain: bring a batch back
+      Rec64 r[kRefill];
+#pragma unroll
+      for (int i = 0; i < kRefill; ++i) {
+        const int idx = base - 1 - i;
+        r[i] = ovf[(uint64_t)(idx >= 0 ? idx : 0) * 64];
+      }
+#pragma unroll
+      for (int i = 0; i < kRefill; ++i) {
+        const int idx = base - 1 - i;
+        if (idx >= 0) {
+          rm[(idx & (S - 1)) * 64] = r[i].x;
+          rv[(idx & (S - 1)) * 64] = r[i].val;
+        }
+      }
+      base = base > kRefill ? base - kRefill : 0;
+    }
     --top;
-    return base[(uint64_t)top * 64];
+    Rec64 r;
+    r.x = rm[(top & (S - 1)) * 64];
+    r.pad_ = 0;
+    r.val = rv[(top & (S - 1)) * 64];
+    return r;
   }
 };
 
@@ -133,6 +188,61 @@ struct Knn64Policy {  // :83-123 / :198-247
       nb.pad_ = 0;
       nb.distance = kDblMax;
       list[k - 1] = nb;
+    }
+  }
+};
+
+// Sorted k-list in registers for k <= K <= 16: K branch-free compare / select steps per accepted
+// candidate, insert_sorted (:24-38) exactly -- strict `<` keeps a new entry behind equal distances;
+// slots start at DBL_MAX (the sentinel of :102).  See KnnRegPolicy in ptk_kernels.hpp.
+template <int K>
+struct Knn64RegPolicy {
+  double ld[K];
+  int32_t li[K];
+  uint32_t k;
+  double worst;
+  double e_inv;
+  __device__ __forceinline__ void init(uint32_t k_, double e_inv_) {
+    k = k_;
+    e_inv = e_inv_;
+    worst = kDblMax;
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      ld[j] = kDblMax;
+      li[j] = 0;
+    }
+  }
+  __device__ __forceinline__ double max() const { return worst; }
+  __device__ __forceinline__ void visit(int32_t idx, double d) {
+    d = d_mul(d, e_inv);
+    if (worst > d) {
+#pragma unroll
+      for (int j = K - 1; j >= 1; --j) {
+        const bool shift = d < ld[j - 1];
+        const bool here = d < ld[j];
+        li[j] = shift ? li[j - 1] : (here ? idx : li[j]);
+        ld[j] = shift ? ld[j - 1] : (here ? d : ld[j]);
+      }
+      if (d < ld[0]) {
+        ld[0] = d;
+        li[0] = idx;
+      }
+      double w = ld[0];
+#pragma unroll
+      for (int j = 1; j < K; ++j) w = (uint32_t)j < k ? ld[j] : w;  // slot k - 1
+      worst = w;
+    }
+  }
+  __device__ __forceinline__ void store(Neighbor64* row) const {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if ((uint32_t)j < k) {
+        Neighbor64 nb;
+        nb.index = li[j];
+        nb.pad_ = 0;
+        nb.distance = ld[j];
+        row[j] = nb;
+      }
     }
   }
 };
@@ -198,7 +308,7 @@ __device__ __forceinline__ void traverse64(const DevTree64& t, LdsDouble* q, Lds
       const uint32_t begin = lv >> t.cbits;
       const uint32_t count = lv & t.cmask;
       for (uint32_t j = 0; j < count; ++j) {
-        const double* p = pts + (uint64_t)(begin + j) * dim;
+        const double* p = pts + (uint64_t)(begin + j) * t.stride;
         double d = 0.0;
         for (uint32_t a = 0; a < dim; ++a) d = M::acc(d, d_sub(q[a * 64], p[a]));  // internal::sum, metric.hpp:36-51
         pol.visit(index[begin + j], d);
@@ -244,24 +354,117 @@ __device__ __forceinline__ void stage_query64(
   }
 }
 
-// Queries [q0, q0 + nq) of the batch; block b of the launch owns stack columns [b * slots * 64, ...).
-template <class M>
+// dim <= 3 (stride 3): the same walk with q and off in registers.
+__device__ __forceinline__ double sel3d(uint32_t axis, double a0, double a1, double a2) {
+  return axis == 0 ? a0 : (axis == 1 ? a1 : a2);
+}
+template <class M, class Policy>
+__device__ __forceinline__ void traverse64_3(const DevTree64& t, double q0, double q1, double q2, Policy& pol, Stack64& st) {
+  const Node64* __restrict__ nodes = t.nodes;
+  const double* __restrict__ pts = t.pts;
+  const int32_t* __restrict__ index = t.index;
+  const uint32_t last = t.n_points - 1;
+  uint32_t ref = t.root_ref;
+  double nbd = 0.0, o0 = 0.0, o1 = 0.0, o2 = 0.0;  // search.hpp:47
+
+  for (;;) {
+    while (!(ref & kLeafBit)) {
+      const Node64 nd = nodes[ref];
+      const double v = sel3d(nd.axis, q0, q1, q2);
+      const bool go_left = d_sub(d_sub(d_add(nd.left_max, nd.right_min), v), v) > 0.0;  // search.hpp:76
+      const double dv = d_sub(go_left ? nd.right_min : nd.left_max, v);
+      const double new_off = M::one(dv);                                                  // :80,84
+      const double far_nbd = d_add(d_sub(nbd, sel3d(nd.axis, o0, o1, o2)), new_off);      // :94
+      if (pol.max() >= far_nbd) st.push(ref | (go_left ? kRecSide : 0u), far_nbd);
+      ref = go_left ? nd.left_ref : nd.right_ref;
+    }
+    {
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      const uint32_t begin = lv >> t.cbits;
+      const uint32_t count = lv & t.cmask;
+      for (uint32_t j = 0; j < count; j += 2) {
+        const uint32_t pa = begin + j;
+        const uint32_t pb = pa + 1 <= last ? pa + 1 : last;  // in range even when the leaf ends at pa
+        const double* a = pts + (uint64_t)pa * 3;
+        const double* b = pts + (uint64_t)pb * 3;
+        const double ax = a[0], ay = a[1], az = a[2], bx = b[0], by = b[1], bz = b[2];
+        const int32_t ia = index[pa], ib = index[pb];
+        // internal::sum (metric.hpp:36-51) from d = 0: acc(0, x) == one(x) exactly
+        const double da = M::acc(M::acc(M::one(d_sub(q0, ax)), d_sub(q1, ay)), d_sub(q2, az));
+        const double db = M::acc(M::acc(M::one(d_sub(q0, bx)), d_sub(q1, by)), d_sub(q2, bz));
+        pol.visit(ia, da);
+        if (j + 1 < count) pol.visit(ib, db);
+      }
+    }
+    for (;;) {
+      if (st.empty()) return;
+      const Rec64 r = st.pop();
+      if (r.x & kRecUndo) {
+        if (r.x & kRecSide) {
+          nbd = r.val;
+        } else {
+          const uint32_t axis = r.x & 0x3FFFFFFFu;
+          o0 = axis == 0 ? r.val : o0;
+          o1 = axis == 1 ? r.val : o1;
+          o2 = axis == 2 ? r.val : o2;
+        }
+        continue;
+      }
+      if (pol.max() >= r.val) {  // the authoritative test of search.hpp:99
+        const uint32_t idx = r.x & 0x3FFFFFFFu;
+        const bool far_is_right = (r.x & kRecSide) != 0;
+        const Node64 nd = nodes[idx];
+        const double dv = d_sub(far_is_right ? nd.right_min : nd.left_max, sel3d(nd.axis, q0, q1, q2));
+        const double new_off = M::one(dv);
+        st.push(kRecUndo | nd.axis, sel3d(nd.axis, o0, o1, o2));
+        st.push(kRecUndo | kRecSide, nbd);
+        o0 = nd.axis == 0 ? new_off : o0;
+        o1 = nd.axis == 1 ? new_off : o1;
+        o2 = nd.axis == 2 ? new_off : o2;
+        nbd = r.val;
+        ref = far_is_right ? nd.right_ref : nd.left_ref;
+        break;
+      }
+    }
+  }
+}
+
+// One query's whole search under either layout: D3 (dim <= 3) or the run-time-dim form.
+template <class M, bool D3, class Policy>
+__device__ __forceinline__ void search64(
+    const DevTree64& t, const double* __restrict__ queries, uint64_t qi, Policy& pol, Rec64* stack, uint32_t slots) {
+  Stack64 st;
+  if constexpr (D3) {
+    const double* row = queries + qi * t.dim;
+    const double q0 = row[0];
+    const double q1 = t.dim > 1 ? row[1] : 0.0;
+    const double q2 = t.dim > 2 ? row[2] : 0.0;
+    st.init(0, 0, stack, slots);
+    traverse64_3<M>(t, q0, q1, q2, pol, st);
+  } else {
+    LdsDouble *q, *off;
+    stage_query64(queries, t.dim, qi, q, off);
+    st.init(2, t.dim, stack, slots);
+    traverse64<M>(t, q, off, pol, st);
+  }
+}
+
+// Launch-order entries [q0, q0 + nq) of the batch (entry j is query perm[j], or j itself without a
+// permutation; results always land in the row of the query); block b of the launch owns stack
+// columns [b * slots * 64, ...).
+template <class M, bool D3>
 __global__ __launch_bounds__(64) void knn64_kernel(
-    DevTree64 t, const double* __restrict__ queries, uint64_t q0, uint64_t nq, uint32_t k, double e_inv,
-    Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
+    DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
+    uint32_t k, double e_inv, Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
   const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= nq) return;
-  const uint64_t qi = q0 + i;
-  LdsDouble *q, *off;
-  stage_query64(queries, t.dim, qi, q, off);
-  Stack64 st;
-  st.init(stack, slots);
+  const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
   if (k == 1) {
     Nn64Policy pol;
     pol.best_d = kDblMax;  // search_visitor.hpp:50
     pol.best_i = 0;
     pol.e_inv = e_inv;
-    traverse64<M>(t, q, off, pol, st);
+    search64<M, D3>(t, queries, qi, pol, stack, slots);
     Neighbor64 nb;
     nb.index = pol.best_i;
     nb.pad_ = 0;
@@ -275,29 +478,59 @@ __global__ __launch_bounds__(64) void knn64_kernel(
   pol.filled = 0;
   pol.worst = kDblMax;
   pol.e_inv = e_inv;
-  traverse64<M>(t, q, off, pol, st);
+  search64<M, D3>(t, queries, qi, pol, stack, slots);
   pol.end_query();
 }
 
-template <class M, bool FILL>
-__global__ __launch_bounds__(64) void radius64_kernel(
-    DevTree64 t, const double* __restrict__ queries, uint64_t q0, uint64_t nq, double radius, double e_inv,
-    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor64* __restrict__ out,
-    Rec64* __restrict__ stack, uint32_t slots) {
+// 1 < k <= K <= 16, k <= n_points (enforced by the caller, kd_tree.hpp:193: every slot below k ends up real).
+template <class M, int K, bool D3>
+__global__ __launch_bounds__(64) void knn64_reg_kernel(
+    DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
+    uint32_t k, double e_inv, Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
   const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= nq) return;
-  const uint64_t qi = q0 + i;
-  LdsDouble *q, *off;
-  stage_query64(queries, t.dim, qi, q, off);
-  Stack64 st;
-  st.init(stack, slots);
+  const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
+  Knn64RegPolicy<K> pol;
+  pol.init(k, e_inv);
+  search64<M, D3>(t, queries, qi, pol, stack, slots);
+  pol.store(out + qi * k);
+}
+
+template <class M, bool FILL, bool D3>
+__global__ __launch_bounds__(64) void radius64_kernel(
+    DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
+    double radius, double e_inv, uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
+    Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
   Radius64Policy<FILL> pol;
   pol.radius = d_mul(radius, e_inv);  // search_visitor.hpp:265
   pol.e_inv = e_inv;
   pol.count = 0;
   pol.out = FILL ? out + offsets[qi] : nullptr;
-  traverse64<M>(t, q, off, pol, st);
+  search64<M, D3>(t, queries, qi, pol, stack, slots);
   if (!FILL) counts[qi] = pol.count;
+}
+
+// Morton key of each query inside the root box (first three axes), as morton_kernel of
+// ptk_kernels.hpp: neighbouring lanes then walk neighbouring leaves.  Only the launch order depends
+// on it, never a result.
+struct Morton64Box {
+  double lo[3], inv[3];
+};
+__global__ __launch_bounds__(kBlock) void morton64_kernel(
+    const double* __restrict__ queries, uint32_t dim, uint64_t nq, Morton64Box box, uint32_t drop,
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nq) return;
+  uint32_t key = 0;
+  for (uint32_t a = 0; a < 3 && a < dim; ++a) {
+    const double f = fmin(fmax((queries[i * dim + a] - box.lo[a]) * box.inv[a], 0.0), 1023.0);
+    key |= spread10((uint32_t)f) << a;
+  }
+  keys[i] = key >> drop;
+  ids[i] = (uint32_t)i;
 }
 
 // Rows ascending by distance (kd_tree.hpp:263-265: std::sort, ties in unspecified order; here
@@ -359,7 +592,7 @@ __global__ __launch_bounds__(64) void box64_kernel(
   uint64_t count = 0;
   int32_t* row = FILL ? out + offsets[bi] : nullptr;
   Stack64 st;
-  st.init(stack, slots);
+  st.init(4, dim, stack, slots);
 
   auto inside = [&]() {  // query_.contains(box_): both corners inside the closed query box
     bool in = true;
@@ -389,7 +622,7 @@ __global__ __launch_bounds__(64) void box64_kernel(
     const uint32_t begin = lv >> t.cbits;
     const uint32_t n = lv & t.cmask;
     for (uint32_t j = 0; j < n; ++j) {
-      const double* p = t.pts + (uint64_t)(begin + j) * dim;
+      const double* p = t.pts + (uint64_t)(begin + j) * t.stride;
       bool in = true;
       for (uint32_t a = 0; a < dim; ++a) in = in && qn[a * 64] <= p[a] && p[a] <= qx[a * 64];
       if (in) {

@@ -660,6 +660,8 @@ void* emu64_create(const double* points, uint64_t n, uint32_t dim, uint64_t max_
   e->dev.cbits = e->enc.cbits;
   e->dev.cmask = (1u << e->enc.cbits) - 1u;
   e->dev.dim = dim;
+  e->dev.stride = e->enc.stride;
+  e->dev.n_points = (uint32_t)n;
   e->root.assign(e->flat.root_box.min(), e->flat.root_box.min() + dim);
   e->root.insert(e->root.end(), e->flat.root_box.max(), e->flat.root_box.max() + dim);
   e->slots = 2 * e->st.max_depth + 4;
@@ -678,26 +680,49 @@ uint64_t emu64_save(void* h, void* buf, uint64_t cap) {
   return bytes.size();
 }
 
+#define EMU64_M(CALL)                          \
+  if (t->metric == 1) {                        \
+    using M = ptk::Metric64L1;                 \
+    CALL;                                      \
+  } else if (t->metric == 2) {                 \
+    using M = ptk::Metric64LInf;               \
+    CALL;                                      \
+  } else {                                     \
+    using M = ptk::Metric64L2;                 \
+    CALL;                                      \
+  }
+// D3: the register form the backend launches for dim <= 3.
 #define EMU64_WITH_METRIC(CALL)                \
   do {                                         \
-    if (t->metric == 1) {                      \
-      using M = ptk::Metric64L1;               \
-      CALL;                                    \
-    } else if (t->metric == 2) {               \
-      using M = ptk::Metric64LInf;             \
-      CALL;                                    \
+    if (t->dev.dim <= 3) {                     \
+      constexpr bool D3 = true;                \
+      EMU64_M(CALL)                            \
     } else {                                   \
-      using M = ptk::Metric64L2;               \
-      CALL;                                    \
+      constexpr bool D3 = false;               \
+      EMU64_M(CALL)                            \
     }                                          \
   } while (0)
 
-int emu64_knn(void* h, const double* q, uint64_t nq, uint32_t k, double e, ptk::Neighbor64* out) {
+int emu64_knn(void* h, const double* q, uint64_t nq, uint32_t k, double e, int list_in_registers, ptk::Neighbor64* out) {
   auto* t = static_cast<Emu64*>(h);
-  if ((size_t)2 * t->dev.dim * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
-  EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
-    ptk::knn64_kernel<M>(t->dev, q, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);
-  }));
+  if (ptk::lds64_bytes(2, t->dev.dim) > sizeof(ptk::ptk_smem)) return -2;
+  // A launch-order permutation (here: the batch backwards); results land in the query's own row.
+  std::vector<uint32_t> order(nq);
+  for (uint64_t i = 0; i < nq; ++i) order[i] = (uint32_t)(nq - 1 - i);
+  const uint32_t* perm = order.data();
+  if (list_in_registers && k > 1 && k <= 4) {
+    EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+      ptk::knn64_reg_kernel<M, 4, D3>(t->dev, q, perm, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);
+    }));
+  } else if (list_in_registers && k > 1 && k <= 16) {
+    EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+      ptk::knn64_reg_kernel<M, 16, D3>(t->dev, q, perm, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);
+    }));
+  } else {
+    EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+      ptk::knn64_kernel<M, D3>(t->dev, q, perm, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);
+    }));
+  }
   return 0;
 }
 
@@ -705,11 +730,11 @@ int emu64_knn(void* h, const double* q, uint64_t nq, uint32_t k, double e, ptk::
 int emu64_radius(void* h, const double* q, uint64_t nq, double radius, double e, int sort, uint64_t* offsets,
                  ptk::Neighbor64* out) {
   auto* t = static_cast<Emu64*>(h);
-  if ((size_t)2 * t->dev.dim * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
+  if (ptk::lds64_bytes(2, t->dev.dim) > sizeof(ptk::ptk_smem)) return -2;
   if (out == nullptr) {
     std::vector<uint64_t> counts(nq + 1, 0);
     EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
-      ptk::radius64_kernel<M, false>(t->dev, q, q0, m, radius, 1.0 / e, counts.data(), nullptr, nullptr, t->stack.data(),
+      ptk::radius64_kernel<M, false, D3>(t->dev, q, nullptr, q0, m, radius, 1.0 / e, counts.data(), nullptr, nullptr, t->stack.data(),
                                      t->slots);
     }));
     offsets[0] = 0;
@@ -717,7 +742,7 @@ int emu64_radius(void* h, const double* q, uint64_t nq, double radius, double e,
     return 0;
   }
   EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
-    ptk::radius64_kernel<M, true>(t->dev, q, q0, m, radius, 1.0 / e, nullptr, offsets, out, t->stack.data(), t->slots);
+    ptk::radius64_kernel<M, true, D3>(t->dev, q, nullptr, q0, m, radius, 1.0 / e, nullptr, offsets, out, t->stack.data(), t->slots);
   }));
   if (sort) for_each_lane(nq, [&] { ptk::sort_rows64_kernel(offsets, nq, out); });
   return 0;
@@ -725,7 +750,7 @@ int emu64_radius(void* h, const double* q, uint64_t nq, double radius, double e,
 
 int emu64_box(void* h, const double* mins, const double* maxs, uint64_t nb, uint64_t* offsets, int32_t* out) {
   auto* t = static_cast<Emu64*>(h);
-  if ((size_t)4 * t->dev.dim * 64 * 8 > sizeof(ptk::ptk_smem)) return -2;
+  if (ptk::lds64_bytes(4, t->dev.dim) > sizeof(ptk::ptk_smem)) return -2;
   if (out == nullptr) {
     std::vector<uint64_t> counts(nb + 1, 0);
     for_each_lane64(t, nb, [&](uint64_t b0, uint64_t m) {

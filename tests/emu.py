@@ -174,7 +174,7 @@ class EmulatedTree64:
         self.lib.emu64_set_metric.argtypes = [c_void_p, c_int]
         self.lib.emu64_save.restype = c_uint64
         self.lib.emu64_save.argtypes = [c_void_p, c_void_p, c_uint64]
-        self.lib.emu64_knn.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, ctypes.c_double, c_void_p]
+        self.lib.emu64_knn.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, ctypes.c_double, c_int, c_void_p]
         self.lib.emu64_radius.argtypes = [c_void_p, c_void_p, c_uint64, ctypes.c_double, ctypes.c_double, c_int,
                                           c_void_p, c_void_p]
         self.lib.emu64_box.argtypes = [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]
@@ -195,10 +195,11 @@ class EmulatedTree64:
         self.lib.emu64_save(self.h, buf.ctypes.data, size)
         return buf.tobytes()
 
-    def search_knn(self, q, k, e=None):
+    def search_knn(self, q, k, e=None, list_in_registers=True):
         q = np.ascontiguousarray(q, dtype=np.float64)
         out = np.zeros((len(q), k), dtype=self.neighbor)
-        assert self.lib.emu64_knn(self.h, q.ctypes.data, len(q), k, e or 1.0, out.ctypes.data) == 0
+        assert self.lib.emu64_knn(self.h, q.ctypes.data, len(q), k, e or 1.0, int(list_in_registers),
+                                  out.ctypes.data) == 0
         return out
 
     def search_radius(self, q, radius, e=None, sort=False):

@@ -95,6 +95,9 @@ def test_emulated_double_kernels_reproduce_the_goldens(name):
     t = emu.EmulatedTree64(g["points"], leaf)
     assert t.save_bytes() == g["save_stream"].tobytes()
     check_against_golden(t, g, lambda m: emu.EmulatedTree64(g["points"], leaf, m))
+    # the k-list kept in the output row (k > 16 on the device) instead of in registers
+    assert same(t.search_knn(g["queries"], int(g["k"]), list_in_registers=False), g["knn_index"], g["knn_distance"])
+    assert same(t.search_knn(g["queries"], 3), g["knn_index"][:, :3], g["knn_distance"][:, :3])  # K = 4 registers
 
 
 def test_host_only_double_handle_builds_the_reference_tree(tmp_path):
