@@ -18,6 +18,14 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 VERBOSE = False
+DTYPE = np.float32  # --dtype float64: the double-precision entry points
+
+
+def same_rows(got, want):
+    """indices and distance bits (the float64 record has padding bytes that are not data)"""
+    got = got.reshape(want.shape)
+    return np.array_equal(got["index"], want["index"]) and \
+        np.ascontiguousarray(got["distance"]).tobytes() == np.ascontiguousarray(want["distance"]).tobytes()
 
 
 def make_cloud(rng, kind, n, dim):
@@ -51,39 +59,45 @@ def one_case(rng, pt, oracle, torch, case):
     scale = float(rng.choice([1.0, 1.0, 1e-6, 1e6, 37.5]))
     shift = float(rng.choice([0.0, 0.0, -0.5, 100.0]))
     metric = str(rng.choice(["L2Squared", "L2Squared", "L1", "LPInf"]))
-    pts = ((make_cloud(rng, kind, n, dim) + shift) * scale).astype(np.float32)
+    pts = ((make_cloud(rng, kind, n, dim) + shift) * scale).astype(DTYPE)
     if rng.random() < 0.5:
-        q = ((make_cloud(rng, kind, nq, dim) + shift) * scale).astype(np.float32)
+        q = ((make_cloud(rng, kind, nq, dim) + shift) * scale).astype(DTYPE)
     else:  # queries near / on tree points
-        q = pts[rng.integers(0, n, nq)] + (rng.normal(0, 1e-3, (nq, dim)) * scale * (rng.random() < 0.7)).astype(np.float32)
-        q = q.astype(np.float32)
+        q = pts[rng.integers(0, n, nq)] + (rng.normal(0, 1e-3, (nq, dim)) * scale * (rng.random() < 0.7)).astype(DTYPE)
+        q = q.astype(DTYPE)
     desc = f"case {case}: dim {dim} n {n} nq {nq} leaf {leaf} {kind} scale {scale} shift {shift} {metric}"
     if VERBOSE:
         print(desc, flush=True)
     tree = pt.KdTree(pts, pt.Metric[metric], leaf, device=0)
     tree.set_reorder(int(rng.choice([pt.REORDER_AUTO, pt.REORDER_ON, pt.REORDER_OFF])))
-    ref = oracle.Oracle(pts, leaf, "port", metric)
+    ref = oracle.Oracle(pts, leaf, "port", metric, dtype=DTYPE)
     bad = []
     for k in {1, int(rng.integers(1, min(n, 48) + 1)), min(n, int(rng.choice([2, 8, 33, 64])))}:
         e = float(rng.choice([1.0, 1.0, 1.3, 4.0]))
         want = ref.search_knn(q, k, e=None if e == 1.0 else e)
         got = tree.search_knn(q, k) if e == 1.0 else tree.search_knn(q, k, e)
-        if got.reshape(want.shape).tobytes() != want.tobytes():
+        if not same_rows(got, want):
             bad.append(f"knn k={k} e={e}")
     nn = ref.search_knn(q, min(n, 4))["distance"][:, -1]
     radius = float(np.quantile(nn, rng.choice([0.1, 0.5, 0.9])) * rng.choice([1.0, 4.0])) or float(scale * 0.01)
     e = float(rng.choice([1.0, 1.0, 2.0]))
     off, flat = ref.search_radius(q, radius, e=None if e == 1.0 else e)
     got = tree.search_radius(q, radius) if e == 1.0 else tree.search_radius(q, radius, e)
-    if not np.array_equal(got.offsets, off) or got.flat.tobytes() != flat.tobytes():
+    if not np.array_equal(got.offsets, off) or not same_rows(got.flat, flat):
         bad.append(f"radius r={radius} e={e}")
-    dq = torch.from_numpy(q).cuda()
-    doff, draw = tree.search_radius_device(dq, radius, e)
-    if not np.array_equal(doff.cpu().numpy().astype(np.uint64), off) or draw.cpu().numpy().tobytes() != flat.tobytes():
-        bad.append(f"radius (device buffers) r={radius} e={e}")
+    if DTYPE is np.float32:
+        dq = torch.from_numpy(q).cuda()
+        doff, draw = tree.search_radius_device(dq, radius, e)
+        if not np.array_equal(doff.cpu().numpy().astype(np.uint64), off) or draw.cpu().numpy().tobytes() != flat.tobytes():
+            bad.append(f"radius (device buffers) r={radius} e={e}")
+    else:  # device tensors in, device rows out
+        kk = min(n, 3)
+        dn = tree.search_knn(torch.from_numpy(q).cuda(), kk).numpy().reshape(nq, kk)
+        if not same_rows(dn, ref.search_knn(q, kk)):
+            bad.append("knn (device buffers)")
     if True:
-        half = (rng.random((nq, dim)) * scale * (0.05 if dim <= 3 else 0.3)).astype(np.float32)
-        boxes = np.empty((2 * nq, dim), dtype=np.float32)
+        half = (rng.random((nq, dim)) * scale * (0.05 if dim <= 3 else 0.3)).astype(DTYPE)
+        boxes = np.empty((2 * nq, dim), dtype=DTYPE)
         boxes[0::2], boxes[1::2] = q - half, q + half
         boff, bflat = ref.search_box(boxes[0::2].copy(), boxes[1::2].copy())
         b = tree.search_box(boxes)
@@ -99,7 +113,10 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--case", type=int, default=-1, help="replay only this case")
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
+    ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
     args = ap.parse_args()
+    global DTYPE
+    DTYPE = np.float64 if args.dtype == "float64" else np.float32
     import torch
     import oracle
     import pico_tree_amd as pt
