@@ -32,7 +32,7 @@
 
 #pragma once
 
-#include "ptk_kernels.hpp"
+#include "ptk_kernels_nd.hpp"
 
 namespace ptk {
 
@@ -309,9 +309,22 @@ __device__ __forceinline__ void traverse64(const DevTree64& t, LdsDouble* q, Lds
       const uint32_t count = lv & t.cmask;
       for (uint32_t j = 0; j < count; ++j) {
         const double* p = pts + (uint64_t)(begin + j) * t.stride;
+        const int32_t pi = index[begin + j];
         double d = 0.0;
-        for (uint32_t a = 0; a < dim; ++a) d = M::acc(d, d_sub(q[a * 64], p[a]));  // internal::sum, metric.hpp:36-51
-        pol.visit(index[begin + j], d);
+        // internal::sum (metric.hpp:36-51), kNdBatch coordinates loaded before the first is used; a
+        // slot past the last axis contributes diff = 0, an exact no-op (see traverse_nd).
+        for (uint32_t a = 0; a < dim; a += kNdBatch) {
+          double pc[kNdBatch], qc[kNdBatch];
+#pragma unroll
+          for (uint32_t u = 0; u < kNdBatch; ++u) {
+            const uint32_t au = a + u < dim ? a + u : dim - 1;
+            pc[u] = p[au];
+            qc[u] = q[au * 64];
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < kNdBatch; ++u) d = M::acc(d, a + u < dim ? d_sub(qc[u], pc[u]) : 0.0);
+        }
+        pol.visit(pi, d);
       }
     }
     for (;;) {

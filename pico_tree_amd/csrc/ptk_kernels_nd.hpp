@@ -37,6 +37,7 @@ struct DevTreeND {
 };
 
 constexpr uint32_t kNdIdxMask = 0x3FFFFFFFu;
+constexpr uint32_t kNdBatch = 4;  // point coordinates in flight per lane (leaf scan)
 
 typedef PTK_LDS float LdsFloat;
 
@@ -71,12 +72,24 @@ __device__ __forceinline__ void traverse_nd(
       const uint32_t count = lv & t.cmask;
       for (uint32_t j = 0; j < count; ++j) {
         const float* p = pts + (uint64_t)(begin + j) * dim;
+        const int32_t pi = index[begin + j];
         float d = 0.0f;
-        for (uint32_t a = 0; a < dim; ++a) {
-          const float diff = f_sub(q[a * stride], p[a]);
-          d = M::acc(d, diff);
+        // kNdBatch coordinates are loaded before the first is used (one coordinate per iteration
+        // waits for memory dim times per point).  A slot past the last axis re-reads the last
+        // coordinate and contributes diff = 0: acc(d, 0) == d exactly for the three metrics
+        // (d >= +0: d + 0 * 0, d + |0|, max(d, |0|)).
+        for (uint32_t a = 0; a < dim; a += kNdBatch) {
+          float pc[kNdBatch], qc[kNdBatch];
+#pragma unroll
+          for (uint32_t u = 0; u < kNdBatch; ++u) {
+            const uint32_t au = a + u < dim ? a + u : dim - 1;
+            pc[u] = p[au];
+            qc[u] = q[au * stride];
+          }
+#pragma unroll
+          for (uint32_t u = 0; u < kNdBatch; ++u) d = M::acc(d, a + u < dim ? f_sub(qc[u], pc[u]) : 0.0f);
         }
-        pol.visit(index[begin + j], d);
+        pol.visit(pi, d);
       }
     }
     for (;;) {
