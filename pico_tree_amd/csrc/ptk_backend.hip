@@ -762,24 +762,44 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
 constexpr size_t kMaxLdsBytes = 160 * 1024;
 
 template <int OVF, class M = ptk::MetricL2>
-int launch_knn_nd(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t k, float e, ptk::Neighbor* d_out,
-                  hipStream_t s) {
+int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
+                  ptk::Neighbor* d_out, hipStream_t s) {
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const size_t base = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
   if (base > kMaxLdsBytes)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
+  if (k <= 32 && env_int("PTK_KNN_LIST", 0) == 0) {  // k-list in registers (K = 4 / 8 / 16 / 32 slots compiled)
+    Timer timer(t, s);
+    int rc = PTK_OK;
+#define PTK_LAUNCH_ND_REG(KK)                                                                                       \
+  do {                                                                                                              \
+    rc = allow_lds(ptk::knn_nd_reg_kernel<KK, S, OVF, M>, base);                                                    \
+    if (rc == PTK_OK)                                                                                               \
+      hipLaunchKernelGGL((ptk::knn_nd_reg_kernel<KK, S, OVF, M>), dim3(blocks), dim3(64), base, s, t->dev_nd, d_q,  \
+                         perm, nq, k, inv_ratio(e), d_out);                                                         \
+  } while (0)
+    if (k <= 4) PTK_LAUNCH_ND_REG(4);
+    else if (k <= 8) PTK_LAUNCH_ND_REG(8);
+    else if (k <= 16) PTK_LAUNCH_ND_REG(16);
+    else PTK_LAUNCH_ND_REG(32);
+#undef PTK_LAUNCH_ND_REG
+    if (rc != PTK_OK) return rc;
+    PTK_HIP(hipGetLastError());
+    timer.stop(0, nq);
+    return PTK_OK;
+  }
   const size_t list_bytes = (size_t)k * 64 * 8;
   const bool list_lds = base + list_bytes <= 64 * 1024;
   const size_t smem = base + (list_lds ? list_bytes : 0);
   Timer timer(t, s);
   if (list_lds) {
-    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, true, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
+    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, true, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, perm, nq, k,
                        inv_ratio(e), d_out);
   } else {
     int rc = allow_lds(ptk::knn_nd_kernel<S, OVF, false, M>, smem);
     if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, false, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq, k,
+    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, false, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, perm, nq, k,
                        inv_ratio(e), d_out);
   }
   PTK_HIP(hipGetLastError());
@@ -1093,18 +1113,19 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   const bool l2 = t->metric.load() == PTK_METRIC_L2_SQUARED;
-  if (t->dim > 3) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_nd<OVF, M>(t, d_q, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
-    return rc;
-  }
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s);
-  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) + (k == 1 && l2 ? two_phase_scratch_bytes(nq) : 0));
+  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
+                       (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(nq) : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
-  if (reorder) {
+  if (reorder) {  // Morton order along the first three axes, whatever the dimension
     rc = make_permutation(t, d_q, nq, s, scratch, &perm);
     if (rc != PTK_OK) return rc;
+  }
+  if (t->dim > 3) {
+    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_nd<OVF, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    return rc;
   }
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);

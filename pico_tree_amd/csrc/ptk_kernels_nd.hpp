@@ -137,12 +137,15 @@ __device__ __forceinline__ void stage_query_nd(
   }
 }
 
+// perm: the launch order of the batch (entry i of the launch is query perm[i]; null = as given).
+// Results always land in the row of the query.
 template <int S, int OVF, bool LIST_LDS, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn_nd_kernel(
-    DevTreeND t, const float* __restrict__ queries, uint64_t nq, uint32_t k, float e_inv,
-    Neighbor* __restrict__ out) {
-  const uint64_t qi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (qi >= nq) return;
+    DevTreeND t, const float* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k,
+    float e_inv, Neighbor* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[i] : i;
   LdsFloat *q, *off;
   stage_query_nd<S>(queries, t.dim, qi, q, off);
   Record spill[OVF > 0 ? OVF : 1];
@@ -163,6 +166,25 @@ __global__ __launch_bounds__(64) void knn_nd_kernel(
   pol.out = out;
   traverse_nd<M>(t, q, off, 64u, pol, st);
   pol.end_query((uint32_t)qi);
+}
+
+// k <= K <= 32: the k-list in registers (KnnRegPolicy, ptk_kernels.hpp).
+template <int K, int S, int OVF, class M = MetricL2>
+__global__ __launch_bounds__(64) void knn_nd_reg_kernel(
+    DevTreeND t, const float* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k,
+    float e_inv, Neighbor* __restrict__ out) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[i] : i;
+  LdsFloat *q, *off;
+  stage_query_nd<S>(queries, t.dim, qi, q, off);
+  Record spill[OVF > 0 ? OVF : 1];
+  Stack<S, OVF, 64> st;
+  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  KnnRegPolicy<K> pol;
+  pol.init(k, e_inv);
+  traverse_nd<M>(t, q, off, 64u, pol, st);
+  pol.store(out + qi * k);
 }
 
 // perm / n_dev (fill pass only): the batch is the first *n_dev rows listed in perm -- the rows a

@@ -179,12 +179,15 @@ std::vector<float4> pack(const float* q, uint32_t dim, const uint32_t* perm, uin
 template <class M>
 int emu_knn_metric(Emu* t, const float* q, uint64_t nq, uint32_t k, float e_inv, const uint32_t* perm,
                    int small_stack, ptk::Neighbor* o) {
-  if (t->dim > 3) {
-    if (perm != nullptr) return -3;
-    if (small_stack)
-      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, true, M>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+  if (t->dim > 3) {  // as launch_knn_nd: registers for k <= 32, else the list in LDS
+    if (k <= 4)
+      for_each_lane(nq, [&] { ptk::knn_nd_reg_kernel<4, 4, 2048, M>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
+    else if (k <= 32)
+      for_each_lane(nq, [&] { ptk::knn_nd_reg_kernel<32, 16, 2048, M>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
+    else if (small_stack)
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, true, M>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
     else
-      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, true, M>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, true, M>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
     return 0;
   }
   if (k <= 32) {
@@ -275,18 +278,24 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
   if (need > 4 + 2048) return -2;
   if (t->metric == 1) return emu_knn_metric<ptk::MetricL1>(t, q, nq, k, e_inv, perm, small_stack, o);
   if (t->metric == 2) return emu_knn_metric<ptk::MetricLInf>(t, q, nq, k, e_inv, perm, small_stack, o);
-  if (t->dim > 3) {  // any-dimension kernels (no launch permutation)
-    if (perm != nullptr) return -3;
+  if (t->dim > 3) {  // any-dimension kernels
+    if (list_in_lds == 2) {  // k-list in registers (k <= 32)
+      if (k > 32) return -2;
+      if (k <= 8) for_each_lane(nq, [&] { ptk::knn_nd_reg_kernel<8, 4, 2048>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
+      else if (k <= 16) for_each_lane(nq, [&] { ptk::knn_nd_reg_kernel<16, 16, 2048>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
+      else for_each_lane(nq, [&] { ptk::knn_nd_reg_kernel<32, 16, 2048>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
+      return 0;
+    }
     const size_t base = (size_t)(small_stack ? 4 : 16) * 64 * 8 + (size_t)t->dim * 64 * 8;
     if (base + (list_in_lds ? (size_t)k * 64 * 8 : 0) > sizeof(ptk::ptk_smem)) return -2;
     if (small_stack && list_in_lds)
-      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, true>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, true>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
     else if (small_stack)
-      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, false>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<4, 2048, false>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
     else if (list_in_lds)
-      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, true>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, true>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
     else
-      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, false>(t->dev_nd, q, nq, k, e_inv, o); }, 64);
+      for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, false>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
     return 0;
   }
   if (k == 1) {

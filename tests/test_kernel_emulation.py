@@ -85,12 +85,14 @@ def test_emulated_any_dimension_kernels_equal_oracle(dim, n, nq, radius):
     pts, q = ds.uniform_cloud(n, dim, 1), ds.uniform_cloud(nq, dim, 2)
     emu = EmulatedTree(pts, 8)
     ref = oracle.Oracle(pts, 8, "port")
-    for k in (1, 7):
+    perm = np.random.default_rng(dim).permutation(nq).astype(np.uint32)  # any launch order, same rows
+    for k in (1, 7, 20):
         want = ref.search_knn(q, k)
         for small_stack in (False, True):
-            for list_in_lds in (False, True):
-                got = emu.search_knn(q, k, small_stack=small_stack, list_in_lds=list_in_lds)
-                assert got.tobytes() == want.tobytes()
+            for list_in_lds in (False, True, 2):  # k-list in the output row / in LDS / in registers
+                for p in (None, perm):
+                    got = emu.search_knn(q, k, perm=p, small_stack=small_stack, list_in_lds=list_in_lds)
+                    assert got.tobytes() == want.tobytes()
     assert emu.search_knn(q, 4, e=1.25).tobytes() == ref.search_knn(q, 4, e=1.25).tobytes()
     off, flat = ref.search_radius(q, radius)
     goff, gflat = emu.search_radius(q, radius)
