@@ -46,8 +46,7 @@ namespace {
 
 // Stack block of one launch; larger batches go through in pieces (PTK_STACK64_MB shrinks it for tests).
 // Default 8 GiB: BASELINE config 2 in one launch (7.2 M queries x 68 slots x 16 B = 7.8 GB; every
-// launch ends with the tail of its slowest queries, so pieces cost time: 8 pieces 442 Mq/s, 1 piece see
-// DESIGN.md).  The block is allocated at the size the largest batch so far needed, not up front.
+// launch ends with the tail of its slowest queries, so pieces cost time: DESIGN.md section 4, K9).  The block is allocated at the size the largest batch so far needed, not up front.
 size_t stack64_bytes() { return (size_t)std::max(1, env_int("PTK_STACK64_MB", 8192)) << 20; }
 
 int encode64(ptk_tree64& t, const double* points) {

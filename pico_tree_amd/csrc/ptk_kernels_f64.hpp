@@ -14,8 +14,7 @@
 //   record stack      the newest S records in an LDS ring ([slot][lane]: a double and a meta word per
 //                     slot), older ones spilled to HBM scratch ([block][slot][lane], 16-byte records:
 //                     a wave's spill / refill is one coalesced 1 KiB access); 2 * depth + 2 slots
-//                     always suffice.  (First version: the whole stack in HBM -- every pop a
-//                     dependent global load; 324 -> see DESIGN.md.)
+//                     always suffice.
 //   k-list            registers for k <= 16 (Knn64RegPolicy, as KnnRegPolicy of ptk_kernels.hpp),
 //                     else the caller's output row itself (neighbor<int, double>, 16 bytes)
 // Layouts (ptk_backend_f64.hpp, encode64):
@@ -24,11 +23,10 @@
 //   pts   : leaf order, row-major, `stride` doubles per point (stride = 3 for dim <= 3, the unused
 //           axes zero: they add an exact +0 to every distance; else stride = dim); index[]:
 //           original index per position
-// dim <= 3 takes traverse64_3: q and off in registers, the coordinates of two leaf points loaded
-// before either is used (the run-time-dim loop waits for memory once per coordinate: 324 Mq/s on
-// BASELINE config 2 in double against ... see DESIGN.md).
 //   record: x = bit 31 undo | bit 30 (pending: far child is the right one; undo: nbd) |
 //               bits 29:0 (pending: branch index; undo_off: axis),  val = double
+// dim <= 3 takes traverse64_3: q and off in registers, the coordinates of two leaf points loaded
+// before either is used.  Measured steps (BASELINE config 2 in double): DESIGN.md section 4, K9.
 
 #pragma once
 

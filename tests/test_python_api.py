@@ -1,8 +1,7 @@
 """The reference's Python unit tests (/root/reference/test/pyco_tree/kd_tree_test.py)
-restated against ``pico_tree_amd.KdTree`` for the path this repository builds (float32,
-Metric.L2Squared): same calls, same assertions.  Cases that need the parts listed as out of
-scope in DESIGN.md (float64, L1) are restated as the
-behaviour this build promises instead: a loud error, never a silent CPU fallback.
+restated against ``pico_tree_amd.KdTree``: same calls, same assertions (float32 here; the float64
+cases of the reference's tests are in tests/test_f64.py).  Anything this build does not run on the
+device is a loud error, never a silent CPU fallback.
 """
 
 from __future__ import annotations
