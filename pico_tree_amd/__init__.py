@@ -289,6 +289,7 @@ class KdTree:
         else:
             self._dtype, self._neighbor, self._f64 = np.dtype(np.float32), NEIGHBOR, False
         self._real = np.float64 if self._f64 else np.float32
+        self._given = pts  # in the caller's own layout (row- or column-major), for __array__
         pts = self._as_matrix(pts, None, "pts", self._dtype)
         if int(max_leaf_size) <= 0:
             raise ValueError("max_leaf_size must be positive")
@@ -310,6 +311,17 @@ class KdTree:
         self._h = handle
         if metric is not Metric.L2Squared:
             _check(self._fn("ptk_tree_set_metric")(handle, _PTK_METRIC[metric]))
+
+    def __array__(self, dtype=None, copy=None):
+        """The tree as a read-only view of its points, shaped as they were given -- ``(npts, sdim)`` for
+        row-major input, ``(sdim, npts)`` for column-major input: the reference exposes exactly this
+        through the buffer protocol (``def_kd_tree.cpp:30-33``, ``_pyco_tree/kd_tree.hpp:292-315``) to
+        show how the data is interpreted.  ``np.asarray(tree)`` does not copy."""
+        v = self._given.view()
+        v.flags.writeable = False
+        if dtype is not None and np.dtype(dtype) != v.dtype:
+            return v.astype(dtype)
+        return v.copy() if copy else v
 
     @property
     def metric_string(self) -> str:  # core.hpp:24-38
