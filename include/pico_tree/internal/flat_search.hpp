@@ -24,7 +24,10 @@
 #include <cstdint>
 #include <vector>
 
+#include <algorithm>
+
 #include "../core.hpp"
+#include "../distance.hpp"
 #include "flat_tree.hpp"
 
 namespace pico_tree::internal {
@@ -133,6 +136,92 @@ inline void nearest_search(
     }
   }
 }
+
+//! Distance from x to the segment [min, max] of the real line (internal/segment.hpp:21-48).
+template <typename Scalar_>
+constexpr Scalar_ segment_distance(Scalar_ min, Scalar_ max, Scalar_ x, one_space_r1) {
+  if (x < min) return min - x;
+  if (x > max) return x - max;
+  return Scalar_(0);
+}
+
+//! ... and to the arc from min to max of the unit circle [0, 1] / 0 ~ 1, which wraps through 0
+//! when min > max (internal/segment.hpp:50-104).
+template <typename Scalar_>
+constexpr Scalar_ segment_distance(Scalar_ min, Scalar_ max, Scalar_ x, one_space_s1) {
+  if (min <= max) {  // linear
+    if (x < min || x > max) return std::min(s1_distance(x, min), s1_distance(x, max));
+    return Scalar_(0);
+  }
+  if (x < max || x > min) return Scalar_(0);
+  return std::min(s1_distance(x, min), s1_distance(x, max));
+}
+
+//! The reference's search for topological spaces (internal/kd_tree_search.hpp:115-229): both boxes
+//! of a branch are measured on the split axis with the metric's notion of that axis (line or
+//! circle: apply_dim_space), the nearer child is visited first (ties: the right one, `d1 < d2`),
+//! the farther iff `visitor.max() >= node_box_distance` with the same incremental update as the
+//! euclidean search.  Needs the four bounds per branch (flat_tree::outer_bounds).  Recursive: this
+//! is a host-only path.
+template <typename Tree_, typename SpaceView_, typename Metric_, typename PointView_, typename Visitor_>
+class nearest_search_topological {
+ public:
+  using scalar = typename Tree_::scalar_type;
+  nearest_search_topological(
+      Tree_ const& tree, SpaceView_ const& space, Metric_ const& metric, PointView_ const& query, Visitor_& visitor)
+      : tree_(tree), space_(space), metric_(metric), query_(query), visitor_(visitor), off_(space.sdim(), scalar(0)) {}
+
+  void operator()() { descend(0, scalar(0)); }
+
+ private:
+  scalar box_distance(scalar min, scalar max, scalar v, int dim) const {
+    scalar d{};
+    metric_.apply_dim_space(dim, [&](auto one_space) { d = segment_distance(min, max, v, one_space); });
+    return metric_(d);
+  }
+
+  void descend(std::uint32_t node, scalar node_box_distance) {
+    auto const& nd = tree_.nodes[node];
+    if (nd.is_leaf()) {
+      for (auto i = nd.begin; i < nd.end; ++i) {
+        auto const idx = tree_.indices[static_cast<size_t>(i)];
+        visitor_(idx, metric_(query_.begin(), query_.end(), space_[idx]));
+      }
+      return;
+    }
+    size_t const axis = nd.split_dim;
+    scalar const v = query_[axis];
+    auto const& outer = tree_.outer_bounds[node];  // {left_min, right_max}
+    scalar const d1 = box_distance(outer[0], nd.left_max, v, static_cast<int>(axis));
+    scalar const d2 = box_distance(nd.right_min, outer[1], v, static_cast<int>(axis));
+    std::uint32_t first, second;
+    scalar new_offset;
+    if (d1 < d2) {
+      first = node + 1;
+      second = nd.right;
+      new_offset = d2;
+    } else {
+      first = nd.right;
+      second = node + 1;
+      new_offset = d1;
+    }
+    descend(first, node_box_distance);
+    scalar const old_offset = off_[axis];
+    node_box_distance = node_box_distance - old_offset + new_offset;
+    if (visitor_.max() >= node_box_distance) {
+      off_[axis] = new_offset;
+      descend(second, node_box_distance);
+      off_[axis] = old_offset;
+    }
+  }
+
+  Tree_ const& tree_;
+  SpaceView_ const& space_;
+  Metric_ const& metric_;
+  PointView_ const& query_;
+  Visitor_& visitor_;
+  std::vector<scalar> off_;
+};
 
 //! All indices inside the closed box [qmin, qmax], in the reference's report
 //! order (internal/kd_tree_search.hpp:238-381): a node whose running box is

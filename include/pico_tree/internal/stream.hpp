@@ -56,6 +56,17 @@ struct stream_branch {
   Scalar_ right_min;
 };
 
+// kd_tree_branch_double<Scalar_> (kd_tree_node.hpp:52-67): the branch of a tree over a topological
+// space (flat_tree::keep_outer_bounds).
+template <typename Scalar_>
+struct stream_branch_double {
+  int split_dim;
+  Scalar_ left_min;
+  Scalar_ left_max;
+  Scalar_ right_min;
+  Scalar_ right_max;
+};
+
 template <typename Tree_>
 inline void write_flat_tree(Tree_ const& tree, std::ostream& s) {
   using index = typename Tree_::index_type;
@@ -70,12 +81,22 @@ inline void write_flat_tree(Tree_ const& tree, std::ostream& s) {
           static_cast<std::streamsize>(sdim * sizeof(scalar)));
   s.write(reinterpret_cast<char const*>(tree.root_box.max()),
           static_cast<std::streamsize>(sdim * sizeof(scalar)));
-  for (auto const& nd : tree.nodes) {
+  for (size_t ni = 0; ni < tree.nodes.size(); ++ni) {
+    auto const& nd = tree.nodes[ni];
     bool const leaf = nd.is_leaf();
     put_pod(s, leaf);
     if (leaf) {
       put_pod(s, nd.begin);
       put_pod(s, nd.end);
+    } else if (tree.keep_outer_bounds) {
+      stream_branch_double<scalar> b;
+      std::memset(&b, 0, sizeof(b));
+      b.split_dim = static_cast<int>(nd.split_dim);
+      b.left_min = tree.outer_bounds[ni][0];
+      b.left_max = nd.left_max;
+      b.right_min = nd.right_min;
+      b.right_max = tree.outer_bounds[ni][1];
+      put_pod(s, b);
     } else {
       stream_branch<scalar> b;
       std::memset(&b, 0, sizeof(b));  // padding included
@@ -88,12 +109,13 @@ inline void write_flat_tree(Tree_ const& tree, std::ostream& s) {
 }
 
 template <typename Tree_>
-inline Tree_ read_flat_tree(std::istream& s) {
+inline Tree_ read_flat_tree(std::istream& s, bool outer_bounds = false) {
   using index = typename Tree_::index_type;
   using scalar = typename Tree_::scalar_type;
   size_t sdim = 0;
   get_pod(s, sdim);
   Tree_ tree(sdim);
+  tree.keep_outer_bounds = outer_bounds;
   size_t n = 0;
   get_pod(s, n);
   tree.indices.resize(n);
@@ -118,16 +140,26 @@ inline Tree_ read_flat_tree(std::istream& s) {
     if (!s) throw std::runtime_error("kd_tree stream ended early");
     std::uint32_t const self = static_cast<std::uint32_t>(tree.nodes.size());
     tree.nodes.emplace_back();
+    if (outer_bounds) tree.outer_bounds.push_back({scalar(0), scalar(0)});
     if (depth > tree.max_depth) tree.max_depth = depth;
     bool leaf = false;
     get_pod(s, leaf);
     if (!leaf) {
-      stream_branch<scalar> rec{};
-      get_pod(s, rec);
       auto& b = tree.nodes[self];
-      b.split_dim = static_cast<std::uint32_t>(rec.split_dim);
-      b.left_max = rec.left_max;
-      b.right_min = rec.right_min;
+      if (outer_bounds) {
+        stream_branch_double<scalar> rec{};
+        get_pod(s, rec);
+        b.split_dim = static_cast<std::uint32_t>(rec.split_dim);
+        b.left_max = rec.left_max;
+        b.right_min = rec.right_min;
+        tree.outer_bounds[self] = {rec.left_min, rec.right_max};
+      } else {
+        stream_branch<scalar> rec{};
+        get_pod(s, rec);
+        b.split_dim = static_cast<std::uint32_t>(rec.split_dim);
+        b.left_max = rec.left_max;
+        b.right_min = rec.right_min;
+      }
       b.right = 0;
       open.push_back(pending{self, depth, false});
       ++depth;  // next node is the left child

@@ -42,9 +42,11 @@ class kd_tree {
   static_assert(
       std::is_same_v<std::remove_cv_t<Space_>, Space_>,
       "SPACE_TYPE_MUST_BE_NON-CONST_NON-VOLATILE");
-  static_assert(
-      std::is_same_v<typename Metric_::space_category, euclidean_space_tag>,
-      "ONLY_EUCLIDEAN_METRICS_ARE_SUPPORTED_BY_THIS_BUILD");
+  //! Topological metrics (metric_so2, metric_se2_squared): the tree keeps four bounds per branch
+  //! (the reference's kd_tree_node_topological) and the per-query members run
+  //! internal::nearest_search_topological on the host.
+  static constexpr bool topological =
+      !std::is_same_v<typename Metric_::space_category, euclidean_space_tag>;
 
   using plain_space_type = internal::unwrap_ref_t<Space_>;
   using space_view_type = internal::space_view<plain_space_type>;
@@ -92,7 +94,7 @@ class kd_tree {
       : space_(std::move(space)),
         metric_(),
         tree_(internal::build_flat_tree<index_type>(
-            view(), stop_condition, start_bounds, rule)) {}
+            view(), stop_condition, start_bounds, rule, topological)) {}
 
   kd_tree(kd_tree const&) = delete;
   kd_tree(kd_tree&&) = default;
@@ -115,7 +117,12 @@ class kd_tree {
         "POINT_AND_TREE_DIMS_DIFFER");
     query_view q(x);
     space_view_type s = view();
-    internal::nearest_search(tree_, s, metric_, q, visitor);
+    if constexpr (topological) {
+      internal::nearest_search_topological<tree_type, space_view_type, metric_type, query_view, V_>(
+          tree_, s, metric_, q, visitor)();
+    } else {
+      internal::nearest_search(tree_, s, metric_, q, visitor);
+    }
   }
 
   template <typename P_>
@@ -354,7 +361,7 @@ class kd_tree {
   kd_tree(space_type space, std::iostream& stream)
       : space_(std::move(space)),
         metric_(),
-        tree_(internal::read_flat_tree<tree_type>(stream)) {}
+        tree_(internal::read_flat_tree<tree_type>(stream, topological)) {}
 
   template <typename T_>
   static T_ const& unwrap(T_ const& s) {

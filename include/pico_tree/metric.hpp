@@ -4,9 +4,11 @@
 //! \details A metric provides (i) space_category, (ii) a point-to-point call
 //! operator()(begin1, end1, begin2) and (iii) a one-dimensional call
 //! operator()(x) that is the un-rooted per-axis term, so that a box distance is
-//! a sum of per-axis terms.  Only metric_l2_squared on float is accelerated by
-//! the HIP backend; the others run the host traversal.  The topological metrics
-//! of the reference (metric_so2, metric_se2_squared) are out of scope here.
+//! a sum of per-axis terms.  metric_l2_squared, metric_l1 and metric_lpinf are
+//! accelerated by the HIP backend (float and double points); the others run the host
+//! traversal: metric_lninf and the topological metrics metric_so2 / metric_se2_squared
+//! (reference metric.hpp:186-257), which also provide apply_dim_space(dim, f) to tell
+//! the search which axes wrap around (internal/flat_search.hpp, nearest_search_topological).
 
 #include <cmath>
 #include <iterator>
@@ -98,6 +100,53 @@ struct metric_lninf {
   template <typename S_>
   constexpr S_ operator()(S_ x) const {
     return std::abs(x);
+  }
+};
+
+//! Distances on the unit circle S1 = [0, 1] / 0 ~ 1 (reference metric.hpp:186-220).
+struct metric_so2 {
+  using space_category = topological_space_tag;
+
+  template <typename It1_, typename End1_, typename It2_>
+  constexpr auto operator()(It1_ a, End1_, It2_ b) const {
+    return s1_distance(*a, *b);
+  }
+
+  template <typename S_>
+  constexpr S_ operator()(S_ x) const {
+    return std::abs(x);
+  }
+
+  template <typename F_>
+  void apply_dim_space(int, F_ f) const {
+    f(one_space_s1{});
+  }
+};
+
+//! Squared distances between Euclidean motions of the plane: (x, y) in R2 and an angle in
+//! [0, 1] / 0 ~ 1 (reference metric.hpp:222-257).
+struct metric_se2_squared {
+  using space_category = topological_space_tag;
+
+  template <typename It1_, typename End1_, typename It2_>
+  constexpr auto operator()(It1_ a, End1_, It2_ b) const {
+    return internal::accumulate_terms(
+               a, a + 2, b, [](auto x, auto y) { return squared_r1_distance(x, y); }) +
+           squared_s1_distance(*(a + 2), *(b + 2));
+  }
+
+  template <typename S_>
+  constexpr S_ operator()(S_ x) const {
+    return squared(x);
+  }
+
+  template <typename F_>
+  void apply_dim_space(int dim, F_ f) const {
+    if (dim < 2) {
+      f(one_space_r1{});
+    } else {
+      f(one_space_s1{});
+    }
   }
 };
 

@@ -203,7 +203,9 @@ void* ptkref_create(scalar_t const* pts, size_t n, size_t dim, size_t max_leaf) 
 }
 
 // The same tree searched under another of the reference's metrics
-// (0 metric_l2_squared, 1 metric_l1, 2 metric_lpinf; metric.hpp:78-152).
+// (0 metric_l2_squared, 1 metric_l1, 2 metric_lpinf; metric.hpp:78-152) or built over a topological
+// space (3 metric_so2: dim 1, coordinates in [0, 1]; 4 metric_se2_squared: dim 3, the third
+// coordinate in [0, 1]; metric.hpp:186-257 -- kd_tree_node_topological, search_nearest_topological).
 void* ptkref_create_metric(scalar_t const* pts, size_t n, size_t dim,
                            size_t max_leaf, int metric) {
   if (n == 0 || dim == 0 || max_leaf == 0) return nullptr;
@@ -216,6 +218,12 @@ void* ptkref_create_metric(scalar_t const* pts, size_t n, size_t dim,
     if (metric == 2)
       return static_cast<tree_base*>(
           new tree_impl<kDim, pico_tree::metric_lpinf>(pts, n, dim, max_leaf));
+    if (metric == 3 && dim == 1)
+      return static_cast<tree_base*>(
+          new tree_impl<kDim, pico_tree::metric_so2>(pts, n, dim, max_leaf));
+    if (metric == 4 && dim == 3)
+      return static_cast<tree_base*>(
+          new tree_impl<kDim, pico_tree::metric_se2_squared>(pts, n, dim, max_leaf));
     return nullptr;
   });
 }

@@ -206,6 +206,56 @@ static int run_host(std::string const& dir) {
     dtree.search_nn(dp[5], dn);
     if (dn.distance != 0.0) return 33;
   }
+  {  // topological spaces (reference metric.hpp:186-257, kd_tree_search.hpp:115-229): host members
+    using space1 = std::vector<std::array<float, 1>>;
+    space1 p1(pts.size()), q1(qs.size());
+    for (size_t i = 0; i < pts.size(); ++i) p1[i] = {pts[i][0]};
+    for (size_t i = 0; i < qs.size(); ++i) q1[i] = {qs[i][0]};
+    pico_tree::kd_tree<space1, pico_tree::metric_so2> so2(std::cref(p1).get(), pico_tree::max_leaf_size_t(10));
+    pico_tree::kd_tree<std::reference_wrapper<space3>, pico_tree::metric_se2_squared> se2(
+        std::ref(pts), pico_tree::max_leaf_size_t(10));
+    size_t const nq = qs.size(), k = 7;
+    std::vector<neighbor> a(nq * k), b(nq * k), c(nq * k);
+    std::vector<std::uint64_t> roff(nq + 1, 0), boff(nq + 1, 0);
+    std::vector<neighbor> rflat, row;
+    std::vector<int> bflat, brow;
+    for (size_t i = 0; i < nq; ++i) {
+      so2.search_knn(q1[i], a.begin() + i * k, a.begin() + (i + 1) * k);
+      se2.search_knn(qs[i], b.begin() + i * k, b.begin() + (i + 1) * k);
+      se2.search_knn(qs[i], 1.44f, c.begin() + i * k, c.begin() + (i + 1) * k);
+      se2.search_radius(qs[i], 0.0009f, row);
+      rflat.insert(rflat.end(), row.begin(), row.end());
+      roff[i + 1] = rflat.size();
+      point3 lo = qs[i], hi = qs[i];
+      for (int d = 0; d < 3; ++d) {
+        lo[d] -= 0.02f;
+        hi[d] += 0.02f;
+      }
+      se2.search_box(lo, hi, brow);
+      bflat.insert(bflat.end(), brow.begin(), brow.end());
+      boff[i + 1] = bflat.size();
+    }
+    write_raw(dir + "/t_so2_knn.bin", a.data(), a.size());
+    write_raw(dir + "/t_se2_knn.bin", b.data(), b.size());
+    write_raw(dir + "/t_se2_aknn.bin", c.data(), c.size());
+    write_raw(dir + "/t_se2_radius_off.bin", roff.data(), roff.size());
+    write_raw(dir + "/t_se2_radius_flat.bin", rflat.data(), rflat.size());
+    write_raw(dir + "/t_se2_box_off.bin", boff.data(), boff.size());
+    write_raw(dir + "/t_se2_box_flat.bin", bflat.data(), bflat.size());
+    {  // four bounds per branch in the tree file (kd_tree_branch_double), and back
+      std::stringstream ss(std::ios::in | std::ios::out | std::ios::binary);
+      decltype(se2)::save(se2, ss);
+      std::string const bytes = ss.str();
+      write_raw(dir + "/t_se2_save.bin", bytes.data(), bytes.size());
+      auto loaded = decltype(se2)::load(std::ref(pts), ss);
+      neighbor x, y;
+      for (size_t i = 0; i < nq; i += 37) {
+        se2.search_nn(qs[i], x);
+        loaded.search_nn(qs[i], y);
+        if (x.index != y.index || x.distance != y.distance) return 34;
+      }
+    }
+  }
   std::printf("host ok\n");
   return 0;
 }

@@ -80,13 +80,42 @@ def test_host_members_match_oracle(workdir):
     assert _load(d, "save.bin", np.uint8).tobytes() == ref.save_bytes()
 
 
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
+def test_topological_metrics_match_the_compiled_reference(workdir):
+    """metric_so2 / metric_se2_squared (reference metric.hpp:186-257, search_nearest_topological
+    kd_tree_search.hpp:115-229) run on the host members of include/pico_tree; checked bit for bit
+    against the reference's own headers (oracle/_ref, kd_tree<space, metric_so2|metric_se2_squared>)."""
+    d, pts, q = workdir
+    exe = os.path.join(d, "host_only")
+    if not os.path.exists(os.path.join(d, "t_se2_knn.bin")):
+        _compile(exe, host_only=True)
+        subprocess.check_call([exe, "host", d])
+    so2 = oracle.Oracle(np.ascontiguousarray(pts[:, :1]), 10, "reference", "SO2")
+    se2 = oracle.Oracle(pts, 10, "reference", "SE2Squared")
+    assert _load(d, "t_so2_knn.bin", pt.NEIGHBOR).tobytes() == so2.search_knn(np.ascontiguousarray(q[:, :1]), K).tobytes()
+    assert _load(d, "t_se2_knn.bin", pt.NEIGHBOR).tobytes() == se2.search_knn(q, K).tobytes()
+    assert _load(d, "t_se2_aknn.bin", pt.NEIGHBOR).tobytes() == se2.search_knn(q, K, e=1.44).tobytes()
+    off, flat = se2.search_radius(q, RADIUS)
+    assert off[-1] > 0 and np.array_equal(_load(d, "t_se2_radius_off.bin", np.uint64), off)
+    assert _load(d, "t_se2_radius_flat.bin", pt.NEIGHBOR).tobytes() == flat.tobytes()
+    boff, bflat = se2.search_box(q - np.float32(0.02), q + np.float32(0.02))
+    assert np.array_equal(_load(d, "t_se2_box_off.bin", np.uint64), boff)
+    assert np.array_equal(_load(d, "t_se2_box_flat.bin", np.int32), bflat)
+    assert _load(d, "t_se2_save.bin", np.uint8).tobytes() == se2.save_bytes()
+    # wrap-around really happens in this data: some neighbours are nearer through 0 ~ 1
+    knn = _load(d, "t_so2_knn.bin", pt.NEIGHBOR).reshape(-1, K)
+    direct = np.abs(pts[knn["index"], 0] - q[:, :1])
+    assert (direct > 0.5).any()
+
+
 REF_EXAMPLES = "/root/reference/examples/kd_tree"
 
 
 @pytest.mark.skipif(not os.path.isdir(REF_EXAMPLES), reason="reference sources not present")
 @pytest.mark.parametrize("example", ["kd_tree_minimal", "kd_tree_creation", "kd_tree_custom_point_type",
                                      "kd_tree_custom_space_type", "kd_tree_custom_search_visitor",
-                                     "kd_tree_dynamic_arrays", "kd_tree_save_and_load"])
+                                     "kd_tree_dynamic_arrays", "kd_tree_save_and_load", "kd_tree_search",
+                                     "kd_tree_custom_metric"])
 def test_reference_examples_compile_unchanged(example, tmp_path):
     """Drop-in check: the reference's example programs, compiled where they lie, against
     include/pico_tree.  Only a stand-in for its pico_toolshed test helpers is ours."""
