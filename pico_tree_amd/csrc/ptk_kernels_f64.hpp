@@ -87,7 +87,14 @@ struct Metric64LInf {
 };
 
 typedef PTK_LDS uint32_t LdsU32;
-constexpr int kRing64 = 8;  // LDS ring slots per lane (12 bytes each)
+#ifndef PTK_RING64
+#define PTK_RING64 8
+#endif
+#ifndef PTK_LEAF64
+#define PTK_LEAF64 2
+#endif
+constexpr int kRing64 = PTK_RING64;  // LDS ring slots per lane (12 bytes each); a power of two
+constexpr int kLeaf64 = PTK_LEAF64;  // leaf points per memory round trip (dim <= 3)
 
 // LDS of a block: [vectors: nvec * dim doubles][ring values: S doubles][ring meta: S words], all [slot][lane].
 __host__ __device__ constexpr size_t lds64_bytes(uint32_t nvec, uint32_t dim) {
@@ -393,18 +400,25 @@ __device__ __forceinline__ void traverse64_3(const DevTree64& t, double q0, doub
       const uint32_t lv = ref & 0x7FFFFFFFu;
       const uint32_t begin = lv >> t.cbits;
       const uint32_t count = lv & t.cmask;
-      for (uint32_t j = 0; j < count; j += 2) {
-        const uint32_t pa = begin + j;
-        const uint32_t pb = pa + 1 <= last ? pa + 1 : last;  // in range even when the leaf ends at pa
-        const double* a = pts + (uint64_t)pa * 3;
-        const double* b = pts + (uint64_t)pb * 3;
-        const double ax = a[0], ay = a[1], az = a[2], bx = b[0], by = b[1], bz = b[2];
-        const int32_t ia = index[pa], ib = index[pb];
-        // internal::sum (metric.hpp:36-51) from d = 0: acc(0, x) == one(x) exactly
-        const double da = M::acc(M::acc(M::one(d_sub(q0, ax)), d_sub(q1, ay)), d_sub(q2, az));
-        const double db = M::acc(M::acc(M::one(d_sub(q0, bx)), d_sub(q1, by)), d_sub(q2, bz));
-        pol.visit(ia, da);
-        if (j + 1 < count) pol.visit(ib, db);
+      for (uint32_t j = 0; j < count; j += kLeaf64) {
+        double px[kLeaf64], py[kLeaf64], pz[kLeaf64];
+        int32_t pi[kLeaf64];
+#pragma unroll
+        for (int u = 0; u < kLeaf64; ++u) {  // every load of the round before the first use
+          const uint32_t pu = begin + j + u <= last ? begin + j + u : last;  // in range past the leaf's end too
+          const double* a = pts + (uint64_t)pu * 3;
+          px[u] = a[0];
+          py[u] = a[1];
+          pz[u] = a[2];
+          pi[u] = index[pu];
+        }
+#pragma unroll
+        for (int u = 0; u < kLeaf64; ++u) {
+          if (j + u < count) {
+            // internal::sum (metric.hpp:36-51) from d = 0: acc(0, x) == one(x) exactly
+            pol.visit(pi[u], M::acc(M::acc(M::one(d_sub(q0, px[u])), d_sub(q1, py[u])), d_sub(q2, pz[u])));
+          }
+        }
       }
     }
     for (;;) {
