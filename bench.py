@@ -61,6 +61,11 @@ def parse_args():
     ap.add_argument("--reorder", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="N > 1: weak = a full batch per GPU, strong = one batch cut into N shards")
+    ap.add_argument("--streams", type=int, default=1,
+                    help="HIP streams successive steps are issued on round-robin (single GPU only).  1 (default): one "
+                         "batch at a time, the per-kernel durations are those of an isolated call.  > 1: batches "
+                         "overlap (the handle keeps one scratch block per stream); kernel_ms then covers "
+                         "kernels that shared the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="approximate budget of the OpenMP CPU baseline sample")
@@ -208,8 +213,22 @@ def main():
     sharded = ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw,
                             lambda: torch.empty((per, k, 2), dtype=torch.int32, device=dev))
 
-    def step():
-        return sharded.step(dq)
+    n_streams = max(1, args.streams) if world == 1 else 1
+    if n_streams > 1:  # successive batches on several streams of ONE handle (per-stream scratch blocks)
+        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+        lanes = [ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw,
+                               lambda: torch.empty((per, k, 2), dtype=torch.int32, device=dev), depth=1)
+                 for _ in range(n_streams)]
+        issued = [0]
+
+        def step():
+            i = issued[0] % n_streams
+            issued[0] += 1
+            with torch.cuda.stream(streams[i]):
+                return lanes[i].step(dq)
+    else:
+        def step():
+            return sharded.step(dq)
 
     def fence():
         sharded.finish()
@@ -301,7 +320,7 @@ def main():
                                    f"({'LiDAR-like room scan' if args.cloud == 'L' else 'uniform cube'}), "
                                    f"{n} tree points / {nq} queries, knn={k}, max_leaf_size={args.leaf}, "
                                    f"sliding midpoint",
-                       "query_order": args.order, "reorder": args.reorder,
+                       "query_order": args.order, "reorder": args.reorder, "streams": n_streams,
                        "parallelism": (f"{world} x {nq} queries (one full batch per GPU), tree replicated"
                                        if weak else f"one batch of {nq} queries cut into {world} shards, "
                                                     f"tree replicated")

@@ -153,6 +153,15 @@ struct ptk_tree {
   std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
   mutable Profile profile;
   mutable Workspace ws;
+  // k-NN calls arriving on other HIP streams get a scratch block of their own (up to kExtraWs
+  // streams per handle; further ones share `ws` in stream order), so that batches issued on several
+  // streams overlap: the tail of one batch's phase 2 is a few long dependent chains with the machine
+  // mostly idle (profiles/r01n_streams.jsonl).  slot_stream[i] is the stream slot i belongs to.
+  static constexpr int kExtraWs = 3;
+  mutable Workspace extra_ws[kExtraWs];
+  mutable std::mutex slot_mutex;
+  mutable hipStream_t slot_stream[1 + kExtraWs] = {};
+  mutable bool slot_taken[1 + kExtraWs] = {};
   mutable HostIo io;
 };
 
@@ -363,9 +372,26 @@ struct Timer {
 };
 
 // One search call's view of the handle's scratch block (see Workspace).
+// The scratch block a call on stream `s` uses: the handle's main one, or -- k-NN calls only (the
+// radius capture lives in the main block) -- the one assigned to that stream.
+inline Workspace& workspace_for(const ptk_tree* t, hipStream_t s, bool per_stream) {
+  if (!per_stream) return t->ws;
+  std::lock_guard<std::mutex> lock(t->slot_mutex);
+  for (int i = 0; i <= ptk_tree::kExtraWs; ++i)
+    if (t->slot_taken[i] && t->slot_stream[i] == s) return i == 0 ? t->ws : t->extra_ws[i - 1];
+  for (int i = 0; i <= ptk_tree::kExtraWs; ++i)
+    if (!t->slot_taken[i]) {
+      t->slot_taken[i] = true;
+      t->slot_stream[i] = s;
+      return i == 0 ? t->ws : t->extra_ws[i - 1];
+    }
+  return t->ws;
+}
+
 class Scratch {
  public:
-  Scratch(const ptk_tree* t, hipStream_t s) : ws_(t->ws), lock_(t->ws.mutex), s_(s) {}
+  Scratch(const ptk_tree* t, hipStream_t s, bool per_stream = false)
+      : ws_(workspace_for(t, s, per_stream)), lock_(ws_.mutex), s_(s) {}
   ~Scratch() {
     if (!reserved_) return;
     if (ws_.done == nullptr && hipEventCreateWithFlags(&ws_.done, hipEventDisableTiming) != hipSuccess) {
@@ -977,6 +1003,11 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->ws.done) (void)hipEventDestroy(t->ws.done);
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->ws.cap_base) (void)hipFree(t->ws.cap_base);
+    for (Workspace& w : t->extra_ws) {
+      if (w.has_work) (void)hipEventSynchronize(w.done);
+      if (w.done) (void)hipEventDestroy(w.done);
+      if (w.base) (void)hipFree(w.base);
+    }
     if (t->io.d_in) (void)hipFree(t->io.d_in);
     if (t->io.d_out) (void)hipFree(t->io.d_out);
     if (t->io.stream) (void)hipStreamDestroy(t->io.stream);
@@ -1114,7 +1145,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   const bool l2 = t->metric.load() == PTK_METRIC_L2_SQUARED;
   const bool reorder = want_reorder(t, nq);
-  Scratch scratch(t, s);
+  Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
                        (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(nq) : 0));
   if (rc != PTK_OK) return rc;

@@ -481,3 +481,24 @@ def test_concurrent_host_threads_on_one_handle(trees):
     for t in threads:
         t.join()
     assert not errors, errors
+
+
+def test_batches_on_several_streams_of_one_handle(trees):
+    """k-NN calls arriving on different HIP streams get a scratch block each (up to 4 per handle; a fifth
+    stream shares the first block in stream order) and may overlap on the device; every result is checked."""
+    import torch
+    tree, ref, pts, q = trees("lidar")
+    dq = torch.from_numpy(q).cuda()
+    want1 = ref.search_knn(q, 1)
+    want9 = ref.search_knn(q, 9)
+    streams = [torch.cuda.Stream() for _ in range(5)]
+    outs = []
+    for rep in range(3):
+        for i, st in enumerate(streams):
+            k = 1 if (i + rep) % 2 == 0 else 9
+            with torch.cuda.stream(st):
+                outs.append((k, tree.search_knn(dq, k)))
+    torch.cuda.synchronize()
+    for k, got in outs:
+        want = want1 if k == 1 else want9
+        assert got.numpy().reshape(want.shape).tobytes() == want.tobytes()
