@@ -847,7 +847,7 @@ int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float rad
     int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, false, M>, smem);
     if (rc != PTK_OK) return rc;
     hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, false, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
-                       radius, inv_ratio(e), d_counts, d_offsets, d_out);
+                       radius, inv_ratio(e), d_counts, d_offsets, d_out, perm, nullptr);
   } else {
     int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, true, M>, smem);
     if (rc != PTK_OK) return rc;
@@ -860,8 +860,8 @@ int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float rad
 }
 
 template <int OVF, class M = ptk::MetricL2>
-int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e,
-                             uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
+int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
+                             float e, uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
@@ -871,8 +871,8 @@ int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, uint64_t nq, f
   int rc = allow_lds(ptk::radius_nd_capture_kernel<S, OVF, M>, smem);
   if (rc != PTK_OK) return rc;
   PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
-  hipLaunchKernelGGL((ptk::radius_nd_capture_kernel<S, OVF, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
-                     radius, inv_ratio(e), d_counts, cap);
+  hipLaunchKernelGGL((ptk::radius_nd_capture_kernel<S, OVF, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, perm,
+                     nq, radius, inv_ratio(e), d_counts, cap);
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
   return PTK_OK;
@@ -1255,8 +1255,8 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
   if (nq == 0) return PTK_OK;
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
-  const bool nd = t->dim > 3;  // the any-dimension kernels take the batch in caller order
-  const bool reorder = !nd && want_reorder(t, nq);
+  const bool nd = t->dim > 3;
+  const bool reorder = want_reorder(t, nq);  // Morton order along the first three axes, whatever the dimension
   const int metric = t->metric.load();
   Scratch scratch(t, s);
   Workspace& ws = t->ws;  // locked by `scratch` for the duration of this call
@@ -1301,7 +1301,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     }
     if (capture) {
       if (nd) {
-        PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd_capture<OVF, M>(t, d_q, nq, radius, e, d_counts, ws.cap, s))));
+        PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd_capture<OVF, M>(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s))));
       } else {
         PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_capture<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, d_counts,
                                                                                    ws.cap, s))));
@@ -1317,7 +1317,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       }
     } else if (nd) {
       PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
-                                                                 reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+                                                                 reinterpret_cast<ptk::Neighbor*>(d_out), s, perm))));
     } else {
       PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));

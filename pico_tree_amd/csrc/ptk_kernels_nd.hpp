@@ -215,10 +215,11 @@ __global__ __launch_bounds__(64) void radius_nd_kernel(
 // The count pass that also captures the rows (RadiusCapture, ptk_kernels.hpp).
 template <int S, int OVF, class M = MetricL2>
 __global__ __launch_bounds__(64) void radius_nd_capture_kernel(
-    DevTreeND t, const float* __restrict__ queries, uint64_t nq, float radius, float e_inv,
-    uint64_t* __restrict__ counts, RadiusCapture cap) {
-  const uint64_t qi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (qi >= nq) return;
+    DevTreeND t, const float* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t nq, float radius,
+    float e_inv, uint64_t* __restrict__ counts, RadiusCapture cap) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[i] : i;  // launch order only: row qi is still chain qi
   LdsFloat *q, *off;
   stage_query_nd<S>(queries, t.dim, qi, q, off);
   Record spill[OVF > 0 ? OVF : 1];

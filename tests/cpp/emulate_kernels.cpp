@@ -379,7 +379,7 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
 int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
                        uint64_t* counts, uint32_t sub_cap) {
   auto* t = static_cast<Emu*>(h);
-  if (t->metric != 0 || (t->dim > 3 && perm != nullptr)) return -3;
+  if (t->metric != 0) return -3;
   t->cap_chunks.assign(((size_t)nq + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kCapChunk, ptk::Neighbor{-1, -1.0f});
   t->cap_counters.assign(ptk::kCapSubPools * ptk::kCapCounterStride, 0u);
   t->cap_flags.assign(nq, 2);
@@ -391,7 +391,7 @@ int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float
   const float e_inv = 1.0f / e;
   if (t->dim > 3) {
     for_each_lane(nq, [&] {
-      ptk::radius_nd_capture_kernel<8, 2048>(t->dev_nd, q, nq, radius, e_inv, counts, t->cap);
+      ptk::radius_nd_capture_kernel<8, 2048>(t->dev_nd, q, perm, nq, radius, e_inv, counts, t->cap);
     }, 64);
     return 0;
   }

@@ -239,9 +239,10 @@ def test_emulated_radius_capture_any_dimension(sub_cap):
     pts, q = ds.uniform_cloud(8_000, 5, 61), ds.uniform_cloud(1_000, 5, 62)
     emu = EmulatedTree(pts, 8)
     ref = oracle.Oracle(pts, 8, "port")
-    for radius, e in ((0.03, None), (0.12, None), (0.1, 1.5)):
+    perm = np.random.default_rng(5).permutation(len(q)).astype(np.uint32)  # any launch order, same rows
+    for radius, e, pm in ((0.03, None, None), (0.12, None, perm), (0.1, 1.5, perm)):
         want_off, want = ref.search_radius(q, radius, e=e)
-        off, got, redone = emu.search_radius_captured(q, radius, e=e, sub_cap=sub_cap)
+        off, got, redone = emu.search_radius_captured(q, radius, e=e, perm=pm, sub_cap=sub_cap)
         assert np.array_equal(off, want_off) and got.tobytes() == want.tobytes()
         long_rows = int((np.diff(want_off.astype(np.int64)) > 31).sum())
         assert redone == (0 if sub_cap == 1024 else long_rows if sub_cap == 0 else redone) and redone <= long_rows
