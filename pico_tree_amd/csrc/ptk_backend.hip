@@ -1508,19 +1508,28 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   uint64_t total = 0;
   const uint32_t blocks = (uint32_t)((nb + 63) / 64);
   const auto* ranges = static_cast<const uint2*>(t->d_ranges);
-  if (he == hipSuccess) {
+  // Boxes in Morton order of their min corners (launch order only; rows stay in the caller's order).
+  Scratch scratch(t, nullptr);
+  uint32_t* perm = nullptr;
+  if (he == hipSuccess && want_reorder(t, nb)) {
+    rc = scratch.reserve(permutation_scratch_bytes(nb));
+    if (rc == PTK_OK) rc = make_permutation(t, d_mn, nb, nullptr, scratch, &perm);
+  }
+  if (he == hipSuccess && rc == PTK_OK) {
+    Timer count_timer(t, nullptr);
     PTK_WITH_OVF(16, ([&]() -> int {
                    if (t->dim > 3) {
                      int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, false>, nd_smem);
                      if (lrc != PTK_OK) return lrc;
                      hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, false>), dim3(blocks), dim3(64), nd_smem, nullptr,
-                                        t->dev_nd, ranges, d_root, d_mn, d_mx, nb, d_c, nullptr, nullptr);
+                                        t->dev_nd, ranges, d_root, d_mn, d_mx, nb, d_c, nullptr, nullptr, perm);
                      return PTK_OK;
                    }
                    hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
-                                      t->dev, ranges, root, d_mn, d_mx, t->dim, nb, d_c, nullptr, nullptr);
+                                      t->dev, ranges, root, d_mn, d_mx, t->dim, nb, d_c, nullptr, nullptr, perm);
                    return PTK_OK;
                  }()));
+    count_timer.stop(0, nb);
     if (rc == PTK_OK) {
       size_t tmp_bytes = 0;
       he = rocprim::exclusive_scan(nullptr, tmp_bytes, d_c, d_o, (uint64_t)0, nb + 1, rocprim::plus<uint64_t>(),
@@ -1535,18 +1544,20 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
         he = hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * 4);
       }
       if (he == hipSuccess) {
+        Timer fill_timer(t, nullptr);
         PTK_WITH_OVF(16, ([&]() -> int {
                        if (t->dim > 3) {
                          int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, true>, nd_smem);
                          if (lrc != PTK_OK) return lrc;
                          hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, true>), dim3(blocks), dim3(64), nd_smem, nullptr,
-                                            t->dev_nd, ranges, d_root, d_mn, d_mx, nb, nullptr, d_o, d_out);
+                                            t->dev_nd, ranges, d_root, d_mn, d_mx, nb, nullptr, d_o, d_out, perm);
                          return PTK_OK;
                        }
                        hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
-                                          t->dev, ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_o, d_out);
+                                          t->dev, ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_o, d_out, perm);
                        return PTK_OK;
                      }()));
+        fill_timer.stop(3, 0);
       }
       if (he == hipSuccess && rc == PTK_OK) {
         *out = static_cast<int32_t*>(std::malloc(std::max<uint64_t>(total, 1) * 4));

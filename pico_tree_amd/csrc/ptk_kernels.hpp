@@ -1289,9 +1289,10 @@ template <int S, int OVF, bool FILL>
 __global__ __launch_bounds__(64) void box_kernel(
     DevTree t, const uint2* __restrict__ ranges, BoxState root, const float* __restrict__ mins,
     const float* __restrict__ maxs, uint32_t dim, uint64_t nb, uint64_t* __restrict__ counts,
-    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out) {
-  const uint64_t bi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (bi >= nb) return;
+    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out, const uint32_t* __restrict__ perm = nullptr) {
+  const uint64_t li = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (li >= nb) return;
+  const uint64_t bi = perm ? perm[li] : li;  // launch order only (boxes sorted by their min corner)
   const float inf = __uint_as_float(0x7F800000u);
   float qn0, qn1, qn2, qx0, qx1, qx2;
   load_query(mins, dim, bi, qn0, qn1, qn2);

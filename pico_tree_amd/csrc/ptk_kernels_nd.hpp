@@ -252,9 +252,11 @@ template <int S, int OVF, bool FILL>
 __global__ __launch_bounds__(64) void box_nd_kernel(
     DevTreeND t, const uint2* __restrict__ ranges, const float* __restrict__ root,
     const float* __restrict__ mins, const float* __restrict__ maxs, uint64_t nb,
-    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, int32_t* __restrict__ out) {
-  const uint64_t bi = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (bi >= nb) return;
+    uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, int32_t* __restrict__ out,
+    const uint32_t* __restrict__ perm = nullptr) {
+  const uint64_t li = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (li >= nb) return;
+  const uint64_t bi = perm ? perm[li] : li;
   const uint32_t dim = t.dim;
   LdsFloat* base = (LdsFloat*)(ptk_smem + (size_t)S * 64 * 8);
   LdsFloat* qn = base + threadIdx.x;
