@@ -226,6 +226,16 @@ int ptk_search_radius(const ptk_tree* tree, const float* queries, uint64_t nq,
  * (closed), in reference traversal order. */
 int ptk_search_box(const ptk_tree* tree, const float* mins, const float* maxs,
                    uint64_t nb, uint64_t* offsets, int32_t** out);
+/* Device forms, asynchronous on `stream`, as ptk_search_radius_*_device: the
+ * count pass, a scan of the counts by the caller (d_offsets: nb + 1 entries),
+ * the fill pass.  d_mins / d_maxs must not change between the two calls. */
+int ptk_search_box_count_device(const ptk_tree* tree, const float* d_mins,
+                                const float* d_maxs, uint64_t nb,
+                                uint64_t* d_counts, void* stream);
+int ptk_search_box_fill_device(const ptk_tree* tree, const float* d_mins,
+                               const float* d_maxs, uint64_t nb,
+                               const uint64_t* d_offsets, int32_t* d_out,
+                               void* stream);
 
 void ptk_free(void* p);
 

@@ -100,6 +100,8 @@ _SIGNATURES = {
                                   POINTER(c_void_p)]),
     "ptk_search_box": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p,
                                POINTER(c_void_p)]),
+    "ptk_search_box_count_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
+    "ptk_search_box_fill_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
     "ptk_free": (None, [c_void_p]),
     "ptk_tree64_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_int32, POINTER(c_void_p)]),
     "ptk_tree64_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
@@ -541,6 +543,30 @@ class KdTree:
             return DArray(offsets, flat)
         nns._assign(offsets, flat)
         return nns
+
+    def search_box_device(self, mins, maxs):
+        """Device form of :meth:`search_box`: ``mins`` / ``maxs`` are float32 ``(nbox, sdim)`` CUDA tensors; returns
+        (offsets int64 tensor [nbox + 1], indices int32 tensor [total]) on the current torch stream."""
+        import torch
+        self._float32_only("search_box_device()")
+        for a in (mins, maxs):
+            if a.dtype != torch.float32 or a.dim() != 2 or a.shape[1] != self._sdim or not a.is_cuda \
+                    or not a.is_contiguous():
+                raise ValueError("mins / maxs must be contiguous float32 (nbox, sdim) CUDA tensors")
+        if mins.shape != maxs.shape:
+            raise ValueError("query min and max don't have equal size")
+        nb = mins.shape[0]
+        lib = _load()
+        stream = torch.cuda.current_stream(mins.device).cuda_stream
+        counts = torch.zeros(nb + 1, dtype=torch.int64, device=mins.device)
+        _check(lib.ptk_search_box_count_device(self._h, mins.data_ptr(), maxs.data_ptr(), nb, counts.data_ptr(), stream))
+        offsets = torch.zeros(nb + 1, dtype=torch.int64, device=mins.device)
+        offsets[1:] = torch.cumsum(counts[:nb], 0)
+        total = int(offsets[-1].item())
+        out = torch.empty(max(total, 1), dtype=torch.int32, device=mins.device)
+        _check(lib.ptk_search_box_fill_device(self._h, mins.data_ptr(), maxs.data_ptr(), nb, offsets.data_ptr(),
+                                              out.data_ptr(), stream))
+        return offsets, out[:total]
 
     def search_radius_device(self, q, radius: float, e: float = 1.0, sort: bool = False):
         """Device form: returns (offsets int64 tensor [nq + 1], raw int32 tensor [total, 2])."""

@@ -1464,6 +1464,94 @@ int ptk_search_radius(const ptk_tree* t, const float* q, uint64_t nq, float radi
   return rc;
 }
 
+// One pass of the box search over device buffers: count (fill == false: d_counts[i] = hits of box i)
+// or fill (d_offsets = exclusive scan of the counts; row i of d_out in reference traversal order).
+static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_mx, uint64_t nb, bool fill,
+                           uint64_t* d_counts, const uint64_t* d_offsets, int32_t* d_out, hipStream_t s) {
+  int rc = check_search(t, d_mn, nb);
+  if (rc != PTK_OK) return rc;
+  if (nb > 0 && d_mx == nullptr) return fail(PTK_ERR_INVALID, "null box buffer");
+  const size_t nd_smem = (size_t)16 * 64 * 8 + (size_t)4 * t->dim * 64 * 4;
+  if (t->dim > 3 && nd_smem > kMaxLdsBytes)
+    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device box search", t->dim);
+  if (nb == 0) return PTK_OK;
+  if (nb >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more boxes are not supported");
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  ptk::BoxState root{0, 0, 0, 0, 0, 0};
+  {
+    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
+    for (uint32_t d = 0; d < t->dim && d < 3; ++d) {  // dim > 3 hands its root box over in scratch
+      mn[d] = t->root_min[d];
+      mx[d] = t->root_max[d];
+    }
+    root = ptk::BoxState{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
+  }
+  // Boxes in Morton order of their min corners (launch order only; rows stay in the caller's order).
+  const bool reorder = want_reorder(t, nb);
+  Scratch scratch(t, s);
+  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nb) : 0) + (size_t)2 * t->dim * sizeof(float) + 512);
+  if (rc != PTK_OK) return rc;
+  float* d_root = nullptr;
+  if (t->dim > 3) {  // the root box of the any-dimension kernel: min[dim], max[dim]
+    d_root = scratch.take<float>((size_t)2 * t->dim);
+    if (d_root == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
+    PTK_HIP(hipMemcpyAsync(d_root, t->root_min.data(), t->dim * sizeof(float), hipMemcpyHostToDevice, s));
+    PTK_HIP(hipMemcpyAsync(d_root + t->dim, t->root_max.data(), t->dim * sizeof(float), hipMemcpyHostToDevice, s));
+  }
+  uint32_t* perm = nullptr;
+  if (reorder) {
+    rc = make_permutation(t, d_mn, nb, s, scratch, &perm);
+    if (rc != PTK_OK) return rc;
+  }
+  const uint32_t blocks = (uint32_t)((nb + 63) / 64);
+  const auto* ranges = static_cast<const uint2*>(t->d_ranges);
+  Timer timer(t, s);
+  if (!fill) {
+    PTK_WITH_OVF(16, ([&]() -> int {
+                   if (t->dim > 3) {
+                     int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, false>, nd_smem);
+                     if (lrc != PTK_OK) return lrc;
+                     hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, false>), dim3(blocks), dim3(64), nd_smem, s, t->dev_nd,
+                                        ranges, d_root, d_mn, d_mx, nb, d_counts, nullptr, nullptr, perm);
+                     return PTK_OK;
+                   }
+                   hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
+                                      ranges, root, d_mn, d_mx, t->dim, nb, d_counts, nullptr, nullptr, perm);
+                   return PTK_OK;
+                 }()));
+  } else {
+    PTK_WITH_OVF(16, ([&]() -> int {
+                   if (t->dim > 3) {
+                     int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, true>, nd_smem);
+                     if (lrc != PTK_OK) return lrc;
+                     hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, true>), dim3(blocks), dim3(64), nd_smem, s, t->dev_nd,
+                                        ranges, d_root, d_mn, d_mx, nb, nullptr, d_offsets, d_out, perm);
+                     return PTK_OK;
+                   }
+                   hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
+                                      ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_offsets, d_out, perm);
+                   return PTK_OK;
+                 }()));
+  }
+  if (rc != PTK_OK) return rc;
+  PTK_HIP(hipGetLastError());
+  timer.stop(fill ? 3 : 0, fill ? 0 : nb);
+  return PTK_OK;
+}
+
+int ptk_search_box_count_device(const ptk_tree* t, const float* d_mins, const float* d_maxs, uint64_t nb,
+                                uint64_t* d_counts, void* stream) {
+  if (nb > 0 && d_counts == nullptr) return fail(PTK_ERR_INVALID, "null counts buffer");
+  return box_pass_device(t, d_mins, d_maxs, nb, false, d_counts, nullptr, nullptr, static_cast<hipStream_t>(stream));
+}
+
+int ptk_search_box_fill_device(const ptk_tree* t, const float* d_mins, const float* d_maxs, uint64_t nb,
+                               const uint64_t* d_offsets, int32_t* d_out, void* stream) {
+  if (nb > 0 && (d_offsets == nullptr || d_out == nullptr)) return fail(PTK_ERR_INVALID, "null offsets / output buffer");
+  return box_pass_device(t, d_mins, d_maxs, nb, true, nullptr, d_offsets, d_out, static_cast<hipStream_t>(stream));
+}
+
 int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint64_t nb, uint64_t* offsets,
                    int32_t** out) {
   if (out == nullptr || offsets == nullptr) return fail(PTK_ERR_INVALID, "null output pointer");
@@ -1471,34 +1559,16 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   int rc = check_search(t, mins, nb);
   if (rc != PTK_OK) return rc;
   if (nb > 0 && maxs == nullptr) return fail(PTK_ERR_INVALID, "null box buffer");
-  const size_t nd_smem = (size_t)16 * 64 * 8 + (size_t)4 * t->dim * 64 * 4;
-  if (t->dim > 3 && nd_smem > kMaxLdsBytes)
-    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device box search", t->dim);
   offsets[0] = 0;
   if (nb == 0) return PTK_OK;
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
-  ptk::BoxState root{0, 0, 0, 0, 0, 0};
-  {
-    float mn[3] = {0, 0, 0}, mx[3] = {0, 0, 0};
-    for (uint32_t d = 0; d < t->dim && d < 3; ++d) {  // dim > 3 hands its root box over in d_root
-      mn[d] = t->root_min[d];
-      mx[d] = t->root_max[d];
-    }
-    root = ptk::BoxState{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
-  }
-  float *d_mn = nullptr, *d_mx = nullptr, *d_root = nullptr;
+  float *d_mn = nullptr, *d_mx = nullptr;
   uint64_t *d_c = nullptr, *d_o = nullptr;
   int32_t* d_out = nullptr;
   void* tmp = nullptr;
   const size_t bbytes = (size_t)nb * t->dim * sizeof(float);
   hipError_t he = hipMalloc((void**)&d_mn, bbytes);
-  if (he == hipSuccess && t->dim > 3) {  // the root box of the any-dimension kernel: min[dim], max[dim]
-    he = hipMalloc((void**)&d_root, (size_t)2 * t->dim * sizeof(float));
-    if (he == hipSuccess) he = hipMemcpy(d_root, t->root_min.data(), t->dim * sizeof(float), hipMemcpyHostToDevice);
-    if (he == hipSuccess)
-      he = hipMemcpy(d_root + t->dim, t->root_max.data(), t->dim * sizeof(float), hipMemcpyHostToDevice);
-  }
   if (he == hipSuccess) he = hipMalloc((void**)&d_mx, bbytes);
   if (he == hipSuccess) he = hipMalloc((void**)&d_c, (nb + 1) * 8);
   if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nb + 1) * 8);
@@ -1506,30 +1576,8 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   if (he == hipSuccess) he = hipMemcpy(d_mn, mins, bbytes, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(d_mx, maxs, bbytes, hipMemcpyHostToDevice);
   uint64_t total = 0;
-  const uint32_t blocks = (uint32_t)((nb + 63) / 64);
-  const auto* ranges = static_cast<const uint2*>(t->d_ranges);
-  // Boxes in Morton order of their min corners (launch order only; rows stay in the caller's order).
-  Scratch scratch(t, nullptr);
-  uint32_t* perm = nullptr;
-  if (he == hipSuccess && want_reorder(t, nb)) {
-    rc = scratch.reserve(permutation_scratch_bytes(nb));
-    if (rc == PTK_OK) rc = make_permutation(t, d_mn, nb, nullptr, scratch, &perm);
-  }
-  if (he == hipSuccess && rc == PTK_OK) {
-    Timer count_timer(t, nullptr);
-    PTK_WITH_OVF(16, ([&]() -> int {
-                   if (t->dim > 3) {
-                     int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, false>, nd_smem);
-                     if (lrc != PTK_OK) return lrc;
-                     hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, false>), dim3(blocks), dim3(64), nd_smem, nullptr,
-                                        t->dev_nd, ranges, d_root, d_mn, d_mx, nb, d_c, nullptr, nullptr, perm);
-                     return PTK_OK;
-                   }
-                   hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
-                                      t->dev, ranges, root, d_mn, d_mx, t->dim, nb, d_c, nullptr, nullptr, perm);
-                   return PTK_OK;
-                 }()));
-    count_timer.stop(0, nb);
+  if (he == hipSuccess) {
+    rc = ptk_search_box_count_device(t, d_mn, d_mx, nb, d_c, nullptr);
     if (rc == PTK_OK) {
       size_t tmp_bytes = 0;
       he = rocprim::exclusive_scan(nullptr, tmp_bytes, d_c, d_o, (uint64_t)0, nb + 1, rocprim::plus<uint64_t>(),
@@ -1543,22 +1591,7 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
         total = offsets[nb];
         he = hipMalloc((void**)&d_out, std::max<uint64_t>(total, 1) * 4);
       }
-      if (he == hipSuccess) {
-        Timer fill_timer(t, nullptr);
-        PTK_WITH_OVF(16, ([&]() -> int {
-                       if (t->dim > 3) {
-                         int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, true>, nd_smem);
-                         if (lrc != PTK_OK) return lrc;
-                         hipLaunchKernelGGL((ptk::box_nd_kernel<16, OVF, true>), dim3(blocks), dim3(64), nd_smem, nullptr,
-                                            t->dev_nd, ranges, d_root, d_mn, d_mx, nb, nullptr, d_o, d_out, perm);
-                         return PTK_OK;
-                       }
-                       hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true>), dim3(blocks), dim3(64), 16 * 64 * 8, nullptr,
-                                          t->dev, ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_o, d_out, perm);
-                       return PTK_OK;
-                     }()));
-        fill_timer.stop(3, 0);
-      }
+      if (he == hipSuccess) rc = ptk_search_box_fill_device(t, d_mn, d_mx, nb, d_o, d_out, nullptr);
       if (he == hipSuccess && rc == PTK_OK) {
         *out = static_cast<int32_t*>(std::malloc(std::max<uint64_t>(total, 1) * 4));
         if (*out == nullptr) {
@@ -1572,7 +1605,6 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
   if (tmp) (void)hipFree(tmp);
   if (d_mn) (void)hipFree(d_mn);
   if (d_mx) (void)hipFree(d_mx);
-  if (d_root) (void)hipFree(d_root);
   if (d_c) (void)hipFree(d_c);
   if (d_o) (void)hipFree(d_o);
   if (d_out) (void)hipFree(d_out);

@@ -502,3 +502,20 @@ def test_batches_on_several_streams_of_one_handle(trees):
     for k, got in outs:
         want = want1 if k == 1 else want9
         assert got.numpy().reshape(want.shape).tobytes() == want.tobytes()
+
+
+@pytest.mark.parametrize("dim", [2, 3, 6])
+def test_box_search_on_device_buffers(gpu, dim):
+    """ptk_search_box_count_device / _fill_device: boxes and rows stay on the device."""
+    import torch
+    pts, q = ds.uniform_cloud(40_000, dim, 71), ds.uniform_cloud(12_000, dim, 72)
+    half = np.float32(0.5 * (300.0 / len(pts)) ** (1.0 / dim))
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    ref = oracle.Oracle(pts, 10, "port")
+    want_off, want = ref.search_box(q - half, q + half)
+    for mode in (pt.REORDER_AUTO, pt.REORDER_OFF):
+        tree.set_reorder(mode)
+        off, rows = tree.search_box_device(torch.from_numpy(q - half).cuda(), torch.from_numpy(q + half).cuda())
+        torch.cuda.synchronize()
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off) and want_off[-1] > len(q)
+        assert np.array_equal(rows.cpu().numpy(), want)

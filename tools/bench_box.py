@@ -24,6 +24,15 @@ def main():
         print(json.dumps({"cloud": cloud, "boxes": len(q), "half_width": half, "hits_per_box": round(len(r.flat) / len(q), 1),
                           "Mboxes_s_end_to_end": round(len(q) / dt / 1e6, 1), "ms": round(dt * 1e3, 1),
                           "kernel_ms": round(prof["search_ms"], 2), "other_ms": round(prof["other_ms"], 2)}), flush=True)
+        import torch
+        dmn, dmx = torch.from_numpy(q - np.float32(half)).cuda(), torch.from_numpy(q + np.float32(half)).cuda()
+        tree.search_box_device(dmn, dmx); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        off, rows = tree.search_box_device(dmn, dmx)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        print(json.dumps({"cloud": cloud, "form": "device buffers", "Mboxes_s": round(len(q) / dt / 1e6, 1),
+                          "ms": round(dt * 1e3, 2), "rows_equal": bool(np.array_equal(rows.cpu().numpy(), r.flat))}), flush=True)
         tree.close()
 
 if __name__ == "__main__":
