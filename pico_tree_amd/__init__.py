@@ -178,6 +178,32 @@ class Metric(enum.Enum):
 _PTK_METRIC = {Metric.L2Squared: 0, Metric.L1: 1, Metric.LPInf: 2}  # PTK_METRIC_* of ptk.h
 
 
+class _LibraryBuffer:
+    """Owner of a result buffer malloc'ed by libptk: frees it (``ptk_free``) when the last numpy view
+    of it is gone."""
+
+    def __init__(self, lib, ptr):
+        self._lib, self._ptr = lib, ptr
+
+    def __del__(self):
+        try:
+            self._lib.ptk_free(self._ptr)
+        except Exception:
+            pass
+
+
+def _adopt(lib, ptr: c_void_p, count: int, dtype) -> np.ndarray:
+    """The library's ragged result as a numpy array WITHOUT copying it (a radius batch of BASELINE
+    config 3 is 6 GB of rows): the array keeps the buffer alive through a ``_LibraryBuffer``."""
+    dtype = np.dtype(dtype)
+    if count == 0 or not ptr.value:
+        lib.ptk_free(ptr)
+        return np.empty(0, dtype=dtype)
+    raw = (ctypes.c_char * (count * dtype.itemsize)).from_address(ptr.value)
+    raw._owner = _LibraryBuffer(lib, ptr)  # the ctypes object is the base of the array below
+    return np.frombuffer(raw, dtype=dtype, count=count)
+
+
 def _is_torch(x) -> bool:
     return type(x).__module__.startswith("torch") and hasattr(x, "data_ptr")
 
@@ -504,11 +530,7 @@ class KdTree:
         _check(self._fn("ptk_search_radius")(self._h, q.ctypes.data, nq, self._real(radius),
                                              self._real(e), int(bool(sort)), offsets.ctypes.data,
                                              byref(rows)))
-        total = int(offsets[-1])
-        flat = np.empty(total, dtype=self._neighbor)
-        if total:
-            ctypes.memmove(flat.ctypes.data, rows.value, total * self._neighbor.itemsize)
-        lib.ptk_free(rows)
+        flat = _adopt(lib, rows, int(offsets[-1]), self._neighbor)
         if nns is None:
             return DArray(offsets, flat)
         nns._assign(offsets, flat)
@@ -534,11 +556,7 @@ class KdTree:
         lib = _load()
         _check(self._fn("ptk_search_box")(self._h, mins.ctypes.data, maxs.ctypes.data, nb, offsets.ctypes.data,
                                           byref(rows)))
-        total = int(offsets[-1])
-        flat = np.empty(total, dtype=np.int32)
-        if total:
-            ctypes.memmove(flat.ctypes.data, rows.value, total * 4)
-        lib.ptk_free(rows)
+        flat = _adopt(lib, rows, int(offsets[-1]), np.int32)
         if nns is None:
             return DArray(offsets, flat)
         nns._assign(offsets, flat)
