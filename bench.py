@@ -66,6 +66,7 @@ def parse_args():
                          "batch at a time, the per-kernel durations are those of an isolated call.  > 1: batches "
                          "overlap (the handle keeps one scratch block per stream); kernel_ms then covers "
                          "kernels that shared the GPU")
+    ap.add_argument("--no-pipelined", action="store_true", help="skip the two-streams context measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0,
                     help="approximate budget of the OpenMP CPU baseline sample")
@@ -255,6 +256,26 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_queries / (elapsed / args.steps) / 1e6
 
+    # Context, never `value`: the same batches with two in flight on two HIP streams of the same handle
+    # ("Pipelined batches").  Single GPU, default stream count only.
+    pipelined = None
+    if world == 1 and n_streams == 1 and not args.no_pipelined:
+        two = [torch.cuda.Stream(device=dev) for _ in range(2)]
+        outs2 = [torch.empty((per, k, 2), dtype=torch.int32, device=dev) for _ in range(2)]
+
+        def run2(steps):
+            for i in range(steps):
+                with torch.cuda.stream(two[i % 2]):
+                    tree.search_knn(dq, k, outs2[i % 2])
+            torch.cuda.synchronize()
+        run2(2 * max(1, args.warmup))
+        t0 = time.perf_counter()
+        run2(args.steps)
+        dt = time.perf_counter() - t0
+        pipelined = {"streams": 2, "value": round(total_queries * args.steps / dt / 1e6, 3), "unit": "Mqueries/s",
+                     "ms_per_step": round(dt / args.steps * 1e3, 4),
+                     "rows_equal_single_stream": bool(torch.equal(outs2[(args.steps - 1) % 2], out))}
+
     result = None
     if rank == 0:
         import oracle
@@ -331,6 +352,7 @@ def main():
                        "host_build_upload_s": round(build_s, 2)},
             "parity_sample_ok": parity_ok,
             "roofline": roofline,
+            "pipelined": pipelined,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
