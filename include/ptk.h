@@ -340,6 +340,11 @@ typedef struct ptk_profile {
 } ptk_profile;
 int ptk_profile_enable(ptk_tree* tree, int on);
 int ptk_profile_get(const ptk_tree* tree, ptk_profile* out, int reset);
+/* Counters of the last two-phase k = 1 search on the handle's default scratch block (synchronises
+ * the device): counts[0] = queries that needed phase 2, [1] = queries phase 2 handed to the
+ * cooperative search, [2] = queries that search could not certify (redone by the reference
+ * traversal from the root), [3] = queries of the classes dealt across wavefronts. */
+int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -125,6 +125,7 @@ _SIGNATURES = {
                                              c_void_p]),
     "ptk_profile_enable": (c_int, [c_void_p, c_int]),
     "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
+    "ptk_debug_knn1_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
 }
 
 #: Every symbol include/ptk.h declares; tests check the library exports them all.
@@ -458,6 +459,13 @@ class KdTree:
         p = _Profile()
         _check(lib.ptk_profile_get(self._h, byref(p), int(reset)))
         return {name: getattr(p, name) for name, _ in _Profile._fields_}
+
+    def knn1_counts(self) -> dict:
+        """Counters of the last two-phase k = 1 search (``ptk_debug_knn1_counts``)."""
+        self._float32_only("knn1_counts()")
+        c = (c_uint32 * 4)()
+        _check(_load().ptk_debug_knn1_counts(self._h, c))
+        return {"phase2": int(c[0]), "cooperative": int(c[1]), "redone": int(c[2]), "dealt": int(c[3])}
 
     # -- k nearest neighbours ------------------------------------------------------------
     def search_knn(self, pts, k: int, *args):

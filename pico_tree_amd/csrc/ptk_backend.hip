@@ -96,6 +96,7 @@ struct Workspace {
   hipStream_t last_stream = nullptr;
   hipEvent_t done = nullptr;
   bool has_work = false;
+  const uint32_t* last_meta = nullptr;  // Cont::meta of the last two-phase k = 1 search (ptk_debug_knn1_counts)
 
   // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
   // it must survive until the fill pass of the same batch while other searches reuse `base`.
@@ -423,6 +424,7 @@ class Scratch {
     reserved_ = true;
     return PTK_OK;
   }
+  void note_meta(const uint32_t* meta) { ws_.last_meta = meta; }
   template <class T>
   T* take(size_t count) {
     const size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
@@ -686,11 +688,13 @@ int pack_queries(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint
   return PTK_OK;
 }
 
-// PTK_TIERS="60:4" (default): the first 60 per mille of the ranked classes at 4 lanes per wave.
-ptk::TierSpec parse_tiers() {
+// PTK_TIERS="60:4": the first 60 per mille of the ranked classes at 4 lanes per wave (the default
+// when phase 2 runs every query to its end; with the cap the long chains go to the cooperative
+// search and there is no narrow tier unless asked for).
+ptk::TierSpec parse_tiers(const char* fallback) {
   ptk::TierSpec t{};
   const char* v = std::getenv("PTK_TIERS");
-  std::string spec = v ? v : "60:4";
+  std::string spec = v ? v : fallback;
   size_t pos = 0;
   for (uint32_t i = 0; i < ptk::kMaxTiers && pos < spec.size(); ++i) {
     unsigned pm = 0, lanes = 0;
@@ -714,7 +718,27 @@ size_t class_sort_tmp_bytes(uint64_t nq) {
 
 size_t two_phase_scratch_bytes(uint64_t nq) {
   return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 4 * nq +
-         2 * (nq * 4) + 64 + class_sort_tmp_bytes(nq);
+         2 * (nq * 4) + 2 * (nq * 4) + 64 + class_sort_tmp_bytes(nq);
+}
+
+// Far children a query may enter in phase 2 before it is handed to the cooperative search
+// (PTK_P2_CAP; 0 = phase 2 runs every query to its end).  Exact searches only: the argument that
+// makes the cooperative result the reference's (ptk_kernels.hpp, knn1_coop_kernel) needs e = 1.
+uint32_t phase2_cap(float e) {
+  if (e != 1.0f) return 0;
+  const int cap = env_int("PTK_P2_CAP", 64);
+  return cap < 0 ? 0u : (uint32_t)cap;
+}
+
+template <int G, int POOL>
+int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
+                     const uint32_t* heavy_list, uint32_t* redo_list, hipStream_t s) {
+  constexpr size_t smem = (size_t)(64 / G) * (6 * POOL + 1) * 4;
+  const int waves = std::max(1, env_int("PTK_COOP_WAVES", 4096));
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, POOL>), dim3(waves), dim3(64), smem, s, t->dev, qs, d_out, cont,
+                     heavy_list, redo_list);
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
 }
 
 // UNIFORM1: phase 1 with the wave-uniform prefix, which also packs the launch-order records (the
@@ -747,17 +771,22 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   void* tmp = scratch.take<char>(tmp_bytes);
   if (!cont.rec || !cont.best || !cont.key || !key_out || !cont.ids || !ids_out || !cont.meta || !tmp)
     return fail(PTK_ERR_NOMEM, "scratch block too small");
+  uint32_t* heavy_list = scratch.take<uint32_t>(nq);
+  uint32_t* redo_list = scratch.take<uint32_t>(nq);
+  if (!heavy_list || !redo_list) return fail(PTK_ERR_NOMEM, "scratch block too small");
+  scratch.note_meta(cont.meta);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
+  const uint32_t cap = phase2_cap(e);
   // Narrow tiers at the head of the ranked classes: "permille:lanes,..." (cumulative marks).  The
   // grid has room for nq / 64 extra waves there; the meta kernel cuts the tiers to what fits.
-  ptk::TierSpec tiers = parse_tiers();
+  ptk::TierSpec tiers = parse_tiers(cap ? "" : "60:4");
   const uint32_t extra_waves = tiers.permille[0] == 0 ? 0u : (uint32_t)(nq / 64) + 2u;
   {
     Timer timer(t, s);
     if (UNIFORM1) {
       hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
-                         e_inv, d_out, cont, (uint32_t)env_int("PTK_DEBUG_PHASE1", 0), d_q, t->dim, perm, qs);
+                         e_inv, d_out, cont, d_q, t->dim, perm, qs);
     } else {
       hipLaunchKernelGGL((ptk::knn1_phase1_kernel<32, OVF, LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs,
                          nq, e_inv, d_out, cont);
@@ -775,11 +804,24 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   {
     Timer timer(t, s);
     hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1 + extra_waves), dim3(64),
-                       (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out,
-                       (uint32_t)env_int("PTK_DEBUG_PHASE2", 0));
+                       (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out, cap, heavy_list);
     timer.stop(3, 0);
   }
   PTK_HIP(hipGetLastError());
+  if (cap) {  // the queries phase 2 gave up on: G lanes per query, then whatever that could not certify
+    Timer timer(t, s);
+    switch (env_int("PTK_COOP_G", 16)) {
+      case 8: rc = launch_knn1_coop<8, 96>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
+      case 32: rc = launch_knn1_coop<32, 192>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
+      case 64: rc = launch_knn1_coop<64, 256>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
+      default: rc = launch_knn1_coop<16, 128>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
+    }
+    if (rc != PTK_OK) return rc;
+    hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), (size_t)S2 * 64 * 8, s, t->dev,
+                       qs, e_inv, d_out, cont, redo_list);
+    PTK_HIP(hipGetLastError());
+    timer.stop(3, 0);
+  }
   return PTK_OK;
 }
 
@@ -1617,6 +1659,22 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
 }
 
 void ptk_free(void* p) { std::free(p); }
+
+int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
+  if (t == nullptr || counts == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (t->device < 0) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
+  DeviceGuard guard(t->device);
+  std::lock_guard<std::mutex> lock(t->ws.mutex);
+  if (t->ws.last_meta == nullptr) return fail(PTK_ERR_INVALID, "no two-phase k = 1 search has run on this handle");
+  uint32_t meta[ptk::kMetaWords];
+  PTK_HIP(hipDeviceSynchronize());
+  PTK_HIP(hipMemcpy(meta, t->ws.last_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  counts[0] = meta[0];
+  counts[1] = meta[ptk::kMetaHeavy];
+  counts[2] = meta[ptk::kMetaRedo];
+  counts[3] = meta[1];
+  return PTK_OK;
+}
 
 int ptk_profile_enable(ptk_tree* t, int on) {
   if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");

@@ -114,6 +114,17 @@ __device__ __forceinline__ Neighbor unpack_neighbor(unsigned long long w) {
   return n;
 }
 
+// min() on a 32-bit LDS word shared by the lanes of a wavefront (ds_min_u32).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lds_min_u32(PTK_LDS uint32_t* p, uint32_t v) {
+  __hip_atomic_fetch_min((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#else
+inline void lds_min_u32(uint32_t* p, uint32_t v) {
+  if (v < *p) *p = v;
+}
+#endif
+
 __device__ __forceinline__ float f_add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float f_sub(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float f_mul(float a, float b) { return __fmul_rn(a, b); }
@@ -460,13 +471,16 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
 // ---- the traversal ----------------------------------------------------------------
 // RESUME: the stack already holds the pending records of a finished first descent (phase 2
 // of the two-phase k = 1 search): start by unwinding instead of descending from the root.
-template <int LEAFB, bool RESUME = false, class M = MetricL2, class Policy, class StackT>
-__device__ __forceinline__ void traverse(
-    const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st) {
+// CAPPED: give up (return false, the stack is abandoned) when more than `cap` far children have
+// been entered; the caller hands the query to the cooperative search (knn1_coop_kernel).
+template <int LEAFB, bool RESUME = false, class M = MetricL2, bool CAPPED = false, class Policy, class StackT>
+__device__ __forceinline__ bool traverse(
+    const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st, uint32_t cap = 0) {
   const uint4* __restrict__ nodes = t.nodes;
   const float4* __restrict__ pts = t.pts;
   uint32_t ref = RESUME ? kLeafBit : t.root_ref;  // RESUME: an empty leaf, falls through to the unwind
   float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
+  uint32_t entered = 0;
 
   for (;;) {
     // Down to a leaf through the nearer children.
@@ -523,7 +537,7 @@ __device__ __forceinline__ void traverse(
     uint32_t enter_meta = 0;
     float enter_val = 0.0f;
     for (;;) {
-      if (st.empty()) return;
+      if (st.empty()) return true;
       Record rr[StackT::kUnwind];
       const int got = st.peek(rr);  // 1 .. kUnwind records, newest first (refills the ring if needed)
       int used = 0;
@@ -551,6 +565,7 @@ __device__ __forceinline__ void traverse(
       }
       st.drop(used);
       if (enter) {
+        if (CAPPED && ++entered > cap) return false;
         const float val = enter_val;
         const uint32_t idx = enter_meta & kRecIdxMask;
         const uint32_t axis = (enter_meta >> 28) & 3u;
@@ -979,9 +994,8 @@ __device__ __forceinline__ uint32_t uniform_value(uint32_t v) {
 template <int LEAFB, bool PACK = false>
 __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
-    Cont cont, uint32_t debug_skip = 0, const float* __restrict__ queries = nullptr, uint32_t dim = 3,
+    Cont cont, const float* __restrict__ queries = nullptr, uint32_t dim = 3,
     const uint32_t* __restrict__ perm = nullptr, float4* __restrict__ qs_out = nullptr) {
-  // debug_skip (timing experiments only, results incomplete): 1 = no second descent, 2 = no stores, 4 = no leaf.
   const uint64_t i0 = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
@@ -1034,7 +1048,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
       ref = go_left ? nd.z : nd.w;
     }
   }
-  if (!(debug_skip & 4u)) {
+  {
     const uint32_t lv = ref & 0x7FFFFFFFu;
     const uint32_t begin = lv >> t.cbits;
     const uint32_t count = lv & t.cmask;
@@ -1073,7 +1087,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
       ++c;
     }
   };
-  if (!(debug_skip & 1u)) {
+  {
     uint32_t r2 = t.root_ref;
     // The lanes agreed on exactly the first `shared_levels` steps of the first descent (the last of
     // which is where they parted); the same holds here because the steps are the same.
@@ -1104,10 +1118,6 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   if (!valid) return;
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
   const uint32_t e = (uint32_t)i;
-  if ((debug_skip & 2u) && pol.best_d >= 0.0f) {
-    if (e == 0xFFFFFFFFu) cont.key[0] = (ContKey)(cls + c + ref);  // keeps the work alive
-    return;
-  }
   cont.key[e] = make_cont_key(cls, pol.best_d);
   cont.ids[e] = e;
   if (cls == 0) {
@@ -1130,8 +1140,11 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 //   meta[4] end of the narrow tiers     meta[5] their waves in total
 //   meta[8 + 4 i ..]  narrow tier i: {first entry, end entry, lanes per wave, first wave}
 // The narrow tiers cut the head of the ranked classes at cumulative per-mille marks.
+//   meta[24] queries phase 2 gave up on (cap reached; listed for knn1_coop_kernel)
+//   meta[25] next entry of that list to hand out     meta[26] queries the cooperative search could not certify
 constexpr uint32_t kMaxTiers = 4;
-constexpr uint32_t kMetaWords = 32;  // size of Cont::meta (8 fixed words + 4 per narrow tier, rounded up)
+constexpr uint32_t kMetaWords = 32;  // size of Cont::meta (8 fixed words + 4 per narrow tier + 3 counters, rounded up)
+constexpr uint32_t kMetaHeavy = 24, kMetaCoopHead = 25, kMetaRedo = 26;
 struct TierSpec {
   uint32_t permille[kMaxTiers];  // cumulative share of the ranked group where tier i ends (0 = unused)
   uint32_t lanes[kMaxTiers];
@@ -1176,13 +1189,20 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
   cont.meta[4] = begin;
   cont.meta[5] = wave;
   cont.meta[6] = deal;
+  cont.meta[kMetaHeavy] = 0;
+  cont.meta[kMetaCoopHead] = 0;
+  cont.meta[kMetaRedo] = 0;
 }
 
 // Phase 2: one continuation per lane, taken from the class-sorted entry list.
+// cap > 0 (exact searches only): a query that has entered `cap` far children and still has work
+// left stops here -- its best so far goes back to cont.best and its slot onto heavy_list, for the
+// cooperative search below.  The few thousand queries this concerns are dependent chains of
+// hundreds of leaf visits which used to decide the duration of the whole launch.
 template <int S, int OVF, int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
-    const uint32_t* __restrict__ sorted_ids, uint32_t debug_mode = 0) {
+    const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, uint32_t* __restrict__ heavy_list = nullptr) {
   const uint32_t n2 = cont.meta[0];
   const uint32_t heavy = cont.meta[1];
   const uint32_t heavy_waves = cont.meta[2];
@@ -1190,13 +1210,6 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   const uint32_t top_waves = cont.meta[5];
   const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
-  // Timing experiments only (results are incomplete): 1 = skip the heavy waves, 2 = only them.
-  // 3 / 4 / 5 = only the top / dealt / light tier.
-  if (debug_mode == 1 && wave < top_waves + heavy_waves) return;
-  if (debug_mode == 2 && wave >= top_waves + heavy_waves) return;
-  if (debug_mode == 3 && wave >= top_waves) return;
-  if (debug_mode == 4 && (wave < top_waves || wave >= top_waves + heavy_waves)) return;
-  if (debug_mode == 5 && wave < top_waves + heavy_waves) return;
   // Three tiers of the sorted list, most expensive first (blocks are dispatched in order):
   //   narrow the head of the ranked classes in up to kMaxTiers tiers of few lanes per wavefront:
   //          these queries are long dependent chains (hundreds of leaves); a wave's round costs
@@ -1237,9 +1250,11 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   NnPolicy pol;
   pol.e_inv = e_inv;
   pol.out = out;
+  bool finished;
   if (cls == kContOverflow) {
     pol.begin_query(qi);
-    traverse<LEAFB, false>(t, qx, qy, qz, pol, st);
+    finished = cap ? traverse<LEAFB, false, MetricL2, true>(t, qx, qy, qz, pol, st, cap)
+                   : traverse<LEAFB, false>(t, qx, qy, qz, pol, st);
   } else {
     pol.best_i = (int32_t)start.x;
     pol.best_d = __uint_as_float(start.y);
@@ -1247,9 +1262,264 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
       const Record r = cont.record(e, j);
       st.push(r.x, __uint_as_float(r.y));
     }
-    traverse<LEAFB, true>(t, qx, qy, qz, pol, st);
+    finished = cap ? traverse<LEAFB, true, MetricL2, true>(t, qx, qy, qz, pol, st, cap)
+                   : traverse<LEAFB, true>(t, qx, qy, qz, pol, st);
   }
-  pol.end_query(qi);
+  if (finished) {
+    pol.end_query(qi);
+  } else {
+    cont.best[e] = make_uint4((uint32_t)pol.best_i, __float_as_uint(pol.best_d), cls, 0u);
+    heavy_list[atomicAdd(&cont.meta[kMetaHeavy], 1u)] = e;
+  }
+}
+
+// ---- cooperative search of the queries phase 2 gave up on ---------------------------------------
+//
+// What is left after the cap are dependent chains: the reference's depth-first search of such a
+// query visits hundreds of leaves one after the other (its bound tightens slowly -- the query sits
+// in an empty region with a ring of points all about equally far away), and no lane-per-query
+// schedule can shorten a chain.  Here G lanes work on ONE query: they share a LIFO pool of
+// subtrees still to be searched and the best distance found so far, and every lane advances its
+// own subtree by one node per step (a branch: keep the far child for later if it can still
+// matter, go near; a leaf: measure four points), so a step is one memory round trip for up to G
+// nodes of the same query.
+//
+// This is NOT the reference's visit order, so what makes the result the reference's?  The
+// reference (kd_tree_search.hpp:52-105 + search_visitor.hpp:42-65) reports, of the points it
+// visits, the first in its depth-first order that attains the smallest distance.  Let p* be the
+// point with the smallest float distance d* among ALL points of the tree.  If p* is the only point
+// at that distance, and every far child on the path from the root to p*'s leaf has a box distance
+// <= d* (the reference enters a far child when `max() >= box distance`, and its max() is never
+// below d*), then the reference reaches p*'s leaf whatever it visited before, accepts p* (strict
+// improvement over anything else) and keeps it: its answer is exactly (p*, d*).  Both conditions
+// hold for all but pathological inputs (exact ties; a float box distance above the distance of a
+// point inside the box); when one of them fails the query is listed for knn1_redo_kernel, which
+// replays the reference search from the root.
+//
+// So the cooperative search has to find the true float minimum over all points, nothing else.  It
+// prunes a subtree only when its box distance exceeds best * (1 + 2^-10): the float box distance
+// (a chain of at most 2 roundings per level) exceeds the exact one by a relative 2^-12 at most for
+// trees less than ~2000 levels deep, and a float point distance is within 5 roundings of the exact
+// one, so a pruned subtree holds no point at a float distance <= best -- neither the minimum nor a
+// tie for it.  Each subtree carries the largest box distance met on its path (`gmax`), which is
+// what the second condition compares with d*.  Searches with a best below 1e-30 or above 1e30
+// (products underflow or overflow; the error bounds above assume neither) are redone as well.
+//
+// Groups take queries from the list through an atomic counter until it is exhausted.
+template <int G, int POOL>
+__global__ __launch_bounds__(64) void knn1_coop_kernel(
+    DevTree t, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
+    const uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ redo_list) {
+  static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per query");
+  constexpr int NG = 64 / G;
+  typedef PTK_LDS uint32_t LdsU32;
+  const uint4* __restrict__ nodes = t.nodes;
+  const float4* __restrict__ pts = t.pts;
+  const uint32_t lane = threadIdx.x;
+  const uint32_t g = lane / G, gl = lane % G;
+  const uint64_t gmask = (G == 64 ? ~0ull : ((1ull << G) - 1ull)) << (g * G);
+  const uint64_t below = gmask & ((1ull << lane) - 1ull);  // lanes of this group before this one
+  LdsU32* pool = (LdsU32*)ptk_smem + g * (6 * POOL);       // [field][slot] of this group
+  LdsU32* gbest = (LdsU32*)ptk_smem + NG * (6 * POOL) + g;  // bits of the group's best distance
+  const uint32_t n_heavy = cont.meta[kMetaHeavy];
+
+  bool have = false, exhausted = false, busy = false, failed = false;
+  uint32_t count = 0;  // subtrees in the pool (the same value in every lane of the group)
+  float qx = 0.0f, qy = 0.0f, qz = 0.0f;
+  uint32_t e = 0, qi = 0;
+  uint32_t ref = 0;
+  float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f, gmax = 0.0f;
+  float cd = 3.402823466e+38f;  // this lane's best: distance, index, "another point at cd", "gmax <= cd"
+  int32_t ci = 0;
+  bool cmulti = false, cok = false;
+
+  for (;;) {
+    // Groups without a query take the next one.
+    const bool need = !have && !exhausted;
+    if (__ballot(need) != 0ull) {
+      uint32_t idx = 0xFFFFFFFFu;
+      if (need && gl == 0) idx = atomicAdd(&cont.meta[kMetaCoopHead], 1u);
+      idx = (uint32_t)__shfl((int)idx, (int)(g * G));
+      if (need) {
+        if (idx < n_heavy) {
+          e = heavy_list[idx];
+          const float4 qrec = qs[e];
+          qx = qrec.x;
+          qy = qrec.y;
+          qz = qrec.z;
+          qi = __float_as_uint(qrec.w);
+          const uint4 st = cont.best[e];
+          const float b0 = __uint_as_float(st.y);
+          have = true;
+          busy = false;
+          failed = !(b0 >= 1e-30f && b0 <= 1e30f);
+          count = failed ? 0u : 1u;
+          cd = 3.402823466e+38f;
+          ci = 0;
+          cmulti = false;
+          cok = false;
+          if (gl == 0) {
+            pool[0 * POOL] = t.root_ref;
+            pool[1 * POOL] = 0u;  // box distance 0, offsets 0
+            pool[2 * POOL] = 0u;
+            pool[3 * POOL] = 0u;
+            pool[4 * POOL] = 0u;
+            pool[5 * POOL] = 0u;
+            *gbest = st.y;
+          }
+        } else {
+          exhausted = true;
+        }
+      }
+    }
+    if (__ballot(have) == 0ull) break;
+
+    const float best = __uint_as_float(*gbest);
+    const float bm = f_add(best, f_mul(best, 0.0009765625f));  // best * (1 + 2^-10), see above
+
+    // Idle lanes take subtrees off the top of the pool.
+    const bool want = have && !busy;
+    const uint64_t wmask = __ballot(want) & gmask;
+    if (want) {
+      const uint32_t rank = (uint32_t)__popcll(wmask & below);
+      if (rank < count) {
+        const uint32_t sl = count - 1u - rank;
+        ref = pool[0 * POOL + sl];
+        nbd = __uint_as_float(pool[1 * POOL + sl]);
+        off0 = __uint_as_float(pool[2 * POOL + sl]);
+        off1 = __uint_as_float(pool[3 * POOL + sl]);
+        off2 = __uint_as_float(pool[4 * POOL + sl]);
+        gmax = __uint_as_float(pool[5 * POOL + sl]);
+        busy = bm >= nbd;  // the bound may have tightened since the subtree was kept
+      }
+    }
+    {
+      const uint32_t nw = (uint32_t)__popcll(wmask);
+      count -= nw < count ? nw : count;
+    }
+
+    // One node per lane.
+    bool push = false;
+    uint32_t p_ref = 0;
+    float p_nbd = 0.0f, p_off0 = 0.0f, p_off1 = 0.0f, p_off2 = 0.0f, p_gmax = 0.0f;
+    if (busy) {
+      if (!(ref & kLeafBit)) {
+        const uint32_t idx = ref & kBranchIdxMask;
+        const uint32_t axis = (ref >> 29) & 3u;
+        const uint4 nd = nodes[idx];
+        const float left_max = __uint_as_float(nd.x);
+        const float right_min = __uint_as_float(nd.y);
+        const float v = sel3(axis, qx, qy, qz);
+        const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+        const float dv = f_sub(go_left ? right_min : left_max, v);
+        const float new_off = f_mul(dv, dv);
+        const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
+        if (bm >= far_nbd) {
+          push = true;
+          p_ref = go_left ? nd.w : nd.z;
+          p_nbd = far_nbd;
+          p_off0 = axis == 0 ? new_off : off0;
+          p_off1 = axis == 1 ? new_off : off1;
+          p_off2 = axis == 2 ? new_off : off2;
+          p_gmax = gmax < far_nbd ? far_nbd : gmax;
+        }
+        ref = go_left ? nd.z : nd.w;
+      } else {
+        const uint32_t lv = ref & 0x7FFFFFFFu;
+        const uint32_t begin = lv >> t.cbits;
+        const uint32_t cnt = lv & t.cmask;
+        float4 p[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[u] = pts[begin + u];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if ((uint32_t)u < cnt) {
+            PTK_KEEP4(p[u]);
+            const float dx = f_sub(qx, p[u].x);
+            const float dy = f_sub(qy, p[u].y);
+            const float dz = f_sub(qz, p[u].z);
+            const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
+            if (d < cd) {
+              cd = d;
+              ci = __float_as_int(p[u].w);
+              cmulti = false;
+              cok = gmax <= d;
+            } else if (d == cd) {
+              cmulti = true;
+            }
+          }
+        }
+        if (cnt > 4u) {
+          ref = kLeafBit | ((begin + 4u) << t.cbits) | (cnt - 4u);
+        } else {
+          busy = false;
+        }
+        if (cd < best) lds_min_u32(gbest, __float_as_uint(cd));
+      }
+    }
+
+    // Far children kept in this step go onto the pool.
+    const uint64_t pmask = __ballot(push) & gmask;
+    if (push) {
+      const uint32_t sl = count + (uint32_t)__popcll(pmask & below);
+      if (sl < (uint32_t)POOL) {
+        pool[0 * POOL + sl] = p_ref;
+        pool[1 * POOL + sl] = __float_as_uint(p_nbd);
+        pool[2 * POOL + sl] = __float_as_uint(p_off0);
+        pool[3 * POOL + sl] = __float_as_uint(p_off1);
+        pool[4 * POOL + sl] = __float_as_uint(p_off2);
+        pool[5 * POOL + sl] = __float_as_uint(p_gmax);
+      }
+    }
+    count += (uint32_t)__popcll(pmask);
+    if (count > (uint32_t)POOL) {  // a subtree was lost: this query cannot be certified here
+      failed = true;
+      count = 0;
+      busy = false;
+    }
+
+    // A query is done when its pool is empty and no lane of the group holds a subtree.
+    const uint64_t bmask = __ballot(busy) & gmask;
+    const bool done = have && count == 0u && bmask == 0ull;
+    const float dstar = __uint_as_float(*gbest);
+    const bool mine = done && cd == dstar;
+    const uint64_t mm = __ballot(mine) & gmask;
+    const uint64_t bad = __ballot(mine && (cmulti || !cok)) & gmask;
+    if (done) {
+      if (!failed && __popcll(mm) == 1 && bad == 0ull) {
+        if (mine) {
+          Neighbor nb;
+          nb.index = ci;
+          nb.distance = cd;
+          out[qi] = nb;
+        }
+      } else if (gl == 0) {
+        redo_list[atomicAdd(&cont.meta[kMetaRedo], 1u)] = e;
+      }
+      have = false;
+    }
+  }
+}
+
+// The reference search from the root for the queries the cooperative search listed.
+template <int S, int OVF, int LEAFB>
+__global__ __launch_bounds__(64) void knn1_redo_kernel(
+    DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
+    const uint32_t* __restrict__ redo_list) {
+  const uint32_t n = cont.meta[kMetaRedo];
+  Record spill[OVF > 0 ? OVF : 1];
+  for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
+    const float4 qrec = qs[redo_list[i]];
+    const uint32_t qi = __float_as_uint(qrec.w);
+    Stack<S, OVF, 64> st;
+    st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+    NnPolicy pol;
+    pol.e_inv = e_inv;
+    pol.out = out;
+    pol.begin_query(qi);
+    traverse<LEAFB, false>(t, qrec.x, qrec.y, qrec.z, pol, st);
+    pol.end_query(qi);
+  }
 }
 
 // Packs the batch in launch order: qs[i] = {query perm[i], bits(perm[i])}

@@ -433,6 +433,16 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
 //   3  wave-uniform-prefix phase 1 that also packs the records (the shipped form; ballots: lanes
 //      run as fibers), default phase 2
 //   4  as 3 with one-point leaf batches and three narrow tiers (1, 4 and 16 lanes per wave)
+//   5  as 3, phase 2 capped at 2 far children per query, the rest through the cooperative search
+//      (16 lanes per query) and the redo pass            6  cap 1, 64 lanes per query
+//   7  cap 1, 8 lanes per query with an 8-entry pool: overflows, so most queries are redone
+//   8  cap 3, 32 lanes per query
+// emu_last_coop(): {queries phase 2 gave up on, queries the cooperative search could not certify}.
+static uint32_t g_last_heavy = 0, g_last_redo = 0;
+void emu_last_coop(uint32_t* heavy, uint32_t* redo) {
+  *heavy = g_last_heavy;
+  *redo = g_last_redo;
+}
 int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint32_t* perm, int variant,
                        ptk_neighbor* out) {
   auto* t = static_cast<Emu*>(h);
@@ -446,13 +456,13 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
   std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(ptk::kMetaWords, 0);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
-  if (variant == 3 || variant == 4) {
+  if (variant >= 3) {
     std::vector<float4> packed(nq);  // written by the kernel itself (PACK)
     for_each_wave((uint32_t)((nq + 63) / 64), [&] {
-      if (variant == 3)
-        ptk::knn1_phase1u_kernel<4, true>(t->dev, nullptr, nq, e_inv, o, cont, 0u, q, t->dim, perm, packed.data());
+      if (variant != 4)
+        ptk::knn1_phase1u_kernel<4, true>(t->dev, nullptr, nq, e_inv, o, cont, q, t->dim, perm, packed.data());
       else
-        ptk::knn1_phase1u_kernel<1, true>(t->dev, nullptr, nq, e_inv, o, cont, 0u, q, t->dim, perm, packed.data());
+        ptk::knn1_phase1u_kernel<1, true>(t->dev, nullptr, nq, e_inv, o, cont, q, t->dim, perm, packed.data());
     });
     for (uint64_t i = 0; i < nq; ++i) {
       if (std::memcmp(&packed[i], &qs[i], sizeof(float4)) != 0) return -4;  // same records as pack_queries_kernel
@@ -490,6 +500,8 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   }
   ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
+  const uint32_t cap = variant == 5 ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
+  std::vector<uint32_t> heavy_list(nq, 0xEEEEEEEEu), redo_list(nq, 0xEEEEEEEEu);
   gridDim.x = blocks;
   blockDim.x = 64;
   for (uint32_t b = 0; b < blocks; ++b) {
@@ -499,7 +511,27 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
       if (variant == 2 || variant == 4)
         ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
       else
-        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, heavy_list.data());
+    }
+  }
+  g_last_heavy = meta[ptk::kMetaHeavy];
+  g_last_redo = 0;
+  if (cap) {
+    for_each_wave(3, [&] {
+      if (variant == 5) ptk::knn1_coop_kernel<16, 128>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
+      else if (variant == 6) ptk::knn1_coop_kernel<64, 256>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
+      else if (variant == 7) ptk::knn1_coop_kernel<8, 8>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
+      else ptk::knn1_coop_kernel<32, 192>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
+    });
+    if (meta[ptk::kMetaCoopHead] < meta[ptk::kMetaHeavy]) return -5;  // every listed query was taken
+    g_last_redo = meta[ptk::kMetaRedo];
+    gridDim.x = 2;
+    for (uint32_t b = 0; b < 2; ++b) {
+      blockIdx.x = b;
+      for (uint32_t l = 0; l < 64; ++l) {
+        threadIdx.x = l;
+        ptk::knn1_redo_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, redo_list.data());
+      }
     }
   }
   return (int)meta[0];

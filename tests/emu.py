@@ -124,6 +124,13 @@ class EmulatedTree:
         assert n2 >= 0
         return out, n2
 
+    def last_coop(self):
+        """(queries phase 2 gave up on, queries the cooperative search could not certify) of the last
+        ``two_phase_knn1`` call with a capped variant (5-8)."""
+        heavy, redo = c_uint32(0), c_uint32(0)
+        self.lib.emu_last_coop(ctypes.byref(heavy), ctypes.byref(redo))
+        return heavy.value, redo.value
+
     def morton_permutation(self, q):
         """The permutation the device would use (keys from the kernel, stable sort)."""
         q = np.ascontiguousarray(q, dtype=np.float32)

@@ -134,6 +134,48 @@ def test_emulated_two_phase_knn1_equals_oracle(case):
     assert got.tobytes() == ref.search_knn(q, 1, e=1.4).tobytes()
 
 
+def _blind_disc_queries(n):
+    """Queries inside the empty disc under the scanner of cloud L: the reference's depth-first search
+    of such a query visits a long chain of leaves (the expensive queries of BASELINE config 2)."""
+    u = ds.raw_uniform24(11, 2 * n).reshape(n, 2)
+    r = 12.0 * np.sqrt(u[:, 0])
+    a = 2.0 * np.pi * u[:, 1]
+    return np.ascontiguousarray(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(n)], axis=1), dtype=np.float32)
+
+
+@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "self", "lidar", "root-is-leaf",
+                                                                  "dim2", "dim1", "leaf1")],
+                         ids=lambda c: c[0])
+def test_emulated_capped_phase2_and_cooperative_search_equal_oracle(case):
+    """Phase 2 with a cap on the far children a query may enter, the cooperative search (8 / 16 / 32 / 64
+    lanes per query, fibers) for what is left and the redo pass for what that cannot certify: exact
+    ties (lattice clouds, queries that are tree points) must come back through the redo list and
+    still equal the reference."""
+    name, pts, q, leaf, _ = case
+    q = q[:1200]
+    if name == "lidar":
+        q = np.concatenate([q[:600], _blind_disc_queries(600)])
+    emu = EmulatedTree(pts, leaf)
+    ref = oracle.Oracle(pts, leaf, "port")
+    perm, _ = emu.morton_permutation(q)
+    want = ref.search_knn(q, 1)
+    stats = {}
+    for variant in (5, 6, 7, 8):
+        for p in (None, perm):
+            got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
+            assert got.tobytes() == want.tobytes(), (name, variant)
+        stats[variant] = emu.last_coop()
+    print(name, stats)
+    if name in ("uniform", "lidar", "ties"):
+        assert stats[5][0] > 0 and stats[6][0] >= stats[5][0]   # the cap does hand queries over
+    if name in ("uniform", "lidar"):
+        assert stats[5][1] <= stats[5][0] // 20                 # generic data: (almost) nothing to redo
+    if name == "lidar":
+        assert stats[7][1] > stats[5][1]                        # the 8-entry pool overflows
+    if name == "ties":
+        assert stats[5][1] > 0                                  # exact ties cannot be certified
+
+
 @pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "dim2", "dim1", "ties", "lidar", "root-is-leaf",
                                                                   "leaf1")], ids=lambda c: c[0])
 def test_emulated_box_search_equals_oracle(case):
