@@ -716,9 +716,14 @@ size_t class_sort_tmp_bytes(uint64_t nq) {
   return tmp_bytes + 256;
 }
 
+// Queries whose unfinished stack phase 2 can hand to the cooperative search (kMaxTasks records
+// each); further ones are searched again from the root.
+uint64_t max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 32, std::min<uint64_t>(nq, 16384)); }
+
 size_t two_phase_scratch_bytes(uint64_t nq) {
   return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 4 * nq +
-         2 * (nq * 4) + 2 * (nq * 4) + 64 + class_sort_tmp_bytes(nq);
+         2 * (nq * 4) + 3 * (nq * 4) + max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + 64 +
+         class_sort_tmp_bytes(nq);
 }
 
 // Far children a query may enter in phase 2 before it is handed to the cooperative search
@@ -732,11 +737,11 @@ uint32_t phase2_cap(float e) {
 
 template <int G, int POOL>
 int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
-                     const uint32_t* heavy_list, uint32_t* redo_list, hipStream_t s) {
+                     const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s) {
   constexpr size_t smem = (size_t)(64 / G) * (6 * POOL + 1) * 4;
   const int waves = std::max(1, env_int("PTK_COOP_WAVES", 4096));
-  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, POOL>), dim3(waves), dim3(64), smem, s, t->dev, qs, d_out, cont,
-                     heavy_list, redo_list);
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, POOL>), dim3(waves), dim3(64), smem, s, t->dev,
+                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
@@ -771,9 +776,14 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   void* tmp = scratch.take<char>(tmp_bytes);
   if (!cont.rec || !cont.best || !cont.key || !key_out || !cont.ids || !ids_out || !cont.meta || !tmp)
     return fail(PTK_ERR_NOMEM, "scratch block too small");
-  uint32_t* heavy_list = scratch.take<uint32_t>(nq);
+  ptk::Handover ho{};
+  ho.meta = cont.meta;
+  ho.heavy_list = scratch.take<uint32_t>(nq);
+  ho.ntasks = scratch.take<uint32_t>(nq);
+  ho.max_heavy = (uint32_t)max_handover(nq);
+  ho.tasks = scratch.take<ptk::Task>((size_t)ho.max_heavy * ptk::kMaxTasks);
   uint32_t* redo_list = scratch.take<uint32_t>(nq);
-  if (!heavy_list || !redo_list) return fail(PTK_ERR_NOMEM, "scratch block too small");
+  if (!ho.heavy_list || !ho.ntasks || !ho.tasks || !redo_list) return fail(PTK_ERR_NOMEM, "scratch block too small");
   scratch.note_meta(cont.meta);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
@@ -804,17 +814,17 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   {
     Timer timer(t, s);
     hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1 + extra_waves), dim3(64),
-                       (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out, cap, heavy_list);
+                       (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out, cap, ho);
     timer.stop(3, 0);
   }
   PTK_HIP(hipGetLastError());
   if (cap) {  // the queries phase 2 gave up on: G lanes per query, then whatever that could not certify
     Timer timer(t, s);
     switch (env_int("PTK_COOP_G", 16)) {
-      case 8: rc = launch_knn1_coop<8, 96>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
-      case 32: rc = launch_knn1_coop<32, 192>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
-      case 64: rc = launch_knn1_coop<64, 256>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
-      default: rc = launch_knn1_coop<16, 128>(t, qs, d_out, cont, heavy_list, redo_list, s); break;
+      case 8: rc = launch_knn1_coop<8, 64>(t, qs, d_out, cont, ho, redo_list, s); break;
+      case 32: rc = launch_knn1_coop<32, 128>(t, qs, d_out, cont, ho, redo_list, s); break;
+      case 64: rc = launch_knn1_coop<64, 192>(t, qs, d_out, cont, ho, redo_list, s); break;
+      default: rc = launch_knn1_coop<16, 96>(t, qs, d_out, cont, ho, redo_list, s); break;
     }
     if (rc != PTK_OK) return rc;
     hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), (size_t)S2 * 64 * 8, s, t->dev,

@@ -471,16 +471,45 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
 // ---- the traversal ----------------------------------------------------------------
 // RESUME: the stack already holds the pending records of a finished first descent (phase 2
 // of the two-phase k = 1 search): start by unwinding instead of descending from the root.
-// CAPPED: give up (return false, the stack is abandoned) when more than `cap` far children have
-// been entered; the caller hands the query to the cooperative search (knn1_coop_kernel).
+// A subtree still to be searched, as the cooperative search (knn1_coop_kernel) keeps it: the state
+// the reference would enter it with.  `gmax` = the largest box distance of a far child on the
+// path from the root down to it; its sign bit marks a subtree handed over by a capped traversal
+// in the form of its pending record: `ref` is then the record's {parent branch | axis | side},
+// the offset of the split axis still the parent's (entering it reads the parent branch).
+struct Task {
+  uint32_t ref;
+  float nbd, off0, off1, off2, gmax;
+};
+// Counters in Cont::meta (zeroed by knn1_phase_meta_kernel): queries phase 2 gave up on, the next
+// entry of that list to hand to a group, queries the cooperative search could not certify.
+constexpr uint32_t kMetaHeavy = 24, kMetaCoopHead = 25, kMetaRedo = 26;
+constexpr uint32_t kMaxTasks = 64;               // tasks a capped traversal can hand over per query
+constexpr uint32_t kTasksFromRoot = 0xFFFFFFFFu;  // more than that (or no room): search again from the root
+constexpr uint32_t kTasksRedo = 0xFFFFFFFEu;      // non-monotone box distances met: only the reference order will do
+
+// Where a capped traversal leaves its unfinished work.
+struct Handover {
+  uint32_t* meta;        // Cont::meta
+  uint32_t* heavy_list;  // [nq] slots of the queries handed over
+  uint32_t* ntasks;      // [nq] tasks of list entry h (or kTasksFromRoot / kTasksRedo)
+  Task* tasks;           // [max_heavy][kMaxTasks]
+  uint32_t max_heavy;
+  uint32_t slot;         // this query
+};
+
+// CAPPED: give up (return false) when more than `cap` far children have been entered: what is
+// still on the stack goes to `ho` -- every pending far child that can still matter together with
+// the state it would be entered with, next-to-visit first.
 template <int LEAFB, bool RESUME = false, class M = MetricL2, bool CAPPED = false, class Policy, class StackT>
 __device__ __forceinline__ bool traverse(
-    const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st, uint32_t cap = 0) {
+    const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st, uint32_t cap = 0,
+    const Handover* ho = nullptr) {
   const uint4* __restrict__ nodes = t.nodes;
   const float4* __restrict__ pts = t.pts;
   uint32_t ref = RESUME ? kLeafBit : t.root_ref;  // RESUME: an empty leaf, falls through to the unwind
   float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
   uint32_t entered = 0;
+  bool monotone = true;  // CAPPED: every far child entered so far had a box distance >= its parent's
 
   for (;;) {
     // Down to a leaf through the nearer children.
@@ -565,8 +594,47 @@ __device__ __forceinline__ bool traverse(
       }
       st.drop(used);
       if (enter) {
-        if (CAPPED && ++entered > cap) return false;
+        if (CAPPED && ++entered > cap) {
+          const uint32_t h = atomicAdd(&ho->meta[kMetaHeavy], 1u);
+          ho->heavy_list[h] = ho->slot;
+          Task* out = h < ho->max_heavy ? ho->tasks + (uint64_t)h * kMaxTasks : nullptr;
+          uint32_t n = 0;
+          auto emit = [&](uint32_t meta, float val) {
+            if (out != nullptr && n < kMaxTasks) {
+              Task k;
+              k.ref = meta;
+              k.nbd = val;
+              k.off0 = off0;
+              k.off1 = off1;
+              k.off2 = off2;
+              // While `monotone` holds the largest box distance on the path so far is the current one.
+              k.gmax = __uint_as_float(__float_as_uint(nbd < val ? val : nbd) | 0x80000000u);
+              out[n] = k;
+            }
+            ++n;
+          };
+          emit(enter_meta, enter_val);
+          while (!st.empty()) {
+            const Record r = st.pop();
+            const float val = __uint_as_float(r.y);
+            if (r.x & kRecUndo) {
+              if (r.x & kRecSide) {
+                nbd = val;
+              } else {
+                const uint32_t axis = (r.x >> 28) & 3u;
+                off0 = axis == 0 ? val : off0;
+                off1 = axis == 1 ? val : off1;
+                off2 = axis == 2 ? val : off2;
+              }
+            } else if (pol.max() >= val) {
+              emit(r.x, val);
+            }
+          }
+          ho->ntasks[h] = !monotone ? kTasksRedo : (out == nullptr || n > kMaxTasks ? kTasksFromRoot : n);
+          return false;
+        }
         const float val = enter_val;
+        if (CAPPED && val < nbd) monotone = false;
         const uint32_t idx = enter_meta & kRecIdxMask;
         const uint32_t axis = (enter_meta >> 28) & 3u;
         const bool far_is_right = (enter_meta & kRecSide) != 0;
@@ -1144,7 +1212,6 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 //   meta[25] next entry of that list to hand out     meta[26] queries the cooperative search could not certify
 constexpr uint32_t kMaxTiers = 4;
 constexpr uint32_t kMetaWords = 32;  // size of Cont::meta (8 fixed words + 4 per narrow tier + 3 counters, rounded up)
-constexpr uint32_t kMetaHeavy = 24, kMetaCoopHead = 25, kMetaRedo = 26;
 struct TierSpec {
   uint32_t permille[kMaxTiers];  // cumulative share of the ranked group where tier i ends (0 = unused)
   uint32_t lanes[kMaxTiers];
@@ -1202,7 +1269,7 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
 template <int S, int OVF, int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
-    const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, uint32_t* __restrict__ heavy_list = nullptr) {
+    const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, Handover ho = Handover{}) {
   const uint32_t n2 = cont.meta[0];
   const uint32_t heavy = cont.meta[1];
   const uint32_t heavy_waves = cont.meta[2];
@@ -1251,9 +1318,10 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   pol.e_inv = e_inv;
   pol.out = out;
   bool finished;
+  ho.slot = e;
   if (cls == kContOverflow) {
     pol.begin_query(qi);
-    finished = cap ? traverse<LEAFB, false, MetricL2, true>(t, qx, qy, qz, pol, st, cap)
+    finished = cap ? traverse<LEAFB, false, MetricL2, true>(t, qx, qy, qz, pol, st, cap, &ho)
                    : traverse<LEAFB, false>(t, qx, qy, qz, pol, st);
   } else {
     pol.best_i = (int32_t)start.x;
@@ -1262,14 +1330,13 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
       const Record r = cont.record(e, j);
       st.push(r.x, __uint_as_float(r.y));
     }
-    finished = cap ? traverse<LEAFB, true, MetricL2, true>(t, qx, qy, qz, pol, st, cap)
+    finished = cap ? traverse<LEAFB, true, MetricL2, true>(t, qx, qy, qz, pol, st, cap, &ho)
                    : traverse<LEAFB, true>(t, qx, qy, qz, pol, st);
   }
   if (finished) {
     pol.end_query(qi);
-  } else {
+  } else {  // listed by the traversal; the cooperative search starts from the best so far
     cont.best[e] = make_uint4((uint32_t)pol.best_i, __float_as_uint(pol.best_d), cls, 0u);
-    heavy_list[atomicAdd(&cont.meta[kMetaHeavy], 1u)] = e;
   }
 }
 
@@ -1279,38 +1346,74 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
 // query visits hundreds of leaves one after the other (its bound tightens slowly -- the query sits
 // in an empty region with a ring of points all about equally far away), and no lane-per-query
 // schedule can shorten a chain.  Here G lanes work on ONE query: they share a LIFO pool of
-// subtrees still to be searched and the best distance found so far, and every lane advances its
-// own subtree by one node per step (a branch: keep the far child for later if it can still
-// matter, go near; a leaf: measure four points), so a step is one memory round trip for up to G
-// nodes of the same query.
+// subtrees still to be searched (it starts with what the capped traversal handed over) and the
+// best distance found so far, and every lane advances its own subtree by one node per step (a
+// branch: keep the far child for later if it can still matter, go near; a leaf: measure four
+// points), so a step is one memory round trip for up to G nodes of the same query.
 //
 // This is NOT the reference's visit order, so what makes the result the reference's?  The
 // reference (kd_tree_search.hpp:52-105 + search_visitor.hpp:42-65) reports, of the points it
-// visits, the first in its depth-first order that attains the smallest distance.  Let p* be the
-// point with the smallest float distance d* among ALL points of the tree.  If p* is the only point
-// at that distance, and every far child on the path from the root to p*'s leaf has a box distance
-// <= d* (the reference enters a far child when `max() >= box distance`, and its max() is never
-// below d*), then the reference reaches p*'s leaf whatever it visited before, accepts p* (strict
-// improvement over anything else) and keeps it: its answer is exactly (p*, d*).  Both conditions
-// hold for all but pathological inputs (exact ties; a float box distance above the distance of a
-// point inside the box); when one of them fails the query is listed for knn1_redo_kernel, which
-// replays the reference search from the root.
+// visits, the first in its depth-first order that attains the smallest distance.  Let d* be the
+// smallest float distance over ALL points of the tree and p* the point at d* that comes first in
+// that depth-first order (near child before far child, a leaf in index order).  If every far child
+// on the path from the root to p*'s leaf has a box distance <= d* -- the reference enters a far
+// child when `max() >= box distance`, and its max() is never below d* -- then the reference
+// reaches p*'s leaf whatever it visited before, accepts p* (a strict improvement on anything else
+// it can hold then) and keeps it: its answer is exactly (p*, d*).  The condition holds unless a
+// float box distance exceeds the float distance of a point inside the box (rounding); when it
+// fails the query is listed for knn1_redo_kernel, which replays the reference search.
 //
-// So the cooperative search has to find the true float minimum over all points, nothing else.  It
-// prunes a subtree only when its box distance exceeds best * (1 + 2^-10): the float box distance
-// (a chain of at most 2 roundings per level) exceeds the exact one by a relative 2^-12 at most for
-// trees less than ~2000 levels deep, and a float point distance is within 5 roundings of the exact
-// one, so a pruned subtree holds no point at a float distance <= best -- neither the minimum nor a
-// tie for it.  Each subtree carries the largest box distance met on its path (`gmax`), which is
-// what the second condition compares with d*.  Searches with a best below 1e-30 or above 1e30
-// (products underflow or overflow; the error bounds above assume neither) are redone as well.
+// So the cooperative search has to find the float minimum over all points, and among several
+// points at the minimum the first in depth-first order (dfs_before(), a descent from the root
+// that only runs on exact ties; more than a few ties per query -> redo).  It prunes a subtree
+// only when its box distance exceeds best * (1 + 2^-10): the float box distance (a chain of at
+// most 2 roundings per level) exceeds the exact one by a relative 2^-12 at most for trees less
+// than ~2000 levels deep, and a float point distance is within 5 roundings of the exact one, so a
+// pruned subtree holds no point at a float distance <= best -- neither the minimum nor a tie for
+// it.  Every subtree carries the largest box distance met on its path (`gmax`), which is what the
+// condition above compares with d*.  Searches with a best below 1e-30 or above 1e30 (products
+// underflow or overflow; the error bounds assume neither) are redone as well.  The points the
+// capped traversal had visited before it stopped need no second look: the reference has visited
+// them too, so if one of them is p* it is the best handed over, and it wins ties against
+// anything found here (it came first).
 //
 // Groups take queries from the list through an atomic counter until it is exhausted.
+
+// True if, in the reference's depth-first order for query q, the point at record position `a`
+// comes before the one at `b` (a != b): they part ways at some branch, where the nearer child is
+// searched first; inside one leaf the lower position is visited first.
+__device__ inline bool dfs_before(const DevTree& t, const uint2* __restrict__ ranges, float qx, float qy, float qz,
+                                  uint32_t a, uint32_t b) {
+  uint32_t ref = t.root_ref;
+  for (;;) {
+    if (ref & kLeafBit) return a < b;
+    const uint32_t axis = (ref >> 29) & 3u;
+    const uint4 nd = t.nodes[ref & kBranchIdxMask];
+    uint32_t mid;  // first record of the right child
+    if (nd.w & kLeafBit) {
+      mid = (nd.w & 0x7FFFFFFFu) >> t.cbits;
+    } else {
+      mid = ranges[nd.w & kBranchIdxMask].x;
+    }
+    const bool a_left = a < mid, b_left = b < mid;
+    if (a_left == b_left) {
+      ref = a_left ? nd.z : nd.w;
+      continue;
+    }
+    const float v = sel3(axis, qx, qy, qz);
+    const bool go_left = f_sub(f_sub(f_add(__uint_as_float(nd.x), __uint_as_float(nd.y)), v), v) > 0.0f;
+    return go_left == a_left;
+  }
+}
+
+constexpr uint32_t kCoopTieBudget = 6;  // exact ties a lane resolves per query before it asks for a redo
+
 template <int G, int POOL>
 __global__ __launch_bounds__(64) void knn1_coop_kernel(
-    DevTree t, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
-    const uint32_t* __restrict__ heavy_list, uint32_t* __restrict__ redo_list) {
+    DevTree t, const uint2* __restrict__ ranges, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
+    Handover ho, uint32_t* __restrict__ redo_list) {
   static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per query");
+  static_assert(POOL >= (int)kMaxTasks, "the pool must hold a handed-over stack");
   constexpr int NG = 64 / G;
   typedef PTK_LDS uint32_t LdsU32;
   const uint4* __restrict__ nodes = t.nodes;
@@ -1329,9 +1432,13 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   uint32_t e = 0, qi = 0;
   uint32_t ref = 0;
   float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f, gmax = 0.0f;
-  float cd = 3.402823466e+38f;  // this lane's best: distance, index, "another point at cd", "gmax <= cd"
-  int32_t ci = 0;
-  bool cmulti = false, cok = false;
+  // This lane's best: distance, record position, "gmax <= cd"; ties it may still resolve.
+  float cd = 3.402823466e+38f;
+  uint32_t cpos = 0;
+  bool cok = false;
+  uint32_t tie_budget = 0;
+  float start_d = 0.0f;  // the best handed over (phase 2's own, already the reference's)
+  uint32_t start_i = 0;
 
   for (;;) {
     // Groups without a query take the next one.
@@ -1342,31 +1449,51 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
       idx = (uint32_t)__shfl((int)idx, (int)(g * G));
       if (need) {
         if (idx < n_heavy) {
-          e = heavy_list[idx];
+          e = ho.heavy_list[idx];
           const float4 qrec = qs[e];
           qx = qrec.x;
           qy = qrec.y;
           qz = qrec.z;
           qi = __float_as_uint(qrec.w);
           const uint4 st = cont.best[e];
-          const float b0 = __uint_as_float(st.y);
+          start_i = st.x;
+          start_d = __uint_as_float(st.y);
+          const uint32_t nt = ho.ntasks[idx];
           have = true;
           busy = false;
-          failed = !(b0 >= 1e-30f && b0 <= 1e30f);
-          count = failed ? 0u : 1u;
+          // A best of exactly 0 cannot be improved on: nothing to search.
+          failed = (start_d != 0.0f && !(start_d >= 1e-30f && start_d <= 1e30f)) || nt == kTasksRedo;
           cd = 3.402823466e+38f;
-          ci = 0;
-          cmulti = false;
+          cpos = 0;
           cok = false;
-          if (gl == 0) {
-            pool[0 * POOL] = t.root_ref;
-            pool[1 * POOL] = 0u;  // box distance 0, offsets 0
-            pool[2 * POOL] = 0u;
-            pool[3 * POOL] = 0u;
-            pool[4 * POOL] = 0u;
-            pool[5 * POOL] = 0u;
-            *gbest = st.y;
+          tie_budget = kCoopTieBudget;
+          if (failed || start_d == 0.0f) {
+            count = 0;
+          } else if (nt == kTasksFromRoot) {  // everything again, the points already visited included
+            count = 1;
+            if (gl == 0) {
+              pool[0 * POOL] = t.root_ref;
+              pool[1 * POOL] = 0u;  // box distance 0, offsets 0, no far child above
+              pool[2 * POOL] = 0u;
+              pool[3 * POOL] = 0u;
+              pool[4 * POOL] = 0u;
+              pool[5 * POOL] = 0u;
+            }
+          } else {  // the capped traversal's stack, next-to-visit on top
+            count = nt;
+            const Task* src = ho.tasks + (uint64_t)idx * kMaxTasks;
+            for (uint32_t i = gl; i < nt; i += G) {
+              const Task k = src[i];
+              const uint32_t sl = nt - 1u - i;
+              pool[0 * POOL + sl] = k.ref;
+              pool[1 * POOL + sl] = __float_as_uint(k.nbd);
+              pool[2 * POOL + sl] = __float_as_uint(k.off0);
+              pool[3 * POOL + sl] = __float_as_uint(k.off1);
+              pool[4 * POOL + sl] = __float_as_uint(k.off2);
+              pool[5 * POOL + sl] = __float_as_uint(k.gmax);
+            }
           }
+          if (gl == 0) *gbest = st.y;
         } else {
           exhausted = true;
         }
@@ -1380,6 +1507,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
     // Idle lanes take subtrees off the top of the pool.
     const bool want = have && !busy;
     const uint64_t wmask = __ballot(want) & gmask;
+    bool fresh = false;  // taken in the handed-over form: the parent branch has to be read first
     if (want) {
       const uint32_t rank = (uint32_t)__popcll(wmask & below);
       if (rank < count) {
@@ -1389,7 +1517,9 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         off0 = __uint_as_float(pool[2 * POOL + sl]);
         off1 = __uint_as_float(pool[3 * POOL + sl]);
         off2 = __uint_as_float(pool[4 * POOL + sl]);
-        gmax = __uint_as_float(pool[5 * POOL + sl]);
+        const uint32_t gb = pool[5 * POOL + sl];
+        gmax = __uint_as_float(gb & 0x7FFFFFFFu);
+        fresh = (gb >> 31) != 0u;
         busy = bm >= nbd;  // the bound may have tightened since the subtree was kept
       }
     }
@@ -1403,7 +1533,18 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
     uint32_t p_ref = 0;
     float p_nbd = 0.0f, p_off0 = 0.0f, p_off1 = 0.0f, p_off2 = 0.0f, p_gmax = 0.0f;
     if (busy) {
-      if (!(ref & kLeafBit)) {
+      if (fresh) {  // enter the far child of a pending record (as traverse() does)
+        const uint32_t axis = (ref >> 28) & 3u;
+        const bool far_is_right = (ref & kRecSide) != 0;
+        const uint4 nd = nodes[ref & kRecIdxMask];
+        const float plane = far_is_right ? __uint_as_float(nd.y) : __uint_as_float(nd.x);
+        const float dv = f_sub(plane, sel3(axis, qx, qy, qz));
+        const float new_off = f_mul(dv, dv);
+        off0 = axis == 0 ? new_off : off0;
+        off1 = axis == 1 ? new_off : off1;
+        off2 = axis == 2 ? new_off : off2;
+        ref = far_is_right ? nd.w : nd.z;
+      } else if (!(ref & kLeafBit)) {
         const uint32_t idx = ref & kBranchIdxMask;
         const uint32_t axis = (ref >> 29) & 3u;
         const uint4 nd = nodes[idx];
@@ -1434,18 +1575,24 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if ((uint32_t)u < cnt) {
-            PTK_KEEP4(p[u]);
             const float dx = f_sub(qx, p[u].x);
             const float dy = f_sub(qy, p[u].y);
             const float dz = f_sub(qz, p[u].z);
             const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
             if (d < cd) {
               cd = d;
-              ci = __float_as_int(p[u].w);
-              cmulti = false;
+              cpos = begin + (uint32_t)u;
               cok = gmax <= d;
-            } else if (d == cd) {
-              cmulti = true;
+            } else if (d == cd && d <= best) {  // an exact tie that can still matter: the one the reference visits first
+              if (tie_budget == 0u) {
+                cok = false;
+              } else {
+                --tie_budget;
+                if (!dfs_before(t, ranges, qx, qy, qz, cpos, begin + (uint32_t)u)) {
+                  cpos = begin + (uint32_t)u;
+                  cok = gmax <= d;
+                }
+              }
             }
           }
         }
@@ -1481,22 +1628,49 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
     // A query is done when its pool is empty and no lane of the group holds a subtree.
     const uint64_t bmask = __ballot(busy) & gmask;
     const bool done = have && count == 0u && bmask == 0ull;
-    const float dstar = __uint_as_float(*gbest);
-    const bool mine = done && cd == dstar;
-    const uint64_t mm = __ballot(mine) & gmask;
-    const uint64_t bad = __ballot(mine && (cmulti || !cok)) & gmask;
-    if (done) {
-      if (!failed && __popcll(mm) == 1 && bad == 0ull) {
-        if (mine) {
-          Neighbor nb;
-          nb.index = ci;
-          nb.distance = cd;
-          out[qi] = nb;
-        }
-      } else if (gl == 0) {
-        redo_list[atomicAdd(&cont.meta[kMetaRedo], 1u)] = e;
+    if (__ballot(done) != 0ull) {
+      const float dstar = __uint_as_float(*gbest);
+      // (A minimum of exactly 0 is safe -- every term of such a distance is 0, so is every box
+      // distance above the point, and nothing is pruned at 0 -- but not one in the denormal range.)
+      if (dstar != 0.0f && dstar < 1e-30f) failed = true;
+      // Lanes holding a point at the minimum; several: keep the one the reference visits first.
+      bool mine = done && !failed && cd == dstar;
+      for (;;) {
+        const uint64_t mm = __ballot(mine) & gmask;
+        const bool several = done && __popcll(mm) > 1;
+        if (__ballot(several) == 0ull) break;
+        const int la = several ? (int)__builtin_ctzll(mm) : (int)lane;
+        const int lb = several ? (int)__builtin_ctzll(mm & (mm - 1ull)) : (int)lane;
+        const uint32_t pos_b = (uint32_t)__shfl((int)cpos, lb);
+        int a_first = 1;
+        if (several && (int)lane == la) a_first = dfs_before(t, ranges, qx, qy, qz, cpos, pos_b) ? 1 : 0;
+        a_first = __shfl(a_first, la);
+        if (several && (int)lane == (a_first ? lb : la)) mine = false;
       }
-      have = false;
+      const uint64_t mm = __ballot(mine) & gmask;
+      const uint64_t good = __ballot(mine && cok) & gmask;
+      if (done) {
+        if (failed) {
+          if (gl == 0) redo_list[atomicAdd(&cont.meta[kMetaRedo], 1u)] = e;
+        } else if (!(dstar < start_d)) {  // nothing closer than what the reference had already found
+          if (gl == 0) {
+            Neighbor nb;
+            nb.index = (int32_t)start_i;
+            nb.distance = start_d;
+            out[qi] = nb;
+          }
+        } else if (__popcll(mm) == 1 && good == mm) {
+          if (mine) {
+            Neighbor nb;
+            nb.index = __float_as_int(pts[cpos].w);
+            nb.distance = cd;
+            out[qi] = nb;
+          }
+        } else if (gl == 0) {
+          redo_list[atomicAdd(&cont.meta[kMetaRedo], 1u)] = e;
+        }
+        have = false;
+      }
     }
   }
 }

@@ -434,9 +434,9 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
 //      run as fibers), default phase 2
 //   4  as 3 with one-point leaf batches and three narrow tiers (1, 4 and 16 lanes per wave)
 //   5  as 3, phase 2 capped at 2 far children per query, the rest through the cooperative search
-//      (16 lanes per query) and the redo pass            6  cap 1, 64 lanes per query
-//   7  cap 1, 8 lanes per query with an 8-entry pool: overflows, so most queries are redone
-//   8  cap 3, 32 lanes per query
+//      (16 lanes per query) and the redo pass; room for the stacks of a part of the queries only
+//   6  cap 1, 64 lanes per query, no room for stacks: every search starts again from the root
+//   7  cap 1, 8 lanes per query            8  cap 3, 32 lanes per query
 // emu_last_coop(): {queries phase 2 gave up on, queries the cooperative search could not certify}.
 static uint32_t g_last_heavy = 0, g_last_redo = 0;
 void emu_last_coop(uint32_t* heavy, uint32_t* redo) {
@@ -501,7 +501,12 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
   const uint32_t cap = variant == 5 ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
-  std::vector<uint32_t> heavy_list(nq, 0xEEEEEEEEu), redo_list(nq, 0xEEEEEEEEu);
+  std::vector<uint32_t> heavy_list(nq, 0xEEEEEEEEu), redo_list(nq, 0xEEEEEEEEu), ntasks(nq, 0xEEEEEEEEu);
+  // Room for the stacks of two thirds of the queries handed over at most: the rest starts from the root.
+  const uint32_t max_heavy = variant == 6 ? 0u : (uint32_t)(nq / 6 + 1);
+  std::vector<ptk::Task> tasks((size_t)max_heavy * ptk::kMaxTasks + 1);
+  ptk::Handover ho{meta.data(), heavy_list.data(), ntasks.data(), tasks.data(), max_heavy, 0u};
+  const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
   gridDim.x = blocks;
   blockDim.x = 64;
   for (uint32_t b = 0; b < blocks; ++b) {
@@ -511,17 +516,17 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
       if (variant == 2 || variant == 4)
         ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
       else
-        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, heavy_list.data());
+        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho);
     }
   }
   g_last_heavy = meta[ptk::kMetaHeavy];
   g_last_redo = 0;
   if (cap) {
     for_each_wave(3, [&] {
-      if (variant == 5) ptk::knn1_coop_kernel<16, 128>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
-      else if (variant == 6) ptk::knn1_coop_kernel<64, 256>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
-      else if (variant == 7) ptk::knn1_coop_kernel<8, 8>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
-      else ptk::knn1_coop_kernel<32, 192>(t->dev, qs.data(), o, cont, heavy_list.data(), redo_list.data());
+      if (variant == 5) ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      else if (variant == 6) ptk::knn1_coop_kernel<64, 192>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      else if (variant == 7) ptk::knn1_coop_kernel<8, 64>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      else ptk::knn1_coop_kernel<32, 128>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
     });
     if (meta[ptk::kMetaCoopHead] < meta[ptk::kMetaHeavy]) return -5;  // every listed query was taken
     g_last_redo = meta[ptk::kMetaRedo];
