@@ -97,6 +97,10 @@ struct Workspace {
   hipEvent_t done = nullptr;
   bool has_work = false;
   const uint32_t* last_meta = nullptr;  // Cont::meta of the last two-phase k = 1 search (ptk_debug_knn1_counts)
+  // A second stream for kernels of one search that may run side by side, forked from and joined to
+  // the caller's stream with events (created on first use, under `mutex`).
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
 
   // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
   // it must survive until the fill pass of the same batch while other searches reuse `base`.
@@ -425,6 +429,22 @@ class Scratch {
     return PTK_OK;
   }
   void note_meta(const uint32_t* meta) { ws_.last_meta = meta; }
+  // The block's side stream and its fork / join events; false if they cannot be created.
+  bool side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
+    if (ws_.side == nullptr) {
+      if (hipStreamCreateWithFlags(&ws_.side, hipStreamNonBlocking) != hipSuccess) ws_.side = nullptr;
+      if (ws_.side && hipEventCreateWithFlags(&ws_.fork, hipEventDisableTiming) != hipSuccess) ws_.fork = nullptr;
+      if (ws_.side && hipEventCreateWithFlags(&ws_.join, hipEventDisableTiming) != hipSuccess) ws_.join = nullptr;
+    }
+    if (!ws_.side || !ws_.fork || !ws_.join) {
+      (void)hipGetLastError();
+      return false;
+    }
+    *side = ws_.side;
+    *fork = ws_.fork;
+    *join = ws_.join;
+    return true;
+  }
   template <class T>
   T* take(size_t count) {
     const size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
@@ -737,11 +757,14 @@ uint32_t phase2_cap(float e) {
 
 template <int G, int POOL>
 int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
-                     const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s) {
+                     const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, uint32_t range) {
   constexpr size_t smem = (size_t)(64 / G) * (6 * POOL + 1) * 4;
-  const int waves = std::max(1, env_int("PTK_COOP_WAVES", 4096));
+  // As many waves as can be resident at once (LDS-bound; 256 CUs x 160 KiB), each group working
+  // through its share of the list: a second round of blocks would start when most of the work is done.
+  const int resident = 256 * (int)std::min<size_t>(24, (160 * 1024) / (smem + 512));
+  const int waves = std::max(1, env_int("PTK_COOP_WAVES", resident));
   hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, POOL>), dim3(waves), dim3(64), smem, s, t->dev,
-                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list);
+                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, range);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
@@ -805,30 +828,70 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   {
     Timer timer(t, s);
-    PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq, 0, 16, s));
+    // With the cap the order inside the heavy classes no longer matters (no query runs long):
+    // one radix pass over the three class bits, stable, so every class keeps its Morton order.
+    const int key_bits = env_int("PTK_CONT_BITS", cap ? 3 : 16);
+    PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq,
+                                      key_bits >= 16 ? 0 : 16 - key_bits, 16, s));
     hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont,
                        (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass), tiers, extra_waves,
                        (uint32_t)env_int("PTK_DEAL", 1));
     timer.stop(2, 0);
   }
+  auto coop = [&](hipStream_t cs, uint32_t range) {  // G lanes per query on the listed queries
+    switch (env_int("PTK_COOP_G", 16)) {
+      case 8: return launch_knn1_coop<8, 64>(t, qs, d_out, cont, ho, redo_list, cs, range);
+      case 32: return launch_knn1_coop<32, 128>(t, qs, d_out, cont, ho, redo_list, cs, range);
+      case 64: return launch_knn1_coop<64, 192>(t, qs, d_out, cont, ho, redo_list, cs, range);
+      default: return launch_knn1_coop<16, 96>(t, qs, d_out, cont, ho, redo_list, cs, range);
+    }
+  };
+  const dim3 p2_grid(blocks + 1 + extra_waves);
+  const size_t p2_lds = (size_t)S2 * 64 * 8;
+  hipStream_t side = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  const bool overlap = cap != 0 && env_int("PTK_COOP_OVERLAP", 1) != 0 && scratch.side_stream(&side, &ev_fork, &ev_join);
+  if (!overlap) {
+    {
+      Timer timer(t, s);
+      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
+                         d_out, cont, ids_out, cap, ho, 0u);
+      timer.stop(3, 0);
+    }
+    PTK_HIP(hipGetLastError());
+    if (cap) {  // the queries phase 2 gave up on, then whatever the cooperative search could not certify
+      Timer timer(t, s);
+      rc = coop(s, 0);
+      if (rc != PTK_OK) return rc;
+      hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), p2_lds, s, t->dev, qs, e_inv,
+                         d_out, cont, redo_list);
+      PTK_HIP(hipGetLastError());
+      timer.stop(3, 0);
+    }
+    return PTK_OK;
+  }
+  // The heavy tiers first (short: every query stops at the cap); what they hand over is searched
+  // cooperatively on the side stream WHILE the light tier runs here; the light tier's own few
+  // leftovers follow.  One timer spans the overlapped region: search_ms stays the traversal's wall time.
   {
     Timer timer(t, s);
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), dim3(blocks + 1 + extra_waves), dim3(64),
-                       (size_t)S2 * 64 * 8, s, t->dev, qs, e_inv, d_out, cont, ids_out, cap, ho);
-    timer.stop(3, 0);
-  }
-  PTK_HIP(hipGetLastError());
-  if (cap) {  // the queries phase 2 gave up on: G lanes per query, then whatever that could not certify
-    Timer timer(t, s);
-    switch (env_int("PTK_COOP_G", 16)) {
-      case 8: rc = launch_knn1_coop<8, 64>(t, qs, d_out, cont, ho, redo_list, s); break;
-      case 32: rc = launch_knn1_coop<32, 128>(t, qs, d_out, cont, ho, redo_list, s); break;
-      case 64: rc = launch_knn1_coop<64, 192>(t, qs, d_out, cont, ho, redo_list, s); break;
-      default: rc = launch_knn1_coop<16, 96>(t, qs, d_out, cont, ho, redo_list, s); break;
-    }
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
+                       d_out, cont, ids_out, cap, ho, 1u);
+    hipLaunchKernelGGL(ptk::knn1_snapshot_kernel, dim3(1), dim3(1), 0, s, cont);
+    PTK_HIP(hipGetLastError());
+    PTK_HIP(hipEventRecord(ev_fork, s));
+    PTK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    rc = coop(side, 1);
     if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), (size_t)S2 * 64 * 8, s, t->dev,
-                       qs, e_inv, d_out, cont, redo_list);
+    PTK_HIP(hipEventRecord(ev_join, side));
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
+                       d_out, cont, ids_out, cap, ho, 2u);
+    PTK_HIP(hipGetLastError());
+    PTK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    rc = coop(s, 2);
+    if (rc != PTK_OK) return rc;
+    hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), p2_lds, s, t->dev, qs, e_inv,
+                       d_out, cont, redo_list);
     PTK_HIP(hipGetLastError());
     timer.stop(3, 0);
   }
@@ -1060,6 +1123,16 @@ void ptk_tree_destroy(ptk_tree* t) {
       if (w.done) (void)hipEventDestroy(w.done);
       if (w.base) (void)hipFree(w.base);
     }
+    auto drop_side = [](Workspace& w) {
+      if (w.side) {
+        (void)hipStreamSynchronize(w.side);
+        (void)hipStreamDestroy(w.side);
+      }
+      if (w.fork) (void)hipEventDestroy(w.fork);
+      if (w.join) (void)hipEventDestroy(w.join);
+    };
+    drop_side(t->ws);
+    for (Workspace& w : t->extra_ws) drop_side(w);
     if (t->io.d_in) (void)hipFree(t->io.d_in);
     if (t->io.d_out) (void)hipFree(t->io.d_out);
     if (t->io.stream) (void)hipStreamDestroy(t->io.stream);

@@ -482,7 +482,7 @@ struct Task {
 };
 // Counters in Cont::meta (zeroed by knn1_phase_meta_kernel): queries phase 2 gave up on, the next
 // entry of that list to hand to a group, queries the cooperative search could not certify.
-constexpr uint32_t kMetaHeavy = 24, kMetaCoopHead = 25, kMetaRedo = 26;
+constexpr uint32_t kMetaHeavy = 24, kMetaHeavyA = 25, kMetaRedo = 26;  // HeavyA: the list's length after the heavy tiers
 constexpr uint32_t kMaxTasks = 64;               // tasks a capped traversal can hand over per query
 constexpr uint32_t kTasksFromRoot = 0xFFFFFFFFu;  // more than that (or no room): search again from the root
 constexpr uint32_t kTasksRedo = 0xFFFFFFFEu;      // non-monotone box distances met: only the reference order will do
@@ -1257,7 +1257,7 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
   cont.meta[5] = wave;
   cont.meta[6] = deal;
   cont.meta[kMetaHeavy] = 0;
-  cont.meta[kMetaCoopHead] = 0;
+  cont.meta[kMetaHeavyA] = 0;
   cont.meta[kMetaRedo] = 0;
 }
 
@@ -1269,13 +1269,16 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
 template <int S, int OVF, int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
-    const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, Handover ho = Handover{}) {
+    const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, Handover ho = Handover{}, uint32_t part = 0) {
   const uint32_t n2 = cont.meta[0];
   const uint32_t heavy = cont.meta[1];
   const uint32_t heavy_waves = cont.meta[2];
   const uint32_t top = cont.meta[4];
   const uint32_t top_waves = cont.meta[5];
-  const uint32_t wave = blockIdx.x;
+  // part 1: the narrow and dealt tiers only; part 2: the light tier only (two launches, so that the
+  // cooperative search of what the heavy tiers hand over can run beside the light tier).
+  if (part == 1 && blockIdx.x >= top_waves + heavy_waves) return;
+  const uint32_t wave = part == 2 ? blockIdx.x + top_waves + heavy_waves : blockIdx.x;
   const uint32_t lane = threadIdx.x;
   // Three tiers of the sorted list, most expensive first (blocks are dispatched in order):
   //   narrow the head of the ranked classes in up to kMaxTiers tiers of few lanes per wavefront:
@@ -1377,7 +1380,7 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
 // them too, so if one of them is p* it is the best handed over, and it wins ties against
 // anything found here (it came first).
 //
-// Groups take queries from the list through an atomic counter until it is exhausted.
+// Group i of the launch takes entries i, i + groups, ... of the list.
 
 // True if, in the reference's depth-first order for query q, the point at record position `a`
 // comes before the one at `b` (a != b): they part ways at some branch, where the nearer child is
@@ -1408,10 +1411,14 @@ __device__ inline bool dfs_before(const DevTree& t, const uint2* __restrict__ ra
 
 constexpr uint32_t kCoopTieBudget = 6;  // exact ties a lane resolves per query before it asks for a redo
 
+// After the heavy tiers of phase 2: how long the list is now (the light tier appends behind).
+__global__ void knn1_snapshot_kernel(Cont cont) { cont.meta[kMetaHeavyA] = cont.meta[kMetaHeavy]; }
+
+// range: 0 = the whole list, 1 = what the heavy tiers listed, 2 = what the light tier added.
 template <int G, int POOL>
 __global__ __launch_bounds__(64) void knn1_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
-    Handover ho, uint32_t* __restrict__ redo_list) {
+    Handover ho, uint32_t* __restrict__ redo_list, uint32_t range = 0) {
   static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per query");
   static_assert(POOL >= (int)kMaxTasks, "the pool must hold a handed-over stack");
   constexpr int NG = 64 / G;
@@ -1424,7 +1431,8 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   const uint64_t below = gmask & ((1ull << lane) - 1ull);  // lanes of this group before this one
   LdsU32* pool = (LdsU32*)ptk_smem + g * (6 * POOL);       // [field][slot] of this group
   LdsU32* gbest = (LdsU32*)ptk_smem + NG * (6 * POOL) + g;  // bits of the group's best distance
-  const uint32_t n_heavy = cont.meta[kMetaHeavy];
+  const uint32_t n_heavy = cont.meta[range == 1 ? kMetaHeavyA : kMetaHeavy];
+  const uint32_t first = range == 2 ? cont.meta[kMetaHeavyA] : 0u;
 
   bool have = false, exhausted = false, busy = false, failed = false;
   uint32_t count = 0;  // subtrees in the pool (the same value in every lane of the group)
@@ -1439,15 +1447,18 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   uint32_t tie_budget = 0;
   float start_d = 0.0f;  // the best handed over (phase 2's own, already the reference's)
   uint32_t start_i = 0;
+  uint32_t next_idx = first + blockIdx.x * (uint32_t)NG + g;  // this group's next entry of the list
 
   for (;;) {
     // Groups without a query take the next one.
     const bool need = !have && !exhausted;
     if (__ballot(need) != 0ull) {
-      uint32_t idx = 0xFFFFFFFFu;
-      if (need && gl == 0) idx = atomicAdd(&cont.meta[kMetaCoopHead], 1u);
-      idx = (uint32_t)__shfl((int)idx, (int)(g * G));
       if (need) {
+        // Entry `group`, `group + groups`, ... of the list: a shared counter would hand the queries
+        // out more evenly, but one atomic per query on one address is what bounds the launch then
+        // (measured: ~11 ns per query whatever the number of waves).
+        const uint32_t idx = next_idx;
+        next_idx += gridDim.x * (uint32_t)NG;
         if (idx < n_heavy) {
           e = ho.heavy_list[idx];
           const float4 qrec = qs[e];
@@ -1533,23 +1544,36 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
     uint32_t p_ref = 0;
     float p_nbd = 0.0f, p_off0 = 0.0f, p_off1 = 0.0f, p_off2 = 0.0f, p_gmax = 0.0f;
     if (busy) {
+      // Every lane's first 16 bytes come from ONE load instruction, whatever it holds -- a pending
+      // record (the parent branch), a branch, or a leaf (its first point; the other three follow at
+      // once) -- so that a step waits for memory once, not once per kind of node.
+      const bool is_leaf = !fresh && (ref & kLeafBit) != 0u;
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      const uint32_t begin = lv >> t.cbits;
+      const uint32_t cnt = lv & t.cmask;
+      const uint4* src = is_leaf ? reinterpret_cast<const uint4*>(pts + begin)
+                                 : nodes + (fresh ? (ref & kRecIdxMask) : (ref & kBranchIdxMask));
+      const uint4 w0 = *src;
+      float4 p[4];
+      p[0] = make_float4(__uint_as_float(w0.x), __uint_as_float(w0.y), __uint_as_float(w0.z), __uint_as_float(w0.w));
+      if (is_leaf) {
+#pragma unroll
+        for (int u = 1; u < 4; ++u) p[u] = pts[begin + u];
+      }
       if (fresh) {  // enter the far child of a pending record (as traverse() does)
         const uint32_t axis = (ref >> 28) & 3u;
         const bool far_is_right = (ref & kRecSide) != 0;
-        const uint4 nd = nodes[ref & kRecIdxMask];
-        const float plane = far_is_right ? __uint_as_float(nd.y) : __uint_as_float(nd.x);
+        const float plane = far_is_right ? __uint_as_float(w0.y) : __uint_as_float(w0.x);
         const float dv = f_sub(plane, sel3(axis, qx, qy, qz));
         const float new_off = f_mul(dv, dv);
         off0 = axis == 0 ? new_off : off0;
         off1 = axis == 1 ? new_off : off1;
         off2 = axis == 2 ? new_off : off2;
-        ref = far_is_right ? nd.w : nd.z;
-      } else if (!(ref & kLeafBit)) {
-        const uint32_t idx = ref & kBranchIdxMask;
+        ref = far_is_right ? w0.w : w0.z;
+      } else if (!is_leaf) {
         const uint32_t axis = (ref >> 29) & 3u;
-        const uint4 nd = nodes[idx];
-        const float left_max = __uint_as_float(nd.x);
-        const float right_min = __uint_as_float(nd.y);
+        const float left_max = __uint_as_float(w0.x);
+        const float right_min = __uint_as_float(w0.y);
         const float v = sel3(axis, qx, qy, qz);
         const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
         const float dv = f_sub(go_left ? right_min : left_max, v);
@@ -1557,21 +1581,15 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
         if (bm >= far_nbd) {
           push = true;
-          p_ref = go_left ? nd.w : nd.z;
+          p_ref = go_left ? w0.w : w0.z;
           p_nbd = far_nbd;
           p_off0 = axis == 0 ? new_off : off0;
           p_off1 = axis == 1 ? new_off : off1;
           p_off2 = axis == 2 ? new_off : off2;
           p_gmax = gmax < far_nbd ? far_nbd : gmax;
         }
-        ref = go_left ? nd.z : nd.w;
+        ref = go_left ? w0.z : w0.w;
       } else {
-        const uint32_t lv = ref & 0x7FFFFFFFu;
-        const uint32_t begin = lv >> t.cbits;
-        const uint32_t cnt = lv & t.cmask;
-        float4 p[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) p[u] = pts[begin + u];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
           if ((uint32_t)u < cnt) {

@@ -437,6 +437,8 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
 //      (16 lanes per query) and the redo pass; room for the stacks of a part of the queries only
 //   6  cap 1, 64 lanes per query, no room for stacks: every search starts again from the root
 //   7  cap 1, 8 lanes per query            8  cap 3, 32 lanes per query
+//   9  as 5 in the two-launch form: heavy tiers, list snapshot, cooperative search of that part,
+//      light tier, cooperative search of what it added
 // emu_last_coop(): {queries phase 2 gave up on, queries the cooperative search could not certify}.
 static uint32_t g_last_heavy = 0, g_last_redo = 0;
 void emu_last_coop(uint32_t* heavy, uint32_t* redo) {
@@ -500,35 +502,47 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   }
   ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
-  const uint32_t cap = variant == 5 ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
+  const uint32_t cap = (variant == 5 || variant == 9) ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
   std::vector<uint32_t> heavy_list(nq, 0xEEEEEEEEu), redo_list(nq, 0xEEEEEEEEu), ntasks(nq, 0xEEEEEEEEu);
   // Room for the stacks of two thirds of the queries handed over at most: the rest starts from the root.
   const uint32_t max_heavy = variant == 6 ? 0u : (uint32_t)(nq / 6 + 1);
   std::vector<ptk::Task> tasks((size_t)max_heavy * ptk::kMaxTasks + 1);
   ptk::Handover ho{meta.data(), heavy_list.data(), ntasks.data(), tasks.data(), max_heavy, 0u};
   const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
-  gridDim.x = blocks;
-  blockDim.x = 64;
-  for (uint32_t b = 0; b < blocks; ++b) {
-    blockIdx.x = b;
-    for (uint32_t l = 0; l < 64; ++l) {
-      threadIdx.x = l;
-      if (variant == 2 || variant == 4)
-        ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
-      else
-        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho);
+  auto phase2 = [&](uint32_t part) {
+    gridDim.x = blocks;
+    blockDim.x = 64;
+    for (uint32_t b = 0; b < blocks; ++b) {
+      blockIdx.x = b;
+      for (uint32_t l = 0; l < 64; ++l) {
+        threadIdx.x = l;
+        if (variant == 2 || variant == 4)
+          ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+        else
+          ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho, part);
+      }
     }
+  };
+  if (variant == 9) {
+    phase2(1);
+    ptk::knn1_snapshot_kernel(cont);
+    for_each_wave(3, [&] { ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), 1u); });
+    phase2(2);
+    for_each_wave(2, [&] { ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), 2u); });
+  } else {
+    phase2(0);
   }
   g_last_heavy = meta[ptk::kMetaHeavy];
   g_last_redo = 0;
-  if (cap) {
+  if (cap && variant != 9) {
     for_each_wave(3, [&] {
       if (variant == 5) ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
       else if (variant == 6) ptk::knn1_coop_kernel<64, 192>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
       else if (variant == 7) ptk::knn1_coop_kernel<8, 64>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
       else ptk::knn1_coop_kernel<32, 128>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
     });
-    if (meta[ptk::kMetaCoopHead] < meta[ptk::kMetaHeavy]) return -5;  // every listed query was taken
+  }
+  if (cap) {
     g_last_redo = meta[ptk::kMetaRedo];
     gridDim.x = 2;
     for (uint32_t b = 0; b < 2; ++b) {

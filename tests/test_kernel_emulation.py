@@ -160,12 +160,12 @@ def test_emulated_capped_phase2_and_cooperative_search_equal_oracle(case):
     perm, _ = emu.morton_permutation(q)
     want = ref.search_knn(q, 1)
     stats = {}
-    for variant in (5, 6, 7, 8):
+    for variant in (5, 6, 7, 8, 9):
         for p in (None, perm):
             got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
             assert got.tobytes() == want.tobytes(), (name, variant)
         stats[variant] = emu.last_coop()
-    print(name, stats)
+    assert stats[9] == stats[5]                                 # two launches, the same lists
     if name in ("uniform", "lidar", "ties"):
         assert stats[5][0] > 0 and stats[6][0] >= stats[5][0]   # the cap does hand queries over
     if name in ("uniform", "lidar"):
