@@ -850,7 +850,9 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   const size_t p2_lds = (size_t)S2 * 64 * 8;
   hipStream_t side = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  const bool overlap = cap != 0 && env_int("PTK_COOP_OVERLAP", 1) != 0 && scratch.side_stream(&side, &ev_fork, &ev_join);
+  // PTK_COOP_OVERLAP=1 (A/B only): measured slower than the plain sequence on BASELINE config 2 (2.34 vs 2.16 ms
+  // per step, profiles/r02_notes.txt: the two kernels compete for the same issue slots).
+  const bool overlap = cap != 0 && env_int("PTK_COOP_OVERLAP", 0) != 0 && scratch.side_stream(&side, &ev_fork, &ev_join);
   if (!overlap) {
     {
       Timer timer(t, s);
