@@ -12,12 +12,18 @@ timed region; the tree is built and uploaded once, outside it.
 
 For N > 1 the driver launches this file under ``torch.distributed.run``, one rank per GPU,
 tree replicated on every GPU, queries independent (no data-path collective).  Default
-``--scaling weak``: every rank searches its own full config-2 batch (7.2 M queries drawn from the
-same cloud with a different seed), so per-GPU work is fixed and ``value`` = N x 7.2 M queries / step;
-rank 0 still collects every rank's (index, distance) rows with one RCCL gather per step, issued
-asynchronously so that it overlaps the next step's search (all gathers complete inside the timed
-region).  ``--scaling strong`` is BASELINE configs[3] literally: ONE 7.2 M batch cut into N
-contiguous shards.
+``--scaling strong`` = BASELINE configs[3] literally: ONE 7.2 M batch cut into N contiguous
+shards, rank 0 collecting every rank's (index, distance) rows with one RCCL gather per step,
+issued asynchronously so that it overlaps the next step's search (all gathers complete inside the
+timed region); ``value`` is that.  The same run then times the weak form (every rank searches a
+full 7.2 M batch of its own: same cloud, another seed) and reports it as the extra object
+``"weak"``.  ``--scaling weak`` makes the weak form ``value`` instead.
+
+At N = 1 the line also carries (none of it inside the timed region of ``value``):
+``host_buffers`` (the host-pointer entry ``ptk_search_knn`` on pageable arrays: H2D + search +
+D2H), ``also`` (the same search on Morton-ordered queries and on cloud U), ``config3`` (knn = 16
+and the radius search of BASELINE configs[2] with their own roofline figures), ``pipelined``
+(two batches in flight on two HIP streams).
 
 Rank 0 prints ONE JSON line; see README.md / DESIGN.md for the field meanings.
 """
@@ -59,8 +65,11 @@ def parse_args():
     ap.add_argument("--nq", type=int, default=None, help="queries (default: config 2)")
     ap.add_argument("--leaf", type=int, default=10)
     ap.add_argument("--reorder", choices=["auto", "on", "off"], default="auto")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="N > 1: weak = a full batch per GPU, strong = one batch cut into N shards")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="N > 1: which form is `value`: strong = one batch cut into N shards (BASELINE configs[3]), "
+                         "weak = a full batch per GPU; the other one is reported as an extra object")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="N = 1: skip host_buffers / also / config3 (the headline line only)")
     ap.add_argument("--streams", type=int, default=1,
                     help="HIP streams successive steps are issued on round-robin (single GPU only).  1 (default): one "
                          "batch at a time, the per-kernel durations are those of an isolated call.  > 1: batches "
@@ -154,6 +163,112 @@ def cpu_baseline(pts, q, k, leaf, seconds):
             "build_s": round(build_s, 3)}
 
 
+def time_device_knn(tree, dq, k, steps, warmup=2):
+    """(ms per step, profile dict, last output) of `steps` device-resident searches on the current stream."""
+    import torch
+
+    out = torch.empty((dq.shape[0], k, 2), dtype=torch.int32, device=dq.device)
+    for _ in range(warmup):
+        tree.search_knn(dq, k, out)
+    torch.cuda.synchronize()
+    tree.profile(enable=True, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tree.search_knn(dq, k, out)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    prof = tree.profile(enable=False, reset=True)
+    return ms, prof, out
+
+
+def roofline_of(b_per_q, nq, kernel_ms):
+    achieved = (b_per_q * nq) / (kernel_ms * 1e-3) / 1e9 if kernel_ms > 0 else 0.0
+    return {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 5), "kernel_ms": round(kernel_ms, 4),
+            "bytes_per_query": round(b_per_q, 1)}
+
+
+def also_entry(pt, ds, oracle, cloud, order, pts, q, tree, leaf, steps, sample):
+    """The headline search on another (cloud, query order): Mq/s, kernel time, roofline fraction, parity sample."""
+    import torch
+
+    if order == "morton":
+        q = np.ascontiguousarray(q[ds.morton_order(q)])
+    dq = torch.from_numpy(q).to(f"cuda:{tree.info()['device']}")
+    ms, prof, out = time_device_knn(tree, dq, 1, steps)
+    ref = oracle.Oracle(pts, leaf, "port")
+    rng = np.random.default_rng(7)
+    cs = np.sort(rng.choice(len(q), size=min(sample, len(q)), replace=False))
+    want, cnt = ref.search_knn(q[cs], 1, counters=True)
+    ref.close()
+    mean = cnt.astype(np.float64).mean(axis=0)
+    b = 12 + 8 + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
+    got = pt.DeviceNeighbors(out).numpy()[cs][:, None]
+    kernel_ms = prof["search_ms"] / max(int(prof["launches"]), 1)
+    return {"cloud": cloud, "query_order": order, "value": round(len(q) / ms / 1e3, 3), "unit": "Mqueries/s",
+            "ms_per_step": round(ms, 4), "steps": steps, "reorder_ms": round(prof["reorder_ms"] / steps, 4),
+            "parity_sample_ok": bool(got.tobytes() == want.tobytes()),
+            "roofline": roofline_of(b, len(q), kernel_ms)}
+
+
+def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
+    """BASELINE configs[2] on the headline clouds: knn = 16 and search_radius r = 1.0 (squared radius 1.0)."""
+    import torch
+
+    nq = len(q)
+    ref = oracle.Oracle(pts, leaf, "port")
+    ref.set_threads(ref.max_threads())
+    rng = np.random.default_rng(7)
+    cs = np.sort(rng.choice(nq, size=min(sample, nq), replace=False))
+    res = {}
+    # ---- knn = 16: one kernel (k-list in registers)
+    k, steps = 16, 5
+    ms, prof, out = time_device_knn(tree, dq, k, steps, warmup=1)
+    want, cnt = ref.search_knn(q[cs], k, counters=True)
+    got = pt.DeviceNeighbors(out).numpy()[cs]
+    del out
+    mean = cnt.astype(np.float64).mean(axis=0)
+    b = 12 + 8 * k + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
+    kernel_ms = prof["search_ms"] / max(int(prof["launches"]), 1)
+    r = roofline_of(b, nq, kernel_ms)
+    r["kernel"] = "ptk::knn_reg_kernel<16>"
+    r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
+    res["knn16"] = {"value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms, 4), "steps": steps,
+                    "parity_sample_ok": bool(got.tobytes() == want.tobytes()), "roofline": r}
+    # ---- radius: count pass that captures the rows + scan + copy
+    radius, steps = 1.0, 3
+    off, raw = tree.search_radius_device(dq, radius)
+    torch.cuda.synchronize()
+    tree.profile(enable=True, reset=True)
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        off, raw = tree.search_radius_device(dq, radius)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    prof = tree.profile(enable=False, reset=True)
+    hits = int(off[-1].item())
+    rs = cs[:: max(1, len(cs) // 20_000)]
+    o2, flat, rcnt = ref.search_radius(q[rs], radius, counters=True)
+    offs = off.cpu().numpy()
+    rawn = raw.cpu().numpy()
+    ok = True
+    for j in range(0, len(rs), 37):
+        a = rawn[offs[rs[j]]:offs[rs[j] + 1]].view(pt.NEIGHBOR)[:, 0]
+        ok = ok and a.tobytes() == flat[int(o2[j]):int(o2[j + 1])].tobytes()
+    del raw, rawn
+    mean = rcnt.astype(np.float64).mean(axis=0)
+    b = 12 + 8 * (hits / nq) + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
+    kernel_ms = prof["search_ms"] / steps
+    r = roofline_of(b, nq, kernel_ms)
+    r["kernel"] = "ptk::radius_capture_kernel + ptk::radius_scatter_kernel"
+    r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
+    res["radius"] = {"radius_squared": radius, "value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s",
+                     "ms_per_step": round(ms, 4), "steps": steps, "hits_per_query": round(hits / nq, 2),
+                     "parity_sample_ok": bool(ok), "roofline": r}
+    ref.close()
+    return res
+
+
 def main():
     args = parse_args()
     import torch
@@ -181,12 +296,15 @@ def main():
     k = args.k
     dim = 3
 
-    weak = args.scaling == "weak" and world > 1
+    def own_batch(r):  # rank r's batch of the weak form: same cloud, its own seed
+        if r == 0:
+            return None
+        qq = (ds.lidar_cloud(nq, seed=2 + r, pose=(3.0, 1.5), unit_scale=20.0) if args.cloud == "L"
+              else ds.uniform_cloud(nq, 3, seed=2 + r, scale=100.0))
+        return np.ascontiguousarray(qq[ds.morton_order(qq)]) if args.order == "morton" else qq
+
     t0 = time.perf_counter()
     pts, q = ds.config2_clouds(args.cloud, n, nq)
-    if weak and rank > 0:  # this rank's own batch: same cloud, different seed
-        q = (ds.lidar_cloud(nq, seed=2 + rank, pose=(3.0, 1.5), unit_scale=20.0) if args.cloud == "L"
-             else ds.uniform_cloud(nq, 3, seed=2 + rank, scale=100.0))
     if args.order == "morton":
         q = np.ascontiguousarray(q[ds.morton_order(q)])
     gen_s = time.perf_counter() - t0
@@ -202,59 +320,70 @@ def main():
 
     from pico_tree_amd.sharded import ShardedSearch, padded_shard, shard_of
 
-    if weak:  # every rank: its whole batch
-        sh = shard_of(nq * world, world, rank)
-        per, lo, hi = nq, 0, nq
-        dq = torch.from_numpy(q).to(dev)
-    else:     # contiguous ranges of ceil(nq / world) rows of ONE batch, in caller order
-        sh = shard_of(nq, world, rank)
-        per, lo, hi = sh.per, sh.lo, sh.hi
-        dq = torch.from_numpy(padded_shard(q, sh)).to(dev)
-    total_queries = nq * world if weak else nq
-    sharded = ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw,
-                            lambda: torch.empty((per, k, 2), dtype=torch.int32, device=dev))
-
-    n_streams = max(1, args.streams) if world == 1 else 1
-    if n_streams > 1:  # successive batches on several streams of ONE handle (per-stream scratch blocks)
-        streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
-        lanes = [ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw,
-                               lambda: torch.empty((per, k, 2), dtype=torch.int32, device=dev), depth=1)
-                 for _ in range(n_streams)]
-        issued = [0]
-
-        def step():
-            i = issued[0] % n_streams
-            issued[0] += 1
-            with torch.cuda.stream(streams[i]):
-                return lanes[i].step(dq)
-    else:
-        def step():
-            return sharded.step(dq)
-
-    def fence():
+    def fence(sharded):
         sharded.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    tree.profile(enable=True, reset=True)
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        out = step()
-    fence()
-    elapsed = time.perf_counter() - t0
-    prof = tree.profile(enable=False, reset=True)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
+    def run_form(weak):
+        """Times `args.steps` steps of one form.  weak: every rank its own full batch; otherwise one batch
+        in `world` contiguous shards (at world == 1 the two coincide).  Returns a dict."""
+        if weak and world > 1:  # every rank: its whole batch
+            sh = shard_of(nq * world, world, rank)
+            per, lo, hi = nq, 0, nq
+            mine = own_batch(rank)
+            dq = torch.from_numpy(q if mine is None else mine).to(dev)
+        else:     # contiguous ranges of ceil(nq / world) rows of ONE batch, in caller order
+            sh = shard_of(nq, world, rank)
+            per, lo, hi = sh.per, sh.lo, sh.hi
+            dq = torch.from_numpy(padded_shard(q, sh)).to(dev)
+        total = nq * world if (weak and world > 1) else nq
+        sharded = ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw,
+                                lambda: torch.empty((per, k, 2), dtype=torch.int32, device=dev))
+        n_streams = max(1, args.streams) if world == 1 else 1
+        if n_streams > 1:  # successive batches on several streams of ONE handle (per-stream scratch blocks)
+            streams = [torch.cuda.Stream(device=dev) for _ in range(n_streams)]
+            lanes = [ShardedSearch(sh, lambda qq, oo: tree.search_knn(qq, k, oo).raw,
+                                   lambda: torch.empty((per, k, 2), dtype=torch.int32, device=dev), depth=1)
+                     for _ in range(n_streams)]
+            issued = [0]
 
-    ms_per_step = elapsed / args.steps * 1e3
-    value = total_queries / (elapsed / args.steps) / 1e6
+            def step():
+                i = issued[0] % n_streams
+                issued[0] += 1
+                with torch.cuda.stream(streams[i]):
+                    return lanes[i].step(dq)
+        else:
+            def step():
+                return sharded.step(dq)
+
+        for _ in range(args.warmup):
+            step()
+        fence(sharded)
+        tree.profile(enable=True, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence(sharded)
+        elapsed = time.perf_counter() - t0
+        prof = tree.profile(enable=False, reset=True)
+        if world > 1:
+            tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            elapsed = float(tmax.item())
+        return {"weak": weak and world > 1, "elapsed": elapsed, "prof": prof, "out": out, "dq": dq, "sharded": sharded,
+                "per": per, "lo": lo, "hi": hi, "total": total, "n_streams": n_streams,
+                "ms_per_step": elapsed / args.steps * 1e3, "value": total / (elapsed / args.steps) / 1e6}
+
+    main_is_weak = args.scaling == "weak" and world > 1
+    form = run_form(main_is_weak)
+    other = run_form(not main_is_weak) if world > 1 else None
+    weak = form["weak"]
+    per, lo, hi, out, dq, sharded, prof = (form[x] for x in ("per", "lo", "hi", "out", "dq", "sharded", "prof"))
+    total_queries, n_streams = form["total"], form["n_streams"]
+    ms_per_step, value = form["ms_per_step"], form["value"]
 
     # Context, never `value`: the same batches with two in flight on two HIP streams of the same handle
     # (DESIGN.md section 8, "Pipelined batches").  Single GPU, default stream count only.
@@ -275,6 +404,7 @@ def main():
         pipelined = {"streams": 2, "value": round(total_queries * args.steps / dt / 1e6, 3), "unit": "Mqueries/s",
                      "ms_per_step": round(dt / args.steps * 1e3, 4),
                      "rows_equal_single_stream": bool(torch.equal(outs2[(args.steps - 1) % 2], out))}
+        del outs2
 
     result = None
     if rank == 0:
@@ -290,10 +420,7 @@ def main():
         if world > 1:  # and the rows rank 0 gathered from rank 1 (last step)
             rows = sharded.result(rows_per_rank=per if weak else None)
             if weak:
-                q1 = (ds.lidar_cloud(nq, seed=3, pose=(3.0, 1.5), unit_scale=20.0) if args.cloud == "L"
-                      else ds.uniform_cloud(nq, 3, seed=3, scale=100.0))
-                if args.order == "morton":
-                    q1 = np.ascontiguousarray(q1[ds.morton_order(q1)])
+                q1 = own_batch(1)
                 got1 = pt.DeviceNeighbors(rows[per:2 * per]).numpy()[sample]
                 want1 = ref_small.search_knn(q1[sample], k)
             else:
@@ -324,29 +451,62 @@ def main():
                     "algorithmic_gb_per_launch": round(b_per_q * q_per_launch / 1e9, 3),
                     "kernel": "+".join(TRAVERSAL_KERNELS) if k == 1 else "ptk::knn_kernel",
                     "kernel_ms": round(kernel_ms, 4), "reorder_ms": round(prof["reorder_ms"] / launches, 4),
+                    "other_ms": round(prof["other_ms"] / launches, 4),
                     "bytes_per_query": round(b_per_q, 1), "queries_per_launch": int(q_per_launch),
                     "visits_per_query": {kk: round(v, 2) for kk, v in visits.items()}}
+
+        extras = {}
+        if world == 1 and not args.no_extras and k == 1 and not args.n and not args.nq:
+            # (a) the host-pointer entry on pageable arrays: H2D + search + D2H (SURVEY 8d asks for both figures)
+            hsteps = 5
+            tree.search_knn(q, 1)
+            t0 = time.perf_counter()
+            for _ in range(hsteps):
+                host_rows = tree.search_knn(q, 1)
+            hdt = (time.perf_counter() - t0) / hsteps
+            extras["host_buffers"] = {"value": round(nq / hdt / 1e6, 3), "unit": "Mqueries/s",
+                                      "ms_per_step": round(hdt * 1e3, 4), "steps": hsteps,
+                                      "what": "ptk_search_knn on pageable numpy arrays: 86 MB up, search, 58 MB down",
+                                      "rows_equal_device_run": bool(host_rows.tobytes() == res.tobytes())}
+            del host_rows
+            # (b) config 3 on the same clouds
+            if args.cloud == "L" and args.order == "generated":
+                extras["config3"] = config3_entries(pt, oracle, pts, q, tree, dq, args.leaf, 100_000)
+            # (c) the headline search on the other query order and on the other cloud
+            also = []
+            other_order = "morton" if args.order == "generated" else "generated"
+            also.append(also_entry(pt, ds, oracle, args.cloud, other_order, pts, q, tree, args.leaf, 10, 100_000))
+            oc = "U" if args.cloud == "L" else "L"
+            del dq
+            pts2, q2 = ds.config2_clouds(oc, n, nq)
+            tree2 = pt.KdTree(pts2, pt.Metric.L2Squared, args.leaf, device=local_rank)
+            for order in ("generated", "morton"):
+                also.append(also_entry(pt, ds, oracle, oc, order, pts2, q2, tree2, args.leaf, 10, 100_000))
+            del tree2
+            extras["also"] = also
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline(pts, q, k, args.leaf, args.cpu_seconds)
+
+        def parallelism(w):
+            return ((f"{world} x {nq} queries (one full batch per GPU), tree replicated" if w
+                     else f"one batch of {nq} queries cut into {world} shards, tree replicated")
+                    + (", (index, distance) rows gathered on rank 0 over RCCL, overlapped with the next step"
+                       if world > 1 else ""))
 
         result = {
             "metric": "Mqueries/sec, knn=1 3D L2, 7.73M-pt tree / 7.20M queries" if k == 1 and not args.n
                       else f"Mqueries/sec, knn={k} 3D L2",
             "value": round(value, 3), "unit": "Mqueries/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"BASELINE configs[1]: cloud {args.cloud} "
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[{3 if world > 1 and not weak else 1}]: cloud {args.cloud} "
                                    f"({'LiDAR-like room scan' if args.cloud == 'L' else 'uniform cube'}), "
                                    f"{n} tree points / {nq} queries, knn={k}, max_leaf_size={args.leaf}, "
                                    f"sliding midpoint",
                        "query_order": args.order, "reorder": args.reorder, "streams": n_streams,
-                       "parallelism": (f"{world} x {nq} queries (one full batch per GPU), tree replicated"
-                                       if weak else f"one batch of {nq} queries cut into {world} shards, "
-                                                    f"tree replicated")
-                                      + (", (index, distance) rows gathered on rank 0 over RCCL, "
-                                         "overlapped with the next step" if world > 1 else ""),
+                       "parallelism": parallelism(weak),
                        "queries_per_step": int(total_queries),
                        "tree_nodes": int(info["n_nodes"]), "tree_depth": int(info["max_depth"]),
                        "host_build_upload_s": round(build_s, 2)},
@@ -355,6 +515,11 @@ def main():
             "pipelined": pipelined,
             "cpu_baseline": cpu,
         }
+        if other is not None:  # the other form of the same run (N > 1)
+            result["weak" if other["weak"] else "strong"] = {
+                "value": round(other["value"], 3), "unit": "Mqueries/s", "ms_per_step": round(other["ms_per_step"], 4),
+                "queries_per_step": int(other["total"]), "parallelism": parallelism(other["weak"])}
+        result.update(extras)
         print(json.dumps(result), flush=True)
     if world > 1:
         dist.barrier()

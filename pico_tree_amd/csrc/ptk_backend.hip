@@ -751,7 +751,7 @@ size_t two_phase_scratch_bytes(uint64_t nq) {
 // makes the cooperative result the reference's (ptk_kernels.hpp, knn1_coop_kernel) needs e = 1.
 uint32_t phase2_cap(float e) {
   if (e != 1.0f) return 0;
-  const int cap = env_int("PTK_P2_CAP", 64);
+  const int cap = env_int("PTK_P2_CAP", 16);  // sweep in profiles/r02_notes.txt
   return cap < 0 ? 0u : (uint32_t)cap;
 }
 
