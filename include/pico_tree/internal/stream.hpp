@@ -108,16 +108,26 @@ inline void write_flat_tree(Tree_ const& tree, std::ostream& s) {
   }
 }
 
+//! \param expect_sdim, expect_n  when non-zero: what the caller's space says; a stream that
+//! disagrees is rejected BEFORE anything is sized from its (unchecked) header fields.
 template <typename Tree_>
-inline Tree_ read_flat_tree(std::istream& s, bool outer_bounds = false) {
+inline Tree_ read_flat_tree(std::istream& s, bool outer_bounds = false, size_t expect_sdim = 0,
+                            size_t expect_n = 0) {
   using index = typename Tree_::index_type;
   using scalar = typename Tree_::scalar_type;
   size_t sdim = 0;
   get_pod(s, sdim);
+  if (!s) throw std::runtime_error("kd_tree stream ended early");
+  if (expect_sdim != 0 && sdim != expect_sdim)
+    throw std::runtime_error("kd_tree stream has another spatial dimension than the space");
+  if (sdim == 0 || sdim > (size_t(1) << 20)) throw std::runtime_error("kd_tree stream has an implausible dimension");
   Tree_ tree(sdim);
   tree.keep_outer_bounds = outer_bounds;
   size_t n = 0;
   get_pod(s, n);
+  if (!s) throw std::runtime_error("kd_tree stream ended early");
+  if (expect_n != 0 && n != expect_n)
+    throw std::runtime_error("kd_tree stream indexes another number of points than the space holds");
   tree.indices.resize(n);
   s.read(reinterpret_cast<char*>(tree.indices.data()),
          static_cast<std::streamsize>(n * sizeof(index)));

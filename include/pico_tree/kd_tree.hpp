@@ -361,7 +361,8 @@ class kd_tree {
   kd_tree(space_type space, std::iostream& stream)
       : space_(std::move(space)),
         metric_(),
-        tree_(internal::read_flat_tree<tree_type>(stream, topological)) {}
+        tree_(internal::read_flat_tree<tree_type>(
+            stream, topological, space_view_type(unwrap(space_)).sdim(), space_view_type(unwrap(space_)).size())) {}
 
   template <typename T_>
   static T_ const& unwrap(T_ const& s) {

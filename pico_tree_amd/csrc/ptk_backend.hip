@@ -75,7 +75,7 @@ struct PendingEvent {
 
 struct Profile {
   std::mutex mutex;
-  bool enabled = false;
+  std::atomic<bool> enabled{false};
   ptk_profile acc{};
   std::vector<PendingEvent> pending;  // recorded, not yet read back
   std::vector<hipEvent_t> idle;       // events ready for reuse (hipEventCreate is slow)
@@ -420,7 +420,11 @@ class Scratch {
       ws_.capacity = 0;
       ws_.has_work = false;
       const size_t want = (bytes + (size_t(32) << 20)) & ~((size_t(32) << 20) - 1);
-      PTK_HIP(hipMalloc((void**)&ws_.base, want));
+      if (hipMalloc((void**)&ws_.base, want) != hipSuccess) {
+        (void)hipGetLastError();  // not sticky: the next launch must not report this again
+        ws_.base = nullptr;
+        return fail(PTK_ERR_NOMEM, "out of device memory (%zu bytes of search scratch)", want);
+      }
       ws_.capacity = want;
     }
     if (ws_.has_work && ws_.last_stream != s_) PTK_HIP(hipStreamWaitEvent(s_, ws_.done, 0));
@@ -466,12 +470,32 @@ class Scratch {
 // spill to OVF private-scratch slots.  A traversal holds, per level of the current
 // root path, either one pending record (went near, far child unexplored) or two
 // undo records (went far), so 2 * depth + 2 slots always suffice.
+constexpr int kDeepClass = 3;  // deeper than the private classes: spill to HBM, generic kernels only
 int ovf_class(const ptk_tree* t, int s_lds) {
   const uint32_t need = 2 * t->max_depth + 2;
   if (need <= (uint32_t)s_lds + 64) return 0;
   if (need <= (uint32_t)s_lds + 256) return 1;
   if (need <= (uint32_t)s_lds + 2048) return 2;
-  return -1;
+  return kDeepClass;
+}
+bool deep_tree(const ptk_tree* t) { return ovf_class(t, 16) == kDeepClass; }
+
+// A deep tree's launches: `cap` spill records per lane, `piece` queries per launch so that the
+// block stays within PTK_DEEP_SPILL_MB (default 2048).
+struct DeepPlan {
+  uint32_t cap;
+  uint64_t piece;
+  size_t bytes() const { return (size_t)piece * cap * sizeof(ptk::Record); }
+};
+DeepPlan deep_plan(const ptk_tree* t, uint64_t n) {
+  DeepPlan p;
+  p.cap = 2 * t->max_depth + 2;
+  const size_t budget = (size_t)std::max(1, env_int("PTK_DEEP_SPILL_MB", 2048)) << 20;
+  uint64_t piece = (budget / ((size_t)p.cap * sizeof(ptk::Record))) & ~(uint64_t)63;
+  if (piece < 64) piece = 64;
+  const uint64_t all = (n + 63) & ~(uint64_t)63;
+  p.piece = piece < all ? piece : all;
+  return p;
 }
 
 // Dynamic LDS above 64 KiB must be opted into per kernel.
@@ -906,13 +930,13 @@ constexpr size_t kMaxLdsBytes = 160 * 1024;
 
 template <int OVF, class M = ptk::MetricL2>
 int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
-                  ptk::Neighbor* d_out, hipStream_t s) {
+                  ptk::Neighbor* d_out, hipStream_t s, bool no_register_list = false) {
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const size_t base = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
   if (base > kMaxLdsBytes)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-  if (k <= 32 && env_int("PTK_KNN_LIST", 0) == 0) {  // k-list in registers (K = 4 / 8 / 16 / 32 slots compiled)
+  if (k <= 32 && !no_register_list && env_int("PTK_KNN_LIST", 0) == 0) {  // k-list in registers (K = 4 / 8 / 16 / 32 slots compiled)
     Timer timer(t, s);
     int rc = PTK_OK;
 #define PTK_LAUNCH_ND_REG(KK)                                                                                       \
@@ -1206,7 +1230,7 @@ int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t
   try {
     using tree_t = pico_tree::internal::flat_tree<int, float, pico_tree::dynamic_extent>;
     std::istringstream is(std::string(static_cast<const char*>(stream), stream_bytes), std::ios::in | std::ios::binary);
-    tree_t flat = pico_tree::internal::read_flat_tree<tree_t>(is);
+    tree_t flat = pico_tree::internal::read_flat_tree<tree_t>(is, false, dim, n_points);
     if (flat.root_box.size() != dim) return fail(PTK_ERR_INVALID, "stream is %zu-dimensional, points are %u-dimensional",
                                                  (size_t)flat.root_box.size(), dim);
     if (flat.indices.size() != n_points)
@@ -1251,12 +1275,17 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   int rc = check_search(t, d_q, nq);
   if (rc != PTK_OK) return rc;
   if (k == 0) return fail(PTK_ERR_INVALID, "k must be >= 1");
-  if (k > t->n_points) return fail(PTK_ERR_INVALID, "k = %u exceeds the number of points (%llu)", k,
-                                   (unsigned long long)t->n_points);
   if (!(e > 0.0f)) return fail(PTK_ERR_INVALID, "approximation ratio e must be > 0");
   if (nq == 0) return PTK_OK;
   if (d_out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
   hipStream_t s = static_cast<hipStream_t>(stream);
+  // k > n_points: what the reference's iterator-range search_knn does with a range longer than the
+  // tree (search_visitor.hpp:95-110; its Python binding passes k through unclamped): the n_points
+  // neighbours in order, the last slot's distance left at the FLT_MAX sentinel.  The slots in
+  // between are the caller's in the reference; here they are zeroed.  (The register k-list assumes
+  // every slot gets filled, so these rows take the list-in-the-row kernels.)
+  const bool short_tree = k > t->n_points;
+  if (short_tree) PTK_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(ptk_neighbor), s));
   // Very large batches go through in pieces of at most 2^25 queries: the scratch of a piece stays
   // at a few GB and every 32-bit index in the kernels holds (PTK_MAX_BATCH shrinks it for tests).
   const uint64_t piece = (uint64_t)std::max(1, env_int("PTK_MAX_BATCH", 1 << 25));
@@ -1271,6 +1300,46 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   const bool l2 = t->metric.load() == PTK_METRIC_L2_SQUARED;
+  if (deep_tree(t)) {  // a few queries at a time, the record stacks spilling to HBM (any k, any metric)
+    const DeepPlan plan = deep_plan(t, nq);
+    Scratch scratch(t, s, /*per_stream=*/true);
+    rc = scratch.reserve(plan.bytes());
+    if (rc != PTK_OK) return rc;
+    ptk::Record* spill = scratch.take<ptk::Record>((size_t)plan.piece * plan.cap);
+    if (spill == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
+    auto* o = reinterpret_cast<ptk::Neighbor*>(d_out);
+    Timer timer(t, s);
+    for (uint64_t lo = 0; lo < nq; lo += plan.piece) {
+      const uint64_t n = std::min<uint64_t>(plan.piece, nq - lo);
+      const uint32_t blocks = (uint32_t)((n + 63) / 64);
+      if (t->dim > 3) {
+        ptk::DevTreeND dev = t->dev_nd;
+        dev.deep_spill = spill;
+        dev.deep_cap = plan.cap;
+        const size_t smem = (size_t)16 * 64 * 8 + (size_t)t->dim * 64 * 8;
+        if (smem > kMaxLdsBytes)
+          return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
+        PTK_WITH_METRIC({
+          rc = allow_lds(ptk::knn_nd_kernel<16, -1, false, M>, smem);
+          if (rc == PTK_OK)
+            hipLaunchKernelGGL((ptk::knn_nd_kernel<16, -1, false, M>), dim3(blocks), dim3(64), smem, s, dev,
+                               d_q + lo * t->dim, nullptr, n, k, inv_ratio(e), o + lo * k);
+        });
+        if (rc != PTK_OK) return rc;
+      } else {
+        ptk::DevTree dev = t->dev;
+        dev.deep_spill = spill;
+        dev.deep_cap = plan.cap;
+        PTK_WITH_METRIC({
+          hipLaunchKernelGGL((ptk::knn_kernel<16, -1, 64, 4, false, M>), dim3(blocks), dim3(64), (size_t)16 * 64 * 8, s,
+                             dev, d_q + lo * t->dim, t->dim, nullptr, n, k, inv_ratio(e), o + lo * k);
+        });
+      }
+      PTK_HIP(hipGetLastError());
+    }
+    timer.stop(0, nq);
+    return PTK_OK;
+  }
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
@@ -1282,12 +1351,12 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
     if (rc != PTK_OK) return rc;
   }
   if (t->dim > 3) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_nd<OVF, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_nd<OVF, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree))));
     return rc;
   }
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
-  } else if (k <= 32 && env_int("PTK_KNN_LIST", 0) == 0) {
+  } else if (k <= 32 && !short_tree && env_int("PTK_KNN_LIST", 0) == 0) {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_reg<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   } else {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
@@ -1314,12 +1383,13 @@ static int grow_device_block(char** p, size_t* capacity, size_t bytes) {
 int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, float e, ptk_neighbor* out) {
   int rc = check_search(t, q, nq);
   if (rc != PTK_OK) return rc;
+  if (k == 0) return fail(PTK_ERR_INVALID, "k must be >= 1");
   if (nq == 0) return PTK_OK;
   if (out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   const size_t qbytes = (size_t)nq * t->dim * sizeof(float);
-  const size_t obytes = (size_t)nq * (k ? k : 1) * sizeof(ptk_neighbor);
+  const size_t obytes = (size_t)nq * k * sizeof(ptk_neighbor);
   HostIo& io = t->io;
   std::lock_guard<std::mutex> lock(io.mutex);
   if (io.stream == nullptr) PTK_HIP(hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking));
@@ -1416,6 +1486,57 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
                                                                          s, n_over))));
     }
+  } else if (deep_tree(t)) {  // record stacks spilling to HBM, a few queries per launch, no capture
+    if (!fill) ws.cap_valid = false;
+    const DeepPlan plan = deep_plan(t, nq);
+    rc = scratch.reserve(plan.bytes());
+    if (rc != PTK_OK) return rc;
+    ptk::Record* spill = scratch.take<ptk::Record>((size_t)plan.piece * plan.cap);
+    if (spill == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
+    auto* o = reinterpret_cast<ptk::Neighbor*>(d_out);
+    Timer timer(t, s);
+    for (uint64_t lo = 0; lo < nq; lo += plan.piece) {
+      const uint64_t n = std::min<uint64_t>(plan.piece, nq - lo);
+      const uint32_t blocks = (uint32_t)((n + 63) / 64);
+      uint64_t* c = fill ? nullptr : d_counts + lo;
+      const uint64_t* of = fill ? d_offsets + lo : nullptr;
+      if (nd) {
+        ptk::DevTreeND dev = t->dev_nd;
+        dev.deep_spill = spill;
+        dev.deep_cap = plan.cap;
+        const size_t smem = (size_t)16 * 64 * 8 + (size_t)t->dim * 64 * 8;
+        if (smem > kMaxLdsBytes)
+          return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
+        PTK_WITH_METRIC({
+          if (fill) {
+            rc = allow_lds(ptk::radius_nd_kernel<16, -1, true, M>, smem);
+            if (rc == PTK_OK)
+              hipLaunchKernelGGL((ptk::radius_nd_kernel<16, -1, true, M>), dim3(blocks), dim3(64), smem, s, dev,
+                                 d_q + lo * t->dim, n, radius, inv_ratio(e), c, of, o, nullptr, nullptr);
+          } else {
+            rc = allow_lds(ptk::radius_nd_kernel<16, -1, false, M>, smem);
+            if (rc == PTK_OK)
+              hipLaunchKernelGGL((ptk::radius_nd_kernel<16, -1, false, M>), dim3(blocks), dim3(64), smem, s, dev,
+                                 d_q + lo * t->dim, n, radius, inv_ratio(e), c, of, o, nullptr, nullptr);
+          }
+        });
+        if (rc != PTK_OK) return rc;
+      } else {
+        ptk::DevTree dev = t->dev;
+        dev.deep_spill = spill;
+        dev.deep_cap = plan.cap;
+        PTK_WITH_METRIC({
+          if (fill)
+            hipLaunchKernelGGL((ptk::radius_kernel<16, -1, 64, 4, true, M>), dim3(blocks), dim3(64), (size_t)16 * 64 * 8, s,
+                               dev, d_q + lo * t->dim, t->dim, nullptr, n, radius, inv_ratio(e), c, of, o, nullptr);
+          else
+            hipLaunchKernelGGL((ptk::radius_kernel<16, -1, 64, 4, false, M>), dim3(blocks), dim3(64), (size_t)16 * 64 * 8, s,
+                               dev, d_q + lo * t->dim, t->dim, nullptr, n, radius, inv_ratio(e), c, of, o, nullptr);
+        });
+      }
+      PTK_HIP(hipGetLastError());
+    }
+    timer.stop(0, fill ? 0 : nq);
   } else {
     const bool capture = !fill && prepare_capture(nq, ws);
     if (!fill) ws.cap_valid = false;
@@ -1475,6 +1596,14 @@ int ptk_search_radius_fill_device(const ptk_tree* t, const float* d_q, uint64_t 
                             static_cast<hipStream_t>(stream));
 }
 
+// The capture of a radius count pass is keyed on the device address of the query batch.  The host
+// forms below own that buffer for one call only: once it is freed the address may be handed out
+// again for ANOTHER batch, so the capture must not outlive the call.
+static void drop_radius_capture(const ptk_tree* t) {
+  std::lock_guard<std::mutex> lock(t->ws.mutex);
+  t->ws.cap_valid = false;
+}
+
 int ptk_search_radius_count(const ptk_tree* t, const float* q, uint64_t nq, float radius, float e,
                             uint64_t* counts) {
   int rc = check_search(t, q, nq);
@@ -1493,6 +1622,7 @@ int ptk_search_radius_count(const ptk_tree* t, const float* q, uint64_t nq, floa
     rc = ptk_search_radius_count_device(t, d_q, nq, radius, e, d_c, nullptr);
     if (rc == PTK_OK) he = hipMemcpy(counts, d_c, nq * 8, hipMemcpyDeviceToHost);
   }
+  drop_radius_capture(t);
   if (d_q) (void)hipFree(d_q);
   if (d_c) (void)hipFree(d_c);
   if (rc != PTK_OK) return rc;
@@ -1520,6 +1650,7 @@ int ptk_search_radius_fill(const ptk_tree* t, const float* q, uint64_t nq, float
   if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
   if (he == hipSuccess) he = hipMemcpy(d_o, offsets, (nq + 1) * 8, hipMemcpyHostToDevice);
   if (he == hipSuccess) {
+    drop_radius_capture(t);  // d_q is this call's own copy: whatever was captured belongs to another buffer
     rc = ptk_search_radius_fill_device(t, d_q, nq, radius, e, d_o, d_out, sort, nullptr);
     if (rc == PTK_OK && total > 0) he = hipMemcpy(out, d_out, total * 8, hipMemcpyDeviceToHost);
   }
@@ -1578,6 +1709,7 @@ int ptk_search_radius(const ptk_tree* t, const float* q, uint64_t nq, float radi
       }
     }
   }
+  drop_radius_capture(t);
   if (tmp) (void)hipFree(tmp);
   if (d_q) (void)hipFree(d_q);
   if (d_c) (void)hipFree(d_c);
@@ -1615,9 +1747,12 @@ static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_
     root = ptk::BoxState{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
   }
   // Boxes in Morton order of their min corners (launch order only; rows stay in the caller's order).
-  const bool reorder = want_reorder(t, nb);
+  const bool deep = deep_tree(t);
+  const bool reorder = !deep && want_reorder(t, nb);
+  const DeepPlan plan = deep ? deep_plan(t, nb) : DeepPlan{0, 0};
   Scratch scratch(t, s);
-  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nb) : 0) + (size_t)2 * t->dim * sizeof(float) + 512);
+  rc = scratch.reserve((reorder ? permutation_scratch_bytes(nb) : 0) + (size_t)2 * t->dim * sizeof(float) + 512 +
+                       (deep ? plan.bytes() : 0));
   if (rc != PTK_OK) return rc;
   float* d_root = nullptr;
   if (t->dim > 3) {  // the root box of the any-dimension kernel: min[dim], max[dim]
@@ -1634,7 +1769,43 @@ static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_
   const uint32_t blocks = (uint32_t)((nb + 63) / 64);
   const auto* ranges = static_cast<const uint2*>(t->d_ranges);
   Timer timer(t, s);
-  if (!fill) {
+  if (deep) {  // record stacks spilling to HBM, a few boxes per launch
+    ptk::Record* spill = scratch.take<ptk::Record>((size_t)plan.piece * plan.cap);
+    if (spill == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
+    for (uint64_t lo = 0; lo < nb; lo += plan.piece) {
+      const uint64_t n = std::min<uint64_t>(plan.piece, nb - lo);
+      const uint32_t pb = (uint32_t)((n + 63) / 64);
+      uint64_t* c = fill ? nullptr : d_counts + lo;
+      const uint64_t* of = fill ? d_offsets + lo : nullptr;
+      if (t->dim > 3) {
+        ptk::DevTreeND dev = t->dev_nd;
+        dev.deep_spill = spill;
+        dev.deep_cap = plan.cap;
+        if (fill) {
+          rc = allow_lds(ptk::box_nd_kernel<16, -1, true>, nd_smem);
+          if (rc != PTK_OK) return rc;
+          hipLaunchKernelGGL((ptk::box_nd_kernel<16, -1, true>), dim3(pb), dim3(64), nd_smem, s, dev, ranges, d_root,
+                             d_mn + lo * t->dim, d_mx + lo * t->dim, n, c, of, d_out, nullptr);
+        } else {
+          rc = allow_lds(ptk::box_nd_kernel<16, -1, false>, nd_smem);
+          if (rc != PTK_OK) return rc;
+          hipLaunchKernelGGL((ptk::box_nd_kernel<16, -1, false>), dim3(pb), dim3(64), nd_smem, s, dev, ranges, d_root,
+                             d_mn + lo * t->dim, d_mx + lo * t->dim, n, c, of, d_out, nullptr);
+        }
+      } else {
+        ptk::DevTree dev = t->dev;
+        dev.deep_spill = spill;
+        dev.deep_cap = plan.cap;
+        if (fill)
+          hipLaunchKernelGGL((ptk::box_kernel<16, -1, true>), dim3(pb), dim3(64), 16 * 64 * 8, s, dev, ranges, root,
+                             d_mn + lo * t->dim, d_mx + lo * t->dim, t->dim, n, c, of, d_out, nullptr);
+        else
+          hipLaunchKernelGGL((ptk::box_kernel<16, -1, false>), dim3(pb), dim3(64), 16 * 64 * 8, s, dev, ranges, root,
+                             d_mn + lo * t->dim, d_mx + lo * t->dim, t->dim, n, c, of, d_out, nullptr);
+      }
+      PTK_HIP(hipGetLastError());
+    }
+  } else if (!fill) {
     PTK_WITH_OVF(16, ([&]() -> int {
                    if (t->dim > 3) {
                      int lrc = allow_lds(ptk::box_nd_kernel<16, OVF, false>, nd_smem);

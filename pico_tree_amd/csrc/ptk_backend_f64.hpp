@@ -371,7 +371,7 @@ int ptk_tree64_create_from_stream(const double* points, uint64_t n_points, uint3
   ptk_tree64* t = nullptr;
   try {
     std::istringstream is(std::string(static_cast<const char*>(stream), stream_bytes), std::ios::in | std::ios::binary);
-    ptk_tree64::flat_t flat = pico_tree::internal::read_flat_tree<ptk_tree64::flat_t>(is);
+    ptk_tree64::flat_t flat = pico_tree::internal::read_flat_tree<ptk_tree64::flat_t>(is, false, dim, n_points);
     if (flat.root_box.size() != dim) return fail(PTK_ERR_INVALID, "stream is %zu-dimensional, points are %u-dimensional",
                                                  (size_t)flat.root_box.size(), dim);
     if (flat.indices.size() != n_points)

@@ -91,6 +91,10 @@ inline std::string analyse_stream(
   uint32_t n_branch = 0;
   std::vector<std::pair<uint32_t, uint32_t>> pending;  // (right child index, its depth)
   uint32_t depth = 0;
+  // The leaves must tile [0, n_points) in stream order (as the reference builds them,
+  // kd_tree_builder.hpp:352-396): the device layout places the points of a leaf by a running sum of
+  // the leaf sizes, so overlapping or out-of-order ranges would silently search the wrong points.
+  uint64_t next_begin = 0;
   for (uint64_t i = 0; i < n_nodes; ++i) {
     if (!pending.empty() && pending.back().first == i) {
       depth = pending.back().second;
@@ -104,6 +108,9 @@ inline std::string analyse_stream(
       std::memcpy(&e, &nd.b, 4);
       if (b < 0 || e < b || (uint64_t)e > n_points)
         return "leaf " + std::to_string(i) + " has a bad index range";
+      if ((uint64_t)b != next_begin)
+        return "leaf " + std::to_string(i) + " does not start where the previous leaf ended";
+      next_begin = (uint64_t)e;
       ++st.n_leaves;
       if ((uint32_t)(e - b) > st.max_leaf_count) st.max_leaf_count = (uint32_t)(e - b);
     } else {
@@ -118,6 +125,7 @@ inline std::string analyse_stream(
   }
   if (!pending.empty()) return "node stream is truncated";
   if (st.n_leaves != (uint64_t)n_branch + 1) return "node stream is not a binary tree";
+  if (next_begin != n_points) return "the leaves do not cover all points";
   return std::string();
 }
 

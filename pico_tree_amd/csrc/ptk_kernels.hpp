@@ -55,6 +55,7 @@ namespace ptk {
 // ref   : bit 31 = leaf.
 //           branch ref: bits 30:29 = split axis of the child, bits 28:0 = branch index
 //           leaf   ref: bits 30:0  = (begin << cbits) | count
+struct Record;
 struct DevTree {
   const uint4* nodes;
   const float4* pts;
@@ -62,6 +63,11 @@ struct DevTree {
   uint32_t cbits;
   uint32_t cmask;
   uint32_t n_points;
+  // Trees deeper than the private spill classes hold (thousands of coincident points peel one
+  // level each): kernels instantiated with OVF < 0 spill to this HBM block, deep_cap records per
+  // lane of the launch (set per launch by the backend; null otherwise).
+  Record* deep_spill;
+  uint32_t deep_cap;
 };
 
 constexpr uint32_t kLeafBit = 0x80000000u;
@@ -160,7 +166,8 @@ __device__ __forceinline__ float point_distance3(float dx, float dy, float dz) {
 // ---- record stack: ring of S slots in LDS + OVF spill slots in private scratch ----
 // Records are numbered 0, 1, 2, ... in push order.  [base, top) is resident in the
 // ring (record i at slot i mod S); [0, base) has been spilled (record i at
-// ovf[i]).  S is a power of two.
+// ovf[i]).  S is a power of two.  OVF > 0: that many private slots; OVF == 0: no spill (the ring
+// always suffices); OVF < 0: the spill slots are in HBM (PTK_STACK, DevTree::deep_spill).
 template <int S, int OVF, int BLOCK>
 struct Stack {
   static_assert(S >= 4, "ring too small");
@@ -184,7 +191,7 @@ struct Stack {
   __device__ __forceinline__ bool empty() const { return top == 0; }
   __device__ __forceinline__ void push(uint32_t meta, float val) {
     if (top - base == S) {  // ring full: spill the oldest resident record
-      if (OVF > 0) ovf[base] = unpack_record(lds[slot(base) * BLOCK]);
+      if (OVF != 0) ovf[base] = unpack_record(lds[slot(base) * BLOCK]);
       ++base;
     }
     Record rec;
@@ -198,7 +205,7 @@ struct Stack {
   // stay on the stack until drop().
   __device__ __forceinline__ int peek(Record (&rr)[kUnwind]) {
     if (top == base) {  // ring empty, spilled records remain: bring a batch back
-      if (OVF > 0) {
+      if (OVF != 0) {
         Record r[kRefill];
 #pragma unroll
         for (int i = 0; i < kRefill; ++i) {
@@ -221,7 +228,7 @@ struct Stack {
   __device__ __forceinline__ void drop(int n) { top -= n; }
   __device__ __forceinline__ Record pop() {
     if (top == base) {  // ring empty, spilled records remain: refill a batch
-      if (OVF > 0) {
+      if (OVF != 0) {
         Record r[kRefill];
 #pragma unroll
         for (int i = 0; i < kRefill; ++i) {
@@ -240,6 +247,14 @@ struct Stack {
     return unpack_record(lds[slot(top) * BLOCK]);
   }
 };
+
+// Declares the record stack `st` of a kernel: private spill slots, or (OVF < 0) this lane's run of
+// TREE.deep_cap records in the launch's HBM spill block.
+#define PTK_STACK(S, OVF, BLOCK, st, TREE)                                                                  \
+  Record spill_[(OVF) > 0 ? (OVF) : 1];                                                                     \
+  Stack<S, OVF, BLOCK> st;                                                                                  \
+  st.init((LdsWord*)ptk_smem, threadIdx.x,                                                                  \
+          (OVF) < 0 ? (TREE).deep_spill + ((uint64_t)blockIdx.x * (BLOCK) + threadIdx.x) * (TREE).deep_cap : spill_)
 
 // ---- result policies ------------------------------------------------------------
 // max()  : current pruning distance            visit(): one measured point
@@ -717,9 +732,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, BLOCK> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  PTK_STACK(S, OVF, BLOCK, st, t);
   KnnPolicy<LIST_LDS> pol;
   if constexpr (LIST_LDS) {
     pol.list = (LdsWord*)(ptk_smem + (size_t)S * BLOCK * 8) + threadIdx.x;
@@ -783,9 +796,7 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
 
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, BLOCK> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  PTK_STACK(S, OVF, BLOCK, st, t);
   RadiusPolicy<FILL ? kRadiusFill : kRadiusCount> pol;
   pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
   pol.e_inv = e_inv;
@@ -1767,9 +1778,7 @@ __global__ __launch_bounds__(64) void box_kernel(
   uint64_t count = 0;
   int32_t* row = FILL ? out + offsets[bi] : nullptr;
 
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  PTK_STACK(S, OVF, 64, st, t);
 
   auto inside = [&]() {  // query_.contains(box_): both corners inside the closed query box
     return qn0 <= b.mn0 && b.mn0 <= qx0 && qn0 <= b.mx0 && b.mx0 <= qx0 &&

@@ -34,6 +34,8 @@ struct DevTreeND {
   uint32_t cbits;
   uint32_t cmask;
   uint32_t dim;
+  Record* deep_spill;  // as DevTree::deep_spill
+  uint32_t deep_cap;
 };
 
 constexpr uint32_t kNdIdxMask = 0x3FFFFFFFu;
@@ -148,9 +150,7 @@ __global__ __launch_bounds__(64) void knn_nd_kernel(
   const uint64_t qi = perm ? perm[i] : i;
   LdsFloat *q, *off;
   stage_query_nd<S>(queries, t.dim, qi, q, off);
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  PTK_STACK(S, OVF, 64, st, t);
   KnnPolicy<LIST_LDS> pol;
   if constexpr (LIST_LDS) {
     pol.list = (LdsWord*)(ptk_smem + (size_t)S * 64 * 8 + (size_t)t.dim * 64 * 8) + threadIdx.x;
@@ -200,9 +200,7 @@ __global__ __launch_bounds__(64) void radius_nd_kernel(
   const uint64_t qi = perm ? perm[i] : i;
   LdsFloat *q, *off;
   stage_query_nd<S>(queries, t.dim, qi, q, off);
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  PTK_STACK(S, OVF, 64, st, t);
   RadiusPolicy<FILL> pol;
   pol.radius = f_mul(radius, e_inv);  // search_visitor.hpp:265
   pol.e_inv = e_inv;
@@ -274,9 +272,7 @@ __global__ __launch_bounds__(64) void box_nd_kernel(
   uint64_t count = 0;
   int32_t* row = FILL ? out + offsets[bi] : nullptr;
 
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
+  PTK_STACK(S, OVF, 64, st, t);
 
   auto inside = [&]() {  // query_.contains(box_), box.hpp: both corners inside the closed query box
     bool in = true;

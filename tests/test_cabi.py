@@ -113,6 +113,14 @@ def test_rejects_malformed_flat_trees():
     leaf = np.flatnonzero(nodes[:, 2] == 0xFFFFFFFF)[0]
     bad = nodes.copy(); bad[leaf, 1] = 1000                # leaf range past the end
     assert create(bad, idx) == -1
+    # Leaves must tile [0, n) in stream order: the device layout places a leaf's points by a running
+    # sum of the leaf sizes, so swapped or overlapping ranges would search the wrong points silently.
+    leaves = np.flatnonzero(nodes[:, 2] == 0xFFFFFFFF)
+    bad = nodes.copy(); bad[leaves[0], :2], bad[leaves[1], :2] = nodes[leaves[1], :2], nodes[leaves[0], :2]
+    assert create(bad, idx) == -1
+    assert b"previous leaf" in lib.ptk_last_error()
+    bad = nodes.copy(); bad[leaves[-1], 1] -= 1            # the last leaf stops short of n
+    assert create(bad, idx) == -1
 
 
 def test_tree_stream_round_trip_on_a_host_only_handle():

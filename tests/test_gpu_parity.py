@@ -332,6 +332,76 @@ def test_radius_rows_captured_in_the_count_pass(trees, monkeypatch, env, cloud, 
     assert np.array_equal(raw.cpu().numpy()[:, 1].view(np.float32), want["distance"])
 
 
+def test_tree_deeper_than_the_private_stack_classes(gpu, monkeypatch):
+    """1 500 coincident points peel one level each (sliding midpoint): depth > 1 031 is past the
+    private spill classes, so the record stacks of these searches spill to HBM (the
+    reference builds and searches such clouds -- LiDAR scans carry thousands of (0, 0, 0) returns)."""
+    pts = np.concatenate([ds.uniform_cloud(60_000, 3, 31) - np.float32(0.5), np.zeros((1_500, 3), np.float32)])
+    q = np.concatenate([ds.uniform_cloud(3_000, 3, 32) - np.float32(0.5), np.zeros((3, 3), np.float32),
+                        np.full((2, 3), 1e-3, np.float32)])
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    assert tree.info()["max_depth"] > 1_040
+    ref = oracle.Oracle(pts, 10, "port")
+    monkeypatch.setenv("PTK_DEEP_SPILL_MB", "16")  # several launches per batch
+    for k in (1, 5, 40):
+        want = ref.search_knn(q, k)
+        assert tree.search_knn(q, k).tobytes() == (want[:, 0] if k == 1 else want).tobytes()
+    got = tree.search_radius(q, 0.002)
+    off, flat = ref.search_radius(q, 0.002)
+    assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+    boxes = np.empty((2 * len(q), 3), dtype=np.float32)
+    boxes[0::2], boxes[1::2] = q - np.float32(0.02), q + np.float32(0.02)
+    gb = tree.search_box(boxes)
+    boff, bflat = ref.search_box(boxes[0::2].copy(), boxes[1::2].copy())
+    assert np.array_equal(gb.offsets, boff) and np.array_equal(gb.flat, bflat)
+
+
+def test_k_larger_than_the_tree(gpu):
+    """k > n_points: the reference's iterator-range search_knn (and its Python binding) fills the n
+    neighbours and leaves the FLT_MAX sentinel in the last slot (search_visitor.hpp:95-110)."""
+    pts, q = ds.uniform_cloud(7, 3, 41), ds.uniform_cloud(50, 3, 42)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 3, device=gpu)
+    ref = oracle.Oracle(pts, 3, "port")
+    got = tree.search_knn(q, 12)
+    want = ref.search_knn(q, 7)
+    assert got.shape == (50, 12)
+    assert got[:, :7].tobytes() == want.tobytes()
+    assert np.all(got["distance"][:, 11] == np.float32(3.402823466e+38))
+
+
+def test_host_radius_passes_do_not_reuse_a_stale_capture(trees):
+    """count(A), count(B), fill(A) through the HOST forms: every call uploads into a fresh device
+    buffer, which the allocator hands out at the same address again -- the capture of count(B) must
+    not serve fill(A)."""
+    tree, ref, _, q = trees("uniform")
+    lib = pt._load()
+    import ctypes
+    radius = 0.0015
+    a, b = np.ascontiguousarray(q[:9000]), np.ascontiguousarray(q[9000:18000])
+
+    def count(x):
+        c = np.zeros(len(x), dtype=np.uint64)
+        assert lib.ptk_search_radius_count(tree._h, x.ctypes.data, len(x), ctypes.c_float(radius), ctypes.c_float(1.0),
+                                           c.ctypes.data) == 0
+        off = np.zeros(len(x) + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(c)
+        return off
+
+    def fill(x, off):
+        out = np.zeros(max(int(off[-1]), 1), dtype=pt.NEIGHBOR)
+        assert lib.ptk_search_radius_fill(tree._h, x.ctypes.data, len(x), ctypes.c_float(radius), ctypes.c_float(1.0),
+                                          off.ctypes.data, out.ctypes.data, 0) == 0
+        return out[:int(off[-1])]
+
+    off_a = count(a)
+    off_b = count(b)
+    want_off, want = ref.search_radius(a, radius)
+    assert np.array_equal(off_a, want_off)
+    assert fill(a, off_a).tobytes() == want.tobytes()
+    want_off, want = ref.search_radius(b, radius)
+    assert np.array_equal(off_b, want_off) and fill(b, off_b).tobytes() == want.tobytes()
+
+
 def test_radius_fill_that_does_not_match_the_last_count(trees):
     """count(A), count(B), fill(A): the capture belongs to B, so A's fill must search again."""
     import ctypes
