@@ -38,6 +38,7 @@ template <typename Metric_>
 inline constexpr int ptk_metric_v = std::is_same_v<Metric_, metric_l2_squared> ? PTK_METRIC_L2_SQUARED
                                     : std::is_same_v<Metric_, metric_l1>       ? PTK_METRIC_L1
                                     : std::is_same_v<Metric_, metric_lpinf>    ? PTK_METRIC_LPINF
+                                    : std::is_same_v<Metric_, metric_lninf>    ? PTK_METRIC_LNINF
                                                                                : -1;
 
 //! Which kd_tree instantiations run on the GPU: float points through ptk_* and double points

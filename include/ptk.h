@@ -154,8 +154,9 @@ int ptk_tree_set_reorder(ptk_tree* tree, int mode);
  *   PTK_METRIC_L2_SQUARED  metric_l2_squared (default): squared distances, radius squared
  *   PTK_METRIC_L1          metric_l1:    sum of |differences|
  *   PTK_METRIC_LPINF       metric_lpinf: max of |differences|
+ *   PTK_METRIC_LNINF       metric_lninf: min of |differences| (metric.hpp:157-186)
  * Set once, before the first search. */
-enum { PTK_METRIC_L2_SQUARED = 0, PTK_METRIC_L1 = 1, PTK_METRIC_LPINF = 2 };
+enum { PTK_METRIC_L2_SQUARED = 0, PTK_METRIC_L1 = 1, PTK_METRIC_LPINF = 2, PTK_METRIC_LNINF = 3 };
 int ptk_tree_set_metric(ptk_tree* tree, int metric);
 
 /* The tree in the reference's own binary format (kd_tree::save / kd_tree::load,

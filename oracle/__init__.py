@@ -72,7 +72,7 @@ class Oracle:
 
     #: SO2 / SE2Squared: the reference's topological metrics, compiled reference only (the
     #: product runs them on the host members; tests/test_cpp_api.py).
-    METRICS = {"L2Squared": 0, "L1": 1, "LPInf": 2, "SO2": 3, "SE2Squared": 4}
+    METRICS = {"L2Squared": 0, "L1": 1, "LPInf": 2, "SO2": 3, "SE2Squared": 4, "LNInf": 5}
 
     def __init__(self, points: np.ndarray, max_leaf_size: int = 10, kind: str = "port",
                  metric: str = "L2Squared", dtype=np.float32):
@@ -108,7 +108,7 @@ class Oracle:
             self._h = create(self._ptr(pts), self.n, self.dim, self.max_leaf_size)
         if not self._h:
             raise RuntimeError("oracle create failed")
-        if kind == "port" and mid > 2:
+        if kind == "port" and mid in (3, 4):
             raise ValueError("the restatement covers the euclidean metrics only")
         if kind == "port" and mid != 0:
             if self._fn("set_metric", c_int, [c_void_p, c_int])(self._h, mid) != 0:

@@ -253,8 +253,16 @@ inline scalar_t lpinf(scalar_t const* a, scalar_t const* b, size_t dim) {
   for (size_t i = 0; i < dim; ++i) d = std::max(d, std::abs(a[i] - b[i]));
   return d;
 }
+// metric_lninf (metric.hpp:157-186): d = std::min(d, |x - y|), d from the largest scalar.
+inline scalar_t lninf(scalar_t const* a, scalar_t const* b, size_t dim) {
+  scalar_t d = std::numeric_limits<scalar_t>::max();
+  for (size_t i = 0; i < dim; ++i) d = std::min(d, std::abs(a[i] - b[i]));
+  return d;
+}
+// metric: 0 L2 squared, 1 L1, 2 LPInf, 5 LNInf (3 and 4 are the topological metrics of the compiled
+// reference only, oracle/ref_driver.cpp).
 inline scalar_t point_distance(int metric, scalar_t const* a, scalar_t const* b, size_t dim) {
-  return metric == 1 ? l1(a, b, dim) : metric == 2 ? lpinf(a, b, dim) : l2sq(a, b, dim);
+  return metric == 1 ? l1(a, b, dim) : metric == 2 ? lpinf(a, b, dim) : metric == 5 ? lninf(a, b, dim) : l2sq(a, b, dim);
 }
 // The one-dimensional form the searches apply to a split offset (metric.hpp:95-98, :120-123, :147-150).
 inline scalar_t scalar_distance(int metric, scalar_t x) { return metric == 0 ? x * x : std::abs(x); }
@@ -746,7 +754,7 @@ scalar_t ptkor_distance(int metric, scalar_t const* a, scalar_t const* b, size_t
 }
 scalar_t ptkor_distance_scalar(int metric, scalar_t x) { return scalar_distance(metric, x); }
 int ptkor_set_metric(void* tree, int metric) {
-  if (tree == nullptr || metric < 0 || metric > 2) return -1;
+  if (tree == nullptr || !(metric == 0 || metric == 1 || metric == 2 || metric == 5)) return -1;
   static_cast<tree_t*>(tree)->metric = metric;
   return 0;
 }

@@ -218,6 +218,9 @@ void* ptkref_create_metric(scalar_t const* pts, size_t n, size_t dim,
     if (metric == 2)
       return static_cast<tree_base*>(
           new tree_impl<kDim, pico_tree::metric_lpinf>(pts, n, dim, max_leaf));
+    if (metric == 5)
+      return static_cast<tree_base*>(
+          new tree_impl<kDim, pico_tree::metric_lninf>(pts, n, dim, max_leaf));
     if (metric == 3 && dim == 1)
       return static_cast<tree_base*>(
           new tree_impl<kDim, pico_tree::metric_so2>(pts, n, dim, max_leaf));

@@ -169,14 +169,16 @@ def device_count() -> int:
 
 
 class Metric(enum.Enum):
-    """Metrics of the reference binding (``def_kd_tree.cpp:14-17``).  ``L2Squared`` takes the
-    tuned kernels; ``L1`` and ``LPInf`` run the generic kernels with the metric swapped in."""
+    """Metrics of the reference binding (``def_kd_tree.cpp:14-17``) plus ``LNInf``, which the reference
+    has in C++ only (``metric_lninf``, metric.hpp:157-186).  ``L2Squared`` takes the tuned kernels; the
+    others run the generic kernels with the metric swapped in."""
     L1 = 1
     L2Squared = 2
     LPInf = 3
+    LNInf = 4
 
 
-_PTK_METRIC = {Metric.L2Squared: 0, Metric.L1: 1, Metric.LPInf: 2}  # PTK_METRIC_* of ptk.h
+_PTK_METRIC = {Metric.L2Squared: 0, Metric.L1: 1, Metric.LPInf: 2, Metric.LNInf: 3}  # PTK_METRIC_* of ptk.h
 
 
 class _LibraryBuffer:

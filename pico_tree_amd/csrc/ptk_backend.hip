@@ -1033,6 +1033,7 @@ int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, const uint32_t
   switch (t->metric.load()) {                                             \
     case PTK_METRIC_L1: { using M = ptk::MetricL1; CALL; } break;         \
     case PTK_METRIC_LPINF: { using M = ptk::MetricLInf; CALL; } break;    \
+    case PTK_METRIC_LNINF: { using M = ptk::MetricLNInf; CALL; } break;   \
     default: { using M = ptk::MetricL2; CALL; } break;                    \
   }
 
@@ -1255,7 +1256,7 @@ int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t
 }
 
 int ptk_tree_set_metric(ptk_tree* t, int metric) {
-  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LPINF)
+  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LNINF)
     return fail(PTK_ERR_INVALID, "bad metric");
   t->metric.store(metric);
   return PTK_OK;

@@ -226,6 +226,9 @@ int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipS
     } else if (metric_ == PTK_METRIC_LPINF) {           \
       using M = ptk::Metric64LInf;                      \
       CALL;                                             \
+    } else if (metric_ == PTK_METRIC_LNINF) {           \
+      using M = ptk::Metric64LNInf;                     \
+      CALL;                                             \
     } else {                                            \
       using M = ptk::Metric64L2;                        \
       CALL;                                             \
@@ -419,7 +422,7 @@ int ptk_tree64_get_info(const ptk_tree64* t, ptk_tree_info* info) {
 }
 
 int ptk_tree64_set_metric(ptk_tree64* t, int metric) {
-  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LPINF)
+  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LNINF)
     return fail(PTK_ERR_INVALID, "bad metric");
   t->metric.store(metric);
   return PTK_OK;

@@ -142,21 +142,46 @@ __device__ __forceinline__ float sel3(uint32_t axis, float a0, float a1, float a
 // The reference's euclidean search is generic over the metric (metric.hpp:72-150): `one(x)` is the
 // one-dimensional form used for the box offsets (search.hpp:80,84), `acc` adds one coordinate to a
 // point distance that starts at 0 (internal::sum, metric.hpp:36-51; metric_lpinf: std::max from 0).
+// `init` is what a point distance starts from and `pad` the coordinate difference of an axis the
+// space does not have (dim < 3 in the 3-D kernels, the tail of a batch of coordinates elsewhere):
+// it must leave the distance as it is.
 struct MetricL2 {  // metric_l2_squared
+  static constexpr bool kMin = false;
   __device__ __forceinline__ static float one(float x) { return f_mul(x, x); }
   __device__ __forceinline__ static float acc(float d, float diff) { return f_add(d, f_mul(diff, diff)); }
 };
 struct MetricL1 {  // metric_l1
+  static constexpr bool kMin = false;
   __device__ __forceinline__ static float one(float x) { return fabsf(x); }
   __device__ __forceinline__ static float acc(float d, float diff) { return f_add(d, fabsf(diff)); }
 };
 struct MetricLInf {  // metric_lpinf
+  static constexpr bool kMin = false;
   __device__ __forceinline__ static float one(float x) { return fabsf(x); }
   __device__ __forceinline__ static float acc(float d, float diff) {
     const float a = fabsf(diff);
     return d < a ? a : d;  // std::max(d, a)
   }
 };
+// metric_lninf (metric.hpp:157-186): d = std::min(d, |x - y|) from the largest float, so the first
+// coordinate's |x - y| is `one`; an axis that does not exist must contribute +inf (kMin: the
+// kernels hand such a query coordinate over as +inf, see pad_query()).
+struct MetricLNInf {
+  static constexpr bool kMin = true;
+  __device__ __forceinline__ static float one(float x) { return fabsf(x); }
+  __device__ __forceinline__ static float acc(float d, float diff) {
+    const float a = fabsf(diff);
+    return a < d ? a : d;  // std::min(d, a)
+  }
+};
+template <class M>
+__device__ __forceinline__ float metric_init() {  // what internal::sum / the min and max loops start from
+  return M::kMin ? 3.402823466e+38f : 0.0f;
+}
+template <class M>
+__device__ __forceinline__ float metric_pad() {  // difference of a coordinate that does not exist
+  return M::kMin ? __uint_as_float(0x7F800000u) : 0.0f;
+}
 // Three coordinates at once: acc(acc(acc(0, dx), dy), dz) without the exact no-op 0 + x.
 template <class M>
 __device__ __forceinline__ float point_distance3(float dx, float dy, float dz) {
@@ -688,6 +713,18 @@ __device__ __forceinline__ void load_query(
   z = dim > 2 ? p[2] : 0.0f;
 }
 
+// The 3-D kernels give a space of fewer dimensions zero coordinates for the missing axes -- exact
+// for sums and maxima, wrong for a minimum: there the query's missing coordinates become +inf
+// (|inf - 0| = inf never is the minimum; no split ever uses those axes).
+template <class M>
+__device__ __forceinline__ void pad_query(uint32_t dim, float& y, float& z) {
+  if (M::kMin) {
+    const float inf = __uint_as_float(0x7F800000u);
+    y = dim > 1 ? y : inf;
+    z = dim > 2 ? z : inf;
+  }
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char ptk_smem[];
 
 // ---- k = 1 ---------------------------------------------------------------------------
@@ -731,6 +768,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
+  pad_query<M>(dim, qy, qz);
 
   PTK_STACK(S, OVF, BLOCK, st, t);
   KnnPolicy<LIST_LDS> pol;
@@ -770,6 +808,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
+  pad_query<M>(dim, qy, qz);
   Record spill[OVF > 0 ? OVF : 1];
   Stack<S, OVF, BLOCK> st;
   st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
@@ -795,6 +834,7 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
+  pad_query<M>(dim, qy, qz);
 
   PTK_STACK(S, OVF, BLOCK, st, t);
   RadiusPolicy<FILL ? kRadiusFill : kRadiusCount> pol;
@@ -818,6 +858,7 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
+  pad_query<M>(dim, qy, qz);
 
   Record spill[OVF > 0 ? OVF : 1];
   Stack<S, OVF, BLOCK> st;

@@ -71,20 +71,39 @@ __device__ __forceinline__ double d_mul(double a, double b) { return __dmul_rn(a
 
 // metric.hpp:72-150, as MetricL2 / MetricL1 / MetricLInf of ptk_kernels.hpp.
 struct Metric64L2 {
+  static constexpr bool kMin = false;
   __device__ __forceinline__ static double one(double x) { return d_mul(x, x); }
   __device__ __forceinline__ static double acc(double d, double diff) { return d_add(d, d_mul(diff, diff)); }
 };
 struct Metric64L1 {
+  static constexpr bool kMin = false;
   __device__ __forceinline__ static double one(double x) { return fabs(x); }
   __device__ __forceinline__ static double acc(double d, double diff) { return d_add(d, fabs(diff)); }
 };
 struct Metric64LInf {
+  static constexpr bool kMin = false;
   __device__ __forceinline__ static double one(double x) { return fabs(x); }
   __device__ __forceinline__ static double acc(double d, double diff) {
     const double a = fabs(diff);
     return d < a ? a : d;  // std::max(d, a)
   }
 };
+struct Metric64LNInf {  // metric_lninf, as MetricLNInf of ptk_kernels.hpp
+  static constexpr bool kMin = true;
+  __device__ __forceinline__ static double one(double x) { return fabs(x); }
+  __device__ __forceinline__ static double acc(double d, double diff) {
+    const double a = fabs(diff);
+    return a < d ? a : d;  // std::min(d, a)
+  }
+};
+template <class M>
+__device__ __forceinline__ double metric64_init() {
+  return M::kMin ? kDblMax : 0.0;
+}
+template <class M>
+__device__ __forceinline__ double metric64_pad() {
+  return M::kMin ? __longlong_as_double(0x7FF0000000000000ll) : 0.0;
+}
 
 typedef PTK_LDS uint32_t LdsU32;
 #ifndef PTK_RING64
@@ -315,7 +334,7 @@ __device__ __forceinline__ void traverse64(const DevTree64& t, LdsDouble* q, Lds
       for (uint32_t j = 0; j < count; ++j) {
         const double* p = pts + (uint64_t)(begin + j) * t.stride;
         const int32_t pi = index[begin + j];
-        double d = 0.0;
+        double d = metric64_init<M>();
         // internal::sum (metric.hpp:36-51), kNdBatch coordinates loaded before the first is used; a
         // slot past the last axis contributes diff = 0, an exact no-op (see traverse_nd).
         for (uint32_t a = 0; a < dim; a += kNdBatch) {
@@ -327,7 +346,7 @@ __device__ __forceinline__ void traverse64(const DevTree64& t, LdsDouble* q, Lds
             qc[u] = q[au * 64];
           }
 #pragma unroll
-          for (uint32_t u = 0; u < kNdBatch; ++u) d = M::acc(d, a + u < dim ? d_sub(qc[u], pc[u]) : 0.0);
+          for (uint32_t u = 0; u < kNdBatch; ++u) d = M::acc(d, a + u < dim ? d_sub(qc[u], pc[u]) : metric64_pad<M>());
         }
         pol.visit(pi, d);
       }
@@ -462,8 +481,9 @@ __device__ __forceinline__ void search64(
   if constexpr (D3) {
     const double* row = queries + qi * t.dim;
     const double q0 = row[0];
-    const double q1 = t.dim > 1 ? row[1] : 0.0;
-    const double q2 = t.dim > 2 ? row[2] : 0.0;
+    // (a missing axis: zero like the points' for sums and maxima, +inf for the minimum of metric_lninf)
+    const double q1 = t.dim > 1 ? row[1] : metric64_pad<M>();
+    const double q2 = t.dim > 2 ? row[2] : metric64_pad<M>();
     st.init(0, 0, stack, slots);
     traverse64_3<M>(t, q0, q1, q2, pol, st);
   } else {

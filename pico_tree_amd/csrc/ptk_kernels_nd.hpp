@@ -75,7 +75,7 @@ __device__ __forceinline__ void traverse_nd(
       for (uint32_t j = 0; j < count; ++j) {
         const float* p = pts + (uint64_t)(begin + j) * dim;
         const int32_t pi = index[begin + j];
-        float d = 0.0f;
+        float d = metric_init<M>();
         // kNdBatch coordinates are loaded before the first is used (one coordinate per iteration
         // waits for memory dim times per point).  A slot past the last axis re-reads the last
         // coordinate and contributes diff = 0: acc(d, 0) == d exactly for the three metrics
@@ -89,7 +89,7 @@ __device__ __forceinline__ void traverse_nd(
             qc[u] = q[au * stride];
           }
 #pragma unroll
-          for (uint32_t u = 0; u < kNdBatch; ++u) d = M::acc(d, a + u < dim ? f_sub(qc[u], pc[u]) : 0.0f);
+          for (uint32_t u = 0; u < kNdBatch; ++u) d = M::acc(d, a + u < dim ? f_sub(qc[u], pc[u]) : metric_pad<M>());
         }
         pol.visit(pi, d);
       }

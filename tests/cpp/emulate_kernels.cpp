@@ -262,7 +262,7 @@ void* emu_create(const float* points, uint64_t n, uint32_t dim, const ptk_node* 
 
 void emu_destroy(void* h) { delete static_cast<Emu*>(h); }
 
-// 0 L2 squared (default), 1 L1, 2 LPInf: the metric of the searches that follow (ptk_tree_set_metric).
+// 0 L2 squared (default), 1 L1, 2 LPInf, 3 LNInf: the metric of the searches that follow (ptk_tree_set_metric).
 void emu_set_metric(void* h, int metric) { static_cast<Emu*>(h)->metric = metric; }
 
 uint32_t emu_max_depth(void* h) { return static_cast<Emu*>(h)->st.max_depth; }
@@ -278,6 +278,7 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
   if (need > 4 + 2048) return -2;
   if (t->metric == 1) return emu_knn_metric<ptk::MetricL1>(t, q, nq, k, e_inv, perm, small_stack, o);
   if (t->metric == 2) return emu_knn_metric<ptk::MetricLInf>(t, q, nq, k, e_inv, perm, small_stack, o);
+  if (t->metric == 3) return emu_knn_metric<ptk::MetricLNInf>(t, q, nq, k, e_inv, perm, small_stack, o);
   if (t->dim > 3) {  // any-dimension kernels
     if (list_in_lds == 2) {  // k-list in registers (k <= 32)
       if (k > 32) return -2;
@@ -334,6 +335,7 @@ int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e
   const float e_inv = 1.0f / e;
   if (t->metric != 0) {
     if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
+    else if (t->metric == 3) emu_radius_metric<ptk::MetricLNInf>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
     else emu_radius_metric<ptk::MetricLInf>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
     return 0;
   }
@@ -356,6 +358,7 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   const float e_inv = 1.0f / e;
   if (t->metric != 0) {
     if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
+    else if (t->metric == 3) emu_radius_metric<ptk::MetricLNInf>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
     else emu_radius_metric<ptk::MetricLInf>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
     if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
     return 0;
@@ -746,6 +749,9 @@ uint64_t emu64_save(void* h, void* buf, uint64_t cap) {
     CALL;                                      \
   } else if (t->metric == 2) {                 \
     using M = ptk::Metric64LInf;               \
+    CALL;                                      \
+  } else if (t->metric == 3) {                 \
+    using M = ptk::Metric64LNInf;              \
     CALL;                                      \
   } else {                                     \
     using M = ptk::Metric64L2;                 \

@@ -40,6 +40,7 @@ inline float __uint_as_float(uint32_t u) { float f; std::memcpy(&f, &u, 4); retu
 inline uint32_t __float_as_uint(float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; }
 inline int32_t __float_as_int(float f) { int32_t i; std::memcpy(&i, &f, 4); return i; }
 inline float __int_as_float(int32_t i) { float f; std::memcpy(&f, &i, 4); return f; }
+inline double __longlong_as_double(long long i) { double f; std::memcpy(&f, &i, 8); return f; }
 
 // Wave-level collectives.  The emulator runs the 64 lanes of a wavefront as 64
 // host threads; __ballot is the rendezvous (see emulate_kernels.cpp).

@@ -258,7 +258,7 @@ def test_subnormal_and_huge_coordinates(gpu):
         assert tree.search_knn(q, 3).tobytes() == ref.search_knn(q, 3).tobytes()
 
 
-@pytest.mark.parametrize("metric", ["L1", "LPInf"])
+@pytest.mark.parametrize("metric", ["L1", "LPInf", "LNInf"])
 @pytest.mark.parametrize("cloud,dim", [("uniform", 3), ("lidar", 3), ("ties", 3), ("u2", 2), ("u6", 6), ("u32", 32)])
 def test_other_metrics_bit_exact(gpu, cloud, dim, metric):
     """metric_l1 / metric_lpinf (metric.hpp:78-152) through ptk_tree_set_metric: same tree, the
@@ -277,7 +277,8 @@ def test_other_metrics_bit_exact(gpu, cloud, dim, metric):
     assert tree.search_knn(q, 6, 1.25).tobytes() == ref.search_knn(q, 6, e=1.25).tobytes()
     scale = float(np.ptp(pts, axis=0).max())
     radius = scale * {("L1", 2): 0.01, ("L1", 3): 0.02, ("L1", 6): 0.45, ("L1", 32): 7.0,
-                      ("LPInf", 2): 0.01, ("LPInf", 3): 0.02, ("LPInf", 6): 0.15, ("LPInf", 32): 0.5}[(metric, dim)]
+                      ("LPInf", 2): 0.01, ("LPInf", 3): 0.02, ("LPInf", 6): 0.15, ("LPInf", 32): 0.5,
+                      ("LNInf", 2): 0.0002, ("LNInf", 3): 0.0002, ("LNInf", 6): 0.0002, ("LNInf", 32): 0.0002}[(metric, dim)]
     got = tree.search_radius(q, radius)
     off, flat = ref.search_radius(q, radius)
     assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()

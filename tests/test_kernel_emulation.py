@@ -217,8 +217,8 @@ def test_emulated_box_search_any_dimension(dim, leaf):
     assert off[-1] > len(pts)
 
 
-@pytest.mark.parametrize("metric", ["L1", "LPInf"])
-@pytest.mark.parametrize("case", ["uniform3", "ties3", "dim2", "dim5"])
+@pytest.mark.parametrize("metric", ["L1", "LPInf", "LNInf"])
+@pytest.mark.parametrize("case", ["uniform3", "ties3", "dim2", "dim1", "dim5"])
 def test_emulated_kernels_other_metrics(case, metric):
     """metric_l1 / metric_lpinf swapped into the generic kernels (the launches the backend makes
     for ptk_tree_set_metric != L2 squared), against the oracle under the same metric."""
@@ -230,6 +230,8 @@ def test_emulated_kernels_other_metrics(case, metric):
         q, leaf = (np.round(ds.uniform_cloud(2_000, 3, 34) * 16) / 16).astype(np.float32), 10
     elif case == "dim2":
         pts, q, leaf = ds.uniform_cloud(8_000, 2, 35), ds.uniform_cloud(1_500, 2, 36), 5
+    elif case == "dim1":
+        pts, q, leaf = ds.uniform_cloud(3_000, 1, 39), ds.uniform_cloud(600, 1, 40), 4
     else:
         pts, q, leaf = ds.uniform_cloud(8_000, 5, 37), ds.uniform_cloud(800, 5, 38), 8
     emu = EmulatedTree(pts, leaf, pt.Metric[metric])
@@ -242,6 +244,8 @@ def test_emulated_kernels_other_metrics(case, metric):
             assert emu.search_knn(q, k, perm=perm, small_stack=small).tobytes() == want.tobytes(), (k, small)
     assert emu.search_knn(q, 5, e=1.4).tobytes() == ref.search_knn(q, 5, e=1.4).tobytes()
     radius = 0.04 * float(np.ptp(pts, axis=0).max()) * (2.0 if pts.shape[1] > 3 else 1.0)
+    if metric == "LNInf":  # the smallest coordinate difference: nearly every point is "near"
+        radius *= 0.01
     for kw in ({}, {"e": 1.5}):
         a, b = emu.search_radius(q, radius, **kw), ref.search_radius(q, radius, **kw)
         assert np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()

@@ -141,11 +141,12 @@ def test_kat_metric_l2_squared():
 
 
 def test_kat_metric_l1_lpinf():
-    """metric_test.cpp:16-24 (L1) and :47-55 (LPInf)."""
+    """metric_test.cpp:16-24 (L1), :47-55 (LPInf) and :57-65 (LNInf)."""
     assert oracle.distance("L1", [2, 4], [10, 1]) == 11.0
     assert oracle.distance("LPInf", [2, 4], [10, 1]) == 8.0
+    assert oracle.distance("LNInf", [2, 4], [10, 1]) == 3.0
     assert oracle.distance("L2Squared", [2, 4], [10, 1]) == 73.0
-    for m in ("L1", "LPInf"):
+    for m in ("L1", "LPInf", "LNInf"):
         assert oracle.distance_scalar(m, -3.1) == float(np.float32(3.1))
 
 
@@ -232,7 +233,7 @@ def test_port_equals_compiled_reference(case):
 
 
 @needs_ref
-@pytest.mark.parametrize("metric", ["L1", "LPInf"])
+@pytest.mark.parametrize("metric", ["L1", "LPInf", "LNInf"])
 @pytest.mark.parametrize("case", ["uniform3", "ties3", "lidar3", "dim2", "dim6"])
 def test_port_equals_compiled_reference_other_metrics(case, metric):
     """The same kd_tree searched under metric_l1 / metric_lpinf (metric.hpp:78-152): the port against
