@@ -75,7 +75,7 @@ def test_argument_validation():
     with pytest.raises(TypeError):
         pt.KdTree(pts, "L1")
     t = pt.KdTree(pts, pt.Metric.L1, device=pt.PTK_DEVICE_NONE)
-    assert lib.ptk_tree_set_metric(t._h, 3) == -1 and lib.ptk_tree_set_metric(t._h, -1) == -1
+    assert lib.ptk_tree_set_metric(t._h, 4) == -1 and lib.ptk_tree_set_metric(t._h, -1) == -1
     assert lib.ptk_tree_set_metric(t._h, pt._PTK_METRIC[pt.Metric.LPInf]) == 0
     # F-ordered (sdim, npts) input is the same memory as C-ordered (npts, sdim): accepted
     t = pt.KdTree(np.asfortranarray(pts.T), pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)

@@ -132,7 +132,7 @@ def test_double_entry_points_validate_arguments():
     assert lib.ptk_tree64_create_from_points(pts.ctypes.data, 0, 3, 10, none, ctypes.byref(h)) == -1
     assert lib.ptk_tree64_create_from_points(pts.ctypes.data, 100, 3, 0, none, ctypes.byref(h)) == -1
     assert lib.ptk_tree64_create_from_points(pts.ctypes.data, 100, 3, 10, none, ctypes.byref(h)) == 0
-    assert lib.ptk_tree64_set_metric(h, 3) == -1 and lib.ptk_tree64_set_metric(h, 1) == 0
+    assert lib.ptk_tree64_set_metric(h, 4) == -1 and lib.ptk_tree64_set_metric(h, 1) == 0
     out = np.zeros(100, dtype=pt.NEIGHBOR64)
     assert lib.ptk_search64_knn(h, pts.ctypes.data, 100, 1, 1.0, out.ctypes.data) == -3  # no device
     assert lib.ptk_search64_knn(None, pts.ctypes.data, 100, 1, 1.0, out.ctypes.data) == -1
