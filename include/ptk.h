@@ -327,6 +327,33 @@ int ptk_forest_search_knn_device(const ptk_forest* forest, const float* d_querie
                                  uint64_t max_leaves_visited,
                                  ptk_neighbor* d_out, void* stream);
 
+/* ---- several GPUs of one node ------------------------------------------- */
+/* One tree replicated on `n_devices` devices of this process (single process, no launcher):
+ * SURVEY.md 8(b) "multi-GPU variant takes a device list", 8(e).  What it replaces in the reference
+ * is the same OpenMP loop over query rows as ptk_search_knn (_pyco_tree/kd_tree.hpp:117-135) --
+ * queries are independent, so a batch is cut into n contiguous row ranges of ceil(nq / n) rows,
+ * range r on devices[r]; results land in the caller's row order.
+ *   ptk_multi_search_knn / _radius   host buffers: every device moves its own range; no collective.
+ *   ptk_multi_search_knn_device      queries and results on devices[0] (BASELINE configs[3]): the
+ *                                    ranges and the (index, distance) rows travel over xGMI as
+ *                                    grouped ncclSend / ncclRecv pairs; RCCL is loaded on first use
+ *                                    (PTK_ERR_DEVICE if it cannot be).  `stream`: a stream of
+ *                                    devices[0], or NULL.  Asynchronous like ptk_search_knn_device. */
+typedef struct ptk_multi ptk_multi;
+int ptk_multi_create_from_points(const float* points, uint64_t n_points, uint32_t dim, uint64_t max_leaf_size,
+                                 const int32_t* devices, uint32_t n_devices, ptk_multi** out);
+int ptk_multi_create(const ptk_tree_desc* desc, const int32_t* devices, uint32_t n_devices, ptk_multi** out);
+void ptk_multi_destroy(ptk_multi* multi);
+int ptk_multi_device_count(const ptk_multi* multi);
+/* The replica on devices[i] (owned by `multi`): for ptk_tree_set_metric, ptk_profile_*, ... */
+int ptk_multi_get_tree(const ptk_multi* multi, uint32_t i, const ptk_tree** tree);
+int ptk_multi_search_knn(const ptk_multi* multi, const float* queries, uint64_t nq, uint32_t k, float e,
+                         ptk_neighbor* out);
+int ptk_multi_search_radius(const ptk_multi* multi, const float* queries, uint64_t nq, float radius, float e, int sort,
+                            uint64_t* offsets, ptk_neighbor** out);
+int ptk_multi_search_knn_device(ptk_multi* multi, const float* d_queries, uint64_t nq, uint32_t k, float e,
+                                ptk_neighbor* d_out, void* stream);
+
 /* ---- measurement ------------------------------------------------------ */
 /* When enabled, every internal kernel launch of this handle is bracketed by HIP
  * events recorded on its stream (no host synchronisation at launch time, so it

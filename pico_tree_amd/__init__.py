@@ -126,6 +126,16 @@ _SIGNATURES = {
     "ptk_profile_enable": (c_int, [c_void_p, c_int]),
     "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
     "ptk_debug_knn1_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
+                                             POINTER(c_void_p)]),
+    "ptk_multi_create": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p)]),
+    "ptk_multi_destroy": (None, [c_void_p]),
+    "ptk_multi_device_count": (c_int, [c_void_p]),
+    "ptk_multi_get_tree": (c_int, [c_void_p, c_uint32, POINTER(c_void_p)]),
+    "ptk_multi_search_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p]),
+    "ptk_multi_search_radius": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_float, c_int, c_void_p,
+                                        POINTER(c_void_p)]),
+    "ptk_multi_search_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p, c_void_p]),
 }
 
 #: Every symbol include/ptk.h declares; tests check the library exports them all.
@@ -649,6 +659,74 @@ class KdTree:
         if not e > 0:
             raise ValueError("e must be positive")
         return e, nns, sort
+
+
+class MultiKdTree:
+    """One kd-tree replicated on several GPUs of this node, single process (``ptk_multi_*``).
+
+    A batch is cut into ``len(devices)`` contiguous row ranges, range ``r`` searched on
+    ``devices[r]``; rows come back in the caller's order and are bit-identical to a single-device
+    :class:`KdTree`.  Host arrays move range by range (no inter-GPU traffic); with torch tensors on
+    ``devices[0]`` the ranges and the (index, distance) rows travel over xGMI through RCCL."""
+
+    def __init__(self, pts, max_leaf_size: int = 10, devices=None):
+        p = np.ascontiguousarray(pts, dtype=np.float32)
+        if p.ndim != 2:
+            raise ValueError("pts must be (n, sdim)")
+        if devices is None:
+            devices = list(range(device_count()))
+        self._devices = np.ascontiguousarray(devices, dtype=np.int32)
+        self._sdim = p.shape[1]
+        self._h = c_void_p()
+        _check(_load().ptk_multi_create_from_points(p.ctypes.data, p.shape[0], p.shape[1], int(max_leaf_size),
+                                                     self._devices.ctypes.data, len(self._devices), byref(self._h)))
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            _load().ptk_multi_destroy(self._h)
+            self._h = None
+
+    @property
+    def devices(self):
+        return [int(d) for d in self._devices]
+
+    def _queries(self, q):
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        if q.ndim != 2 or q.shape[1] != self._sdim:
+            raise ValueError("pts must be (nq, sdim)")
+        return q
+
+    def search_knn(self, pts, k: int, e: float | None = None):
+        """Host arrays: ``(nq,)`` (k = 1) or ``(nq, k)`` :data:`NEIGHBOR` records; a torch tensor on
+        ``devices[0]``: :class:`DeviceNeighbors` (asynchronous on the current torch stream)."""
+        k = int(k)
+        if _is_torch(pts):
+            import torch
+
+            if pts.dtype != torch.float32 or pts.dim() != 2 or pts.shape[1] != self._sdim or not pts.is_contiguous():
+                raise ValueError("pts must be a contiguous float32 (nq, sdim) tensor")
+            if pts.device.index != int(self._devices[0]):
+                raise ValueError("pts must live on devices[0]")
+            out = torch.empty((pts.shape[0], k, 2), dtype=torch.int32, device=pts.device)
+            stream = torch.cuda.current_stream(pts.device).cuda_stream
+            _check(_load().ptk_multi_search_knn_device(self._h, pts.data_ptr(), pts.shape[0], k,
+                                                       np.float32(1.0 if e is None else e), out.data_ptr(), stream))
+            return DeviceNeighbors(out)
+        q = self._queries(pts)
+        out = np.empty((q.shape[0],) if k == 1 else (q.shape[0], k), dtype=NEIGHBOR)
+        _check(_load().ptk_multi_search_knn(self._h, q.ctypes.data, q.shape[0], k, np.float32(1.0 if e is None else e),
+                                            out.ctypes.data))
+        return out
+
+    def search_radius(self, pts, radius: float, e: float | None = None, sort: bool = False) -> "DArray":
+        q = self._queries(pts)
+        offsets = np.zeros(q.shape[0] + 1, dtype=np.uint64)
+        rows = c_void_p()
+        lib = _load()
+        _check(lib.ptk_multi_search_radius(self._h, q.ctypes.data, q.shape[0], np.float32(radius),
+                                           np.float32(1.0 if e is None else e), int(bool(sort)), offsets.ctypes.data,
+                                           byref(rows)))
+        return DArray(offsets, _adopt(lib, rows, int(offsets[-1]), NEIGHBOR))
 
 
 class KdForest:

@@ -24,6 +24,7 @@ HEADERS = [
     os.path.join(CSRC, "ptk_backend_f64.hpp"),
     os.path.join(CSRC, "ptk_forest.hpp"),
     os.path.join(CSRC, "ptk_forest_host.hpp"),
+    os.path.join(CSRC, "ptk_multi.hpp"),
     os.path.join(CSRC, "ptk_encode.hpp"),
     os.path.join(ROOT, "include", "ptk.h"),
     os.path.join(ROOT, "include", "pico_tree", "internal", "flat_tree.hpp"),

@@ -192,3 +192,18 @@ def test_degenerate_point_set_is_refused_not_crashed():
         pt.KdTree(pts, pt.Metric.L2Squared, 5, device=pt.PTK_DEVICE_NONE)
     t = pt.KdTree(np.full((6_000, 3), 1.5, dtype=np.float32), pt.Metric.L2Squared, 2, device=pt.PTK_DEVICE_NONE)
     assert len(t.flat()[0]) == 11_997  # deep (2 999 levels) but built
+
+
+def test_multi_device_entry_points_fail_loudly_without_a_device():
+    """ptk_multi_*: argument checks, and no silent single-device or CPU stand-in."""
+    import torch
+    lib = pt._load()
+    pts = ds.uniform_cloud(100, 3, seed=5)
+    h = ctypes.c_void_p()
+    dev = np.zeros(1, dtype=np.int32)
+    assert lib.ptk_multi_create_from_points(pts.ctypes.data, 100, 3, 10, None, 0, ctypes.byref(h)) == -1
+    if not torch.cuda.is_available():
+        rc = lib.ptk_multi_create_from_points(pts.ctypes.data, 100, 3, 10, dev.ctypes.data, 1, ctypes.byref(h))
+        assert rc == -3 and not h.value  # PTK_ERR_DEVICE
+    assert lib.ptk_multi_device_count(None) == 0
+    assert lib.ptk_multi_search_knn(None, pts.ctypes.data, 1, 1, ctypes.c_float(1.0), None) == -1

@@ -588,3 +588,26 @@ def test_box_search_on_device_buffers(gpu, dim):
         torch.cuda.synchronize()
         assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off) and want_off[-1] > len(q)
         assert np.array_equal(rows.cpu().numpy(), want)
+
+
+def test_multi_device_handle_on_the_devices_present(gpu, monkeypatch):
+    """ptk_multi_* with every visible device (one on the test box): host form (ranges moved by the
+    devices themselves) and device form; with PTK_MULTI_SELF_GATHER=1 devices[0] sends its rows to
+    itself, so the grouped ncclSend / ncclRecv path runs on a one-GPU box too."""
+    import torch
+    pts, q = ds.lidar_cloud(60_000, 1), ds.lidar_cloud(30_001, 2, pose=(3.0, 1.5))
+    ref = oracle.Oracle(pts, 10, "port")
+    multi = pt.MultiKdTree(pts, 10, devices=list(range(pt.device_count())))
+    want1, want8 = ref.search_knn(q, 1)[:, 0], ref.search_knn(q, 8)
+    assert multi.search_knn(q, 1).tobytes() == want1.tobytes()
+    assert multi.search_knn(q, 8).tobytes() == want8.tobytes()
+    got = multi.search_radius(q, 1.0)
+    off, flat = ref.search_radius(q, 1.0)
+    assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+    dq = torch.from_numpy(q).to(f"cuda:{multi.devices[0]}")
+    for self_gather in ("0", "1"):
+        monkeypatch.setenv("PTK_MULTI_SELF_GATHER", self_gather)
+        for k, want in ((1, want1), (8, want8)):
+            rows = multi.search_knn(dq, k).numpy()
+            torch.cuda.synchronize()
+            assert (rows[:, 0] if k == 1 else rows).tobytes() == want.tobytes(), (self_gather, k)
