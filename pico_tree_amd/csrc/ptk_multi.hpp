@@ -80,7 +80,7 @@ Rccl& rccl() {
 struct ptk_multi {
   std::vector<int> devices;
   std::vector<ptk_tree*> trees;       // one replica per device
-  std::vector<hipStream_t> streams;   // per device (device 0: used when the caller passes none)
+  std::vector<hipStream_t> streams;   // per device: the peers' work of a device-buffer call
   std::vector<hipEvent_t> done;       // per device: its part of the current call has been enqueued and finished
   std::vector<ncclComm_t> comms;      // made on the first device-buffer call with more than one device
   // staging of the device-buffer form on the peers (grow-only): their range of the queries and their rows
@@ -329,7 +329,7 @@ int ptk_multi_search_radius(const ptk_multi* m, const float* q, uint64_t nq, flo
   return rc;
 }
 
-// Device buffers on devices[0]; `stream` is a stream of devices[0] (null: the handle's own).
+// Device buffers on devices[0]; `stream` is a stream of devices[0] (null: its default stream).
 int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uint32_t k, float e, ptk_neighbor* d_out,
                                 void* stream) {
   if (m == nullptr) return fail(PTK_ERR_INVALID, "null handle");
@@ -342,7 +342,7 @@ int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uin
   // PTK_MULTI_SELF_GATHER=1 (tests on a one-GPU box): devices[0] sends its own rows to itself too,
   // so that the RCCL path runs whatever the number of devices.
   const bool self = env_int("PTK_MULTI_SELF_GATHER", 0) != 0;
-  hipStream_t s0 = stream != nullptr ? static_cast<hipStream_t>(stream) : m->streams[0];
+  hipStream_t s0 = static_cast<hipStream_t>(stream);  // null = the default stream of devices[0], as everywhere in HIP
   int rc = PTK_OK;
   if (n > 1 || self) {
     rc = multi_comms(m);
