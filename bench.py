@@ -63,6 +63,10 @@ def parse_args():
     ap.add_argument("--k", type=int, default=1)
     ap.add_argument("--n", type=int, default=None, help="tree points (default: config 2)")
     ap.add_argument("--nq", type=int, default=None, help="queries (default: config 2)")
+    ap.add_argument("--points", default=None,
+                    help="tree points from a file instead of a synthetic cloud: the reference's write_bin format "
+                         "(float32 triples, e.g. the Bremen scans0.bin), .fvecs / .bvecs or .npy")
+    ap.add_argument("--queries", default=None, help="query points from a file (same formats)")
     ap.add_argument("--leaf", type=int, default=10)
     ap.add_argument("--reorder", choices=["auto", "on", "off"], default="auto")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
@@ -304,7 +308,16 @@ def main():
         return np.ascontiguousarray(qq[ds.morton_order(qq)]) if args.order == "morton" else qq
 
     t0 = time.perf_counter()
-    pts, q = ds.config2_clouds(args.cloud, n, nq)
+    if args.points or args.queries:
+        if not (args.points and args.queries):
+            raise SystemExit("--points and --queries go together")
+        pts, q = ds.load_points(args.points), ds.load_points(args.queries)
+        if pts.shape[1] != 3 or q.shape[1] != 3:
+            raise SystemExit("bench.py times the 3-D search; use tools/bench_forest.py / tools/bench_nd.py otherwise")
+        n, nq = len(pts), len(q)
+        args.n, args.nq = n, nq  # not the BASELINE sizes: the metric string and the extras follow
+    else:
+        pts, q = ds.config2_clouds(args.cloud, n, nq)
     if args.order == "morton":
         q = np.ascontiguousarray(q[ds.morton_order(q)])
     gen_s = time.perf_counter() - t0
@@ -500,7 +513,8 @@ def main():
                       else f"Mqueries/sec, knn={k} 3D L2",
             "value": round(value, 3), "unit": "Mqueries/s", "n_gpus": n_gpus, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic" if not args.points else f"files {os.path.basename(args.points)} / {os.path.basename(args.queries)}",
             "config": {"workload": f"BASELINE configs[{3 if world > 1 and not weak else 1}]: cloud {args.cloud} "
                                    f"({'LiDAR-like room scan' if args.cloud == 'L' else 'uniform cube'}), "
                                    f"{n} tree points / {nq} queries, knn={k}, max_leaf_size={args.leaf}, "

@@ -18,6 +18,8 @@ C++ ``<random>`` implementation.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 _M64 = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -126,3 +128,75 @@ def sift_like_cloud(n: int, dim: int = 128, seed: int = 1, centres: int = 1000, 
     which = rng.integers(0, centres, size=n)
     x = c[which] + rng.normal(0.0, sigma, size=(n, dim)).astype(np.float32)
     return np.ascontiguousarray(np.rint(np.clip(x, 0.0, 218.0)).astype(np.float32))
+
+
+# ---- real data: the reference's own input files ---------------------------------------------------
+# (None of these ship here -- there is no network -- but a user who has the Bremen scans converted
+# by the reference's uosr_to_bin tool, or SIFT-1M from corpus-texmex, can hand them to bench.py
+# --points / --queries or to tools/bench_forest.py.)
+
+def read_bin(path: str, dim: int = 3, dtype=np.float32) -> np.ndarray:
+    """A file written by the reference's ``write_bin`` (pico_toolshed/format/format_bin.hpp:9-32):
+    the raw elements of a ``std::vector<point>`` back to back, no header -- for its benchmark
+    (examples/benchmark/benchmark.hpp:28-31: ``scans0.bin`` / ``scans1.bin``) float32 triples.
+    Returns ``(n, dim)``; trailing bytes that do not make a whole point are ignored, as
+    ``file_size / sizeof(T)`` does there."""
+    dt = np.dtype(dtype)
+    n = os.path.getsize(path) // (dt.itemsize * dim)
+    return np.ascontiguousarray(np.fromfile(path, dtype=dt, count=n * dim).reshape(n, dim))
+
+
+def write_bin(path: str, points: np.ndarray) -> None:
+    """The inverse of :func:`read_bin` (format_bin.hpp:9-19)."""
+    np.ascontiguousarray(points).tofile(path)
+
+
+def read_xvecs(path: str) -> np.ndarray:
+    """``.fvecs`` / ``.bvecs`` / ``.ivecs`` of corpus-texmex as the reference reads them
+    (pico_toolshed/format/format_xvecs.hpp:41-67): every row is an int32 component count followed
+    by that many float32 / uint8 / int32 values; the element type comes from the file name.
+    Returns ``(rows, dim)`` in the file's element type (convert ``bvecs`` with ``astype(float32)``
+    for a tree)."""
+    low = path.lower()
+    if low.endswith(".fvecs"):
+        dt = np.dtype("<f4")
+    elif low.endswith(".bvecs"):
+        dt = np.dtype("u1")
+    elif low.endswith(".ivecs"):
+        dt = np.dtype("<i4")
+    else:
+        raise ValueError("filename expected to end with .fvecs, .bvecs or .ivecs")
+    size = os.path.getsize(path)
+    if size < 4:
+        return np.empty((0, 0), dtype=dt)
+    dim = int(np.fromfile(path, dtype="<i4", count=1)[0])
+    if dim <= 0:
+        raise ValueError("bad component count in the first row")
+    row = 4 + dt.itemsize * dim
+    rows = size // row
+    raw = np.fromfile(path, dtype=np.uint8, count=rows * row).reshape(rows, row)
+    if not np.all(raw[:, :4].copy().view("<i4")[:, 0] == dim):
+        raise ValueError("rows of different lengths")
+    return np.ascontiguousarray(raw[:, 4:]).view(dt).reshape(rows, dim)
+
+
+def write_xvecs(path: str, rows: np.ndarray) -> None:
+    """Writes ``rows`` in the format :func:`read_xvecs` reads (element type from the file name)."""
+    low = path.lower()
+    dt = np.dtype("<f4") if low.endswith(".fvecs") else np.dtype("u1") if low.endswith(".bvecs") else np.dtype("<i4")
+    r = np.ascontiguousarray(rows, dtype=dt)
+    out = np.empty((r.shape[0], 4 + dt.itemsize * r.shape[1]), dtype=np.uint8)
+    out[:, :4] = np.full(r.shape[0], r.shape[1], dtype="<i4").view(np.uint8).reshape(-1, 4)
+    out[:, 4:] = r.view(np.uint8).reshape(r.shape[0], -1)
+    out.tofile(path)
+
+
+def load_points(path: str, dim: int = 3) -> np.ndarray:
+    """float32 ``(n, dim)`` points from a ``.bin`` (reference ``write_bin``), ``.fvecs`` / ``.bvecs`` or
+    ``.npy`` file."""
+    low = path.lower()
+    if low.endswith((".fvecs", ".bvecs", ".ivecs")):
+        return np.ascontiguousarray(read_xvecs(path), dtype=np.float32)
+    if low.endswith(".npy"):
+        return np.ascontiguousarray(np.load(path), dtype=np.float32)
+    return read_bin(path, dim)

@@ -207,3 +207,26 @@ def test_multi_device_entry_points_fail_loudly_without_a_device():
         assert rc == -3 and not h.value  # PTK_ERR_DEVICE
     assert lib.ptk_multi_device_count(None) == 0
     assert lib.ptk_multi_search_knn(None, pts.ctypes.data, 1, 1, ctypes.c_float(1.0), None) == -1
+
+
+def test_input_file_formats_round_trip(tmp_path):
+    """CPU tier: the reference's write_bin / read_bin (format_bin.hpp:9-32) and xvecs readers
+    (format_xvecs.hpp:41-67) as pico_tree_amd.datasets reads them."""
+    from pico_tree_amd import datasets as ds
+    pts = ds.uniform_cloud(1000, 3, 5)
+    ds.write_bin(str(tmp_path / "scan.bin"), pts)
+    assert ds.read_bin(str(tmp_path / "scan.bin")).tobytes() == pts.tobytes()
+    with open(tmp_path / "scan.bin", "ab") as f:
+        f.write(b"\x00" * 7)  # a torn tail is ignored (file_size / sizeof(point))
+    assert ds.load_points(str(tmp_path / "scan.bin")).tobytes() == pts.tobytes()
+    rows = ds.sift_like_cloud(50, 128, seed=3)
+    ds.write_xvecs(str(tmp_path / "base.fvecs"), rows)
+    raw = np.fromfile(tmp_path / "base.fvecs", dtype=np.uint8)
+    assert len(raw) == 50 * (4 + 4 * 128) and raw[:4].view("<i4")[0] == 128
+    assert ds.read_xvecs(str(tmp_path / "base.fvecs")).tobytes() == rows.tobytes()
+    ds.write_xvecs(str(tmp_path / "base.bvecs"), rows)
+    b = ds.read_xvecs(str(tmp_path / "base.bvecs"))
+    assert b.dtype == np.uint8 and np.array_equal(b.astype(np.float32), rows)  # SIFT bytes
+    assert ds.load_points(str(tmp_path / "base.bvecs")).dtype == np.float32
+    with pytest.raises(ValueError):
+        ds.read_xvecs(str(tmp_path / "scan.bin"))

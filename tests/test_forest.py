@@ -97,6 +97,37 @@ def test_forest_recall_and_device_buffers(gpu):
 
 
 @pytest.mark.gpu
+def test_forest_config5_at_full_size(gpu):
+    """BASELINE configs[4] at its own size: 1 M x 128 points (SIFT-like synthetic), 10 k queries,
+    8 trees, leaf 32, 64 leaves per tree, k = 10 (the reference's SIFT setting,
+    examples/kd_forest/kd_forest.cpp:113-123).  Recall against the EXACT neighbours (brute force on
+    the GPU, test-side torch), no queue entry dropped, and bit-equality with the restated forest
+    on a 500-query sample."""
+    import torch
+
+    n, nq, dim, k = 1_000_000, 10_000, 128, 10
+    pts, q = ds.sift_like_cloud(n, dim, seed=1), ds.sift_like_cloud(nq, dim, seed=2)
+    forest = pt.KdForest(pts, 32, 8, seed=1, device=gpu)
+    got = forest.search_knn(q, k, 64)
+    assert forest.dropped == 0
+    dev = torch.device("cuda", gpu)
+    dp = torch.from_numpy(pts).to(dev)
+    pn = (dp.double() ** 2).sum(1)
+    exact = np.empty((nq, k), dtype=np.int64)
+    for lo in range(0, nq, 500):  # float64 distances: the values are integers below 2^24, so this is exact
+        dq = torch.from_numpy(q[lo:lo + 500]).to(dev).double()
+        d2 = (dq ** 2).sum(1)[:, None] - 2.0 * (dq @ dp.double().T) + pn[None, :]
+        exact[lo:lo + 500] = torch.topk(d2, k, dim=1, largest=False).indices.cpu().numpy()
+        del d2
+    r1 = float(np.mean(got["index"][:, 0] == exact[:, 0]))
+    r10 = float(np.mean([len(set(a.tolist()) & set(b.tolist())) / k for a, b in zip(got["index"], exact)]))
+    assert r1 >= 0.93 and r10 >= 0.90, (r1, r10)
+    sample = np.arange(0, nq, nq // 500)[:500]
+    want = oracle.ForestOracle(pts, 32, forest.rotations).search_knn(q[sample], k, 64)
+    assert got[sample].tobytes() == want.tobytes()
+
+
+@pytest.mark.gpu
 def test_cpp_kd_forest_header(gpu, tmp_path):
     """include/pico_understory/kd_forest.hpp (the reference's class shape) through the C ABI:
     per-query search_nn, batched search_nn / search_knn, all equal to the Python binding and

@@ -181,3 +181,4 @@ def test_file_io_is_byte_compatible_with_the_reference(gpu, tmp_path):
     got = t2.search_radius(q, 0.002)
     off, flat = ref.search_radius(q, 0.002)
     assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+

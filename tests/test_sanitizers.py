@@ -1,0 +1,106 @@
+"""CPU tier: the host-side C++ under the sanitizers (SURVEY.md section 5 asks for
+-fsanitize=address,undefined on the host tier; the GPU pool has no device sanitizer).
+
+* AddressSanitizer + UndefinedBehaviorSanitizer: tests/cpp/host_api_main.cpp, i.e. the header-only
+  API of include/pico_tree (builder, per-query searches, visitors, save / load, parallel_partition),
+  and the threaded builder driver.
+* ThreadSanitizer: the task-parallel tree build (subtree tasks + parallel_partition) with 8 threads.
+* UndefinedBehaviorSanitizer: the DEVICE source (ptk_kernels*.hpp) compiled for the host as the
+  kernel emulator does, run lane by lane and as wavefront fibers on a few searches.  (ASan does not
+  follow ucontext fibers without annotations, so the emulator gets UBSan only.)
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+import oracle
+import pico_tree_amd as pt
+from pico_tree_amd import datasets as ds
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+INC = os.path.join(ROOT, "include")
+CPP = os.path.join(ROOT, "tests", "cpp")
+
+
+def _have(flag):
+    probe = subprocess.run(["g++", flag, "-x", "c++", "-", "-o", "/dev/null"], input=b"int main(){return 0;}",
+                           capture_output=True)
+    return probe.returncode == 0
+
+
+def _run(cmd, **env):
+    e = dict(os.environ, **env)
+    r = subprocess.run(cmd, capture_output=True, env=e, timeout=600)
+    assert r.returncode == 0, (r.stdout.decode()[-2000:], r.stderr.decode()[-4000:])
+    assert b"runtime error" not in r.stderr and b"Sanitizer" not in r.stderr, r.stderr.decode()[-4000:]
+    return r
+
+
+@pytest.mark.skipif(not _have("-fsanitize=address,undefined"), reason="no ASan / UBSan runtime")
+def test_host_api_under_asan_and_ubsan(tmp_path):
+    exe = str(tmp_path / "host_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-DPTK_TEST_HOST_ONLY",
+                           "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-fno-omit-frame-pointer",
+                           "-I" + INC, os.path.join(CPP, "host_api_main.cpp"), "-o", exe])
+    pts = ds.uniform_cloud(12_000, 3, seed=91)
+    q = ds.uniform_cloud(600, 3, seed=92)
+    q[:20] = pts[:20]
+    pts.tofile(tmp_path / "points.bin")
+    q.tofile(tmp_path / "queries.bin")
+    _run([exe, "host", str(tmp_path)], ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1")
+    ref = oracle.Oracle(pts, 10, "port")
+    assert np.fromfile(tmp_path / "nn.bin", dtype=pt.NEIGHBOR).tobytes() == ref.search_nn(q).tobytes()
+    assert np.fromfile(tmp_path / "save.bin", dtype=np.uint8).tobytes() == ref.save_bytes()
+    exe2 = str(tmp_path / "build_asan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-fsanitize=address,undefined",
+                           "-fno-sanitize-recover=undefined", "-I" + INC, os.path.join(CPP, "build_threads_main.cpp"),
+                           "-o", exe2])
+    _run([exe2, "200000", "8"], ASAN_OPTIONS="detect_leaks=1")
+
+
+@pytest.mark.skipif(not _have("-fsanitize=thread"), reason="no TSan runtime")
+def test_threaded_build_under_tsan(tmp_path):
+    exe = str(tmp_path / "build_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-pthread", "-fsanitize=thread", "-I" + INC,
+                           os.path.join(CPP, "build_threads_main.cpp"), "-o", exe])
+    r = _run([exe, "300000", "8"], TSAN_OPTIONS="halt_on_error=1:second_deadlock_stack=1")
+    assert b"identical with 1 and 8 threads" in r.stdout
+
+
+@pytest.mark.skipif(not _have("-fsanitize=undefined"), reason="no UBSan runtime")
+def test_device_source_under_ubsan_in_the_emulator(tmp_path):
+    lib = str(tmp_path / "libptk_emu_ubsan.so")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-ffp-contract=off", "-fPIC", "-shared", "-pthread",
+                           "-fsanitize=undefined", "-fno-sanitize-recover=undefined", "-w",
+                           "-I" + os.path.join(CPP, "hip_stub"), "-I" + INC, "-I" + os.path.join(ROOT, "pico_tree_amd", "csrc"),
+                           os.path.join(CPP, "emulate_kernels.cpp"), "-o", lib])
+    # Run in a child process: -fno-sanitize-recover aborts the process on the first report.
+    code = f"""
+import numpy as np, sys
+sys.path.insert(0, {ROOT!r})
+import tests.emu as emu
+emu._LIB = {lib!r}
+import oracle
+from pico_tree_amd import datasets as ds
+pts, q = ds.lidar_cloud(20_000, 1), ds.lidar_cloud(1_500, 2, pose=(3.0, 1.5))
+t = emu.EmulatedTree(pts, 10)
+ref = oracle.Oracle(pts, 10, "port")
+perm, _ = t.morton_permutation(q)
+want = ref.search_knn(q, 1)
+for variant in (3, 5, 9):
+    got, _ = t.two_phase_knn1(q, perm=perm, variant=variant)
+    assert got.tobytes() == want.tobytes(), variant
+assert t.search_knn(q, 16, perm=perm, list_in_lds=2).tobytes() == ref.search_knn(q, 16).tobytes()
+off, flat = ref.search_radius(q, 1.0)
+goff, gflat, _ = t.search_radius_captured(q, 1.0, perm=perm)
+assert np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
+print("ok")
+"""
+    r = _run(["python", "-c", code], UBSAN_OPTIONS="print_stacktrace=1")
+    assert b"ok" in r.stdout
