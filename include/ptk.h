@@ -155,9 +155,25 @@ int ptk_tree_set_reorder(ptk_tree* tree, int mode);
  *   PTK_METRIC_L1          metric_l1:    sum of |differences|
  *   PTK_METRIC_LPINF       metric_lpinf: max of |differences|
  *   PTK_METRIC_LNINF       metric_lninf: min of |differences| (metric.hpp:157-186)
+ *   PTK_METRIC_SO2         metric_so2 (metric.hpp:186-220): points on the circle [0, 1] / 0 ~ 1; dim 1 only
+ *   PTK_METRIC_SE2_SQUARED metric_se2_squared (metric.hpp:228-257): x, y on the plane, angle on the circle;
+ *                          dim 3 only.  The two topological metrics are searched as the reference's
+ *                          search_nearest_topological does (kd_tree_search.hpp:115-229) and need the four
+ *                          bounds per branch: trees made by ptk_tree_create_from_points have them; for
+ *                          ptk_tree_create hand them over with ptk_tree_set_outer_bounds first.  float32,
+ *                          knn and radius searches (the box search of these trees stays on the host members).
  * Set once, before the first search. */
-enum { PTK_METRIC_L2_SQUARED = 0, PTK_METRIC_L1 = 1, PTK_METRIC_LPINF = 2, PTK_METRIC_LNINF = 3 };
+enum { PTK_METRIC_L2_SQUARED = 0, PTK_METRIC_L1 = 1, PTK_METRIC_LPINF = 2, PTK_METRIC_LNINF = 3, PTK_METRIC_SO2 = 4,
+       PTK_METRIC_SE2_SQUARED = 5 };
 int ptk_tree_set_metric(ptk_tree* tree, int metric);
+/* The two bounds of every branch that ptk_node does not hold -- outer[2 i] = min of the left
+ * child's box, outer[2 i + 1] = max of the right child's box along the split axis of node i (the
+ * other half of the reference's kd_tree_node_topological, kd_tree_node.hpp:56-67); entries of leaf
+ * nodes are ignored.  Needed (before ptk_tree_set_metric) by the topological metrics on a tree made
+ * by ptk_tree_create. */
+int ptk_tree_set_outer_bounds(ptk_tree* tree, const float* outer, uint64_t n_nodes);
+/* The same array back (2 floats per node; PTK_ERR_INVALID if the tree has none). */
+int ptk_tree_get_outer_bounds(const ptk_tree* tree, float* outer);
 
 /* The tree in the reference's own binary format (kd_tree::save / kd_tree::load,
  * kd_tree.hpp:336-370, internal/kd_tree_data.hpp:43-58,90-135): sdim, indices,

@@ -83,6 +83,8 @@ _SIGNATURES = {
     "ptk_tree_get_flat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]),
     "ptk_tree_set_reorder": (c_int, [c_void_p, c_int]),
     "ptk_tree_set_metric": (c_int, [c_void_p, c_int]),
+    "ptk_tree_set_outer_bounds": (c_int, [c_void_p, c_void_p, c_uint64]),
+    "ptk_tree_get_outer_bounds": (c_int, [c_void_p, c_void_p]),
     "ptk_tree_serialize": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
     "ptk_tree_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
                                             POINTER(c_void_p)]),
@@ -186,9 +188,14 @@ class Metric(enum.Enum):
     L2Squared = 2
     LPInf = 3
     LNInf = 4
+    #: the reference's topological metrics (C++ only there, metric.hpp:186-257): points on the circle
+    #: [0, 1] / 0 ~ 1 (1-D), and planar poses x, y, angle (3-D).  float32; knn and radius searches.
+    SO2 = 5
+    SE2Squared = 6
 
 
-_PTK_METRIC = {Metric.L2Squared: 0, Metric.L1: 1, Metric.LPInf: 2, Metric.LNInf: 3}  # PTK_METRIC_* of ptk.h
+_PTK_METRIC = {Metric.L2Squared: 0, Metric.L1: 1, Metric.LPInf: 2, Metric.LNInf: 3, Metric.SO2: 4,
+               Metric.SE2Squared: 5}  # PTK_METRIC_* of ptk.h
 
 
 class _LibraryBuffer:
@@ -435,7 +442,7 @@ class KdTree:
         """The metric's one-dimensional form in the tree's scalar type: ``x * x`` for L2Squared, ``|x|``
         for L1 and LPInf (metric.hpp:95-98, :120-123, :147-150)."""
         x = self._real(scalar)
-        return float(x * x) if self._metric is Metric.L2Squared else float(abs(x))
+        return float(x * x) if self._metric in (Metric.L2Squared, Metric.SE2Squared) else float(abs(x))
 
     def info(self) -> dict:
         inf = _Info()

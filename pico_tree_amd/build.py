@@ -20,6 +20,7 @@ SOURCES = [os.path.join(CSRC, "ptk_backend.hip")]
 HEADERS = [
     os.path.join(CSRC, "ptk_kernels.hpp"),
     os.path.join(CSRC, "ptk_kernels_nd.hpp"),
+    os.path.join(CSRC, "ptk_kernels_topo.hpp"),
     os.path.join(CSRC, "ptk_kernels_f64.hpp"),
     os.path.join(CSRC, "ptk_backend_f64.hpp"),
     os.path.join(CSRC, "ptk_forest.hpp"),

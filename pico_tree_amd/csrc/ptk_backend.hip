@@ -31,6 +31,7 @@
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_nd.hpp"
+#include "ptk_kernels_topo.hpp"
 #include "ptk_forest.hpp"
 
 // Host-side builder: the product's own header-only flat-tree builder.
@@ -138,6 +139,7 @@ struct ptk_tree {
   std::vector<ptk_node> nodes;
   std::vector<int32_t> indices;
   std::vector<float> root_min, root_max;
+  std::vector<float> outer;  // per node {left_min, right_max} (topological metrics); may be empty
   uint32_t max_depth = 0;
   uint64_t n_leaves = 0;
   uint32_t max_leaf_count = 0;
@@ -150,6 +152,7 @@ struct ptk_tree {
   void* d_ranges = nullptr; // dim <= 3: subtree ranges for the box search
   void* d_axes = nullptr;   // dim > 3 only
   void* d_index = nullptr;  // dim > 3 only
+  void* d_outer = nullptr;  // topological metrics only: float2 per branch
   ptk::DevTreeND dev_nd{};
   uint64_t device_bytes = 0;
   bool gpu_layout = false;
@@ -1037,6 +1040,62 @@ int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, const uint32_t
     default: { using M = ptk::MetricL2; CALL; } break;                    \
   }
 
+// ---- topological metrics (ptk_kernels_topo.hpp) ------------------------------------------------
+bool topological(const ptk_tree* t) {
+  const int m = t->metric.load();
+  return m == PTK_METRIC_SO2 || m == PTK_METRIC_SE2_SQUARED;
+}
+#define PTK_WITH_TOPO(CALL)                                         \
+  if (t->metric.load() == PTK_METRIC_SO2) {                         \
+    using T = ptk::TopoSO2;                                         \
+    CALL;                                                           \
+  } else {                                                          \
+    using T = ptk::TopoSE2;                                         \
+    CALL;                                                           \
+  }
+
+template <int OVF>
+int launch_knn_topo(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
+                    ptk::Neighbor* d_out, hipStream_t s, bool short_tree) {
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+  const size_t smem = (size_t)16 * 64 * 8;
+  Timer timer(t, s);
+#define PTK_LAUNCH_TOPO_REG(KK)                                                                                         \
+  PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::knn_topo_reg_kernel<KK, 16, OVF, T>), dim3(blocks), dim3(64), smem, s, t->dev, \
+                                     d_q, t->dim, perm, nq, k, inv_ratio(e), d_out); })
+  if (k <= 32 && !short_tree) {
+    if (k <= 4) { PTK_LAUNCH_TOPO_REG(4); }
+    else if (k <= 8) { PTK_LAUNCH_TOPO_REG(8); }
+    else if (k <= 16) { PTK_LAUNCH_TOPO_REG(16); }
+    else { PTK_LAUNCH_TOPO_REG(32); }
+  } else {
+    PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::knn_topo_kernel<16, OVF, T>), dim3(blocks), dim3(64), smem, s, t->dev, d_q,
+                                       t->dim, perm, nq, k, inv_ratio(e), d_out); });
+  }
+#undef PTK_LAUNCH_TOPO_REG
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
+template <int OVF>
+int launch_radius_topo(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
+                       bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out, hipStream_t s) {
+  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
+  const size_t smem = (size_t)16 * 64 * 8;
+  Timer timer(t, s);
+  if (fill) {
+    PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::radius_topo_kernel<16, OVF, true, T>), dim3(blocks), dim3(64), smem, s, t->dev,
+                                       d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out); });
+  } else {
+    PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::radius_topo_kernel<16, OVF, false, T>), dim3(blocks), dim3(64), smem, s, t->dev,
+                                       d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out); });
+  }
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, fill ? 0 : nq);
+  return PTK_OK;
+}
+
 // k = 1.  PTK_KNN1_VARIANT selects an A/B form (tools/ab_knn1.py): 0 = the shipped two-phase
 // search, 22 = the same behind the plain phase 1 (no wave-uniform prefix, separate packing pass),
 // 4 = the single-kernel search every query of which runs to completion in its lane.  The forms
@@ -1113,12 +1172,16 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
     using space_t = space_map<point_map<float const, dynamic_extent>>;
     space_t space(points, n_points, dim);
     internal::space_view<space_t> view(space);
+    // (the two outer bounds per branch come for free while the child boxes are at hand; only the
+    // topological metrics ever read them)
     auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
-                                               sliding_midpoint_max_side, false, build_threads());
+                                               sliding_midpoint_max_side, true, build_threads());
     t->dim = dim;
     t->n_points = n_points;
     t->nodes.resize(flat.nodes.size());
     std::memcpy(t->nodes.data(), flat.nodes.data(), flat.nodes.size() * sizeof(ptk_node));
+    t->outer.resize(flat.outer_bounds.size() * 2);
+    if (!flat.outer_bounds.empty()) std::memcpy(t->outer.data(), flat.outer_bounds.data(), t->outer.size() * sizeof(float));
     t->indices = std::move(flat.indices);
     t->root_min.assign(flat.root_box.min(), flat.root_box.min() + dim);
     t->root_max.assign(flat.root_box.max(), flat.root_box.max() + dim);
@@ -1171,6 +1234,7 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->d_ranges) (void)hipFree(t->d_ranges);
     if (t->d_axes) (void)hipFree(t->d_axes);
     if (t->d_index) (void)hipFree(t->d_index);
+    if (t->d_outer) (void)hipFree(t->d_outer);
   }
   delete t;
 }
@@ -1255,9 +1319,52 @@ int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t
   return finish_create(t, points, device, out);
 }
 
+int ptk_tree_set_outer_bounds(ptk_tree* t, const float* outer, uint64_t n_nodes) {
+  if (t == nullptr || outer == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (n_nodes != t->nodes.size()) return fail(PTK_ERR_INVALID, "outer bounds for %llu nodes, the tree has %zu",
+                                              (unsigned long long)n_nodes, t->nodes.size());
+  try {
+    t->outer.assign(outer, outer + 2 * n_nodes);
+  } catch (const std::bad_alloc&) {
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  }
+  return PTK_OK;
+}
+
+int ptk_tree_get_outer_bounds(const ptk_tree* t, float* outer) {
+  if (t == nullptr || outer == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (t->outer.size() != 2 * t->nodes.size()) return fail(PTK_ERR_INVALID, "this tree has no outer bounds");
+  std::memcpy(outer, t->outer.data(), t->outer.size() * sizeof(float));
+  return PTK_OK;
+}
+
 int ptk_tree_set_metric(ptk_tree* t, int metric) {
-  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LNINF)
+  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_SE2_SQUARED)
     return fail(PTK_ERR_INVALID, "bad metric");
+  if (metric == PTK_METRIC_SO2 || metric == PTK_METRIC_SE2_SQUARED) {
+    if (metric == PTK_METRIC_SO2 && t->dim != 1) return fail(PTK_ERR_INVALID, "metric_so2 is a metric of 1-dimensional points");
+    if (metric == PTK_METRIC_SE2_SQUARED && t->dim != 3)
+      return fail(PTK_ERR_INVALID, "metric_se2_squared is a metric of 3-dimensional points (x, y, angle)");
+    if (t->outer.size() != 2 * t->nodes.size())
+      return fail(PTK_ERR_INVALID, "the topological metrics need the outer bounds of every branch (ptk_tree_set_outer_bounds)");
+    if (t->device >= 0 && t->gpu_layout && t->d_outer == nullptr) {  // branch order of the device records
+      ptk::TreeStats st;
+      std::vector<uint32_t> branch_id;
+      std::string err = ptk::analyse_stream(t->dim, t->n_points, t->nodes.data(), t->nodes.size(), st, &branch_id);
+      if (!err.empty()) return fail(PTK_ERR_INVALID, "%s", err.c_str());
+      std::vector<float> dev_outer(2 * std::max<size_t>(t->nodes.size() - st.n_leaves, 1), 0.0f);
+      for (size_t i = 0; i < t->nodes.size(); ++i) {
+        if (t->nodes[i].right == PTK_LEAF) continue;
+        dev_outer[2 * (size_t)branch_id[i]] = t->outer[2 * i];
+        dev_outer[2 * (size_t)branch_id[i] + 1] = t->outer[2 * i + 1];
+      }
+      DeviceGuard guard(t->device);
+      PTK_HIP(hipMalloc(&t->d_outer, dev_outer.size() * sizeof(float)));
+      PTK_HIP(hipMemcpy(t->d_outer, dev_outer.data(), dev_outer.size() * sizeof(float), hipMemcpyHostToDevice));
+      t->dev.outer = static_cast<const float2*>(t->d_outer);
+      t->device_bytes += dev_outer.size() * sizeof(float);
+    }
+  }
   t->metric.store(metric);
   return PTK_OK;
 }
@@ -1301,6 +1408,20 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
   const bool l2 = t->metric.load() == PTK_METRIC_L2_SQUARED;
+  if (topological(t)) {
+    if (deep_tree(t)) return fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth);
+    const bool reorder = want_reorder(t, nq);
+    Scratch scratch(t, s, /*per_stream=*/true);
+    rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
+    if (rc != PTK_OK) return rc;
+    uint32_t* perm = nullptr;
+    if (reorder) {
+      rc = make_permutation(t, d_q, nq, s, scratch, &perm);
+      if (rc != PTK_OK) return rc;
+    }
+    PTK_WITH_OVF(16, (launch_knn_topo<OVF>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree)));
+    return rc;
+  }
   if (deep_tree(t)) {  // a few queries at a time, the record stacks spilling to HBM (any k, any metric)
     const DeepPlan plan = deep_plan(t, nq);
     Scratch scratch(t, s, /*per_stream=*/true);
@@ -1487,6 +1608,18 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
                                                                          s, n_over))));
     }
+  } else if (topological(t)) {  // count pass and fill pass both traverse (no capture)
+    if (deep_tree(t)) return fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth);
+    if (!fill) ws.cap_valid = false;
+    rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
+    if (rc != PTK_OK) return rc;
+    uint32_t* perm = nullptr;
+    if (reorder) {
+      rc = make_permutation(t, d_q, nq, s, scratch, &perm);
+      if (rc != PTK_OK) return rc;
+    }
+    PTK_WITH_OVF(16, (launch_radius_topo<OVF>(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
+                                              reinterpret_cast<ptk::Neighbor*>(d_out), s)));
   } else if (deep_tree(t)) {  // record stacks spilling to HBM, a few queries per launch, no capture
     if (!fill) ws.cap_valid = false;
     const DeepPlan plan = deep_plan(t, nq);
@@ -1747,6 +1880,8 @@ static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_
     }
     root = ptk::BoxState{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
   }
+  if (topological(t))
+    return fail(PTK_ERR_UNSUPPORTED, "the box search of a topological tree runs on the host members (kd_tree::search_box)");
   // Boxes in Morton order of their min corners (launch order only; rows stay in the caller's order).
   const bool deep = deep_tree(t);
   const bool reorder = !deep && want_reorder(t, nb);

@@ -68,6 +68,9 @@ struct DevTree {
   // lane of the launch (set per launch by the backend; null otherwise).
   Record* deep_spill;
   uint32_t deep_cap;
+  // Topological metrics only (ptk_kernels_topo.hpp): {left_min, right_max} per branch, the two
+  // bounds the 16-byte record does not hold; null otherwise.
+  const float2* outer;
 };
 
 constexpr uint32_t kLeafBit = 0x80000000u;

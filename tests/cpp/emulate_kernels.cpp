@@ -27,6 +27,7 @@ thread_local dim3 blockDim;
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_nd.hpp"
+#include "ptk_kernels_topo.hpp"
 #include "ptk_kernels_f64.hpp"
 #include "pico_tree/internal/flat_tree.hpp"
 #include "pico_tree/internal/stream.hpp"
@@ -97,10 +98,11 @@ struct Emu {
   ptk::EncodedTree enc;
   ptk::EncodedTreeND enc_nd;  // dim > 3
   ptk::TreeStats st;
-  ptk::DevTree dev;
-  ptk::DevTreeND dev_nd;
+  ptk::DevTree dev{};
+  ptk::DevTreeND dev_nd{};
   uint32_t dim;
   int metric = 0;
+  std::vector<float2> outer;  // per branch {left_min, right_max}: topological metrics (emu_set_outer)
   // rows captured by emu_radius_capture (ptk::RadiusCapture)
   std::vector<ptk::Neighbor> cap_chunks;
   std::vector<uint32_t> cap_counters;
@@ -220,6 +222,27 @@ void emu_radius_metric(Emu* t, const float* q, uint64_t nq, float radius, float 
     for_each_lane(nq, [&] { ptk::radius_kernel<16, 2048, 64, 4, true, M>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o); }, 64);
 }
 
+template <class T>
+int emu_knn_topo(Emu* t, const float* q, uint64_t nq, uint32_t k, float e_inv, const uint32_t* perm, int small_stack,
+                 ptk::Neighbor* o) {
+  if (k <= 32) {
+    if (small_stack) for_each_lane(nq, [&] { ptk::knn_topo_reg_kernel<32, 4, 2048, T>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+    else if (k <= 8) for_each_lane(nq, [&] { ptk::knn_topo_reg_kernel<8, 16, 2048, T>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+    else for_each_lane(nq, [&] { ptk::knn_topo_reg_kernel<32, 16, 2048, T>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+  } else {
+    for_each_lane(nq, [&] { ptk::knn_topo_kernel<16, 2048, T>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
+  }
+  return 0;
+}
+template <class T>
+void emu_radius_topo(Emu* t, const float* q, uint64_t nq, float radius, float e_inv, const uint32_t* perm,
+                     uint64_t* counts, const uint64_t* offsets, ptk::Neighbor* o) {
+  if (o == nullptr)
+    for_each_lane(nq, [&] { ptk::radius_topo_kernel<4, 2048, false, T>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, nullptr, nullptr); }, 64);
+  else
+    for_each_lane(nq, [&] { ptk::radius_topo_kernel<16, 2048, true, T>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o); }, 64);
+}
+
 extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
@@ -262,8 +285,24 @@ void* emu_create(const float* points, uint64_t n, uint32_t dim, const ptk_node* 
 
 void emu_destroy(void* h) { delete static_cast<Emu*>(h); }
 
-// 0 L2 squared (default), 1 L1, 2 LPInf, 3 LNInf: the metric of the searches that follow (ptk_tree_set_metric).
+// 0 L2 squared (default), 1 L1, 2 LPInf, 3 LNInf, 4 SO2, 5 SE2 squared: the metric of the searches that
+// follow (ptk_tree_set_metric).  The topological ones need emu_set_outer first.
 void emu_set_metric(void* h, int metric) { static_cast<Emu*>(h)->metric = metric; }
+
+// The outer bounds of the host tree (2 floats per node, ptk_tree_get_outer_bounds) in branch order.
+int emu_set_outer(void* h, const ptk_node* nodes, uint64_t n_nodes, uint64_t n_points, const float* outer) {
+  auto* e = static_cast<Emu*>(h);
+  ptk::TreeStats st;
+  std::vector<uint32_t> branch_id;
+  g_err = ptk::analyse_stream(e->dim, n_points, nodes, n_nodes, st, &branch_id);
+  if (!g_err.empty()) return -1;
+  e->outer.assign(std::max<size_t>(n_nodes - st.n_leaves, 1), float2{0.0f, 0.0f});
+  for (uint64_t i = 0; i < n_nodes; ++i)
+    if (nodes[i].right != PTK_LEAF) e->outer[branch_id[i]] = float2{outer[2 * i], outer[2 * i + 1]};
+  e->dev.outer = e->outer.data();
+  return 0;
+}
+
 
 uint32_t emu_max_depth(void* h) { return static_cast<Emu*>(h)->st.max_depth; }
 
@@ -279,6 +318,8 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
   if (t->metric == 1) return emu_knn_metric<ptk::MetricL1>(t, q, nq, k, e_inv, perm, small_stack, o);
   if (t->metric == 2) return emu_knn_metric<ptk::MetricLInf>(t, q, nq, k, e_inv, perm, small_stack, o);
   if (t->metric == 3) return emu_knn_metric<ptk::MetricLNInf>(t, q, nq, k, e_inv, perm, small_stack, o);
+  if (t->metric == 4) return emu_knn_topo<ptk::TopoSO2>(t, q, nq, k, e_inv, perm, small_stack, o);
+  if (t->metric == 5) return emu_knn_topo<ptk::TopoSE2>(t, q, nq, k, e_inv, perm, small_stack, o);
   if (t->dim > 3) {  // any-dimension kernels
     if (list_in_lds == 2) {  // k-list in registers (k <= 32)
       if (k > 32) return -2;
@@ -334,7 +375,9 @@ int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e
   auto* t = static_cast<Emu*>(h);
   const float e_inv = 1.0f / e;
   if (t->metric != 0) {
-    if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
+    if (t->metric == 4) emu_radius_topo<ptk::TopoSO2>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
+    else if (t->metric == 5) emu_radius_topo<ptk::TopoSE2>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
+    else if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
     else if (t->metric == 3) emu_radius_metric<ptk::MetricLNInf>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
     else emu_radius_metric<ptk::MetricLInf>(t, q, nq, radius, e_inv, perm, counts, nullptr, nullptr);
     return 0;
@@ -357,7 +400,9 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
   const float e_inv = 1.0f / e;
   if (t->metric != 0) {
-    if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
+    if (t->metric == 4) emu_radius_topo<ptk::TopoSO2>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
+    else if (t->metric == 5) emu_radius_topo<ptk::TopoSE2>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
+    else if (t->metric == 1) emu_radius_metric<ptk::MetricL1>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
     else if (t->metric == 3) emu_radius_metric<ptk::MetricLNInf>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
     else emu_radius_metric<ptk::MetricLInf>(t, q, nq, radius, e_inv, perm, nullptr, offsets, o);
     if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });

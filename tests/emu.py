@@ -39,7 +39,9 @@ class EmulatedTree:
         self.lib = _lib()
         self.pts = np.ascontiguousarray(pts, dtype=np.float32)
         self.leaf = int(leaf)
-        self.host = pt.KdTree(self.pts, metric, leaf, device=pt.PTK_DEVICE_NONE)
+        # (a host-only handle: the topological metrics are set on the emulator, the tree is the same)
+        self.host = pt.KdTree(self.pts, pt.Metric.L2Squared if metric.name in ("SO2", "SE2Squared") else metric, leaf,
+                              device=pt.PTK_DEVICE_NONE)
         nodes, idx, self.rmin, self.rmax = self.host.flat()
         self.h = self.lib.emu_create(self.pts.ctypes.data, len(self.pts), self.pts.shape[1],
                                      nodes.ctypes.data, len(nodes), idx.ctypes.data)
@@ -47,7 +49,13 @@ class EmulatedTree:
             raise RuntimeError(self.lib.emu_last_error().decode())
         self.lib.emu_set_metric.argtypes = [c_void_p, ctypes.c_int]
         self.lib.emu_set_metric.restype = None
-        self.lib.emu_set_metric(self.h, {"L2Squared": 0, "L1": 1, "LPInf": 2, "LNInf": 3}[metric.name])
+        mid = {"L2Squared": 0, "L1": 1, "LPInf": 2, "LNInf": 3, "SO2": 4, "SE2Squared": 5}[metric.name]
+        if mid >= 4:  # the two outer bounds per branch, as the host builder left them
+            outer = np.empty((len(nodes), 2), dtype=np.float32)
+            assert pt._load().ptk_tree_get_outer_bounds(self.host._h, outer.ctypes.data) == 0
+            self.lib.emu_set_outer.argtypes = [c_void_p, c_void_p, c_uint64, c_uint64, c_void_p]
+            assert self.lib.emu_set_outer(self.h, nodes.ctypes.data, len(nodes), len(self.pts), outer.ctypes.data) == 0
+        self.lib.emu_set_metric(self.h, mid)
 
     def __del__(self):
         if getattr(self, "h", None):

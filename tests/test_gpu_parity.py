@@ -611,3 +611,38 @@ def test_multi_device_handle_on_the_devices_present(gpu, monkeypatch):
             rows = multi.search_knn(dq, k).numpy()
             torch.cuda.synchronize()
             assert rows.tobytes() == want.tobytes(), (self_gather, k)
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
+@pytest.mark.parametrize("metric", ["SO2", "SE2Squared"])
+def test_topological_metrics_on_the_device(gpu, metric):
+    """metric_so2 / metric_se2_squared (metric.hpp:186-257) searched on the device as
+    search_nearest_topological does (kd_tree_search.hpp:115-229; four bounds per branch), against
+    kd_tree<space, metric_so2 | metric_se2_squared> of the reference's own headers, wrap-around
+    cases included (queries next to the seam 0 ~ 1)."""
+    if metric == "SO2":
+        pts, q, leaf = ds.uniform_cloud(200_000, 1, 51), ds.uniform_cloud(30_000, 1, 52), 10
+        q[:200] = np.float32(0.00001) * np.arange(200, dtype=np.float32)[:, None]
+        q[200:400] = np.float32(1.0) - np.float32(0.00001) * np.arange(200, dtype=np.float32)[:, None]
+        radius = 0.0001
+    else:
+        pts, q, leaf = ds.uniform_cloud(200_000, 3, 53), ds.uniform_cloud(30_000, 3, 54), 10
+        q[:500, 2] = np.float32(0.0005)
+        q[500:1000, 2] = np.float32(0.9995)
+        radius = 0.0004
+    tree = pt.KdTree(pts, pt.Metric[metric], leaf, device=gpu)
+    ref = oracle.Oracle(pts, leaf, "reference", metric)
+    assert tree.search_knn(q, 1).tobytes() == ref.search_knn(q, 1)[:, 0].tobytes()
+    for k in (7, 16, 40):
+        assert tree.search_knn(q, k).tobytes() == ref.search_knn(q, k).tobytes()
+    assert tree.search_knn(q, 6, 1.3).tobytes() == ref.search_knn(q, 6, e=1.3).tobytes()
+    got = tree.search_radius(q, radius)
+    off, flat = ref.search_radius(q, radius)
+    assert off[-1] > 0 and np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+    got = tree.search_radius(q, radius, 1.5, sort=True)
+    off, flat = ref.search_radius(q, radius, e=1.5, sort=True)
+    assert np.array_equal(got.offsets, off) and np.array_equal(got.flat["distance"], flat["distance"])
+    knn = ref.search_knn(q, 4)
+    assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # neighbours through the seam
+    with pytest.raises(pt.PtkError):  # dimension check
+        pt.KdTree(ds.uniform_cloud(100, 2, 1), pt.Metric[metric], 10, device=gpu)

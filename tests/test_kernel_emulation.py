@@ -293,3 +293,35 @@ def test_emulated_radius_capture_any_dimension(sub_cap):
         long_rows = int((np.diff(want_off.astype(np.int64)) > 31).sum())
         assert redone == (0 if sub_cap == 1024 else long_rows if sub_cap == 0 else redone) and redone <= long_rows
     assert want_off[-1] > 31 * len(q)
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
+@pytest.mark.parametrize("metric", ["SO2", "SE2Squared"])
+def test_emulated_topological_kernels_equal_the_compiled_reference(metric):
+    """metric_so2 (points on the circle, 1-D) and metric_se2_squared (x, y, angle; 3-D) through
+    traverse_topo of ptk_kernels_topo.hpp, against kd_tree<space, metric_so2 | metric_se2_squared>
+    of the reference's own headers (oracle/_ref): wrap-around neighbours included."""
+    import pico_tree_amd as pt
+    if metric == "SO2":
+        pts, q, leaf = ds.uniform_cloud(6_000, 1, 51), ds.uniform_cloud(1_500, 1, 52), 6
+        q[:20] = np.float32(0.0005) * np.arange(20, dtype=np.float32)[:, None]          # next to the seam 0 ~ 1
+        q[20:40] = np.float32(1.0) - np.float32(0.0005) * np.arange(20, dtype=np.float32)[:, None]
+        radius = 0.002
+    else:
+        pts, q, leaf = ds.uniform_cloud(20_000, 3, 53), ds.uniform_cloud(1_500, 3, 54), 10
+        q[:40, 2] = np.float32(0.001)
+        q[40:80, 2] = np.float32(0.999)
+        radius = 0.002
+    emu = EmulatedTree(pts, leaf, pt.Metric[metric])
+    ref = oracle.Oracle(pts, leaf, "reference", metric)
+    perm = emu.morton_permutation(q)[0]
+    for k, small in ((1, False), (1, True), (7, False), (7, True), (40, False)):
+        want = ref.search_knn(q, k)
+        for p in (None, perm):
+            assert emu.search_knn(q, k, perm=p, small_stack=small).tobytes() == want.tobytes(), (k, small)
+    assert emu.search_knn(q, 5, e=1.4).tobytes() == ref.search_knn(q, 5, e=1.4).tobytes()
+    for kw in ({}, {"e": 1.5}):
+        a, b = emu.search_radius(q, radius, **kw), ref.search_radius(q, radius, **kw)
+        assert b[0][-1] > 0 and np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()
+    knn = ref.search_knn(q, 4)
+    assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # some neighbours are nearer through 0 ~ 1
