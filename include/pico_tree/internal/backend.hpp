@@ -39,13 +39,20 @@ inline constexpr int ptk_metric_v = std::is_same_v<Metric_, metric_l2_squared> ?
                                     : std::is_same_v<Metric_, metric_l1>       ? PTK_METRIC_L1
                                     : std::is_same_v<Metric_, metric_lpinf>    ? PTK_METRIC_LPINF
                                     : std::is_same_v<Metric_, metric_lninf>    ? PTK_METRIC_LNINF
+                                    : std::is_same_v<Metric_, metric_so2>      ? PTK_METRIC_SO2
+                                    : std::is_same_v<Metric_, metric_se2_squared> ? PTK_METRIC_SE2_SQUARED
                                                                                : -1;
+//! The topological metrics: float points only, knn and radius searches (the tree carries four bounds per branch).
+template <typename Metric_>
+inline constexpr bool ptk_topological_v =
+    std::is_same_v<Metric_, metric_so2> || std::is_same_v<Metric_, metric_se2_squared>;
 
 //! Which kd_tree instantiations run on the GPU: float points through ptk_* and double points
 //! through ptk_tree64_* / ptk_search64_* (include/ptk.h).
 template <typename Metric_, typename Scalar_, typename Index_>
 inline constexpr bool is_accelerated_v =
-    ptk_metric_v<Metric_> >= 0 && (std::is_same_v<Scalar_, float> || std::is_same_v<Scalar_, double>) &&
+    ptk_metric_v<Metric_> >= 0 &&
+    (std::is_same_v<Scalar_, float> || (std::is_same_v<Scalar_, double> && !ptk_topological_v<Metric_>)) &&
     std::is_same_v<Index_, int> && sizeof(int) == 4;
 
 //! The C entry points of one scalar type under one set of names.
@@ -163,6 +170,14 @@ class device_tree {
         desc.max_depth = tree.max_depth;
         desc.device = PTK_DEVICE_CURRENT;
         ptk_check(ptk_tree_create(&desc, &h), "ptk_tree_create");
+        if (metric == PTK_METRIC_SO2 || metric == PTK_METRIC_SE2_SQUARED) {  // the other two bounds of every branch
+          static_assert(sizeof(tree.outer_bounds[0]) == 2 * sizeof(float), "outer bounds layout");
+          int const rc = tree.outer_bounds.size() == tree.nodes.size()
+                             ? ptk_tree_set_outer_bounds(h, tree.outer_bounds[0].data(), tree.nodes.size())
+                             : PTK_ERR_INVALID;
+          if (rc != PTK_OK) ptk_tree_destroy(h);
+          ptk_check(rc, "ptk_tree_set_outer_bounds");
+        }
       } else {
         // The already built tree crosses the boundary in the reference's own stream format.
         std::ostringstream os(std::ios::out | std::ios::binary);

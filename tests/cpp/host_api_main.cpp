@@ -321,6 +321,20 @@ static int run_batch(std::string const& dir) {
     write_raw(dir + "/b_l1_radius_off.bin", off.data(), off.size());
     write_raw(dir + "/b_l1_radius_flat.bin", flat.data(), flat.size());
   }
+  {  // metric_lninf and the topological metric_se2_squared (x, y, angle), batched on the device too
+    auto lninf = pico_tree::make_kd_tree<pico_tree::metric_lninf>(std::cref(qs), pico_tree::max_leaf_size_t(10));
+    auto se2 = pico_tree::make_kd_tree<pico_tree::metric_se2_squared>(std::cref(qs), pico_tree::max_leaf_size_t(10));
+    std::vector<neighbor> a(nq * k), b(nq * k);
+    lninf.search_knn(qmap, k, a.data());
+    se2.search_knn(qmap, k, b.data());
+    write_raw(dir + "/b_lninf_knn.bin", a.data(), a.size());
+    write_raw(dir + "/b_se2_knn.bin", b.data(), b.size());
+    std::vector<std::uint64_t> off;
+    std::vector<neighbor> flat;
+    se2.search_radius(qs, 0.0009f, off, flat, false);
+    write_raw(dir + "/b_se2_radius_off.bin", off.data(), off.size());
+    write_raw(dir + "/b_se2_radius_flat.bin", flat.data(), flat.size());
+  }
   {  // double precision: kd_tree over double points takes the ptk_tree64_* / ptk_search64_* entry points
     using neighbor64 = pico_tree::neighbor<int, double>;
     std::vector<std::array<double, 3>> dp(tree.space().size()), dq(nq);

@@ -151,6 +151,14 @@ def test_batched_members_match_oracle(workdir, gpu):
     off, flat = l1.search_radius(q, 0.03)
     assert np.array_equal(_load(d, "b_l1_radius_off.bin", np.uint64), off)
     assert _load(d, "b_l1_radius_flat.bin", pt.NEIGHBOR).tobytes() == flat.tobytes()
+    lninf = oracle.Oracle(q, 10, "port", "LNInf")
+    assert _load(d, "b_lninf_knn.bin", pt.NEIGHBOR).tobytes() == lninf.search_knn(q, K).tobytes()
+    if oracle.have_reference():  # the topological metric against the reference's own kd_tree<space, metric_se2_squared>
+        se2 = oracle.Oracle(q, 10, "reference", "SE2Squared")
+        assert _load(d, "b_se2_knn.bin", pt.NEIGHBOR).tobytes() == se2.search_knn(q, K).tobytes()
+        off, flat = se2.search_radius(q, RADIUS)
+        assert np.array_equal(_load(d, "b_se2_radius_off.bin", np.uint64), off)
+        assert _load(d, "b_se2_radius_flat.bin", pt.NEIGHBOR).tobytes() == flat.tobytes()
     # double precision members (ptk_tree64_* / ptk_search64_*): the driver scales the clouds by 1.0000001 in double
     pd, qd = pts.astype(np.float64) * 1.0000001, q.astype(np.float64) * 1.0000001
     r64 = oracle.Oracle(pd, 10, "port", dtype=np.float64)
