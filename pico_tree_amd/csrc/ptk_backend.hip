@@ -846,7 +846,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     Timer timer(t, s);
     if (UNIFORM1) {
       hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
-                         e_inv, d_out, cont, d_q, t->dim, perm, qs);
+                         e_inv, d_out, cont, d_q, t->dim, perm, qs, (uint32_t)env_int("PTK_MERGE_LIGHT", 0));
     } else {
       hipLaunchKernelGGL((ptk::knn1_phase1_kernel<32, OVF, LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs,
                          nq, e_inv, d_out, cont);

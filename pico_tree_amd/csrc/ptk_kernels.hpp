@@ -949,8 +949,12 @@ constexpr uint32_t kHeavyClass = 4;     // classes >= this are dealt across wave
 //   class 0 (final after phase 1): 7 << 13, sorts behind everything.
 typedef uint16_t ContKey;
 constexpr uint32_t kRankedClass = 5;
-__device__ __forceinline__ ContKey make_cont_key(uint32_t cls, float best_d) {
+// merge_light: classes 1 .. 3 share one key, so the light tier of phase 2 is ONE sweep of the
+// batch in Morton order instead of three (one per class): every region of the tree then passes
+// through the XCDs' L2 once (profiles/r02_notes.txt, item 8).
+__device__ __forceinline__ ContKey make_cont_key(uint32_t cls, float best_d, bool merge_light = false) {
   if (cls >= kRankedClass) return (ContKey)(0x1FFFu - ((__float_as_uint(best_d) >> 18) & 0x1FFFu));
+  if (merge_light && cls >= 1u && cls < kHeavyClass) return (ContKey)(4u << 13);
   return (ContKey)((7u - cls) << 13);
 }
 __device__ __forceinline__ bool cont_key_is_final(ContKey k) { return (k >> 13) == 7u; }
@@ -1118,7 +1122,7 @@ template <int LEAFB, bool PACK = false>
 __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
     Cont cont, const float* __restrict__ queries = nullptr, uint32_t dim = 3,
-    const uint32_t* __restrict__ perm = nullptr, float4* __restrict__ qs_out = nullptr) {
+    const uint32_t* __restrict__ perm = nullptr, float4* __restrict__ qs_out = nullptr, uint32_t merge_light = 0) {
   const uint64_t i0 = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
@@ -1241,7 +1245,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   if (!valid) return;
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
   const uint32_t e = (uint32_t)i;
-  cont.key[e] = make_cont_key(cls, pol.best_d);
+  cont.key[e] = make_cont_key(cls, pol.best_d, merge_light != 0u);
   cont.ids[e] = e;
   if (cls == 0) {
     pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
