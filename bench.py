@@ -43,8 +43,9 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
-#: The k = 1 traversal is two kernels; the algorithmic bytes cover both.
-TRAVERSAL_KERNELS = ("ptk::knn1_phase1", "ptk::knn1_phase2")
+#: The k = 1 traversal is phase 1, the capped phase 2 and the cooperative search of what the cap left
+#: (+ the usually empty redo pass); the algorithmic bytes cover all of them.
+TRAVERSAL_KERNELS = ("ptk::knn1_phase1", "ptk::knn1_phase2", "ptk::knn1_coop", "ptk::knn1_redo")
 
 
 def log(*a):
