@@ -880,11 +880,48 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // PTK_COOP_OVERLAP=1 (A/B only): measured slower than the plain sequence on BASELINE config 2 (2.34 vs 2.16 ms
   // per step, profiles/r02_notes.txt: the two kernels compete for the same issue slots).
   const bool overlap = cap != 0 && env_int("PTK_COOP_OVERLAP", 0) != 0 && scratch.side_stream(&side, &ev_fork, &ev_join);
+  // PTK_P2_SPLIT=1: the heavy tiers (deep stacks: 16-slot ring) on the side stream BESIDE the light tier (1-3
+  // pending far children: 8 slots, twice the waves per CU) on the caller's stream; then the cooperative search.
+  const bool split = cap != 0 && !overlap && env_int("PTK_P2_SPLIT", 0) != 0 &&
+                     scratch.side_stream(&side, &ev_fork, &ev_join);
+  if (split) {
+    Timer timer(t, s);
+    PTK_HIP(hipEventRecord(ev_fork, s));
+    PTK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, side, t->dev, qs, e_inv,
+                       d_out, cont, ids_out, cap, ho, 1u);
+    PTK_HIP(hipEventRecord(ev_join, side));
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<8, OVF, LEAFB>), p2_grid, dim3(64), (size_t)8 * 64 * 8, s, t->dev, qs,
+                       e_inv, d_out, cont, ids_out, cap, ho, 2u);
+    PTK_HIP(hipGetLastError());
+    PTK_HIP(hipStreamWaitEvent(s, ev_join, 0));
+    rc = coop(s, 0);
+    if (rc != PTK_OK) return rc;
+    hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), p2_lds, s, t->dev, qs, e_inv,
+                       d_out, cont, redo_list);
+    PTK_HIP(hipGetLastError());
+    timer.stop(3, 0);
+    return PTK_OK;
+  }
   if (!overlap) {
     {
       Timer timer(t, s);
-      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
-                         d_out, cont, ids_out, cap, ho, 0u);
+      // LDS ring of phase 2: 16 / 12 / 8 slots = 8 / 6 / 4 KB per wave = 20 / 26 / 40 waves per CU (PTK_P2_RING, A/B).
+      // With the cap no stack grows deep any more: 12 slots beat 16 on both clouds (cloud L 1.67 vs 1.74 ms of
+      // traversal kernels, cloud U 1.32 vs 1.47; 8 slots: 1.79 / 1.38 -- profiles/r02_notes.txt item 10).
+      switch (env_int("PTK_P2_RING", 12)) {
+        case 8:
+          hipLaunchKernelGGL((ptk::knn1_phase2_kernel<8, OVF, LEAFB>), p2_grid, dim3(64), (size_t)8 * 64 * 8, s, t->dev, qs,
+                             e_inv, d_out, cont, ids_out, cap, ho, 0u);
+          break;
+        case 12:
+          hipLaunchKernelGGL((ptk::knn1_phase2_kernel<12, OVF, LEAFB>), p2_grid, dim3(64), (size_t)12 * 64 * 8, s, t->dev, qs,
+                             e_inv, d_out, cont, ids_out, cap, ho, 0u);
+          break;
+        default:
+          hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
+                             d_out, cont, ids_out, cap, ho, 0u);
+      }
       timer.stop(3, 0);
     }
     PTK_HIP(hipGetLastError());
