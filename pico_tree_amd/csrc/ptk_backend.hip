@@ -767,10 +767,21 @@ size_t class_sort_tmp_bytes(uint64_t nq) {
 // each); further ones are searched again from the root.
 uint64_t max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 32, std::min<uint64_t>(nq, 16384)); }
 
+// The class order as a counting sort: chunks of kClassPer slots, one wavefront each.
+constexpr uint32_t kClassPer = 1792;  // 7 rounds of 4 x 64 keys
+uint32_t class_chunks(uint64_t nq) { return (uint32_t)((nq + kClassPer - 1) / kClassPer); }
+size_t class_scan_tmp_bytes(uint64_t nq) {
+  size_t tmp_bytes = 0;
+  uint32_t* p = nullptr;
+  (void)rocprim::exclusive_scan(nullptr, tmp_bytes, p, p, 0u, (size_t)ptk::kClassBuckets * class_chunks(nq),
+                                rocprim::plus<uint32_t>(), (hipStream_t) nullptr);
+  return tmp_bytes + 256;
+}
+
 size_t two_phase_scratch_bytes(uint64_t nq) {
   return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 4 * nq +
          2 * (nq * 4) + 3 * (nq * 4) + max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + 64 +
-         class_sort_tmp_bytes(nq);
+         class_sort_tmp_bytes(nq) + 2 * (size_t)ptk::kClassBuckets * class_chunks(nq) * 4 + class_scan_tmp_bytes(nq) + 1024;
 }
 
 // Far children a query may enter in phase 2 before it is handed to the cooperative search
@@ -858,11 +869,31 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     // With the cap the order inside the heavy classes no longer matters (no query runs long):
     // one radix pass over the three class bits, stable, so every class keeps its Morton order.
     const int key_bits = env_int("PTK_CONT_BITS", cap ? 3 : 16);
-    PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq,
-                                      key_bits >= 16 ? 0 : 16 - key_bits, 16, s));
-    hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont,
-                       (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass), tiers, extra_waves,
-                       (uint32_t)env_int("PTK_DEAL", 1));
+    const uint32_t heavy_class = (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass);
+    const uint32_t deal = (uint32_t)env_int("PTK_DEAL", 1);
+    if (key_bits == 3 && env_int("PTK_CLASS_SORT", 1) != 0) {
+      // 8 buckets: count per chunk, scan the 8 x chunks counters, stable scatter; the tier table from the
+      // scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
+      const uint32_t chunks = class_chunks(nq);
+      const size_t n_counters = (size_t)ptk::kClassBuckets * chunks;
+      uint32_t* counters = scratch.take<uint32_t>(n_counters);
+      uint32_t* offsets = scratch.take<uint32_t>(n_counters);
+      size_t scan_bytes = class_scan_tmp_bytes(nq);
+      void* scan_tmp = scratch.take<char>(scan_bytes);
+      if (!counters || !offsets || !scan_tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
+      hipLaunchKernelGGL(ptk::class_count_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer, counters);
+      PTK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, counters, offsets, 0u, n_counters, rocprim::plus<uint32_t>(), s));
+      hipLaunchKernelGGL(ptk::class_meta_kernel, dim3(1), dim3(1), 0, s, offsets, chunks, cont, heavy_class, tiers,
+                         extra_waves, deal);
+      hipLaunchKernelGGL(ptk::class_scatter_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer,
+                         offsets, ids_out);
+      PTK_HIP(hipGetLastError());
+    } else {
+      PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq,
+                                        key_bits >= 16 ? 0 : 16 - key_bits, 16, s));
+      hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont, heavy_class,
+                         tiers, extra_waves, deal);
+    }
     timer.stop(2, 0);
   }
   auto coop = [&](hipStream_t cs, uint32_t range) {  // G lanes per query on the listed queries

@@ -1276,21 +1276,9 @@ struct TierSpec {
   uint32_t lanes[kMaxTiers];
 };
 
-__global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, uint32_t nq, Cont cont,
-                                       uint32_t heavy_class, TierSpec tiers, uint32_t max_narrow_waves,
-                                       uint32_t deal) {
-  auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
-    uint32_t lo = 0, hi = nq;
-    while (lo < hi) {
-      const uint32_t mid = lo + (hi - lo) / 2;
-      if (sorted_key[mid] < k) lo = mid + 1; else hi = mid;
-    }
-    return lo;
-  };
-  const uint32_t n2 = first_at_least(7u << 13);
-  const uint32_t ranked = first_at_least(1u << 13);  // classes >= kRankedClass
-  const uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
-  const uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : first_at_least((7u - hc + 1u) << 13));
+// The tier table of phase 2 from the three boundaries of the class-sorted list.
+__device__ inline void write_phase_meta(const Cont& cont, uint32_t n2, uint32_t ranked, uint32_t heavy,
+                                        const TierSpec& tiers, uint32_t max_narrow_waves, uint32_t deal) {
   uint32_t begin = 0, wave = 0;
   for (uint32_t i = 0; i < kMaxTiers; ++i) {
     uint32_t end = (uint32_t)(((uint64_t)ranked * tiers.permille[i]) / 1000u);
@@ -1318,6 +1306,108 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
   cont.meta[kMetaHeavy] = 0;
   cont.meta[kMetaHeavyA] = 0;
   cont.meta[kMetaRedo] = 0;
+}
+
+// Behind a full 16-bit radix sort of the keys (PTK_CONT_BITS=16): the boundaries by binary search.
+__global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, uint32_t nq, Cont cont,
+                                       uint32_t heavy_class, TierSpec tiers, uint32_t max_narrow_waves,
+                                       uint32_t deal) {
+  auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
+    uint32_t lo = 0, hi = nq;
+    while (lo < hi) {
+      const uint32_t mid = lo + (hi - lo) / 2;
+      if (sorted_key[mid] < k) lo = mid + 1; else hi = mid;
+    }
+    return lo;
+  };
+  const uint32_t n2 = first_at_least(7u << 13);
+  const uint32_t ranked = first_at_least(1u << 13);  // classes >= kRankedClass
+  const uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
+  const uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : first_at_least((7u - hc + 1u) << 13));
+  write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves, deal);
+}
+
+// ---- the class order as a counting sort (the shipped form) -----------------------------------------
+// With the cap only the three class bits of a key matter, i.e. 8 buckets: a stable counting sort in
+// two passes over the 2-byte keys -- count per chunk, scan of the 8 x chunks counters (bucket-major),
+// stable scatter of the slot numbers -- instead of a general radix sort of (key, value) pairs with its
+// histogram, look-back state and their memsets; and the tier table comes from the scanned counters
+// (the first counter of every bucket IS where the bucket starts) instead of binary searches.
+// One wavefront per chunk of `per` consecutive slots; everything wave-synchronous (ballots), no LDS.
+constexpr uint32_t kClassBuckets = 8;
+
+__global__ __launch_bounds__(64) void class_count_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
+                                                         uint32_t* __restrict__ counters) {
+  const uint32_t chunk = blockIdx.x, chunks = gridDim.x;
+  const uint32_t lo = chunk * per;
+  const uint32_t hi = lo + per < nq ? lo + per : nq;
+  uint32_t c[kClassBuckets];
+#pragma unroll
+  for (uint32_t b = 0; b < kClassBuckets; ++b) c[b] = 0;
+  for (uint32_t i = lo; i < hi; i += 256u) {  // four tiles of 64 per round trip
+    uint32_t k[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t j = i + u * 64u + threadIdx.x;
+      k[u] = j < hi ? (uint32_t)(keys[j] >> 13) : kClassBuckets;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+#pragma unroll
+      for (uint32_t b = 0; b < kClassBuckets; ++b) c[b] += (uint32_t)__popcll(__ballot(k[u] == b));
+    }
+  }
+  if (threadIdx.x < kClassBuckets) {
+    uint32_t v = c[0];
+#pragma unroll
+    for (uint32_t b = 1; b < kClassBuckets; ++b) v = threadIdx.x == b ? c[b] : v;
+    counters[threadIdx.x * chunks + chunk] = v;  // bucket-major
+  }
+}
+
+// `offsets` = exclusive scan of `counters` (bucket-major, 8 x chunks entries): offsets[b * chunks + c] is
+// where chunk c's slots of bucket b go.  Slot numbers are the values (phase 1 numbers its slots 0 .. nq - 1).
+__global__ __launch_bounds__(64) void class_scatter_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
+                                                           const uint32_t* __restrict__ offsets,
+                                                           uint32_t* __restrict__ sorted_ids) {
+  const uint32_t chunk = blockIdx.x, chunks = gridDim.x;
+  const uint32_t lo = chunk * per;
+  const uint32_t hi = lo + per < nq ? lo + per : nq;
+  const uint64_t below = (1ull << threadIdx.x) - 1ull;
+  uint32_t base[kClassBuckets];  // next free position of every bucket for this chunk
+#pragma unroll
+  for (uint32_t b = 0; b < kClassBuckets; ++b) base[b] = offsets[b * chunks + chunk];
+  for (uint32_t i = lo; i < hi; i += 256u) {
+    uint32_t k[4];
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {
+      const uint32_t j = i + u * 64u + threadIdx.x;
+      k[u] = j < hi ? (uint32_t)(keys[j] >> 13) : kClassBuckets;
+    }
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) {  // tiles in slot order: the sort is stable
+      uint32_t pos = 0;
+#pragma unroll
+      for (uint32_t b = 0; b < kClassBuckets; ++b) {
+        const uint64_t m = __ballot(k[u] == b);
+        if (k[u] == b) pos = base[b] + (uint32_t)__popcll(m & below);
+        base[b] += (uint32_t)__popcll(m);
+      }
+      const uint32_t j = i + u * 64u + threadIdx.x;
+      if (j < hi) sorted_ids[pos] = j;
+    }
+  }
+}
+
+// The tier table from the scanned counters: bucket b starts at offsets[b * chunks].
+__global__ void class_meta_kernel(const uint32_t* __restrict__ offsets, uint32_t chunks, Cont cont, uint32_t heavy_class,
+                                  TierSpec tiers, uint32_t max_narrow_waves, uint32_t deal) {
+  auto start = [&](uint32_t b) { return offsets[b * chunks]; };  // b = 1 .. 7
+  const uint32_t n2 = start(7);       // everything before class 0
+  const uint32_t ranked = start(1);   // classes >= kRankedClass
+  const uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
+  const uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : start(7u - hc + 1u));
+  write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves, deal);
 }
 
 // Phase 2: one continuation per lane, taken from the class-sorted entry list.

@@ -536,9 +536,6 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
       sorted_key[i] = ckey[order[i]];
     }
   }
-  gridDim.x = 1;
-  blockIdx.x = 0;
-  threadIdx.x = 0;
   const uint32_t top_extra = variant == 4 ? (uint32_t)nq + 2u : (uint32_t)(nq / 64) + 2u;
   ptk::TierSpec tiers{};
   if (variant == 4) {
@@ -548,7 +545,41 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   } else {  // the shipped default
     tiers.permille[0] = 60; tiers.lanes[0] = 4;
   }
-  ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
+  if (variant >= 5) {  // the shipped class order: counting sort over the three class bits + tier table from the counters
+    const uint32_t per = 200, chunks = (uint32_t)((nq + per - 1) / per);
+    std::vector<uint32_t> counters((size_t)ptk::kClassBuckets * chunks, 0xEEEEEEEEu), offsets(counters.size());
+    for_each_wave(chunks, [&] { ptk::class_count_kernel(ckey.data(), (uint32_t)nq, per, counters.data()); });
+    uint32_t run = 0;
+    for (size_t i = 0; i < counters.size(); ++i) {
+      offsets[i] = run;
+      run += counters[i];
+    }
+    if (run != nq) return -6;
+    std::vector<uint32_t> by_count(nq, 0xEEEEEEEEu);
+    for_each_wave(chunks, [&] { ptk::class_scatter_kernel(ckey.data(), (uint32_t)nq, per, offsets.data(), by_count.data()); });
+    for (uint64_t i = 0; i < nq; ++i) {
+      // the same permutation as the stable sort on the class bits (the light classes keep their order)
+      if ((sorted_key[i] >> 13) != (ckey[by_count[i]] >> 13)) return -7;
+    }
+    std::vector<uint32_t> by_class(nq);
+    {
+      std::vector<uint32_t> order(nq);
+      for (uint64_t i = 0; i < nq; ++i) order[i] = (uint32_t)i;
+      std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return (ckey[a] >> 13) < (ckey[b] >> 13); });
+      for (uint64_t i = 0; i < nq; ++i) by_class[i] = cids[order[i]];
+    }
+    if (by_class != by_count) return -8;
+    sorted = by_count;
+    gridDim.x = 1;
+    blockIdx.x = 0;
+    threadIdx.x = 0;
+    ptk::class_meta_kernel(offsets.data(), chunks, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
+  } else {
+    gridDim.x = 1;
+    blockIdx.x = 0;
+    threadIdx.x = 0;
+    ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
+  }
   const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
   const uint32_t cap = (variant == 5 || variant == 9) ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
   std::vector<uint32_t> heavy_list(nq, 0xEEEEEEEEu), redo_list(nq, 0xEEEEEEEEu), ntasks(nq, 0xEEEEEEEEu);
