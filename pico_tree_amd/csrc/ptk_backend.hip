@@ -849,6 +849,10 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
   const uint32_t cap = phase2_cap(e);
+  const int key_bits = env_int("PTK_CONT_BITS", cap ? 3 : 16);
+  const bool counting = key_bits == 3 && env_int("PTK_CLASS_SORT", 1) != 0;
+  uint32_t* const slot_ids = cont.ids;
+  if (counting) cont.ids = nullptr;  // phase 1 need not write slot numbers: the counting sort produces them
   // Narrow tiers at the head of the ranked classes: "permille:lanes,..." (cumulative marks).  The
   // grid has room for nq / 64 extra waves there; the meta kernel cuts the tiers to what fits.
   ptk::TierSpec tiers = parse_tiers(cap ? "" : "60:4");
@@ -868,10 +872,9 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     Timer timer(t, s);
     // With the cap the order inside the heavy classes no longer matters (no query runs long):
     // one radix pass over the three class bits, stable, so every class keeps its Morton order.
-    const int key_bits = env_int("PTK_CONT_BITS", cap ? 3 : 16);
     const uint32_t heavy_class = (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass);
     const uint32_t deal = (uint32_t)env_int("PTK_DEAL", 1);
-    if (key_bits == 3 && env_int("PTK_CLASS_SORT", 1) != 0) {
+    if (counting) {
       // 8 buckets: count per chunk, scan the 8 x chunks counters, stable scatter; the tier table from the
       // scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
       const uint32_t chunks = class_chunks(nq);
@@ -889,7 +892,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
                          offsets, ids_out);
       PTK_HIP(hipGetLastError());
     } else {
-      PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, cont.ids, ids_out, nq,
+      PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, slot_ids, ids_out, nq,
                                         key_bits >= 16 ? 0 : 16 - key_bits, 16, s));
       hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont, heavy_class,
                          tiers, extra_waves, deal);

@@ -1246,7 +1246,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
   const uint32_t e = (uint32_t)i;
   cont.key[e] = make_cont_key(cls, pol.best_d, merge_light != 0u);
-  cont.ids[e] = e;
+  if (cont.ids != nullptr) cont.ids[e] = e;  // (the counting sort numbers the slots itself)
   if (cls == 0) {
     pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
   } else {
