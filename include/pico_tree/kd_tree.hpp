@@ -288,10 +288,10 @@ class kd_tree {
             device(), q.data(), q.rows(), radius, scalar_type(1), sort ? 1 : 0,
             offsets.data(), &rows),
         "ptk_search_radius");
+    library_rows keep(rows);  // freed even if the copy below throws
     flat.resize(offsets.back());
     auto const* src = reinterpret_cast<neighbor_type const*>(rows);
     std::copy(src, src + flat.size(), flat.data());
-    ptk_free(rows);
   }
 
   //! Batched box search: row i (flat[offsets[i] .. offsets[i + 1])) lists the indices inside the
@@ -311,8 +311,8 @@ class kd_tree {
     std::int32_t* rows = nullptr;
     internal::ptk_check(
         api::box(device(), lo.data(), hi.data(), lo.rows(), offsets.data(), &rows), "ptk_search_box");
+    library_rows keep(rows);
     flat.assign(rows, rows + offsets.back());
-    ptk_free(rows);
   }
 
   //! Uploads the tree to the device now instead of at the first batched call.
@@ -363,6 +363,12 @@ class kd_tree {
         metric_(),
         tree_(internal::read_flat_tree<tree_type>(
             stream, topological, space_view_type(unwrap(space_)).sdim(), space_view_type(unwrap(space_)).size())) {}
+
+  //! A result buffer allocated by libptk: released with ptk_free on every path out of the scope.
+  struct ptk_free_fn {
+    void operator()(void* p) const { ptk_free(p); }
+  };
+  using library_rows = std::unique_ptr<void, ptk_free_fn>;
 
   template <typename T_>
   static T_ const& unwrap(T_ const& s) {
@@ -417,12 +423,12 @@ class kd_tree {
         api::radius(
             device(), q.data(), q.rows(), radius, e, sort ? 1 : 0, offsets.data(), &rows),
         "ptk_search_radius");
+    library_rows keep(rows);
     out.resize(q.rows());
     auto const* src = reinterpret_cast<neighbor_type const*>(rows);
     for (size_type i = 0; i < q.rows(); ++i) {
       out[i].assign(src + offsets[i], src + offsets[i + 1]);
     }
-    ptk_free(rows);
   }
 
   space_type space_;

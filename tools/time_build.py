@@ -8,7 +8,7 @@ from pico_tree_amd import datasets as ds
 
 pts, _ = ds.config2_clouds("L", ds.CONFIG2_N, 1000)
 ref = None
-for th in (1, 2, 4, 8, 16, 32, 64):
+for th in (1, 8, 32, 32, 64, 128, 256):
     os.environ["PTK_BUILD_THREADS"] = str(th)
     t0 = time.perf_counter()
     tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=0)
