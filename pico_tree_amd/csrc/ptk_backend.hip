@@ -10,6 +10,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstddef>
@@ -198,6 +199,19 @@ unsigned build_threads() {
   return hc == 0 ? 1u : (hc > 32u ? 32u : hc);
 }
 
+// PTK_CREATE_TIMING=1: the phases of a tree creation on stderr (tools/time_build.py).
+struct CreateClock {
+  bool on;
+  std::chrono::steady_clock::time_point t0;
+  CreateClock() : on(env_int("PTK_CREATE_TIMING", 0) != 0), t0(std::chrono::steady_clock::now()) {}
+  void lap(const char* what) {
+    if (!on) return;
+    const auto t1 = std::chrono::steady_clock::now();
+    std::fprintf(stderr, "[ptk create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    t0 = t1;
+  }
+};
+
 int analyse(ptk_tree& t) {
   ptk::TreeStats st;
   std::string err = ptk::analyse_stream(t.dim, t.n_points, t.nodes.data(), t.nodes.size(), st, nullptr);
@@ -209,8 +223,10 @@ int analyse(ptk_tree& t) {
 }
 
 int upload(ptk_tree& t, const float* points) {
+  CreateClock clock;
   int rc = analyse(t);
   if (rc != PTK_OK) return rc;
+  clock.lap("analyse stream");
   if (t.dim > 3) {  // any-dimension layout (ptk_kernels_nd.hpp)
     ptk::TreeStats st;
     ptk::EncodedTreeND enc;
@@ -252,8 +268,10 @@ int upload(ptk_tree& t, const float* points) {
   std::string err = ptk::encode_tree(t.dim, t.n_points, nullptr, t.nodes.data(), t.nodes.size(),
                                      t.indices.data(), st, enc, unsupported, /*with_points=*/false);
   if (!err.empty()) return fail(unsupported ? PTK_ERR_UNSUPPORTED : PTK_ERR_INVALID, "%s", err.c_str());
+  clock.lap("encode branch records");
   for (int32_t idx : t.indices)
     if (idx < 0 || (uint64_t)idx >= t.n_points) return fail(PTK_ERR_INVALID, "index out of range in the permutation");
+  clock.lap("check permutation");
 
   static_assert(sizeof(ptk::EncNode) == sizeof(uint4) && sizeof(ptk::EncPoint) == sizeof(float4), "records");
   const size_t n_records = t.n_points + ptk::kEncLeafPad;
@@ -278,6 +296,7 @@ int upload(ptk_tree& t, const float* points) {
     if (d_idx) (void)hipFree(d_idx);
     if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error while encoding the points: %s", hipGetErrorString(he));
   }
+  clock.lap("upload + gather points");
   PTK_HIP(hipMalloc(&t.d_ranges, enc.ranges.size() * sizeof(ptk::EncRange)));
   PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), enc.ranges.size() * sizeof(ptk::EncRange), hipMemcpyHostToDevice));
   t.device_bytes = enc.nodes.size() * sizeof(uint4) + n_records * sizeof(float4) +
@@ -1245,8 +1264,10 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
     internal::space_view<space_t> view(space);
     // (the two outer bounds per branch come for free while the child boxes are at hand; only the
     // topological metrics ever read them)
+    CreateClock clock;
     auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
                                                sliding_midpoint_max_side, true, build_threads());
+    clock.lap("host build");
     t->dim = dim;
     t->n_points = n_points;
     t->nodes.resize(flat.nodes.size());
@@ -1256,6 +1277,7 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
     t->indices = std::move(flat.indices);
     t->root_min.assign(flat.root_box.min(), flat.root_box.min() + dim);
     t->root_max.assign(flat.root_box.max(), flat.root_box.max() + dim);
+    clock.lap("copy into the handle");
   } catch (const std::bad_alloc&) {
     delete t;
     return fail(PTK_ERR_NOMEM, "out of memory");
