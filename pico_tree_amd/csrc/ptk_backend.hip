@@ -27,7 +27,6 @@
 
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 
 #include "ptk.h"
 #include "ptk_encode.hpp"
@@ -554,17 +553,14 @@ int morton_bits() {
   return b < 3 ? 3 : (b > 30 ? 30 : b);
 }
 
-// The values sorted along with the Morton keys are the row numbers 0 .. nq - 1: a counting iterator, so
-// no identity array is written by the key kernel and read by the first radix pass.
 size_t sort_tmp_bytes(uint64_t nq, int bits) {
   size_t tmp_bytes = 0;
   uint32_t* k32 = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k32, k32, rocprim::counting_iterator<uint32_t>(0u), k32, nq, 0,
-                                  bits, (hipStream_t) nullptr);
+  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k32, k32, k32, k32, nq, 0, bits, (hipStream_t) nullptr);
   return tmp_bytes + 256;
 }
 
-size_t permutation_scratch_bytes(uint64_t nq) { return 3 * (nq * 4) + sort_tmp_bytes(nq, morton_bits()); }
+size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, morton_bits()); }
 
 // Device-side Morton ordering of a batch: *perm (device, nq uint32, in `scratch`) lists the
 // query rows in launch order.
@@ -577,9 +573,10 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   size_t tmp_bytes = sort_tmp_bytes(nq, bits);
   uint32_t* keys = scratch.take<uint32_t>(nq);
   uint32_t* keys_out = scratch.take<uint32_t>(nq);
+  uint32_t* ids = scratch.take<uint32_t>(nq);
   uint32_t* ids_out = scratch.take<uint32_t>(nq);
   void* tmp = scratch.take<char>(tmp_bytes);
-  if (!keys || !keys_out || !ids_out || !tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
+  if (!keys || !keys_out || !ids || !ids_out || !tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
   float3 lo, inv;
   float lo_[3] = {0, 0, 0}, inv_[3] = {0, 0, 0};
   for (uint32_t d = 0; d < t->dim && d < 3; ++d) {
@@ -591,9 +588,8 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   inv = make_float3(inv_[0], inv_[1], inv_[2]);
   const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
   hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq, lo, inv,
-                     (uint32_t)(30 - bits), keys, static_cast<uint32_t*>(nullptr));
-  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, rocprim::counting_iterator<uint32_t>(0u), ids_out, nq, 0,
-                                    bits, s));
+                     (uint32_t)(30 - bits), keys, ids);
+  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
   *perm = ids_out;
   timer.stop(1, 0);
   return PTK_OK;

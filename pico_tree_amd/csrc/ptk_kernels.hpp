@@ -2069,7 +2069,7 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(
   const float fz = fminf(fmaxf((z - lo.z) * inv.z, 0.0f), 1023.0f);
   // `drop` low bits of the 30-bit key are not worth a radix pass (see morton_bits()).
   keys[i] = (spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2)) >> drop;
-  if (ids != nullptr) ids[i] = (uint32_t)i;  // (the backend sorts a counting iterator along instead)
+  ids[i] = (uint32_t)i;
 }
 
 // Inclusive-to-exclusive helper for the radius offsets: offsets[0] = 0 is written
