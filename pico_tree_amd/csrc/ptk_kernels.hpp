@@ -1592,71 +1592,39 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   // This lane's best: distance, record position, "gmax <= cd"; ties it may still resolve.
   float cd = 3.402823466e+38f;
   uint32_t cpos = 0;
-  int32_t ci = 0;  // its index (kept with it: fetching it at the end would stall the other groups of the wavefront)
   bool cok = false;
   uint32_t tie_budget = 0;
   float start_d = 0.0f;  // the best handed over (phase 2's own, already the reference's)
   uint32_t start_i = 0;
   uint32_t next_idx = first + blockIdx.x * (uint32_t)NG + g;  // this group's next entry of the list
-  const uint32_t stride = gridDim.x * (uint32_t)NG;
-
-  // The NEXT query of the group is fetched while the current one is searched: taking a query is a chain of
-  // three dependent reads (list entry -> query and best -> tasks) during which the other groups of the
-  // wavefront would stand still -- with four groups per wavefront that was a quarter of the kernel.  The list
-  // is walked by static striding, so everything but the query record itself has a known address in advance:
-  //   stage 1 (when the current query starts)  slot, task count, this lane's task of the next entry
-  //   stage 2 (one step later)                 its query record and best so far
-  uint32_t pf_stage = 0;  // 0 nothing in flight, 1 stage 1 issued, 2 stage 2 issued
-  uint32_t pf_idx = 0, pf_e = 0, pf_nt = 0;
-  Task pf_task = Task{0u, 0.0f, 0.0f, 0.0f, 0.0f, 0.0f};
-  float4 pf_q = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
-  uint32_t pf_bi = 0, pf_bd = 0;
-  auto prefetch1 = [&]() {  // entry next_idx, if there is one
-    pf_idx = next_idx;
-    next_idx += stride;
-    if (pf_idx < n_heavy) {
-      pf_e = ho.heavy_list[pf_idx];
-      pf_nt = ho.ntasks[pf_idx];
-      if (pf_idx < ho.max_heavy) pf_task = ho.tasks[(uint64_t)pf_idx * kMaxTasks + gl];
-      pf_stage = 1;
-    } else {
-      pf_stage = 3;  // the list is exhausted
-    }
-  };
-  auto prefetch2 = [&]() {
-    pf_q = qs[pf_e];
-    const uint4 st = cont.best[pf_e];
-    pf_bi = st.x;
-    pf_bd = st.y;
-    pf_stage = 2;
-  };
-  prefetch1();
 
   for (;;) {
-    if (pf_stage == 1) prefetch2();
-    // Groups without a query take the next one (already in registers).
+    // Groups without a query take the next one.
     const bool need = !have && !exhausted;
     if (__ballot(need) != 0ull) {
       if (need) {
-        if (pf_stage == 3) {
-          exhausted = true;
-        } else {
-          const uint32_t idx = pf_idx;
-          e = pf_e;
-          qx = pf_q.x;
-          qy = pf_q.y;
-          qz = pf_q.z;
-          qi = __float_as_uint(pf_q.w);
-          start_i = pf_bi;
-          start_d = __uint_as_float(pf_bd);
-          const uint32_t nt = pf_nt;
+        // Entry `group`, `group + groups`, ... of the list: a shared counter would hand the queries
+        // out more evenly, but one atomic per query on one address is what bounds the launch then
+        // (measured: ~11 ns per query whatever the number of waves).
+        const uint32_t idx = next_idx;
+        next_idx += gridDim.x * (uint32_t)NG;
+        if (idx < n_heavy) {
+          e = ho.heavy_list[idx];
+          const float4 qrec = qs[e];
+          qx = qrec.x;
+          qy = qrec.y;
+          qz = qrec.z;
+          qi = __float_as_uint(qrec.w);
+          const uint4 st = cont.best[e];
+          start_i = st.x;
+          start_d = __uint_as_float(st.y);
+          const uint32_t nt = ho.ntasks[idx];
           have = true;
           busy = false;
           // A best of exactly 0 cannot be improved on: nothing to search.
           failed = (start_d != 0.0f && !(start_d >= 1e-30f && start_d <= 1e30f)) || nt == kTasksRedo;
           cd = 3.402823466e+38f;
           cpos = 0;
-          ci = 0;
           cok = false;
           tie_budget = kCoopTieBudget;
           if (failed || start_d == 0.0f) {
@@ -1675,7 +1643,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
             count = nt;
             const Task* src = ho.tasks + (uint64_t)idx * kMaxTasks;
             for (uint32_t i = gl; i < nt; i += G) {
-              const Task k = i == gl ? pf_task : src[i];  // (the first G tasks came with the prefetch)
+              const Task k = src[i];
               const uint32_t sl = nt - 1u - i;
               pool[0 * POOL + sl] = k.ref;
               pool[1 * POOL + sl] = __float_as_uint(k.nbd);
@@ -1685,8 +1653,9 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
               pool[5 * POOL + sl] = __float_as_uint(k.gmax);
             }
           }
-          if (gl == 0) *gbest = pf_bd;
-          prefetch1();  // the entry after this one
+          if (gl == 0) *gbest = st.y;
+        } else {
+          exhausted = true;
         }
       }
     }
@@ -1780,7 +1749,6 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
             if (d < cd) {
               cd = d;
               cpos = begin + (uint32_t)u;
-              ci = __float_as_int(p[u].w);
               cok = gmax <= d;
             } else if (d == cd && d <= best) {  // an exact tie that can still matter: the one the reference visits first
               if (tie_budget == 0u) {
@@ -1789,7 +1757,6 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
                 --tie_budget;
                 if (!dfs_before(t, ranges, qx, qy, qz, cpos, begin + (uint32_t)u)) {
                   cpos = begin + (uint32_t)u;
-                  ci = __float_as_int(p[u].w);
                   cok = gmax <= d;
                 }
               }
@@ -1862,7 +1829,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         } else if (__popcll(mm) == 1 && good == mm) {
           if (mine) {
             Neighbor nb;
-            nb.index = ci;
+            nb.index = __float_as_int(pts[cpos].w);
             nb.distance = cd;
             out[qi] = nb;
           }
