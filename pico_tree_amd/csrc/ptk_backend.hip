@@ -649,8 +649,8 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
 #define PTK_LAUNCH_REG(KK)                                                                                          \
-  hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M, true>), dim3(blocks), dim3(BLOCK), smem, s,   \
-                     t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out)
+  hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q, \
+                     t->dim, perm, nq, k, inv_ratio(e), d_out)
   if (k <= 4) PTK_LAUNCH_REG(4);
   else if (k <= 8) PTK_LAUNCH_REG(8);
   else if (k <= 16) PTK_LAUNCH_REG(16);
@@ -669,10 +669,10 @@ int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
   if (!fill) {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, false, M, true>), dim3(blocks), dim3(BLOCK), smem, s,
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, false, M>), dim3(blocks), dim3(BLOCK), smem, s,
                        t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
   } else {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true, M, true>), dim3(blocks), dim3(BLOCK), smem, s,
+    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK), smem, s,
                        t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out, n_dev);
   }
   PTK_HIP(hipGetLastError());
@@ -688,7 +688,7 @@ int launch_radius_capture(const ptk_tree* t, const float* d_q, const uint32_t* p
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
   PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
-  hipLaunchKernelGGL((ptk::radius_capture_kernel<S, OVF, BLOCK, LEAFB, M, true>), dim3(blocks), dim3(BLOCK), smem, s,
+  hipLaunchKernelGGL((ptk::radius_capture_kernel<S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s,
                      t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, cap);
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);

@@ -543,16 +543,7 @@ struct Handover {
 // CAPPED: give up (return false) when more than `cap` far children have been entered: what is
 // still on the stack goes to `ho` -- every pending far child that can still matter together with
 // the state it would be entered with, next-to-visit first.
-// UNIFORM: the first descent starts with a wave-uniform prefix, as phase 1 of the k = 1 search does (see
-// knn1_phase1u_kernel): the batch is spatially sorted, so the 64 queries of a wavefront walk the same
-// branches for most of the way down (they part ways 4-6 levels above the leaves); while they agree the
-// branch record is fetched ONCE through the scalar cache (an s_load on a readfirstlane'd index) instead
-// of by a 64-lane gather -- 17 of the ~60 vector loads of a knn = 16 query.  Same arithmetic, same pushes,
-// same results; every lane of the wavefront must call traverse() together (lanes past the end of the
-// batch shadow the last query, see the kernels).  Needs the ballot, so the lane-by-lane emulator
-// instantiates UNIFORM = false and the fibre emulator UNIFORM = true.
-template <int LEAFB, bool RESUME = false, class M = MetricL2, bool CAPPED = false, bool UNIFORM = false, class Policy,
-          class StackT>
+template <int LEAFB, bool RESUME = false, class M = MetricL2, bool CAPPED = false, class Policy, class StackT>
 __device__ __forceinline__ bool traverse(
     const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st, uint32_t cap = 0,
     const Handover* ho = nullptr) {
@@ -562,28 +553,6 @@ __device__ __forceinline__ bool traverse(
   float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
   uint32_t entered = 0;
   bool monotone = true;  // CAPPED: every far child entered so far had a box distance >= its parent's
-
-  if (UNIFORM && !RESUME) {
-    bool together = true;
-    while (together && !(ref & kLeafBit)) {
-      const uint32_t uref = (uint32_t)__builtin_amdgcn_readfirstlane((int)ref);
-      const uint32_t idx = uref & kBranchIdxMask;
-      const uint32_t axis = (uref >> 29) & 3u;
-      const uint4 nd = nodes[idx];
-      const float left_max = __uint_as_float(nd.x);
-      const float right_min = __uint_as_float(nd.y);
-      const float v = sel3(axis, qx, qy, qz);
-      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
-      const float dv = f_sub(go_left ? right_min : left_max, v);
-      const float new_off = M::one(dv);
-      // (first descent: box distance and offsets are still 0, but computed as the reference does)
-      const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
-      if (pol.max() >= far_nbd) st.push(idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
-      ref = go_left ? nd.z : nd.w;
-      const uint64_t b = __ballot(go_left);
-      together = b == 0ull || b == ~0ull;
-    }
-  }
 
   for (;;) {
     // Down to a leaf through the nearer children.
@@ -831,7 +800,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   }
 }
 
-template <int K, int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2, bool UNIFORM = false>
+template <int K, int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
@@ -848,14 +817,14 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
   st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
   KnnRegPolicy<K> pol;
   pol.init(k, e_inv);
-  traverse<LEAFB, false, M, false, UNIFORM>(t, qx, qy, qz, pol, st);
+  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   pol.store(out + qi * k);
 }
 
 // ---- radius: count pass and fill pass ------------------------------------------------------
 // n_dev (fill pass only): the batch is the first *n_dev entries of perm -- the rows a capture
 // could not hold, listed on the device (no host round trip to size the launch).
-template <int S, int OVF, int BLOCK, int LEAFB, bool FILL, class M = MetricL2, bool UNIFORM = false>
+template <int S, int OVF, int BLOCK, int LEAFB, bool FILL, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void radius_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
@@ -876,12 +845,12 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   pol.e_inv = e_inv;
   pol.count = 0;
   pol.out = FILL ? out + offsets[qi] : nullptr;
-  traverse<LEAFB, false, M, false, UNIFORM>(t, qx, qy, qz, pol, st);
+  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   if (!FILL) counts[qi] = pol.count;
 }
 
 // The count pass that also captures the rows (see RadiusCapture).
-template <int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2, bool UNIFORM = false>
+template <int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
@@ -910,7 +879,7 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
   pol.sub_cap = cap.sub_cap;
   pol.n_static = cap.n_static;
   pol.capturing = true;
-  traverse<LEAFB, false, M, false, UNIFORM>(t, qx, qy, qz, pol, st);
+  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   counts[qi] = pol.count;
   cap.captured[qi] = pol.capturing ? 1 : 0;
 }

@@ -347,12 +347,6 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
       for_each_lane(nq, [&] { ptk::knn1_kernel<16, 64, 64, 4>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 64);
     else
       for_each_lane(nq, [&] { ptk::knn1_kernel<32, 2048, 256, 8>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 256);
-  } else if (list_in_lds == 3) {  // registers + the wave-uniform prefix of the first descent (the launches of the backend): fibres
-    if (k > 32) return -2;
-    const uint32_t waves = (uint32_t)((nq + 63) / 64);
-    if (small_stack) for_each_wave(waves, [&] { ptk::knn_reg_kernel<32, 4, 2048, 64, 1, ptk::MetricL2, true>(t->dev, q, t->dim, perm, nq, k, e_inv, o); });
-    else if (k <= 16) for_each_wave(waves, [&] { ptk::knn_reg_kernel<16, 16, 2048, 64, 4, ptk::MetricL2, true>(t->dev, q, t->dim, perm, nq, k, e_inv, o); });
-    else for_each_wave(waves, [&] { ptk::knn_reg_kernel<32, 16, 2048, 64, 4, ptk::MetricL2, true>(t->dev, q, t->dim, perm, nq, k, e_inv, o); });
   } else if (list_in_lds == 2) {  // k-list in registers (k <= 32)
     if (k > 32) return -2;
     if (small_stack) {
@@ -432,8 +426,6 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
 // the static first chunk of every row, so rows above 31 hits take the re-traversal path.
 int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
                        uint64_t* counts, uint32_t sub_cap) {
-  const bool uniform_prefix = (sub_cap >> 31) != 0u;  // flag bit: the wave-uniform prefix, as the backend launches it (fibres)
-  sub_cap &= 0x7FFFFFFFu;
   auto* t = static_cast<Emu*>(h);
   if (t->metric != 0) return -3;
   t->cap_chunks.assign(((size_t)nq + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kCapChunk, ptk::Neighbor{-1, -1.0f});
@@ -449,12 +441,6 @@ int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float
     for_each_lane(nq, [&] {
       ptk::radius_nd_capture_kernel<8, 2048>(t->dev_nd, q, perm, nq, radius, e_inv, counts, t->cap);
     }, 64);
-    return 0;
-  }
-  if (uniform_prefix) {
-    for_each_wave((uint32_t)((nq + 63) / 64), [&] {
-      ptk::radius_capture_kernel<8, 2048, 64, 4, ptk::MetricL2, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
-    });
     return 0;
   }
   for_each_lane(nq, [&] {

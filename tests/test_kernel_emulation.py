@@ -325,26 +325,3 @@ def test_emulated_topological_kernels_equal_the_compiled_reference(metric):
         assert b[0][-1] > 0 and np.array_equal(a[0], b[0]) and a[1].tobytes() == b[1].tobytes()
     knn = ref.search_knn(q, 4)
     assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # some neighbours are nearer through 0 ~ 1
-
-
-@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "lidar", "dim2", "root-is-leaf")],
-                         ids=lambda c: c[0])
-def test_emulated_wave_uniform_prefix_of_the_generic_kernels(case):
-    """knn (register k-list) and the capturing radius count pass as the backend launches them: the first
-    descent starts with the wave-uniform prefix (branch records through the scalar cache while the 64
-    lanes agree).  Wavefronts run as fibres; same rows as the lane-by-lane form and the oracle."""
-    _, pts, q, leaf, radius = case
-    q = q[:1500]
-    emu = EmulatedTree(pts, leaf)
-    ref = oracle.Oracle(pts, leaf, "port")
-    perm, _ = emu.morton_permutation(q)
-    for k in (1, 7, 16, 30):
-        if k > len(pts):
-            continue
-        want = ref.search_knn(q, k)
-        for small in (False, True):
-            for p in (None, perm):
-                assert emu.search_knn(q, k, perm=p, small_stack=small, list_in_lds=3).tobytes() == want.tobytes(), (k, small)
-    off, flat = ref.search_radius(q, radius)
-    goff, gflat, _ = emu.search_radius_captured(q, radius, perm=perm, sub_cap=64 | 0x80000000)
-    assert np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
