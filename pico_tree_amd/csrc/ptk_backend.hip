@@ -553,10 +553,17 @@ int morton_bits() {
   return b < 3 ? 3 : (b > 30 ? 30 : b);
 }
 
+// rocprim switches from the onesweep radix sort to a merge sort below 1 M items by default -- 24 launches
+// and 0.16 ms for the 900 k queries of one eighth of BASELINE config 2 (a shard of configs[3]), where three
+// onesweep passes take 0.05 ms (profiles/r02_notes.txt item 17).  The limit is lowered to 128 k items.
+using MortonSortConfig =
+    rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, rocprim::default_config, 131072>;
+
 size_t sort_tmp_bytes(uint64_t nq, int bits) {
   size_t tmp_bytes = 0;
   uint32_t* k32 = nullptr;
-  (void)rocprim::radix_sort_pairs(nullptr, tmp_bytes, k32, k32, k32, k32, nq, 0, bits, (hipStream_t) nullptr);
+  (void)rocprim::radix_sort_pairs<MortonSortConfig>(nullptr, tmp_bytes, k32, k32, k32, k32, nq, 0, bits,
+                                                    (hipStream_t) nullptr);
   return tmp_bytes + 256;
 }
 
@@ -589,7 +596,7 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
   hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq, lo, inv,
                      (uint32_t)(30 - bits), keys, ids);
-  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
+  PTK_HIP(rocprim::radix_sort_pairs<MortonSortConfig>(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
   *perm = ids_out;
   timer.stop(1, 0);
   return PTK_OK;
@@ -806,9 +813,12 @@ size_t two_phase_scratch_bytes(uint64_t nq) {
 // Far children a query may enter in phase 2 before it is handed to the cooperative search
 // (PTK_P2_CAP; 0 = phase 2 runs every query to its end).  Exact searches only: the argument that
 // makes the cooperative result the reference's (ptk_kernels.hpp, knn1_coop_kernel) needs e = 1.
-uint32_t phase2_cap(float e) {
+// The cap is a chain length (cap x ~10 us of dependent rounds in the dealt tier): what a big batch hides behind
+// its light tier is exposed on a small one, e.g. one shard of BASELINE configs[3] -- 900 k queries: 0.556 ms per
+// step with a cap of 8, 0.604 with 16, 0.612 with 4; 7.2 M queries: 16 (profiles/r02_notes.txt items 4, 17).
+uint32_t phase2_cap(float e, uint64_t nq) {
   if (e != 1.0f) return 0;
-  const int cap = env_int("PTK_P2_CAP", 16);  // sweep in profiles/r02_notes.txt
+  const int cap = env_int("PTK_P2_CAP", nq >= (4ull << 20) ? 16 : 8);
   return cap < 0 ? 0u : (uint32_t)cap;
 }
 
@@ -867,7 +877,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   scratch.note_meta(cont.meta);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
-  const uint32_t cap = phase2_cap(e);
+  const uint32_t cap = phase2_cap(e, nq);
   const int key_bits = env_int("PTK_CONT_BITS", cap ? 3 : 16);
   const bool counting = key_bits == 3 && env_int("PTK_CLASS_SORT", 1) != 0;
   uint32_t* const slot_ids = cont.ids;
