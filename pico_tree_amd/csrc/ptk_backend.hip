@@ -548,8 +548,18 @@ bool want_reorder(const ptk_tree* t, uint64_t nq) {
 // The search only needs neighbouring lanes to walk neighbouring leaves, so the low bits of
 // the full 30-bit key buy nothing: 24 bits (cells of 1/256 of the root box per axis) is one
 // 8-bit radix pass less.  PTK_MORTON_BITS overrides it for A/B runs.
-int morton_bits() {
-  const int b = env_int("PTK_MORTON_BITS", 24);
+// A cloud whose density varies a lot (cloud L: the points crowd around the scanner) wants finer cells where it is
+// dense: 30 bits (a fourth radix pass, +0.07 ms) make the traversal kernels 0.14 ms faster there, and nothing on
+// a uniform cloud (profiles/r02_notes.txt item 18).  The tree knows: the sliding-midpoint tree of a uniform
+// cloud is about log2(leaves) deep, every factor two of density contrast adds a level.
+int morton_bits(const ptk_tree* t = nullptr) {
+  int fallback = 24;
+  if (t != nullptr && t->n_leaves > 1) {
+    int balanced = 0;
+    while ((1ull << balanced) < t->n_leaves) ++balanced;
+    if ((int)t->max_depth - balanced >= 8) fallback = 30;
+  }
+  const int b = env_int("PTK_MORTON_BITS", fallback);
   return b < 3 ? 3 : (b > 30 ? 30 : b);
 }
 
@@ -567,7 +577,7 @@ size_t sort_tmp_bytes(uint64_t nq, int bits) {
   return tmp_bytes + 256;
 }
 
-size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, morton_bits()); }
+size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, 30); }
 
 // Device-side Morton ordering of a batch: *perm (device, nq uint32, in `scratch`) lists the
 // query rows in launch order.
@@ -576,7 +586,7 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   *perm = nullptr;
   if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
   Timer timer(t, s);
-  const int bits = morton_bits();
+  const int bits = morton_bits(t);
   size_t tmp_bytes = sort_tmp_bytes(nq, bits);
   uint32_t* keys = scratch.take<uint32_t>(nq);
   uint32_t* keys_out = scratch.take<uint32_t>(nq);
