@@ -141,6 +141,7 @@ struct ptk_tree {
   std::vector<int32_t> indices;
   std::vector<float> root_min, root_max;
   std::vector<float> outer;  // per node {left_min, right_max} (topological metrics); may be empty
+  double axis_splits[3] = {0, 0, 0};  // mean number of splits per axis on a root-to-leaf path (point-weighted)
   uint32_t max_depth = 0;
   uint64_t n_leaves = 0;
   uint32_t max_leaf_count = 0;
@@ -219,6 +220,35 @@ int analyse(ptk_tree& t) {
   t.n_leaves = st.n_leaves;
   t.max_leaf_count = st.max_leaf_count;
   t.max_depth = st.max_depth;
+  if (t.dim <= 3) {  // how a root-to-leaf path divides space, per axis (weights: points per leaf)
+    struct Frame {
+      uint32_t right;
+      uint32_t cnt[3];
+    };
+    std::vector<Frame> stack;
+    uint32_t cnt[3] = {0, 0, 0};
+    double sum[3] = {0, 0, 0};
+    for (size_t i = 0; i < t.nodes.size(); ++i) {
+      if (!stack.empty() && stack.back().right == i) {
+        std::memcpy(cnt, stack.back().cnt, sizeof(cnt));
+        stack.pop_back();
+      }
+      const ptk_node& nd = t.nodes[i];
+      if (nd.right == PTK_LEAF) {
+        int32_t b, e;
+        std::memcpy(&b, &nd.a, 4);
+        std::memcpy(&e, &nd.b, 4);
+        for (int a = 0; a < 3; ++a) sum[a] += (double)cnt[a] * (e - b);
+      } else {
+        ++cnt[nd.split_dim];
+        Frame f;
+        f.right = nd.right;
+        std::memcpy(f.cnt, cnt, sizeof(cnt));
+        stack.push_back(f);
+      }
+    }
+    for (int a = 0; a < 3; ++a) t.axis_splits[a] = t.n_points ? sum[a] / (double)t.n_points : 0.0;
+  }
   return PTK_OK;
 }
 
@@ -227,6 +257,9 @@ int upload(ptk_tree& t, const float* points) {
   int rc = analyse(t);
   if (rc != PTK_OK) return rc;
   clock.lap("analyse stream");
+  if (clock.on && t.dim <= 3)
+    std::fprintf(stderr, "[ptk create] splits per root-to-leaf path: x %.2f  y %.2f  z %.2f (depth %u)\n", t.axis_splits[0],
+                 t.axis_splits[1], t.axis_splits[2], t.max_depth);
   if (t.dim > 3) {  // any-dimension layout (ptk_kernels_nd.hpp)
     ptk::TreeStats st;
     ptk::EncodedTreeND enc;
@@ -544,23 +577,31 @@ bool want_reorder(const ptk_tree* t, uint64_t nq) {
   return nq >= 8192;
 }
 
-// Bits of the Morton key the batch is sorted by (3 axes interleaved, 10 bits each at most).
-// The search only needs neighbouring lanes to walk neighbouring leaves, so the low bits of
-// the full 30-bit key buy nothing: 24 bits (cells of 1/256 of the root box per axis) is one
-// 8-bit radix pass less.  PTK_MORTON_BITS overrides it for A/B runs.
-// A cloud whose density varies a lot (cloud L: the points crowd around the scanner) wants finer cells where it is
-// dense: 30 bits (a fourth radix pass, +0.07 ms) make the traversal kernels 0.14 ms faster there, and nothing on
-// a uniform cloud (profiles/r02_notes.txt item 18).  The tree knows: the sliding-midpoint tree of a uniform
-// cloud is about log2(leaves) deep, every factor two of density contrast adds a level.
-int morton_bits(const ptk_tree* t = nullptr) {
-  int fallback = 24;
-  if (t != nullptr && t->n_leaves > 1) {
-    int balanced = 0;
-    while ((1ull << balanced) < t->n_leaves) ++balanced;
-    if ((int)t->max_depth - balanced >= 8) fallback = 30;
-  }
-  const int b = env_int("PTK_MORTON_BITS", fallback);
+// Bits of the Morton key the batch is sorted by.  The search only needs neighbouring lanes to walk neighbouring
+// leaves: 24 bits -- three 8-bit radix passes -- spread over the axes the way the tree itself divides space
+// (axis_bits below) order the batch as well as 30 bits spent evenly do, for one pass less
+// (profiles/r02_notes.txt items 18 and 20).  PTK_MORTON_BITS overrides it for A/B runs.
+int morton_bits() {
+  const int b = env_int("PTK_MORTON_BITS", 24);
   return b < 3 ? 3 : (b > 30 ? 30 : b);
+}
+
+// `bits` key bits over the three axes in proportion to how often a root-to-leaf path splits on each (at most 15
+// per axis).  A cloud that is flat along one axis -- most of a LiDAR scan is floor -- gets few bits there and finer
+// cells in the plane; a uniform cube gets bits / 3 each.
+void axis_bits(const ptk_tree* t, int bits, uint32_t b[3]) {
+  b[0] = b[1] = b[2] = 0;
+  const uint32_t axes = t->dim < 3 ? t->dim : 3;
+  double want[3] = {0, 0, 0};
+  const double total = t->axis_splits[0] + t->axis_splits[1] + t->axis_splits[2];
+  for (uint32_t a = 0; a < axes; ++a) want[a] = total > 0.0 ? bits * t->axis_splits[a] / total : (double)bits / axes;
+  for (int given = 0; given < bits; ++given) {  // largest remaining share first
+    int best = -1;
+    for (uint32_t a = 0; a < axes; ++a)
+      if (b[a] < 15 && (best < 0 || want[a] - b[a] > want[best] - b[best])) best = (int)a;
+    if (best < 0) break;
+    ++b[best];
+  }
 }
 
 // rocprim switches from the onesweep radix sort to a merge sort below 1 M items by default -- 24 launches
@@ -586,7 +627,7 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   *perm = nullptr;
   if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
   Timer timer(t, s);
-  const int bits = morton_bits(t);
+  const int bits = morton_bits();
   size_t tmp_bytes = sort_tmp_bytes(nq, bits);
   uint32_t* keys = scratch.take<uint32_t>(nq);
   uint32_t* keys_out = scratch.take<uint32_t>(nq);
@@ -594,18 +635,18 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   uint32_t* ids_out = scratch.take<uint32_t>(nq);
   void* tmp = scratch.take<char>(tmp_bytes);
   if (!keys || !keys_out || !ids || !ids_out || !tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
-  float3 lo, inv;
-  float lo_[3] = {0, 0, 0}, inv_[3] = {0, 0, 0};
+  uint32_t b[3];
+  axis_bits(t, bits, b);
+  float lo[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
   for (uint32_t d = 0; d < t->dim && d < 3; ++d) {
-    lo_[d] = t->root_min[d];
+    lo[d] = t->root_min[d];
     const float ext = t->root_max[d] - t->root_min[d];
-    inv_[d] = ext > 0 ? 1024.0f / ext : 0.0f;
+    inv[d] = ext > 0 ? (float)(1u << b[d]) / ext : 0.0f;
   }
-  lo = make_float3(lo_[0], lo_[1], lo_[2]);
-  inv = make_float3(inv_[0], inv_[1], inv_[2]);
   const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
-  hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq, lo, inv,
-                     (uint32_t)(30 - bits), keys, ids);
+  hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq,
+                     make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]),
+                     keys, ids);
   PTK_HIP(rocprim::radix_sort_pairs<MortonSortConfig>(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
   *perm = ids_out;
   timer.stop(1, 0);

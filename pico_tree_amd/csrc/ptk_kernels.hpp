@@ -2046,8 +2046,8 @@ __global__ __launch_bounds__(kBlock) void encode_points_kernel(
 }
 
 // ---- batch ordering ------------------------------------------------------------------------
-// 30-bit Morton key of each query inside the tree's root box (clamped), plus the
-// identity permutation to be sorted along with it.
+// Morton key of each query inside the tree's root box (clamped), plus the identity permutation
+// to be sorted along with it.  spread10 serves the float64 kernel (ten bits per axis).
 __device__ __forceinline__ uint32_t spread10(uint32_t x) {
   x &= 0x3FFu;
   x = (x | (x << 16)) & 0x030000FFu;
@@ -2057,18 +2057,28 @@ __device__ __forceinline__ uint32_t spread10(uint32_t x) {
   return x;
 }
 
+// The float32 key has an uneven number of bits per axis (bx + by + bz <= 30; the backend derives them from the
+// tree: how often a root-to-leaf path splits on each axis).  A cloud that is flat along one axis -- a LiDAR
+// scan is mostly floor -- then spends its key bits where its leaves actually divide space.  Bits are
+// interleaved from the most significant level down; an axis joins in at the level its own bits begin.
 __global__ __launch_bounds__(kBlock) void morton_kernel(
-    const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv, uint32_t drop,
+    const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv, uint3 bits,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nq) return;
   float x, y, z;
   load_query(queries, dim, i, x, y, z);
-  const float fx = fminf(fmaxf((x - lo.x) * inv.x, 0.0f), 1023.0f);
-  const float fy = fminf(fmaxf((y - lo.y) * inv.y, 0.0f), 1023.0f);
-  const float fz = fminf(fmaxf((z - lo.z) * inv.z, 0.0f), 1023.0f);
-  // `drop` low bits of the 30-bit key are not worth a radix pass (see morton_bits()).
-  keys[i] = (spread10((uint32_t)fx) | (spread10((uint32_t)fy) << 1) | (spread10((uint32_t)fz) << 2)) >> drop;
+  const uint32_t cx = (uint32_t)fminf(fmaxf((x - lo.x) * inv.x, 0.0f), (float)((1u << bits.x) - 1u));
+  const uint32_t cy = (uint32_t)fminf(fmaxf((y - lo.y) * inv.y, 0.0f), (float)((1u << bits.y) - 1u));
+  const uint32_t cz = (uint32_t)fminf(fmaxf((z - lo.z) * inv.z, 0.0f), (float)((1u << bits.z) - 1u));
+  const uint32_t top = bits.x > bits.y ? (bits.x > bits.z ? bits.x : bits.z) : (bits.y > bits.z ? bits.y : bits.z);
+  uint32_t key = 0;
+  for (uint32_t level = top; level-- > 0;) {
+    if (bits.z > level) key = (key << 1) | ((cz >> level) & 1u);
+    if (bits.y > level) key = (key << 1) | ((cy >> level) & 1u);
+    if (bits.x > level) key = (key << 1) | ((cx >> level) & 1u);
+  }
+  keys[i] = key;
   ids[i] = (uint32_t)i;
 }
 

@@ -733,11 +733,11 @@ int emu_forest_knn(const float* points, uint64_t n, uint32_t dim, uint64_t max_l
 }
 
 // Morton keys + identity ids exactly as the device computes them.
-void emu_morton(const float* q, uint32_t dim, uint64_t nq, const float* lo, const float* inv, uint32_t* keys,
-                uint32_t* ids) {
+void emu_morton(const float* q, uint32_t dim, uint64_t nq, const float* lo, const float* inv, const uint32_t* bits,
+                uint32_t* keys, uint32_t* ids) {
   float3 l = make_float3(lo[0], lo[1], lo[2]);
   float3 i = make_float3(inv[0], inv[1], inv[2]);
-  for_each_lane(nq, [&] { ptk::morton_kernel(q, dim, nq, l, i, 0u, keys, ids); });
+  for_each_lane(nq, [&] { ptk::morton_kernel(q, dim, nq, l, i, make_uint3(bits[0], bits[1], bits[2]), keys, ids); });
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@
 #define __launch_bounds__(...)
 
 struct uint2 { uint32_t x, y; };
+struct uint3 { uint32_t x, y, z; };
 struct uint4 { uint32_t x, y, z, w; };
 struct float2 { float x, y; };
 struct float3 { float x, y, z; };
@@ -24,6 +25,7 @@ struct float4 { float x, y, z, w; };
 struct dim3 { uint32_t x = 1, y = 1, z = 1; };
 
 inline uint2 make_uint2(uint32_t x, uint32_t y) { return uint2{x, y}; }
+inline uint3 make_uint3(uint32_t x, uint32_t y, uint32_t z) { return uint3{x, y, z}; }
 inline uint4 make_uint4(uint32_t x, uint32_t y, uint32_t z, uint32_t w) { return uint4{x, y, z, w}; }
 inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 inline float2 make_float2(float x, float y) { return float2{x, y}; }

@@ -27,7 +27,7 @@ def _lib():
     lib.emu_radius_fill.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_void_p,
                                     c_void_p, c_int]
     lib.emu_knn1_two_phase.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_void_p, c_int, c_void_p]
-    lib.emu_morton.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p]
+    lib.emu_morton.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
     return lib
 
 
@@ -139,18 +139,22 @@ class EmulatedTree:
         self.lib.emu_last_coop(ctypes.byref(heavy), ctypes.byref(redo))
         return heavy.value, redo.value
 
-    def morton_permutation(self, q):
-        """The permutation the device would use (keys from the kernel, stable sort)."""
+    def morton_permutation(self, q, bits=None):
+        """A permutation as the device makes it (keys from the kernel, stable sort).  `bits`: key bits per
+        axis (the backend derives them from the tree, ptk_backend.hip axis_bits(); default 8 each)."""
         q = np.ascontiguousarray(q, dtype=np.float32)
+        bits = np.zeros(3, dtype=np.uint32) if bits is None else np.asarray(list(bits) + [0] * 3, dtype=np.uint32)[:3]
+        if not bits.any():
+            bits[:self.pts.shape[1]] = 8
         lo = np.zeros(3, dtype=np.float32)
         inv = np.zeros(3, dtype=np.float32)
         d = self.pts.shape[1]
         lo[:d] = self.rmin
         ext = self.rmax - self.rmin
-        inv[:d] = np.where(ext > 0, np.float32(1024.0) / ext, 0).astype(np.float32)
+        inv[:d] = np.where(ext > 0, np.exp2(bits[:d]).astype(np.float32) / ext, 0).astype(np.float32)
         keys = np.zeros(len(q), dtype=np.uint32)
         ids = np.zeros(len(q), dtype=np.uint32)
-        self.lib.emu_morton(q.ctypes.data, d, len(q), lo.ctypes.data, inv.ctypes.data,
+        self.lib.emu_morton(q.ctypes.data, d, len(q), lo.ctypes.data, inv.ctypes.data, bits.ctypes.data,
                             keys.ctypes.data, ids.ctypes.data)
         return ids[np.argsort(keys, kind="stable")].astype(np.uint32), keys
 

@@ -103,13 +103,18 @@ def test_morton_keys_follow_the_curve():
     pts = ds.uniform_cloud(5_000, 3, 3)
     emu = EmulatedTree(pts, 10)
     q = ds.uniform_cloud(4_000, 3, 4)
-    perm, keys = emu.morton_permutation(q)
-    assert keys.max() < (1 << 30)
-    host = ds.morton_order(np.concatenate([q, pts.min(0)[None], pts.max(0)[None]]))  # same box
-    # Both orders must put spatial neighbours together: compare mean jump length.
     jump = lambda o: float(np.linalg.norm(np.diff(q[o], axis=0), axis=1).mean())  # noqa: E731
-    assert jump(perm) < 0.25 * jump(np.arange(len(q)))
-    del host
+    for bits, total in (((8, 8, 8), 24), ((10, 10, 10), 30), ((11, 9, 4), 24), ((15, 0, 9), 24), ((1, 1, 1), 3)):
+        perm, keys = emu.morton_permutation(q, bits)
+        assert keys.max() < (1 << total)
+        assert sorted(perm.tolist()) == list(range(len(q)))
+        if min(bits) >= 8:  # (even bits suit this cube) spatial neighbours end up together: mean jump length
+            assert jump(perm) < 0.25 * jump(np.arange(len(q)))
+    # Uneven bits interleave from the top: with (2, 1, 0) the key is x1 y0 x0 (x's first bit, then y's and x's).
+    lo, hi = pts.min(0), pts.max(0)
+    probe = lo + (hi - lo) * np.array([[0.80, 0.75, 0.5], [0.30, 0.75, 0.9], [0.55, 0.25, 0.1]], dtype=np.float32)
+    _, keys = emu.morton_permutation(probe, (2, 1, 0))
+    assert keys.tolist() == [0b111, 0b011, 0b100]
 
 
 @pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "self", "lidar", "root-is-leaf",
