@@ -698,14 +698,24 @@ __device__ __forceinline__ bool traverse(
   }
 }
 
-// Blocks are dealt round-robin to the 8 XCDs; give each XCD one contiguous
-// eighth of the (spatially sorted) batch so its private L2 only ever sees one
-// region of the tree.  Pure performance: any mapping is correct.
-__device__ __forceinline__ uint32_t xcd_tile(uint32_t b, uint32_t nb) {
-  const uint32_t per = nb >> 3;  // blocks per XCD in the evenly divisible part
-  const uint32_t even = per << 3;
-  if (b >= even) return b;  // tail blocks keep their index
-  return (b & 7u) * per + (b >> 3);
+// Blocks are dealt round-robin to the 8 XCDs, each with an L2 of its own: a wavefront's neighbours in the
+// (spatially sorted) batch should run on the same XCD.  Pure performance: any mapping is correct.
+// Blocks are taken in groups of 8 << run_log2; inside a group XCD x gets the run of
+// 1 << run_log2 consecutive tiles number x.  Every XCD then moves through the batch at the same pace while its
+// L2 still sees runs of neighbouring queries.  A batch whose cost varies along the order must not leave one XCD
+// with the expensive eighth: the radius search of BASELINE config 3 on the scan-like cloud took 32 ms with
+// contiguous eighths (the XCD that got the dense middle of the scan ran on alone) and 16.7 ms in runs of 8 - 32
+// wavefronts; knn = 16 7.65 -> 6.67 ms (profiles/r02_notes.txt item 21).
+#ifndef PTK_XCD_RUN_LOG2
+#define PTK_XCD_RUN_LOG2 4
+#endif
+constexpr uint32_t kXcdRunLog2 = PTK_XCD_RUN_LOG2;
+__device__ __forceinline__ uint32_t xcd_runs(uint32_t b, uint32_t nb, uint32_t run_log2 = kXcdRunLog2) {
+  const uint32_t group = 8u << run_log2;
+  const uint32_t g = b / group;
+  if ((g + 1u) * group > nb) return b;  // the incomplete last group keeps its order
+  const uint32_t r = b - g * group;
+  return g * group + ((r & 7u) << run_log2) + (r >> 3);
 }
 
 __device__ __forceinline__ void load_query(
@@ -735,7 +745,7 @@ template <int S, int OVF, int BLOCK, int LEAFB>
 __global__ __launch_bounds__(BLOCK) void knn1_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float e_inv, Neighbor* __restrict__ out) {
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -765,7 +775,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
     Neighbor* __restrict__ out) {
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -805,7 +815,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
     Neighbor* __restrict__ out) {
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -831,7 +841,7 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
     uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
     Neighbor* __restrict__ out, const uint32_t* __restrict__ n_dev = nullptr) {
   if (n_dev != nullptr) nq = *n_dev;
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -855,7 +865,7 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
     uint64_t* __restrict__ counts, RadiusCapture cap) {
-  const uint32_t tile = xcd_tile(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -980,7 +990,7 @@ template <int S, int OVF, int LEAFB, bool DOUBLE>
 __global__ __launch_bounds__(64) void knn1_phase1_kernel(
     DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
     Cont cont) {
-  const uint64_t i = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint4* __restrict__ nodes = t.nodes;
   const float4* __restrict__ pts = t.pts;
@@ -1123,7 +1133,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
     Cont cont, const float* __restrict__ queries = nullptr, uint32_t dim = 3,
     const uint32_t* __restrict__ perm = nullptr, float4* __restrict__ qs_out = nullptr, uint32_t merge_light = 0) {
-  const uint64_t i0 = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  const uint64_t i0 = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
   const uint4* __restrict__ nodes = t.nodes;

@@ -501,7 +501,7 @@ template <class M, bool D3>
 __global__ __launch_bounds__(64) void knn64_kernel(
     DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
     uint32_t k, double e_inv, Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
   if (k == 1) {
@@ -532,7 +532,7 @@ template <class M, int K, bool D3>
 __global__ __launch_bounds__(64) void knn64_reg_kernel(
     DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
     uint32_t k, double e_inv, Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
   Knn64RegPolicy<K> pol;
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(64) void radius64_kernel(
     DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
     double radius, double e_inv, uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
     Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
   Radius64Policy<FILL> pol;
@@ -619,7 +619,7 @@ __global__ __launch_bounds__(64) void box64_kernel(
     DevTree64 t, const double* __restrict__ root, const double* __restrict__ mins,
     const double* __restrict__ maxs, uint64_t b0, uint64_t nb, uint64_t* __restrict__ counts,
     const uint64_t* __restrict__ offsets, int32_t* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nb) return;
   const uint64_t bi = b0 + i;
   const uint32_t dim = t.dim;

@@ -145,7 +145,7 @@ template <int S, int OVF, bool LIST_LDS, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn_nd_kernel(
     DevTreeND t, const float* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k,
     float e_inv, Neighbor* __restrict__ out) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   LdsFloat *q, *off;
@@ -173,7 +173,7 @@ template <int K, int S, int OVF, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn_nd_reg_kernel(
     DevTreeND t, const float* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k,
     float e_inv, Neighbor* __restrict__ out) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   LdsFloat *q, *off;
@@ -195,7 +195,7 @@ __global__ __launch_bounds__(64) void radius_nd_kernel(
     uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out,
     const uint32_t* __restrict__ perm = nullptr, const uint32_t* __restrict__ n_dev = nullptr) {
   if (n_dev != nullptr) nq = *n_dev;
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   LdsFloat *q, *off;
@@ -215,7 +215,7 @@ template <int S, int OVF, class M = MetricL2>
 __global__ __launch_bounds__(64) void radius_nd_capture_kernel(
     DevTreeND t, const float* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t nq, float radius,
     float e_inv, uint64_t* __restrict__ counts, RadiusCapture cap) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;  // launch order only: row qi is still chain qi
   LdsFloat *q, *off;

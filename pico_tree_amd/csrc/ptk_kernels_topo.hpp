@@ -141,7 +141,7 @@ template <int K, int S, int OVF, class T>
 __global__ __launch_bounds__(64) void knn_topo_reg_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
     uint32_t k, float e_inv, Neighbor* __restrict__ out) {
-  const uint64_t i = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
@@ -157,7 +157,7 @@ template <int S, int OVF, class T>
 __global__ __launch_bounds__(64) void knn_topo_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
     uint32_t k, float e_inv, Neighbor* __restrict__ out) {
-  const uint64_t i = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
@@ -180,7 +180,7 @@ __global__ __launch_bounds__(64) void radius_topo_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
     float radius, float e_inv, uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
     Neighbor* __restrict__ out) {
-  const uint64_t i = (uint64_t)xcd_tile(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
   float qx, qy, qz;
