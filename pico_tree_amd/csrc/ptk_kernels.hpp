@@ -1749,27 +1749,33 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         }
         ref = go_left ? w0.z : w0.w;
       } else {
+        // The nearest of the (up to) four points, the first of them on a tie (a leaf is visited in index
+        // order), without a branch per point; then one comparison with what this lane holds.
+        float d = 3.402823466e+38f;
+        uint32_t du = 0;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          if ((uint32_t)u < cnt) {
-            const float dx = f_sub(qx, p[u].x);
-            const float dy = f_sub(qy, p[u].y);
-            const float dz = f_sub(qz, p[u].z);
-            const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
-            if (d < cd) {
-              cd = d;
-              cpos = begin + (uint32_t)u;
+        for (int u = 3; u >= 0; --u) {
+          const float dx = f_sub(qx, p[u].x);
+          const float dy = f_sub(qy, p[u].y);
+          const float dz = f_sub(qz, p[u].z);
+          const float du_d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
+          const bool take = (uint32_t)u < cnt && du_d <= d;
+          d = take ? du_d : d;
+          du = take ? (uint32_t)u : du;
+        }
+        // (d stays FLT_MAX only for an empty batch, which does not occur: cnt >= 1.)
+        if (d < cd) {
+          cd = d;
+          cpos = begin + du;
+          cok = gmax <= d;
+        } else if (d == cd && d <= best) {  // an exact tie that can still matter: the one the reference visits first
+          if (tie_budget == 0u) {
+            cok = false;
+          } else {
+            --tie_budget;
+            if (!dfs_before(t, ranges, qx, qy, qz, cpos, begin + du)) {
+              cpos = begin + du;
               cok = gmax <= d;
-            } else if (d == cd && d <= best) {  // an exact tie that can still matter: the one the reference visits first
-              if (tie_budget == 0u) {
-                cok = false;
-              } else {
-                --tie_budget;
-                if (!dfs_before(t, ranges, qx, qy, qz, cpos, begin + (uint32_t)u)) {
-                  cpos = begin + (uint32_t)u;
-                  cok = gmax <= d;
-                }
-              }
             }
           }
         }
