@@ -1719,35 +1719,36 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
 #pragma unroll
         for (int u = 1; u < 4; ++u) p[u] = pts[begin + u];
       }
-      if (fresh) {  // enter the far child of a pending record (as traverse() does)
-        const uint32_t axis = (ref >> 28) & 3u;
-        const bool far_is_right = (ref & kRecSide) != 0;
-        const float plane = far_is_right ? __uint_as_float(w0.y) : __uint_as_float(w0.x);
-        const float dv = f_sub(plane, sel3(axis, qx, qy, qz));
-        const float new_off = f_mul(dv, dv);
-        off0 = axis == 0 ? new_off : off0;
-        off1 = axis == 1 ? new_off : off1;
-        off2 = axis == 2 ? new_off : off2;
-        ref = far_is_right ? w0.w : w0.z;
-      } else if (!is_leaf) {
-        const uint32_t axis = (ref >> 29) & 3u;
+      if (!is_leaf) {
+        // A branch, or (fresh) the parent branch of a pending record whose far child is entered as traverse()
+        // enters it: the same arithmetic with the side given instead of chosen, and nothing kept.
+        const uint32_t axis = fresh ? (ref >> 28) & 3u : (ref >> 29) & 3u;
         const float left_max = __uint_as_float(w0.x);
         const float right_min = __uint_as_float(w0.y);
         const float v = sel3(axis, qx, qy, qz);
-        const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+        const bool near_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+        const bool go_left = fresh ? (ref & kRecSide) != 0u : near_left;  // near side left = far child right (the record's side bit)
         const float dv = f_sub(go_left ? right_min : left_max, v);
         const float new_off = f_mul(dv, dv);
-        const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
-        if (bm >= far_nbd) {
-          push = true;
-          p_ref = go_left ? w0.w : w0.z;
-          p_nbd = far_nbd;
-          p_off0 = axis == 0 ? new_off : off0;
-          p_off1 = axis == 1 ? new_off : off1;
-          p_off2 = axis == 2 ? new_off : off2;
-          p_gmax = gmax < far_nbd ? far_nbd : gmax;
+        const uint32_t far_ref = go_left ? w0.w : w0.z;
+        if (fresh) {
+          off0 = axis == 0 ? new_off : off0;
+          off1 = axis == 1 ? new_off : off1;
+          off2 = axis == 2 ? new_off : off2;
+          ref = far_ref;
+        } else {
+          const float far_nbd = f_add(f_sub(nbd, sel3(axis, off0, off1, off2)), new_off);
+          if (bm >= far_nbd) {
+            push = true;
+            p_ref = far_ref;
+            p_nbd = far_nbd;
+            p_off0 = axis == 0 ? new_off : off0;
+            p_off1 = axis == 1 ? new_off : off1;
+            p_off2 = axis == 2 ? new_off : off2;
+            p_gmax = gmax < far_nbd ? far_nbd : gmax;
+          }
+          ref = go_left ? w0.z : w0.w;
         }
-        ref = go_left ? w0.z : w0.w;
       } else {
         // The nearest of the (up to) four points, the first of them on a tie (a leaf is visited in index
         // order), without a branch per point; then one comparison with what this lane holds.
