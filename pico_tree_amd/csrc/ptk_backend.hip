@@ -99,10 +99,6 @@ struct Workspace {
   hipEvent_t done = nullptr;
   bool has_work = false;
   const uint32_t* last_meta = nullptr;  // Cont::meta of the last two-phase k = 1 search (ptk_debug_knn1_counts)
-  // A second stream for kernels of one search that may run side by side, forked from and joined to
-  // the caller's stream with events (created on first use, under `mutex`).
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
 
   // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
   // it must survive until the fill pass of the same batch while other searches reuse `base`.
@@ -488,22 +484,6 @@ class Scratch {
     return PTK_OK;
   }
   void note_meta(const uint32_t* meta) { ws_.last_meta = meta; }
-  // The block's side stream and its fork / join events; false if they cannot be created.
-  bool side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
-    if (ws_.side == nullptr) {
-      if (hipStreamCreateWithFlags(&ws_.side, hipStreamNonBlocking) != hipSuccess) ws_.side = nullptr;
-      if (ws_.side && hipEventCreateWithFlags(&ws_.fork, hipEventDisableTiming) != hipSuccess) ws_.fork = nullptr;
-      if (ws_.side && hipEventCreateWithFlags(&ws_.join, hipEventDisableTiming) != hipSuccess) ws_.join = nullptr;
-    }
-    if (!ws_.side || !ws_.fork || !ws_.join) {
-      (void)hipGetLastError();
-      return false;
-    }
-    *side = ws_.side;
-    *fork = ws_.fork;
-    *join = ws_.join;
-    return true;
-  }
   template <class T>
   T* take(size_t count) {
     const size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
@@ -580,11 +560,9 @@ bool want_reorder(const ptk_tree* t, uint64_t nq) {
 // Bits of the Morton key the batch is sorted by.  The search only needs neighbouring lanes to walk neighbouring
 // leaves: 24 bits -- three 8-bit radix passes -- spread over the axes the way the tree itself divides space
 // (axis_bits below) order the batch as well as 30 bits spent evenly do, for one pass less
-// (profiles/r02_notes.txt items 18 and 20).  PTK_MORTON_BITS overrides it for A/B runs.
-int morton_bits() {
-  const int b = env_int("PTK_MORTON_BITS", 24);
-  return b < 3 ? 3 : (b > 30 ? 30 : b);
-}
+// (profiles/r02_notes.txt items 18 and 20).
+constexpr int kMortonBits = 24;
+int morton_bits() { return kMortonBits; }
 
 // `bits` key bits over the three axes in proportion to how often a root-to-leaf path splits on each (at most 15
 // per axis).  A cloud that is flat along one axis -- most of a LiDAR scan is floor -- gets few bits there and finer
@@ -662,21 +640,6 @@ int check_search(const ptk_tree* t, const void* q, uint64_t nq) {
 }
 
 float inv_ratio(float e) { return 1.0f / e; }
-
-template <int S, int OVF, int BLOCK, int LEAFB>
-int launch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
-                ptk::Neighbor* d_out, hipStream_t s) {
-  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  const size_t smem = (size_t)S * BLOCK * 8;
-  int rc = allow_lds(ptk::knn1_kernel<S, OVF, BLOCK, LEAFB>, smem);
-  if (rc != PTK_OK) return rc;
-  Timer timer(t, s);
-  hipLaunchKernelGGL((ptk::knn1_kernel<S, OVF, BLOCK, LEAFB>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q,
-                     t->dim, perm, nq, inv_ratio(e), d_out);
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
 
 template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
@@ -797,37 +760,15 @@ bool prepare_capture(uint64_t nq, Workspace& ws) {
   return true;
 }
 
-// Packs the batch as {x, y, z, bits(index)} records in launch order (perm or identity).
-int pack_queries(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, hipStream_t s,
-                 Scratch& scratch, float4** qs) {
-  *qs = nullptr;
-  if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
-  Timer timer(t, s);
-  *qs = scratch.take<float4>(nq);
-  if (*qs == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
-  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
-  hipLaunchKernelGGL(ptk::pack_queries_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, perm, nq, *qs);
-  PTK_HIP(hipGetLastError());
-  timer.stop(1, 0);
-  return PTK_OK;
-}
-
-// PTK_TIERS="60:4": the first 60 per mille of the ranked classes at 4 lanes per wave (the default
-// when phase 2 runs every query to its end; with the cap the long chains go to the cooperative
-// search and there is no narrow tier unless asked for).
-ptk::TierSpec parse_tiers(const char* fallback) {
+// Narrow tiers of phase 2 (cumulative per-mille marks of the ranked classes, lanes per wavefront).  A search that
+// runs every query to its end (e != 1: no cap, see phase2_cap) starts the 6 % most expensive continuations four to
+// a wavefront: they are the critical path of the launch (profiles/r01e_notes.txt).  With the cap the long chains go
+// to the cooperative search and there is no narrow tier.
+ptk::TierSpec phase2_tiers(uint32_t cap) {
   ptk::TierSpec t{};
-  const char* v = std::getenv("PTK_TIERS");
-  std::string spec = v ? v : fallback;
-  size_t pos = 0;
-  for (uint32_t i = 0; i < ptk::kMaxTiers && pos < spec.size(); ++i) {
-    unsigned pm = 0, lanes = 0;
-    int used = 0;
-    if (std::sscanf(spec.c_str() + pos, "%u:%u%n", &pm, &lanes, &used) < 2) break;
-    t.permille[i] = pm > 1000 ? 1000 : pm;
-    t.lanes[i] = lanes;
-    pos += (size_t)used;
-    if (pos < spec.size() && spec[pos] == ',') ++pos;
+  if (cap == 0) {
+    t.permille[0] = 60;
+    t.lanes[0] = 4;
   }
   return t;
 }
@@ -873,37 +814,31 @@ uint32_t phase2_cap(float e, uint64_t nq) {
   return cap < 0 ? 0u : (uint32_t)cap;
 }
 
-template <int G, int POOL>
+// The cooperative search: 16 lanes per query, a pool of 96 subtrees per group (8 / 32 / 64 lanes were measured:
+// 1.91 / 1.90 / slower vs 1.72 ms of traversal kernels, profiles/r02_notes.txt items 6, 12).
+constexpr int kCoopLanes = 16, kCoopPool = 96;
 int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
-                     const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, uint32_t range) {
-  constexpr size_t smem = (size_t)(64 / G) * (6 * POOL + 1) * 4;
+                     const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s) {
+  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
   // As many waves as can be resident at once (LDS-bound; 256 CUs x 160 KiB), each group working
   // through its share of the list: a second round of blocks would start when most of the work is done.
-  const int resident = 256 * (int)std::min<size_t>(24, (160 * 1024) / (smem + 512));
-  const int waves = std::max(1, env_int("PTK_COOP_WAVES", resident));
-  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, POOL>), dim3(waves), dim3(64), smem, s, t->dev,
-                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, range);
+  const int waves = 256 * (int)std::min<size_t>(24, (160 * 1024) / (smem + 512));
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool>), dim3(waves), dim3(64), smem, s, t->dev,
+                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
 
-// UNIFORM1: phase 1 with the wave-uniform prefix, which also packs the launch-order records (the
-// shipped form); otherwise the plain double-descent phase 1 behind pack_queries_kernel (A/B).
-template <int OVF, bool UNIFORM1>
+// The k = 1 search under the default metric (ptk_kernels.hpp, "the two-phase k = 1 search"): phase 1 (which also
+// packs the launch-order records), the class order of the continuations, phase 2, and for exact searches the
+// cooperative search of what phase 2 handed over plus the replay of what that could not certify.
+template <int OVF>
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
-  constexpr int S2 = 16;    // LDS ring of phase 2 (8 KB per wave: 20 waves per CU; 12 / 8 slots: r01l_notes item 8)
   constexpr int LEAFB = 4;  // points fetched per round trip
-  float4* qs = nullptr;
-  int rc = PTK_OK;
-  if (UNIFORM1) {
-    if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
-    qs = scratch.take<float4>(nq);
-    if (qs == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
-  } else {
-    rc = pack_queries(t, d_q, perm, nq, s, scratch, &qs);
-  }
-  if (rc != PTK_OK) return rc;
+  if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
+  float4* qs = scratch.take<float4>(nq);
+  if (qs == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
   ptk::Cont cont{};
   cont.nq = nq;
   size_t tmp_bytes = class_sort_tmp_bytes(nq);
@@ -929,34 +864,23 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
   const uint32_t cap = phase2_cap(e, nq);
-  const int key_bits = env_int("PTK_CONT_BITS", cap ? 3 : 16);
-  const bool counting = key_bits == 3 && env_int("PTK_CLASS_SORT", 1) != 0;
   uint32_t* const slot_ids = cont.ids;
-  if (counting) cont.ids = nullptr;  // phase 1 need not write slot numbers: the counting sort produces them
-  // Narrow tiers at the head of the ranked classes: "permille:lanes,..." (cumulative marks).  The
-  // grid has room for nq / 64 extra waves there; the meta kernel cuts the tiers to what fits.
-  ptk::TierSpec tiers = parse_tiers(cap ? "" : "60:4");
+  if (cap) cont.ids = nullptr;  // phase 1 need not write slot numbers: the counting sort produces them
+  // The grid has room for nq / 64 extra waves in the narrow tiers; the meta kernel cuts the tiers to what fits.
+  const ptk::TierSpec tiers = phase2_tiers(cap);
   const uint32_t extra_waves = tiers.permille[0] == 0 ? 0u : (uint32_t)(nq / 64) + 2u;
   {
     Timer timer(t, s);
-    if (UNIFORM1) {
-      hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs, nq,
-                         e_inv, d_out, cont, d_q, t->dim, perm, qs, (uint32_t)env_int("PTK_MERGE_LIGHT", 0));
-    } else {
-      hipLaunchKernelGGL((ptk::knn1_phase1_kernel<32, OVF, LEAFB, true>), dim3(blocks), dim3(64), 0, s, t->dev, qs,
-                         nq, e_inv, d_out, cont);
-    }
+    hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, t->dev, d_q, t->dim, perm, nq,
+                       e_inv, d_out, cont, qs);
     timer.stop(0, nq);
   }
   {
     Timer timer(t, s);
-    // With the cap the order inside the heavy classes no longer matters (no query runs long):
-    // one radix pass over the three class bits, stable, so every class keeps its Morton order.
-    const uint32_t heavy_class = (uint32_t)env_int("PTK_HEAVY_CLASS", (int)ptk::kHeavyClass);
-    const uint32_t deal = (uint32_t)env_int("PTK_DEAL", 1);
-    if (counting) {
-      // 8 buckets: count per chunk, scan the 8 x chunks counters, stable scatter; the tier table from the
-      // scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
+    if (cap) {
+      // With the cap the order inside the heavy classes does not matter (no query runs long), only the three class
+      // bits do: 8 buckets -- count per chunk, scan the 8 x chunks counters, stable scatter; the tier table from
+      // the scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
       const uint32_t chunks = class_chunks(nq);
       const size_t n_counters = (size_t)ptk::kClassBuckets * chunks;
       uint32_t* counters = scratch.take<uint32_t>(n_counters);
@@ -966,112 +890,41 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
       if (!counters || !offsets || !scan_tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
       hipLaunchKernelGGL(ptk::class_count_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer, counters);
       PTK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, counters, offsets, 0u, n_counters, rocprim::plus<uint32_t>(), s));
-      hipLaunchKernelGGL(ptk::class_meta_kernel, dim3(1), dim3(1), 0, s, offsets, chunks, cont, heavy_class, tiers,
-                         extra_waves, deal);
+      hipLaunchKernelGGL(ptk::class_meta_kernel, dim3(1), dim3(1), 0, s, offsets, chunks, cont, tiers, extra_waves);
       hipLaunchKernelGGL(ptk::class_scatter_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer,
                          offsets, ids_out);
       PTK_HIP(hipGetLastError());
     } else {
-      PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, slot_ids, ids_out, nq,
-                                        key_bits >= 16 ? 0 : 16 - key_bits, 16, s));
-      hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont, heavy_class,
-                         tiers, extra_waves, deal);
+      // Every query runs to its end in phase 2: the full 16-bit key (the ranked classes by how far their
+      // home-leaf best is), so that the most expensive continuations start first.
+      PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, slot_ids, ids_out, nq, 0, 16, s));
+      hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont, tiers,
+                         extra_waves);
     }
     timer.stop(2, 0);
   }
-  auto coop = [&](hipStream_t cs, uint32_t range) {  // G lanes per query on the listed queries
-    switch (env_int("PTK_COOP_G", 16)) {
-      case 8: return launch_knn1_coop<8, 64>(t, qs, d_out, cont, ho, redo_list, cs, range);
-      case 32: return launch_knn1_coop<32, 128>(t, qs, d_out, cont, ho, redo_list, cs, range);
-      case 64: return launch_knn1_coop<64, 192>(t, qs, d_out, cont, ho, redo_list, cs, range);
-      default: return launch_knn1_coop<16, 96>(t, qs, d_out, cont, ho, redo_list, cs, range);
-    }
-  };
   const dim3 p2_grid(blocks + 1 + extra_waves);
-  const size_t p2_lds = (size_t)S2 * 64 * 8;
-  hipStream_t side = nullptr;
-  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-  // PTK_COOP_OVERLAP=1 (A/B only): measured slower than the plain sequence on BASELINE config 2 (2.34 vs 2.16 ms
-  // per step, profiles/r02_notes.txt: the two kernels compete for the same issue slots).
-  const bool overlap = cap != 0 && env_int("PTK_COOP_OVERLAP", 0) != 0 && scratch.side_stream(&side, &ev_fork, &ev_join);
-  // PTK_P2_SPLIT=1: the heavy tiers (deep stacks: 16-slot ring) on the side stream BESIDE the light tier (1-3
-  // pending far children: 8 slots, twice the waves per CU) on the caller's stream; then the cooperative search.
-  const bool split = cap != 0 && !overlap && env_int("PTK_P2_SPLIT", 0) != 0 &&
-                     scratch.side_stream(&side, &ev_fork, &ev_join);
-  if (split) {
-    Timer timer(t, s);
-    PTK_HIP(hipEventRecord(ev_fork, s));
-    PTK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, side, t->dev, qs, e_inv,
-                       d_out, cont, ids_out, cap, ho, 1u);
-    PTK_HIP(hipEventRecord(ev_join, side));
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<8, OVF, LEAFB>), p2_grid, dim3(64), (size_t)8 * 64 * 8, s, t->dev, qs,
-                       e_inv, d_out, cont, ids_out, cap, ho, 2u);
-    PTK_HIP(hipGetLastError());
-    PTK_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    rc = coop(s, 0);
-    if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), p2_lds, s, t->dev, qs, e_inv,
-                       d_out, cont, redo_list);
-    PTK_HIP(hipGetLastError());
-    timer.stop(3, 0);
-    return PTK_OK;
-  }
-  if (!overlap) {
-    {
-      Timer timer(t, s);
-      // LDS ring of phase 2: 16 / 12 / 8 slots = 8 / 6 / 4 KB per wave = 20 / 26 / 40 waves per CU (PTK_P2_RING, A/B).
-      // With the cap no stack grows deep any more: 12 slots beat 16 on both clouds (cloud L 1.67 vs 1.74 ms of
-      // traversal kernels, cloud U 1.32 vs 1.47; 8 slots: 1.79 / 1.38 -- profiles/r02_notes.txt item 10).
-      switch (env_int("PTK_P2_RING", 12)) {
-        case 8:
-          hipLaunchKernelGGL((ptk::knn1_phase2_kernel<8, OVF, LEAFB>), p2_grid, dim3(64), (size_t)8 * 64 * 8, s, t->dev, qs,
-                             e_inv, d_out, cont, ids_out, cap, ho, 0u);
-          break;
-        case 12:
-          hipLaunchKernelGGL((ptk::knn1_phase2_kernel<12, OVF, LEAFB>), p2_grid, dim3(64), (size_t)12 * 64 * 8, s, t->dev, qs,
-                             e_inv, d_out, cont, ids_out, cap, ho, 0u);
-          break;
-        default:
-          hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
-                             d_out, cont, ids_out, cap, ho, 0u);
-      }
-      timer.stop(3, 0);
-    }
-    PTK_HIP(hipGetLastError());
-    if (cap) {  // the queries phase 2 gave up on, then whatever the cooperative search could not certify
-      Timer timer(t, s);
-      rc = coop(s, 0);
-      if (rc != PTK_OK) return rc;
-      hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), p2_lds, s, t->dev, qs, e_inv,
-                         d_out, cont, redo_list);
-      PTK_HIP(hipGetLastError());
-      timer.stop(3, 0);
-    }
-    return PTK_OK;
-  }
-  // The heavy tiers first (short: every query stops at the cap); what they hand over is searched
-  // cooperatively on the side stream WHILE the light tier runs here; the light tier's own few
-  // leftovers follow.  One timer spans the overlapped region: search_ms stays the traversal's wall time.
   {
     Timer timer(t, s);
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
-                       d_out, cont, ids_out, cap, ho, 1u);
-    hipLaunchKernelGGL(ptk::knn1_snapshot_kernel, dim3(1), dim3(1), 0, s, cont);
+    // LDS ring of phase 2.  With the cap no stack grows deep: 12 slots = 6 KB per wave = 26 waves per CU beat
+    // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt item 10); without it 16 slots
+    // (r01l_notes item 8).
+    if (cap) {
+      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<12, OVF, LEAFB>), p2_grid, dim3(64), (size_t)12 * 64 * 8, s, t->dev, qs,
+                         e_inv, d_out, cont, ids_out, cap, ho);
+    } else {
+      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
+                         e_inv, d_out, cont, ids_out, 0u, ho);
+    }
     PTK_HIP(hipGetLastError());
-    PTK_HIP(hipEventRecord(ev_fork, s));
-    PTK_HIP(hipStreamWaitEvent(side, ev_fork, 0));
-    rc = coop(side, 1);
+    timer.stop(3, 0);
+  }
+  if (cap) {  // the queries phase 2 gave up on, then whatever the cooperative search could not certify
+    Timer timer(t, s);
+    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s);
     if (rc != PTK_OK) return rc;
-    PTK_HIP(hipEventRecord(ev_join, side));
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<S2, OVF, LEAFB>), p2_grid, dim3(64), p2_lds, s, t->dev, qs, e_inv,
-                       d_out, cont, ids_out, cap, ho, 2u);
-    PTK_HIP(hipGetLastError());
-    PTK_HIP(hipStreamWaitEvent(s, ev_join, 0));
-    rc = coop(s, 2);
-    if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::knn1_redo_kernel<S2, OVF, LEAFB>), dim3(256), dim3(64), p2_lds, s, t->dev, qs, e_inv,
-                       d_out, cont, redo_list);
+    hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(256), dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
+                       e_inv, d_out, cont, redo_list);
     PTK_HIP(hipGetLastError());
     timer.stop(3, 0);
   }
@@ -1090,7 +943,7 @@ int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   const size_t base = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
   if (base > kMaxLdsBytes)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-  if (k <= 32 && !no_register_list && env_int("PTK_KNN_LIST", 0) == 0) {  // k-list in registers (K = 4 / 8 / 16 / 32 slots compiled)
+  if (k <= 32 && !no_register_list) {  // k-list in registers (K = 4 / 8 / 16 / 32 slots compiled)
     Timer timer(t, s);
     int rc = PTK_OK;
 #define PTK_LAUNCH_ND_REG(KK)                                                                                       \
@@ -1247,22 +1100,10 @@ int launch_radius_topo(const ptk_tree* t, const float* d_q, const uint32_t* perm
   return PTK_OK;
 }
 
-// k = 1.  PTK_KNN1_VARIANT selects an A/B form (tools/ab_knn1.py): 0 = the shipped two-phase
-// search, 22 = the same behind the plain phase 1 (no wave-uniform prefix, separate packing pass),
-// 4 = the single-kernel search every query of which runs to completion in its lane.  The forms
-// measured and rejected on the way (persistent / refill state machines, deeper rings on a second
-// stream, ...) are described in profiles/r01e_notes.txt and live in the git history only.
 int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                   ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
-  const int variant = env_int("PTK_KNN1_VARIANT", 0);
   int rc = PTK_OK;
-  if (variant == 4) {
-    PTK_WITH_OVF(16, (launch_knn1<16, OVF, 64, 4>(t, d_q, perm, nq, e, d_out, s)));
-  } else if (variant == 22) {
-    PTK_WITH_OVF(16, (launch_knn1_two_phase<OVF, false>(t, d_q, perm, nq, e, d_out, s, scratch)));
-  } else {
-    PTK_WITH_OVF(16, (launch_knn1_two_phase<OVF, true>(t, d_q, perm, nq, e, d_out, s, scratch)));
-  }
+  PTK_WITH_OVF(16, (launch_knn1_two_phase<OVF>(t, d_q, perm, nq, e, d_out, s, scratch)));
   return rc;
 }
 
@@ -1367,16 +1208,6 @@ void ptk_tree_destroy(ptk_tree* t) {
       if (w.done) (void)hipEventDestroy(w.done);
       if (w.base) (void)hipFree(w.base);
     }
-    auto drop_side = [](Workspace& w) {
-      if (w.side) {
-        (void)hipStreamSynchronize(w.side);
-        (void)hipStreamDestroy(w.side);
-      }
-      if (w.fork) (void)hipEventDestroy(w.fork);
-      if (w.join) (void)hipEventDestroy(w.join);
-    };
-    drop_side(t->ws);
-    for (Workspace& w : t->extra_ws) drop_side(w);
     if (t->io.d_in) (void)hipFree(t->io.d_in);
     if (t->io.d_out) (void)hipFree(t->io.d_out);
     if (t->io.stream) (void)hipStreamDestroy(t->io.stream);
@@ -1632,7 +1463,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   }
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
-  } else if (k <= 32 && !short_tree && env_int("PTK_KNN_LIST", 0) == 0) {
+  } else if (k <= 32 && !short_tree) {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_reg<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   } else {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
@@ -1683,9 +1514,7 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
   // calling thread until it is done.
   // (Measured on BASELINE config 3, knn = 16, 922 MB of rows: 1 / 2 / 3 / 4 pieces 27.3 / 24.5 / 23.6 / 25.3 ms
   // on cloud L -- every piece pays the slowest queries of its own -- and 24.6 / 21.6 / 20.7 / 20.1 on cloud U.)
-  const int forced_pieces = env_int("PTK_HOST_PIECES", 0);
-  const uint64_t pieces = forced_pieces > 0 ? (uint64_t)forced_pieces
-                                            : std::min<uint64_t>(std::max<uint64_t>(obytes / (size_t(256) << 20), 1), 3);
+  const uint64_t pieces = std::min<uint64_t>(std::max<uint64_t>(obytes / (size_t(256) << 20), 1), 3);
   const uint64_t per = (nq + pieces - 1) / pieces;
   const size_t row_out = (size_t)(k ? k : 1) * sizeof(ptk_neighbor);
   hipError_t he = hipSuccess;

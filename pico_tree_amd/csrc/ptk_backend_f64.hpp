@@ -182,7 +182,7 @@ struct Stack64Lease {
   }
 };
 
-bool want_reorder64(uint64_t nq) { return nq >= 8192 && nq < (1ull << 32) && env_int("PTK_REORDER64", 1) != 0; }
+bool want_reorder64(uint64_t nq) { return nq >= 8192 && nq < (1ull << 32); }
 size_t permutation64_bytes(uint64_t nq) { return want_reorder64(nq) ? permutation_scratch_bytes(nq) + 5 * 256 : 0; }
 
 // Device-side Morton ordering of a batch (make_permutation of the float32 side): *perm lists the
@@ -242,8 +242,8 @@ int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, u
   const size_t smem = ptk::lds64_bytes(d3 ? 0 : 2, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
   int rc = PTK_OK;
-  // k-list in registers for 1 < k <= 16 (PTK_KNN_LIST=1: the list in the output row, for A/B runs).
-  const int reg = (k > 1 && k <= 16 && env_int("PTK_KNN_LIST", 0) == 0) ? (k <= 4 ? 4 : (k <= 8 ? 8 : 16)) : 0;
+  // k-list in registers for 1 < k <= 16.
+  const int reg = (k > 1 && k <= 16) ? (k <= 4 ? 4 : (k <= 8 ? 8 : 16)) : 0;
 #define PTK_LAUNCH64(KERNEL)                                                                                          \
   do {                                                                                                                \
     rc = allow_lds(KERNEL, smem);                                                                                     \

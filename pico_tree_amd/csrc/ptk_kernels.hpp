@@ -525,7 +525,7 @@ struct Task {
 };
 // Counters in Cont::meta (zeroed by knn1_phase_meta_kernel): queries phase 2 gave up on, the next
 // entry of that list to hand to a group, queries the cooperative search could not certify.
-constexpr uint32_t kMetaHeavy = 24, kMetaHeavyA = 25, kMetaRedo = 26;  // HeavyA: the list's length after the heavy tiers
+constexpr uint32_t kMetaHeavy = 24, kMetaRedo = 26;
 constexpr uint32_t kMaxTasks = 64;               // tasks a capped traversal can hand over per query
 constexpr uint32_t kTasksFromRoot = 0xFFFFFFFFu;  // more than that (or no room): search again from the root
 constexpr uint32_t kTasksRedo = 0xFFFFFFFEu;      // non-monotone box distances met: only the reference order will do
@@ -740,33 +740,6 @@ __device__ __forceinline__ void pad_query(uint32_t dim, float& y, float& z) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ptk_smem[];
 
-// ---- k = 1 ---------------------------------------------------------------------------
-template <int S, int OVF, int BLOCK, int LEAFB>
-__global__ __launch_bounds__(BLOCK) void knn1_kernel(
-    DevTree t, const float* __restrict__ queries, uint32_t dim,
-    const uint32_t* __restrict__ perm, uint64_t nq, float e_inv, Neighbor* __restrict__ out) {
-  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
-  const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
-  if (i >= nq) return;
-  const uint64_t qi = perm ? perm[i] : i;
-  float qx, qy, qz;
-  load_query(queries, dim, qi, qx, qy, qz);
-
-  Record spill[OVF > 0 ? OVF : 1];
-  Stack<S, OVF, BLOCK> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
-  NnPolicy pol;
-  pol.best_d = 3.402823466e+38f;
-  pol.best_i = 0;
-  pol.e_inv = e_inv;
-  traverse<LEAFB>(t, qx, qy, qz, pol, st);
-
-  Neighbor nb;
-  nb.index = pol.best_i;
-  nb.distance = pol.best_d;
-  out[qi] = nb;
-}
-
 // ---- general k -------------------------------------------------------------------------
 // LIST_LDS: the k-list lives in LDS behind the stack ([slot][lane]) and is copied
 // to the output row at the end; otherwise the output row itself is the list.
@@ -939,10 +912,11 @@ __global__ __launch_bounds__(256) void radius_scatter_kernel(
 //            pop-time test of the reference can only reject more) are written out as a
 //            CONTINUATION: at most kContSlots records, typically 1-3, none for ~20 % of the
 //            queries, whose answer is then already final.
-//   sort     continuations are ordered by a 16-bit key (make_cont_key): the classes that hold
-//            every expensive query first, ranked by how far their home-leaf best is (which
-//            predicts the cost), then the light classes by record count in Morton order; the
-//            heaviest start first, in three tiers (knn1_phase2_kernel).
+//   sort     continuations are ordered by class (= record count), each class keeping its Morton order: a
+//            counting sort over the three class bits for exact searches (phase 2 is capped, see below); for
+//            approximate ones, which phase 2 runs to their end, by the full 16-bit key (make_cont_key) that
+//            also ranks the classes holding every expensive query by how far their home-leaf best is (which
+//            predicts the cost).  The heaviest start first, in three tiers (knn1_phase2_kernel).
 //   phase 2  the records are pushed back and the reference traversal resumes exactly where
 //            it left off (state: box distance 0, all offsets 0, best = home-leaf best).
 //
@@ -959,12 +933,8 @@ constexpr uint32_t kHeavyClass = 4;     // classes >= this are dealt across wave
 //   class 0 (final after phase 1): 7 << 13, sorts behind everything.
 typedef uint16_t ContKey;
 constexpr uint32_t kRankedClass = 5;
-// merge_light: classes 1 .. 3 share one key, so the light tier of phase 2 is ONE sweep of the
-// batch in Morton order instead of three (one per class): every region of the tree then passes
-// through the XCDs' L2 once (profiles/r02_notes.txt, item 8).
-__device__ __forceinline__ ContKey make_cont_key(uint32_t cls, float best_d, bool merge_light = false) {
+__device__ __forceinline__ ContKey make_cont_key(uint32_t cls, float best_d) {
   if (cls >= kRankedClass) return (ContKey)(0x1FFFu - ((__float_as_uint(best_d) >> 18) & 0x1FFFu));
-  if (merge_light && cls >= 1u && cls < kHeavyClass) return (ContKey)(4u << 13);
   return (ContKey)((7u - cls) << 13);
 }
 __device__ __forceinline__ bool cont_key_is_final(ContKey k) { return (k >> 13) == 7u; }
@@ -982,175 +952,33 @@ struct Cont {
   __device__ __forceinline__ Record& record(uint32_t slot, uint32_t s) const { return rec[(uint64_t)s * nq + slot]; }
 };
 
-// Phase 1.  DOUBLE = false: one descent, every far child kept in the LDS ring, filtered
-// against the home-leaf best afterwards.  DOUBLE = true: no LDS at all -- a first descent
-// finds the home-leaf best, a second (cache-hot) descent keeps only the far children that
-// pass, in registers.
-template <int S, int OVF, int LEAFB, bool DOUBLE>
-__global__ __launch_bounds__(64) void knn1_phase1_kernel(
-    DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
-    Cont cont) {
-  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  if (i >= nq) return;
-  const uint4* __restrict__ nodes = t.nodes;
-  const float4* __restrict__ pts = t.pts;
-  const float4 qrec = qs[i];
-  const float qx = qrec.x, qy = qrec.y, qz = qrec.z;
-  const uint32_t qi = __float_as_uint(qrec.w);
-
-  NnPolicy pol;
-  pol.e_inv = e_inv;
-  pol.out = out;
-  pol.begin_query(qi);
-
-  Record spill[(!DOUBLE && OVF > 0) ? OVF : 1];
-  Stack<S, DOUBLE ? 0 : OVF, 64> st;
-  st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
-
-  // First descent: the state is trivial (box distance 0, offsets 0), so a far child's box
-  // distance is just its new offset: (0 - 0) + new_off, exactly as the reference computes it.
-  uint32_t ref = t.root_ref;
-  while (!(ref & kLeafBit)) {
-    const uint32_t idx = ref & kBranchIdxMask;
-    const uint32_t axis = (ref >> 29) & 3u;
-    const uint4 nd = nodes[idx];
-    const float left_max = __uint_as_float(nd.x);
-    const float right_min = __uint_as_float(nd.y);
-    const float v = sel3(axis, qx, qy, qz);
-    const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
-    if (!DOUBLE) {
-      const float dv = f_sub(go_left ? right_min : left_max, v);
-      const float far_nbd = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
-      st.push(idx | (axis << 28) | (go_left ? kRecSide : 0u), far_nbd);
-    }
-    ref = go_left ? nd.z : nd.w;
-  }
-  {
-    const uint32_t lv = ref & 0x7FFFFFFFu;
-    const uint32_t begin = lv >> t.cbits;
-    const uint32_t count = lv & t.cmask;
-    for (uint32_t j = 0; j < count; j += LEAFB) {
-      float4 p[LEAFB];
-#pragma unroll
-      for (int u = 0; u < LEAFB; ++u) p[u] = pts[begin + j + u];
-#pragma unroll
-      for (int u = 0; u < LEAFB; ++u) {
-        if (j + u < count) {
-          const float dx = f_sub(qx, p[u].x);
-          const float dy = f_sub(qy, p[u].y);
-          const float dz = f_sub(qz, p[u].z);
-          pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
-        }
-      }
-    }
-  }
-  // Collect the far children that can still matter, shallowest first.
-  Record keep[kContSlots];
-  uint32_t c = 0;
-  if (DOUBLE) {
-    uint32_t r2 = t.root_ref;
-    while (!(r2 & kLeafBit)) {
-      const uint32_t idx = r2 & kBranchIdxMask;
-      const uint32_t axis = (r2 >> 29) & 3u;
-      const uint4 nd = nodes[idx];
-      const float left_max = __uint_as_float(nd.x);
-      const float right_min = __uint_as_float(nd.y);
-      const float v = sel3(axis, qx, qy, qz);
-      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
-      const float dv = f_sub(go_left ? right_min : left_max, v);
-      const float far_nbd = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
-      if (pol.max() >= far_nbd) {
-        Record r;
-        r.x = idx | (axis << 28) | (go_left ? kRecSide : 0u);
-        r.y = __float_as_uint(far_nbd);
-#pragma unroll
-        for (int s = 0; s < kContSlots; ++s) {
-          if (c == (uint32_t)s) keep[s] = r;
-        }
-        ++c;
-      }
-      r2 = go_left ? nd.z : nd.w;
-    }
-  } else {
-    // Unwind the ring deepest-first; slot (n - 1 - c) keeps the shallowest-first order.
-    uint32_t passed = 0;
-    const int total = st.top;
-    for (int n = 0; n < total; ++n) {
-      const Record r = st.pop();
-      if (pol.max() >= __uint_as_float(r.y)) {
-#pragma unroll
-        for (int s = 0; s < kContSlots; ++s) {
-          if (passed == (uint32_t)s) keep[s] = r;  // deepest first for now
-        }
-        ++passed;
-      }
-    }
-    c = passed;
-  }
-  const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
-  const uint32_t e = (uint32_t)i;
-  cont.key[e] = make_cont_key(cls, pol.best_d);
-  cont.ids[e] = e;
-  if (cls == 0) {
-    pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
-  } else {
-    cont.best[e] = make_uint4((uint32_t)pol.best_i, __float_as_uint(pol.best_d), cls, 0u);
-  }
-  if (cls != 0 && cls != kContOverflow) {
-#pragma unroll
-    for (int s = 0; s < kContSlots; ++s) {
-      if ((uint32_t)s < c) {
-        // DOUBLE collected shallowest-first already; the ring unwind collected deepest-first.
-        const int src = DOUBLE ? s : (int)c - 1 - s;
-        Record r = keep[0];
-#pragma unroll
-        for (int u = 1; u < kContSlots; ++u) {
-          if (src == u) r = keep[u];
-        }
-        cont.record(e, (uint32_t)s) = r;
-      }
-    }
-  }
-}
-
-// Phase 1 with a wave-uniform prefix (the shipped form).  The batch is spatially sorted, so the 64
+// Phase 1, with a wave-uniform prefix.  The batch is spatially sorted, so the 64
 // queries of a wavefront walk the SAME branches for most of the way down (measured: they part
 // ways 4-6 levels above the leaves).  profiles/r01d: phase 1 is bound by the rate at which the
 // vector-memory pipe takes divergent 16-byte loads (59 per wave, ~48 cycles each per CU), so while
 // all lanes agree the node is fetched ONCE, through the scalar cache (s_load_dwordx4 on a
 // readfirstlane'd index), and only the per-lane arithmetic stays on the vector unit.  A ballot
-// after each step tells whether the lanes still agree.  Same two descents as the DOUBLE form
-// above (first: home leaf and its best; second: the far children that pass), same arithmetic,
-// same records -- only where the node bytes come from differs.
+// after each step tells whether the lanes still agree.  Two descents, no LDS: the first finds the home
+// leaf and its best, the second (cache-hot) keeps the far children that pass, in registers.
 __device__ __forceinline__ uint32_t uniform_value(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
 
-// PACK: the launch-order query records are made here (gather through `perm` + one coalesced
-// 16-byte store for phase 2) instead of by a separate pack_queries_kernel pass.
-template <int LEAFB, bool PACK = false>
+// The launch-order query records {x, y, z, bits(row)} of phase 2 are made here as well (gather through `perm`,
+// or the identity if it is null, + one coalesced 16-byte store) instead of by a packing pass of their own.
+template <int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
-    DevTree t, const float4* __restrict__ qs, uint64_t nq, float e_inv, Neighbor* __restrict__ out,
-    Cont cont, const float* __restrict__ queries = nullptr, uint32_t dim = 3,
-    const uint32_t* __restrict__ perm = nullptr, float4* __restrict__ qs_out = nullptr, uint32_t merge_light = 0) {
+    DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
+    float e_inv, Neighbor* __restrict__ out, Cont cont, float4* __restrict__ qs_out) {
   const uint64_t i0 = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
   const uint4* __restrict__ nodes = t.nodes;
   const float4* __restrict__ pts = t.pts;
   float qx, qy, qz;
-  uint32_t qi;
-  if constexpr (PACK) {
-    qi = perm ? perm[i] : (uint32_t)i;
-    load_query(queries, dim, qi, qx, qy, qz);
-    if (valid) qs_out[i] = make_float4(qx, qy, qz, __uint_as_float(qi));
-  } else {
-    const float4 qrec = qs[i];
-    qx = qrec.x;
-    qy = qrec.y;
-    qz = qrec.z;
-    qi = __float_as_uint(qrec.w);
-  }
+  const uint32_t qi = perm ? perm[i] : (uint32_t)i;
+  load_query(queries, dim, qi, qx, qy, qz);
+  if (valid) qs_out[i] = make_float4(qx, qy, qz, __uint_as_float(qi));
 
   NnPolicy pol;
   pol.e_inv = e_inv;
@@ -1255,7 +1083,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   if (!valid) return;
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
   const uint32_t e = (uint32_t)i;
-  cont.key[e] = make_cont_key(cls, pol.best_d, merge_light != 0u);
+  cont.key[e] = make_cont_key(cls, pol.best_d);
   if (cont.ids != nullptr) cont.ids[e] = e;  // (the counting sort numbers the slots itself)
   if (cls == 0) {
     pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
@@ -1272,13 +1100,13 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 
 // One thread, after the sort: where the tiers of the sorted list end.
 //   meta[0] n2      continuations (everything before class 0)
-//   meta[1] heavy   end of the dealt tier (classes >= heavy_class)
-//   meta[2] waves of the dealt tier     meta[6] dealt (1) or consecutive (0) middle tier
+//   meta[1] heavy   end of the dealt tier (classes >= kHeavyClass)
+//   meta[2] waves of the dealt tier
 //   meta[4] end of the narrow tiers     meta[5] their waves in total
 //   meta[8 + 4 i ..]  narrow tier i: {first entry, end entry, lanes per wave, first wave}
 // The narrow tiers cut the head of the ranked classes at cumulative per-mille marks.
 //   meta[24] queries phase 2 gave up on (cap reached; listed for knn1_coop_kernel)
-//   meta[25] next entry of that list to hand out     meta[26] queries the cooperative search could not certify
+//   meta[26] queries the cooperative search could not certify
 constexpr uint32_t kMaxTiers = 4;
 constexpr uint32_t kMetaWords = 32;  // size of Cont::meta (8 fixed words + 4 per narrow tier + 3 counters, rounded up)
 struct TierSpec {
@@ -1288,7 +1116,7 @@ struct TierSpec {
 
 // The tier table of phase 2 from the three boundaries of the class-sorted list.
 __device__ inline void write_phase_meta(const Cont& cont, uint32_t n2, uint32_t ranked, uint32_t heavy,
-                                        const TierSpec& tiers, uint32_t max_narrow_waves, uint32_t deal) {
+                                        const TierSpec& tiers, uint32_t max_narrow_waves) {
   uint32_t begin = 0, wave = 0;
   for (uint32_t i = 0; i < kMaxTiers; ++i) {
     uint32_t end = (uint32_t)(((uint64_t)ranked * tiers.permille[i]) / 1000u);
@@ -1312,16 +1140,14 @@ __device__ inline void write_phase_meta(const Cont& cont, uint32_t n2, uint32_t 
   cont.meta[2] = (heavy - begin + 63u) / 64u;
   cont.meta[4] = begin;
   cont.meta[5] = wave;
-  cont.meta[6] = deal;
   cont.meta[kMetaHeavy] = 0;
-  cont.meta[kMetaHeavyA] = 0;
   cont.meta[kMetaRedo] = 0;
 }
 
-// Behind a full 16-bit radix sort of the keys (PTK_CONT_BITS=16): the boundaries by binary search.
+// Behind a full 16-bit radix sort of the keys (searches without the cap): the boundaries by binary search.
+static_assert(kHeavyClass < kRankedClass && kHeavyClass >= 1u, "the dealt tier begins inside the unranked classes");
 __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, uint32_t nq, Cont cont,
-                                       uint32_t heavy_class, TierSpec tiers, uint32_t max_narrow_waves,
-                                       uint32_t deal) {
+                                       TierSpec tiers, uint32_t max_narrow_waves) {
   auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
     uint32_t lo = 0, hi = nq;
     while (lo < hi) {
@@ -1332,9 +1158,8 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
   };
   const uint32_t n2 = first_at_least(7u << 13);
   const uint32_t ranked = first_at_least(1u << 13);  // classes >= kRankedClass
-  const uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
-  const uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : first_at_least((7u - hc + 1u) << 13));
-  write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves, deal);
+  const uint32_t heavy = first_at_least((7u - kHeavyClass + 1u) << 13);
+  write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves);
 }
 
 // ---- the class order as a counting sort (the shipped form) -----------------------------------------
@@ -1410,14 +1235,13 @@ __global__ __launch_bounds__(64) void class_scatter_kernel(const ContKey* __rest
 }
 
 // The tier table from the scanned counters: bucket b starts at offsets[b * chunks].
-__global__ void class_meta_kernel(const uint32_t* __restrict__ offsets, uint32_t chunks, Cont cont, uint32_t heavy_class,
-                                  TierSpec tiers, uint32_t max_narrow_waves, uint32_t deal) {
+__global__ void class_meta_kernel(const uint32_t* __restrict__ offsets, uint32_t chunks, Cont cont, TierSpec tiers,
+                                  uint32_t max_narrow_waves) {
   auto start = [&](uint32_t b) { return offsets[b * chunks]; };  // b = 1 .. 7
   const uint32_t n2 = start(7);       // everything before class 0
   const uint32_t ranked = start(1);   // classes >= kRankedClass
-  const uint32_t hc = heavy_class > 7u ? 8u : heavy_class;
-  const uint32_t heavy = hc > 7u ? 0u : (hc >= kRankedClass ? ranked : start(7u - hc + 1u));
-  write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves, deal);
+  const uint32_t heavy = start(7u - kHeavyClass + 1u);
+  write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves);
 }
 
 // Phase 2: one continuation per lane, taken from the class-sorted entry list.
@@ -1428,16 +1252,13 @@ __global__ void class_meta_kernel(const uint32_t* __restrict__ offsets, uint32_t
 template <int S, int OVF, int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
-    const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, Handover ho = Handover{}, uint32_t part = 0) {
+    const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, Handover ho = Handover{}) {
   const uint32_t n2 = cont.meta[0];
   const uint32_t heavy = cont.meta[1];
   const uint32_t heavy_waves = cont.meta[2];
   const uint32_t top = cont.meta[4];
   const uint32_t top_waves = cont.meta[5];
-  // part 1: the narrow and dealt tiers only; part 2: the light tier only (two launches, so that the
-  // cooperative search of what the heavy tiers hand over can run beside the light tier).
-  if (part == 1 && blockIdx.x >= top_waves + heavy_waves) return;
-  const uint32_t wave = part == 2 ? blockIdx.x + top_waves + heavy_waves : blockIdx.x;
+  const uint32_t wave = blockIdx.x;
   const uint32_t lane = threadIdx.x;
   // Three tiers of the sorted list, most expensive first (blocks are dispatched in order):
   //   narrow the head of the ranked classes in up to kMaxTiers tiers of few lanes per wavefront:
@@ -1459,7 +1280,7 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     s = cont.meta[8 + 4 * tier + 0] + (wave - cont.meta[8 + 4 * tier + 3]) * hl + lane;
     valid = lane < hl && s < cont.meta[8 + 4 * tier + 1];
   } else if (wave < top_waves + heavy_waves) {
-    s = cont.meta[6] ? top + lane * heavy_waves + (wave - top_waves) : top + (wave - top_waves) * 64u + lane;
+    s = top + lane * heavy_waves + (wave - top_waves);
     valid = s < heavy;
   } else {
     s = heavy + (wave - top_waves - heavy_waves) * 64u + lane;
@@ -1570,14 +1391,11 @@ __device__ inline bool dfs_before(const DevTree& t, const uint2* __restrict__ ra
 
 constexpr uint32_t kCoopTieBudget = 6;  // exact ties a lane resolves per query before it asks for a redo
 
-// After the heavy tiers of phase 2: how long the list is now (the light tier appends behind).
-__global__ void knn1_snapshot_kernel(Cont cont) { cont.meta[kMetaHeavyA] = cont.meta[kMetaHeavy]; }
-
 // range: 0 = the whole list, 1 = what the heavy tiers listed, 2 = what the light tier added.
 template <int G, int POOL>
 __global__ __launch_bounds__(64) void knn1_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
-    Handover ho, uint32_t* __restrict__ redo_list, uint32_t range = 0) {
+    Handover ho, uint32_t* __restrict__ redo_list) {
   static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per query");
   static_assert(POOL >= (int)kMaxTasks, "the pool must hold a handed-over stack");
   constexpr int NG = 64 / G;
@@ -1590,8 +1408,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   const uint64_t below = gmask & ((1ull << lane) - 1ull);  // lanes of this group before this one
   LdsU32* pool = (LdsU32*)ptk_smem + g * (6 * POOL);       // [field][slot] of this group
   LdsU32* gbest = (LdsU32*)ptk_smem + NG * (6 * POOL) + g;  // bits of the group's best distance
-  const uint32_t n_heavy = cont.meta[range == 1 ? kMetaHeavyA : kMetaHeavy];
-  const uint32_t first = range == 2 ? cont.meta[kMetaHeavyA] : 0u;
+  const uint32_t n_heavy = cont.meta[kMetaHeavy];
 
   bool have = false, exhausted = false, busy = false, failed = false;
   uint32_t count = 0;  // subtrees in the pool (the same value in every lane of the group)
@@ -1606,7 +1423,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   uint32_t tie_budget = 0;
   float start_d = 0.0f;  // the best handed over (phase 2's own, already the reference's)
   uint32_t start_i = 0;
-  uint32_t next_idx = first + blockIdx.x * (uint32_t)NG + g;  // this group's next entry of the list
+  uint32_t next_idx = blockIdx.x * (uint32_t)NG + g;  // this group's next entry of the list
 
   for (;;) {
     // Groups without a query take the next one.
@@ -1878,19 +1695,6 @@ __global__ __launch_bounds__(64) void knn1_redo_kernel(
     traverse<LEAFB, false>(t, qrec.x, qrec.y, qrec.z, pol, st);
     pol.end_query(qi);
   }
-}
-
-// Packs the batch in launch order: qs[i] = {query perm[i], bits(perm[i])}
-// (perm == nullptr: identity).
-__global__ __launch_bounds__(kBlock) void pack_queries_kernel(
-    const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
-    float4* __restrict__ qs) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nq) return;
-  const uint32_t qi = perm ? perm[i] : (uint32_t)i;
-  float x, y, z;
-  load_query(queries, dim, qi, x, y, z);
-  qs[i] = make_float4(x, y, z, __uint_as_float(qi));
 }
 
 // ---- box search ---------------------------------------------------------------------------

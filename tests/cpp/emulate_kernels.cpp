@@ -168,9 +168,14 @@ void for_each_wave(uint32_t blocks, F&& f) {
   g_fibers = nullptr;
 }
 
+// The launch-order query records {x, y, z, bits(row)} phase 1 has to produce (host restatement).
 std::vector<float4> pack(const float* q, uint32_t dim, const uint32_t* perm, uint64_t nq) {
   std::vector<float4> qs(nq ? nq : 1);
-  for_each_lane(nq, [&] { ptk::pack_queries_kernel(q, dim, perm, nq, qs.data()); });
+  for (uint64_t i = 0; i < nq; ++i) {
+    const uint32_t qi = perm ? perm[i] : (uint32_t)i;
+    const float* p = q + (uint64_t)qi * dim;
+    qs[i] = make_float4(p[0], dim > 1 ? p[1] : 0.0f, dim > 2 ? p[2] : 0.0f, __uint_as_float(qi));
+  }
   return qs;
 }
 
@@ -340,14 +345,7 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
       for_each_lane(nq, [&] { ptk::knn_nd_kernel<16, 2048, false>(t->dev_nd, q, perm, nq, k, e_inv, o); }, 64);
     return 0;
   }
-  if (k == 1) {
-    if (small_stack)
-      for_each_lane(nq, [&] { ptk::knn1_kernel<4, 2048, 64, 1>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 64);
-    else if (need <= 16 + 64)
-      for_each_lane(nq, [&] { ptk::knn1_kernel<16, 64, 64, 4>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 64);
-    else
-      for_each_lane(nq, [&] { ptk::knn1_kernel<32, 2048, 256, 8>(t->dev, q, t->dim, perm, nq, e_inv, o); }, 256);
-  } else if (list_in_lds == 2) {  // k-list in registers (k <= 32)
+  if (k == 1 || list_in_lds == 2) {  // k-list in registers (k <= 32; what the backend launches for k = 1 too)
     if (k > 32) return -2;
     if (small_stack) {
       if (k <= 4) for_each_lane(nq, [&] { ptk::knn_reg_kernel<4, 4, 2048, 64, 1>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 64);
@@ -474,19 +472,15 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
   return (int64_t)n_over;
 }
 
-// The two-phase k = 1 search: phase 1, sort by continuation key (stable sort standing in for the
-// device radix pass), phase 2.  variant:
-//   0  LDS-ring phase 1            1  double-descent phase 1
-//   2  tiny rings everywhere (spill paths)
-//   3  wave-uniform-prefix phase 1 that also packs the records (the shipped form; ballots: lanes
-//      run as fibers), default phase 2
-//   4  as 3 with one-point leaf batches and three narrow tiers (1, 4 and 16 lanes per wave)
+// The two-phase k = 1 search: phase 1 (ballots: lanes run as fibers), sort by continuation key (stable
+// sort standing in for the device radix pass), phase 2.  variant:
+//   3  the form of an approximate search: no cap, full key order, one narrow tier
+//   4  as 3 with one-point leaf batches, 4-slot rings (spill paths) and three narrow tiers (1, 4 and 16
+//      lanes per wave)
 //   5  as 3, phase 2 capped at 2 far children per query, the rest through the cooperative search
 //      (16 lanes per query) and the redo pass; room for the stacks of a part of the queries only
 //   6  cap 1, 64 lanes per query, no room for stacks: every search starts again from the root
 //   7  cap 1, 8 lanes per query            8  cap 3, 32 lanes per query
-//   9  as 5 in the two-launch form: heavy tiers, list snapshot, cooperative search of that part,
-//      light tier, cooperative search of what it added
 // emu_last_coop(): {queries phase 2 gave up on, queries the cooperative search could not certify}.
 static uint32_t g_last_heavy = 0, g_last_redo = 0;
 void emu_last_coop(uint32_t* heavy, uint32_t* redo) {
@@ -506,23 +500,18 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
   std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(ptk::kMetaWords, 0);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
-  if (variant >= 3) {
-    std::vector<float4> packed(nq);  // written by the kernel itself (PACK)
+  if (variant < 3 || variant > 8) return -3;
+  {
+    std::vector<float4> packed(nq);  // written by the kernel itself
     for_each_wave((uint32_t)((nq + 63) / 64), [&] {
       if (variant != 4)
-        ptk::knn1_phase1u_kernel<4, true>(t->dev, nullptr, nq, e_inv, o, cont, q, t->dim, perm, packed.data());
+        ptk::knn1_phase1u_kernel<4>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
       else
-        ptk::knn1_phase1u_kernel<1, true>(t->dev, nullptr, nq, e_inv, o, cont, q, t->dim, perm, packed.data());
+        ptk::knn1_phase1u_kernel<1>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
     });
     for (uint64_t i = 0; i < nq; ++i) {
-      if (std::memcmp(&packed[i], &qs[i], sizeof(float4)) != 0) return -4;  // same records as pack_queries_kernel
+      if (std::memcmp(&packed[i], &qs[i], sizeof(float4)) != 0) return -4;
     }
-  } else if (variant == 0) {
-    for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
-  } else if (variant == 1) {
-    for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
-  } else {
-    for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<4, 2048, 1, false>(t->dev, qs.data(), nq, e_inv, o, cont); }, 64);
   }
   // stable sort by key (what the device's radix pass does)
   std::vector<uint32_t> sorted(nq);
@@ -542,7 +531,7 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     tiers.permille[0] = 200; tiers.lanes[0] = 1;
     tiers.permille[1] = 500; tiers.lanes[1] = 4;
     tiers.permille[2] = 800; tiers.lanes[2] = 16;
-  } else {  // the shipped default
+  } else if (variant == 3) {  // what the backend uses without the cap
     tiers.permille[0] = 60; tiers.lanes[0] = 4;
   }
   if (variant >= 5) {  // the shipped class order: counting sort over the three class bits + tier table from the counters
@@ -573,47 +562,38 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     gridDim.x = 1;
     blockIdx.x = 0;
     threadIdx.x = 0;
-    ptk::class_meta_kernel(offsets.data(), chunks, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
+    ptk::class_meta_kernel(offsets.data(), chunks, cont, tiers, top_extra);
   } else {
     gridDim.x = 1;
     blockIdx.x = 0;
     threadIdx.x = 0;
-    ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, ptk::kHeavyClass, tiers, top_extra, 1u);
+    ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, tiers, top_extra);
   }
   const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
-  const uint32_t cap = (variant == 5 || variant == 9) ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
+  const uint32_t cap = variant == 5 ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
   std::vector<uint32_t> heavy_list(nq, 0xEEEEEEEEu), redo_list(nq, 0xEEEEEEEEu), ntasks(nq, 0xEEEEEEEEu);
   // Room for the stacks of two thirds of the queries handed over at most: the rest starts from the root.
   const uint32_t max_heavy = variant == 6 ? 0u : (uint32_t)(nq / 6 + 1);
   std::vector<ptk::Task> tasks((size_t)max_heavy * ptk::kMaxTasks + 1);
   ptk::Handover ho{meta.data(), heavy_list.data(), ntasks.data(), tasks.data(), max_heavy, 0u};
   const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
-  auto phase2 = [&](uint32_t part) {
-    gridDim.x = blocks;
-    blockDim.x = 64;
-    for (uint32_t b = 0; b < blocks; ++b) {
-      blockIdx.x = b;
-      for (uint32_t l = 0; l < 64; ++l) {
-        threadIdx.x = l;
-        if (variant == 2 || variant == 4)
-          ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
-        else
-          ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho, part);
-      }
+  gridDim.x = blocks;
+  blockDim.x = 64;
+  for (uint32_t b = 0; b < blocks; ++b) {
+    blockIdx.x = b;
+    for (uint32_t l = 0; l < 64; ++l) {
+      threadIdx.x = l;
+      if (variant == 4)
+        ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+      else if (variant == 3)
+        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+      else
+        ptk::knn1_phase2_kernel<12, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho);
     }
-  };
-  if (variant == 9) {
-    phase2(1);
-    ptk::knn1_snapshot_kernel(cont);
-    for_each_wave(3, [&] { ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), 1u); });
-    phase2(2);
-    for_each_wave(2, [&] { ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), 2u); });
-  } else {
-    phase2(0);
   }
   g_last_heavy = meta[ptk::kMetaHeavy];
   g_last_redo = 0;
-  if (cap && variant != 9) {
+  if (cap) {
     for_each_wave(3, [&] {
       if (variant == 5) ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
       else if (variant == 6) ptk::knn1_coop_kernel<64, 192>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
@@ -689,14 +669,16 @@ int emu_box(void* h, const float* mins, const float* maxs, uint64_t nb, const fl
 int emu_phase1(void* h, const float* q, uint64_t nq, uint8_t* cls_out, float* best_out) {
   auto* t = static_cast<Emu*>(h);
   if (nq == 0) return 0;
-  std::vector<float4> qs = pack(q, t->dim, nullptr, nq);
+  std::vector<float4> qs(nq);
   std::vector<ptk::Record> crec(nq * ptk::kContSlots + 8);
   std::vector<uint4> cbest(nq);
   std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
   std::vector<uint32_t> cids(nq), meta(ptk::kMetaWords, 0);
   std::vector<ptk::Neighbor> o(nq);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
-  for_each_lane(nq, [&] { ptk::knn1_phase1_kernel<32, 2048, 4, true>(t->dev, qs.data(), nq, 1.0f, o.data(), cont); }, 64);
+  for_each_wave((uint32_t)((nq + 63) / 64), [&] {
+    ptk::knn1_phase1u_kernel<4>(t->dev, q, t->dim, nullptr, nq, 1.0f, o.data(), cont, qs.data());
+  });
   for (uint64_t i = 0; i < nq; ++i) {
     const bool final_ = (ckey[i] >> 13) == 7;
     cls_out[i] = final_ ? 0 : (uint8_t)cbest[i].z;

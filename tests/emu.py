@@ -122,7 +122,7 @@ class EmulatedTree:
                                 off.ctypes.data, out.ctypes.data) == 0
         return off, out[:int(off[-1])]
 
-    def two_phase_knn1(self, q, e=None, perm=None, variant=0):
+    def two_phase_knn1(self, q, e=None, perm=None, variant=5):
         """Returns (result (nq,1), number of continuations handed to phase 2)."""
         q = np.ascontiguousarray(q, dtype=np.float32)
         out = np.zeros((len(q), 1), dtype=pt.NEIGHBOR)

@@ -93,7 +93,7 @@ t = emu.EmulatedTree(pts, 10)
 ref = oracle.Oracle(pts, 10, "port")
 perm, _ = t.morton_permutation(q)
 want = ref.search_knn(q, 1)
-for variant in (3, 5, 9):
+for variant in (3, 4, 5):
     got, _ = t.two_phase_knn1(q, perm=perm, variant=variant)
     assert got.tobytes() == want.tobytes(), variant
 assert t.search_knn(q, 16, perm=perm, list_in_lds=2).tobytes() == ref.search_knn(q, 16).tobytes()
