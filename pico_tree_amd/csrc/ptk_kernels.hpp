@@ -1080,6 +1080,57 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
       r2 = go_left ? nd.z : nd.w;
     }
   }
+  // ---- the reference's next steps while they are leaves ----
+  // The reference now pops the deepest record, tests it against the best so far and enters the far child.
+  // While that child is a LEAF (the sibling of the home leaf, more often than not) the step needs no stack:
+  // it is taken here, in the reference's order, and the better best it leaves behind drops records that the
+  // reference would skip when it pops them (the best only shrinks) -- for many queries all of them.
+  if (c <= (uint32_t)kContSlots) {
+    while (c > 0u) {
+      Record r = keep[0];
+#pragma unroll
+      for (int s = 1; s < kContSlots; ++s) {
+        if (c - 1u == (uint32_t)s) r = keep[s];
+      }
+      if (pol.max() >= __uint_as_float(r.y)) {
+        const uint4 nd = nodes[r.x & kRecIdxMask];
+        const uint32_t far = (r.x & kRecSide) ? nd.w : nd.z;
+        if (!(far & kLeafBit)) break;
+        const uint32_t lv = far & 0x7FFFFFFFu;
+        const uint32_t begin = lv >> t.cbits;
+        const uint32_t count = lv & t.cmask;
+        for (uint32_t j = 0; j < count; j += LEAFB) {
+          float4 p[LEAFB];
+#pragma unroll
+          for (int u = 0; u < LEAFB; ++u) p[u] = pts[begin + j + u];
+#pragma unroll
+          for (int u = 0; u < LEAFB; ++u) {
+            if (j + u < count) {
+              const float dx = f_sub(qx, p[u].x);
+              const float dy = f_sub(qy, p[u].y);
+              const float dz = f_sub(qz, p[u].z);
+              pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
+            }
+          }
+        }
+      }
+      --c;
+    }
+    // What is left, still shallowest first, without the records the best has overtaken.
+    uint32_t kept = 0;
+#pragma unroll
+    for (int s = 0; s < kContSlots; ++s) {
+      const Record r = keep[s];
+      if ((uint32_t)s < c && pol.max() >= __uint_as_float(r.y)) {
+#pragma unroll
+        for (int d = 0; d <= s; ++d) {
+          if (kept == (uint32_t)d) keep[d] = r;
+        }
+        ++kept;
+      }
+    }
+    c = kept;
+  }
   if (!valid) return;
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
   const uint32_t e = (uint32_t)i;
