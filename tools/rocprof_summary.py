@@ -103,17 +103,23 @@ def traffic(paths) -> None:
 
 
 def timeline(path: str) -> None:
-    """Kernel sequence of ONE bench step (between the last two launches of the top kernel)."""
+    """Kernel sequence of ONE step of the headline search: between the second and third launch of phase 2 of the
+    k = 1 search (bench.py runs the headline form first); without such launches, between the last two launches of
+    the kernel with the largest total."""
     db = sqlite3.connect(path)
     rows = db.cursor().execute("select name, start, end from kernels order by start").fetchall()
     top = db.cursor().execute(
         "select name from kernels group by name order by sum(end-start) desc limit 1").fetchone()[0]
-    idx = [i for i, r in enumerate(rows) if r[0] == top]
-    if len(idx) < 2:
-        return
-    i0, i1 = idx[-2], idx[-1]
+    p2 = [i for i, r in enumerate(rows) if "knn1_phase2_kernel" in r[0]]
+    if len(p2) >= 3:
+        i0, i1 = p2[1], p2[2]
+    else:
+        idx = [i for i, r in enumerate(rows) if r[0] == top]
+        if len(idx) < 2:
+            return
+        i0, i1 = idx[-2], idx[-1]
     t0 = rows[i0][2]
-    print(f"# one step of {path}: t = 0 at the end of the previous step's dominant kernel")
+    print(f"# one step of {path}: t = 0 at the end of the previous step's phase 2 (or dominant kernel)")
     print(f"{'start_us':>10s} {'dur_us':>10s}  kernel")
     for r in rows[i0 + 1:i1 + 1]:
         print(f"{(r[1] - t0) / 1e3:10.1f} {(r[2] - r[1]) / 1e3:10.1f}  {short(r[0])}")
