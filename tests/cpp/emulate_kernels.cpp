@@ -714,6 +714,11 @@ int emu_forest_knn(const float* points, uint64_t n, uint32_t dim, uint64_t max_l
   return 0;
 }
 
+// The block -> tile mapping of the traversal kernels (ptk::xcd_runs) for every block of a grid of nb blocks.
+void emu_xcd_runs(uint32_t nb, uint32_t* tiles) {
+  for (uint32_t b = 0; b < nb; ++b) tiles[b] = ptk::xcd_runs(b, nb);
+}
+
 // Morton keys + identity ids exactly as the device computes them.
 void emu_morton(const float* q, uint32_t dim, uint64_t nq, const float* lo, const float* inv, const uint32_t* bits,
                 uint32_t* keys, uint32_t* ids) {

@@ -99,6 +99,25 @@ def test_emulated_any_dimension_kernels_equal_oracle(dim, n, nq, radius):
     assert off[-1] > 0 and np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
 
 
+def test_block_mapping_is_a_permutation_in_runs():
+    """xcd_runs(): every tile exactly once whatever the grid size, and in a complete group of 8 x 16 blocks the
+    blocks that land on one XCD (block index mod 8) take 16 consecutive tiles."""
+    import ctypes
+    from tests.emu import _lib
+    lib = _lib()
+    lib.emu_xcd_runs.argtypes = [ctypes.c_uint32, ctypes.c_void_p]
+    lib.emu_xcd_runs.restype = None
+    for nb in (1, 7, 8, 127, 128, 129, 255, 256, 1000, 112514):
+        tiles = np.full(nb, 0xFFFFFFFF, dtype=np.uint32)
+        lib.emu_xcd_runs(nb, tiles.ctypes.data)
+        assert np.array_equal(np.sort(tiles), np.arange(nb, dtype=np.uint32)), nb
+        for g in range(nb // 128):
+            grp = tiles[g * 128:(g + 1) * 128]
+            for x in range(8):
+                assert np.array_equal(grp[x::8], g * 128 + x * 16 + np.arange(16)), (nb, g, x)
+        assert np.array_equal(tiles[nb // 128 * 128:], np.arange(nb // 128 * 128, nb))  # the incomplete group
+
+
 def test_morton_keys_follow_the_curve():
     pts = ds.uniform_cloud(5_000, 3, 3)
     emu = EmulatedTree(pts, 10)
