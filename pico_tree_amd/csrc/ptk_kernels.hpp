@@ -909,9 +909,11 @@ __global__ __launch_bounds__(256) void radius_scatter_kernel(
 //
 //   phase 1  every query: root -> home leaf, best = nearest point of that leaf.  The far
 //            children passed on the way that can still matter (box distance <= best; the
-//            pop-time test of the reference can only reject more) are written out as a
-//            CONTINUATION: at most kContSlots records, typically 1-3, none for ~20 % of the
-//            queries, whose answer is then already final.
+//            pop-time test of the reference can only reject more) are kept, at most kContSlots
+//            records.  The reference's next steps are taken as well while they need no stack
+//            (the deepest record's far child is a leaf: typically the home leaf's sibling).
+//            What then remains is written out as a CONTINUATION, typically 1-3 records; none
+//            for about half of the queries, whose answer is then already final.
 //   sort     continuations are ordered by class (= record count), each class keeping its Morton order: a
 //            counting sort over the three class bits for exact searches (phase 2 is capped, see below); for
 //            approximate ones, which phase 2 runs to their end, by the full 16-bit key (make_cont_key) that
