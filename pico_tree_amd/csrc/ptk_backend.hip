@@ -560,9 +560,10 @@ bool want_reorder(const ptk_tree* t, uint64_t nq) {
 // Bits of the Morton key the batch is sorted by.  The search only needs neighbouring lanes to walk neighbouring
 // leaves: 24 bits -- three 8-bit radix passes -- spread over the axes the way the tree itself divides space
 // (axis_bits below) order the batch as well as 30 bits spent evenly do, for one pass less
-// (profiles/r02_notes.txt items 18 and 20).
-constexpr int kMortonBits = 24;
-int morton_bits() { return kMortonBits; }
+// (profiles/r02_notes.txt items 18 and 20).  A small batch is thin in space anyway and pays ~35 us per pass in fixed
+// costs: 16 bits (two passes) below 1 M queries (one eighth of BASELINE config 2: 0.537 vs 0.560 ms per step; at
+// 1.8 M queries the two are equal, at 3.6 M 24 bits win by 6 %; item 29).
+int morton_bits(uint64_t nq) { return nq < (1ull << 20) ? 16 : 24; }
 
 // `bits` key bits over the three axes in proportion to how often a root-to-leaf path splits on each (at most 15
 // per axis).  A cloud that is flat along one axis -- most of a LiDAR scan is floor -- gets few bits there and finer
@@ -605,7 +606,7 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   *perm = nullptr;
   if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
   Timer timer(t, s);
-  const int bits = morton_bits();
+  const int bits = morton_bits(nq);
   size_t tmp_bytes = sort_tmp_bytes(nq, bits);
   uint32_t* keys = scratch.take<uint32_t>(nq);
   uint32_t* keys_out = scratch.take<uint32_t>(nq);

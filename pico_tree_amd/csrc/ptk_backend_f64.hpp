@@ -191,7 +191,7 @@ int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipS
                        const uint32_t** perm) {
   *perm = nullptr;
   if (!want_reorder64(nq)) return PTK_OK;
-  const int bits = morton_bits();
+  const int bits = morton_bits(nq);
   size_t tmp_bytes = sort_tmp_bytes(nq, bits);
   auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
   char* p = lease.aux;
