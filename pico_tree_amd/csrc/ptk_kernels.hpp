@@ -478,6 +478,11 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
   uint32_t* counters;
   uint32_t cur, pos, next, sub, sub_cap, n_static;
   bool capturing;
+  Neighbor staged;
+  // After the traversal: the entry still waiting for a successor.
+  __device__ __forceinline__ void flush() {
+    if (MODE == kRadiusCapture && capturing && pos >= 3u && (pos & 1u) != 0u) out[(uint64_t)cur * kCapChunk + pos - 1u] = staged;
+  }
   __device__ __forceinline__ float max() const { return radius; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
@@ -501,7 +506,17 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
           }
         }
         if (capturing) {
-          out[(uint64_t)cur * kCapChunk + pos] = nb;
+          // Entries 2, 4, ... wait in registers for their successor: the two go out as one aligned 16-byte
+          // store (entry 0 is the chunk's header, so entry 1 goes alone and a chunk ends on a pair).
+          if (pos == 1u) {
+            out[(uint64_t)cur * kCapChunk + 1u] = nb;
+          } else if ((pos & 1u) == 0u) {
+            staged = nb;
+          } else {
+            *reinterpret_cast<uint4*>(out + (uint64_t)cur * kCapChunk + pos - 1u) =
+                make_uint4((uint32_t)staged.index, __float_as_uint(staged.distance), (uint32_t)nb.index,
+                           __float_as_uint(nb.distance));
+          }
           ++pos;
           if (pos == kCapChunk / 2) next = atomicAdd(&counters[sub * kCapCounterStride], 1u);
         }
@@ -862,8 +877,10 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
   pol.sub_cap = cap.sub_cap;
   pol.n_static = cap.n_static;
   pol.capturing = true;
+  pol.staged = Neighbor{0, 0.0f};
   traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   counts[qi] = pol.count;
+  pol.flush();
   cap.captured[qi] = pol.capturing ? 1 : 0;
 }
 

@@ -236,8 +236,10 @@ __global__ __launch_bounds__(64) void radius_nd_capture_kernel(
   pol.sub_cap = cap.sub_cap;
   pol.n_static = cap.n_static;
   pol.capturing = true;
+  pol.staged = Neighbor{0, 0.0f};
   traverse_nd<M>(t, q, off, 64u, pol, st);
   counts[qi] = pol.count;
+  pol.flush();
   cap.captured[qi] = pol.capturing ? 1 : 0;
 }
 
