@@ -450,7 +450,8 @@ struct KnnRegPolicy {
 // becomes a copy (radius_scatter_kernel).  The next chunk is claimed when the current one is half
 // full and the answer is only looked at when it is needed.  A row whose chain could not grow is
 // marked and searched again by the ordinary fill kernel: a small pool costs time, never
-// correctness.  Entry 0 of a chunk is its header: .index = next chunk.
+// correctness.  Entry 0 of a chunk is its header: .index = next chunk.  Entries leave the lane in
+// aligned pairs (2|3, 4|5, ...: one 16-byte store; entry 1 alone, a last odd one by flush()).
 // (Measured and rejected, profiles/r01l_notes.txt: a per-wavefront log of hits in LDS flushed 64
 // entries at a time with full-width stores -- every KB of LDS per wavefront costs more occupancy
 // than the stores give back.)
