@@ -389,6 +389,10 @@ int ptk_profile_get(const ptk_tree* tree, ptk_profile* out, int reset);
  * cooperative search, [2] = queries that search could not certify (redone by the reference
  * traversal from the root), [3] = queries of the classes dealt across wavefronts. */
 int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
+/* How a batch of nq queries would be ordered on the device: bits[a] = bits of the Morton key spent on axis a (the
+ * first three axes; in proportion to how often a root-to-leaf path of this tree splits on each).  Works on handles
+ * without a device replica too. */
+int ptk_debug_key_bits(const ptk_tree* tree, uint64_t nq, uint32_t bits[3]);
 
 #ifdef __cplusplus
 } /* extern "C" */

@@ -128,6 +128,7 @@ _SIGNATURES = {
     "ptk_profile_enable": (c_int, [c_void_p, c_int]),
     "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
     "ptk_debug_knn1_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
     "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
                                              POINTER(c_void_p)]),
     "ptk_multi_create": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p)]),
@@ -485,6 +486,13 @@ class KdTree:
         c = (c_uint32 * 4)()
         _check(_load().ptk_debug_knn1_counts(self._h, c))
         return {"phase2": int(c[0]), "cooperative": int(c[1]), "redone": int(c[2]), "dealt": int(c[3])}
+
+    def key_bits(self, nq: int) -> tuple:
+        """Bits of the Morton key per axis for a batch of ``nq`` queries (``ptk_debug_key_bits``)."""
+        self._float32_only("key_bits()")
+        b = (c_uint32 * 3)()
+        _check(_load().ptk_debug_key_bits(self._h, int(nq), b))
+        return int(b[0]), int(b[1]), int(b[2])
 
     # -- k nearest neighbours ------------------------------------------------------------
     def search_knn(self, pts, k: int, *args):

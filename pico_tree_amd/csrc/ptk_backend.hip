@@ -2052,6 +2052,12 @@ int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
   return PTK_OK;
 }
 
+int ptk_debug_key_bits(const ptk_tree* t, uint64_t nq, uint32_t bits[3]) {
+  if (t == nullptr || bits == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  axis_bits(t, morton_bits(nq), bits);
+  return PTK_OK;
+}
+
 int ptk_profile_enable(ptk_tree* t, int on) {
   if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
   std::lock_guard<std::mutex> lock(t->profile.mutex);

@@ -230,3 +230,28 @@ def test_input_file_formats_round_trip(tmp_path):
     assert ds.load_points(str(tmp_path / "base.bvecs")).dtype == np.float32
     with pytest.raises(ValueError):
         ds.read_xvecs(str(tmp_path / "scan.bin"))
+
+
+def test_key_bits_follow_the_splits_of_the_tree():
+    """The Morton key of a batch spends its bits where the tree divides space: evenly on a cube, (almost) none
+    on the axis a flat cloud does not extend along; 24 bits for a big batch, 16 below 2^20 queries, 15 at
+    most per axis; fewer axes share all of them."""
+    cube = ds.uniform_cloud(40_000, 3, 1)
+    t = pt.KdTree(cube, pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+    assert t.key_bits(5_000_000) == (8, 8, 8)
+    b = t.key_bits(1000)
+    assert sum(b) == 16 and max(b) - min(b) <= 1
+    flat = cube.copy()
+    flat[:, 2] *= np.float32(1e-4)  # a sheet: the sliding midpoint rule splits the longest side, never z
+    t = pt.KdTree(flat, pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+    bx, by, bz = t.key_bits(5_000_000)
+    assert bz == 0 and bx + by == 24 and abs(bx - by) <= 1
+    long = cube.copy()
+    long[:, 0] *= np.float32(4096.0)  # a rod: x gets the most a single axis may have
+    t = pt.KdTree(long, pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+    bx, by, bz = t.key_bits(5_000_000)
+    assert bx >= 10 and bx <= 15 and bx + by + bz == 24
+    t = pt.KdTree(np.ascontiguousarray(cube[:, :2]), pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+    assert t.key_bits(5_000_000) == (12, 12, 0)
+    t = pt.KdTree(cube[:1], pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)  # one leaf: nothing to go by
+    assert t.key_bits(5_000_000) == (8, 8, 8)
