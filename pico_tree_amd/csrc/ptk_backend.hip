@@ -543,8 +543,7 @@ int allow_lds(K kernel, size_t bytes) {
   return PTK_OK;
 }
 
-// Tuning knob for A/B measurements (tools/ab_knn1.py): selects among the compiled
-// geometries of the k = 1 kernel.  Unset = the default geometry.
+// An integer from the environment (the memory caps and test switches listed in INTEGRATION.md section 6).
 int env_int(const char* name, int fallback) {
   const char* v = std::getenv(name);
   return v ? std::atoi(v) : fallback;
