@@ -73,6 +73,7 @@ struct PendingEvent {
   hipEvent_t a, b;
   int kind;  // 0 search, 1 reorder, 2 other, 3 search (continuation of the same launch)
   uint64_t queries;
+  bool keep_b;  // `b` is also the `a` of the next section (Timer::next), which recycles it
 };
 
 struct Profile {
@@ -410,7 +411,11 @@ struct Timer {
           idle.pop_back();
         }
       }
-      if (a == nullptr) on = hipEventCreate(&a) == hipSuccess && hipEventCreate(&b) == hipSuccess;
+      // Timing only: no system-scope fence when the event completes (the default event makes the device write
+      // its caches back, which costs the kernels around it: 0.042 ms per k = 1 search with ten such events).
+      if (a == nullptr)
+        on = hipEventCreateWithFlags(&a, hipEventDisableSystemFence) == hipSuccess &&
+             hipEventCreateWithFlags(&b, hipEventDisableSystemFence) == hipSuccess;
       if (on) (void)hipEventRecord(a, s);
     }
   }
@@ -418,10 +423,32 @@ struct Timer {
     if (!on) return;
     (void)hipEventRecord(b, s);
     std::lock_guard<std::mutex> lock(t->profile.mutex);
-    t->profile.pending.push_back(PendingEvent{a, b, kind, queries});
+    t->profile.pending.push_back(PendingEvent{a, b, kind, queries, false});
     a = b = nullptr;
+    on = false;
   }
-  ~Timer() {
+  // Ends a section and begins the next at the same instant: ONE event between two kernels instead of two
+  // (an event between dependent launches costs ~3 us of idle device).
+  void next(int kind, uint64_t queries) {
+    if (!on) return;
+    (void)hipEventRecord(b, s);
+    hipEvent_t fresh = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(t->profile.mutex);
+      t->profile.pending.push_back(PendingEvent{a, b, kind, queries, true});
+      if (!t->profile.idle.empty()) {
+        fresh = t->profile.idle.back();
+        t->profile.idle.pop_back();
+      }
+    }
+    a = b;  // ours now: the section that ended does not recycle it
+    b = fresh;
+    if (b == nullptr && hipEventCreateWithFlags(&b, hipEventDisableSystemFence) != hipSuccess) {
+      b = nullptr;
+      on = false;  // (the destructor drops `a`; the ended section only reads it before that if it is resolved first)
+    }
+  }
+  ~Timer() {  // only reached with events in hand when a search failed half-way
     if (a) (void)hipEventDestroy(a);
     if (b) (void)hipEventDestroy(b);
   }
@@ -869,65 +896,56 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // The grid has room for nq / 64 extra waves in the narrow tiers; the meta kernel cuts the tiers to what fits.
   const ptk::TierSpec tiers = phase2_tiers(cap);
   const uint32_t extra_waves = tiers.permille[0] == 0 ? 0u : (uint32_t)(nq / 64) + 2u;
-  {
-    Timer timer(t, s);
-    hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, t->dev, d_q, t->dim, perm, nq,
-                       e_inv, d_out, cont, qs);
-    timer.stop(0, nq);
-  }
-  {
-    Timer timer(t, s);
-    if (cap) {
-      // With the cap the order inside the heavy classes does not matter (no query runs long), only the three class
-      // bits do: 8 buckets -- count per chunk, scan the 8 x chunks counters, stable scatter; the tier table from
-      // the scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
-      const uint32_t chunks = class_chunks(nq);
-      const size_t n_counters = (size_t)ptk::kClassBuckets * chunks;
-      uint32_t* counters = scratch.take<uint32_t>(n_counters);
-      uint32_t* offsets = scratch.take<uint32_t>(n_counters);
-      size_t scan_bytes = class_scan_tmp_bytes(nq);
-      void* scan_tmp = scratch.take<char>(scan_bytes);
-      if (!counters || !offsets || !scan_tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
-      hipLaunchKernelGGL(ptk::class_count_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer, counters);
-      PTK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, counters, offsets, 0u, n_counters, rocprim::plus<uint32_t>(), s));
-      hipLaunchKernelGGL(ptk::class_meta_kernel, dim3(1), dim3(1), 0, s, offsets, chunks, cont, tiers, extra_waves);
-      hipLaunchKernelGGL(ptk::class_scatter_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer,
-                         offsets, ids_out);
-      PTK_HIP(hipGetLastError());
-    } else {
-      // Every query runs to its end in phase 2: the full 16-bit key (the ranked classes by how far their
-      // home-leaf best is), so that the most expensive continuations start first.
-      PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, slot_ids, ids_out, nq, 0, 16, s));
-      hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont, tiers,
-                         extra_waves);
-    }
-    timer.stop(2, 0);
-  }
-  const dim3 p2_grid(blocks + 1 + extra_waves);
-  {
-    Timer timer(t, s);
-    // LDS ring of phase 2.  With the cap no stack grows deep: 12 slots = 6 KB per wave = 26 waves per CU beat
-    // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt item 10); without it 16 slots
-    // (r01l_notes item 8).
-    if (cap) {
-      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<12, OVF, LEAFB>), p2_grid, dim3(64), (size_t)12 * 64 * 8, s, t->dev, qs,
-                         e_inv, d_out, cont, ids_out, cap, ho);
-    } else {
-      hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
-                         e_inv, d_out, cont, ids_out, 0u, ho);
-    }
+  // One chain of sections: search (phase 1) | other (class order) | search (phase 2, cooperative search, replay).
+  Timer timer(t, s);
+  hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, t->dev, d_q, t->dim, perm, nq,
+                     e_inv, d_out, cont, qs);
+  timer.next(0, nq);
+  if (cap) {
+    // With the cap the order inside the heavy classes does not matter (no query runs long), only the three class
+    // bits do: 8 buckets -- count per chunk, scan the 8 x chunks counters, stable scatter; the tier table from
+    // the scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
+    const uint32_t chunks = class_chunks(nq);
+    const size_t n_counters = (size_t)ptk::kClassBuckets * chunks;
+    uint32_t* counters = scratch.take<uint32_t>(n_counters);
+    uint32_t* offsets = scratch.take<uint32_t>(n_counters);
+    size_t scan_bytes = class_scan_tmp_bytes(nq);
+    void* scan_tmp = scratch.take<char>(scan_bytes);
+    if (!counters || !offsets || !scan_tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
+    hipLaunchKernelGGL(ptk::class_count_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer, counters);
+    PTK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, counters, offsets, 0u, n_counters, rocprim::plus<uint32_t>(), s));
+    hipLaunchKernelGGL(ptk::class_meta_kernel, dim3(1), dim3(1), 0, s, offsets, chunks, cont, tiers, extra_waves);
+    hipLaunchKernelGGL(ptk::class_scatter_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer,
+                       offsets, ids_out);
     PTK_HIP(hipGetLastError());
-    timer.stop(3, 0);
+  } else {
+    // Every query runs to its end in phase 2: the full 16-bit key (the ranked classes by how far their
+    // home-leaf best is), so that the most expensive continuations start first.
+    PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, cont.key, key_out, slot_ids, ids_out, nq, 0, 16, s));
+    hipLaunchKernelGGL(ptk::knn1_phase_meta_kernel, dim3(1), dim3(1), 0, s, key_out, (uint32_t)nq, cont, tiers,
+                       extra_waves);
   }
+  timer.next(2, 0);
+  const dim3 p2_grid(blocks + 1 + extra_waves);
+  // LDS ring of phase 2.  With the cap no stack grows deep: 12 slots = 6 KB per wave = 26 waves per CU beat
+  // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt items 10, 23); without it 16 slots
+  // (r01l_notes item 8).
+  if (cap) {
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<12, OVF, LEAFB>), p2_grid, dim3(64), (size_t)12 * 64 * 8, s, t->dev, qs,
+                       e_inv, d_out, cont, ids_out, cap, ho);
+  } else {
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
+                       e_inv, d_out, cont, ids_out, 0u, ho);
+  }
+  PTK_HIP(hipGetLastError());
   if (cap) {  // the queries phase 2 gave up on, then whatever the cooperative search could not certify
-    Timer timer(t, s);
     int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s);
     if (rc != PTK_OK) return rc;
     hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(256), dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
                        e_inv, d_out, cont, redo_list);
     PTK_HIP(hipGetLastError());
-    timer.stop(3, 0);
   }
+  timer.stop(3, 0);
   return PTK_OK;
 }
 
@@ -1196,7 +1214,7 @@ void ptk_tree_destroy(ptk_tree* t) {
     DeviceGuard guard(t->device);
     for (PendingEvent& p : t->profile.pending) {
       (void)hipEventDestroy(p.a);
-      (void)hipEventDestroy(p.b);
+      if (!p.keep_b) (void)hipEventDestroy(p.b);
     }
     for (hipEvent_t e : t->profile.idle) (void)hipEventDestroy(e);
     if (t->ws.has_work) (void)hipEventSynchronize(t->ws.done);
@@ -2083,7 +2101,7 @@ int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
       }
     }
     t->profile.idle.push_back(p.a);
-    t->profile.idle.push_back(p.b);
+    if (!p.keep_b) t->profile.idle.push_back(p.b);
   }
   t->profile.pending.clear();
   *out = t->profile.acc;
