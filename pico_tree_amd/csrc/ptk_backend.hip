@@ -903,8 +903,8 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   timer.next(0, nq);
   if (cap) {
     // With the cap the order inside the heavy classes does not matter (no query runs long), only the three class
-    // bits do: 8 buckets -- count per chunk, scan the 8 x chunks counters, stable scatter; the tier table from
-    // the scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
+    // bits do: 8 buckets -- count per chunk, scan the 8 x chunks counters, stable scatter, which also writes the tier
+    // table from the scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
     const uint32_t chunks = class_chunks(nq);
     const size_t n_counters = (size_t)ptk::kClassBuckets * chunks;
     uint32_t* counters = scratch.take<uint32_t>(n_counters);
@@ -914,9 +914,8 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     if (!counters || !offsets || !scan_tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
     hipLaunchKernelGGL(ptk::class_count_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer, counters);
     PTK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, counters, offsets, 0u, n_counters, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(ptk::class_meta_kernel, dim3(1), dim3(1), 0, s, offsets, chunks, cont, tiers, extra_waves);
     hipLaunchKernelGGL(ptk::class_scatter_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer,
-                       offsets, ids_out);
+                       offsets, ids_out, cont, tiers, extra_waves);
     PTK_HIP(hipGetLastError());
   } else {
     // Every query runs to its end in phase 2: the full 16-bit key (the ranked classes by how far their

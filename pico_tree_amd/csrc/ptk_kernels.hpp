@@ -1273,9 +1273,12 @@ __global__ __launch_bounds__(64) void class_count_kernel(const ContKey* __restri
 
 // `offsets` = exclusive scan of `counters` (bucket-major, 8 x chunks entries): offsets[b * chunks + c] is
 // where chunk c's slots of bucket b go.  Slot numbers are the values (phase 1 numbers its slots 0 .. nq - 1).
+// The first chunk also writes the tier table of phase 2: bucket b starts at offsets[b * chunks], which is where
+// chunk 0's slots of bucket b go.
 __global__ __launch_bounds__(64) void class_scatter_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
                                                            const uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ sorted_ids) {
+                                                           uint32_t* __restrict__ sorted_ids, Cont cont, TierSpec tiers,
+                                                           uint32_t max_narrow_waves) {
   const uint32_t chunk = blockIdx.x, chunks = gridDim.x;
   const uint32_t lo = chunk * per;
   const uint32_t hi = lo + per < nq ? lo + per : nq;
@@ -1283,6 +1286,10 @@ __global__ __launch_bounds__(64) void class_scatter_kernel(const ContKey* __rest
   uint32_t base[kClassBuckets];  // next free position of every bucket for this chunk
 #pragma unroll
   for (uint32_t b = 0; b < kClassBuckets; ++b) base[b] = offsets[b * chunks + chunk];
+  if (chunk == 0 && threadIdx.x == 0) {
+    // n2 = everything before class 0, ranked = classes >= kRankedClass, heavy = classes >= kHeavyClass
+    write_phase_meta(cont, base[7], base[1], base[7u - kHeavyClass + 1u], tiers, max_narrow_waves);
+  }
   for (uint32_t i = lo; i < hi; i += 256u) {
     uint32_t k[4];
 #pragma unroll
@@ -1303,16 +1310,6 @@ __global__ __launch_bounds__(64) void class_scatter_kernel(const ContKey* __rest
       if (j < hi) sorted_ids[pos] = j;
     }
   }
-}
-
-// The tier table from the scanned counters: bucket b starts at offsets[b * chunks].
-__global__ void class_meta_kernel(const uint32_t* __restrict__ offsets, uint32_t chunks, Cont cont, TierSpec tiers,
-                                  uint32_t max_narrow_waves) {
-  auto start = [&](uint32_t b) { return offsets[b * chunks]; };  // b = 1 .. 7
-  const uint32_t n2 = start(7);       // everything before class 0
-  const uint32_t ranked = start(1);   // classes >= kRankedClass
-  const uint32_t heavy = start(7u - kHeavyClass + 1u);
-  write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves);
 }
 
 // Phase 2: one continuation per lane, taken from the class-sorted entry list.

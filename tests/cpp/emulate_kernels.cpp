@@ -545,7 +545,9 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     }
     if (run != nq) return -6;
     std::vector<uint32_t> by_count(nq, 0xEEEEEEEEu);
-    for_each_wave(chunks, [&] { ptk::class_scatter_kernel(ckey.data(), (uint32_t)nq, per, offsets.data(), by_count.data()); });
+    for_each_wave(chunks, [&] {
+      ptk::class_scatter_kernel(ckey.data(), (uint32_t)nq, per, offsets.data(), by_count.data(), cont, tiers, top_extra);
+    });
     for (uint64_t i = 0; i < nq; ++i) {
       // the same permutation as the stable sort on the class bits (the light classes keep their order)
       if ((sorted_key[i] >> 13) != (ckey[by_count[i]] >> 13)) return -7;
@@ -559,10 +561,6 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     }
     if (by_class != by_count) return -8;
     sorted = by_count;
-    gridDim.x = 1;
-    blockIdx.x = 0;
-    threadIdx.x = 0;
-    ptk::class_meta_kernel(offsets.data(), chunks, cont, tiers, top_extra);
   } else {
     gridDim.x = 1;
     blockIdx.x = 0;
