@@ -363,6 +363,10 @@ void ptk_multi_destroy(ptk_multi* multi);
 int ptk_multi_device_count(const ptk_multi* multi);
 /* The replica on devices[i] (owned by `multi`): for ptk_tree_set_metric, ptk_profile_*, ... */
 int ptk_multi_get_tree(const ptk_multi* multi, uint32_t i, const ptk_tree** tree);
+/* ptk_tree_set_metric on every replica.  Handles made by ptk_multi_create_from_points carry the outer
+   bounds the topological metrics need; a descriptor (ptk_multi_create) has none, so metric_so2 /
+   metric_se2_squared answer PTK_ERR_INVALID there, as ptk_tree_set_metric does. */
+int ptk_multi_set_metric(ptk_multi* multi, int metric);
 int ptk_multi_search_knn(const ptk_multi* multi, const float* queries, uint64_t nq, uint32_t k, float e,
                          ptk_neighbor* out);
 int ptk_multi_search_radius(const ptk_multi* multi, const float* queries, uint64_t nq, float radius, float e, int sort,

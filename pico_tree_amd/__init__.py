@@ -135,6 +135,7 @@ _SIGNATURES = {
     "ptk_multi_destroy": (None, [c_void_p]),
     "ptk_multi_device_count": (c_int, [c_void_p]),
     "ptk_multi_get_tree": (c_int, [c_void_p, c_uint32, POINTER(c_void_p)]),
+    "ptk_multi_set_metric": (c_int, [c_void_p, c_int]),
     "ptk_multi_search_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p]),
     "ptk_multi_search_radius": (c_int, [c_void_p, c_void_p, c_uint64, c_float, c_float, c_int, c_void_p,
                                         POINTER(c_void_p)]),

@@ -31,6 +31,7 @@
 #include "ptk.h"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
 #include "ptk_kernels_topo.hpp"
 #include "ptk_forest.hpp"
@@ -623,7 +624,29 @@ size_t sort_tmp_bytes(uint64_t nq, int bits) {
   return tmp_bytes + 256;
 }
 
-size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, 30); }
+// The library's own radix sort (ptk_sort.hpp): tiles of `tile` items, one wavefront each.  At most 4096 tiles
+// (a row of the digit-by-tile histogram is scanned by one wavefront), at least 512 items per tile (256 / 512 / 1024:
+// 68 / 58 / 60 us for 900 k queries; PTK_SORT_TILE for experiments).
+uint32_t sort_tile(uint64_t nq) {
+  const uint64_t t = ((nq + 4095) / 4096 + 63) & ~(uint64_t)63;
+  return (uint32_t)std::max<uint64_t>(t, (uint64_t)std::max(64, env_int("PTK_SORT_TILE", 512)) & ~(uint64_t)63);
+}
+uint32_t sort_tiles(uint64_t nq) { return (uint32_t)((nq + sort_tile(nq) - 1) / sort_tile(nq)); }
+uint32_t sort_stride(uint64_t nq) { return (sort_tiles(nq) + 3u) & ~3u;  }  // row of the histogram: 16-byte steps
+size_t own_sort_bytes(uint64_t nq) {
+  return ((size_t)ptk::kRadixBins * sort_stride(nq) + ptk::kRadixBins) * 4 + 2 * nq * sizeof(uint2) + 1024;
+}
+
+// Which sort orders the batch: the library's own below 2 M queries (six launches and 58 us for a 900 k-query shard
+// against ten launches and 96 us), rocprim's onesweep above (7.2 M queries, three passes: 0.26 against 0.32 ms;
+// profiles/r03_notes.txt item 1).  PTK_SORT = 0 / 1 forces rocprim's / the library's own.
+bool own_sort(uint64_t nq) {
+  const int mode = env_int("PTK_SORT", -1);
+  if (nq >= (1ull << 31)) return false;
+  return mode < 0 ? nq < (2ull << 20) : mode != 0;
+}
+
+size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, 30) + own_sort_bytes(nq); }
 
 // Device-side Morton ordering of a batch: *perm (device, nq uint32, in `scratch`) lists the
 // query rows in launch order.
@@ -647,6 +670,47 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     lo[d] = t->root_min[d];
     const float ext = t->root_max[d] - t->root_min[d];
     inv[d] = ext > 0 ? (float)(1u << b[d]) / ext : 0.0f;
+  }
+  if (own_sort(nq)) {
+    // Key + histogram kernel, then per 8-bit pass: scan of the digit-by-tile histogram, stable scatter (and the
+    // histogram of the next digit): 3 launches per pass - 1... nothing to clear, no look-back (ptk_sort.hpp).
+    // keys -> pairs A -> [pairs B ->] permutation; the arrays of the rocprim path serve (keys | keys_out + ids = A).
+    const uint32_t tile = sort_tile(nq), tiles = sort_tiles(nq), stride = sort_stride(nq);
+    uint32_t* hist = scratch.take<uint32_t>((size_t)ptk::kRadixBins * stride);
+    uint32_t* totals = scratch.take<uint32_t>(ptk::kRadixBins);
+    uint2* pairs_a = scratch.take<uint2>(nq);
+    uint2* pairs_b = bits > 16 ? scratch.take<uint2>(nq) : pairs_a;
+    if (!hist || !totals || !pairs_a || !pairs_b) return fail(PTK_ERR_NOMEM, "scratch block too small");
+    const float3 lo3 = make_float3(lo[0], lo[1], lo[2]), inv3 = make_float3(inv[0], inv[1], inv[2]);
+    const uint3 b3 = make_uint3(b[0], b[1], b[2]);
+    const int passes = (bits + 7) / 8;
+    const size_t smem = ptk::kRadixBins * 4;
+    const uint2* in = nullptr;
+    for (int p = 0; p < passes; ++p) {
+      const uint32_t shift = 8u * (uint32_t)p;
+      const bool first = p == 0, last = p + 1 == passes;
+      uint2* out = in == pairs_a ? pairs_b : pairs_a;
+      if (first)
+        hipLaunchKernelGGL((ptk::radix_hist_kernel<true>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
+                           inv3, b3, keys, in, shift, tile, stride, hist);
+      else
+        hipLaunchKernelGGL((ptk::radix_hist_kernel<false>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
+                           inv3, b3, keys, in, shift, tile, stride, hist);
+      hipLaunchKernelGGL(ptk::radix_scan_kernel, dim3(ptk::kRadixBins), dim3(64), 0, s, hist, tiles, stride, totals);
+#define PTK_SCATTER(F, L)                                                                                              \
+  hipLaunchKernelGGL((ptk::radix_scatter_kernel<F, L>), dim3(tiles), dim3(64), smem, s, keys, in, out, ids_out,        \
+                     (uint32_t)nq, shift, tile, stride, hist, totals)
+      if (first && last) PTK_SCATTER(true, true);
+      else if (first) PTK_SCATTER(true, false);
+      else if (last) PTK_SCATTER(false, true);
+      else PTK_SCATTER(false, false);
+#undef PTK_SCATTER
+      in = out;
+    }
+    PTK_HIP(hipGetLastError());
+    *perm = ids_out;
+    timer.stop(1, 0);
+    return PTK_OK;
   }
   const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
   hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq,
@@ -1395,7 +1459,6 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   // between are the caller's in the reference; here they are zeroed.  (The register k-list assumes
   // every slot gets filled, so these rows take the list-in-the-row kernels.)
   const bool short_tree = k > t->n_points;
-  if (short_tree) PTK_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(ptk_neighbor), s));
   // Very large batches go through in pieces of at most 2^25 queries: the scratch of a piece stays
   // at a few GB and every 32-bit index in the kernels holds (PTK_MAX_BATCH shrinks it for tests).
   const uint64_t piece = (uint64_t)std::max(1, env_int("PTK_MAX_BATCH", 1 << 25));
@@ -1409,6 +1472,8 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   }
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  // (on the tree's device, once per piece: a null stream is the null stream of THAT device)
+  if (short_tree) PTK_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(ptk_neighbor), s));
   const bool l2 = t->metric.load() == PTK_METRIC_L2_SQUARED;
   if (topological(t)) {
     if (deep_tree(t)) return fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth);

@@ -237,13 +237,13 @@ int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipS
 
 template <class M>
 int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, double e,
-                 ptk::Neighbor64* d_out, hipStream_t s, Stack64Lease& lease) {
+                 ptk::Neighbor64* d_out, hipStream_t s, Stack64Lease& lease, bool short_tree = false) {
   const bool d3 = t->dim <= 3;  // q / off in registers: the LDS holds the record ring only
   const size_t smem = ptk::lds64_bytes(d3 ? 0 : 2, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
   int rc = PTK_OK;
-  // k-list in registers for 1 < k <= 16.
-  const int reg = (k > 1 && k <= 16) ? (k <= 4 ? 4 : (k <= 8 ? 8 : 16)) : 0;
+  // k-list in registers for 1 < k <= 16 (it assumes every slot gets filled: not for k > n_points).
+  const int reg = (k > 1 && k <= 16 && !short_tree) ? (k <= 4 ? 4 : (k <= 8 ? 8 : 16)) : 0;
 #define PTK_LAUNCH64(KERNEL)                                                                                          \
   do {                                                                                                                \
     rc = allow_lds(KERNEL, smem);                                                                                     \
@@ -450,21 +450,24 @@ int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq,
   int rc = check_search64(t, d_q, nq);
   if (rc != PTK_OK) return rc;
   if (k == 0) return fail(PTK_ERR_INVALID, "k must be >= 1");
-  if (k > t->n_points) return fail(PTK_ERR_INVALID, "k = %u exceeds the number of points (%llu)", k,
-                                   (unsigned long long)t->n_points);
   if (!(e > 0.0)) return fail(PTK_ERR_INVALID, "approximation ratio e must be > 0");
   if (nq == 0) return PTK_OK;
   if (d_out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
   hipStream_t s = static_cast<hipStream_t>(stream);
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  // k > n_points, as the float32 entry (ptk_search_knn_device): the n_points neighbours in order, the last
+  // slot's distance at the DBL_MAX sentinel (search_visitor.hpp:95-110), the slots in between zeroed.
+  const bool short_tree = k > t->n_points;
+  if (short_tree) PTK_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(ptk_neighbor64), s));
   Stack64Lease lease(t, s);
   rc = lease.acquire(nq, permutation64_bytes(nq));
   if (rc != PTK_OK) return rc;
   const uint32_t* perm = nullptr;
   rc = make_permutation64(t, d_q, nq, s, lease, &perm);
   if (rc != PTK_OK) return rc;
-  PTK_WITH_METRIC64(rc = launch_knn64<M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease));
+  PTK_WITH_METRIC64(rc = launch_knn64<M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease,
+                                         short_tree));
   return rc;
 }
 

@@ -75,6 +75,26 @@ Rccl& rccl() {
     if (r_ != ncclSuccess) return fail(PTK_ERR_DEVICE, "%s failed: %s", #expr, rccl().GetErrorString(r_)); \
   } while (0)
 
+// An open RCCL group is closed on every way out of the scope: a send / recv that fails half-way must not leave
+// the thread's group open (later collectives of the process would be queued into it and never start).
+struct NcclGroup {
+  Rccl& r;
+  bool open = false;
+  explicit NcclGroup(Rccl& rccl_) : r(rccl_) {}
+  ncclResult_t start() {
+    const ncclResult_t rc = r.GroupStart();
+    open = rc == ncclSuccess;
+    return rc;
+  }
+  ncclResult_t end() {
+    open = false;
+    return r.GroupEnd();
+  }
+  ~NcclGroup() {
+    if (open) (void)r.GroupEnd();
+  }
+};
+
 }  // namespace
 
 struct ptk_multi {
@@ -129,6 +149,10 @@ int multi_finish_create(ptk_multi* m, ptk_tree* host, const float* points, ptk_m
     rc = ptk_tree_create(&d, &t);
     if (rc != PTK_OK) break;
     m->trees.push_back(t);
+    // the two outer bounds per branch (only the topological metrics read them; ptk_multi_set_metric)
+    if (host->outer.size() == 2 * host->nodes.size())
+      rc = ptk_tree_set_outer_bounds(t, host->outer.data(), host->nodes.size());
+    if (rc != PTK_OK) break;
     DeviceGuard guard(m->devices[i]);
     hipStream_t s = nullptr;
     hipEvent_t e = nullptr;
@@ -243,6 +267,16 @@ int ptk_multi_device_count(const ptk_multi* m) { return m == nullptr ? 0 : (int)
 int ptk_multi_get_tree(const ptk_multi* m, uint32_t i, const ptk_tree** tree) {
   if (m == nullptr || tree == nullptr || i >= m->trees.size()) return fail(PTK_ERR_INVALID, "bad argument");
   *tree = m->trees[i];
+  return PTK_OK;
+}
+
+int ptk_multi_set_metric(ptk_multi* m, int metric) {
+  if (m == nullptr) return fail(PTK_ERR_INVALID, "null handle");
+  std::lock_guard<std::mutex> lock(m->mutex);
+  for (ptk_tree* t : m->trees) {
+    const int rc = ptk_tree_set_metric(t, metric);
+    if (rc != PTK_OK) return rc;
+  }
   return PTK_OK;
 }
 
@@ -369,7 +403,8 @@ int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uin
       DeviceGuard guard(m->devices[r]);
       PTK_HIP(hipStreamWaitEvent(m->streams[r], m->ready, 0));
     }
-    PTK_NCCL(nccl.GroupStart());
+    NcclGroup group(nccl);
+    PTK_NCCL(group.start());
     for (uint32_t r = 1; r < n; ++r) {
       uint64_t lo, hi;
       shard_rows(nq, n, r, &lo, &hi);
@@ -377,7 +412,7 @@ int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uin
       PTK_NCCL(nccl.Send(d_q + lo * m->dim, (hi - lo) * row_q, ncclInt8, (int)r, m->comms[0], s0));
       PTK_NCCL(nccl.Recv(m->d_q[r], (hi - lo) * row_q, ncclInt8, 0, m->comms[r], m->streams[r]));
     }
-    PTK_NCCL(nccl.GroupEnd());
+    PTK_NCCL(group.end());
   }
   // 2. every device searches its range
   for (uint32_t r = 0; r < n; ++r) {
@@ -388,11 +423,20 @@ int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uin
     const float* q_r = r == 0 ? d_q : reinterpret_cast<const float*>(m->d_q[r]);
     ptk_neighbor* o_r = staged ? reinterpret_cast<ptk_neighbor*>(m->d_o[r]) : d_out + lo * k;
     rc = ptk_search_knn_device(m->trees[r], q_r, hi - lo, k, e, o_r, r == 0 ? s0 : m->streams[r]);
-    if (rc != PTK_OK) return rc;
+    if (rc != PTK_OK) {  // the peers may hold received ranges and searches: let them finish before anything is reused
+      const std::string keep = g_error;
+      for (uint32_t p = 1; p < n; ++p) {
+        DeviceGuard guard(m->devices[p]);
+        (void)hipStreamSynchronize(m->streams[p]);
+      }
+      g_error = keep;
+      return rc;
+    }
   }
   // 3. the rows come back: each peer over its own link into its place of the caller's buffer
   if (n > 1 || self) {
-    PTK_NCCL(nccl.GroupStart());
+    NcclGroup group(nccl);
+    PTK_NCCL(group.start());
     for (uint32_t r = self ? 0 : 1; r < n; ++r) {
       uint64_t lo, hi;
       shard_rows(nq, n, r, &lo, &hi);
@@ -400,7 +444,7 @@ int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uin
       PTK_NCCL(nccl.Send(m->d_o[r], (hi - lo) * row_o, ncclInt8, 0, m->comms[r], r == 0 ? s0 : m->streams[r]));
       PTK_NCCL(nccl.Recv(d_out + lo * k, (hi - lo) * row_o, ncclInt8, (int)r, m->comms[0], s0));
     }
-    PTK_NCCL(nccl.GroupEnd());
+    PTK_NCCL(group.end());
   }
   // The peers' staging buffers are reused by the next call: it must not start before the caller's
   // stream has received everything, which the next call's `ready` event (recorded on s0) implies.

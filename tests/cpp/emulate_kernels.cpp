@@ -26,6 +26,7 @@ thread_local dim3 blockDim;
 #include "ptk.h"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
 #include "ptk_kernels_topo.hpp"
 #include "ptk_kernels_f64.hpp"
@@ -723,6 +724,44 @@ void emu_morton(const float* q, uint32_t dim, uint64_t nq, const float* lo, cons
   float3 l = make_float3(lo[0], lo[1], lo[2]);
   float3 i = make_float3(inv[0], inv[1], inv[2]);
   for_each_lane(nq, [&] { ptk::morton_kernel(q, dim, nq, l, i, make_uint3(bits[0], bits[1], bits[2]), keys, ids); });
+}
+
+// The batch order as make_permutation() of the backend produces it with the library's own radix sort
+// (ptk_sort.hpp): key + histogram kernel, then scan and stable scatter per 8-bit pass.  keys = the Morton keys.
+void emu_radix_sort(const float* q, uint32_t dim, uint64_t nq, const float* lo, const float* inv, const uint32_t* bits,
+                    uint32_t key_bits, uint32_t tile, uint32_t* keys, uint32_t* perm) {
+  const float3 l = make_float3(lo[0], lo[1], lo[2]);
+  const float3 i = make_float3(inv[0], inv[1], inv[2]);
+  const uint3 b3 = make_uint3(bits[0], bits[1], bits[2]);
+  const uint32_t tiles = (uint32_t)((nq + tile - 1) / tile), stride = (tiles + 3u) & ~3u;
+  std::vector<uint32_t> hist((size_t)ptk::kRadixBins * stride, 0xEEEEEEEEu), totals(ptk::kRadixBins, 0xEEEEEEEEu);
+  std::vector<uint32_t> k0(nq, 0xEEEEEEEEu), out_perm(nq, 0xEEEEEEEEu);
+  std::vector<uint2> pa(nq, uint2{0xEEEEEEEEu, 0xEEEEEEEEu}), pb(nq, uint2{0xEEEEEEEEu, 0xEEEEEEEEu});
+  const uint32_t passes = (key_bits + 7) / 8;
+  const uint2* in = nullptr;
+  for (uint32_t p = 0; p < passes; ++p) {
+    const uint32_t shift = 8 * p;
+    const bool first = p == 0, last = p + 1 == passes;
+    uint2* out = in == pa.data() ? pb.data() : pa.data();
+    for_each_wave(tiles, [&] {
+      if (first) ptk::radix_hist_kernel<true>(q, dim, (uint32_t)nq, l, i, b3, k0.data(), in, shift, tile, stride, hist.data());
+      else ptk::radix_hist_kernel<false>(q, dim, (uint32_t)nq, l, i, b3, k0.data(), in, shift, tile, stride, hist.data());
+    });
+    for_each_wave(ptk::kRadixBins, [&] { ptk::radix_scan_kernel(hist.data(), tiles, stride, totals.data()); });
+    for_each_wave(tiles, [&] {
+      if (first && last)
+        ptk::radix_scatter_kernel<true, true>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, tile, stride, hist.data(), totals.data());
+      else if (first)
+        ptk::radix_scatter_kernel<true, false>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, tile, stride, hist.data(), totals.data());
+      else if (last)
+        ptk::radix_scatter_kernel<false, true>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, tile, stride, hist.data(), totals.data());
+      else
+        ptk::radix_scatter_kernel<false, false>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, tile, stride, hist.data(), totals.data());
+    });
+    in = out;
+  }
+  std::memcpy(keys, k0.data(), nq * 4);
+  std::memcpy(perm, out_perm.data(), nq * 4);
 }
 
 }  // extern "C"

@@ -158,6 +158,26 @@ class EmulatedTree:
                             keys.ctypes.data, ids.ctypes.data)
         return ids[np.argsort(keys, kind="stable")].astype(np.uint32), keys
 
+    def radix_sorted_permutation(self, q, bits, tile=256):
+        """The batch order from the library's own radix sort (ptk_sort.hpp) under the emulator:
+        (permutation, Morton keys).  `bits`: key bits per axis."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        bits = np.asarray(list(bits) + [0] * 3, dtype=np.uint32)[:3]
+        lo = np.zeros(3, dtype=np.float32)
+        inv = np.zeros(3, dtype=np.float32)
+        d = self.pts.shape[1]
+        lo[:d] = self.rmin
+        ext = self.rmax - self.rmin
+        inv[:d] = np.where(ext > 0, np.exp2(bits[:d]).astype(np.float32) / ext, 0).astype(np.float32)
+        keys = np.zeros(len(q), dtype=np.uint32)
+        perm = np.zeros(len(q), dtype=np.uint32)
+        self.lib.emu_radix_sort.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32,
+                                            c_uint32, c_void_p, c_void_p]
+        self.lib.emu_radix_sort.restype = None
+        self.lib.emu_radix_sort(q.ctypes.data, d, len(q), lo.ctypes.data, inv.ctypes.data, bits.ctypes.data,
+                                int(bits.sum()), int(tile), keys.ctypes.data, perm.ctypes.data)
+        return perm, keys
+
 
 def emulated_forest_knn(pts, max_leaf, n_trees, seed, q, k, max_leaves):
     """Host build (product code) + forest kernel under the CPU emulator.

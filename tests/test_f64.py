@@ -241,6 +241,19 @@ def test_gpu_double_device_tensors_and_python_api(gpu, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_double_k_larger_than_the_tree(gpu):
+    """k > n_points on a float64 tree: as the float32 entry (tests/test_gpu_parity.py::test_k_larger_than_the_tree):
+    the n neighbours in order, the DBL_MAX sentinel in the last slot (search_visitor.hpp:95-110)."""
+    rng = np.random.default_rng(44)
+    pts, q = rng.random((7, 3)), rng.random((50, 3))
+    t = pt.KdTree(pts, pt.Metric.L2Squared, 3, device=gpu)
+    ref = oracle.Oracle(pts, 3, "port", dtype=np.float64)
+    got, want = t.search_knn(q, 12), ref.search_knn(q, 7)
+    assert got.shape == (50, 12) and same(got[:, :7], want["index"], want["distance"])
+    assert np.all(got["distance"][:, 11] == np.finfo(np.float64).max)
+
+
+@pytest.mark.gpu
 def test_gpu_double_large_batch_in_pieces(gpu, monkeypatch):
     """More queries than one launch's stack block holds (deep tree: many slots per lane)."""
     monkeypatch.setenv("PTK_STACK64_MB", "64")

@@ -136,6 +136,20 @@ def test_morton_keys_follow_the_curve():
     assert keys.tolist() == [0b111, 0b011, 0b100]
 
 
+@pytest.mark.parametrize("nq,bits,tile", [(4_000, (6, 5, 5), 256), (4_096, (8, 8, 8), 512), (777, (3, 2, 1), 64),
+                                          (64, (8, 8, 0), 64), (1, (8, 8, 8), 256), (9_001, (11, 10, 3), 1024)])
+def test_own_radix_sort_is_the_stable_sort_of_the_keys(nq, bits, tile):
+    """ptk_sort.hpp (histogram / scan / scatter per 8-bit pass) against numpy's stable argsort of the same keys,
+    incl. a ragged last tile, a last pass of fewer than 8 bits, heavy duplicates (6 key bits for 777 items)."""
+    pts = ds.lidar_cloud(3_000, seed=5)
+    emu = EmulatedTree(pts, 10)
+    q = ds.lidar_cloud(nq, seed=6, pose=(1.0, 0.5))
+    perm, keys = emu.radix_sorted_permutation(q, bits, tile)
+    _, want_keys = emu.morton_permutation(q, bits)
+    assert np.array_equal(keys, want_keys)
+    assert np.array_equal(perm, np.argsort(keys, kind="stable").astype(np.uint32))
+
+
 @pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "self", "lidar", "root-is-leaf",
                                                                   "dim2", "leaf1")],
                          ids=lambda c: c[0])
