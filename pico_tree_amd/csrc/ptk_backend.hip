@@ -101,6 +101,10 @@ struct Workspace {
   hipEvent_t done = nullptr;
   bool has_work = false;
   const uint32_t* last_meta = nullptr;  // Cont::meta of the last two-phase k = 1 search (ptk_debug_knn1_counts)
+  // Second stream of a small k = 1 batch: the cooperative search of the ranked classes runs beside phase 2
+  // (launch_knn1_two_phase); forked and joined with events, so the caller's stream still orders everything.
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
 
   // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
   // it must survive until the fill pass of the same batch while other searches reuse `base`.
@@ -512,6 +516,26 @@ class Scratch {
     return PTK_OK;
   }
   void note_meta(const uint32_t* meta) { ws_.last_meta = meta; }
+  // The second stream of this scratch block and its two events (made on first use); false if they cannot be had.
+  bool side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
+    if (ws_.side == nullptr) {
+      if (hipStreamCreateWithFlags(&ws_.side, hipStreamNonBlocking) != hipSuccess) {
+        ws_.side = nullptr;
+        (void)hipGetLastError();
+        return false;
+      }
+    }
+    if (ws_.fork == nullptr && hipEventCreateWithFlags(&ws_.fork, hipEventDisableTiming) != hipSuccess) ws_.fork = nullptr;
+    if (ws_.join == nullptr && hipEventCreateWithFlags(&ws_.join, hipEventDisableTiming) != hipSuccess) ws_.join = nullptr;
+    if (ws_.fork == nullptr || ws_.join == nullptr) {
+      (void)hipGetLastError();
+      return false;
+    }
+    *side = ws_.side;
+    *fork = ws_.fork;
+    *join = ws_.join;
+    return true;
+  }
   template <class T>
   T* take(size_t count) {
     const size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
@@ -876,21 +900,40 @@ size_t class_sort_tmp_bytes(uint64_t nq) {
 // each); further ones are searched again from the root.
 uint64_t max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 32, std::min<uint64_t>(nq, 16384)); }
 
-// The class order as a counting sort: chunks of kClassPer slots, one wavefront each.
-constexpr uint32_t kClassPer = 1792;  // 7 rounds of 4 x 64 keys
-uint32_t class_chunks(uint64_t nq) { return (uint32_t)((nq + kClassPer - 1) / kClassPer); }
-size_t class_scan_tmp_bytes(uint64_t nq) {
-  size_t tmp_bytes = 0;
-  uint32_t* p = nullptr;
-  (void)rocprim::exclusive_scan(nullptr, tmp_bytes, p, p, 0u, (size_t)ptk::kClassBuckets * class_chunks(nq),
-                                rocprim::plus<uint32_t>(), (hipStream_t) nullptr);
-  return tmp_bytes + 256;
+// The class order as a counting sort (ptk_kernels.hpp, class_scan_kernel / class_order_kernel): phase 1 counts its
+// own tile of 64 slots; the rows of counters are scanned in at most kClassMaxSegs segments of a multiple of 1024
+// tiles; the scatter takes chunks of `per` slots, one wavefront each (short chains for a small batch).
+struct ClassPlan {
+  uint32_t ntiles, stride, seg, segs, per, chunks;
+};
+ClassPlan class_plan(uint64_t nq) {
+  ClassPlan p;
+  p.ntiles = (uint32_t)((nq + 63) / 64);
+  p.stride = (p.ntiles + 3u) & ~3u;
+  p.seg = 1024u * std::max<uint32_t>(1u, (p.ntiles + 1024u * ptk::kClassMaxSegs - 1u) / (1024u * ptk::kClassMaxSegs));
+  p.segs = (p.ntiles + p.seg - 1u) / p.seg;
+  p.per = (uint32_t)std::max(64, env_int("PTK_CLASS_PER", nq < (2ull << 20) ? 512 : 1792)) & ~63u;
+  p.chunks = (uint32_t)((nq + p.per - 1) / p.per);
+  return p;
 }
+
+// The cooperative search: 16 lanes per query, a pool of 96 subtrees per group (8 / 32 / 64 lanes were measured:
+// 1.91 / 1.90 / slower vs 1.72 ms of traversal kernels, profiles/r02_notes.txt items 6, 12).
+constexpr int kCoopLanes = 16, kCoopPool = 96;
+// Tasks a group of the cooperative search may park in HBM when its LDS pool is full.
+constexpr uint32_t kCoopSpill = 256;
+inline int coop_waves() {
+  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
+  // As many waves as can be resident at once (LDS-bound; 256 CUs x 160 KiB), each group working
+  // through its share of the list: a second round of blocks would start when most of the work is done.
+  return 256 * (int)std::min<size_t>(24, (160 * 1024) / (smem + 512));
+}
+size_t coop_spill_bytes() { return (size_t)coop_waves() * (64 / kCoopLanes) * kCoopSpill * sizeof(ptk::Task); }
 
 size_t two_phase_scratch_bytes(uint64_t nq) {
   return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 4 * nq +
-         2 * (nq * 4) + 3 * (nq * 4) + max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + 64 +
-         class_sort_tmp_bytes(nq) + 2 * (size_t)ptk::kClassBuckets * class_chunks(nq) * 4 + class_scan_tmp_bytes(nq) + 1024;
+         2 * (nq * 4) + 3 * (nq * 4) + max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + 64 + 2 * coop_spill_bytes() +
+         class_sort_tmp_bytes(nq) + (size_t)ptk::kClassBuckets * (class_plan(nq).stride + ptk::kClassMaxSegs) * 4 + 2048;
 }
 
 // Far children a query may enter in phase 2 before it is handed to the cooperative search
@@ -905,20 +948,50 @@ uint32_t phase2_cap(float e, uint64_t nq) {
   return cap < 0 ? 0u : (uint32_t)cap;
 }
 
-// The cooperative search: 16 lanes per query, a pool of 96 subtrees per group (8 / 32 / 64 lanes were measured:
-// 1.91 / 1.90 / slower vs 1.72 ms of traversal kernels, profiles/r02_notes.txt items 6, 12).
-constexpr int kCoopLanes = 16, kCoopPool = 96;
-int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
-                     const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s) {
-  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
-  // As many waves as can be resident at once (LDS-bound; 256 CUs x 160 KiB), each group working
-  // through its share of the list: a second round of blocks would start when most of the work is done.
-  const int waves = 256 * (int)std::min<size_t>(24, (160 * 1024) / (smem + 512));
-  hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool>), dim3(waves), dim3(64), smem, s, t->dev,
-                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list);
+// direct_ids == nullptr: the list is `ho`'s.  Otherwise it is the ranked head of the class-sorted entries, searched
+// straight from the continuation records of phase 1 (knn1_coop_kernel<.., DIRECT>), `lanes` lanes per query.
+template <int G>
+int launch_knn1_coop_direct(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
+                            const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
+                            const uint32_t* direct_ids) {
+  constexpr size_t smem = (size_t)(64 / G) * (6 * kCoopPool + 1) * 4;
+  // (the spill block is sized for coop_waves() x 64 / kCoopLanes groups: a wider group count would not fit)
+  static_assert(G >= kCoopLanes, "the spill block is sized for groups of kCoopLanes lanes");
+  const int resident = 256 * (int)std::min<size_t>(32, (160 * 1024) / (smem + 512));
+  const int waves = std::min(resident, coop_waves() * (G / kCoopLanes));
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, kCoopPool, true>), dim3(waves), dim3(64), smem, s, t->dev,
+                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, direct_ids, spill, kCoopSpill);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
+
+int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
+                     const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
+                     const uint32_t* direct_ids = nullptr) {
+  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
+  const int waves = coop_waves();
+  const uint32_t spill_cap = spill ? kCoopSpill : 0u;
+  if (direct_ids != nullptr) {
+    switch (env_int("PTK_COOP_DIRECT_LANES", 32)) {
+      case 32: return launch_knn1_coop_direct<32>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
+      case 64: return launch_knn1_coop_direct<64>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
+      default: return launch_knn1_coop_direct<16>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
+    }
+  }
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false>), dim3(waves), dim3(64), smem, s, t->dev,
+                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, nullptr, spill, spill_cap);
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+
+// How the ranked classes of an exact k = 1 batch -- 2 % of the queries, every expensive one among them -- are
+// searched (PTK_COOP_DIRECT overrides):
+//   0  by phase 2 up to the cap like everything else, what is left cooperatively afterwards
+//   1  cooperatively straight from phase 1, on the same stream, before phase 2
+//   2  the same on a second stream BESIDE phase 2.  On a small batch the capped traversal of such a query and its
+//      cooperative search are two chains of dependent rounds one after the other on a GPU that is mostly idle
+//      (900 k queries: phase 2 164 us, then the cooperative search 107 us; profiles/r03_notes.txt item 3)
+int coop_direct_mode(uint64_t nq) { return env_int("PTK_COOP_DIRECT", nq < (2ull << 20) ? 2 : 0); }
 
 // The k = 1 search under the default metric (ptk_kernels.hpp, "the two-phase k = 1 search"): phase 1 (which also
 // packs the launch-order records), the class order of the continuations, phase 2, and for exact searches the
@@ -944,6 +1017,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   if (!cont.rec || !cont.best || !cont.key || !key_out || !cont.ids || !ids_out || !cont.meta || !tmp)
     return fail(PTK_ERR_NOMEM, "scratch block too small");
   ptk::Handover ho{};
+  ho.counter = ptk::kMetaHeavy;
   ho.meta = cont.meta;
   ho.heavy_list = scratch.take<uint32_t>(nq);
   ho.ntasks = scratch.take<uint32_t>(nq);
@@ -951,6 +1025,11 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   ho.tasks = scratch.take<ptk::Task>((size_t)ho.max_heavy * ptk::kMaxTasks);
   uint32_t* redo_list = scratch.take<uint32_t>(nq);
   if (!ho.heavy_list || !ho.ntasks || !ho.tasks || !redo_list) return fail(PTK_ERR_NOMEM, "scratch block too small");
+  // Where the groups of the cooperative search park subtrees their LDS pool has no room for (one block per launch
+  // that may be in flight: the direct one on the second stream, the one behind phase 2).
+  ptk::Task* spill_a = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes()));
+  ptk::Task* spill_b = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes()));
+  if (!spill_a || !spill_b) return fail(PTK_ERR_NOMEM, "scratch block too small");
   scratch.note_meta(cont.meta);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
@@ -960,26 +1039,35 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // The grid has room for nq / 64 extra waves in the narrow tiers; the meta kernel cuts the tiers to what fits.
   const ptk::TierSpec tiers = phase2_tiers(cap);
   const uint32_t extra_waves = tiers.permille[0] == 0 ? 0u : (uint32_t)(nq / 64) + 2u;
+  // The ranked classes straight to the cooperative search (exact searches only), beside phase 2 if a second stream
+  // can be had.
+  int direct = cap ? coop_direct_mode(nq) : 0;
+  hipStream_t side = nullptr;
+  hipEvent_t fork = nullptr, join = nullptr;
+  if (direct == 2 && !scratch.side_stream(&side, &fork, &join)) direct = 1;
+  // Exact searches: phase 1 counts the class buckets of its tile for the counting sort below.
+  const ClassPlan cp = class_plan(nq);
+  uint32_t* tile_counts = nullptr;
+  uint32_t* seg_totals = nullptr;
+  if (cap) {
+    tile_counts = scratch.take<uint32_t>((size_t)ptk::kClassBuckets * cp.stride);
+    seg_totals = scratch.take<uint32_t>((size_t)ptk::kClassBuckets * ptk::kClassMaxSegs);
+    if (!tile_counts || !seg_totals) return fail(PTK_ERR_NOMEM, "scratch block too small");
+  }
   // One chain of sections: search (phase 1) | other (class order) | search (phase 2, cooperative search, replay).
   Timer timer(t, s);
   hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, t->dev, d_q, t->dim, perm, nq,
-                     e_inv, d_out, cont, qs);
+                     e_inv, d_out, cont, qs, tile_counts, cp.stride);
   timer.next(0, nq);
   if (cap) {
     // With the cap the order inside the heavy classes does not matter (no query runs long), only the three class
-    // bits do: 8 buckets -- count per chunk, scan the 8 x chunks counters, stable scatter, which also writes the tier
-    // table from the scanned counters (ptk_kernels.hpp, "the class order as a counting sort").
-    const uint32_t chunks = class_chunks(nq);
-    const size_t n_counters = (size_t)ptk::kClassBuckets * chunks;
-    uint32_t* counters = scratch.take<uint32_t>(n_counters);
-    uint32_t* offsets = scratch.take<uint32_t>(n_counters);
-    size_t scan_bytes = class_scan_tmp_bytes(nq);
-    void* scan_tmp = scratch.take<char>(scan_bytes);
-    if (!counters || !offsets || !scan_tmp) return fail(PTK_ERR_NOMEM, "scratch block too small");
-    hipLaunchKernelGGL(ptk::class_count_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer, counters);
-    PTK_HIP(rocprim::exclusive_scan(scan_tmp, scan_bytes, counters, offsets, 0u, n_counters, rocprim::plus<uint32_t>(), s));
-    hipLaunchKernelGGL(ptk::class_scatter_kernel, dim3(chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, kClassPer,
-                       offsets, ids_out, cont, tiers, extra_waves);
+    // bits do: 8 buckets, counted per tile by phase 1 -- scan of the counters, stable scatter, which also writes
+    // the tier table (ptk_kernels.hpp, "the class order from the tile counts of phase 1").
+    hipLaunchKernelGGL(ptk::class_scan_kernel, dim3(ptk::kClassBuckets * cp.segs), dim3(64), 0, s, tile_counts, cp.ntiles,
+                       cp.stride, cp.seg, seg_totals);
+    hipLaunchKernelGGL(ptk::class_order_kernel, dim3(cp.chunks), dim3(64), 0, s, cont.key, (uint32_t)nq, cp.per,
+                       tile_counts, cp.stride, cp.seg, cp.segs, seg_totals, ids_out, cont, tiers, extra_waves,
+                       direct ? 1u : 0u);
     PTK_HIP(hipGetLastError());
   } else {
     // Every query runs to its end in phase 2: the full 16-bit key (the ranked classes by how far their
@@ -989,6 +1077,24 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
                        extra_waves);
   }
   timer.next(2, 0);
+  // (a failure between fork and join must not leave the second stream working on a scratch block the next call reuses)
+  struct SideGuard {
+    hipStream_t side = nullptr;
+    ~SideGuard() {
+      if (side) (void)hipStreamSynchronize(side);
+    }
+  } side_guard;
+  if (direct == 2) {  // fork: the ranked classes, cooperatively, while phase 2 takes the rest
+    side_guard.side = side;
+    PTK_HIP(hipEventRecord(fork, s));
+    PTK_HIP(hipStreamWaitEvent(side, fork, 0));
+    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, side, spill_a, ids_out);
+    if (rc != PTK_OK) return rc;
+    PTK_HIP(hipEventRecord(join, side));
+  } else if (direct == 1) {
+    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s, spill_a, ids_out);
+    if (rc != PTK_OK) return rc;
+  }
   const dim3 p2_grid(blocks + 1 + extra_waves);
   // LDS ring of phase 2.  With the cap no stack grows deep: 12 slots = 6 KB per wave = 26 waves per CU beat
   // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt items 10, 23); without it 16 slots
@@ -1002,7 +1108,11 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   PTK_HIP(hipGetLastError());
   if (cap) {  // the queries phase 2 gave up on, then whatever the cooperative search could not certify
-    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s);
+    if (direct == 2) {  // join (both cooperative launches append to the redo list, one counter)
+      PTK_HIP(hipStreamWaitEvent(s, join, 0));
+      side_guard.side = nullptr;
+    }
+    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s, spill_b);
     if (rc != PTK_OK) return rc;
     hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(256), dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
                        e_inv, d_out, cont, redo_list);
@@ -1280,12 +1390,20 @@ void ptk_tree_destroy(ptk_tree* t) {
       if (!p.keep_b) (void)hipEventDestroy(p.b);
     }
     for (hipEvent_t e : t->profile.idle) (void)hipEventDestroy(e);
+    auto drop_side = [](Workspace& w) {
+      if (w.side) (void)hipStreamSynchronize(w.side);
+      if (w.fork) (void)hipEventDestroy(w.fork);
+      if (w.join) (void)hipEventDestroy(w.join);
+      if (w.side) (void)hipStreamDestroy(w.side);
+    };
     if (t->ws.has_work) (void)hipEventSynchronize(t->ws.done);
+    drop_side(t->ws);
     if (t->ws.done) (void)hipEventDestroy(t->ws.done);
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->ws.cap_base) (void)hipFree(t->ws.cap_base);
     for (Workspace& w : t->extra_ws) {
       if (w.has_work) (void)hipEventSynchronize(w.done);
+      drop_side(w);
       if (w.done) (void)hipEventDestroy(w.done);
       if (w.base) (void)hipFree(w.base);
     }

@@ -541,13 +541,14 @@ struct Task {
 };
 // Counters in Cont::meta (zeroed by knn1_phase_meta_kernel): queries phase 2 gave up on, the next
 // entry of that list to hand to a group, queries the cooperative search could not certify.
-constexpr uint32_t kMetaHeavy = 24, kMetaRedo = 26;
+constexpr uint32_t kMetaHeavy = 24, kMetaRedo = 26, kMetaRanked = 3;
 constexpr uint32_t kMaxTasks = 64;               // tasks a capped traversal can hand over per query
 constexpr uint32_t kTasksFromRoot = 0xFFFFFFFFu;  // more than that (or no room): search again from the root
 constexpr uint32_t kTasksRedo = 0xFFFFFFFEu;      // non-monotone box distances met: only the reference order will do
 
 // Where a capped traversal leaves its unfinished work.
 struct Handover {
+  uint32_t counter;      // word of Cont::meta that counts this list (kMetaHeavy)
   uint32_t* meta;        // Cont::meta
   uint32_t* heavy_list;  // [nq] slots of the queries handed over
   uint32_t* ntasks;      // [nq] tasks of list entry h (or kTasksFromRoot / kTasksRedo)
@@ -654,7 +655,7 @@ __device__ __forceinline__ bool traverse(
       st.drop(used);
       if (enter) {
         if (CAPPED && ++entered > cap) {
-          const uint32_t h = atomicAdd(&ho->meta[kMetaHeavy], 1u);
+          const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
           ho->heavy_list[h] = ho->slot;
           Task* out = h < ho->max_heavy ? ho->tasks + (uint64_t)h * kMaxTasks : nullptr;
           uint32_t n = 0;
@@ -989,7 +990,8 @@ __device__ __forceinline__ uint32_t uniform_value(uint32_t v) {
 template <int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
-    float e_inv, Neighbor* __restrict__ out, Cont cont, float4* __restrict__ qs_out) {
+    float e_inv, Neighbor* __restrict__ out, Cont cont, float4* __restrict__ qs_out,
+    uint32_t* __restrict__ tile_counts = nullptr, uint32_t count_stride = 0) {
   const uint64_t i0 = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
@@ -1151,10 +1153,22 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     }
     c = kept;
   }
-  if (!valid) return;
   const uint32_t cls = c > (uint32_t)kContSlots ? kContOverflow : c;
+  const ContKey ckey = make_cont_key(cls, pol.best_d);
+  if (tile_counts != nullptr) {
+    // The class order is a counting sort over the three class bits of the key (class_order_kernel below): this
+    // wavefront's 64 slots are one tile of it, counted here (lane b stores bucket b).
+    uint32_t mine = 0;
+#pragma unroll
+    for (uint32_t b = 0; b < 8; ++b) {
+      const uint32_t n = (uint32_t)__popcll(__ballot(valid && (uint32_t)(ckey >> 13) == b));
+      mine = threadIdx.x == b ? n : mine;
+    }
+    if (threadIdx.x < 8u) tile_counts[(uint64_t)threadIdx.x * count_stride + (uint32_t)(i0 / 64u)] = mine;
+  }
+  if (!valid) return;
   const uint32_t e = (uint32_t)i;
-  cont.key[e] = make_cont_key(cls, pol.best_d);
+  cont.key[e] = ckey;
   if (cont.ids != nullptr) cont.ids[e] = e;  // (the counting sort numbers the slots itself)
   if (cls == 0) {
     pol.end_query(qi);  // nothing else can be nearer: the home-leaf best is the answer
@@ -1173,6 +1187,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 //   meta[0] n2      continuations (everything before class 0)
 //   meta[1] heavy   end of the dealt tier (classes >= kHeavyClass)
 //   meta[2] waves of the dealt tier
+//   meta[3] entries of the ranked classes (the head of the list)
 //   meta[4] end of the narrow tiers     meta[5] their waves in total
 //   meta[8 + 4 i ..]  narrow tier i: {first entry, end entry, lanes per wave, first wave}
 // The narrow tiers cut the head of the ranked classes at cumulative per-mille marks.
@@ -1186,9 +1201,11 @@ struct TierSpec {
 };
 
 // The tier table of phase 2 from the three boundaries of the class-sorted list.
+// skip_ranked: the ranked classes (>= kRankedClass, the head of the list) are not phase 2's -- the cooperative
+// search takes them straight from phase 1 (knn1_coop_kernel<.., DIRECT>): the dealt tier begins behind them.
 __device__ inline void write_phase_meta(const Cont& cont, uint32_t n2, uint32_t ranked, uint32_t heavy,
-                                        const TierSpec& tiers, uint32_t max_narrow_waves) {
-  uint32_t begin = 0, wave = 0;
+                                        const TierSpec& tiers, uint32_t max_narrow_waves, bool skip_ranked = false) {
+  uint32_t begin = skip_ranked ? ranked : 0u, wave = 0;
   for (uint32_t i = 0; i < kMaxTiers; ++i) {
     uint32_t end = (uint32_t)(((uint64_t)ranked * tiers.permille[i]) / 1000u);
     if (end > heavy) end = heavy;
@@ -1209,6 +1226,7 @@ __device__ inline void write_phase_meta(const Cont& cont, uint32_t n2, uint32_t 
   cont.meta[0] = n2;
   cont.meta[1] = heavy;
   cont.meta[2] = (heavy - begin + 63u) / 64u;
+  cont.meta[kMetaRanked] = ranked;
   cont.meta[4] = begin;
   cont.meta[5] = wave;
   cont.meta[kMetaHeavy] = 0;
@@ -1233,68 +1251,113 @@ __global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, u
   write_phase_meta(cont, n2, ranked, heavy, tiers, max_narrow_waves);
 }
 
-// ---- the class order as a counting sort (the shipped form) -----------------------------------------
-// With the cap only the three class bits of a key matter, i.e. 8 buckets: a stable counting sort in
-// two passes over the 2-byte keys -- count per chunk, scan of the 8 x chunks counters (bucket-major),
-// stable scatter of the slot numbers -- instead of a general radix sort of (key, value) pairs with its
-// histogram, look-back state and their memsets; and the tier table comes from the scanned counters
-// (the first counter of every bucket IS where the bucket starts) instead of binary searches.
-// One wavefront per chunk of `per` consecutive slots; everything wave-synchronous (ballots), no LDS.
+// ---- the class order as a counting sort ----------------------------------------------------------------
+// With the cap only the three class bits of a key matter, i.e. 8 buckets: a stable counting sort over the 2-byte
+// keys -- count per tile, scan of the 8 rows of counters, stable scatter of the slot numbers -- instead of a general
+// radix sort of (key, value) pairs with its histogram, look-back state and their memsets; and the tier table comes
+// from the scanned counters (where a bucket starts) instead of binary searches.  Everything wave-synchronous
+// (ballots), no LDS.
 constexpr uint32_t kClassBuckets = 8;
 
-__global__ __launch_bounds__(64) void class_count_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
-                                                         uint32_t* __restrict__ counters) {
-  const uint32_t chunk = blockIdx.x, chunks = gridDim.x;
-  const uint32_t lo = chunk * per;
-  const uint32_t hi = lo + per < nq ? lo + per : nq;
-  uint32_t c[kClassBuckets];
-#pragma unroll
-  for (uint32_t b = 0; b < kClassBuckets; ++b) c[b] = 0;
-  for (uint32_t i = lo; i < hi; i += 256u) {  // four tiles of 64 per round trip
-    uint32_t k[4];
+// ---- the class order from the tile counts of phase 1 (the shipped form) ---------------------------------------
+// Phase 1 leaves counts[b * stride + tile] = slots of bucket b in tile `tile` (64 consecutive slots).  Two launches
+// instead of count + library scan (two launches of its own) + scatter:
+//   class_scan_kernel     the rows are cut into segments of `seg` tiles (a multiple of 4), one wavefront each:
+//                         exclusive prefix inside the segment, in place; segment total -> seg_totals[b * segs + s]
+//   class_order_kernel    chunk of `per` slots per wavefront, as class_scatter_kernel; where bucket b of the chunk
+//                         goes = (everything in earlier buckets and earlier segments: a prefix over the flattened
+//                         bucket-major table of segment totals, at most 128 words) + the prefix of its first tile
+constexpr uint32_t kClassMaxSegs = 16;
+
+__global__ __launch_bounds__(64) void class_scan_kernel(uint32_t* __restrict__ counts, uint32_t ntiles, uint32_t stride,
+                                                        uint32_t seg, uint32_t* __restrict__ seg_totals) {
+  const uint32_t lane = threadIdx.x;
+  const uint32_t segs = gridDim.x / kClassBuckets;
+  const uint32_t b = blockIdx.x / segs, sg = blockIdx.x % segs;
+  const uint32_t t0 = sg * seg;                                    // first tile of the segment (a multiple of 4)
+  const uint32_t t1 = t0 + seg < ntiles ? t0 + seg : ntiles;       // one past its last tile
+  uint4* row = reinterpret_cast<uint4*>(counts + (uint64_t)b * stride + t0);
+  const uint32_t n4 = (t1 - t0 + 3u) / 4u;                         // (stride is a multiple of 4: the row has room)
+  uint32_t carry = 0;
+  for (uint32_t c0 = 0; c0 < n4; c0 += 256u) {
+    uint4 v[4];
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
-      const uint32_t j = i + u * 64u + threadIdx.x;
-      k[u] = j < hi ? (uint32_t)(keys[j] >> 13) : kClassBuckets;
+      const uint32_t i4 = c0 + lane * 4u + u;
+      v[u] = i4 < n4 ? row[i4] : make_uint4(0u, 0u, 0u, 0u);
+      const uint32_t e = t0 + i4 * 4u;  // (what lies behind the last tile was never written)
+      v[u].x = e + 0u < t1 ? v[u].x : 0u;
+      v[u].y = e + 1u < t1 ? v[u].y : 0u;
+      v[u].z = e + 2u < t1 ? v[u].z : 0u;
+      v[u].w = e + 3u < t1 ? v[u].w : 0u;
     }
+    uint32_t sum = 0;
+#pragma unroll
+    for (uint32_t u = 0; u < 4; ++u) sum += v[u].x + v[u].y + v[u].z + v[u].w;
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+      if ((int)lane >= d) incl += up;
+    }
+    uint32_t run = carry + incl - sum;
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
-#pragma unroll
-      for (uint32_t b = 0; b < kClassBuckets; ++b) c[b] += (uint32_t)__popcll(__ballot(k[u] == b));
+      uint4 o;
+      o.x = run;
+      o.y = o.x + v[u].x;
+      o.z = o.y + v[u].y;
+      o.w = o.z + v[u].z;
+      run = o.w + v[u].w;
+      const uint32_t i4 = c0 + lane * 4u + u;
+      if (i4 < n4) row[i4] = o;
     }
+    carry += (uint32_t)__shfl((int)incl, 63);
   }
-  if (threadIdx.x < kClassBuckets) {
-    uint32_t v = c[0];
-#pragma unroll
-    for (uint32_t b = 1; b < kClassBuckets; ++b) v = threadIdx.x == b ? c[b] : v;
-    counters[threadIdx.x * chunks + chunk] = v;  // bucket-major
-  }
+  if (lane == 0u) seg_totals[blockIdx.x] = carry;
 }
 
-// `offsets` = exclusive scan of `counters` (bucket-major, 8 x chunks entries): offsets[b * chunks + c] is
-// where chunk c's slots of bucket b go.  Slot numbers are the values (phase 1 numbers its slots 0 .. nq - 1).
-// The first chunk also writes the tier table of phase 2: bucket b starts at offsets[b * chunks], which is where
-// chunk 0's slots of bucket b go.
-__global__ __launch_bounds__(64) void class_scatter_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
-                                                           const uint32_t* __restrict__ offsets,
-                                                           uint32_t* __restrict__ sorted_ids, Cont cont, TierSpec tiers,
-                                                           uint32_t max_narrow_waves) {
-  const uint32_t chunk = blockIdx.x, chunks = gridDim.x;
+// `prefix` = the counts after class_scan_kernel.  per: slots per chunk, a multiple of 64.
+__global__ __launch_bounds__(64) void class_order_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
+                                                         const uint32_t* __restrict__ prefix, uint32_t stride,
+                                                         uint32_t seg, uint32_t segs,
+                                                         const uint32_t* __restrict__ seg_totals,
+                                                         uint32_t* __restrict__ sorted_ids, Cont cont, TierSpec tiers,
+                                                         uint32_t max_narrow_waves, uint32_t skip_ranked) {
+  const uint32_t chunk = blockIdx.x, lane = threadIdx.x;
   const uint32_t lo = chunk * per;
   const uint32_t hi = lo + per < nq ? lo + per : nq;
-  const uint64_t below = (1ull << threadIdx.x) - 1ull;
-  uint32_t base[kClassBuckets];  // next free position of every bucket for this chunk
+  const uint64_t below = (1ull << lane) - 1ull;
+  const uint32_t tile0 = lo / 64u, seg0 = tile0 / seg;
+  // Exclusive prefix over the flattened table seg_totals[b * segs + s] (at most 8 x 16 words: two per lane).
+  const uint32_t n_tab = kClassBuckets * segs;
+  const uint32_t a0 = 2u * lane < n_tab ? seg_totals[2u * lane] : 0u;
+  const uint32_t a1 = 2u * lane + 1u < n_tab ? seg_totals[2u * lane + 1u] : 0u;
+  uint32_t incl = a0 + a1;
 #pragma unroll
-  for (uint32_t b = 0; b < kClassBuckets; ++b) base[b] = offsets[b * chunks + chunk];
-  if (chunk == 0 && threadIdx.x == 0) {
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t up = (uint32_t)__shfl_up((int)incl, d);
+    if ((int)lane >= d) incl += up;
+  }
+  const uint32_t ex0 = incl - a0 - a1, ex1 = ex0 + a0;  // exclusive prefixes of table entries 2 lane, 2 lane + 1
+  uint32_t base[kClassBuckets];   // next free position of every bucket for this chunk
+  uint32_t start[kClassBuckets];  // where every bucket starts in the list
+#pragma unroll
+  for (uint32_t b = 0; b < kClassBuckets; ++b) {
+    // (f and f0 are the same in every lane: the holder of table entry f is lane f / 2, the parity picks its word)
+    const uint32_t f = b * segs + seg0, f0 = b * segs;
+    base[b] = (uint32_t)__shfl((int)((f & 1u) ? ex1 : ex0), (int)(f >> 1)) + prefix[(uint64_t)b * stride + tile0];
+    start[b] = (uint32_t)__shfl((int)((f0 & 1u) ? ex1 : ex0), (int)(f0 >> 1));
+  }
+  if (chunk == 0 && lane == 0) {
     // n2 = everything before class 0, ranked = classes >= kRankedClass, heavy = classes >= kHeavyClass
-    write_phase_meta(cont, base[7], base[1], base[7u - kHeavyClass + 1u], tiers, max_narrow_waves);
+    write_phase_meta(cont, start[7], start[1], start[7u - kHeavyClass + 1u], tiers, max_narrow_waves, skip_ranked != 0u);
   }
   for (uint32_t i = lo; i < hi; i += 256u) {
     uint32_t k[4];
 #pragma unroll
     for (uint32_t u = 0; u < 4; ++u) {
-      const uint32_t j = i + u * 64u + threadIdx.x;
+      const uint32_t j = i + u * 64u + lane;
       k[u] = j < hi ? (uint32_t)(keys[j] >> 13) : kClassBuckets;
     }
 #pragma unroll
@@ -1306,7 +1369,7 @@ __global__ __launch_bounds__(64) void class_scatter_kernel(const ContKey* __rest
         if (k[u] == b) pos = base[b] + (uint32_t)__popcll(m & below);
         base[b] += (uint32_t)__popcll(m);
       }
-      const uint32_t j = i + u * 64u + threadIdx.x;
+      const uint32_t j = i + u * 64u + lane;
       if (j < hi) sorted_ids[pos] = j;
     }
   }
@@ -1460,12 +1523,25 @@ __device__ inline bool dfs_before(const DevTree& t, const uint2* __restrict__ ra
 constexpr uint32_t kCoopTieBudget = 6;  // exact ties a lane resolves per query before it asks for a redo
 
 // range: 0 = the whole list, 1 = what the heavy tiers listed, 2 = what the light tier added.
-template <int G, int POOL>
+// DIRECT: the list is the head of the class-sorted entry list -- the ranked classes, which hold every expensive
+// query (tools/analyse_cost.py) -- and a query's subtrees are its continuation records as phase 1 left them (the
+// pending-record form a capped traversal hands over: offsets 0, box distance 0 above them).  On a small batch the
+// capped traversal of such a query and its cooperative search afterwards are two chains of dependent rounds, one
+// after the other, on a GPU that is mostly idle; taken straight from phase 1 the query is searched once, beside
+// phase 2 (which then runs without the ranked classes) on a second stream.
+//
+// A group's pool of subtrees lives in LDS (POOL tasks); what does not fit goes to the group's run of `spill_cap`
+// tasks in HBM and comes back when the pool has drained (the order of the visits is free, see above).  A search
+// that starts from the home-leaf bound only (DIRECT) keeps many more subtrees alive than one that a capped
+// traversal has tightened first: without the spill 39 of 12 139 ranked queries of a 900 k-query shard overflowed
+// a pool of 96 and their single-lane replays took 1.3 ms (profiles/r03_notes.txt item 3).
+template <int G, int POOL, bool DIRECT = false>
 __global__ __launch_bounds__(64) void knn1_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
-    Handover ho, uint32_t* __restrict__ redo_list) {
+    Handover ho, uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ sorted_ids = nullptr,
+    Task* __restrict__ spill = nullptr, uint32_t spill_cap = 0) {
   static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per query");
-  static_assert(POOL >= (int)kMaxTasks, "the pool must hold a handed-over stack");
+  static_assert(DIRECT ? POOL >= 2 * kContSlots : POOL >= (int)kMaxTasks, "the pool must hold what a query starts with");
   constexpr int NG = 64 / G;
   typedef PTK_LDS uint32_t LdsU32;
   const uint4* __restrict__ nodes = t.nodes;
@@ -1476,7 +1552,9 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   const uint64_t below = gmask & ((1ull << lane) - 1ull);  // lanes of this group before this one
   LdsU32* pool = (LdsU32*)ptk_smem + g * (6 * POOL);       // [field][slot] of this group
   LdsU32* gbest = (LdsU32*)ptk_smem + NG * (6 * POOL) + g;  // bits of the group's best distance
-  const uint32_t n_heavy = cont.meta[kMetaHeavy];
+  const uint32_t n_heavy = DIRECT ? cont.meta[kMetaRanked] : cont.meta[ho.counter];
+  Task* const spill_g = spill + (uint64_t)(blockIdx.x * (uint32_t)NG + g) * spill_cap;  // this group's run
+  uint32_t spill_n = 0;  // tasks in it (the same value in every lane of the group)
 
   bool have = false, exhausted = false, busy = false, failed = false;
   uint32_t count = 0;  // subtrees in the pool (the same value in every lane of the group)
@@ -1504,7 +1582,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         const uint32_t idx = next_idx;
         next_idx += gridDim.x * (uint32_t)NG;
         if (idx < n_heavy) {
-          e = ho.heavy_list[idx];
+          e = DIRECT ? sorted_ids[idx] : ho.heavy_list[idx];
           const float4 qrec = qs[e];
           qx = qrec.x;
           qy = qrec.y;
@@ -1513,8 +1591,9 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
           const uint4 st = cont.best[e];
           start_i = st.x;
           start_d = __uint_as_float(st.y);
-          const uint32_t nt = ho.ntasks[idx];
+          const uint32_t nt = DIRECT ? (st.z == kContOverflow ? kTasksFromRoot : st.z) : ho.ntasks[idx];
           have = true;
+          spill_n = 0;
           busy = false;
           // A best of exactly 0 cannot be improved on: nothing to search.
           failed = (start_d != 0.0f && !(start_d >= 1e-30f && start_d <= 1e30f)) || nt == kTasksRedo;
@@ -1533,6 +1612,17 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
               pool[3 * POOL] = 0u;
               pool[4 * POOL] = 0u;
               pool[5 * POOL] = 0u;
+            }
+          } else if (DIRECT) {  // the continuation records, shallowest first: the deepest is the next to visit
+            count = nt;
+            for (uint32_t i = gl; i < nt; i += G) {
+              const Record r = cont.record(e, i);
+              pool[0 * POOL + i] = r.x;
+              pool[1 * POOL + i] = r.y;
+              pool[2 * POOL + i] = 0u;
+              pool[3 * POOL + i] = 0u;
+              pool[4 * POOL + i] = 0u;
+              pool[5 * POOL + i] = r.y | 0x80000000u;  // largest box distance so far = its own; pending-record form
             }
           } else {  // the capped traversal's stack, next-to-visit on top
             count = nt;
@@ -1553,6 +1643,21 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
           exhausted = true;
         }
       }
+    }
+    // A drained pool takes back what had to be parked in HBM (the newest first, up to half a pool).
+    if (have && count == 0u && spill_n != 0u) {
+      const uint32_t m = spill_n < (uint32_t)(POOL / 2) ? spill_n : (uint32_t)(POOL / 2);
+      for (uint32_t i = gl; i < m; i += G) {
+        const Task k = spill_g[spill_n - m + i];
+        pool[0 * POOL + i] = k.ref;
+        pool[1 * POOL + i] = __float_as_uint(k.nbd);
+        pool[2 * POOL + i] = __float_as_uint(k.off0);
+        pool[3 * POOL + i] = __float_as_uint(k.off1);
+        pool[4 * POOL + i] = __float_as_uint(k.off2);
+        pool[5 * POOL + i] = __float_as_uint(k.gmax);
+      }
+      count = m;
+      spill_n -= m;
     }
     if (__ballot(have) == 0ull) break;
 
@@ -1685,18 +1790,32 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         pool[3 * POOL + sl] = __float_as_uint(p_off1);
         pool[4 * POOL + sl] = __float_as_uint(p_off2);
         pool[5 * POOL + sl] = __float_as_uint(p_gmax);
+      } else if (spill_n + (sl - (uint32_t)POOL) < spill_cap) {  // no room in LDS: parked in HBM
+        Task k;
+        k.ref = p_ref;
+        k.nbd = p_nbd;
+        k.off0 = p_off0;
+        k.off1 = p_off1;
+        k.off2 = p_off2;
+        k.gmax = p_gmax;
+        spill_g[spill_n + (sl - (uint32_t)POOL)] = k;
       }
     }
     count += (uint32_t)__popcll(pmask);
-    if (count > (uint32_t)POOL) {  // a subtree was lost: this query cannot be certified here
-      failed = true;
-      count = 0;
-      busy = false;
+    if (count > (uint32_t)POOL) {
+      spill_n += count - (uint32_t)POOL;
+      count = (uint32_t)POOL;
+      if (spill_n > spill_cap) {  // a subtree was lost: this query cannot be certified here
+        failed = true;
+        count = 0;
+        spill_n = 0;
+        busy = false;
+      }
     }
 
     // A query is done when its pool is empty and no lane of the group holds a subtree.
     const uint64_t bmask = __ballot(busy) & gmask;
-    const bool done = have && count == 0u && bmask == 0ull;
+    const bool done = have && count == 0u && spill_n == 0u && bmask == 0ull;
     if (__ballot(done) != 0ull) {
       const float dstar = __uint_as_float(*gbest);
       // (A minimum of exactly 0 is safe -- every term of such a distance is 0, so is every box

@@ -484,6 +484,8 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
 //   7  cap 1, 8 lanes per query            8  cap 3, 32 lanes per query
 // emu_last_coop(): {queries phase 2 gave up on, queries the cooperative search could not certify}.
 static uint32_t g_last_heavy = 0, g_last_redo = 0;
+uint32_t g_last_spilled = 0;
+uint32_t emu_last_spilled() { return g_last_spilled; }  // spill slots the cooperative launches of variant 9 wrote
 void emu_last_coop(uint32_t* heavy, uint32_t* redo) {
   *heavy = g_last_heavy;
   *redo = g_last_redo;
@@ -501,11 +503,19 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   std::vector<ptk::ContKey> ckey(nq, 0xEEEE);
   std::vector<uint32_t> cids(nq, 0xEEEEEEEEu), meta(ptk::kMetaWords, 0);
   ptk::Cont cont{cbest.data(), crec.data(), ckey.data(), cids.data(), meta.data(), nq};
-  if (variant < 3 || variant > 8) return -3;
+  if (variant < 3 || variant > 9) return -3;
+  // the class order of the capped variants: tile counts from phase 1, scanned in segments of 4 tiles (so that
+  // small batches exercise several segments), chunks of 192 slots
+  const uint32_t ntiles = (uint32_t)((nq + 63) / 64), cstride = (ntiles + 3u) & ~3u;
+  const uint32_t cseg = 4u * std::max<uint32_t>(1u, (ntiles + 4u * ptk::kClassMaxSegs - 1u) / (4u * ptk::kClassMaxSegs));
+  const uint32_t csegs = (ntiles + cseg - 1u) / cseg;
+  std::vector<uint32_t> tile_counts((size_t)ptk::kClassBuckets * cstride, 0xEEEEEEEEu);
   {
     std::vector<float4> packed(nq);  // written by the kernel itself
     for_each_wave((uint32_t)((nq + 63) / 64), [&] {
-      if (variant != 4)
+      if (variant >= 5)
+        ptk::knn1_phase1u_kernel<4>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data(), tile_counts.data(), cstride);
+      else if (variant != 4)
         ptk::knn1_phase1u_kernel<4>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
       else
         ptk::knn1_phase1u_kernel<1>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
@@ -536,18 +546,21 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     tiers.permille[0] = 60; tiers.lanes[0] = 4;
   }
   if (variant >= 5) {  // the shipped class order: counting sort over the three class bits + tier table from the counters
-    const uint32_t per = 200, chunks = (uint32_t)((nq + per - 1) / per);
-    std::vector<uint32_t> counters((size_t)ptk::kClassBuckets * chunks, 0xEEEEEEEEu), offsets(counters.size());
-    for_each_wave(chunks, [&] { ptk::class_count_kernel(ckey.data(), (uint32_t)nq, per, counters.data()); });
-    uint32_t run = 0;
-    for (size_t i = 0; i < counters.size(); ++i) {
-      offsets[i] = run;
-      run += counters[i];
+    const uint32_t per = 192, chunks = (uint32_t)((nq + per - 1) / per);
+    {
+      uint64_t run = 0;  // the counts of phase 1 cover every slot once
+      for (uint32_t b = 0; b < ptk::kClassBuckets; ++b)
+        for (uint32_t tl = 0; tl < ntiles; ++tl) run += tile_counts[(size_t)b * cstride + tl];
+      if (run != nq) return -6;
     }
-    if (run != nq) return -6;
+    std::vector<uint32_t> seg_totals((size_t)ptk::kClassBuckets * ptk::kClassMaxSegs, 0xEEEEEEEEu);
+    for_each_wave(ptk::kClassBuckets * csegs, [&] {
+      ptk::class_scan_kernel(tile_counts.data(), ntiles, cstride, cseg, seg_totals.data());
+    });
     std::vector<uint32_t> by_count(nq, 0xEEEEEEEEu);
     for_each_wave(chunks, [&] {
-      ptk::class_scatter_kernel(ckey.data(), (uint32_t)nq, per, offsets.data(), by_count.data(), cont, tiers, top_extra);
+      ptk::class_order_kernel(ckey.data(), (uint32_t)nq, per, tile_counts.data(), cstride, cseg, csegs, seg_totals.data(),
+                              by_count.data(), cont, tiers, top_extra, variant == 9 ? 1u : 0u);
     });
     for (uint64_t i = 0; i < nq; ++i) {
       // the same permutation as the stable sort on the class bits (the light classes keep their order)
@@ -569,13 +582,25 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     ptk::knn1_phase_meta_kernel(sorted_key.data(), (uint32_t)nq, cont, tiers, top_extra);
   }
   const uint32_t blocks = (uint32_t)((nq + 63) / 64) + 1 + top_extra;
-  const uint32_t cap = variant == 5 ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
+  const uint32_t cap = (variant == 5 || variant == 9) ? 2u : (variant == 6 || variant == 7) ? 1u : variant == 8 ? 3u : 0u;
   std::vector<uint32_t> heavy_list(nq, 0xEEEEEEEEu), redo_list(nq, 0xEEEEEEEEu), ntasks(nq, 0xEEEEEEEEu);
   // Room for the stacks of two thirds of the queries handed over at most: the rest starts from the root.
   const uint32_t max_heavy = variant == 6 ? 0u : (uint32_t)(nq / 6 + 1);
   std::vector<ptk::Task> tasks((size_t)max_heavy * ptk::kMaxTasks + 1);
-  ptk::Handover ho{meta.data(), heavy_list.data(), ntasks.data(), tasks.data(), max_heavy, 0u};
+  ptk::Handover ho{ptk::kMetaHeavy, meta.data(), heavy_list.data(), ntasks.data(), tasks.data(), max_heavy, 0u};
   const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
+  uint32_t direct_listed = 0;
+  // What the groups park in HBM: 3 waves x 4 groups (x 2 for the narrow variants) of `spill_cap` tasks.  The direct
+  // launch of variant 9 runs with a pool of 12 tasks, so the spill really is used.
+  const uint32_t spill_cap = 64;
+  std::vector<ptk::Task> spill((size_t)3 * 8 * spill_cap + 1, ptk::Task{0xEEEEEEEEu, 0, 0, 0, 0, 0});
+  if (variant == 9) {  // the ranked classes straight from phase 1 to the cooperative search, phase 2 without them
+    direct_listed = meta[ptk::kMetaRanked];
+    for_each_wave(3, [&] {
+      ptk::knn1_coop_kernel<16, 12, true>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), sorted.data(),
+                                          spill.data(), spill_cap);
+    });
+  }
   gridDim.x = blocks;
   blockDim.x = 64;
   for (uint32_t b = 0; b < blocks; ++b) {
@@ -590,16 +615,21 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
         ptk::knn1_phase2_kernel<12, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho);
     }
   }
-  g_last_heavy = meta[ptk::kMetaHeavy];
+  g_last_heavy = meta[ptk::kMetaHeavy] + direct_listed;
   g_last_redo = 0;
   if (cap) {
     for_each_wave(3, [&] {
       if (variant == 5) ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      else if (variant == 9)
+        ptk::knn1_coop_kernel<16, 64, false>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), nullptr, spill.data(),
+                                             spill_cap);
       else if (variant == 6) ptk::knn1_coop_kernel<64, 192>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
       else if (variant == 7) ptk::knn1_coop_kernel<8, 64>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
       else ptk::knn1_coop_kernel<32, 128>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
     });
   }
+  g_last_spilled = 0;
+  for (const ptk::Task& k : spill) g_last_spilled += k.ref != 0xEEEEEEEEu ? 1u : 0u;
   if (cap) {
     g_last_redo = meta[ptk::kMetaRedo];
     gridDim.x = 2;

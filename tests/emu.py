@@ -139,6 +139,11 @@ class EmulatedTree:
         self.lib.emu_last_coop(ctypes.byref(heavy), ctypes.byref(redo))
         return heavy.value, redo.value
 
+    def last_spilled(self):
+        """Spill slots (HBM) the cooperative launches of the last variant-9 ``two_phase_knn1`` call wrote."""
+        self.lib.emu_last_spilled.restype = c_uint32
+        return int(self.lib.emu_last_spilled())
+
     def morton_permutation(self, q, bits=None):
         """A permutation as the device makes it (keys from the kernel, stable sort).  `bits`: key bits per
         axis (the backend derives them from the tree, ptk_backend.hip axis_bits(); default 8 each)."""

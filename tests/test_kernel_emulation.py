@@ -197,7 +197,7 @@ def test_emulated_capped_phase2_and_cooperative_search_equal_oracle(case):
     perm, _ = emu.morton_permutation(q)
     want = ref.search_knn(q, 1)
     stats = {}
-    for variant in (5, 6, 7, 8):
+    for variant in (5, 6, 7, 8, 9):  # (9: the ranked classes straight from phase 1 to the cooperative search)
         for p in (None, perm):
             got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
             assert got.tobytes() == want.tobytes(), (name, variant)
@@ -210,6 +210,20 @@ def test_emulated_capped_phase2_and_cooperative_search_equal_oracle(case):
         assert stats[5][1] < stats[5][0] // 2
     if name == "self":                                          # a best of 0 ends the search at once
         assert stats[5][0] > 0 and stats[5][1] == 0
+
+
+def test_emulated_direct_cooperative_search_parks_subtrees_in_hbm():
+    """Variant 9 = the small-batch form: the ranked classes go straight from phase 1 to the cooperative search.  Its
+    emulated launch has a pool of 12 subtrees per group, so the queries of the scanner's blind disc (hundreds of
+    leaves each) must park subtrees in the HBM spill (and a few overflow even that and come back through the redo
+    list): results equal the reference either way."""
+    pts = ds.lidar_cloud(120_000, seed=1, unit_scale=20.0)
+    q = (_blind_disc_queries(1500) * 20.0).astype(np.float32)
+    emu = EmulatedTree(pts, 10)
+    ref = oracle.Oracle(pts, 10, "port")
+    got, _ = emu.two_phase_knn1(q, variant=9)
+    assert got.tobytes() == ref.search_knn(q, 1).tobytes()
+    assert emu.last_spilled() > 0 and emu.last_coop()[0] > 0
 
 
 @pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "dim2", "dim1", "ties", "lidar", "root-is-leaf",
