@@ -90,8 +90,10 @@ struct Profile {
 // double buffers, continuation records); asking the runtime for them on every call left
 // the GPU idle for ~0.6 ms per step (profiles/r01c_two_phase_timeline.txt), so they are
 // kept.  Calls on one handle enqueue under `mutex`; the block is reused in stream order,
-// and a call that arrives on a different stream first waits for `done` (recorded when the
-// previous call finished enqueueing).
+// and a call that arrives on a DIFFERENT stream first waits for everything the last stream
+// holds: the event for that is recorded on the last stream when the switch happens, not at
+// the end of every call (an event between two calls costs the GPU ~4 us of a 0.3 ms
+// search).  A stream searches were issued on has to be synchronised before it is destroyed.
 struct Workspace {
   std::mutex mutex;
   char* base = nullptr;
@@ -476,19 +478,22 @@ inline Workspace& workspace_for(const ptk_tree* t, hipStream_t s, bool per_strea
   return t->ws;
 }
 
+// Everything enqueued for the block's last user has finished (host wait).
+inline void drain_workspace(Workspace& ws) {
+  if (!ws.has_work) return;
+  if (hipStreamSynchronize(ws.last_stream) != hipSuccess) {  // (the stream is gone: whatever it held is waited for)
+    (void)hipGetLastError();
+    (void)hipDeviceSynchronize();
+  }
+  ws.has_work = false;
+}
+
 class Scratch {
  public:
   Scratch(const ptk_tree* t, hipStream_t s, bool per_stream = false)
       : ws_(workspace_for(t, s, per_stream)), lock_(ws_.mutex), s_(s) {}
   ~Scratch() {
     if (!reserved_) return;
-    if (ws_.done == nullptr && hipEventCreateWithFlags(&ws_.done, hipEventDisableTiming) != hipSuccess) {
-      ws_.done = nullptr;
-      (void)hipStreamSynchronize(s_);  // cannot order the next call: drain instead
-      ws_.has_work = false;
-      return;
-    }
-    (void)hipEventRecord(ws_.done, s_);
     ws_.last_stream = s_;
     ws_.has_work = true;
   }
@@ -497,7 +502,7 @@ class Scratch {
   int reserve(size_t bytes) {
     bytes += 64 * kAlign;  // alignment slack of the individual arrays
     if (bytes > ws_.capacity) {
-      if (ws_.has_work) (void)hipEventSynchronize(ws_.done);
+      drain_workspace(ws_);
       if (ws_.base) (void)hipFree(ws_.base);
       ws_.base = nullptr;
       ws_.capacity = 0;
@@ -510,7 +515,15 @@ class Scratch {
       }
       ws_.capacity = want;
     }
-    if (ws_.has_work && ws_.last_stream != s_) PTK_HIP(hipStreamWaitEvent(s_, ws_.done, 0));
+    if (ws_.has_work && ws_.last_stream != s_) {  // the block changes streams: behind all the last one holds
+      bool ordered = ws_.done != nullptr || hipEventCreateWithFlags(&ws_.done, hipEventDisableTiming) == hipSuccess;
+      ordered = ordered && hipEventRecord(ws_.done, ws_.last_stream) == hipSuccess &&
+                hipStreamWaitEvent(s_, ws_.done, 0) == hipSuccess;
+      if (!ordered) {
+        (void)hipGetLastError();
+        drain_workspace(ws_);
+      }
+    }
     ws_.used = 0;
     reserved_ = true;
     return PTK_OK;
@@ -853,7 +866,7 @@ bool prepare_capture(uint64_t nq, Workspace& ws) {
   if (nq + sub_cap * ptk::kCapSubPools >= (1ull << 32)) sub_cap = ((1ull << 32) - 1 - nq) / ptk::kCapSubPools;
   const size_t bytes = head + (nq + sub_cap * ptk::kCapSubPools) * chunk_bytes;
   if (bytes > ws.cap_capacity) {
-    if (ws.has_work) (void)hipEventSynchronize(ws.done);
+    drain_workspace(ws);
     if (ws.cap_base) (void)hipFree(ws.cap_base);
     ws.cap_base = nullptr;
     ws.cap_capacity = 0;
@@ -1108,12 +1121,14 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   PTK_HIP(hipGetLastError());
   if (cap) {  // the queries phase 2 gave up on, then whatever the cooperative search could not certify
-    if (direct == 2) {  // join (both cooperative launches append to the redo list, one counter)
+    // (the two cooperative launches may run side by side: each has its own spill block, and they append to the one
+    // redo list through one atomic counter)
+    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s, spill_b);
+    if (rc != PTK_OK) return rc;
+    if (direct == 2) {  // join: the replay needs both lists complete
       PTK_HIP(hipStreamWaitEvent(s, join, 0));
       side_guard.side = nullptr;
     }
-    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s, spill_b);
-    if (rc != PTK_OK) return rc;
     hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(256), dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
                        e_inv, d_out, cont, redo_list);
     PTK_HIP(hipGetLastError());
@@ -1396,13 +1411,13 @@ void ptk_tree_destroy(ptk_tree* t) {
       if (w.join) (void)hipEventDestroy(w.join);
       if (w.side) (void)hipStreamDestroy(w.side);
     };
-    if (t->ws.has_work) (void)hipEventSynchronize(t->ws.done);
+    drain_workspace(t->ws);
     drop_side(t->ws);
     if (t->ws.done) (void)hipEventDestroy(t->ws.done);
     if (t->ws.base) (void)hipFree(t->ws.base);
     if (t->ws.cap_base) (void)hipFree(t->ws.cap_base);
     for (Workspace& w : t->extra_ws) {
-      if (w.has_work) (void)hipEventSynchronize(w.done);
+      drain_workspace(w);
       drop_side(w);
       if (w.done) (void)hipEventDestroy(w.done);
       if (w.base) (void)hipFree(w.base);

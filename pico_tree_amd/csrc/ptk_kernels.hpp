@@ -979,8 +979,9 @@ struct Cont {
 // vector-memory pipe takes divergent 16-byte loads (59 per wave, ~48 cycles each per CU), so while
 // all lanes agree the node is fetched ONCE, through the scalar cache (s_load_dwordx4 on a
 // readfirstlane'd index), and only the per-lane arithmetic stays on the vector unit.  A ballot
-// after each step tells whether the lanes still agree.  Two descents, no LDS: the first finds the home
-// leaf and its best, the second (cache-hot) keeps the far children that pass, in registers.
+// after each step tells whether the lanes still agree.  One descent, no LDS: the far children that can still
+// matter once the home leaf has given a bound are chosen from the few with the smallest box distances, kept in
+// registers on the way down.
 __device__ __forceinline__ uint32_t uniform_value(uint32_t v) {
   return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
 }
@@ -1007,31 +1008,65 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   pol.out = out;
   pol.begin_query(qi);
 
-  // ---- first descent: home leaf ----
+  // ---- the descent to the home leaf ----
+  // Which far children can still matter is only known once the home leaf has given a bound, and a wave cannot
+  // afford a record per level (24+ levels x 8 bytes x 64 lanes of LDS, or a second descent: 12 more divergent
+  // 16-byte gathers per query on the unit that bounds this kernel, profiles/r01d).  But a continuation carries at
+  // most kContSlots records, and the far children that pass `best >= box distance` are those with the SMALLEST
+  // box distances: the kContSlots + 1 smallest seen so far are kept in registers, sorted (an insertion is seven
+  // compare / select steps).  If even the last of them passes, more than kContSlots may: the overflow class.
+  constexpr int kCand = kContSlots + 1;
+  float cand_d[kCand];
+  uint32_t cand_m[kCand];
+#pragma unroll
+  for (int j = 0; j < kCand; ++j) {
+    cand_d[j] = __uint_as_float(0x7F800000u);
+    cand_m[j] = 0xFFFFFFFFu;
+  }
+  auto candidate = [&](uint32_t idx, uint32_t axis, float left_max, float right_min, bool go_left) {
+    const float v = sel3(axis, qx, qy, qz);
+    const float dv = f_sub(go_left ? right_min : left_max, v);
+    // Descent state: box distance 0, offsets 0 => (0 - 0) + new_off, as the reference computes it.
+    const float d = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
+    const uint32_t m = idx | (axis << 28) | (go_left ? kRecSide : 0u);
+#pragma unroll
+    for (int j = kCand - 1; j >= 1; --j) {
+      const bool shift = d < cand_d[j - 1];
+      const bool here = d < cand_d[j];
+      cand_m[j] = shift ? cand_m[j - 1] : (here ? m : cand_m[j]);
+      cand_d[j] = shift ? cand_d[j - 1] : (here ? d : cand_d[j]);
+    }
+    if (d < cand_d[0]) {
+      cand_d[0] = d;
+      cand_m[0] = m;
+    }
+  };
   uint32_t ref = t.root_ref;
-  uint32_t shared_levels = 0;  // branches every lane of the wave passed together
   {
     bool together = true;
     while (together && !(ref & kLeafBit)) {
       const uint32_t uref = uniform_value(ref);
-      const uint4 nd = nodes[uref & kBranchIdxMask];
+      const uint32_t idx = uref & kBranchIdxMask;
+      const uint4 nd = nodes[idx];
       const uint32_t axis = (uref >> 29) & 3u;
       const float left_max = __uint_as_float(nd.x);
       const float right_min = __uint_as_float(nd.y);
       const float v = sel3(axis, qx, qy, qz);
       const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+      candidate(idx, axis, left_max, right_min, go_left);
       ref = go_left ? nd.z : nd.w;
       const uint64_t b = __ballot(go_left);
       together = b == 0ull || b == ~0ull;
-      ++shared_levels;
     }
     while (!(ref & kLeafBit)) {
-      const uint4 nd = nodes[ref & kBranchIdxMask];
+      const uint32_t idx = ref & kBranchIdxMask;
+      const uint4 nd = nodes[idx];
       const uint32_t axis = (ref >> 29) & 3u;
       const float left_max = __uint_as_float(nd.x);
       const float right_min = __uint_as_float(nd.y);
       const float v = sel3(axis, qx, qy, qz);
       const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
+      candidate(idx, axis, left_max, right_min, go_left);
       ref = go_left ? nd.z : nd.w;
     }
   }
@@ -1055,52 +1090,39 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     }
   }
 
-  // ---- second descent: the far children that can still matter, shallowest first ----
+  // ---- the far children that can still matter, shallowest first ----
+  // The candidates are sorted by box distance, so those that pass are a prefix; along a root-to-leaf path the
+  // branch numbers of the depth-first layout increase, so sorting the survivors by branch number is sorting them
+  // by depth (a 12-comparator network; the slots behind the survivors sort to the end).
   Record keep[kContSlots];
   uint32_t c = 0;
-  auto consider = [&](uint32_t idx, uint32_t axis, float left_max, float right_min, bool go_left) {
-    const float v = sel3(axis, qx, qy, qz);
-    const float dv = f_sub(go_left ? right_min : left_max, v);
-    // First descent state: box distance 0, offsets 0 => (0 - 0) + new_off, as the reference computes it.
-    const float far_nbd = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
-    if (pol.max() >= far_nbd) {
-      Record r;
-      r.x = idx | (axis << 28) | (go_left ? kRecSide : 0u);
-      r.y = __float_as_uint(far_nbd);
 #pragma unroll
-      for (int s = 0; s < kContSlots; ++s) {
-        if (c == (uint32_t)s) keep[s] = r;
-      }
-      ++c;
-    }
-  };
+  for (int j = 0; j < kCand; ++j) c += pol.max() >= cand_d[j] ? 1u : 0u;
   {
-    uint32_t r2 = t.root_ref;
-    // The lanes agreed on exactly the first `shared_levels` steps of the first descent (the last of
-    // which is where they parted); the same holds here because the steps are the same.
-    for (uint32_t l = 0; l < shared_levels; ++l) {
-      const uint32_t uref = uniform_value(r2);
-      const uint32_t idx = uref & kBranchIdxMask;
-      const uint4 nd = nodes[idx];
-      const uint32_t axis = (uref >> 29) & 3u;
-      const float left_max = __uint_as_float(nd.x);
-      const float right_min = __uint_as_float(nd.y);
-      const float v = sel3(axis, qx, qy, qz);
-      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
-      consider(idx, axis, left_max, right_min, go_left);
-      r2 = go_left ? nd.z : nd.w;
+    uint32_t key[kContSlots];
+#pragma unroll
+    for (int j = 0; j < kContSlots; ++j) {
+      keep[j].x = cand_m[j];
+      keep[j].y = __float_as_uint(cand_d[j]);
+      key[j] = (uint32_t)j < c ? (cand_m[j] & kRecIdxMask) : 0xFFFFFFFFu;
     }
-    while (!(r2 & kLeafBit)) {
-      const uint32_t idx = r2 & kBranchIdxMask;
-      const uint32_t axis = (r2 >> 29) & 3u;
-      const uint4 nd = nodes[idx];
-      const float left_max = __uint_as_float(nd.x);
-      const float right_min = __uint_as_float(nd.y);
-      const float v = sel3(axis, qx, qy, qz);
-      const bool go_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
-      consider(idx, axis, left_max, right_min, go_left);
-      r2 = go_left ? nd.z : nd.w;
-    }
+    auto order = [&](int a, int b) {
+      const bool swap = key[a] > key[b];
+      const uint32_t ka = key[a], kb = key[b];
+      const Record ra = keep[a], rb = keep[b];
+      key[a] = swap ? kb : ka;
+      key[b] = swap ? ka : kb;
+      keep[a].x = swap ? rb.x : ra.x;
+      keep[a].y = swap ? rb.y : ra.y;
+      keep[b].x = swap ? ra.x : rb.x;
+      keep[b].y = swap ? ra.y : rb.y;
+    };
+    static_assert(kContSlots == 6, "the sorting network below is the one for six");
+    order(0, 5); order(1, 3); order(2, 4);
+    order(1, 2); order(3, 4);
+    order(0, 3); order(2, 5);
+    order(0, 1); order(2, 3); order(4, 5);
+    order(1, 2); order(3, 4);
   }
   // ---- the reference's next steps while they are leaves ----
   // The reference now pops the deepest record, tests it against the best so far and enters the far child.
