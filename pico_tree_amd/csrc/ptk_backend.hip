@@ -954,10 +954,12 @@ size_t two_phase_scratch_bytes(uint64_t nq) {
 // makes the cooperative result the reference's (ptk_kernels.hpp, knn1_coop_kernel) needs e = 1.
 // The cap is a chain length (cap x ~10 us of dependent rounds in the dealt tier): what a big batch hides behind
 // its light tier is exposed on a small one, e.g. one shard of BASELINE configs[3] -- 900 k queries: 0.556 ms per
-// step with a cap of 8, 0.604 with 16, 0.612 with 4; 7.2 M queries: 16 (profiles/r02_notes.txt items 4, 17).
+// step with a cap of 8, 0.604 with 16, 0.612 with 4 (profiles/r02_notes.txt items 4, 17).  With the ranked classes
+// taken out of phase 2 (coop_direct_mode): 900 k queries 6 / 8 / 12 / 16 = 0.247 / 0.245 / 0.265 / 0.285 ms of traversal
+// kernels, 7.2 M queries 8 / 12 / 16 / 24 / 32 = 1.287 / 1.268 / 1.255 / 1.238 / 1.271 (profiles/r03_notes.txt item 3).
 uint32_t phase2_cap(float e, uint64_t nq) {
   if (e != 1.0f) return 0;
-  const int cap = env_int("PTK_P2_CAP", nq >= (4ull << 20) ? 16 : 8);
+  const int cap = env_int("PTK_P2_CAP", nq >= (4ull << 20) ? 24 : 8);
   return cap < 0 ? 0u : (uint32_t)cap;
 }
 
@@ -991,8 +993,15 @@ int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, 
       default: return launch_knn1_coop_direct<16>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
     }
   }
-  hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false>), dim3(waves), dim3(64), smem, s, t->dev,
-                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, nullptr, spill, spill_cap);
+  // What phase 2 hands over has been tightened by its first far children: a pool of 96 holds it (0 of 152 k queries of
+  // BASELINE config 2 overflow; the spill costs the step loop 5 %).  PTK_COOP_SPILL=1: with the spill all the same
+  // (tie-prone data whose replays would be long chains).
+  if (spill_cap != 0u && env_int("PTK_COOP_SPILL", 0) != 0)
+    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, true>), dim3(waves), dim3(64), smem, s, t->dev,
+                       static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, nullptr, spill, spill_cap);
+  else
+    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, false>), dim3(waves), dim3(64), smem, s, t->dev,
+                       static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, nullptr, spill, 0u);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
@@ -1001,10 +1010,20 @@ int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, 
 // searched (PTK_COOP_DIRECT overrides):
 //   0  by phase 2 up to the cap like everything else, what is left cooperatively afterwards
 //   1  cooperatively straight from phase 1, on the same stream, before phase 2
-//   2  the same on a second stream BESIDE phase 2.  On a small batch the capped traversal of such a query and its
-//      cooperative search are two chains of dependent rounds one after the other on a GPU that is mostly idle
-//      (900 k queries: phase 2 164 us, then the cooperative search 107 us; profiles/r03_notes.txt item 3)
-int coop_direct_mode(uint64_t nq) { return env_int("PTK_COOP_DIRECT", nq < (2ull << 20) ? 2 : 0); }
+//   2  the same on a second stream BESIDE phase 2: the capped traversal of such a query and its cooperative search
+//      afterwards are two chains of dependent rounds; taken straight from phase 1 it is searched once, while phase 2
+//      works on the rest.  Scan-like cloud (profiles/r03_notes.txt item 3): 900 k queries 0.348 -> 0.245 ms of
+//      traversal kernels, 7.2 M queries 1.35 -> 1.23 ms.  A uniform cloud has no expensive queries: there the
+//      cooperative search of the ranked classes is merely the dearer way (7.2 M queries 1.31 -> 1.35 ms; 900 k queries
+//      0.255 -> 0.242 ms all the same, the GPU being mostly idle).
+// The sign of a cloud with expensive queries is a tree much deeper than a balanced one (the sliding midpoint peels
+// dense regions level by level: scan-like cloud 33 levels for 2^20 leaves, uniform cloud 23).
+int coop_direct_mode(const ptk_tree* t, uint64_t nq) {
+  uint32_t balanced = 0;
+  while ((1ull << balanced) < t->n_leaves) ++balanced;
+  const bool deep = t->max_depth >= balanced + 6u;
+  return env_int("PTK_COOP_DIRECT", deep || nq < (1ull << 20) ? 2 : 0);
+}
 
 // The k = 1 search under the default metric (ptk_kernels.hpp, "the two-phase k = 1 search"): phase 1 (which also
 // packs the launch-order records), the class order of the continuations, phase 2, and for exact searches the
@@ -1054,7 +1073,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   const uint32_t extra_waves = tiers.permille[0] == 0 ? 0u : (uint32_t)(nq / 64) + 2u;
   // The ranked classes straight to the cooperative search (exact searches only), beside phase 2 if a second stream
   // can be had.
-  int direct = cap ? coop_direct_mode(nq) : 0;
+  int direct = cap ? coop_direct_mode(t, nq) : 0;
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
   if (direct == 2 && !scratch.side_stream(&side, &fork, &join)) direct = 1;

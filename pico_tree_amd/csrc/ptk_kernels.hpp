@@ -1552,12 +1552,12 @@ constexpr uint32_t kCoopTieBudget = 6;  // exact ties a lane resolves per query 
 // after the other, on a GPU that is mostly idle; taken straight from phase 1 the query is searched once, beside
 // phase 2 (which then runs without the ranked classes) on a second stream.
 //
-// A group's pool of subtrees lives in LDS (POOL tasks); what does not fit goes to the group's run of `spill_cap`
-// tasks in HBM and comes back when the pool has drained (the order of the visits is free, see above).  A search
+// A group's pool of subtrees lives in LDS (POOL tasks); with SPILL what does not fit goes to the group's run of
+// `spill_cap` tasks in HBM and comes back when the pool has drained (the order of the visits is free, see above).  A search
 // that starts from the home-leaf bound only (DIRECT) keeps many more subtrees alive than one that a capped
 // traversal has tightened first: without the spill 39 of 12 139 ranked queries of a 900 k-query shard overflowed
 // a pool of 96 and their single-lane replays took 1.3 ms (profiles/r03_notes.txt item 3).
-template <int G, int POOL, bool DIRECT = false>
+template <int G, int POOL, bool DIRECT = false, bool SPILL = DIRECT>
 __global__ __launch_bounds__(64) void knn1_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
     Handover ho, uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ sorted_ids = nullptr,
@@ -1667,7 +1667,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
       }
     }
     // A drained pool takes back what had to be parked in HBM (the newest first, up to half a pool).
-    if (have && count == 0u && spill_n != 0u) {
+    if (SPILL && have && count == 0u && spill_n != 0u) {
       const uint32_t m = spill_n < (uint32_t)(POOL / 2) ? spill_n : (uint32_t)(POOL / 2);
       for (uint32_t i = gl; i < m; i += G) {
         const Task k = spill_g[spill_n - m + i];
@@ -1812,7 +1812,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         pool[3 * POOL + sl] = __float_as_uint(p_off1);
         pool[4 * POOL + sl] = __float_as_uint(p_off2);
         pool[5 * POOL + sl] = __float_as_uint(p_gmax);
-      } else if (spill_n + (sl - (uint32_t)POOL) < spill_cap) {  // no room in LDS: parked in HBM
+      } else if (SPILL && spill_n + (sl - (uint32_t)POOL) < spill_cap) {  // no room in LDS: parked in HBM
         Task k;
         k.ref = p_ref;
         k.nbd = p_nbd;
@@ -1825,9 +1825,11 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
     }
     count += (uint32_t)__popcll(pmask);
     if (count > (uint32_t)POOL) {
-      spill_n += count - (uint32_t)POOL;
-      count = (uint32_t)POOL;
-      if (spill_n > spill_cap) {  // a subtree was lost: this query cannot be certified here
+      if (SPILL) {
+        spill_n += count - (uint32_t)POOL;
+        count = (uint32_t)POOL;
+      }
+      if (!SPILL || spill_n > spill_cap) {  // a subtree was lost: this query cannot be certified here
         failed = true;
         count = 0;
         spill_n = 0;
@@ -1837,7 +1839,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
 
     // A query is done when its pool is empty and no lane of the group holds a subtree.
     const uint64_t bmask = __ballot(busy) & gmask;
-    const bool done = have && count == 0u && spill_n == 0u && bmask == 0ull;
+    const bool done = have && count == 0u && (!SPILL || spill_n == 0u) && bmask == 0ull;
     if (__ballot(done) != 0ull) {
       const float dstar = __uint_as_float(*gbest);
       // (A minimum of exactly 0 is safe -- every term of such a distance is 0, so is every box
