@@ -82,8 +82,9 @@ def parse_args():
                          "kernels that shared the GPU")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-streams context measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0,
-                    help="approximate budget of the OpenMP CPU baseline sample")
+    ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-seconds", type=float, default=16.0,
+                    help="approximate budget of the CPU baseline samples (OpenMP and single thread, two query orders)")
     ap.add_argument("--counter-sample", type=int, default=200_000,
                     help="queries sampled for the algorithmic-bytes visit counters")
     return ap.parse_args()
@@ -122,49 +123,124 @@ def measured_traffic(prefixes):
     return (total, os.path.basename(files[-1])) if seen else (None, None)
 
 
-def cpu_baseline(pts, q, k, leaf, seconds):
-    """Times the reference (oracle/_ref, compiled from the reference's own headers) or,
-    failing that, the oracle port, on the host cores, on a bounded sample."""
+def host_cpus():
+    """(model name, sockets, physical cores this process may run on, logical CPUs it may run on)."""
+    allowed = os.sched_getaffinity(0) if hasattr(os, "sched_getaffinity") else set(range(os.cpu_count() or 1))
+    model, cores, sockets = "unknown", set(), set()
+    try:
+        cpu, phys, core = None, None, None
+        with open("/proc/cpuinfo") as f:
+            for line in f.read().splitlines() + [""]:
+                if not line.strip():
+                    if cpu is not None and cpu in allowed:
+                        cores.add((phys, core if core is not None else cpu))
+                        sockets.add(phys)
+                    cpu, phys, core = None, None, None
+                    continue
+                key, _, val = line.partition(":")
+                key, val = key.strip(), val.strip()
+                if key == "processor":
+                    cpu = int(val)
+                elif key == "physical id":
+                    phys = int(val)
+                elif key == "core id":
+                    core = int(val)
+                elif key == "model name":
+                    model = val
+    except (OSError, ValueError):
+        pass
+    n_cores = len(cores) if cores else len(allowed)
+    return model, max(len(sockets), 1), n_cores, len(allowed)
+
+
+def cpu_baseline_subprocess(args):
+    """The CPU baseline runs in a process of its own: one OpenMP thread per PHYSICAL core, pinned
+    (OMP_PLACES=cores OMP_PROC_BIND=spread).  An OpenMP runtime that binds pins the thread that loads it as well --
+    here that would be the thread that drives the GPU and whose affinity the library's build threads inherit."""
+    import subprocess
+
+    env = dict(os.environ)
+    env["OMP_PLACES"] = "cores"
+    env["OMP_PROC_BIND"] = "spread"
+    env.pop("OMP_NUM_THREADS", None)
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cloud", args.cloud, "--order", args.order,
+           "--k", str(args.k), "--leaf", str(args.leaf), "--cpu-seconds", str(args.cpu_seconds)]
+    for name in ("n", "nq", "points", "queries"):
+        v = getattr(args, name)
+        if v is not None:
+            cmd += [f"--{name}", str(v)]
+    try:
+        out = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, check=True)
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except (subprocess.SubprocessError, ValueError, IndexError) as exc:
+        log(f"[bench] cpu baseline failed: {exc!r}")
+        return None
+
+
+def cpu_baseline_worker(args):
+    model_cores = host_cpus()  # before any OpenMP runtime is loaded and binds this thread
+    from pico_tree_amd import datasets as ds
+
+    if args.points:
+        pts, q = ds.load_points(args.points), ds.load_points(args.queries)
+    else:
+        pts, q = ds.config2_clouds(args.cloud, args.n or ds.CONFIG2_N, args.nq or ds.CONFIG2_NQ)
+    if args.order == "morton":
+        q = np.ascontiguousarray(q[ds.morton_order(q)])
+    print(json.dumps(cpu_baseline(pts, q, args.k, args.leaf, args.cpu_seconds, model_cores)), flush=True)
+
+
+def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
+    """Times the reference (oracle/_ref, compiled from the reference's own headers) or, failing that, the oracle
+    port, on the host cores, on bounded samples: its OpenMP schedule(dynamic,128) loop on one pinned thread per
+    physical core, and one thread alone; on the queries as given to the GPU and on a Morton-sorted copy (order alone
+    moves a CPU kd-tree by an order of magnitude).  Every figure: one untimed warm-up pass over
+    a slice, then passes over fresh slices until the time budget is used, rate of the median pass."""
     import oracle
+    from pico_tree_amd import datasets as ds
 
     kind = "reference" if oracle.have_reference() else "port"
     t0 = time.perf_counter()
     cpu = oracle.Oracle(pts, leaf, kind)
     build_s = time.perf_counter() - t0
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    cpu.set_threads(cores)
-    # OpenMP, schedule(dynamic, 128): chunks until the time budget is used.
-    chunk = 250_000
-    done, t_used = 0, 0.0
-    while done < len(q) and t_used < seconds:
-        part = q[done:done + chunk]
-        t0 = time.perf_counter()
-        cpu.search_knn(part, k)
-        t_used += time.perf_counter() - t0
-        done += len(part)
-    omp = done / t_used / 1e6
-    # single thread on a smaller slice
-    cpu.set_threads(1)
-    n1 = min(len(q), max(20_000, int(omp * 1e6 / cores * 3)))
-    t0 = time.perf_counter()
-    cpu.search_knn(q[:n1], k)
-    st = n1 / (time.perf_counter() - t0) / 1e6
-    # The same loop on a spatially sorted copy of a sample (scan-ordered real data looks like this;
-    # order alone moves the CPU figure several times, BASELINE.md section 2): context, not `value`.
-    from pico_tree_amd import datasets as ds
-    cpu.set_threads(cores)
-    ns = min(len(q), 2_000_000)
-    qs = np.ascontiguousarray(q[:ns][ds.morton_order(q[:ns])])
-    t0 = time.perf_counter()
-    cpu.search_knn(qs, k)
-    omp_sorted = ns / (time.perf_counter() - t0) / 1e6
+    model, sockets, cores, logical = cpus if cpus is not None else host_cpus()
+    cores = max(1, cores)
+    nsorted = min(len(q), 2_000_000)
+    q_sorted = np.ascontiguousarray(q[:nsorted][ds.morton_order(q[:nsorted])])
+
+    def rate(queries, threads, chunk, budget, min_passes=3):
+        cpu.set_threads(threads)
+        chunk = max(1, min(chunk, len(queries) // (min_passes + 1)))
+        cpu.search_knn(queries[:chunk], k)  # warm-up: pages touched, threads started
+        rates, at, used = [], chunk, 0.0
+        while (used < budget or len(rates) < min_passes) and at + chunk <= len(queries):
+            t0 = time.perf_counter()
+            cpu.search_knn(queries[at:at + chunk], k)
+            dt = time.perf_counter() - t0
+            rates.append(chunk / dt / 1e6)
+            used += dt
+            at += chunk
+        rates.sort()
+        return rates[len(rates) // 2], at - chunk, len(rates)
+
+    omp, n_omp, p_omp = rate(q, cores, 400_000, seconds * 0.45)
+    omp_sorted, n_omps, p_omps = rate(q_sorted, cores, 400_000, seconds * 0.15)
+    one, n_one, p_one = rate(q, 1, 50_000, max(1.0, seconds * 0.25))
+    one_sorted, n_ones, p_ones = rate(q_sorted, 1, 100_000, max(1.0, seconds * 0.15))
     cpu.close()
     return {"value": round(omp, 4), "unit": "Mqueries/s", "cores": cores, "kind": kind,
+            "cpu": model, "sockets": sockets, "logical_cpus": logical,
+            "threads": f"{cores} (one per physical core; OMP_PLACES={os.environ.get('OMP_PLACES')}, "
+                       f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
+            "sample": f"OpenMP schedule(dynamic,128): warm-up + {p_omp} passes of 400000 queries in the order given to "
+                      f"the GPU ({n_omp} queries), median pass",
             "morton_sorted_queries_value": round(omp_sorted, 4),
-            "morton_sorted_queries_sample": f"first {ns} queries, Morton-sorted",
-            "sample": f"first {done} of {len(q)} queries, same order as the GPU run, "
-                      f"OpenMP schedule(dynamic,128) on {cores} threads",
-            "single_thread_value": round(st, 4), "single_thread_sample": f"first {n1} queries",
+            "morton_sorted_queries_sample": f"the first {nsorted} queries Morton-sorted, warm-up + {p_omps} passes, "
+                                            f"median pass ({n_omps} queries)",
+            "single_thread_value": round(one, 4),
+            "single_thread_sample": f"warm-up + {p_one} passes of 50000 queries as given ({n_one} queries), median pass",
+            "single_thread_morton_sorted_value": round(one_sorted, 4),
+            "single_thread_morton_sorted_sample": f"warm-up + {p_ones} passes of 100000 sorted queries ({n_ones} queries)",
             "build_s": round(build_s, 3)}
 
 
@@ -274,8 +350,108 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     return res
 
 
+def shard_entry(pt, oracle, pts, q, tree, leaf, parts, b_per_q_full):
+    """One shard of BASELINE configs[3] on THIS GPU: the first ceil(nq / parts) rows of the batch against the whole
+    tree -- what each of `parts` GPUs does per step before the gather.  Step time with the profiling events off
+    (steps back to back), kernel split from a second, profiled pass; rows byte-equal to the full-batch rows."""
+    import torch
+
+    nq = len(q)
+    per = (nq + parts - 1) // parts
+    dq = torch.from_numpy(np.ascontiguousarray(q[:per])).to(f"cuda:{tree.info()['device']}")
+    out = torch.empty((per, 1, 2), dtype=torch.int32, device=dq.device)
+    steps = 50
+    for _ in range(5):
+        tree.search_knn(dq, 1, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tree.search_knn(dq, 1, out)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    tree.profile(enable=True, reset=True)
+    for _ in range(steps):
+        tree.search_knn(dq, 1, out)
+    torch.cuda.synchronize()
+    prof = tree.profile(enable=False, reset=True)
+    counts = tree.knn1_counts()
+    ref = oracle.Oracle(pts, leaf, "port")
+    sample = np.linspace(0, per - 1, num=min(4096, per), dtype=np.int64)
+    want = ref.search_knn(q[:per][sample], 1)
+    ref.close()
+    got = pt.DeviceNeighbors(out).numpy()
+    kernel_ms = prof["search_ms"] / steps
+    return {"what": f"one shard of BASELINE configs[3] on one GPU: rows [0, {per}) of the batch, the whole tree",
+            "parts": parts, "queries": per, "ms_per_step": round(ms, 4), "steps": steps,
+            "value": round(per / ms / 1e3, 3), "unit": "Mqueries/s",
+            "projected_parts_x_value": round(parts * per / ms / 1e3, 1),
+            "kernels_ms": {"reorder": round(prof["reorder_ms"] / steps, 4),
+                           "phase1": round((prof["search_ms"] - prof["search_tail_ms"]) / steps, 4),
+                           "class_order": round(prof["other_ms"] / steps, 4),
+                           "phase2_cooperative_replay": round(prof["search_tail_ms"] / steps, 4),
+                           "note": "HIP events inside the library, a second pass of the same steps"},
+            "counts": counts, "parity_sample_ok": bool(got[sample][:, None].tobytes() == want.tobytes()),
+            "rows": got, "roofline": roofline_of(b_per_q_full, per, kernel_ms)}
+
+
+def quantised_entry(pt, ds, oracle, pts, q, leaf, grid, device, steps, sample):
+    """The headline search with every coordinate of points and queries snapped to a grid (what a scan stored with a
+    few decimals looks like: exact ties between distances, coincident points)."""
+    import torch
+
+    p2 = np.ascontiguousarray(np.round(pts / grid) * grid, dtype=np.float32)
+    q2 = np.ascontiguousarray(np.round(q / grid) * grid, dtype=np.float32)
+    tree = pt.KdTree(p2, pt.Metric.L2Squared, leaf, device=device)
+    e = also_entry(pt, ds, oracle, f"L, coordinates snapped to a grid of {grid}", "generated", p2, q2, tree, leaf, steps,
+                   sample)
+    e["tree_depth"] = int(tree.info()["max_depth"])
+    e["counts"] = tree.knn1_counts()
+    return e
+
+
+def config5_entry(pt, ds, device):
+    """BASELINE configs[4]: approximate knn = 10 through the kd-forest (8 trees, leaf 32, 64 leaves per tree) on a
+    SIFT-1M-shaped synthetic cloud; recall against brute force on the GPU (tools/bench_forest.py)."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from bench_forest import exact_knn, recall
+
+    n, nq, dim, trees, leaf, leaves, k, steps = 1_000_000, 10_000, 128, 8, 32, 64, 10, 10
+    pts = ds.sift_like_cloud(n, dim, seed=1)
+    q = ds.sift_like_cloud(nq, dim, seed=2)
+    t0 = time.perf_counter()
+    forest = pt.KdForest(pts, leaf, trees, seed=1, device=device)
+    build_s = time.perf_counter() - t0
+    dq = torch.from_numpy(q).to(f"cuda:{device}")
+    res = forest.search_knn(dq, k, leaves)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        res = forest.search_knn(dq, k, leaves)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    got = res.numpy()["index"].reshape(nq, -1)
+    exact = exact_knn(torch.from_numpy(pts).to(dq.device), dq, k)
+    row_bytes = trees * leaves * leaf * dim * 4  # every leaf row a query reads
+    achieved = row_bytes * nq / (ms * 1e-3) / 1e9
+    return {"what": f"kd_forest approximate knn={k}: {trees} trees, max_leaf_size {leaf}, {leaves} leaves per tree, "
+                    f"{n} x {dim} float32 (synthetic SIFT-like mixture), {nq} queries per batch",
+            "value": round(nq / ms * 1e3, 1), "unit": "queries/s", "ms_per_batch": round(ms, 3), "steps": steps,
+            "recall_at_1": round(recall(got, exact, 1), 4), f"recall_at_{k}": round(recall(got, exact, k), 4),
+            "recall_reference": "brute force on the GPU (float32 expansion, candidates re-ranked in float64)",
+            "queue_entries_dropped": int(forest.dropped), "host_build_upload_s": round(build_s, 2),
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel": "ptk::forest_knn_kernel",
+                         "bytes_per_query": row_bytes,
+                         "note": "leaf rows only (every visited leaf's points, 512 B each); part of them is served by "
+                                 "the Infinity Cache, so this is an upper bound on the HBM share"}}
+
+
 def main():
     args = parse_args()
+    if args.cpu_baseline_worker:
+        return cpu_baseline_worker(args)
     import torch
     import torch.distributed as dist
 
@@ -326,6 +502,7 @@ def main():
     t0 = time.perf_counter()
     tree = pt.KdTree(pts, pt.Metric.L2Squared, args.leaf, device=local_rank)
     build_s = time.perf_counter() - t0
+    create = {"first_s": round(build_s, 3), "first_phases": {k_: round(v, 3) for k_, v in tree.create_phases().items()}}
     tree.set_reorder({"auto": pt.REORDER_AUTO, "on": pt.REORDER_ON, "off": pt.REORDER_OFF}[args.reorder])
     info = tree.info()
     if rank == 0:
@@ -483,6 +660,19 @@ def main():
                                       "what": "ptk_search_knn on pageable numpy arrays: 86 MB up, search, 58 MB down",
                                       "rows_equal_device_run": bool(host_rows.tobytes() == res.tobytes())}
             del host_rows
+            # (a2) one shard of configs[3] (strong scaling decided on one GPU) and its rows against the full batch
+            sh8 = shard_entry(pt, oracle, pts, q, tree, args.leaf, 8, b_per_q)
+            sh8["rows_equal_full_batch"] = bool(sh8.pop("rows").tobytes() == res[:sh8["queries"]].tobytes())
+            extras["shard_of_8"] = sh8
+            # (a3) what a second creation of the same handle takes (the first pays for loading the code object)
+            t0 = time.perf_counter()
+            tree_b = pt.KdTree(pts, pt.Metric.L2Squared, args.leaf, device=local_rank)
+            create["steady_s"] = round(time.perf_counter() - t0, 3)
+            create["steady_phases"] = {k_: round(v, 3) for k_, v in tree_b.create_phases().items()}
+            create["what"] = ("KdTree(points): host build of the tree (threads of the library), re-encoding for the "
+                              "device, upload + point gather; first = first handle of the process")
+            del tree_b
+            extras["create"] = create
             # (b) config 3 on the same clouds
             if args.cloud == "L" and args.order == "generated":
                 extras["config3"] = config3_entries(pt, oracle, pts, q, tree, dq, args.leaf, 100_000)
@@ -496,12 +686,16 @@ def main():
             tree2 = pt.KdTree(pts2, pt.Metric.L2Squared, args.leaf, device=local_rank)
             for order in ("generated", "morton"):
                 also.append(also_entry(pt, ds, oracle, oc, order, pts2, q2, tree2, args.leaf, 10, 100_000))
-            del tree2
+            del tree2, pts2, q2
+            if args.cloud == "L":  # tie-prone data: every coordinate a multiple of 0.1
+                also.append(quantised_entry(pt, ds, oracle, pts, q, args.leaf, 0.1, local_rank, 10, 100_000))
             extras["also"] = also
+            # (d) BASELINE configs[4]
+            extras["config5"] = config5_entry(pt, ds, local_rank)
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:
-            cpu = cpu_baseline(pts, q, k, args.leaf, args.cpu_seconds)
+            cpu = cpu_baseline_subprocess(args)
 
         def parallelism(w):
             return ((f"{world} x {nq} queries (one full batch per GPU), tree replicated" if w

@@ -385,6 +385,8 @@ typedef struct ptk_profile {
   double other_ms;    /* scans, fills, copies issued by the backend            */
   uint64_t launches;  /* traversal kernel launches accumulated                 */
   uint64_t queries;   /* queries those launches processed                      */
+  double search_tail_ms; /* the part of search_ms behind the first traversal kernel of a call: k = 1 -- phase 2,
+                            the cooperative search and the replay (search_ms - search_tail_ms = phase 1)   */
 } ptk_profile;
 int ptk_profile_enable(ptk_tree* tree, int on);
 int ptk_profile_get(const ptk_tree* tree, ptk_profile* out, int reset);
@@ -393,6 +395,9 @@ int ptk_profile_get(const ptk_tree* tree, ptk_profile* out, int reset);
  * cooperative search, [2] = queries that search could not certify (redone by the reference
  * traversal from the root), [3] = queries of the classes dealt across wavefronts. */
 int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
+/* Where the creation of this handle went, in ms: [0] host build of the tree (ptk_tree_create_from_points only),
+ * [1] re-encoding for the device and stream checks, [2] upload and the point gather on the device. */
+int ptk_debug_create_phases(const ptk_tree* tree, double ms[3]);
 /* How a batch of nq queries would be ordered on the device: bits[a] = bits of the Morton key spent on axis a (the
  * first three axes; in proportion to how often a root-to-leaf path of this tree splits on each).  Works on handles
  * without a device replica too. */

@@ -66,7 +66,7 @@ class _Info(Structure):
 
 class _Profile(Structure):
     _fields_ = [("search_ms", c_double), ("reorder_ms", c_double), ("other_ms", c_double),
-                ("launches", c_uint64), ("queries", c_uint64)]
+                ("launches", c_uint64), ("queries", c_uint64), ("search_tail_ms", c_double)]
 
 
 _lib = None
@@ -128,6 +128,7 @@ _SIGNATURES = {
     "ptk_profile_enable": (c_int, [c_void_p, c_int]),
     "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
     "ptk_debug_knn1_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ptk_debug_create_phases": (c_int, [c_void_p, POINTER(c_double)]),
     "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
     "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
                                              POINTER(c_void_p)]),
@@ -480,6 +481,13 @@ class KdTree:
         p = _Profile()
         _check(lib.ptk_profile_get(self._h, byref(p), int(reset)))
         return {name: getattr(p, name) for name, _ in _Profile._fields_}
+
+    def create_phases(self) -> dict:
+        """Where the creation of the handle went, in seconds (``ptk_debug_create_phases``)."""
+        self._float32_only("create_phases()")
+        ms = (c_double * 3)()
+        _check(_load().ptk_debug_create_phases(self._h, ms))
+        return {"host_build_s": ms[0] / 1e3, "encode_s": ms[1] / 1e3, "upload_s": ms[2] / 1e3}
 
     def knn1_counts(self) -> dict:
         """Counters of the last two-phase k = 1 search (``ptk_debug_knn1_counts``)."""

@@ -149,6 +149,7 @@ struct ptk_tree {
   uint32_t max_depth = 0;
   uint64_t n_leaves = 0;
   uint32_t max_leaf_count = 0;
+  double create_ms[3] = {0, 0, 0};  // host build | re-encoding + checks | upload + point gather (ptk_debug_create_phases)
 
   // device replica
   int device = kDeviceNone;
@@ -207,12 +208,16 @@ unsigned build_threads() {
 // PTK_CREATE_TIMING=1: the phases of a tree creation on stderr (tools/time_build.py).
 struct CreateClock {
   bool on;
+  double* sink;  // ptk_tree::create_ms (ptk_debug_create_phases), or null
   std::chrono::steady_clock::time_point t0;
-  CreateClock() : on(env_int("PTK_CREATE_TIMING", 0) != 0), t0(std::chrono::steady_clock::now()) {}
-  void lap(const char* what) {
-    if (!on) return;
+  explicit CreateClock(double* phases = nullptr)
+      : on(env_int("PTK_CREATE_TIMING", 0) != 0), sink(phases), t0(std::chrono::steady_clock::now()) {}
+  // slot: 0 host build, 1 re-encoding for the device (+ stream checks), 2 upload + point gather on the device
+  void lap(const char* what, int slot) {
     const auto t1 = std::chrono::steady_clock::now();
-    std::fprintf(stderr, "[ptk create] %-28s %8.2f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+    const double ms = std::chrono::duration<double, std::milli>(t1 - t0).count();
+    if (sink != nullptr && slot >= 0) sink[slot] += ms;
+    if (on) std::fprintf(stderr, "[ptk create] %-28s %8.2f ms\n", what, ms);
     t0 = t1;
   }
 };
@@ -257,10 +262,10 @@ int analyse(ptk_tree& t) {
 }
 
 int upload(ptk_tree& t, const float* points) {
-  CreateClock clock;
+  CreateClock clock(t.create_ms);
   int rc = analyse(t);
   if (rc != PTK_OK) return rc;
-  clock.lap("analyse stream");
+  clock.lap("analyse stream", 1);
   if (clock.on && t.dim <= 3)
     std::fprintf(stderr, "[ptk create] splits per root-to-leaf path: x %.2f  y %.2f  z %.2f (depth %u)\n", t.axis_splits[0],
                  t.axis_splits[1], t.axis_splits[2], t.max_depth);
@@ -305,10 +310,10 @@ int upload(ptk_tree& t, const float* points) {
   std::string err = ptk::encode_tree(t.dim, t.n_points, nullptr, t.nodes.data(), t.nodes.size(),
                                      t.indices.data(), st, enc, unsupported, /*with_points=*/false);
   if (!err.empty()) return fail(unsupported ? PTK_ERR_UNSUPPORTED : PTK_ERR_INVALID, "%s", err.c_str());
-  clock.lap("encode branch records");
+  clock.lap("encode branch records", 1);
   for (int32_t idx : t.indices)
     if (idx < 0 || (uint64_t)idx >= t.n_points) return fail(PTK_ERR_INVALID, "index out of range in the permutation");
-  clock.lap("check permutation");
+  clock.lap("check permutation", 1);
 
   static_assert(sizeof(ptk::EncNode) == sizeof(uint4) && sizeof(ptk::EncPoint) == sizeof(float4), "records");
   const size_t n_records = t.n_points + ptk::kEncLeafPad;
@@ -333,7 +338,7 @@ int upload(ptk_tree& t, const float* points) {
     if (d_idx) (void)hipFree(d_idx);
     if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error while encoding the points: %s", hipGetErrorString(he));
   }
-  clock.lap("upload + gather points");
+  clock.lap("upload + gather points", 2);
   PTK_HIP(hipMalloc(&t.d_ranges, enc.ranges.size() * sizeof(ptk::EncRange)));
   PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), enc.ranges.size() * sizeof(ptk::EncRange), hipMemcpyHostToDevice));
   t.device_bytes = enc.nodes.size() * sizeof(uint4) + n_records * sizeof(float4) +
@@ -1391,10 +1396,10 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
     internal::space_view<space_t> view(space);
     // (the two outer bounds per branch come for free while the child boxes are at hand; only the
     // topological metrics ever read them)
-    CreateClock clock;
+    CreateClock clock(t->create_ms);
     auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
                                                sliding_midpoint_max_side, true, build_threads());
-    clock.lap("host build");
+    clock.lap("host build", 0);
     t->dim = dim;
     t->n_points = n_points;
     t->nodes.resize(flat.nodes.size());
@@ -1404,7 +1409,7 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
     t->indices = std::move(flat.indices);
     t->root_min.assign(flat.root_box.min(), flat.root_box.min() + dim);
     t->root_max.assign(flat.root_box.max(), flat.root_box.max() + dim);
-    clock.lap("copy into the handle");
+    clock.lap("copy into the handle", 1);
   } catch (const std::bad_alloc&) {
     delete t;
     return fail(PTK_ERR_NOMEM, "out of memory");
@@ -2285,6 +2290,12 @@ int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
   return PTK_OK;
 }
 
+int ptk_debug_create_phases(const ptk_tree* t, double ms[3]) {
+  if (t == nullptr || ms == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  for (int i = 0; i < 3; ++i) ms[i] = t->create_ms[i];
+  return PTK_OK;
+}
+
 int ptk_debug_key_bits(const ptk_tree* t, uint64_t nq, uint32_t bits[3]) {
   if (t == nullptr || bits == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   axis_bits(t, morton_bits(nq), bits);
@@ -2310,6 +2321,7 @@ int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
         t->profile.acc.queries += p.queries;
       } else if (p.kind == 3) {  // second traversal kernel of the same search
         t->profile.acc.search_ms += ms;
+        t->profile.acc.search_tail_ms += ms;
       } else if (p.kind == 1) {
         t->profile.acc.reorder_ms += ms;
       } else {
