@@ -29,6 +29,7 @@
 #include <rocprim/device/device_scan.hpp>
 
 #include "ptk.h"
+#include "ptk_hostio.hpp"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_sort.hpp"
@@ -122,17 +123,24 @@ struct Workspace {
   hipStream_t cap_stream = nullptr;
 };
 
-// Device-side staging of the host-buffer entry points (ptk_search_knn with host pointers): kept
-// with the handle so that a call costs two copies and a search, not two hipMalloc / hipFree pairs
-// (hipFree synchronises the device) and a stream.  Calls that use it are serialised by `mutex`.
+// Staging of the host-buffer entry points (ptk_search_knn with host pointers, see ptk_hostio.hpp): device blocks
+// for a whole batch, rings of pinned host pieces, streams, events and the copy threads, kept with the handle so that
+// a call costs copies and searches, not allocations (hipFree synchronises the device; pinning memory takes
+// milliseconds).  Calls that use it are serialised by `mutex`.
 struct HostIo {
+  static constexpr int kRing = 3;  // pinned pieces per direction
   std::mutex mutex;
-  hipStream_t stream = nullptr;       // uploads and searches
-  hipStream_t down_stream = nullptr;  // downloads, behind `searched`
-  hipEvent_t searched[2] = {nullptr, nullptr};
+  hipStream_t up = nullptr, down = nullptr;
+  hipStream_t search[2] = {nullptr, nullptr};
+  hipEvent_t up_done[kRing] = {}, down_done[kRing] = {};
+  std::vector<hipEvent_t> searched;  // one per piece of the batch in flight
   char* d_in = nullptr;
   char* d_out = nullptr;
   size_t in_capacity = 0, out_capacity = 0;
+  char* h_in[kRing] = {};
+  char* h_out[kRing] = {};
+  size_t h_in_capacity = 0, h_out_capacity = 0;  // bytes per ring slot
+  std::unique_ptr<CopyPool> pool;
 };
 
 }  // namespace
@@ -1448,8 +1456,14 @@ void ptk_tree_destroy(ptk_tree* t) {
     }
     if (t->io.d_in) (void)hipFree(t->io.d_in);
     if (t->io.d_out) (void)hipFree(t->io.d_out);
-    if (t->io.stream) (void)hipStreamDestroy(t->io.stream);
-    if (t->io.down_stream) (void)hipStreamDestroy(t->io.down_stream);
+    for (int i = 0; i < HostIo::kRing; ++i) {
+      if (t->io.h_in[i]) (void)hipHostFree(t->io.h_in[i]);
+      if (t->io.h_out[i]) (void)hipHostFree(t->io.h_out[i]);
+      if (t->io.up_done[i]) (void)hipEventDestroy(t->io.up_done[i]);
+      if (t->io.down_done[i]) (void)hipEventDestroy(t->io.down_done[i]);
+    }
+    for (hipStream_t st : {t->io.up, t->io.down, t->io.search[0], t->io.search[1]})
+      if (st) (void)hipStreamDestroy(st);
     for (hipEvent_t ev : t->io.searched)
       if (ev) (void)hipEventDestroy(ev);
     if (t->d_nodes) (void)hipFree(t->d_nodes);
@@ -1726,6 +1740,55 @@ static int grow_device_block(char** p, size_t* capacity, size_t bytes) {
   return PTK_OK;
 }
 
+// Grow-only ring of pinned host pieces (the old contents are dropped).
+static int grow_pinned_ring(char* (&ring)[HostIo::kRing], size_t* capacity, size_t bytes) {
+  if (bytes <= *capacity) return PTK_OK;
+  for (char*& p : ring) {
+    if (p) (void)hipHostFree(p);
+    p = nullptr;
+  }
+  *capacity = 0;
+  const size_t want = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
+  for (char*& p : ring) {
+    if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      p = nullptr;
+      return fail(PTK_ERR_NOMEM, "out of pinned host memory (%zu bytes)", want);
+    }
+  }
+  *capacity = want;
+  return PTK_OK;
+}
+
+// The pieces a host-buffer batch goes through in: first rows of every piece (and nq at the end).
+//   k = 1   eight equal pieces, none below 256 k queries (the pipeline fills and drains by one piece on either side;
+//           a search of fewer queries is all fixed cost).  On this platform the copy engine takes uploads and
+//           downloads one after the other (48 and 56 GB/s alone, 53 GB/s together, profiles/r03a_pcie.json), so
+//           the 144 MB of BASELINE config 2 cannot pass in less than 2.7 ms; ms per batch on one box
+//           (profiles/r03_notes.txt item 7): one piece 8.5-22 (pageable copies, nothing overlapped), eight pieces 3.5,
+//           four 3.6, two 3.9; a small first and last piece around large ones (the downloads then queue behind long
+//           uploads) 3.8-4.3; uploads read by a kernel instead of the copy engine 5.2.
+//   k > 1   the general kernels end with the tail of their slowest queries (3.4 ms for ANY piece of config 3 at
+//           knn = 16), so a piece costs its tail: at most three pieces of at most 256 MB of rows.
+// PTK_HOST_PIECE = n: equal pieces of n queries (experiments).
+static std::vector<uint64_t> host_pieces(uint64_t nq, uint32_t k, bool two_phase) {
+  std::vector<uint64_t> first;
+  const int forced = env_int("PTK_HOST_PIECE", 0);
+  if (forced > 0) {
+    for (uint64_t lo = 0; lo < nq; lo += (uint64_t)forced) first.push_back(lo);
+  } else if (!two_phase) {
+    const size_t obytes = (size_t)nq * k * sizeof(ptk_neighbor);
+    const uint64_t pieces = std::min<uint64_t>(std::max<uint64_t>(obytes / (size_t(256) << 20), 1), 3);
+    const uint64_t per = (nq + pieces - 1) / pieces;
+    for (uint64_t lo = 0; lo < nq; lo += per) first.push_back(lo);
+  } else {
+    const uint64_t per = std::max<uint64_t>((nq + 7) / 8, uint64_t(1) << 18);
+    for (uint64_t lo = 0; lo < nq; lo += per) first.push_back(lo);
+  }
+  first.push_back(nq);
+  return first;
+}
+
 int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, float e, ptk_neighbor* out) {
   int rc = check_search(t, q, nq);
   if (rc != PTK_OK) return rc;
@@ -1734,54 +1797,183 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
   if (out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
-  const size_t qbytes = (size_t)nq * t->dim * sizeof(float);
-  const size_t obytes = (size_t)nq * k * sizeof(ptk_neighbor);
+  const size_t row_in = (size_t)t->dim * sizeof(float), row_out = (size_t)k * sizeof(ptk_neighbor);
   HostIo& io = t->io;
   std::lock_guard<std::mutex> lock(io.mutex);
-  if (io.stream == nullptr) PTK_HIP(hipStreamCreateWithFlags(&io.stream, hipStreamNonBlocking));
-  rc = grow_device_block(&io.d_in, &io.in_capacity, qbytes);
-  if (rc == PTK_OK) rc = grow_device_block(&io.d_out, &io.out_capacity, obytes);
+  for (hipStream_t* st : {&io.up, &io.down, &io.search[0], &io.search[1]})
+    if (*st == nullptr) PTK_HIP(hipStreamCreateWithFlags(st, hipStreamNonBlocking));
+  for (int i = 0; i < HostIo::kRing; ++i) {
+    if (io.up_done[i] == nullptr) PTK_HIP(hipEventCreateWithFlags(&io.up_done[i], hipEventDisableTiming));
+    if (io.down_done[i] == nullptr) PTK_HIP(hipEventCreateWithFlags(&io.down_done[i], hipEventDisableTiming));
+  }
+  const bool two_phase = k == 1 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED && !deep_tree(t);
+  const std::vector<uint64_t> first = host_pieces(nq, k, two_phase);
+  const uint64_t pieces = first.size() - 1;
+  uint64_t piece = 0;  // the largest piece: the size of a ring slot
+  for (uint64_t i = 0; i < pieces; ++i) piece = std::max(piece, first[i + 1] - first[i]);
+  while (io.searched.size() < pieces) {
+    hipEvent_t ev = nullptr;
+    PTK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    io.searched.push_back(ev);
+  }
+  rc = grow_device_block(&io.d_in, &io.in_capacity, (size_t)nq * row_in);
+  if (rc == PTK_OK) rc = grow_device_block(&io.d_out, &io.out_capacity, (size_t)nq * row_out);
+  const int n_search_streams = env_int("PTK_HOST_STREAMS", 2);
+  if (rc == PTK_OK) rc = grow_pinned_ring(io.h_in, &io.h_in_capacity, (size_t)piece * row_in);
+  // The rows of a piece come down in chunks of at most 32 MB, each copied into the caller's array while the next
+  // is on the link (a piece of knn = 16 rows is 300 MB: one copy per piece left the host copy exposed).
+  const uint64_t out_chunk = std::max<uint64_t>(std::min<uint64_t>(piece, (size_t(32) << 20) / row_out), 1);
+  struct Chunk {
+    uint64_t piece, lo, n;
+  };
+  std::vector<Chunk> chunks;
+  for (uint64_t pi = 0; pi < pieces; ++pi)
+    for (uint64_t lo = first[pi]; lo < first[pi + 1]; lo += out_chunk)
+      chunks.push_back(Chunk{pi, lo, std::min(out_chunk, first[pi + 1] - lo)});
+  if (rc == PTK_OK) rc = grow_pinned_ring(io.h_out, &io.h_out_capacity, (size_t)out_chunk * row_out);
   if (rc != PTK_OK) return rc;
-  if (io.down_stream == nullptr) PTK_HIP(hipStreamCreateWithFlags(&io.down_stream, hipStreamNonBlocking));
-  for (hipEvent_t& ev : io.searched)
-    if (ev == nullptr) PTK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+  if (io.pool == nullptr) {
+    const unsigned hc = std::thread::hardware_concurrency();
+    const int want = env_int("PTK_IO_THREADS", hc >= 16 ? 8 : (hc >= 4 ? (int)hc / 2 : 1));
+    io.pool.reset(new CopyPool((unsigned)std::max(0, want - 1)));  // (the calling threads copy too)
+  }
   float* d_q = reinterpret_cast<float*>(io.d_in);
   ptk_neighbor* d_out = reinterpret_cast<ptk_neighbor*>(io.d_out);
-  // Large results go down in pieces while the next piece is searched (the link is full duplex and
-  // the download of k = 16 rows takes twice as long as the search): piece c + 1 is uploaded and
-  // enqueued BEFORE the download of piece c is issued, because a copy to pageable memory keeps the
-  // calling thread until it is done.
-  // (Measured on BASELINE config 3, knn = 16, 922 MB of rows: 1 / 2 / 3 / 4 pieces 27.3 / 24.5 / 23.6 / 25.3 ms
-  // on cloud L -- every piece pays the slowest queries of its own -- and 24.6 / 21.6 / 20.7 / 20.1 on cloud U.)
-  const uint64_t pieces = std::min<uint64_t>(std::max<uint64_t>(obytes / (size_t(256) << 20), 1), 3);
-  const uint64_t per = (nq + pieces - 1) / pieces;
-  const size_t row_out = (size_t)(k ? k : 1) * sizeof(ptk_neighbor);
+  const char* src = reinterpret_cast<const char*>(q);
+  char* dst = reinterpret_cast<char*>(out);
+
+  const bool trace = env_int("PTK_HOST_TRACE", 0) != 0;
+  const auto t_begin = std::chrono::steady_clock::now();
+  auto stamp = [&](const char* what, uint64_t i) {
+    if (!trace) return;
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t_begin).count();
+    std::fprintf(stderr, "[ptk host] %9.1f us  %-22s piece %llu\n", us, what, (unsigned long long)i);
+  };
+  // What the two threads tell each other: pieces whose search has been enqueued, and whether anything failed.
+  std::mutex m;
+  std::condition_variable cv;
+  uint64_t issued = 0;
+  bool failed = false;
+  std::string down_error;
+  const int device = t->device;
+
+  std::thread downloader([&] {
+    if (hipSetDevice(device) != hipSuccess) {
+      std::lock_guard<std::mutex> l(m);
+      failed = true;
+      down_error = "hipSetDevice failed in the download thread";
+      return;
+    }
+    auto bail = [&](hipError_t he) {
+      std::lock_guard<std::mutex> l(m);
+      failed = true;
+      down_error = std::string("HIP error in the download thread: ") + hipGetErrorString(he);
+    };
+    // `e` chunks have their D2H enqueued, `c` are copied out (c <= e <= c + kRing).  A D2H is enqueued only when the
+    // search of its piece HAS finished (see the header of ptk_hostio.hpp); while a search is still running the
+    // thread copies out what has arrived.
+    const uint64_t n_chunks = chunks.size();
+    uint64_t e_ = 0, c_ = 0, searched_pieces = 0;  // pieces [0, searched_pieces) are known to be done
+    while (c_ < n_chunks) {
+      bool can_enqueue = false;
+      if (e_ < n_chunks && e_ < c_ + (uint64_t)HostIo::kRing) {
+        const uint64_t pi = chunks[e_].piece;
+        can_enqueue = pi < searched_pieces;
+        if (!can_enqueue) {
+          {
+            std::unique_lock<std::mutex> l(m);
+            if (e_ == c_) cv.wait(l, [&] { return issued > pi || failed; });  // nothing to copy out meanwhile
+            if (failed) return;
+            can_enqueue = issued > pi;
+          }
+          if (can_enqueue) {
+            const hipError_t q_ = e_ == c_ ? hipEventSynchronize(io.searched[pi]) : hipEventQuery(io.searched[pi]);
+            if (q_ == hipErrorNotReady) {
+              (void)hipGetLastError();
+              can_enqueue = false;
+            } else if (q_ != hipSuccess) {
+              return bail(q_);
+            } else {
+              searched_pieces = pi + 1;
+            }
+          }
+        }
+      }
+      if (can_enqueue) {
+        const Chunk& ch = chunks[e_];
+        const int slot = (int)(e_ % HostIo::kRing);
+        hipError_t he = hipMemcpyAsync(io.h_out[slot], io.d_out + ch.lo * row_out, (size_t)ch.n * row_out,
+                                       hipMemcpyDeviceToHost, io.down);
+        if (he == hipSuccess) he = hipEventRecord(io.down_done[slot], io.down);
+        if (he != hipSuccess) return bail(he);
+        stamp("down: D2H enqueued", e_);
+        ++e_;
+        continue;
+      }
+      // (c_ < e_ here: the search of the next piece is still running, or the ring is full)
+      const Chunk& ch = chunks[c_];
+      const int slot = (int)(c_ % HostIo::kRing);
+      const hipError_t he = hipEventSynchronize(io.down_done[slot]);
+      if (he != hipSuccess) return bail(he);
+      stamp("down: copy out", c_);
+      io.pool->copy(dst + ch.lo * row_out, io.h_out[slot], (size_t)ch.n * row_out);
+      stamp("down: copied", c_);
+      ++c_;
+    }
+  });
+
   hipError_t he = hipSuccess;
-  uint64_t down_lo = 0, down_n = 0;  // the piece waiting for its download
-  for (uint64_t c = 0, lo = 0; lo < nq && he == hipSuccess && rc == PTK_OK; ++c, lo += per) {
-    const uint64_t n = std::min<uint64_t>(per, nq - lo);
-    he = hipMemcpyAsync(d_q + lo * t->dim, q + lo * t->dim, (size_t)n * t->dim * sizeof(float), hipMemcpyHostToDevice,
-                        io.stream);
+  // The copy of piece i + 1 into its ring slot runs on the pool while piece i is issued.
+  auto start_copy_in = [&](uint64_t i) {
+    const uint64_t lo = first[i], n = first[i + 1] - lo;
+    return io.pool->start(io.h_in[i % HostIo::kRing], src + lo * row_in, (size_t)n * row_in);
+  };
+  std::shared_ptr<CopyPool::Job> copy_in = start_copy_in(0);
+  for (uint64_t i = 0; i < pieces && he == hipSuccess && rc == PTK_OK; ++i) {
+    const uint64_t lo = first[i], n = first[i + 1] - lo;
+    const int slot = (int)(i % HostIo::kRing);
+    io.pool->finish(copy_in);
+    stamp("up: copied", i);
+    if (i + 1 < pieces) {
+      // (slot of piece i + 1: its last upload, of piece i + 1 - kRing, must have left it)
+      if (i + 1 >= (uint64_t)HostIo::kRing) he = hipEventSynchronize(io.up_done[(i + 1) % HostIo::kRing]);
+      if (he != hipSuccess) break;
+      copy_in = start_copy_in(i + 1);
+    }
+    he = hipMemcpyAsync(io.d_in + lo * row_in, io.h_in[slot], (size_t)n * row_in, hipMemcpyHostToDevice, io.up);
+    if (he == hipSuccess) he = hipEventRecord(io.up_done[slot], io.up);
+    hipStream_t ss = io.search[n_search_streams > 1 ? (i & 1) : 0];  // consecutive pieces on two streams: the tail of one overlaps the next
+    if (he == hipSuccess) he = hipStreamWaitEvent(ss, io.up_done[slot], 0);
     if (he != hipSuccess) break;
-    rc = ptk_search_knn_device(t, d_q + lo * t->dim, n, k, e, d_out + lo * (k ? k : 1), io.stream);
+    rc = ptk_search_knn_device(t, d_q + lo * t->dim, n, k, e, d_out + lo * k, ss);
     if (rc != PTK_OK) break;
-    he = hipEventRecord(io.searched[c & 1], io.stream);
-    if (he == hipSuccess && down_n > 0)
-      he = hipMemcpyAsync(reinterpret_cast<char*>(out) + down_lo * row_out, io.d_out + down_lo * row_out,
-                          (size_t)down_n * row_out, hipMemcpyDeviceToHost, io.down_stream);
-    if (he == hipSuccess) he = hipStreamWaitEvent(io.down_stream, io.searched[c & 1], 0);
-    down_lo = lo;
-    down_n = n;
+    he = hipEventRecord(io.searched[i], ss);
+    if (he != hipSuccess) break;
+    stamp("up: search enqueued", i);
+    {
+      std::lock_guard<std::mutex> l(m);
+      issued = i + 1;
+      if (failed) break;
+    }
+    cv.notify_all();
   }
-  if (he == hipSuccess && rc == PTK_OK && down_n > 0)
-    he = hipMemcpyAsync(reinterpret_cast<char*>(out) + down_lo * row_out, io.d_out + down_lo * row_out,
-                        (size_t)down_n * row_out, hipMemcpyDeviceToHost, io.down_stream);
-  hipError_t hs = hipStreamSynchronize(io.stream);
-  hipError_t hd = hipStreamSynchronize(io.down_stream);
+  io.pool->finish(copy_in);  // (a piece copied ahead when the loop was left early: the caller's array is still being read)
+  {
+    std::lock_guard<std::mutex> l(m);
+    if (he != hipSuccess || rc != PTK_OK) failed = true;
+  }
+  cv.notify_all();
+  downloader.join();
+  // Nothing of this call may be in flight when the caller's arrays (and, on failure, the ring) are touched again.
+  hipError_t hs = hipSuccess;
+  for (hipStream_t st : {io.up, io.search[0], io.search[1], io.down}) {
+    const hipError_t r = hipStreamSynchronize(st);
+    if (hs == hipSuccess) hs = r;
+  }
   if (rc != PTK_OK) return rc;
   if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
+  if (!down_error.empty()) return fail(PTK_ERR_DEVICE, "%s", down_error.c_str());
   if (hs != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(hs));
-  if (hd != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(hd));
   return PTK_OK;
 }
 
