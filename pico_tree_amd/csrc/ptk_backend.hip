@@ -168,6 +168,8 @@ struct ptk_tree {
   void* d_axes = nullptr;   // dim > 3 only
   void* d_index = nullptr;  // dim > 3 only
   void* d_outer = nullptr;  // topological metrics only: float2 per branch
+  void* d_cells = nullptr;  // dim <= 3: which cells of a coarse Morton grid hold tree points (ptk::CellTable)
+  ptk::CellTable cells{};
   ptk::DevTreeND dev_nd{};
   uint64_t device_bytes = 0;
   bool gpu_layout = false;
@@ -203,6 +205,7 @@ struct DeviceGuard {
 };
 
 int env_int(const char* name, int fallback);  // defined with the launch helpers below
+void axis_bits(const ptk_tree* t, int bits, uint32_t b[3]);
 
 // Host threads for the tree build (the result does not depend on it): PTK_BUILD_THREADS, else the
 // hardware concurrency capped at 32.
@@ -345,6 +348,41 @@ int upload(ptk_tree& t, const float* points) {
     if (d_raw) (void)hipFree(d_raw);
     if (d_idx) (void)hipFree(d_idx);
     if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error while encoding the points: %s", hipGetErrorString(he));
+  }
+  {
+    // The coarse grid of occupied cells (ptk::CellTable): about 32 tree points per cell on average, the cell bits
+    // spread over the axes like the bits of the order key.  PTK_CELL_TABLE=0: none.
+    int cb = 0;
+    while ((64ull << cb) <= t.n_points) ++cb;  // floor(log2(n / 32))
+    cb = std::min(std::max(cb, 6), 22);
+    if (env_int("PTK_CELL_TABLE", 1) != 0) {
+      uint32_t b[3];
+      axis_bits(&t, cb, b);
+      float lo[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+      for (uint32_t d = 0; d < t.dim && d < 3; ++d) {
+        lo[d] = t.root_min[d];
+        const float ext = t.root_max[d] - t.root_min[d];
+        inv[d] = ext > 0 ? (float)(1u << b[d]) / ext : 0.0f;
+      }
+      const size_t n_cells = (size_t)1 << (b[0] + b[1] + b[2]);
+      uint32_t* d_counts = nullptr;
+      PTK_HIP(hipMalloc(&t.d_cells, n_cells));
+      PTK_HIP(hipMalloc((void**)&d_counts, n_cells * 4));
+      PTK_HIP(hipMemsetAsync(d_counts, 0, n_cells * 4, nullptr));
+      const uint32_t blocks = (uint32_t)((t.n_points + ptk::kBlock - 1) / ptk::kBlock);
+      hipLaunchKernelGGL(ptk::cell_count_kernel, dim3(blocks), dim3(ptk::kBlock), 0, nullptr,
+                         static_cast<const float4*>(t.d_pts), t.n_points, make_float3(lo[0], lo[1], lo[2]),
+                         make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]), d_counts);
+      hipLaunchKernelGGL(ptk::cell_class_kernel, dim3((uint32_t)((n_cells + ptk::kBlock - 1) / ptk::kBlock)),
+                         dim3(ptk::kBlock), 0, nullptr, d_counts, n_cells, static_cast<uint8_t*>(t.d_cells));
+      const hipError_t he = hipDeviceSynchronize();
+      (void)hipFree(d_counts);
+      if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error while counting the grid cells: %s", hipGetErrorString(he));
+      t.cells.occ = static_cast<const uint8_t*>(t.d_cells);
+      t.cells.inv = make_float3(inv[0], inv[1], inv[2]);
+      t.cells.bits = make_uint3(b[0], b[1], b[2]);
+      t.device_bytes += n_cells;
+    }
   }
   clock.lap("upload + gather points", 2);
   PTK_HIP(hipMalloc(&t.d_ranges, enc.ranges.size() * sizeof(ptk::EncRange)));
@@ -700,8 +738,11 @@ size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_b
 
 // Device-side Morton ordering of a batch: *perm (device, nq uint32, in `scratch`) lists the
 // query rows in launch order.
+// heavy_first (ptk::kCellsEmptyFirst / kCellsDenseFirst, 0 = plain Morton order): the queries that will be expensive
+// -- by the tree's coarse grid of cell occupancies, ptk::CellTable -- go to the front of the order: for the kernels that
+// run every query to its end in its lane.
 int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch,
-                     uint32_t** perm) {
+                     uint32_t** perm, uint32_t heavy_first = 0) {
   *perm = nullptr;
   if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
   Timer timer(t, s);
@@ -720,6 +761,12 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     lo[d] = t->root_min[d];
     const float ext = t->root_max[d] - t->root_min[d];
     inv[d] = ext > 0 ? (float)(1u << b[d]) / ext : 0.0f;
+  }
+  ptk::CellTable cells{};
+  if (heavy_first != 0u && t->cells.occ != nullptr && env_int("PTK_HEAVY_FIRST", 1) != 0) {
+    cells = t->cells;
+    cells.key_bits = (uint32_t)bits;
+    cells.mode = heavy_first;
   }
   if (own_sort(nq)) {
     // Key + histogram kernel, then per 8-bit pass: scan of the digit-by-tile histogram, stable scatter (and the
@@ -742,10 +789,10 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
       uint2* out = in == pairs_a ? pairs_b : pairs_a;
       if (first)
         hipLaunchKernelGGL((ptk::radix_hist_kernel<true>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
-                           inv3, b3, keys, in, shift, tile, stride, hist);
+                           inv3, b3, keys, in, shift, tile, stride, hist, cells);
       else
         hipLaunchKernelGGL((ptk::radix_hist_kernel<false>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
-                           inv3, b3, keys, in, shift, tile, stride, hist);
+                           inv3, b3, keys, in, shift, tile, stride, hist, ptk::CellTable{});
       hipLaunchKernelGGL(ptk::radix_scan_kernel, dim3(ptk::kRadixBins), dim3(64), 0, s, hist, tiles, stride, totals);
 #define PTK_SCATTER(F, L)                                                                                              \
   hipLaunchKernelGGL((ptk::radix_scatter_kernel<F, L>), dim3(tiles), dim3(64), smem, s, keys, in, out, ids_out,        \
@@ -765,7 +812,7 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
   hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq,
                      make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]),
-                     keys, ids);
+                     keys, ids, cells);
   PTK_HIP(rocprim::radix_sort_pairs<MortonSortConfig>(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
   *perm = ids_out;
   timer.stop(1, 0);
@@ -1472,6 +1519,7 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->d_axes) (void)hipFree(t->d_axes);
     if (t->d_index) (void)hipFree(t->d_index);
     if (t->d_outer) (void)hipFree(t->d_outer);
+    if (t->d_cells) (void)hipFree(t->d_cells);
   }
   delete t;
 }
@@ -1707,7 +1755,8 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
   if (reorder) {  // Morton order along the first three axes, whatever the dimension
-    rc = make_permutation(t, d_q, nq, s, scratch, &perm);
+    // (the general kernels run every query to its end in its lane: the expensive queries to the front of the launch)
+    rc = make_permutation(t, d_q, nq, s, scratch, &perm, t->dim <= 3 && !(k == 1 && l2) ? ptk::kCellsEmptyFirst : 0u);
     if (rc != PTK_OK) return rc;
   }
   if (t->dim > 3) {
@@ -2091,8 +2140,8 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
     if (rc != PTK_OK) return rc;
     uint32_t* perm = nullptr;
-    if (reorder) {
-      rc = make_permutation(t, d_q, nq, s, scratch, &perm);
+    if (reorder) {  // (a query costs what it finds: the densest cells to the front of the launch)
+      rc = make_permutation(t, d_q, nq, s, scratch, &perm, nd ? 0u : ptk::kCellsDenseFirst);
       if (rc != PTK_OK) return rc;
     }
     if (capture) {

@@ -228,7 +228,10 @@ struct Stack {
     lds[slot(top) * BLOCK] = pack_record(rec);
     ++top;
   }
-  static constexpr int kUnwind = 8;
+#ifndef PTK_UNWIND
+#define PTK_UNWIND 8
+#endif
+  static constexpr int kUnwind = PTK_UNWIND;
   // The newest records, rr[0] the newest; returns how many are valid (>= 1 unless empty).  They
   // stay on the stack until drop().
   __device__ __forceinline__ int peek(Record (&rr)[kUnwind]) {
@@ -383,59 +386,68 @@ struct KnnPolicy {  // search_visitor.hpp:83-123 / :198-247
 
 // Sorted k-list in REGISTERS for k <= K <= 32 (profiles/r01f_config3_*: the LDS list above
 // makes knn = 16 seven times slower per query than knn = 1 -- every accepted candidate walks a
-// divergent shift loop of ds_read / ds_write pairs).  Here an insertion is K branch-free
-// compare / select steps on registers:
+// divergent shift loop of ds_read / ds_write pairs).  Here an insertion is K branch-free steps on registers:
 //   new[j] = d < old[j-1] ? old[j-1] : (d < old[j] ? d : old[j])
 // which is insert_sorted (search_visitor.hpp:24-38) exactly: strict `<` keeps the new entry
-// BEHIND equal distances.  Slots start at FLT_MAX (the reference's sentinel, :102), so max() =
-// slot k-1 needs no fill counter; k <= n_points is enforced by the caller (kd_tree.hpp:193), hence
-// every slot below k is a real point when the search ends.
+// BEHIND equal distances.  Slots start at FLT_MAX (the reference's sentinel, :102), so max() needs no fill
+// counter; k <= n_points is enforced by the caller (kd_tree.hpp:193), hence every slot ends up a real point.
+//
+// The kernel that uses this is bound by VALU issue, not by memory (profiles/r03l_knn16_pmc.txt: 22 k vector
+// instructions per wavefront at knn = 16, 75 % of the kernel's duration, two thirds of them this chain, which the whole
+// wavefront executes whenever ONE lane has a candidate).  So the chain is as short as it gets:
+//   - the k entries live in the LAST k of the K slots (the slots below hold -inf, which nothing is smaller than:
+//     they never move), so that max() is always slot K - 1 -- no scan for slot k - 1 after every insertion;
+//   - the new distance of slot j is the MEDIAN of old[j-1], old[j] and d (old[j-1] <= old[j]: d below both -> old[j-1],
+//     between -> d, above -> old[j]): one v_med3_f32 instead of two selects; the indices follow the K comparisons
+//     d < old[j], two selects each.
+__device__ __forceinline__ float f_med3(float a, float b, float c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_fmed3f(a, b, c);
+#else
+  const float lo = a < b ? a : b, hi = a < b ? b : a;
+  return c < lo ? lo : (c < hi ? c : hi);
+#endif
+}
+
 template <int K>
 struct KnnRegPolicy {
   float ld[K];
   int32_t li[K];
   uint32_t k;
-  float worst;
   float e_inv;
   __device__ __forceinline__ void init(uint32_t k_, float e_inv_) {
     k = k_;
     e_inv = e_inv_;
-    worst = 3.402823466e+38f;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      ld[j] = 3.402823466e+38f;
+      ld[j] = (uint32_t)j + k >= (uint32_t)K ? 3.402823466e+38f : __uint_as_float(0xFF800000u);  // unused slots: -inf
       li[j] = 0;
     }
   }
-  __device__ __forceinline__ float max() const { return worst; }
+  __device__ __forceinline__ float max() const { return ld[K - 1]; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
-    if (worst > d) {
+    if (ld[K - 1] > d) {
+      bool below[K];
+#pragma unroll
+      for (int j = 0; j < K; ++j) below[j] = d < ld[j];
 #pragma unroll
       for (int j = K - 1; j >= 1; --j) {
-        const bool shift = d < ld[j - 1];
-        const bool here = d < ld[j];
-        li[j] = shift ? li[j - 1] : (here ? idx : li[j]);
-        ld[j] = shift ? ld[j - 1] : (here ? d : ld[j]);
+        li[j] = below[j - 1] ? li[j - 1] : (below[j] ? idx : li[j]);
+        ld[j] = f_med3(ld[j - 1], ld[j], d);
       }
-      if (d < ld[0]) {
-        ld[0] = d;
-        li[0] = idx;
-      }
-      float w = ld[0];
-#pragma unroll
-      for (int j = 1; j < K; ++j) w = (uint32_t)j < k ? ld[j] : w;  // slot k - 1
-      worst = w;
+      li[0] = below[0] ? idx : li[0];
+      ld[0] = below[0] ? d : ld[0];
     }
   }
   __device__ __forceinline__ void store(Neighbor* row) const {
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      if ((uint32_t)j < k) {
+      if ((uint32_t)j + k >= (uint32_t)K) {
         Neighbor nb;
         nb.index = li[j];
         nb.distance = ld[j];
-        row[j] = nb;
+        row[(uint32_t)j + k - (uint32_t)K] = nb;
       }
     }
   }
@@ -2093,13 +2105,7 @@ __device__ __forceinline__ uint32_t spread10(uint32_t x) {
 // tree: how often a root-to-leaf path splits on each axis).  A cloud that is flat along one axis -- a LiDAR
 // scan is mostly floor -- then spends its key bits where its leaves actually divide space.  Bits are
 // interleaved from the most significant level down; an axis joins in at the level its own bits begin.
-__global__ __launch_bounds__(kBlock) void morton_kernel(
-    const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv, uint3 bits,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= nq) return;
-  float x, y, z;
-  load_query(queries, dim, i, x, y, z);
+__device__ __forceinline__ uint32_t morton_key(float x, float y, float z, float3 lo, float3 inv, uint3 bits) {
   const uint32_t cx = (uint32_t)fminf(fmaxf((x - lo.x) * inv.x, 0.0f), (float)((1u << bits.x) - 1u));
   const uint32_t cy = (uint32_t)fminf(fmaxf((y - lo.y) * inv.y, 0.0f), (float)((1u << bits.y) - 1u));
   const uint32_t cz = (uint32_t)fminf(fmaxf((z - lo.z) * inv.z, 0.0f), (float)((1u << bits.z) - 1u));
@@ -2110,7 +2116,72 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(
     if (bits.y > level) key = (key << 1) | ((cy >> level) & 1u);
     if (bits.x > level) key = (key << 1) | ((cx >> level) & 1u);
   }
-  keys[i] = key;
+  return key;
+}
+
+// Which queries will be expensive?  A kd-tree search is long where the query sits in EMPTY space: its bound stays
+// loose and it walks the ring of points around the hole (the scanner's blind disc: 600 leaves at knn = 16 where the
+// mean is 12).  The tree's handle keeps one byte per cell of a coarse Morton grid over the root box (about 32 tree
+// points per cell on average: 2^18 cells for BASELINE config 2): 1 = the cell holds a tree point.  On that cloud the
+// queries in empty cells are 3.2 % of the batch and include EVERY query with more than 99 leaf visits (knn = 16;
+// more than 42 at knn = 1), profiles/r03_notes.txt item 8.  The kernels that run every query to its end in its lane
+// sort them to the FRONT of the launch: their long dependent chains then start at once and run beside the bulk
+// of the batch instead of behind it.
+struct CellTable {
+  const uint8_t* occ = nullptr;  // [1 << (bits.x + bits.y + bits.z)]: 0 = no tree point in the cell, else
+                                 // 1 + floor(log2(points in it)); null = no table (the key is the plain Morton key)
+  float3 inv = make_float3(0.0f, 0.0f, 0.0f);
+  uint3 bits = make_uint3(0u, 0u, 0u);
+  uint32_t key_bits = 0;         // width of the order key
+  uint32_t mode = 0;             // kCellsEmptyFirst / kCellsDenseFirst: what the top bit(s) of the key say
+};
+// kCellsEmptyFirst  (k nearest neighbours): top bit = "the query's cell holds tree points": the searches that will be
+//                   long start first.
+// kCellsDenseFirst  (radius search): the cost of a query is its number of hits, i.e. the density around it.  A batch of
+//                   config 3 ends with the queries on the floor under the scanner (thousands of hits each; 225 k
+//                   queries take 5.5 ms, 7.2 M 15.4: a tail of ~4.5 ms whatever the size, profiles/r03_notes.txt item
+//                   9): two top bits = density class, the densest cells first.
+constexpr uint32_t kCellsEmptyFirst = 1, kCellsDenseFirst = 2;
+__device__ __forceinline__ uint32_t order_key(float x, float y, float z, float3 lo, float3 inv, uint3 bits,
+                                              const CellTable& cells) {
+  const uint32_t key = morton_key(x, y, z, lo, inv, bits);
+  if (cells.occ == nullptr) return key;
+  const uint32_t v = cells.occ[morton_key(x, y, z, lo, cells.inv, cells.bits)];
+  if (cells.mode == kCellsEmptyFirst) {
+    const uint32_t cheap = v != 0u ? 1u : 0u;
+    return (cheap << (cells.key_bits - 1u)) | (key >> 1);  // (the lowest Morton bit makes room)
+  }
+  // >= 2048 / 512 / 128 points in the cell (the average is ~32), the rest
+  const uint32_t cls = v >= 12u ? 0u : (v >= 10u ? 1u : (v >= 8u ? 2u : 3u));
+  return (cls << (cells.key_bits - 2u)) | (key >> 2);
+}
+
+// Points per cell of the coarse grid (one atomic per tree point, at creation), then its class byte.
+__global__ __launch_bounds__(kBlock) void cell_count_kernel(const float4* __restrict__ pts, uint64_t n, float3 lo, float3 inv,
+                                                            uint3 bits, uint32_t* __restrict__ counts) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n) return;
+  const float4 p = pts[i];
+  atomicAdd(&counts[morton_key(p.x, p.y, p.z, lo, inv, bits)], 1u);
+}
+__global__ __launch_bounds__(kBlock) void cell_class_kernel(const uint32_t* __restrict__ counts, uint64_t n_cells,
+                                                            uint8_t* __restrict__ occ) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= n_cells) return;
+  const uint32_t c = counts[i];
+  uint32_t v = 0;
+  while ((c >> v) != 0u) ++v;  // 0 for an empty cell, else 1 + floor(log2(c))
+  occ[i] = (uint8_t)v;
+}
+
+__global__ __launch_bounds__(kBlock) void morton_kernel(
+    const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv, uint3 bits,
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, CellTable cells = CellTable{}) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nq) return;
+  float x, y, z;
+  load_query(queries, dim, i, x, y, z);
+  keys[i] = order_key(x, y, z, lo, inv, bits, cells);
   ids[i] = (uint32_t)i;
 }
 

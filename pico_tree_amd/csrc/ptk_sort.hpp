@@ -27,22 +27,6 @@ namespace ptk {
 
 constexpr uint32_t kRadixBins = 256;  // 8 bits per pass
 
-// Morton key of a point inside the tree's root box (clamped): bits.x + bits.y + bits.z <= 30 key bits, interleaved
-// from the most significant level down; an axis joins in at the level its own bits begin (see morton_kernel).
-__device__ __forceinline__ uint32_t morton_key(float x, float y, float z, float3 lo, float3 inv, uint3 bits) {
-  const uint32_t cx = (uint32_t)fminf(fmaxf((x - lo.x) * inv.x, 0.0f), (float)((1u << bits.x) - 1u));
-  const uint32_t cy = (uint32_t)fminf(fmaxf((y - lo.y) * inv.y, 0.0f), (float)((1u << bits.y) - 1u));
-  const uint32_t cz = (uint32_t)fminf(fmaxf((z - lo.z) * inv.z, 0.0f), (float)((1u << bits.z) - 1u));
-  const uint32_t top = bits.x > bits.y ? (bits.x > bits.z ? bits.x : bits.z) : (bits.y > bits.z ? bits.y : bits.z);
-  uint32_t key = 0;
-  for (uint32_t level = top; level-- > 0;) {
-    if (bits.z > level) key = (key << 1) | ((cz >> level) & 1u);
-    if (bits.y > level) key = (key << 1) | ((cy >> level) & 1u);
-    if (bits.x > level) key = (key << 1) | ((cx >> level) & 1u);
-  }
-  return key;
-}
-
 // Lanes of the wavefront holding the same 8-bit digit as this one (among `valid` lanes): eight ballots.
 __device__ __forceinline__ uint64_t same_digit_lanes(uint32_t digit, bool valid) {
   uint64_t peers = __ballot(valid);
@@ -74,7 +58,7 @@ template <bool FROM_QUERIES>
 __global__ __launch_bounds__(64) void radix_hist_kernel(
     const float* __restrict__ queries, uint32_t dim, uint32_t nq, float3 lo, float3 inv, uint3 bits,
     uint32_t* __restrict__ keys, const uint2* __restrict__ pairs, uint32_t shift, uint32_t tile, uint32_t stride,
-    uint32_t* __restrict__ hist) {
+    uint32_t* __restrict__ hist, CellTable cells = CellTable{}) {
   typedef PTK_LDS uint32_t LdsU32;
   LdsU32* cnt = (LdsU32*)ptk_smem;  // [256]
   const uint32_t lane = threadIdx.x;
@@ -94,7 +78,7 @@ __global__ __launch_bounds__(64) void radix_hist_kernel(
       }
 #pragma unroll
       for (uint32_t u = 0; u < kRadixGroup; ++u) {
-        key[u] = morton_key(x[u], y[u], z[u], lo, inv, bits);
+        key[u] = order_key(x[u], y[u], z[u], lo, inv, bits, cells);
         if (valid[u]) keys[base + j0 + 64u * u + lane] = key[u];
       }
     } else {
