@@ -168,6 +168,12 @@ struct ptk_tree {
   void* d_axes = nullptr;   // dim > 3 only
   void* d_index = nullptr;  // dim > 3 only
   void* d_outer = nullptr;  // topological metrics only: float2 per branch
+  // What the device is (hipDeviceProp_t at creation): launches are sized from this, not from "an MI355X has 256 CUs
+  // of 160 KiB" -- a partitioned device (CPX: 32 CUs per logical GPU) or another part must not be oversubscribed.
+  int cus = 256;                      // compute units
+  size_t lds_per_cu = 160 * 1024;     // LDS of one CU
+  size_t lds_per_block = 160 * 1024;  // most dynamic LDS one workgroup may ask for
+  size_t hbm_bytes = 0;               // device memory in total
   void* d_cells = nullptr;  // dim <= 3: which cells of a coarse Morton grid hold tree points (ptk::CellTable)
   ptk::CellTable cells{};
   ptk::DevTreeND dev_nd{};
@@ -436,6 +442,18 @@ int finish_create(ptk_tree* t, const float* points, int32_t device, ptk_tree** o
   if (!guard.ok) {
     delete t;
     return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", dev);
+  }
+  {
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) == hipSuccess) {
+      if (prop.multiProcessorCount > 0) t->cus = prop.multiProcessorCount;
+      if (prop.maxSharedMemoryPerMultiProcessor > 0) t->lds_per_cu = prop.maxSharedMemoryPerMultiProcessor;
+      const size_t optin = prop.sharedMemPerBlockOptin > 0 ? (size_t)prop.sharedMemPerBlockOptin : (size_t)prop.sharedMemPerBlock;
+      if (optin > 0) t->lds_per_block = std::min(optin, t->lds_per_cu);
+      t->hbm_bytes = prop.totalGlobalMem;
+    } else {
+      (void)hipGetLastError();
+    }
   }
   int rc = upload(*t, points);
   if (rc != PTK_OK) {
@@ -906,16 +924,18 @@ int launch_radius_capture(const ptk_tree* t, const float* d_q, const uint32_t* p
 
 // PTK_RADIUS_CAPTURE_MB: the most device memory the captured rows of a radius batch may take
 // (default 16384; 0 switches the capture off and every fill pass repeats the traversal).
-size_t capture_budget_bytes() {
-  const int mb = env_int("PTK_RADIUS_CAPTURE_MB", 16384);
+size_t capture_budget_bytes(const ptk_tree* t) {
+  // default: 16 GiB, but no more than a quarter of the device's memory (a partitioned or smaller device)
+  const size_t quarter_mb = t->hbm_bytes ? (t->hbm_bytes >> 22) : 16384;
+  const int mb = env_int("PTK_RADIUS_CAPTURE_MB", (int)std::min<size_t>(16384, std::max<size_t>(quarter_mb, 64)));
   return mb <= 0 ? 0 : (size_t)mb << 20;
 }
 
 // Sizes (and if needed allocates) the capture block for a batch of nq rows; false = no capture.
 // Layout: counters | captured flags | chunks.  The dynamic pool is 8 chunks (248 hits) per row
 // when the budget allows; PTK_RADIUS_CAPTURE_CHUNKS overrides chunks per sub-pool (tests).
-bool prepare_capture(uint64_t nq, Workspace& ws) {
-  const size_t budget = capture_budget_bytes();
+bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
+  const size_t budget = capture_budget_bytes(t);
   if (budget == 0 || nq == 0 || nq >= (1ull << 31)) return false;
   const size_t chunk_bytes = (size_t)ptk::kCapChunk * sizeof(ptk::Neighbor);
   const size_t head = (size_t)ptk::kCapSubPools * ptk::kCapCounterStride * 4 + ((nq + 255) & ~(size_t)255);
@@ -995,17 +1015,19 @@ ClassPlan class_plan(uint64_t nq) {
 constexpr int kCoopLanes = 16, kCoopPool = 96;
 // Tasks a group of the cooperative search may park in HBM when its LDS pool is full.
 constexpr uint32_t kCoopSpill = 256;
-inline int coop_waves() {
+inline int coop_waves(const ptk_tree* t) {
   constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
-  // As many waves as can be resident at once (LDS-bound; 256 CUs x 160 KiB), each group working
+  // As many waves as can be resident at once (LDS-bound: CUs x LDS per CU of the device), each group working
   // through its share of the list: a second round of blocks would start when most of the work is done.
-  return 256 * (int)std::min<size_t>(24, (160 * 1024) / (smem + 512));
+  return t->cus * (int)std::max<size_t>(1, std::min<size_t>(24, t->lds_per_cu / (smem + 512)));
 }
-size_t coop_spill_bytes() { return (size_t)coop_waves() * (64 / kCoopLanes) * kCoopSpill * sizeof(ptk::Task); }
+size_t coop_spill_bytes(const ptk_tree* t) {
+  return (size_t)coop_waves(t) * (64 / kCoopLanes) * kCoopSpill * sizeof(ptk::Task);
+}
 
-size_t two_phase_scratch_bytes(uint64_t nq) {
+size_t two_phase_scratch_bytes(const ptk_tree* t, uint64_t nq) {
   return nq * sizeof(float4) + nq * ptk::kContSlots * sizeof(ptk::Record) + nq * sizeof(uint4) + 4 * nq +
-         2 * (nq * 4) + 3 * (nq * 4) + max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + 64 + 2 * coop_spill_bytes() +
+         2 * (nq * 4) + 3 * (nq * 4) + max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + 64 + 2 * coop_spill_bytes(t) +
          class_sort_tmp_bytes(nq) + (size_t)ptk::kClassBuckets * (class_plan(nq).stride + ptk::kClassMaxSegs) * 4 + 2048;
 }
 
@@ -1030,10 +1052,10 @@ int launch_knn1_coop_direct(const ptk_tree* t, const float4* qs, ptk::Neighbor* 
                             const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
                             const uint32_t* direct_ids) {
   constexpr size_t smem = (size_t)(64 / G) * (6 * kCoopPool + 1) * 4;
-  // (the spill block is sized for coop_waves() x 64 / kCoopLanes groups: a wider group count would not fit)
+  // (the spill block is sized for coop_waves(t) x 64 / kCoopLanes groups: a wider group count would not fit)
   static_assert(G >= kCoopLanes, "the spill block is sized for groups of kCoopLanes lanes");
-  const int resident = 256 * (int)std::min<size_t>(32, (160 * 1024) / (smem + 512));
-  const int waves = std::min(resident, coop_waves() * (G / kCoopLanes));
+  const int resident = t->cus * (int)std::max<size_t>(1, std::min<size_t>(32, t->lds_per_cu / (smem + 512)));
+  const int waves = std::min(resident, coop_waves(t) * (G / kCoopLanes));
   hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, kCoopPool, true>), dim3(waves), dim3(64), smem, s, t->dev,
                      static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, direct_ids, spill, kCoopSpill);
   PTK_HIP(hipGetLastError());
@@ -1044,7 +1066,7 @@ int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, 
                      const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
                      const uint32_t* direct_ids = nullptr) {
   constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
-  const int waves = coop_waves();
+  const int waves = coop_waves(t);
   const uint32_t spill_cap = spill ? kCoopSpill : 0u;
   if (direct_ids != nullptr) {
     switch (env_int("PTK_COOP_DIRECT_LANES", 32)) {
@@ -1119,8 +1141,8 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   if (!ho.heavy_list || !ho.ntasks || !ho.tasks || !redo_list) return fail(PTK_ERR_NOMEM, "scratch block too small");
   // Where the groups of the cooperative search park subtrees their LDS pool has no room for (one block per launch
   // that may be in flight: the direct one on the second stream, the one behind phase 2).
-  ptk::Task* spill_a = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes()));
-  ptk::Task* spill_b = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes()));
+  ptk::Task* spill_a = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes(t)));
+  ptk::Task* spill_b = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes(t)));
   if (!spill_a || !spill_b) return fail(PTK_ERR_NOMEM, "scratch block too small");
   scratch.note_meta(cont.meta);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
@@ -1208,7 +1230,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
       PTK_HIP(hipStreamWaitEvent(s, join, 0));
       side_guard.side = nullptr;
     }
-    hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(256), dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
+    hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(t->cus), dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
                        e_inv, d_out, cont, redo_list);
     PTK_HIP(hipGetLastError());
   }
@@ -1218,7 +1240,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
 
 // ---- any dimension (dim > 3) -----------------------------------------------------------------
 // LDS per 64-lane block: record ring + q[dim] + off[dim] (+ the k-list while it fits).
-constexpr size_t kMaxLdsBytes = 160 * 1024;
+// (the most dynamic LDS a block may ask for is the handle's lds_per_block, from the device's properties)
 
 template <int OVF, class M = ptk::MetricL2>
 int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
@@ -1226,7 +1248,7 @@ int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const size_t base = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
-  if (base > kMaxLdsBytes)
+  if (base > t->lds_per_block)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
   if (k <= 32 && !no_register_list) {  // k-list in registers (K = 4 / 8 / 16 / 32 slots compiled)
     Timer timer(t, s);
@@ -1273,7 +1295,7 @@ int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float rad
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
-  if (smem > kMaxLdsBytes)
+  if (smem > t->lds_per_block)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
   Timer timer(t, s);
   if (!fill) {
@@ -1298,7 +1320,7 @@ int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, const uint32_t
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
-  if (smem > kMaxLdsBytes)
+  if (smem > t->lds_per_block)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
   Timer timer(t, s);
   int rc = allow_lds(ptk::radius_nd_capture_kernel<S, OVF, M>, smem);
@@ -1725,7 +1747,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
         dev.deep_spill = spill;
         dev.deep_cap = plan.cap;
         const size_t smem = (size_t)16 * 64 * 8 + (size_t)t->dim * 64 * 8;
-        if (smem > kMaxLdsBytes)
+        if (smem > t->lds_per_block)
           return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
         PTK_WITH_METRIC({
           rc = allow_lds(ptk::knn_nd_kernel<16, -1, false, M>, smem);
@@ -1751,7 +1773,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
-                       (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(nq) : 0));
+                       (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(t, nq) : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
   if (reorder) {  // Morton order along the first three axes, whatever the dimension
@@ -2102,7 +2124,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
         dev.deep_spill = spill;
         dev.deep_cap = plan.cap;
         const size_t smem = (size_t)16 * 64 * 8 + (size_t)t->dim * 64 * 8;
-        if (smem > kMaxLdsBytes)
+        if (smem > t->lds_per_block)
           return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
         PTK_WITH_METRIC({
           if (fill) {
@@ -2135,7 +2157,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     }
     timer.stop(0, fill ? 0 : nq);
   } else {
-    const bool capture = !fill && prepare_capture(nq, ws);
+    const bool capture = !fill && prepare_capture(t, nq, ws);
     if (!fill) ws.cap_valid = false;
     rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
     if (rc != PTK_OK) return rc;
@@ -2328,7 +2350,7 @@ static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_
   if (rc != PTK_OK) return rc;
   if (nb > 0 && d_mx == nullptr) return fail(PTK_ERR_INVALID, "null box buffer");
   const size_t nd_smem = (size_t)16 * 64 * 8 + (size_t)4 * t->dim * 64 * 4;
-  if (t->dim > 3 && nd_smem > kMaxLdsBytes)
+  if (t->dim > 3 && nd_smem > t->lds_per_block)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device box search", t->dim);
   if (nb == 0) return PTK_OK;
   if (nb >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more boxes are not supported");

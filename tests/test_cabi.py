@@ -255,3 +255,11 @@ def test_key_bits_follow_the_splits_of_the_tree():
     assert t.key_bits(5_000_000) == (12, 12, 0)
     t = pt.KdTree(cube[:1], pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)  # one leaf: nothing to go by
     assert t.key_bits(5_000_000) == (8, 8, 8)
+
+
+def test_the_reference_module_name_is_importable():
+    """``import pico_tree`` (the reference binding's module name) resolves to this package's classes."""
+    import pico_tree
+
+    assert pico_tree.KdTree is pt.KdTree and pico_tree.DArray is pt.DArray and pico_tree.Metric is pt.Metric
+    assert pico_tree.load_kd_tree is pt.load_kd_tree and pico_tree.save_kd_tree is pt.save_kd_tree

@@ -646,3 +646,106 @@ def test_topological_metrics_on_the_device(gpu, metric):
     assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # neighbours through the seam
     with pytest.raises(pt.PtkError):  # dimension check
         pt.KdTree(ds.uniform_cloud(100, 2, 1), pt.Metric[metric], 10, device=gpu)
+
+
+def _blind_disc(n, scale=1.0):
+    """Queries inside the empty disc under the scanner of the LiDAR-like cloud: the reference's depth-first search of
+    such a query visits a long chain of leaves (the expensive queries of BASELINE config 2)."""
+    u = ds.raw_uniform24(11, 2 * n).reshape(n, 2)
+    r = 12.0 * np.sqrt(u[:, 0])
+    a = 2.0 * np.pi * u[:, 1]
+    return np.ascontiguousarray(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(n)], axis=1) * scale, dtype=np.float32)
+
+
+@pytest.mark.parametrize("cloud", ["ties", "self", "blind-disc"])
+@pytest.mark.parametrize("direct", ["0", "2"])
+def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch, cloud, direct):
+    """The only place where the k = 1 search does NOT replay the reference's visit order: with a cap of 1 or 2 far
+    children nearly every continuation is handed to the cooperative search; on a lattice cloud (exact ties beyond
+    the tie budget) the certificate FAILS for some queries and they come back through the replay; the queries of the
+    scanner's blind disc (on a grid of 0.5) are the long chains the cooperative search exists for.  Both forms: the
+    ranked classes through phase 2 first (PTK_COOP_DIRECT=0) and straight from phase 1 on a second stream (2, with
+    the HBM spill of the subtree pool).  Counters say the paths ran; rows equal the oracle."""
+    import torch
+
+    if cloud == "blind-disc":
+        pts = ds.lidar_cloud(400_000, seed=1, unit_scale=20.0)
+        q = np.concatenate([_blind_disc(20_000, 20.0), ds.lidar_cloud(20_000, seed=2, pose=(3.0, 1.5), unit_scale=20.0)])
+        grid = 0.5
+        pts = np.ascontiguousarray(np.round(pts / grid) * grid, dtype=np.float32)
+        q = np.ascontiguousarray(np.round(q / grid) * grid, dtype=np.float32)
+    else:
+        pts, q = _clouds(cloud, 120_000, 40_000)
+    monkeypatch.setenv("PTK_COOP_DIRECT", direct)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    ref = oracle.Oracle(pts, 10, "port")
+    ref.set_threads(ref.max_threads())
+    want = ref.search_knn(q, 1)[:, 0]
+    dq = torch.from_numpy(q).to(f"cuda:{gpu}")
+    redone = 0
+    for cap in ("1", "2"):
+        monkeypatch.setenv("PTK_P2_CAP", cap)
+        got = tree.search_knn(dq, 1).numpy()
+        torch.cuda.synchronize()
+        counts = tree.knn1_counts()
+        assert got.tobytes() == want.tobytes(), cap
+        if cloud != "self":  # (a query that IS a tree point is final after phase 1: distance 0)
+            assert counts["cooperative"] > 0, counts
+        redone += counts["redone"]
+    if cloud == "ties":  # more exact ties per query than a lane resolves: the certificate fails, the replay runs
+        assert redone > 0
+
+
+def test_config1_through_the_device_matches_the_committed_hashes(gpu):
+    """BASELINE configs[0] (100 k / 100 k uniform, knn = 1, leaf 10): the reference's own CPU-runnable case, through
+    the HIP path, against tests/golden/hashes.json (SHA-256 of the compiled reference's indices and distance bits)."""
+    import hashlib
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "hashes.json")) as f:
+        e = json.load(f)["config1_uniform_100k_knn1"]
+    p, q = ds.uniform_cloud(100_000, 3, seed=1), ds.uniform_cloud(100_000, 3, seed=2)
+    tree = pt.KdTree(p, pt.Metric.L2Squared, 10, device=gpu)
+    for rows in (tree.search_knn(q, 1), None):
+        if rows is None:  # device buffers
+            import torch
+            rows = tree.search_knn(torch.from_numpy(q).to(f"cuda:{gpu}"), 1).numpy()
+        assert hashlib.sha256(np.ascontiguousarray(rows["index"]).tobytes()).hexdigest() == e["index_sha256"]
+        assert hashlib.sha256(np.ascontiguousarray(rows["distance"]).tobytes()).hexdigest() == e["distance_bits_sha256"]
+        assert int(rows["index"].astype(np.int64).sum()) == e["index_sum"]
+
+
+def test_all_devices_of_the_node(gpu, monkeypatch):
+    """With two or more GPUs visible: ptk_multi_* over ALL of them (real peer send / recv through RCCL, no
+    self-gather) and one rank per GPU through pico_tree_amd.sharded over RCCL.  Skips on the one-GPU test box; runs
+    the day the suite sees a node."""
+    import torch
+
+    n_dev = pt.device_count()
+    if n_dev < 2:
+        pytest.skip("one GPU visible")
+    pts, q = ds.lidar_cloud(200_000, 1), ds.lidar_cloud(100_003, 2, pose=(3.0, 1.5))
+    ref = oracle.Oracle(pts, 10, "port")
+    ref.set_threads(ref.max_threads())
+    want1, want8 = ref.search_knn(q, 1)[:, 0], ref.search_knn(q, 8)
+    multi = pt.MultiKdTree(pts, 10, devices=list(range(n_dev)))
+    assert multi.search_knn(q, 1).tobytes() == want1.tobytes()
+    dq = torch.from_numpy(q).to("cuda:0")
+    for k, want in ((1, want1), (8, want8)):
+        rows = multi.search_knn(dq, k).numpy()
+        torch.cuda.synchronize()
+        assert rows.tobytes() == want.tobytes(), k
+    # one process per GPU (what bench.py --gpus N runs): torch.distributed over RCCL, rows gathered on rank 0
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n_dev}",
+           "--master-addr", "127.0.0.1", "--master-port", "29631", os.path.join(root, "bench.py"), "--gpus", str(n_dev),
+           "--steps", "3", "--warmup", "1", "--n", "400000", "--nq", "200003", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, cwd=root)
+    assert out.returncode == 0, out.stderr.decode()[-2000:]
+    import json
+    line = json.loads(out.stdout.decode().strip().splitlines()[-1])
+    assert line["n_gpus"] == n_dev and line["parity_sample_ok"] is True

@@ -182,3 +182,42 @@ def test_file_io_is_byte_compatible_with_the_reference(gpu, tmp_path):
     off, flat = ref.search_radius(q, 0.002)
     assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
 
+
+
+def test_import_pico_tree_runs_a_script_written_for_the_reference(gpu, tmp_path, monkeypatch):
+    """``import pico_tree as pt`` (examples/python/kd_tree.py:5): the calls of the reference's Python example, made
+    through the alias package -- default device, no device argument, as a script written for the reference makes them."""
+    import pico_tree as ref_name
+
+    assert ref_name.KdTree is pt.KdTree and ref_name.Metric is pt.Metric and ref_name.DArray is pt.DArray
+    assert set(["DArray", "Metric", "KdTree", "load_kd_tree", "save_kd_tree"]) <= set(ref_name.__all__)
+    monkeypatch.chdir(tmp_path)
+    p = np.array(A, dtype=np.float32)
+    for metric in (ref_name.Metric.L1, ref_name.Metric.LPInf, ref_name.Metric.L2Squared):  # creation, kd_tree.py:14-33
+        t = ref_name.KdTree(p, metric, 10)
+        assert str(t) and (t.npts, t.sdim) == (3, 2)
+    t = ref_name.KdTree(p, ref_name.Metric.L2Squared, 1)
+    assert t.metric(-2.0) == 4.0
+    knns = t.search_knn(p, 1)                                # :42-49
+    assert [int(i) for i in knns["index"].reshape(-1)] == [0, 1, 2] and not knns["distance"].any()
+    t.search_knn(p, 2, knns)
+    assert knns.shape == (3, 2) and [int(i) for i in knns[:, 1]["index"]] == [1, 0, 1]
+    ratio = t.metric(1.0 + 0.75)                             # :57-66
+    knns = t.search_knn(p, 2, ratio)
+    t.search_knn(p, 2, ratio, knns)
+    assert np.allclose(knns[:, 1]["distance"] * ratio, [8.0, 8.0, 32.0])
+    rnns = t.search_radius(p, t.metric(2.5))                 # :73-82
+    assert [len(r) for r in rnns] == [1, 1, 1]
+    t.search_radius(p, 25.0, rnns)
+    assert [len(r) for r in rnns] == [2, 2, 1]
+    boxes = np.array([[0, 0], [3, 3], [2, 2], [3, 3], [0, 0], [9, 9], [6, 6], [9, 9]], dtype=np.float32)  # :91-103
+    bnns = t.search_box(boxes)
+    t.search_box(boxes, bnns)
+    assert [list(b) for b in bnns] == [[0], [], [0, 1, 2], [2]]
+    assert len(bnns) == 4 and list(bnns[0]) == [0] and list(bnns[-2]) == [0, 1, 2]   # :111-117
+    assert [list(b) for b in bnns[0:4:2]] == [[0], [0, 1, 2]]
+    a = np.array(A, dtype=np.float64, order="C")             # file io, :130-143
+    t1 = ref_name.KdTree(a, ref_name.Metric.L2Squared, 10)
+    ref_name.save_kd_tree(t1, "tree.bin")
+    t2 = ref_name.load_kd_tree(a, "tree.bin")
+    assert repr(t1) == repr(t2) and t2.search_knn(a, 1)["index"].reshape(-1).tolist() == [0, 1, 2]
