@@ -405,6 +405,29 @@ int upload(ptk_tree& t, const float* points) {
   return PTK_OK;
 }
 
+// The first kernel launch of a process loads libptk's code object for the device (~10 MB: 0.17 s on the bench box,
+// profiles/r02_notes.txt item 13).  A creation that builds the tree on the host first starts that load on a thread of
+// its own, beside the build, instead of paying for it afterwards.
+__global__ void ptk_warm_kernel() {}
+struct DeviceWarmup {
+  std::thread thread;
+  explicit DeviceWarmup(int32_t device) {
+    static std::atomic<bool> done{false};
+    if (device == kDeviceNone || done.exchange(true)) return;
+    thread = std::thread([device] {
+      int dev = device;
+      if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+      if (hipSetDevice(dev) != hipSuccess) return;
+      hipLaunchKernelGGL(ptk_warm_kernel, dim3(1), dim3(1), 0, nullptr);
+      (void)hipDeviceSynchronize();
+      (void)hipGetLastError();
+    });
+  }
+  ~DeviceWarmup() {
+    if (thread.joinable()) thread.join();
+  }
+};
+
 int finish_create(ptk_tree* t, const float* points, int32_t device, ptk_tree** out) {
   if (t->root_min.empty()) {  // start bounds not supplied: bounding box of the points
     t->root_min.assign(t->dim, std::numeric_limits<float>::max());
@@ -1466,6 +1489,7 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
   if (n_points >= (1ull << 31)) return fail(PTK_ERR_INVALID, "n_points must be < 2^31");
   ptk_tree* t = new (std::nothrow) ptk_tree;
   if (t == nullptr) return fail(PTK_ERR_NOMEM, "out of memory");
+  DeviceWarmup warm(device);  // (joined when this function returns: before that, in finish_create, if it is quick)
   try {
     using namespace pico_tree;
     using space_t = space_map<point_map<float const, dynamic_extent>>;
@@ -2365,8 +2389,11 @@ static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_
     }
     root = ptk::BoxState{mn[0], mn[1], mn[2], mx[0], mx[1], mx[2]};
   }
-  if (topological(t))
-    return fail(PTK_ERR_UNSUPPORTED, "the box search of a topological tree runs on the host members (kd_tree::search_box)");
+  // A topological tree: circle axes (metric_so2: axis 0; metric_se2_squared: axis 2), the four-bound tests.
+  const bool topo = topological(t);
+  const uint32_t s1_mask = !topo ? 0u : (t->metric.load() == PTK_METRIC_SO2 ? 1u : 4u);
+  if (topo && (deep_tree(t) || t->dev.outer == nullptr))
+    return fail(PTK_ERR_UNSUPPORTED, "the box search of this topological tree runs on the host members (kd_tree::search_box)");
   // Boxes in Morton order of their min corners (launch order only; rows stay in the caller's order).
   const bool deep = deep_tree(t);
   const bool reorder = !deep && want_reorder(t, nb);
@@ -2435,8 +2462,12 @@ static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_
                                         ranges, d_root, d_mn, d_mx, nb, d_counts, nullptr, nullptr, perm);
                      return PTK_OK;
                    }
-                   hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
-                                      ranges, root, d_mn, d_mx, t->dim, nb, d_counts, nullptr, nullptr, perm);
+                   if (topo)
+                     hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false, true>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
+                                        ranges, root, d_mn, d_mx, t->dim, nb, d_counts, nullptr, nullptr, perm, s1_mask);
+                   else
+                     hipLaunchKernelGGL((ptk::box_kernel<16, OVF, false>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
+                                        ranges, root, d_mn, d_mx, t->dim, nb, d_counts, nullptr, nullptr, perm, 0u);
                    return PTK_OK;
                  }()));
   } else {
@@ -2448,8 +2479,12 @@ static int box_pass_device(const ptk_tree* t, const float* d_mn, const float* d_
                                         ranges, d_root, d_mn, d_mx, nb, nullptr, d_offsets, d_out, perm);
                      return PTK_OK;
                    }
-                   hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
-                                      ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_offsets, d_out, perm);
+                   if (topo)
+                     hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true, true>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
+                                        ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_offsets, d_out, perm, s1_mask);
+                   else
+                     hipLaunchKernelGGL((ptk::box_kernel<16, OVF, true>), dim3(blocks), dim3(64), 16 * 64 * 8, s, t->dev,
+                                        ranges, root, d_mn, d_mx, t->dim, nb, nullptr, d_offsets, d_out, perm, 0u);
                    return PTK_OK;
                  }()));
   }

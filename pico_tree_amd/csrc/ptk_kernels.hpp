@@ -1940,11 +1940,18 @@ __device__ __forceinline__ void set_axis(float& a0, float& a1, float& a2, uint32
   a2 = axis == 2 ? v : a2;
 }
 
-template <int S, int OVF, bool FILL>
+// TOPO: the tree of a topological metric (metric_so2: axis 0 a circle; metric_se2_squared: axis 2), searched as the
+// reference's search_box does with a metric_box_map query (kd_tree_search.hpp:238-381, box.hpp:300-376, segment.hpp):
+// on a circle axis (bit of s1_mask) a query interval with min > max wraps around the seam -- it contains x iff
+// x >= min || x <= max and a node interval iff node.min >= min || node.max <= max; and EVERY axis of such a tree uses
+// the four-bound intersection tests (`query.min <= left_max || query.max >= left_min`, :311-327), for which the two
+// outer bounds of the branch come from t.outer.
+template <int S, int OVF, bool FILL, bool TOPO = false>
 __global__ __launch_bounds__(64) void box_kernel(
     DevTree t, const uint2* __restrict__ ranges, BoxState root, const float* __restrict__ mins,
     const float* __restrict__ maxs, uint32_t dim, uint64_t nb, uint64_t* __restrict__ counts,
-    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out, const uint32_t* __restrict__ perm = nullptr) {
+    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out, const uint32_t* __restrict__ perm = nullptr,
+    uint32_t s1_mask = 0) {
   const uint64_t li = (uint64_t)blockIdx.x * 64 + threadIdx.x;
   if (li >= nb) return;
   const uint64_t bi = perm ? perm[li] : li;  // launch order only (boxes sorted by their min corner)
@@ -1962,7 +1969,18 @@ __global__ __launch_bounds__(64) void box_kernel(
 
   PTK_STACK(S, OVF, 64, st, t);
 
+  // One axis of metric_box_map::contains (segment_r1 / segment_s1::contains of an interval and of a coordinate).
+  auto seg_in = [&](uint32_t axis, float qn, float qx, float mn, float mx) {
+    const bool wrap = ((s1_mask >> axis) & 1u) != 0u && !(qn <= qx);
+    return wrap ? (mn >= qn || mx <= qx) : (qn <= mn && mx <= qx);
+  };
+  auto pt_in = [&](uint32_t axis, float qn, float qx, float x) {
+    const bool wrap = ((s1_mask >> axis) & 1u) != 0u && !(qn <= qx);
+    return wrap ? (x >= qn || x <= qx) : (qn <= x && x <= qx);
+  };
   auto inside = [&]() {  // query_.contains(box_): both corners inside the closed query box
+    if (TOPO)
+      return seg_in(0, qn0, qx0, b.mn0, b.mx0) && seg_in(1, qn1, qx1, b.mn1, b.mx1) && seg_in(2, qn2, qx2, b.mn2, b.mx2);
     return qn0 <= b.mn0 && b.mn0 <= qx0 && qn0 <= b.mx0 && b.mx0 <= qx0 &&
            qn1 <= b.mn1 && b.mn1 <= qx1 && qn1 <= b.mx1 && b.mx1 <= qx1 &&
            qn2 <= b.mn2 && b.mn2 <= qx2 && qn2 <= b.mx2 && b.mx2 <= qx2;
@@ -1989,7 +2007,9 @@ __global__ __launch_bounds__(64) void box_kernel(
     for (uint32_t j = 0; j < n; ++j) {
       const float4 p = pts[begin + j];
       PTK_KEEP4(p);  // one 16-byte load: the index must not become a dependent load inside the branch
-      if (qn0 <= p.x && p.x <= qx0 && qn1 <= p.y && p.y <= qx1 && qn2 <= p.z && p.z <= qx2) {
+      const bool hit = TOPO ? (pt_in(0, qn0, qx0, p.x) && pt_in(1, qn1, qx1, p.y) && pt_in(2, qn2, qx2, p.z))
+                            : (qn0 <= p.x && p.x <= qx0 && qn1 <= p.y && p.y <= qx1 && qn2 <= p.z && p.z <= qx2);
+      if (hit) {
         if (FILL) row[count] = __float_as_int(p.w);
         ++count;
       }
@@ -2010,10 +2030,12 @@ __global__ __launch_bounds__(64) void box_kernel(
         const float left_max = __uint_as_float(nd.x);
         st.push(idx | (axis << 28), sel3(axis, b.mx0, b.mx1, b.mx2));  // the right child comes later
         set_axis(b.mx0, b.mx1, b.mx2, axis, left_max);
+        bool enter_left = sel3(axis, qn0, qn1, qn2) <= left_max;  // intersects_left
+        if (TOPO) enter_left = enter_left || sel3(axis, qx0, qx1, qx2) >= t.outer[idx].x;  // || query.max >= left_min
         if (inside()) {
           report(nd.z);
           have = false;
-        } else if (sel3(axis, qn0, qn1, qn2) <= left_max) {  // intersects_left
+        } else if (enter_left) {
           ref = nd.z;
         } else {
           have = false;
@@ -2035,9 +2057,11 @@ __global__ __launch_bounds__(64) void box_kernel(
     const float right_min = __uint_as_float(nd.y);
     st.push(kRecUndo | (axis << 28), sel3(axis, b.mn0, b.mn1, b.mn2));
     set_axis(b.mn0, b.mn1, b.mn2, axis, right_min);
+    bool enter_right = sel3(axis, qx0, qx1, qx2) >= right_min;  // intersects_right
+    if (TOPO) enter_right = enter_right || sel3(axis, qn0, qn1, qn2) <= t.outer[r.x & kRecIdxMask].y;  // || query.min <= right_max
     if (inside()) {
       report(nd.w);
-    } else if (sel3(axis, qx0, qx1, qx2) >= right_min) {  // intersects_right
+    } else if (enter_right) {
       ref = nd.w;
       have = true;
     }
@@ -2156,13 +2180,25 @@ __device__ __forceinline__ uint32_t order_key(float x, float y, float z, float3 
   return (cls << (cells.key_bits - 2u)) | (key >> 2);
 }
 
-// Points per cell of the coarse grid (one atomic per tree point, at creation), then its class byte.
+// Points per cell of the coarse grid (at creation), then its class byte.  The points come in leaf order, so the
+// lanes of a wavefront hold runs of the same cell: one atomic per run (its first lane adds the run's length) instead of
+// one per point (7.7 M atomics on 262 k words took 4.6 ms, the dense cells serialising).
 __global__ __launch_bounds__(kBlock) void cell_count_kernel(const float4* __restrict__ pts, uint64_t n, float3 lo, float3 inv,
                                                             uint3 bits, uint32_t* __restrict__ counts) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
-  if (i >= n) return;
-  const float4 p = pts[i];
-  atomicAdd(&counts[morton_key(p.x, p.y, p.z, lo, inv, bits)], 1u);
+  const bool valid = i < n;
+  const float4 p = pts[valid ? i : n - 1];
+  const uint32_t cell = valid ? morton_key(p.x, p.y, p.z, lo, inv, bits) : 0xFFFFFFFFu;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t prev = (uint32_t)__shfl_up((int)cell, 1);
+  const bool head = lane == 0u || prev != cell;
+  const uint64_t heads = __ballot(head);
+  if (head && valid) {
+    const uint64_t above = lane == 63u ? 0ull : heads >> (lane + 1u);   // the next run's head, if any
+    const uint32_t len = above != 0ull ? (uint32_t)__builtin_ctzll(above) + 1u : 64u - lane;
+    // (an invalid tail of the last wavefront is a run of its own: `len` of the last valid run stops before it)
+    atomicAdd(&counts[cell], len);
+  }
 }
 __global__ __launch_bounds__(kBlock) void cell_class_kernel(const uint32_t* __restrict__ counts, uint64_t n_cells,
                                                             uint8_t* __restrict__ occ) {

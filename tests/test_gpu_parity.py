@@ -648,6 +648,38 @@ def test_topological_metrics_on_the_device(gpu, metric):
         pt.KdTree(ds.uniform_cloud(100, 2, 1), pt.Metric[metric], 10, device=gpu)
 
 
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
+@pytest.mark.parametrize("metric", ["SO2", "SE2Squared"])
+def test_topological_box_search_on_the_device(gpu, metric):
+    """search_box of a kd_tree<space, metric_so2 | metric_se2_squared> (kd_tree_search.hpp:238-381 with the
+    metric_box_map query of box.hpp:300-376): boxes whose circle interval wraps around the seam (min > max) included,
+    against the reference's own headers; rows in the reference's report order."""
+    rng = np.random.default_rng(77)
+    if metric == "SO2":
+        pts, leaf, nb = ds.uniform_cloud(100_000, 1, 61), 8, 20_000
+        mins = rng.random((nb, 1), dtype=np.float32)
+        maxs = (mins + rng.random((nb, 1), dtype=np.float32) * np.float32(0.02)).astype(np.float32)
+        wrap = maxs[:, 0] > 1.0                     # intervals through the seam: max comes back below min
+        maxs[wrap, 0] -= np.float32(1.0)
+        assert wrap.sum() > 50
+    else:
+        pts, leaf, nb = ds.uniform_cloud(150_000, 3, 63), 10, 20_000
+        mins = rng.random((nb, 3), dtype=np.float32)
+        maxs = (mins + np.float32(0.03) * (1 + rng.random((nb, 3), dtype=np.float32))).astype(np.float32)
+        wrap = maxs[:, 2] > 1.0
+        maxs[wrap, 2] -= np.float32(1.0)
+        assert wrap.sum() > 50
+    tree = pt.KdTree(pts, pt.Metric[metric], leaf, device=gpu)
+    ref = oracle.Oracle(pts, leaf, "reference", metric)
+    boxes = np.empty((2 * nb, pts.shape[1]), dtype=np.float32)
+    boxes[0::2], boxes[1::2] = mins, maxs
+    got = tree.search_box(boxes)
+    off, flat = ref.search_box(mins, maxs)
+    assert off[-1] > 0 and np.array_equal(got.offsets, off) and np.array_equal(got.flat, flat)
+    counts = np.diff(off)
+    assert counts[wrap].sum() > 0  # the boxes through the seam do find points
+
+
 def _blind_disc(n, scale=1.0):
     """Queries inside the empty disc under the scanner of the LiDAR-like cloud: the reference's depth-first search of
     such a query visits a long chain of leaves (the expensive queries of BASELINE config 2)."""
