@@ -1039,7 +1039,7 @@ constexpr int kCoopLanes = 16, kCoopPool = 96;
 // Tasks a group of the cooperative search may park in HBM when its LDS pool is full.
 constexpr uint32_t kCoopSpill = 256;
 inline int coop_waves(const ptk_tree* t) {
-  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
+  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 2) * 4;
   // As many waves as can be resident at once (LDS-bound: CUs x LDS per CU of the device), each group working
   // through its share of the list: a second round of blocks would start when most of the work is done.
   return t->cus * (int)std::max<size_t>(1, std::min<size_t>(24, t->lds_per_cu / (smem + 512)));
@@ -1074,7 +1074,7 @@ template <int G>
 int launch_knn1_coop_direct(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
                             const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
                             const uint32_t* direct_ids) {
-  constexpr size_t smem = (size_t)(64 / G) * (6 * kCoopPool + 1) * 4;
+  constexpr size_t smem = (size_t)(64 / G) * (6 * kCoopPool + 2) * 4;
   // (the spill block is sized for coop_waves(t) x 64 / kCoopLanes groups: a wider group count would not fit)
   static_assert(G >= kCoopLanes, "the spill block is sized for groups of kCoopLanes lanes");
   const int resident = t->cus * (int)std::max<size_t>(1, std::min<size_t>(32, t->lds_per_cu / (smem + 512)));
@@ -1088,7 +1088,7 @@ int launch_knn1_coop_direct(const ptk_tree* t, const float4* qs, ptk::Neighbor* 
 int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
                      const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
                      const uint32_t* direct_ids = nullptr) {
-  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 1) * 4;
+  constexpr size_t smem = (size_t)(64 / kCoopLanes) * (6 * kCoopPool + 2) * 4;
   const int waves = coop_waves(t);
   const uint32_t spill_cap = spill ? kCoopSpill : 0u;
   if (direct_ids != nullptr) {

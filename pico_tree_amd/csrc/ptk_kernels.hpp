@@ -1586,6 +1586,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   const uint64_t below = gmask & ((1ull << lane) - 1ull);  // lanes of this group before this one
   LdsU32* pool = (LdsU32*)ptk_smem + g * (6 * POOL);       // [field][slot] of this group
   LdsU32* gbest = (LdsU32*)ptk_smem + NG * (6 * POOL) + g;  // bits of the group's best distance
+  LdsU32* gsecond = gbest + NG;                             // (when a query ends) the nearest of all OTHER points
   const uint32_t n_heavy = DIRECT ? cont.meta[kMetaRanked] : cont.meta[ho.counter];
   Task* const spill_g = spill + (uint64_t)(blockIdx.x * (uint32_t)NG + g) * spill_cap;  // this group's run
   uint32_t spill_n = 0;  // tasks in it (the same value in every lane of the group)
@@ -1600,6 +1601,8 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
   float cd = 3.402823466e+38f;
   uint32_t cpos = 0;
   bool cok = false;
+  float cg = 0.0f;                  // the largest box distance on the way to this lane's best (what cok compared)
+  float cd2 = 3.402823466e+38f;     // the nearest point this lane has measured other than its best
   uint32_t tie_budget = 0;
   float start_d = 0.0f;  // the best handed over (phase 2's own, already the reference's)
   uint32_t start_i = 0;
@@ -1634,6 +1637,8 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
           cd = 3.402823466e+38f;
           cpos = 0;
           cok = false;
+          cg = 0.0f;
+          cd2 = 3.402823466e+38f;
           tie_budget = kCoopTieBudget;
           if (failed || start_d == 0.0f) {
             count = 0;
@@ -1776,31 +1781,39 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
       } else {
         // The nearest of the (up to) four points, the first of them on a tie (a leaf is visited in index
         // order), without a branch per point; then one comparison with what this lane holds.
-        float d = 3.402823466e+38f;
+        float d = 3.402823466e+38f, d_second = 3.402823466e+38f;  // the batch's nearest and its runner-up
         uint32_t du = 0;
 #pragma unroll
         for (int u = 3; u >= 0; --u) {
           const float dx = f_sub(qx, p[u].x);
           const float dy = f_sub(qy, p[u].y);
           const float dz = f_sub(qz, p[u].z);
-          const float du_d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
+          const float du_d = (uint32_t)u < cnt ? f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)) : 3.402823466e+38f;
           const bool take = (uint32_t)u < cnt && du_d <= d;
+          d_second = take ? d : (du_d < d_second ? du_d : d_second);
           d = take ? du_d : d;
           du = take ? (uint32_t)u : du;
         }
         // (d stays FLT_MAX only for an empty batch, which does not occur: cnt >= 1.)
         if (d < cd) {
+          cd2 = cd < d_second ? cd : d_second;  // the old best and the rest of the batch are "other points" now
           cd = d;
           cpos = begin + du;
           cok = gmax <= d;
-        } else if (d == cd && d <= best) {  // an exact tie that can still matter: the one the reference visits first
-          if (tie_budget == 0u) {
-            cok = false;
-          } else {
-            --tie_budget;
-            if (!dfs_before(t, ranges, qx, qy, qz, cpos, begin + du)) {
-              cpos = begin + du;
-              cok = gmax <= d;
+          cg = gmax;
+        } else {
+          cd2 = d < cd2 ? d : cd2;
+          if (d == cd && d <= best) {  // an exact tie that can still matter: the one the reference visits first
+            if (tie_budget == 0u) {
+              cok = false;
+              cg = 3.402823466e+38f;
+            } else {
+              --tie_budget;
+              if (!dfs_before(t, ranges, qx, qy, qz, cpos, begin + du)) {
+                cpos = begin + du;
+                cok = gmax <= d;
+                cg = gmax;
+              }
             }
           }
         }
@@ -1871,8 +1884,22 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         a_first = __shfl(a_first, la);
         if (several && (int)lane == (a_first ? lb : la)) mine = false;
       }
+      // The certificate, widened by one case.  `cok` says every far child on the way to the winner has a box distance
+      // <= d*.  On data with coordinates on a grid the nearest point often lies ON the planes that bound its subtrees
+      // and the incrementally updated box distance ends one rounding ABOVE the point's distance: cok fails, though the
+      // reference does reach the point -- it enters a far child when its best so far is >= the box distance, and its
+      // best so far is the distance of some OTHER point.  So: if every other point is at least as far as the largest
+      // box distance g on the winner's path, the reference enters every far child on that path, accepts the winner
+      // (its best then is >= g > d*, strictly) and keeps it.  "Every other point" = the nearest of what the lanes have
+      // measured except the winner (their bests, the winner's runner-up) and the best that was handed over; what was
+      // pruned is farther than d* (1 + 2^-11) (see above), hence g <= d* (1 + 2^-12) is required as well.
+      if (done && gl == 0) *gsecond = __float_as_uint(start_d);
       const uint64_t mm = __ballot(mine) & gmask;
-      const uint64_t good = __ballot(mine && cok) & gmask;
+      if (done && !failed) lds_min_u32(gsecond, __float_as_uint(mine ? cd2 : cd));
+      const uint64_t strict = __ballot(mine && cok) & gmask;
+      const float d_other = __uint_as_float(*gsecond);
+      const bool wide = mine && !cok && cg <= d_other && cg <= f_add(dstar, f_mul(dstar, 0.000244140625f));
+      const uint64_t good = strict | (__ballot(wide) & gmask);
       if (done) {
         if (failed) {
           if (gl == 0) redo_list[atomicAdd(&cont.meta[kMetaRedo], 1u)] = e;
