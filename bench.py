@@ -341,7 +341,7 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     b = 12 + 8 * (hits / nq) + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
     kernel_ms = prof["search_ms"] / steps
     r = roofline_of(b, nq, kernel_ms)
-    r["kernel"] = "ptk::radius_capture_kernel + ptk::radius_scatter_kernel"
+    r["kernel"] = "ptk::radius_capture_kernel + ptk::radius_log_scatter_kernel"
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
     res["radius"] = {"radius_squared": radius, "value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s",
                      "ms_per_step": round(ms, 4), "steps": steps, "hits_per_query": round(hits / nq, 2),

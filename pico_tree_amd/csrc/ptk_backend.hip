@@ -935,7 +935,7 @@ template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_radius_capture(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
                           float e, uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  const size_t smem = (size_t)S * BLOCK * 8;
+  const size_t smem = (size_t)S * BLOCK * 8 + 16;  // + the cursor of the wavefront's log
   Timer timer(t, s);
   PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
   hipLaunchKernelGGL((ptk::radius_capture_kernel<S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s,
@@ -955,19 +955,26 @@ size_t capture_budget_bytes(const ptk_tree* t) {
 }
 
 // Sizes (and if needed allocates) the capture block for a batch of nq rows; false = no capture.
-// Layout: counters | captured flags | chunks.  The dynamic pool is 8 chunks (248 hits) per row
-// when the budget allows; PTK_RADIUS_CAPTURE_CHUNKS overrides chunks per sub-pool (tests).
+// Layout: counters | captured flags (one per wavefront) | query of every lane | chunks.  Every wavefront of the
+// launch owns one static chunk; the dynamic pool is sized for 1024 hits per row when the budget allows (the
+// scan-like cloud of BASELINE config 3 averages 105); PTK_RADIUS_CAPTURE_CHUNKS overrides chunks per sub-pool (tests).
 bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
   const size_t budget = capture_budget_bytes(t);
   if (budget == 0 || nq == 0 || nq >= (1ull << 31)) return false;
-  const size_t chunk_bytes = (size_t)ptk::kCapChunk * sizeof(ptk::Neighbor);
-  const size_t head = (size_t)ptk::kCapSubPools * ptk::kCapCounterStride * 4 + ((nq + 255) & ~(size_t)255);
-  if (head + nq * chunk_bytes > budget) return false;
-  const size_t dyn = std::min<size_t>((budget - head - nq * chunk_bytes) / chunk_bytes, nq * 8);
+  const size_t waves = (size_t)((nq + 63) / 64);
+  const size_t chunk_bytes = (size_t)ptk::kLogChunk * sizeof(ptk::Neighbor);
+  const size_t flags_at = (size_t)ptk::kCapSubPools * ptk::kCapCounterStride * 4;
+  const size_t qids_at = flags_at + ((waves + 255) & ~(size_t)255);
+  const size_t head = (qids_at + waves * 64 * 4 + 4095) & ~(size_t)4095;
+  if (head + waves * chunk_bytes > budget) return false;
+  const size_t dyn = std::min<size_t>((budget - head - waves * chunk_bytes) / chunk_bytes, waves * 64 * 2);
   const int forced = env_int("PTK_RADIUS_CAPTURE_CHUNKS", -1);
   size_t sub_cap = forced >= 0 ? (size_t)forced : dyn / ptk::kCapSubPools;
-  if (nq + sub_cap * ptk::kCapSubPools >= (1ull << 32)) sub_cap = ((1ull << 32) - 1 - nq) / ptk::kCapSubPools;
-  const size_t bytes = head + (nq + sub_cap * ptk::kCapSubPools) * chunk_bytes;
+  // (a slot of the log is addressed with 32 bits)
+  const size_t max_chunks = ((1ull << 32) - 1) / ptk::kLogChunk;
+  if (waves >= max_chunks) return false;
+  if (waves + sub_cap * ptk::kCapSubPools > max_chunks) sub_cap = (max_chunks - waves) / ptk::kCapSubPools;
+  const size_t bytes = head + (waves + sub_cap * ptk::kCapSubPools) * chunk_bytes;
   if (bytes > ws.cap_capacity) {
     drain_workspace(ws);
     if (ws.cap_base) (void)hipFree(ws.cap_base);
@@ -984,9 +991,10 @@ bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
     ws.cap_capacity = bytes;
   }
   ws.cap.counters = reinterpret_cast<uint32_t*>(ws.cap_base);
-  ws.cap.captured = reinterpret_cast<uint8_t*>(ws.cap_base + (size_t)ptk::kCapSubPools * ptk::kCapCounterStride * 4);
+  ws.cap.captured = reinterpret_cast<uint8_t*>(ws.cap_base + flags_at);
+  ws.cap.qids = reinterpret_cast<uint32_t*>(ws.cap_base + qids_at);
   ws.cap.chunks = reinterpret_cast<ptk::Neighbor*>(ws.cap_base + head);
-  ws.cap.n_static = (uint32_t)nq;
+  ws.cap.n_static = (uint32_t)waves;
   ws.cap.sub_cap = (uint32_t)sub_cap;
   return true;
 }
@@ -1342,7 +1350,7 @@ int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, const uint32_t
                              float e, uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
   constexpr int S = 16;
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-  const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
+  const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8 + 16;  // + the cursor of the wavefront's log
   if (smem > t->lds_per_block)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
   Timer timer(t, s);
@@ -2100,10 +2108,12 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     {
       Timer timer(t, s);
       PTK_HIP(hipMemsetAsync(n_over, 0, 4, s));
-      constexpr int G = 32;
-      const uint64_t threads = nq * G;
-      hipLaunchKernelGGL((ptk::radius_scatter_kernel<G>), dim3((uint32_t)((threads + 255) / 256)), dim3(256), 0, s,
-                         ws.cap, nq, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over);
+      constexpr int W = 1;  // (one wavefront per block: the LDS of a CU divides evenly)
+      const size_t hold = (size_t)W * ptk::kLogScatterLds;  // a staged and a sorted chunk per wavefront
+      rc = allow_lds(ptk::radius_log_scatter_kernel<W>, hold);
+      if (rc != PTK_OK) return rc;
+      hipLaunchKernelGGL((ptk::radius_log_scatter_kernel<W>), dim3((ws.cap.n_static + W - 1) / W), dim3(64 * W), hold, s,
+                         ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over);
       PTK_HIP(hipGetLastError());
       timer.stop(0, 0);
     }

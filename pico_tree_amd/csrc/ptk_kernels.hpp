@@ -453,86 +453,234 @@ struct KnnRegPolicy {
   }
 };
 
-// Rows captured during the count pass.  The radius search is a count pass, a scan and a fill pass;
-// the fill pass repeats the whole traversal only to learn where each hit goes.  With a capture the
-// count pass also writes every hit into a chain of 256-byte chunks -- chunk qi is the first chunk
-// of row qi, later ones come from kCapSubPools bump allocators (one atomic per 31 hits, the
-// counters on separate cache lines, a wavefront staying with the pool of its block: atomics of
-// one wavefront on many lines were measured 1.6x slower for the whole pass) -- and the fill pass
-// becomes a copy (radius_scatter_kernel).  The next chunk is claimed when the current one is half
-// full and the answer is only looked at when it is needed.  A row whose chain could not grow is
-// marked and searched again by the ordinary fill kernel: a small pool costs time, never
-// correctness.  Entry 0 of a chunk is its header: .index = next chunk.  Entries leave the lane in
-// aligned pairs (2|3, 4|5, ...: one 16-byte store; entry 1 alone, a last odd one by flush()).
-// (Measured and rejected, profiles/r01l_notes.txt: a per-wavefront log of hits in LDS flushed 64
-// entries at a time with full-width stores -- every KB of LDS per wavefront costs more occupancy
-// than the stores give back.)
-constexpr uint32_t kCapChunk = 32;           // 8-byte entries per chunk, header included
+// Rows captured during the count pass.  The radius search is a count pass, a scan and a fill pass; the fill pass
+// would repeat the whole traversal only to learn where each hit goes.  With a capture the count pass also writes
+// every hit to a LOG OF ITS WAVEFRONT, and the fill pass becomes a copy (radius_log_scatter_kernel).
+//
+// Why a log per wavefront.  r01/r02 kept a chain of 256-byte chunks per ROW, every lane storing its own hits 16
+// bytes at a time: the 16 bytes of one lane are followed by the next 16 of the same 128-byte line hundreds of
+// microseconds later, 330 k such lines are open at once (more than the L2s hold), so each store went to HBM on its
+// own as a 32-byte write -- 13.9 GB of WRITE_SIZE for 6.06 GB of rows on BASELINE config 3 (profiles/r02y_pmc.txt,
+// r03m_c3_traffic.json), 4.7 of the 9.7 ms of the pass.  Here the hits a wavefront finds in ONE visit step (ballot
+// of `radius > d` over the lanes executing that step) leave as one contiguous store of 8 bytes per hit at the
+// wavefront's cursor, and the next step's store continues where this one ended: the lines of a log fill within
+// a few hundred cycles and go to HBM once, whole.
+//
+// Format.  The log is a chain of chunks of kLogChunk 8-byte slots.  Slot 0 is the header {next chunk, groups in
+// this chunk}; entries grow upwards from slot 1; the 64-bit lane mask of each group (which lane owns which entry:
+// the entries of a group are in lane order) grows downwards from the last slot, so that the copy can fetch 64 masks
+// with one coalesced load.  A group never straddles chunks.  Chunk `w` is the first chunk of wavefront `w` of the
+// launch; later ones come from kCapSubPools bump allocators (one atomic per chunk, the counters on separate cache
+// lines, a wavefront staying with one pool).  The cursor {next slot, groups, chunk} of the wavefront is two LDS
+// words behind the record stack, read and written by the first lane of each group only.  A wavefront whose chain
+// could not grow is marked and its 64 rows are searched again by the ordinary fill kernel: a small pool costs time,
+// never correctness.  The order of the hits of one row is the order its lane found them in: the visit order of the
+// reference (search_visitor.hpp:127-156).
+#ifndef PTK_LOG_CHUNK
+#define PTK_LOG_CHUNK 1024
+#endif
+constexpr uint32_t kLogChunk = PTK_LOG_CHUNK;  // 8-byte slots per chunk (8 KB), header and masks included
+constexpr uint32_t kLogEnd = 0xFFFFFFFFu;    // header: no next chunk / cursor: the capture has failed
 constexpr uint32_t kCapSubPools = 256;
 constexpr uint32_t kCapCounterStride = 16;   // words between counters: one 64-byte line each
 
 struct RadiusCapture {
-  Neighbor* chunks;     // (n_static + kCapSubPools * sub_cap) * kCapChunk entries
+  Neighbor* chunks;     // (n_static + kCapSubPools * sub_cap) * kLogChunk slots
   uint32_t* counters;   // kCapSubPools * kCapCounterStride words, zero before the count pass
-  uint8_t* captured;    // per query: 1 = the whole row is in its chain
-  uint32_t n_static;    // queries of the batch
+  uint8_t* captured;    // per wavefront of the launch: 1 = all of its rows are in its log
+  uint32_t* qids;       // [n_static * 64] the query each lane of each wavefront searched (kLogEnd: none)
+  uint32_t n_static;    // wavefronts of the launch
   uint32_t sub_cap;     // chunks per sub-pool
 };
 
 constexpr int kRadiusCount = 0, kRadiusFill = 1, kRadiusCapture = 2;
 
+// Lanes below `lane` set in m.
+__device__ __forceinline__ uint32_t lanes_below(uint64_t m, uint32_t lane) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  (void)lane;
+  return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+#else
+  return (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
+#endif
+}
+
+// Policies that take the points of a leaf round together (visit_round<N>) say so with kRoundVisit.
+template <class P, class = void>
+struct takes_rounds : std::false_type {};
+template <class P>
+struct takes_rounds<P, std::void_t<decltype(P::kRoundVisit)>> : std::integral_constant<bool, P::kRoundVisit> {};
+
 template <int MODE>
 struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
+  static constexpr bool kRoundVisit = MODE == kRadiusCapture;
   float radius;  // already scaled by 1/e for the approximate search (:265)
   float e_inv;
   uint64_t count;
   Neighbor* out;  // fill: first record of this query's row; capture: the chunk array
   // capture only
   uint32_t* counters;
-  uint32_t cur, pos, next, sub, sub_cap, n_static;
-  bool capturing;
-  Neighbor staged;
-  // After the traversal: the entry still waiting for a successor.
-  __device__ __forceinline__ void flush() {
-    if (MODE == kRadiusCapture && capturing && pos >= 3u && (pos & 1u) != 0u) out[(uint64_t)cur * kCapChunk + pos - 1u] = staged;
+  LdsWord* cursor;  // [0] = next slot | groups << 32, [1] = chunk (kLogEnd: capture failed)
+  uint32_t sub, sub_cap, n_static, lane;
+
+  // capture: the cursor of a wavefront that starts on its static chunk (one lane; LDS operations of a wavefront
+  // are executed in order, so no barrier is needed before the first group reads it)
+  __device__ __forceinline__ void open_log(uint32_t wave) {
+    cursor[0] = 1ull;
+    cursor[1] = wave;
+  }
+  // capture, after the traversal: the header of the last chunk; true = the log holds every hit of the wavefront
+  __device__ __forceinline__ bool close_log() {
+    const uint32_t chunk = (uint32_t)cursor[1];
+    if (chunk == kLogEnd) return false;
+    const uint32_t ng = (uint32_t)(cursor[0] >> 32);
+    Neighbor h;
+    h.index = (int32_t)kLogEnd;
+    h.distance = __uint_as_float(ng);
+    out[(uint64_t)chunk * kLogChunk] = h;
+    return true;
+  }
+  // The first lane of a group: room for n entries and their mask; returns the slot of the first entry (0 = none).
+  __device__ __forceinline__ uint32_t append_group(uint64_t mask, uint32_t n) {
+    const unsigned long long w = cursor[0];
+    uint32_t chunk = (uint32_t)cursor[1];
+    if (chunk == kLogEnd) return 0u;
+    uint32_t pos = (uint32_t)w, ng = (uint32_t)(w >> 32);
+    if (pos + n + ng + 1u > kLogChunk) {  // entries [1, pos) and masks [kLogChunk - ng, kLogChunk) would meet
+      const uint32_t nx = atomicAdd(&counters[sub * kCapCounterStride], 1u);
+      Neighbor h;
+      h.index = (int32_t)(nx < sub_cap ? n_static + sub * sub_cap + nx : kLogEnd);
+      h.distance = __uint_as_float(ng);
+      out[(uint64_t)chunk * kLogChunk] = h;
+      chunk = (uint32_t)h.index;
+      cursor[1] = chunk;
+      if (chunk == kLogEnd) return 0u;
+      pos = 1u;
+      ng = 0u;
+    }
+    Neighbor mk;
+    mk.index = (int32_t)(uint32_t)mask;
+    mk.distance = __uint_as_float((uint32_t)(mask >> 32));
+    out[(uint64_t)chunk * kLogChunk + (kLogChunk - 1u - ng)] = mk;
+    cursor[0] = (unsigned long long)(pos + n) | ((unsigned long long)(ng + 1u) << 32);
+    return chunk * kLogChunk + pos;
   }
   __device__ __forceinline__ float max() const { return radius; }
+  // capture: the N points of one round of a leaf scan at once (traverse<> hands them over together when the policy
+  // has this member): one exchange with the cursor for up to N groups instead of N -- the read-modify-write of the
+  // cursor is a chain of two LDS latencies that every lane of the wavefront waits for.
+  template <int N>
+  __device__ __forceinline__ void visit_round(const int32_t* idx, const float* dist, uint32_t nvalid) {
+    float d[N];
+    bool hit[N];
+    uint64_t m[N];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      d[u] = f_mul(dist[u], e_inv);
+      hit[u] = (uint32_t)u < nvalid && radius > d[u];  // strict
+#if defined(__HIP_DEVICE_COMPILE__)
+      m[u] = __ballot(hit[u]);
+#else
+      m[u] = hit[u] ? 1ull << lane : 0ull;
+#endif
+      any = any || hit[u];
+    }
+    if (any) {
+      uint64_t all = 0ull;
+#pragma unroll
+      for (int u = 0; u < N; ++u) all |= m[u];
+      const uint32_t leader = (uint32_t)__builtin_ctzll(all);
+      uint32_t base = 0u;
+      if (lane == leader) base = append_groups<N>(m);
+#if defined(__HIP_DEVICE_COMPILE__)
+      base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)leader);
+#endif
+#pragma unroll
+      for (int u = 0; u < N; ++u) {
+        if (hit[u]) {
+          if (base != 0u) {
+            Neighbor nb;
+            nb.index = idx[u];
+            nb.distance = d[u];
+            out[base + lanes_below(m[u], lane)] = nb;
+          }
+          ++count;
+        }
+        base += base != 0u ? (uint32_t)__popcll(m[u]) : 0u;
+      }
+    }
+  }
+  // One lane: room for the groups of a round (the non-empty masks among m[0..N)); the slot of the first entry.
+  template <int N>
+  __device__ __forceinline__ uint32_t append_groups(const uint64_t* m) {
+    const unsigned long long w = cursor[0];
+    uint32_t chunk = (uint32_t)cursor[1];
+    if (chunk == kLogEnd) return 0u;
+    uint32_t n = 0u, groups = 0u;
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      n += (uint32_t)__popcll(m[u]);
+      groups += m[u] != 0ull ? 1u : 0u;
+    }
+    uint32_t pos = (uint32_t)w, ng = (uint32_t)(w >> 32);
+    if (pos + n + ng + groups > kLogChunk) {
+      const uint32_t nx = atomicAdd(&counters[sub * kCapCounterStride], 1u);
+      Neighbor h;
+      h.index = (int32_t)(nx < sub_cap ? n_static + sub * sub_cap + nx : kLogEnd);
+      h.distance = __uint_as_float(ng);
+      out[(uint64_t)chunk * kLogChunk] = h;
+      chunk = (uint32_t)h.index;
+      cursor[1] = chunk;
+      if (chunk == kLogEnd) return 0u;
+      pos = 1u;
+      ng = 0u;
+    }
+    cursor[0] = (unsigned long long)(pos + n) | ((unsigned long long)(ng + groups) << 32);
+#pragma unroll
+    for (int u = 0; u < N; ++u) {
+      if (m[u] != 0ull) {
+        Neighbor mk;
+        mk.index = (int32_t)(uint32_t)m[u];
+        mk.distance = __uint_as_float((uint32_t)(m[u] >> 32));
+        out[(uint64_t)chunk * kLogChunk + (kLogChunk - 1u - ng)] = mk;
+        ++ng;
+      }
+    }
+    return chunk * kLogChunk + pos;
+  }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
-    if (radius > d) {  // strict
-      Neighbor nb;
-      nb.index = idx;
-      nb.distance = d;
-      if (MODE == kRadiusFill) out[count] = nb;
-      if (MODE == kRadiusCapture && capturing) {
-        if (pos == kCapChunk) {  // the chunk claimed half a chunk ago: was there room?
-          if (next < sub_cap) {
-            const uint32_t id = n_static + sub * sub_cap + next;
-            Neighbor link;
-            link.index = (int32_t)id;
-            link.distance = 0.0f;
-            out[(uint64_t)cur * kCapChunk] = link;
-            cur = id;
-            pos = 1;
-          } else {
-            capturing = false;
-          }
+    const bool hit = radius > d;  // strict
+    if (MODE == kRadiusCapture) {
+      // The lanes executing this visit together and their hits.  (The CPU emulation of the test tier runs one lane
+      // at a time: every hit is a group of its own there.)
+#if defined(__HIP_DEVICE_COMPILE__)
+      const uint64_t m = __ballot(hit);
+#else
+      const uint64_t m = hit ? 1ull << lane : 0ull;
+#endif
+      if (hit) {
+        const uint32_t rank = lanes_below(m, lane);
+        uint32_t base = 0u;
+        if (rank == 0u) base = append_group(m, (uint32_t)__popcll(m));
+#if defined(__HIP_DEVICE_COMPILE__)
+        base = (uint32_t)__builtin_amdgcn_readlane((int)base, (int)__builtin_ctzll(m));
+#endif
+        if (base != 0u) {
+          Neighbor nb;
+          nb.index = idx;
+          nb.distance = d;
+          out[base + rank] = nb;
         }
-        if (capturing) {
-          // Entries 2, 4, ... wait in registers for their successor: the two go out as one aligned 16-byte
-          // store (entry 0 is the chunk's header, so entry 1 goes alone and a chunk ends on a pair).
-          if (pos == 1u) {
-            out[(uint64_t)cur * kCapChunk + 1u] = nb;
-          } else if ((pos & 1u) == 0u) {
-            staged = nb;
-          } else {
-            *reinterpret_cast<uint4*>(out + (uint64_t)cur * kCapChunk + pos - 1u) =
-                make_uint4((uint32_t)staged.index, __float_as_uint(staged.distance), (uint32_t)nb.index,
-                           __float_as_uint(nb.distance));
-          }
-          ++pos;
-          if (pos == kCapChunk / 2) next = atomicAdd(&counters[sub * kCapCounterStride], 1u);
-        }
+        ++count;
+      }
+    } else if (hit) {
+      if (MODE == kRadiusFill) {
+        Neighbor nb;
+        nb.index = idx;
+        nb.distance = d;
+        out[count] = nb;
       }
       ++count;
     }
@@ -615,6 +763,18 @@ __device__ __forceinline__ bool traverse(
         float4 p[LEAFB];
 #pragma unroll
         for (int u = 0; u < LEAFB; ++u) p[u] = pts[begin + j + u];
+        if constexpr (takes_rounds<Policy>::value) {
+          int32_t ids[LEAFB];
+          float ds[LEAFB];
+#pragma unroll
+          for (int u = 0; u < LEAFB; ++u) {
+            PTK_KEEP4(p[u]);
+            ids[u] = __float_as_int(p[u].w);
+            ds[u] = point_distance3<M>(f_sub(qx, p[u].x), f_sub(qy, p[u].y), f_sub(qz, p[u].z));
+          }
+          pol.template visit_round<LEAFB>(ids, ds, count - j);
+          continue;
+        }
 #pragma unroll
         for (int u = 0; u < LEAFB; ++u) {
           if (j + u < count) {
@@ -861,16 +1021,22 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
   if (!FILL) counts[qi] = pol.count;
 }
 
-// The count pass that also captures the rows (see RadiusCapture).
+// The count pass that also captures the rows (see RadiusCapture).  One wavefront per block: the cursor of its log
+// is the two LDS words behind the record stack.
 template <int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
     uint64_t* __restrict__ counts, RadiusCapture cap) {
+  static_assert(BLOCK == 64, "one log per block");
   const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
-  if (i >= nq) return;
+  if (i >= nq) {
+    cap.qids[i] = kLogEnd;
+    return;
+  }
   const uint64_t qi = perm ? perm[i] : i;
+  cap.qids[i] = (uint32_t)qi;
   float qx, qy, qz;
   load_query(queries, dim, qi, qx, qy, qz);
   pad_query<M>(dim, qy, qz);
@@ -884,49 +1050,172 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
   pol.count = 0;
   pol.out = cap.chunks;
   pol.counters = cap.counters;
-  pol.cur = (uint32_t)qi;
-  pol.pos = 1;
-  pol.next = 0xFFFFFFFFu;
+  pol.cursor = (LdsWord*)(ptk_smem + (size_t)S * BLOCK * 8);
   pol.sub = (blockIdx.x * 0x9E3779B1u) >> 24;  // kCapSubPools = 256: the top byte of a hash of the block
   pol.sub_cap = cap.sub_cap;
   pol.n_static = cap.n_static;
-  pol.capturing = true;
-  pol.staged = Neighbor{0, 0.0f};
+  pol.lane = threadIdx.x;
+  if (threadIdx.x == 0) pol.open_log(tile);
   traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   counts[qi] = pol.count;
-  pol.flush();
-  cap.captured[qi] = pol.capturing ? 1 : 0;
+  cap.captured[tile] = pol.close_log() ? 1 : 0;  // (every lane writes the same two values)
 }
 
-// The fill pass of a captured batch: G lanes copy one row out of its chain, one chunk per step at
-// G = 32 (lane j moves entry j; the header rides along and gives the next chunk).  Rows of up to
-// 31 hits -- most -- lie in the static chunks, which are in row order like the output: for them
-// this is a coalesced stream compaction.  Rows that were not captured are listed for
-// radius_kernel<FILL>.
-template <int G>
-__global__ __launch_bounds__(256) void radius_scatter_kernel(
-    RadiusCapture cap, uint64_t nq, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out,
+// The fill pass of a captured batch: one wavefront copies the log of one wavefront of the count pass into the 64
+// rows it belongs to, a chunk at a time:
+//   stage   the chunk is brought into LDS whole -- loads of 512 contiguous bytes, all in flight together, and the
+//           loads of the NEXT chunk (its number is in this chunk's header) are issued before this one is taken
+//           apart: one memory latency per chunk;
+//   count   the masks of up to 64 groups are read with one LDS access (lane g holds group g's); every lane counts
+//           the groups it has an entry in, and a scan over the lanes gives each row its place in the sorted chunk;
+//   move    group by group (the slot of a group's first entry is a running sum on the scalar unit) the owners move
+//           their entries, LDS to LDS, behind one another: the chunk is now ordered by row, each row's entries in
+//           log order -- the order its lane found them in;
+//   write   the sorted chunk leaves with consecutive lanes on consecutive entries; the entries of a row lie at
+//           consecutive addresses, so each run of them is one request.  A run stops at the last 32-byte boundary
+//           of its row it reaches; the up to three entries behind it wait (in registers) for the next chunk, so no
+//           32-byte sector of a row is written twice (without this: 10.4 GB of WRITE_SIZE for 6.06 GB of rows).
+// (Appending entry by entry from the log to 64 rows -- the first form of this kernel -- is 758 M uncoalesced 8-byte
+// stores on BASELINE config 3, each a request of its own and a 32-byte write in HBM: 8.7 ms, 13.0 GB of WRITE_SIZE
+// for 6.06 GB of rows, 90 % of the wavefront cycles waiting to issue; profiles/r03r_c3_pmc.txt.)
+// Wavefronts the capture could not hold are listed, row by row, for radius_kernel<FILL>.
+constexpr int kLogUnroll = 4;
+// LDS bytes per wavefront: staged chunk, sorted chunk (+ 3 entries kept back per row), row tables, owner of each slot
+constexpr uint32_t kLogScatterLds = kLogChunk * 8u * 2u + 256u * 8u + 64u * 12u + kLogChunk + 256u;
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
+    RadiusCapture cap, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out,
     uint32_t* __restrict__ over_list, uint32_t* __restrict__ n_over) {
-  const uint64_t tid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t qi = tid / G;
-  const uint32_t sub = (uint32_t)(tid % G);
-  if (qi >= nq) return;
-  const uint64_t o = offsets[qi];
-  const uint64_t c = offsets[qi + 1] - o;
-  if (!cap.captured[qi]) {
-    if (sub == 0) over_list[atomicAdd(n_over, 1u)] = (uint32_t)qi;
+  const uint32_t lane = threadIdx.x & 63u;
+  const uint32_t tile = blockIdx.x * WAVES + threadIdx.x / 64u;
+  if (tile >= cap.n_static) return;
+  const uint32_t qi = cap.qids[(uint64_t)tile * 64 + lane];
+  const bool valid = qi != kLogEnd;
+  if (!cap.captured[tile]) {
+    if (valid) over_list[atomicAdd(n_over, 1u)] = qi;
     return;
   }
-  uint32_t chunk = (uint32_t)qi;
-  for (uint64_t done = 0; done < c;) {
-    const Neighbor* base = cap.chunks + (uint64_t)chunk * kCapChunk;
-    const uint64_t left = c - done;
-    const uint32_t n = left < kCapChunk - 1 ? (uint32_t)left : kCapChunk - 1;
-    const uint32_t link = left > kCapChunk - 1 ? (uint32_t)base[0].index : 0u;  // same address in all G lanes
-    for (uint32_t j = sub; j < n; j += G) out[o + done + j] = base[1 + j];
-    done += n;
-    chunk = link;
+  uint32_t chunk = tile;
+#if defined(__HIP_DEVICE_COMPILE__)
+  constexpr uint32_t kPer = kLogChunk / 64u;  // slots of a chunk per lane
+  uint64_t rowpos = valid ? offsets[qi] : 0ull;  // where this lane's next entry goes
+  unsigned char PTK_LDS* mine_lds = (unsigned char PTK_LDS*)ptk_smem + (size_t)(threadIdx.x / 64u) * kLogScatterLds;
+  LdsWord* stage = (LdsWord*)mine_lds;
+  LdsWord* sorted = stage + kLogChunk;
+  LdsWord* adj = sorted + kLogChunk + 256;
+  uint32_t PTK_LDS* lim = (uint32_t PTK_LDS*)(adj + 64);
+  unsigned char PTK_LDS* own = (unsigned char PTK_LDS*)(lim + 64);
+  const unsigned long long* __restrict__ words = reinterpret_cast<const unsigned long long*>(cap.chunks);
+  unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(out);
+  unsigned long long in[kPer];
+#pragma unroll
+  for (uint32_t j = 0; j < kPer; ++j) in[j] = __builtin_nontemporal_load(words + (uint64_t)chunk * kLogChunk + j * 64u + lane);
+  unsigned long long kept[3] = {0ull, 0ull, 0ull};  // entries of this lane's row still to be written
+  uint32_t n_kept = 0u;
+  for (;;) {
+#pragma unroll
+    for (uint32_t j = 0; j < kPer; ++j) stage[j * 64u + lane] = in[j];
+    const unsigned long long head = stage[0];
+    const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)head);
+    const uint32_t ng = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(head >> 32));
+    if (next != kLogEnd) {
+#pragma unroll
+      for (uint32_t j = 0; j < kPer; ++j) in[j] = __builtin_nontemporal_load(words + (uint64_t)next * kLogChunk + j * 64u + lane);
+    }
+    // count
+    uint32_t n_mine = 0u;
+    for (uint32_t g0 = 0; g0 < ng; g0 += 64u) {
+      const uint32_t left = ng - g0 < 64u ? ng - g0 : 64u;
+      const unsigned long long mk = lane < left ? stage[kLogChunk - 1u - g0 - lane] : 0ull;  // (no group: no owner)
+      for (uint32_t g = 0; g < left; ++g) {
+        const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, (int)g) |
+                           ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), (int)g) << 32);
+        n_mine += (uint32_t)((m >> lane) & 1ull);
+      }
+    }
+    // (entries held back from the last chunk come first, see `write`)
+    const uint32_t n_row = n_mine + n_kept;
+    uint32_t incl = n_row;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const uint32_t v = (uint32_t)__shfl_up((int)incl, d);
+      incl += lane >= (uint32_t)d ? v : 0u;
+    }
+    const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+    const uint32_t first = incl - n_row;
+    uint32_t c = first;
+    adj[lane] = rowpos - (uint64_t)first;  // (row position of sorted slot f of this lane = adj + f; wraps are harmless)
+    // What leaves now: up to the last 32-byte boundary of the row this chunk reaches (everything with the last chunk).
+    const uint64_t row_end = rowpos + n_row;
+    const uint64_t stop = next == kLogEnd ? row_end : (row_end & ~3ull);
+    const uint32_t n_out = stop > rowpos ? (uint32_t)(stop - rowpos) : 0u;
+    lim[lane] = first + n_out;
+    // move
+#pragma unroll
+    for (uint32_t j = 0; j < 3u; ++j) {
+      if (j < n_kept) {
+        sorted[c] = kept[j];
+        own[c] = (unsigned char)lane;
+        ++c;
+      }
+    }
+    uint32_t pos = 1u;
+    for (uint32_t g0 = 0; g0 < ng; g0 += 64u) {
+      const uint32_t left = ng - g0 < 64u ? ng - g0 : 64u;
+      const unsigned long long mk = lane < left ? stage[kLogChunk - 1u - g0 - lane] : 0ull;
+      for (uint32_t g = 0; g < left; g += kLogUnroll) {
+        unsigned long long e[kLogUnroll];
+        bool mine[kLogUnroll];
+#pragma unroll
+        for (int u = 0; u < kLogUnroll; ++u) {
+          const int src = (int)((g + u) & 63u);
+          const uint64_t m = (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)mk, src) |
+                             ((uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mk >> 32), src) << 32);
+          const uint64_t mm = g + u < left ? m : 0ull;
+          mine[u] = ((mm >> lane) & 1ull) != 0ull;
+          if (mine[u]) e[u] = stage[pos + lanes_below(mm, lane)];
+          pos += (uint32_t)__popcll(mm);
+        }
+#pragma unroll
+        for (int u = 0; u < kLogUnroll; ++u) {
+          if (mine[u]) {
+            sorted[c] = e[u];
+            own[c] = (unsigned char)lane;
+            ++c;
+          }
+        }
+      }
+    }
+    // write
+    for (uint32_t f = lane; f < total; f += 64u) {
+      const uint32_t o = own[f];
+      if (f < lim[o]) dst[adj[o] + f] = sorted[f];
+    }
+    rowpos += n_out;
+    n_kept = n_row - n_out;  // <= 3
+#pragma unroll
+    for (uint32_t j = 0; j < 3u; ++j) {
+      if (j < n_kept) kept[j] = sorted[first + n_out + j];
+    }
+    if (next == kLogEnd) break;
   }
+#else
+  Neighbor* row = out + (valid ? offsets[qi] : 0ull);
+  for (;;) {  // one lane at a time: the same walk without the wavefront
+    const Neighbor* base = cap.chunks + (uint64_t)chunk * kLogChunk;
+    const Neighbor head = base[0];
+    const uint32_t ng = __float_as_uint(head.distance);
+    uint32_t pos = 1u;
+    for (uint32_t g = 0; g < ng; ++g) {
+      const Neighbor mk = base[kLogChunk - 1u - g];
+      const uint64_t m = (uint64_t)(uint32_t)mk.index | ((uint64_t)__float_as_uint(mk.distance) << 32);
+      if ((m >> lane) & 1ull) *row++ = base[pos + lanes_below(m, lane)];
+      pos += (uint32_t)__popcll(m);
+    }
+    if ((uint32_t)head.index == kLogEnd) break;
+    chunk = (uint32_t)head.index;
+  }
+#endif
 }
 
 // ---- two-phase k = 1 search ---------------------------------------------------------------

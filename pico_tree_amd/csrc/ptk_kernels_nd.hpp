@@ -210,14 +210,20 @@ __global__ __launch_bounds__(64) void radius_nd_kernel(
   if (!FILL) counts[qi] = pol.count;
 }
 
-// The count pass that also captures the rows (RadiusCapture, ptk_kernels.hpp).
+// The count pass that also captures the rows (RadiusCapture, ptk_kernels.hpp): the cursor of the wavefront's log
+// lies behind the staged query.
 template <int S, int OVF, class M = MetricL2>
 __global__ __launch_bounds__(64) void radius_nd_capture_kernel(
     DevTreeND t, const float* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t nq, float radius,
     float e_inv, uint64_t* __restrict__ counts, RadiusCapture cap) {
-  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
-  if (i >= nq) return;
-  const uint64_t qi = perm ? perm[i] : i;  // launch order only: row qi is still chain qi
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
+  const uint64_t i = (uint64_t)tile * 64 + threadIdx.x;
+  if (i >= nq) {
+    cap.qids[i] = kLogEnd;
+    return;
+  }
+  const uint64_t qi = perm ? perm[i] : i;
+  cap.qids[i] = (uint32_t)qi;
   LdsFloat *q, *off;
   stage_query_nd<S>(queries, t.dim, qi, q, off);
   Record spill[OVF > 0 ? OVF : 1];
@@ -229,18 +235,15 @@ __global__ __launch_bounds__(64) void radius_nd_capture_kernel(
   pol.count = 0;
   pol.out = cap.chunks;
   pol.counters = cap.counters;
-  pol.cur = (uint32_t)qi;
-  pol.pos = 1;
-  pol.next = 0xFFFFFFFFu;
+  pol.cursor = (LdsWord*)(ptk_smem + (size_t)S * 64 * 8 + (size_t)t.dim * 64 * 8);
   pol.sub = (blockIdx.x * 0x9E3779B1u) >> 24;
   pol.sub_cap = cap.sub_cap;
   pol.n_static = cap.n_static;
-  pol.capturing = true;
-  pol.staged = Neighbor{0, 0.0f};
+  pol.lane = threadIdx.x;
+  if (threadIdx.x == 0) pol.open_log(tile);
   traverse_nd<M>(t, q, off, 64u, pol, st);
   counts[qi] = pol.count;
-  pol.flush();
-  cap.captured[qi] = pol.capturing ? 1 : 0;
+  cap.captured[tile] = pol.close_log() ? 1 : 0;
 }
 
 // ---- box search, any dimension ------------------------------------------------------------

@@ -108,6 +108,8 @@ struct Emu {
   std::vector<ptk::Neighbor> cap_chunks;
   std::vector<uint32_t> cap_counters;
   std::vector<uint8_t> cap_flags;
+  std::vector<uint32_t> cap_qids;
+  uint64_t cap_nq = 0;
   ptk::RadiusCapture cap{};
 };
 
@@ -421,28 +423,35 @@ int emu_radius_fill(void* h, const float* q, uint64_t nq, float radius, float e,
   return 0;
 }
 
-// The capturing count pass (dim <= 3, L2): sub_cap dynamic chunks per sub-pool -- 0 leaves only
-// the static first chunk of every row, so rows above 31 hits take the re-traversal path.
+// Slots of a chunk of the capture log (header and masks included).
+int emu_log_chunk() { return (int)ptk::kLogChunk; }
+
+// The capturing count pass (L2 family): sub_cap dynamic chunks per sub-pool -- 0 leaves only the static first
+// chunk of every wavefront, so wavefronts with more hits than it holds take the re-traversal path.
 int emu_radius_capture(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
                        uint64_t* counts, uint32_t sub_cap) {
   auto* t = static_cast<Emu*>(h);
   if (t->metric != 0) return -3;
-  t->cap_chunks.assign(((size_t)nq + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kCapChunk, ptk::Neighbor{-1, -1.0f});
+  const size_t waves = (size_t)((nq + 63) / 64);
+  t->cap_chunks.assign((waves + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kLogChunk, ptk::Neighbor{-1, -1.0f});
   t->cap_counters.assign(ptk::kCapSubPools * ptk::kCapCounterStride, 0u);
-  t->cap_flags.assign(nq, 2);
+  t->cap_flags.assign(waves, 2);
+  t->cap_qids.assign(waves * 64, 0u);
   t->cap.chunks = t->cap_chunks.data();
   t->cap.counters = t->cap_counters.data();
   t->cap.captured = t->cap_flags.data();
-  t->cap.n_static = (uint32_t)nq;
+  t->cap.qids = t->cap_qids.data();
+  t->cap.n_static = (uint32_t)waves;
   t->cap.sub_cap = sub_cap;
+  t->cap_nq = nq;
   const float e_inv = 1.0f / e;
   if (t->dim > 3) {
-    for_each_lane(nq, [&] {
+    for_each_lane(waves * 64, [&] {
       ptk::radius_nd_capture_kernel<8, 2048>(t->dev_nd, q, perm, nq, radius, e_inv, counts, t->cap);
     }, 64);
     return 0;
   }
-  for_each_lane(nq, [&] {
+  for_each_lane(waves * 64, [&] {
     ptk::radius_capture_kernel<8, 2048, 64, 4>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
   }, 64);
   return 0;
@@ -454,11 +463,12 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
                                  const uint64_t* offsets, ptk_neighbor* out, int sort) {
   auto* t = static_cast<Emu*>(h);
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
-  if (t->cap_flags.size() != nq) return -1;
+  if (t->cap_nq != nq || t->cap_flags.empty()) return -1;
   std::vector<uint32_t> over(nq + 1, 0u);
   uint32_t n_over = 0;
   const float e_inv = 1.0f / e;
-  for_each_lane(nq * 32, [&] { ptk::radius_scatter_kernel<32>(t->cap, nq, offsets, o, over.data(), &n_over); }, 256);
+  for_each_lane((uint64_t)t->cap.n_static * 64,
+                [&] { ptk::radius_log_scatter_kernel<4>(t->cap, offsets, o, over.data(), &n_over); }, 256);
   if (t->dim > 3) {
     for_each_lane(nq, [&] {
       ptk::radius_nd_kernel<16, 2048, true>(t->dev_nd, q, nq, radius, e_inv, nullptr, offsets, o, over.data(), &n_over);

@@ -307,7 +307,7 @@ def test_metric_round_trips_through_saved_file(gpu, tmp_path):
     assert again.search_knn(q, 4).tobytes() == oracle.Oracle(pts, 8, "port", "L1").search_knn(q, 4).tobytes()
 
 
-@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "40"},
+@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "1"},
                                  {"PTK_RADIUS_CAPTURE_MB": "0"}, {"PTK_RADIUS_CAPTURE_MB": "2"}],
                          ids=["default", "static-chunk-only", "pool-runs-dry", "capture-off", "budget-too-small"])
 @pytest.mark.parametrize("cloud,radius", [("lidar", 1.0), ("ties", 0.03)])
@@ -502,7 +502,7 @@ def test_randomised_differential_sweep(gpu, dtype):
     assert ran >= 60
 
 
-@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "5"},
+@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "1"},
                                  {"PTK_RADIUS_CAPTURE_MB": "0"}], ids=["default", "static-chunk-only", "pool-runs-dry", "off"])
 @pytest.mark.parametrize("dim,radius", [(5, 0.06), (16, 1.1)])
 def test_radius_capture_any_dimension(gpu, monkeypatch, env, dim, radius):
