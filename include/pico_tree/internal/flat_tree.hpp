@@ -23,11 +23,16 @@
 #include <array>
 #include <atomic>
 #include <cassert>
+#include <chrono>
 #include <cstdint>
 #include <future>
+#include <exception>
 #include <limits>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 #include <type_traits>
+#include <utility>
 #include <vector>
 
 #include "../core.hpp"
@@ -299,6 +304,10 @@ struct flat_tree {
   //! kd_forest's priority search needs.
   bool keep_outer_bounds = false;
   std::vector<std::array<Scalar_, 2>> outer_bounds;
+  //! Per axis: the number of splits on that axis on the way from the root to a leaf, summed over the points
+  //! (integers held in doubles: exact in any order of summation).  Divided by the number of points this is how finely
+  //! a root-to-leaf path cuts each axis -- what a space-filling order of queries should spend its bits on.
+  std::vector<double> axis_weight;
 };
 
 //! Builds a flat_tree over a space_view.
@@ -329,6 +338,8 @@ class flat_builder {
                             : 1024);
     box_type work = start_bounds;
     index_base_ = tree_.indices.data();
+    path_.assign(tree_.root_box.size(), 0);
+    tree_.axis_weight.assign(tree_.root_box.size(), 0.0);
     task_pool pool;
     pool.idle.store(static_cast<int>(threads) - 1);  // this thread is the first worker
     pool.threads = threads;
@@ -336,6 +347,21 @@ class flat_builder {
     pool_ = threads > 1 ? &pool : nullptr;
     grow(0, index_base_, index_base_ + n, work);
   }
+
+  //! The subtree over [begin, end) of a permutation that starts at `base`, for a node at `depth` whose (loose)
+  //! box is `box`: exactly what grow() does when the recursion arrives there.  `box` leaves tightened.  Nodes
+  //! are numbered from 0 in this builder's tree (see append()).  Serial.
+  void run_range(std::uint32_t depth, Index_* base, Index_* begin, Index_* end, box_type& box,
+                 std::vector<std::uint32_t> const& splits_above) {
+    index_base_ = base;
+    pool_ = nullptr;
+    path_ = splits_above;  // splits per axis between the root and this node
+    tree_.axis_weight.assign(tree_.root_box.size(), 0.0);
+    grow(depth, begin, end, box);
+  }
+
+  //! Appends a separately built subtree in depth-first position (its links are relative to its first node).
+  void append(tree_type const& sub) { splice(sub); }
 
  private:
   bool stops(std::uint32_t depth, Index_ const* begin, Index_ const* end) const {
@@ -430,6 +456,7 @@ class flat_builder {
     tree_.max_depth = std::max(tree_.max_depth, sub.max_depth);
     tree_.leaf_count += sub.leaf_count;
     tree_.max_leaf_points = std::max(tree_.max_leaf_points, sub.max_leaf_points);
+    for (size_t a = 0; a < sub.axis_weight.size() && a < tree_.axis_weight.size(); ++a) tree_.axis_weight[a] += sub.axis_weight[a];
   }
 
   std::uint32_t grow(
@@ -452,6 +479,7 @@ class flat_builder {
       ++tree_.leaf_count;
       tree_.max_leaf_points =
           std::max(tree_.max_leaf_points, static_cast<size_t>(end - begin));
+      for (size_t a = 0; a < path_.size(); ++a) tree_.axis_weight[a] += static_cast<double>(path_[a]) * static_cast<double>(end - begin);
       // Shrink the box to the leaf's points; an empty leaf (midpoint rule only)
       // keeps the box it was given.
       if (begin < end || !std::is_same_v<Rule_, midpoint_max_side_t>) {
@@ -475,6 +503,7 @@ class flat_builder {
     box_type right = box;
     box.max(axis) = plane;    // `box` now bounds the left child
     right.min(axis) = plane;
+    ++path_[axis];
 
     std::uint32_t r;
     if (pool_ != nullptr && (cut - begin) >= kParallelMin && (end - cut) >= kParallelMin && pool_->try_acquire()) {
@@ -485,6 +514,9 @@ class flat_builder {
       flat_builder lb(space_, static_cast<size_t>(stop_), lt), rb(space_, static_cast<size_t>(stop_), rt);
       lb.index_base_ = rb.index_base_ = index_base_;
       lb.pool_ = rb.pool_ = pool_;
+      lb.path_ = rb.path_ = path_;
+      lt.axis_weight.assign(sdim, 0.0);
+      rt.axis_weight.assign(sdim, 0.0);
       task_pool* const pool = pool_;
       auto left_done = std::async(std::launch::async, [&lb, &box, pool, depth, begin, cut] {
         struct on_exit {  // the worker goes idle again, also when the subtree throws
@@ -515,6 +547,7 @@ class flat_builder {
       r = grow(depth + 1, cut, end, right);
     }
 
+    --path_[axis];
     auto& branch = tree_.nodes[self];  // taken after the recursion: vector may grow
     branch.left_max = box.max(axis);   // both tightened by the children
     branch.right_min = right.min(axis);
@@ -530,6 +563,7 @@ class flat_builder {
   Index_ stop_;
   tree_type& tree_;
   Index_* index_base_ = nullptr;  //!< first element of the (shared) index permutation
+  std::vector<std::uint32_t> path_;  //!< splits per axis between the root and the node grow() is at
   task_pool* pool_ = nullptr;     //!< shared by the builders of one threaded build
 };
 
@@ -576,6 +610,296 @@ flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_
   tree_type tree(sdim);
   tree.keep_outer_bounds = keep_outer_bounds;
   flat_builder<SpaceView_, Index_, Rule_, Stop_>(space, stop.derived().value, tree).run(start, threads);
+  return tree;
+}
+
+//! A branch of the top of a tree whose partitions were made elsewhere (by the device: ptk_build.hpp): the
+//! split the builder would have chosen for its box, and where std::partition left the cut.
+template <typename Scalar_>
+struct top_branch {
+  std::uint32_t axis;
+  Scalar_ plane;
+  std::int32_t left;   //!< >= 0: top_branch; < 0: ~(index into the frontier ranges)
+  std::int32_t right;
+};
+
+//! One node of a level of the top of the tree, for the partitioner of split_top_levels(): the points of
+//! [begin, end) with coordinate `axis` below `plane` go first, as std::partition leaves them; `cut` (out) is the
+//! position of the first point of the second group.
+template <typename Scalar_>
+struct top_segment {
+  size_t begin, end;
+  std::uint32_t axis;
+  Scalar_ plane;
+  size_t cut;
+};
+
+//! The top of a sliding-midpoint tree, level by level: every node of more than `threshold` points (>= the leaf
+//! size) is split the way flat_builder::split() splits it -- longest side of the box handed down, plane at its
+//! middle -- with the partitions of one level made together by `partition_level(std::vector<top_segment>&)`
+//! (false = it failed).  When a partition leaves one side empty the rule slides the plane to the nearest point:
+//! `slide(top_segment&, nth)` has to leave [begin, end) as std::nth_element(begin, begin + nth, end) by the
+//! coordinate of the axis leaves it and set `plane` to the coordinate of the point at begin + nth (false = it
+//! failed).  Returns false, leaving the caller to build the whole tree the ordinary way, when a callback fails.
+//! Output: see build_flat_tree_below().
+template <typename Scalar_, size_t Dim_, typename PartitionLevel_, typename Slide_>
+bool split_top_levels(
+    aabb<Scalar_, Dim_> const& root_box,
+    size_t n,
+    size_t threshold,
+    PartitionLevel_&& partition_level,
+    Slide_&& slide,
+    std::vector<top_branch<Scalar_>>& top,
+    std::vector<std::pair<size_t, size_t>>& frontier) {
+  using box_type = aabb<Scalar_, Dim_>;
+  struct open_node {
+    std::int32_t id;  // its top_branch
+    size_t begin, end;
+    box_type box;
+  };
+  top.clear();
+  frontier.clear();
+  if (n <= threshold) {
+    frontier.emplace_back(size_t(0), n);
+    return true;
+  }
+  std::vector<open_node> level;
+  top.emplace_back();
+  level.push_back(open_node{0, 0, n, root_box});
+  std::vector<top_segment<Scalar_>> segments;
+  while (!level.empty()) {
+    segments.clear();
+    for (auto const& node : level) {
+      size_t axis = 0;
+      Scalar_ extent;
+      node.box.longest_side(axis, extent);
+      Scalar_ const plane = extent / Scalar_(2.0) + node.box.min(axis);  // flat_builder::split(), sliding midpoint
+      segments.push_back(top_segment<Scalar_>{node.begin, node.end, static_cast<std::uint32_t>(axis), plane, node.begin});
+    }
+    if (!partition_level(segments)) return false;
+    std::vector<open_node> next;
+    for (size_t i = 0; i < level.size(); ++i) {
+      auto& seg = segments[i];
+      if (seg.cut >= seg.end) {  // nothing on the right: slide the largest point over (flat_builder::split())
+        if (!slide(seg, seg.end - seg.begin - 1)) return false;
+        seg.cut = seg.end - 1;
+      } else if (seg.cut <= seg.begin) {  // nothing on the left
+        if (!slide(seg, size_t(1))) return false;
+        seg.cut = seg.begin + 1;
+      }
+      box_type left = level[i].box, right = level[i].box;
+      left.max(seg.axis) = seg.plane;
+      right.min(seg.axis) = seg.plane;
+      auto child = [&](size_t begin, size_t end, box_type const& box) -> std::int32_t {
+        if (end - begin > threshold) {
+          std::int32_t const id = static_cast<std::int32_t>(top.size());
+          top.emplace_back();
+          next.push_back(open_node{id, begin, end, box});
+          return id;
+        }
+        frontier.emplace_back(begin, end);
+        return ~static_cast<std::int32_t>(frontier.size() - 1);
+      };
+      std::int32_t const l = child(seg.begin, seg.cut, left);
+      std::int32_t const r = child(seg.cut, seg.end, right);
+      auto& branch = top[static_cast<size_t>(level[i].id)];
+      branch.axis = seg.axis;
+      branch.plane = seg.plane;
+      branch.left = l;
+      branch.right = r;
+    }
+    level.swap(next);
+  }
+  return true;
+}
+
+//! Finishes a sliding-midpoint / midpoint build whose top levels are given: `indices` already holds the
+//! permutation every std::partition of those levels leaves behind, `top` the branches (top[0] = the root; empty:
+//! the root is frontier range 0) and `frontier` the [begin, end) ranges the builder has not split yet.  The
+//! subtrees below the frontier are built by `threads` workers, each exactly as grow() builds it, and the whole
+//! is spliced in depth-first order: the result is the tree build_flat_tree() returns for the same input.
+template <typename Index_, typename SpaceView_, typename Stop_, typename Rule_>
+flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim> build_flat_tree_below(
+    SpaceView_ const& space,
+    splitter_stop_condition_t<Stop_> const& stop,
+    splitter_rule_t<Rule_> const&,
+    typename flat_tree<Index_, typename SpaceView_::scalar_type, SpaceView_::dim>::box_type const& root_box,
+    std::vector<Index_>&& indices,
+    std::vector<top_branch<typename SpaceView_::scalar_type>> const& top,
+    std::vector<std::pair<size_t, size_t>> const& frontier,
+    bool keep_outer_bounds,
+    unsigned threads,
+    double* phase_ms = nullptr) {
+  using scalar_type = typename SpaceView_::scalar_type;
+  using tree_type = flat_tree<Index_, scalar_type, SpaceView_::dim>;
+  using box_type = typename tree_type::box_type;
+  using builder_type = flat_builder<SpaceView_, Index_, Rule_, Stop_>;
+  size_t const sdim = space.sdim();
+  auto const t_begin = std::chrono::steady_clock::now();
+
+  tree_type tree(sdim);
+  tree.keep_outer_bounds = keep_outer_bounds;
+  tree.indices = std::move(indices);
+  tree.root_box = root_box;
+
+  // The depth and the (loose) box each frontier range is reached with.
+  struct start {
+    std::uint32_t depth;
+    box_type box;
+    std::vector<std::uint32_t> splits;  // per axis, between the root and the range
+  };
+  std::vector<start> starts(frontier.size(), start{0, box_type(sdim), {}});
+  {
+    struct frame {
+      std::int32_t id;
+      std::uint32_t depth;
+      box_type box;
+      std::vector<std::uint32_t> splits;
+    };
+    std::vector<frame> todo;
+    todo.push_back(frame{top.empty() ? ~std::int32_t(0) : 0, 0, root_box, std::vector<std::uint32_t>(sdim, 0)});
+    while (!todo.empty()) {
+      frame f = std::move(todo.back());
+      todo.pop_back();
+      if (f.id < 0) {
+        starts[static_cast<size_t>(~f.id)] = start{f.depth, f.box, f.splits};
+        continue;
+      }
+      auto const& b = top[static_cast<size_t>(f.id)];
+      box_type right = f.box;
+      f.box.max(b.axis) = b.plane;
+      right.min(b.axis) = b.plane;
+      ++f.splits[b.axis];
+      todo.push_back(frame{b.right, f.depth + 1, right, f.splits});
+      todo.push_back(frame{b.left, f.depth + 1, f.box, f.splits});
+    }
+  }
+
+  // The subtrees, largest first, by a pool of workers.
+  std::vector<tree_type> subs(frontier.size(), tree_type(sdim));
+  std::vector<size_t> order(frontier.size());
+  for (size_t i = 0; i < order.size(); ++i) order[i] = i;
+  std::sort(order.begin(), order.end(), [&](size_t a, size_t b) {
+    return frontier[a].second - frontier[a].first > frontier[b].second - frontier[b].first;
+  });
+  std::atomic<size_t> next{0};
+  std::exception_ptr failure;
+  std::mutex failure_lock;
+  Index_* const base = tree.indices.data();
+  auto work = [&] {
+    for (;;) {
+      size_t const k = next.fetch_add(1);
+      if (k >= order.size()) return;
+      size_t const i = order[k];
+      try {
+        subs[i].keep_outer_bounds = keep_outer_bounds;
+        subs[i].nodes.reserve(4 * (frontier[i].second - frontier[i].first) / (stop.derived().value > 0 ? stop.derived().value : 1) + 16);
+        builder_type(space, stop.derived().value, subs[i])
+            .run_range(starts[i].depth, base, base + frontier[i].first, base + frontier[i].second, starts[i].box,
+                       starts[i].splits);
+      } catch (...) {
+        std::lock_guard<std::mutex> hold(failure_lock);
+        if (!failure) failure = std::current_exception();
+      }
+    }
+  };
+  {
+    unsigned const workers = std::max(1u, std::min<unsigned>(threads, static_cast<unsigned>(order.size())));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < workers; ++t) pool.emplace_back(work);
+    work();
+    for (auto& t : pool) t.join();
+  }
+  if (failure) std::rethrow_exception(failure);
+  auto const t_built = std::chrono::steady_clock::now();
+  if (phase_ms != nullptr) phase_ms[0] = std::chrono::duration<double, std::milli>(t_built - t_begin).count();
+
+  // Where everything goes in depth-first order: a walk over the top gives every branch and every subtree its
+  // first node; the subtrees are then copied into place by the workers (right-child links shifted by the base, as
+  // flat_builder::splice() does) and the top branches filled in on the way back up, boxes tightening as in grow().
+  std::vector<std::uint32_t> sub_base(frontier.size(), 0), top_self(top.size(), 0);
+  {
+    std::uint32_t cursor = 0;
+    std::vector<std::int32_t> todo;
+    todo.push_back(top.empty() ? ~std::int32_t(0) : 0);
+    while (!todo.empty()) {  // pre-order: node, left subtree, right subtree
+      std::int32_t const id = todo.back();
+      todo.pop_back();
+      if (id < 0) {
+        sub_base[static_cast<size_t>(~id)] = cursor;
+        cursor += static_cast<std::uint32_t>(subs[static_cast<size_t>(~id)].nodes.size());
+      } else {
+        top_self[static_cast<size_t>(id)] = cursor++;
+        todo.push_back(top[static_cast<size_t>(id)].right);
+        todo.push_back(top[static_cast<size_t>(id)].left);
+      }
+    }
+    tree.nodes.resize(cursor);
+    if (keep_outer_bounds) tree.outer_bounds.resize(cursor);
+  }
+  next.store(0);
+  auto copy = [&] {
+    for (;;) {
+      size_t const k = next.fetch_add(1);
+      if (k >= order.size()) return;
+      size_t const i = order[k];
+      std::uint32_t const base_node = sub_base[i];
+      auto const& sub = subs[i];
+      auto* dst = tree.nodes.data() + base_node;
+      for (size_t j = 0; j < sub.nodes.size(); ++j) {
+        auto nd = sub.nodes[j];
+        if (nd.right != flat_leaf_tag) nd.right += base_node;
+        dst[j] = nd;
+      }
+      if (keep_outer_bounds) std::copy(sub.outer_bounds.begin(), sub.outer_bounds.end(), tree.outer_bounds.begin() + base_node);
+    }
+  };
+  {
+    unsigned const workers = std::max(1u, std::min<unsigned>(threads, static_cast<unsigned>(order.size())));
+    std::vector<std::thread> pool;
+    for (unsigned t = 1; t < workers; ++t) pool.emplace_back(copy);
+    copy();
+    for (auto& t : pool) t.join();
+  }
+  tree.axis_weight.assign(sdim, 0.0);
+  for (auto const& sub : subs) {
+    tree.max_depth = std::max(tree.max_depth, sub.max_depth);
+    tree.leaf_count += sub.leaf_count;
+    tree.max_leaf_points = std::max(tree.max_leaf_points, sub.max_leaf_points);
+    for (size_t a = 0; a < sdim; ++a) tree.axis_weight[a] += sub.axis_weight[a];
+  }
+  struct placer {
+    tree_type& tree;
+    std::vector<top_branch<scalar_type>> const& top;
+    std::vector<start>& starts;
+    std::vector<std::uint32_t> const& sub_base;
+    std::vector<std::uint32_t> const& top_self;
+    std::uint32_t place(std::int32_t id, std::uint32_t depth, box_type& box) {
+      if (id < 0) {
+        box = starts[static_cast<size_t>(~id)].box;  // (tightened by run_range())
+        return sub_base[static_cast<size_t>(~id)];
+      }
+      auto const& b = top[static_cast<size_t>(id)];
+      std::uint32_t const self = top_self[static_cast<size_t>(id)];
+      if (depth > tree.max_depth) tree.max_depth = depth;
+      box_type right = box;
+      box.max(b.axis) = b.plane;
+      right.min(b.axis) = b.plane;
+      place(b.left, depth + 1, box);
+      std::uint32_t const r = place(b.right, depth + 1, right);
+      auto& branch = tree.nodes[self];
+      branch.left_max = box.max(b.axis);
+      branch.right_min = right.min(b.axis);
+      branch.right = r;
+      branch.split_dim = b.axis;
+      if (tree.keep_outer_bounds) tree.outer_bounds[self] = {box.min(b.axis), right.max(b.axis)};
+      box.fit(right);
+      return self;
+    }
+  } p{tree, top, starts, sub_base, top_self};
+  box_type work_box = root_box;
+  p.place(top.empty() ? ~std::int32_t(0) : 0, 0, work_box);
+  if (phase_ms != nullptr) phase_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_built).count();
   return tree;
 }
 

@@ -171,6 +171,10 @@ def _load():
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = lib
+        # The first question about devices also starts loading the library's code object for the device on a thread of
+        # the library (0.17 s that would otherwise be paid by the first tree): ask now.
+        if os.environ.get("PTK_EAGER_WARMUP", "1") != "0":
+            lib.ptk_device_count()
     return _lib
 
 

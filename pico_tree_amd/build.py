@@ -19,6 +19,9 @@ LIB = os.path.join(CSRC, "libptk.so")
 SOURCES = [os.path.join(CSRC, "ptk_backend.hip")]
 HEADERS = [
     os.path.join(CSRC, "ptk_kernels.hpp"),
+    os.path.join(CSRC, "ptk_build.hpp"),
+    os.path.join(CSRC, "ptk_sort.hpp"),
+    os.path.join(CSRC, "ptk_hostio.hpp"),
     os.path.join(CSRC, "ptk_kernels_nd.hpp"),
     os.path.join(CSRC, "ptk_kernels_topo.hpp"),
     os.path.join(CSRC, "ptk_kernels_f64.hpp"),

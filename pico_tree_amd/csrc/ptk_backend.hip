@@ -32,6 +32,7 @@
 #include "ptk_hostio.hpp"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#include "ptk_build.hpp"
 #include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
 #include "ptk_kernels_topo.hpp"
@@ -154,6 +155,8 @@ struct ptk_tree {
   std::vector<float> root_min, root_max;
   std::vector<float> outer;  // per node {left_min, right_max} (topological metrics); may be empty
   double axis_splits[3] = {0, 0, 0};  // mean number of splits per axis on a root-to-leaf path (point-weighted)
+  bool builder_made = false;  // nodes / indices come from the library's own builder: n_leaves, max_leaf_count, max_depth and
+                              // axis_splits are set and the stream needs no validation
   uint32_t max_depth = 0;
   uint64_t n_leaves = 0;
   uint32_t max_leaf_count = 0;
@@ -240,6 +243,7 @@ struct CreateClock {
 };
 
 int analyse(ptk_tree& t) {
+  if (t.builder_made) return PTK_OK;
   ptk::TreeStats st;
   std::string err = ptk::analyse_stream(t.dim, t.n_points, t.nodes.data(), t.nodes.size(), st, nullptr);
   if (!err.empty()) return fail(PTK_ERR_INVALID, "%s", err.c_str());
@@ -324,13 +328,23 @@ int upload(ptk_tree& t, const float* points) {
   // Branch records and references on the host; the 16-byte point records are gathered on the
   // device from the raw points and the leaf-order permutation (no host pass over the points).
   static_assert(ptk::kEncLeafAlign == 1, "encode_points_kernel assumes packed leaves");
-  std::string err = ptk::encode_tree(t.dim, t.n_points, nullptr, t.nodes.data(), t.nodes.size(),
-                                     t.indices.data(), st, enc, unsupported, /*with_points=*/false);
+  std::string err;
+  if (t.builder_made) {
+    st.n_leaves = t.n_leaves;
+    st.max_leaf_count = t.max_leaf_count;
+    st.max_depth = t.max_depth;
+    err = ptk::encode_tree_of_builder(t.dim, t.n_points, t.nodes.data(), t.nodes.size(), st, enc, unsupported, build_threads());
+  } else {
+    err = ptk::encode_tree(t.dim, t.n_points, nullptr, t.nodes.data(), t.nodes.size(), t.indices.data(), st, enc, unsupported,
+                           /*with_points=*/false);
+  }
   if (!err.empty()) return fail(unsupported ? PTK_ERR_UNSUPPORTED : PTK_ERR_INVALID, "%s", err.c_str());
   clock.lap("encode branch records", 1);
-  for (int32_t idx : t.indices)
-    if (idx < 0 || (uint64_t)idx >= t.n_points) return fail(PTK_ERR_INVALID, "index out of range in the permutation");
-  clock.lap("check permutation", 1);
+  if (!t.builder_made) {
+    for (int32_t idx : t.indices)
+      if (idx < 0 || (uint64_t)idx >= t.n_points) return fail(PTK_ERR_INVALID, "index out of range in the permutation");
+    clock.lap("check permutation", 1);
+  }
 
   static_assert(sizeof(ptk::EncNode) == sizeof(uint4) && sizeof(ptk::EncPoint) == sizeof(float4), "records");
   const size_t n_records = t.n_points + ptk::kEncLeafPad;
@@ -406,27 +420,37 @@ int upload(ptk_tree& t, const float* points) {
 }
 
 // The first kernel launch of a process loads libptk's code object for the device (~10 MB: 0.17 s on the bench box,
-// profiles/r02_notes.txt item 13).  A creation that builds the tree on the host first starts that load on a thread of
-// its own, beside the build, instead of paying for it afterwards.
+// profiles/r02_notes.txt item 13).  That load is started on a thread of its own as early as the library hears of a
+// device -- the first ptk_device_count() that finds one (the Python package asks when it loads the library), or the
+// first creation -- so that it runs beside whatever the caller does before its first tree (reading the points), and
+// beside the host part of that creation.  wait() before the first launch of the calling thread.
 __global__ void ptk_warm_kernel() {}
-struct DeviceWarmup {
+struct ProcessWarmup {
+  std::mutex lock;
   std::thread thread;
-  explicit DeviceWarmup(int32_t device) {
-    static std::atomic<bool> done{false};
-    if (device == kDeviceNone || done.exchange(true)) return;
-    thread = std::thread([device] {
-      int dev = device;
-      if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+  bool started = false;
+  void start(int32_t device) {
+    std::lock_guard<std::mutex> hold(lock);
+    if (started || device == kDeviceNone) return;
+    started = true;
+    int dev = device;  // (the device the CALLER is on, not the new thread's default)
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
+    thread = std::thread([dev] {
       if (hipSetDevice(dev) != hipSuccess) return;
       hipLaunchKernelGGL(ptk_warm_kernel, dim3(1), dim3(1), 0, nullptr);
       (void)hipDeviceSynchronize();
       (void)hipGetLastError();
     });
   }
-  ~DeviceWarmup() {
+  void wait() {
+    std::lock_guard<std::mutex> hold(lock);
+    if (thread.joinable()) thread.join();
+  }
+  ~ProcessWarmup() {
     if (thread.joinable()) thread.join();
   }
 };
+ProcessWarmup g_warmup;
 
 int finish_create(ptk_tree* t, const float* points, int32_t device, ptk_tree** out) {
   if (t->root_min.empty()) {  // start bounds not supplied: bounding box of the points
@@ -1457,6 +1481,7 @@ const char* ptk_last_error(void) { return g_error.c_str(); }
 int ptk_device_count(void) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) return -1;
+  if (count > 0) g_warmup.start(-1);  // the code object starts loading now (see ProcessWarmup)
   return count;
 }
 
@@ -1497,7 +1522,7 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
   if (n_points >= (1ull << 31)) return fail(PTK_ERR_INVALID, "n_points must be < 2^31");
   ptk_tree* t = new (std::nothrow) ptk_tree;
   if (t == nullptr) return fail(PTK_ERR_NOMEM, "out of memory");
-  DeviceWarmup warm(device);  // (joined when this function returns: before that, in finish_create, if it is quick)
+  g_warmup.start(device);
   try {
     using namespace pico_tree;
     using space_t = space_map<point_map<float const, dynamic_extent>>;
@@ -1506,16 +1531,43 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
     // (the two outer bounds per branch come for free while the child boxes are at hand; only the
     // topological metrics ever read them)
     CreateClock clock(t->create_ms);
-    auto flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
-                                               sliding_midpoint_max_side, true, build_threads());
-    clock.lap("host build", 0);
+    // Large clouds bound for a device: the partitions of the top levels are made there (ptk_build.hpp), the subtrees
+    // below by the host's workers -- the same tree.  PTK_DEVICE_BUILD=0: everything on the host.
+    internal::flat_tree<int, float, dynamic_extent> flat(dim);
+    bool built = false;
+    if (device != kDeviceNone && n_points >= (1ull << 18) && env_int("PTK_DEVICE_BUILD", 1) != 0) {
+      int count = 0, dev = device;
+      if (hipGetDeviceCount(&count) == hipSuccess && count > 0 && (dev >= 0 || hipGetDevice(&dev) == hipSuccess) && dev < count) {
+        DeviceGuard guard(dev);
+        g_warmup.wait();
+        double ms[2] = {0, 0};
+        const char* why = "hipSetDevice failed";
+        if (guard.ok) built = ptk::device_top_build(points, n_points, dim, (size_t)max_leaf_size, build_threads(), view, flat, ms, &why);
+        if (!built && clock.on) std::fprintf(stderr, "[ptk create] top levels not on the device: %s\n", why);
+        if (built && clock.on)
+          std::fprintf(stderr, "[ptk create] top levels on the device     %8.2f ms\n[ptk create] subtrees on the host          %8.2f ms\n",
+                       ms[0], ms[1]);
+      }
+      (void)hipGetLastError();
+    }
+    if (!built)
+      flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
+                                            sliding_midpoint_max_side, true, build_threads());
+    clock.lap(built ? "device + host build" : "host build", 0);
     t->dim = dim;
     t->n_points = n_points;
     t->nodes.resize(flat.nodes.size());
-    std::memcpy(t->nodes.data(), flat.nodes.data(), flat.nodes.size() * sizeof(ptk_node));
     t->outer.resize(flat.outer_bounds.size() * 2);
-    if (!flat.outer_bounds.empty()) std::memcpy(t->outer.data(), flat.outer_bounds.data(), t->outer.size() * sizeof(float));
+    ptk::parallel_chunks(flat.nodes.size(), build_threads(), 1u << 16, [&](size_t lo, size_t hi, unsigned) {
+      std::memcpy(t->nodes.data() + lo, flat.nodes.data() + lo, (hi - lo) * sizeof(ptk_node));
+      if (!flat.outer_bounds.empty()) std::memcpy(t->outer.data() + 2 * lo, flat.outer_bounds.data() + lo, (hi - lo) * 2 * sizeof(float));
+    });
     t->indices = std::move(flat.indices);
+    t->builder_made = true;
+    t->n_leaves = flat.leaf_count;
+    t->max_leaf_count = (uint32_t)flat.max_leaf_points;
+    t->max_depth = flat.max_depth;
+    for (uint32_t a = 0; a < 3; ++a) t->axis_splits[a] = a < dim && a < flat.axis_weight.size() ? flat.axis_weight[a] / (double)n_points : 0.0;
     t->root_min.assign(flat.root_box.min(), flat.root_box.min() + dim);
     t->root_max.assign(flat.root_box.max(), flat.root_box.max() + dim);
     clock.lap("copy into the handle", 1);

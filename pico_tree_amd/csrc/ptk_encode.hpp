@@ -24,10 +24,12 @@
 
 #pragma once
 
+#include <algorithm>
 #include <cstdint>
 #include <cstring>
 #include <string>
 #include <utility>
+#include <thread>
 #include <vector>
 
 #include "ptk.h"
@@ -223,6 +225,91 @@ inline std::string encode_tree(
     for (uint64_t i = 0; i < n_nodes; ++i)
       if (nodes[i].right != PTK_LEAF) out.ranges[branch_id[i]] = of_node[i];
   }
+  out.root_ref = ref_of(0);
+  out.cbits = cbits;
+  return std::string();
+}
+
+// fn(lo, hi, chunk) over [0, n) cut into at most `threads` chunks of at least `grain` items, one thread each.
+template <typename Fn_>
+inline void parallel_chunks(size_t n, unsigned threads, size_t grain, Fn_&& fn) {
+  const size_t want = grain > 0 ? (n + grain - 1) / grain : 1;
+  const unsigned chunks = (unsigned)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(threads ? threads : 1, 64), want));
+  const size_t per = (n + chunks - 1) / chunks;
+  if (chunks == 1) {
+    fn(size_t(0), n, 0u);
+    return;
+  }
+  std::vector<std::thread> pool;
+  for (unsigned c = 1; c < chunks; ++c) pool.emplace_back([&fn, c, per, n] { fn(std::min(n, per * c), std::min(n, per * (c + 1)), c); });
+  fn(size_t(0), std::min(n, per), 0u);
+  for (auto& t : pool) t.join();
+}
+
+// encode_tree() without the point records for a stream the library's own builder has just made: nothing to validate,
+// the statistics are the builder's (`st`: n_leaves, max_leaf_count, max_depth), and every pass runs on `threads`
+// threads.  The leaves of such a stream tile [0, n_points) in order, so a leaf's device position is its `a`.
+inline std::string encode_tree_of_builder(
+    uint32_t dim, uint64_t n_points, const ptk_node* nodes, uint64_t n_nodes, const TreeStats& st, EncodedTree& out,
+    bool& unsupported, unsigned threads) {
+  static_assert(kEncLeafAlign == 1, "leaf positions assume packed leaves");
+  unsupported = false;
+  if (dim == 0 || dim > 3) {
+    unsupported = true;
+    return "only dim <= 3 is encoded for the device";
+  }
+  const uint64_t n_branch = n_nodes - st.n_leaves;
+  const uint32_t cbits = bits_for(st.max_leaf_count);
+  const uint32_t bbits = bits_for(n_points);
+  if (cbits + bbits > 31) {
+    unsupported = true;
+    return "leaf reference needs " + std::to_string(bbits) + " + " + std::to_string(cbits) +
+           " bits (> 31): n_points x max leaf size too large";
+  }
+  if (n_branch >= (1ull << 28)) {
+    unsupported = true;
+    return "more than 2^28 branch nodes";
+  }
+  // Branch numbers: branches per chunk, their running sum, then the numbers.
+  std::vector<uint32_t> branch_id(n_nodes);
+  std::vector<uint64_t> chunk_count(65, 0);
+  const size_t grain = 1u << 15;
+  parallel_chunks(n_nodes, threads, grain, [&](size_t lo, size_t hi, unsigned c) {
+    uint64_t count = 0;
+    for (size_t i = lo; i < hi; ++i) count += nodes[i].right != PTK_LEAF ? 1 : 0;
+    chunk_count[c + 1] = count;
+  });
+  for (size_t c = 0; c + 1 < chunk_count.size(); ++c) chunk_count[c + 1] += chunk_count[c];
+  parallel_chunks(n_nodes, threads, grain, [&](size_t lo, size_t hi, unsigned c) {
+    uint32_t next = (uint32_t)chunk_count[c];
+    for (size_t i = lo; i < hi; ++i) branch_id[i] = nodes[i].right != PTK_LEAF ? next++ : 0u;
+  });
+  auto ref_of = [&](uint64_t i) -> uint32_t {
+    const ptk_node& nd = nodes[i];
+    if (nd.right == PTK_LEAF) return kEncLeafBit | (nd.a << cbits) | (nd.b - nd.a);
+    return (nd.split_dim << 29) | branch_id[i];
+  };
+  out.nodes.assign(n_branch > 0 ? n_branch : 1, EncNode{0, 0, 0, 0});
+  out.ranges.assign(n_branch > 0 ? n_branch : 1, EncRange{0, 0});
+  out.points.clear();
+  parallel_chunks(n_nodes, threads, grain, [&](size_t lo, size_t hi, unsigned) {
+    for (size_t i = lo; i < hi; ++i) {
+      const ptk_node& nd = nodes[i];
+      if (nd.right == PTK_LEAF) continue;
+      EncNode r;
+      r.left_max_bits = nd.a;
+      r.right_min_bits = nd.b;
+      r.left_ref = ref_of(i + 1);
+      r.right_ref = ref_of(nd.right);
+      out.nodes[branch_id[i]] = r;
+      // The records of the subtree: from the first point of its leftmost leaf (left children follow their parent
+      // in the stream) to the last of its rightmost one.
+      size_t l = i + 1, rr = nd.right;
+      while (nodes[l].right != PTK_LEAF) ++l;
+      while (nodes[rr].right != PTK_LEAF) rr = nodes[rr].right;
+      out.ranges[branch_id[i]] = EncRange{nodes[l].a, nodes[rr].b};
+    }
+  });
   out.root_ref = ref_of(0);
   out.cbits = cbits;
   return std::string();
