@@ -670,8 +670,10 @@ def main():
             tree_b = pt.KdTree(pts, pt.Metric.L2Squared, args.leaf, device=local_rank)
             create["steady_s"] = round(time.perf_counter() - t0, 3)
             create["steady_phases"] = {k_: round(v, 3) for k_, v in tree_b.create_phases().items()}
-            create["what"] = ("KdTree(points): host build of the tree (threads of the library), re-encoding for the "
-                              "device, upload + point gather; first = first handle of the process")
+            create["what"] = ("KdTree(points): build (partitions of the top levels on the device, the subtrees below by the "
+                              "host threads of the library; phase host_build_s), re-encoding for the device, upload + "
+                              "point gather; first = first handle of the process (the code object loads from "
+                              "device_count() on, beside the generation of the clouds)")
             del tree_b
             extras["create"] = create
             # (b) config 3 on the same clouds
