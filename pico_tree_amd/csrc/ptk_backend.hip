@@ -572,6 +572,17 @@ struct Timer {
     }
   }
   ~Timer() {  // only reached with events in hand when a search failed half-way
+    if (a) {
+      // After next() `a` is also the end of the section before (kept there with keep_b): that section takes it
+      // over instead of being left with a destroyed event.
+      std::lock_guard<std::mutex> lock(t->profile.mutex);
+      for (auto it = t->profile.pending.rbegin(); it != t->profile.pending.rend(); ++it)
+        if (it->b == a && it->keep_b) {
+          it->keep_b = false;
+          a = nullptr;
+          break;
+        }
+    }
     if (a) (void)hipEventDestroy(a);
     if (b) (void)hipEventDestroy(b);
   }
@@ -641,6 +652,7 @@ class Scratch {
       }
     }
     ws_.used = 0;
+    ws_.last_meta = nullptr;  // whatever the last k = 1 search left in the block is about to be overwritten (or freed)
     reserved_ = true;
     return PTK_OK;
   }
@@ -2638,11 +2650,20 @@ int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
   if (t == nullptr || counts == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   if (t->device < 0) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
   DeviceGuard guard(t->device);
-  std::lock_guard<std::mutex> lock(t->ws.mutex);
-  if (t->ws.last_meta == nullptr) return fail(PTK_ERR_INVALID, "no two-phase k = 1 search has run on this handle");
+  // The scratch block of the LAST search on the handle's main workspace or on one of its per-stream ones (a k-NN call
+  // on a stream of its own uses those): the first that still holds the counters of a two-phase search.
+  Workspace* holder = nullptr;
+  for (int i = 0; i <= ptk_tree::kExtraWs && holder == nullptr; ++i) {
+    Workspace& w = i == 0 ? t->ws : t->extra_ws[i - 1];
+    std::lock_guard<std::mutex> lock(w.mutex);
+    if (w.last_meta != nullptr) holder = &w;
+  }
+  if (holder == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle was not a two-phase k = 1 search");
+  std::lock_guard<std::mutex> lock(holder->mutex);
+  if (holder->last_meta == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle was not a two-phase k = 1 search");
   uint32_t meta[ptk::kMetaWords];
   PTK_HIP(hipDeviceSynchronize());
-  PTK_HIP(hipMemcpy(meta, t->ws.last_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  PTK_HIP(hipMemcpy(meta, holder->last_meta, sizeof(meta), hipMemcpyDeviceToHost));
   counts[0] = meta[0];
   counts[1] = meta[ptk::kMetaHeavy];
   counts[2] = meta[ptk::kMetaRedo];

@@ -46,6 +46,12 @@
 
 #include <type_traits>
 
+// One batch of stack records per turn of a general search's outer loop (see traverse()); 0 = unwind to the next far
+// child in one go, as the two-phase k = 1 kernels do.
+#ifndef PTK_BOUND_UNWIND
+#define PTK_BOUND_UNWIND 1
+#endif
+
 namespace ptk {
 
 // ---- device tree --------------------------------------------------------------
@@ -825,6 +831,19 @@ __device__ __forceinline__ bool traverse(
         }
       }
       st.drop(used);
+#if PTK_BOUND_UNWIND
+      // General searches look at ONE batch of records per turn of the outer loop: a lane with a long way back up --
+      // above all the last unwind of a query, which pops what is left of the home path, some thirty records nearly
+      // all rejected -- no longer holds the wavefront in this loop while the other lanes have leaves to scan (an
+      // empty leaf brings it back here next turn).  knn = 16: 5.28 -> 4.86 ms on cloud L, 5.80 -> 5.16 on cloud U;
+      // bounding the descent (4 steps per turn) or the leaf scan (one round per turn) the same way loses
+      // (profiles/r03_notes.txt item 13).
+      if (!CAPPED && !RESUME && !enter) {
+        if (st.empty()) return true;
+        ref = kLeafBit;
+        break;
+      }
+#endif
       if (enter) {
         if (CAPPED && ++entered > cap) {
           const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
