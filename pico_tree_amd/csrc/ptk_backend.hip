@@ -32,6 +32,12 @@
 #include "ptk_hostio.hpp"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#ifndef PTK_GEN_RING
+#define PTK_GEN_RING 16
+#endif
+#ifndef PTK_GEN_LEAFB
+#define PTK_GEN_LEAFB 5  // points per leaf round of the general searches (4 / 5 / 6: knn = 16 4.85 / 4.71 / 4.68 ms, radius capture 7.21 / 7.16 / 7.69)
+#endif
 #include "ptk_build.hpp"
 #include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
@@ -1884,7 +1890,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else if (k <= 32 && !short_tree) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_reg<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    PTK_WITH_METRIC(PTK_WITH_OVF(PTK_GEN_RING, (launch_knn_reg<PTK_GEN_RING, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   } else {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   }
@@ -2187,7 +2193,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
                                                                  reinterpret_cast<ptk::Neighbor*>(d_out), s, over_list,
                                                                  n_over))));
     } else {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
                                                                          s, n_over))));
     }
@@ -2268,7 +2274,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       if (nd) {
         PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd_capture<OVF, M>(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s))));
       } else {
-        PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_capture<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, d_counts,
+        PTK_WITH_METRIC(PTK_WITH_OVF(PTK_GEN_RING, (launch_radius_capture<PTK_GEN_RING, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, perm, nq, radius, e, d_counts,
                                                                                    ws.cap, s))));
       }
       if (rc == PTK_OK) {
@@ -2284,7 +2290,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
                                                                  reinterpret_cast<ptk::Neighbor*>(d_out), s, perm))));
     } else {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, 4, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
     }
   }
