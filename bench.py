@@ -208,6 +208,12 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
     nsorted = min(len(q), 2_000_000)
     q_sorted = np.ascontiguousarray(q[:nsorted][ds.morton_order(q[:nsorted])])
 
+    spreads = []  # (slowest, fastest) pass of every figure, in the order they are measured
+    try:
+        load_before = [round(x, 1) for x in os.getloadavg()]  # other tenants of the host show up here
+    except OSError:
+        load_before = None
+
     def rate(queries, threads, chunk, budget, min_passes=3):
         cpu.set_threads(threads)
         chunk = max(1, min(chunk, len(queries) // (min_passes + 1)))
@@ -221,6 +227,7 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
             used += dt
             at += chunk
         rates.sort()
+        spreads.append((round(rates[0], 4), round(rates[-1], 4)))
         return rates[len(rates) // 2], at - chunk, len(rates)
 
     omp, n_omp, p_omp = rate(q, cores, 400_000, seconds * 0.45)
@@ -241,7 +248,13 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
             "single_thread_sample": f"warm-up + {p_one} passes of 50000 queries as given ({n_one} queries), median pass",
             "single_thread_morton_sorted_value": round(one_sorted, 4),
             "single_thread_morton_sorted_sample": f"warm-up + {p_ones} passes of 100000 sorted queries ({n_ones} queries)",
-            "build_s": round(build_s, 3)}
+            "build_s": round(build_s, 3),
+            "slowest_fastest_pass": {"value": spreads[0], "morton_sorted_queries_value": spreads[1],
+                                     "single_thread_value": spreads[2], "single_thread_morton_sorted_value": spreads[3]},
+            "host_loadavg_before": load_before,
+            "note": "the bench boxes are shared (four GPU slots per host): with another tenant's job on the cores the "
+                    "memory-bound figure -- all cores, queries as given -- has been seen at 4.5 instead of 80 Mqueries/s "
+                    "while the cache-resident ones did not move (profiles/r03_notes.txt item 15)"}
 
 
 def time_device_knn(tree, dq, k, steps, warmup=2):

@@ -838,7 +838,7 @@ __device__ __forceinline__ bool traverse(
       // empty leaf brings it back here next turn).  knn = 16: 5.28 -> 4.86 ms on cloud L, 5.80 -> 5.16 on cloud U;
       // bounding the descent (4 steps per turn) or the leaf scan (one round per turn) the same way loses
       // (profiles/r03_notes.txt item 13).
-      if (!CAPPED && !RESUME && !enter) {
+      if ((PTK_BOUND_UNWIND > 1 || (!CAPPED && !RESUME)) && !enter) {
         if (st.empty()) return true;
         ref = kLeafBit;
         break;
