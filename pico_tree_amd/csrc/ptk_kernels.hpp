@@ -46,8 +46,10 @@
 
 #include <type_traits>
 
-// One batch of stack records per turn of a general search's outer loop (see traverse()); 0 = unwind to the next far
-// child in one go, as the two-phase k = 1 kernels do.
+// One batch of stack records per turn of the outer loop of traverse(); 0 = unwind to the next far child in one go.
+#ifndef PTK_LOG_NT_STORE
+#define PTK_LOG_NT_STORE 1
+#endif
 #ifndef PTK_BOUND_UNWIND
 #define PTK_BOUND_UNWIND 1
 #endif
@@ -501,6 +503,16 @@ struct RadiusCapture {
 
 constexpr int kRadiusCount = 0, kRadiusFill = 1, kRadiusCapture = 2;
 
+// An entry of a capture log: written once, read once by another kernel -- it need not displace the tree in the L2
+// (non-temporal store: capture kernel 7.20 -> 6.86 ms on BASELINE config 3).
+__device__ __forceinline__ void store_entry(Neighbor* p, Neighbor nb) {
+#if defined(__HIP_DEVICE_COMPILE__) && PTK_LOG_NT_STORE
+  __builtin_nontemporal_store(pack_neighbor(nb), reinterpret_cast<unsigned long long*>(p));
+#else
+  *p = nb;
+#endif
+}
+
 // Lanes below `lane` set in m.
 __device__ __forceinline__ uint32_t lanes_below(uint64_t m, uint32_t lane) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -609,7 +621,7 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
             Neighbor nb;
             nb.index = idx[u];
             nb.distance = d[u];
-            out[base + lanes_below(m[u], lane)] = nb;
+            store_entry(out + base + lanes_below(m[u], lane), nb);
           }
           ++count;
         }
@@ -677,7 +689,7 @@ struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
           Neighbor nb;
           nb.index = idx;
           nb.distance = d;
-          out[base + rank] = nb;
+          store_entry(out + base + rank, nb);
         }
         ++count;
       }
@@ -832,13 +844,14 @@ __device__ __forceinline__ bool traverse(
       }
       st.drop(used);
 #if PTK_BOUND_UNWIND
-      // General searches look at ONE batch of records per turn of the outer loop: a lane with a long way back up --
+      // ONE batch of records per turn of the outer loop: a lane with a long way back up --
       // above all the last unwind of a query, which pops what is left of the home path, some thirty records nearly
       // all rejected -- no longer holds the wavefront in this loop while the other lanes have leaves to scan (an
       // empty leaf brings it back here next turn).  knn = 16: 5.28 -> 4.86 ms on cloud L, 5.80 -> 5.16 on cloud U;
       // bounding the descent (4 steps per turn) or the leaf scan (one round per turn) the same way loses
-      // (profiles/r03_notes.txt item 13).
-      if ((PTK_BOUND_UNWIND > 1 || (!CAPPED && !RESUME)) && !enter) {
+      // (profiles/r03_notes.txt item 13).  Phase 2 of the k = 1 search (RESUME, CAPPED): 1.330 -> 1.299 ms of
+      // traversal kernels on cloud L, 1.332 -> 1.297 on cloud U.
+      if (!enter) {
         if (st.empty()) return true;
         ref = kLeafBit;
         break;
@@ -1208,7 +1221,7 @@ __global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
     // write
     for (uint32_t f = lane; f < total; f += 64u) {
       const uint32_t o = own[f];
-      if (f < lim[o]) dst[adj[o] + f] = sorted[f];
+      if (f < lim[o]) dst[adj[o] + f] = sorted[f];  // (not a non-temporal store: the runs of a row merge in the L2; 4.4 vs 5.2 ms)
     }
     rowpos += n_out;
     n_kept = n_row - n_out;  // <= 3
