@@ -931,6 +931,9 @@ __device__ __forceinline__ bool traverse(
 #define PTK_XCD_RUN_LOG2 4
 #endif
 constexpr uint32_t kXcdRunLog2 = PTK_XCD_RUN_LOG2;
+// The general 3-D kernels (one launch, expensive queries first) take longer runs: knn = 16 with runs of 8 / 16 / 32 / 64
+// wavefronts 4.69 / 4.73 / 4.65 / 4.62 ms on cloud L, 5.06 / 5.01 / 4.94 / 4.88 on cloud U; the radius capture does not care.
+constexpr uint32_t kXcdRunGeneral = 6;
 __device__ __forceinline__ uint32_t xcd_runs(uint32_t b, uint32_t nb, uint32_t run_log2 = kXcdRunLog2) {
   const uint32_t group = 8u << run_log2;
   const uint32_t g = b / group;
@@ -969,7 +972,7 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
     Neighbor* __restrict__ out) {
-  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -1009,7 +1012,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
     Neighbor* __restrict__ out) {
-  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(BLOCK) void radius_kernel(
     uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
     Neighbor* __restrict__ out, const uint32_t* __restrict__ n_dev = nullptr) {
   if (n_dev != nullptr) nq = *n_dev;
-  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[i] : i;
@@ -1061,7 +1064,7 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
     const uint32_t* __restrict__ perm, uint64_t nq, float radius, float e_inv,
     uint64_t* __restrict__ counts, RadiusCapture cap) {
   static_assert(BLOCK == 64, "one log per block");
-  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x);
+  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) {
     cap.qids[i] = kLogEnd;
