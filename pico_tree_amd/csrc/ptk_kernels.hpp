@@ -45,8 +45,12 @@
 #include <stdint.h>
 
 #include <type_traits>
+#include <utility>
 
 // One batch of stack records per turn of the outer loop of traverse(); 0 = unwind to the next far child in one go.
+#ifndef PTK_SETTLE
+#define PTK_SETTLE 1
+#endif
 #ifndef PTK_LOG_NT_STORE
 #define PTK_LOG_NT_STORE 1
 #endif
@@ -319,6 +323,9 @@ struct NnPolicy {  // search_visitor.hpp:42-65 / :165-193
     out[qi] = nb;
   }
   __device__ __forceinline__ float max() const { return best_d; }
+  // No later point can be accepted (a candidate must be STRICTLY nearer, search_visitor.hpp:55, and no distance is
+  // below zero): the search may stop here, its answer is final.
+  __device__ __forceinline__ bool settled() const { return PTK_SETTLE && best_d == 0.0f; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
     if (best_d > d) {
@@ -433,6 +440,7 @@ struct KnnRegPolicy {
     }
   }
   __device__ __forceinline__ float max() const { return ld[K - 1]; }
+  __device__ __forceinline__ bool settled() const { return PTK_SETTLE && ld[K - 1] == 0.0f; }  // k points AT the query: see NnPolicy
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
     if (ld[K - 1] > d) {
@@ -522,6 +530,12 @@ __device__ __forceinline__ uint32_t lanes_below(uint64_t m, uint32_t lane) {
   return (uint32_t)__builtin_popcountll(m & ((1ull << lane) - 1ull));
 #endif
 }
+
+// Policies whose result can become final before the traversal ends have settled().
+template <class P, class = void>
+struct can_settle : std::false_type {};
+template <class P>
+struct can_settle<P, std::void_t<decltype(std::declval<const P&>().settled())>> : std::true_type {};
 
 // Policies that take the points of a leaf round together (visit_round<N>) say so with kRoundVisit.
 template <class P, class = void>
@@ -817,6 +831,9 @@ __device__ __forceinline__ bool traverse(
     float enter_val = 0.0f;
     for (;;) {
       if (st.empty()) return true;
+      if constexpr (can_settle<Policy>::value) {
+        if (pol.settled()) return true;  // (every record left would be popped for nothing)
+      }
       Record rr[StackT::kUnwind];
       const int got = st.peek(rr);  // 1 .. kUnwind records, newest first (refills the ring if needed)
       int used = 0;
@@ -1434,6 +1451,9 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
   uint32_t c = 0;
 #pragma unroll
   for (int j = 0; j < kCand; ++j) c += pol.max() >= cand_d[j] ? 1u : 0u;
+  // A point AT the query: nothing can be strictly nearer, so whatever the reference still visits (every subtree that
+  // touches the query -- on data snapped to a grid a pile of hundreds of coincident points) cannot change its answer.
+  c = pol.settled() ? 0u : c;
   {
     uint32_t key[kContSlots];
 #pragma unroll

@@ -10,9 +10,11 @@ import pico_tree_amd as pt
 from pico_tree_amd import datasets as ds
 import oracle
 pts, q = ds.config2_clouds("L")
-for grid in (0.05, 0.1, 0.25, 1.0):
+# (grid, shift): the queries are snapped to the same grid and then moved by shift x grid along every axis -- 0: most
+# queries coincide with a pile of points (distance 0); 0.3: none does, every pile is at a distance > 0
+for grid, shift in ((0.05, 0.0), (0.1, 0.0), (0.25, 0.0), (1.0, 0.0), (0.25, 0.3), (1.0, 0.3)):
     p2 = np.ascontiguousarray(np.round(pts / grid) * grid, dtype=np.float32)
-    q2 = np.ascontiguousarray(np.round(q / grid) * grid, dtype=np.float32)
+    q2 = np.ascontiguousarray(np.round(q / grid) * grid + np.float32(shift * grid), dtype=np.float32)
     tree = pt.KdTree(p2, pt.Metric.L2Squared, 10, device=0)
     dq = torch.from_numpy(q2).cuda()
     out = torch.empty((len(q2), 1, 2), dtype=torch.int32, device="cuda")
@@ -26,5 +28,5 @@ for grid in (0.05, 0.1, 0.25, 1.0):
     want = ref.search_knn(q2[sample], 1)
     ok = res[sample][:, None].tobytes() == want.tobytes()
     ref.close()
-    print(f"grid {grid}: depth {tree.info()['max_depth']}, {ms:.3f} ms per step, counts {tree.knn1_counts()}, parity on 20 k sample {ok}", flush=True)
+    print(f"grid {grid} shift {shift}: depth {tree.info()['max_depth']}, {ms:.3f} ms per step, counts {tree.knn1_counts()}, parity on 20 k sample {ok}", flush=True)
     del tree
