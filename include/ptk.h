@@ -186,6 +186,14 @@ int ptk_tree_serialize(const ptk_tree* tree, void* buf, uint64_t cap, uint64_t* 
 int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t dim,
                                 const void* stream, uint64_t stream_bytes,
                                 int32_t device, ptk_tree** out);
+/* The same for a tree over a topological space (kd_tree<space, metric_so2 | metric_se2_squared>::save /
+ * ::load): its branches carry four bounds on disk (kd_tree_branch_double, internal/kd_tree_node.hpp:52-67).
+ * Loading keeps the two outer ones with the handle (as ptk_tree_set_outer_bounds would), so that
+ * ptk_tree_set_metric(PTK_METRIC_SO2 | PTK_METRIC_SE2_SQUARED) can follow at once; writing needs them. */
+int ptk_tree_serialize_topological(const ptk_tree* tree, void* buf, uint64_t cap, uint64_t* size);
+int ptk_tree_create_from_topological_stream(const float* points, uint64_t n_points, uint32_t dim,
+                                            const void* stream, uint64_t stream_bytes,
+                                            int32_t device, ptk_tree** out);
 
 /* ---- k nearest neighbours --------------------------------------------- */
 

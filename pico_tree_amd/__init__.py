@@ -88,6 +88,9 @@ _SIGNATURES = {
     "ptk_tree_serialize": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
     "ptk_tree_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
                                             POINTER(c_void_p)]),
+    "ptk_tree_create_from_topological_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
+                                                        POINTER(c_void_p)]),
+    "ptk_tree_serialize_topological": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
     "ptk_search_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p]),
     "ptk_search_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p,
                                       c_void_p]),
@@ -361,8 +364,9 @@ class KdTree:
                                                            self._max_leaf_size, dev, byref(handle)))
         else:  # load_kd_tree: the tree comes from a saved stream
             buf = ctypes.create_string_buffer(_stream, len(_stream))
-            _check(self._fn("ptk_tree_create_from_stream")(pts.ctypes.data, self._npts, self._sdim, buf,
-                                                           len(_stream), dev, byref(handle)))
+            # (a tree over a topological space is written with four bounds per branch, kd_tree_node.hpp:52-67)
+            entry = "ptk_tree_create_from_topological_stream" if self._topological() else "ptk_tree_create_from_stream"
+            _check(self._fn(entry)(pts.ctypes.data, self._npts, self._sdim, buf, len(_stream), dev, byref(handle)))
         self._h = handle
         if metric is not Metric.L2Squared:
             _check(self._fn("ptk_tree_set_metric")(handle, _PTK_METRIC[metric]))
@@ -382,11 +386,15 @@ class KdTree:
     def metric_string(self) -> str:  # core.hpp:24-38
         return self._metric.name
 
+    def _topological(self) -> bool:
+        return self._metric.name in ("SO2", "SE2Squared")
+
     def _serialize(self) -> bytes:
+        entry = "ptk_tree_serialize_topological" if self._topological() else "ptk_tree_serialize"
         size = c_uint64()
-        _check(self._fn("ptk_tree_serialize")(self._h, None, 0, byref(size)))
+        _check(self._fn(entry)(self._h, None, 0, byref(size)))
         buf = ctypes.create_string_buffer(size.value)
-        _check(self._fn("ptk_tree_serialize")(self._h, buf, size.value, byref(size)))
+        _check(self._fn(entry)(self._h, buf, size.value, byref(size)))
         return buf.raw[:size.value]
 
     # -- helpers ---------------------------------------------------------------

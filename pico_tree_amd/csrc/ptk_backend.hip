@@ -1670,8 +1670,10 @@ int ptk_tree_get_flat(const ptk_tree* t, ptk_node* nodes, int32_t* indices, floa
   return PTK_OK;
 }
 
-int ptk_tree_serialize(const ptk_tree* t, void* buf, uint64_t cap, uint64_t* size) {
+static int serialize_tree(const ptk_tree* t, bool topological, void* buf, uint64_t cap, uint64_t* size) {
   if (t == nullptr || size == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (topological && t->outer.size() != 2 * t->nodes.size())
+    return fail(PTK_ERR_INVALID, "this tree has no outer bounds (ptk_tree_set_outer_bounds): it cannot be written as a topological tree");
   try {
     using tree_t = pico_tree::internal::flat_tree<int, float, pico_tree::dynamic_extent>;
     tree_t flat(t->dim);
@@ -1680,6 +1682,11 @@ int ptk_tree_serialize(const ptk_tree* t, void* buf, uint64_t cap, uint64_t* siz
     std::memcpy(flat.root_box.max(), t->root_max.data(), t->dim * sizeof(float));
     flat.nodes.resize(t->nodes.size());
     std::memcpy(static_cast<void*>(flat.nodes.data()), t->nodes.data(), t->nodes.size() * sizeof(ptk_node));
+    if (topological) {  // the four bounds of kd_tree_branch_double (kd_tree_node.hpp:52-67)
+      flat.keep_outer_bounds = true;
+      flat.outer_bounds.resize(t->nodes.size());
+      std::memcpy(static_cast<void*>(flat.outer_bounds.data()), t->outer.data(), t->outer.size() * sizeof(float));
+    }
     std::ostringstream os(std::ios::out | std::ios::binary);
     pico_tree::internal::write_flat_tree(flat, os);
     const std::string bytes = os.str();
@@ -1694,8 +1701,16 @@ int ptk_tree_serialize(const ptk_tree* t, void* buf, uint64_t cap, uint64_t* siz
   }
 }
 
-int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t dim, const void* stream,
-                                uint64_t stream_bytes, int32_t device, ptk_tree** out) {
+int ptk_tree_serialize(const ptk_tree* t, void* buf, uint64_t cap, uint64_t* size) {
+  return serialize_tree(t, false, buf, cap, size);
+}
+
+int ptk_tree_serialize_topological(const ptk_tree* t, void* buf, uint64_t cap, uint64_t* size) {
+  return serialize_tree(t, true, buf, cap, size);
+}
+
+static int create_from_stream(const float* points, uint64_t n_points, uint32_t dim, const void* stream,
+                              uint64_t stream_bytes, bool topological, int32_t device, ptk_tree** out) {
   if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
   *out = nullptr;
   if (points == nullptr || stream == nullptr) return fail(PTK_ERR_INVALID, "null argument");
@@ -1704,7 +1719,7 @@ int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t
   try {
     using tree_t = pico_tree::internal::flat_tree<int, float, pico_tree::dynamic_extent>;
     std::istringstream is(std::string(static_cast<const char*>(stream), stream_bytes), std::ios::in | std::ios::binary);
-    tree_t flat = pico_tree::internal::read_flat_tree<tree_t>(is, false, dim, n_points);
+    tree_t flat = pico_tree::internal::read_flat_tree<tree_t>(is, topological, dim, n_points);
     if (flat.root_box.size() != dim) return fail(PTK_ERR_INVALID, "stream is %zu-dimensional, points are %u-dimensional",
                                                  (size_t)flat.root_box.size(), dim);
     if (flat.indices.size() != n_points)
@@ -1715,6 +1730,10 @@ int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t
     t->n_points = n_points;
     t->nodes.resize(flat.nodes.size());
     std::memcpy(t->nodes.data(), flat.nodes.data(), flat.nodes.size() * sizeof(ptk_node));
+    if (topological) {  // {left_min, right_max} per node: what the topological metrics need besides the 16-byte record
+      t->outer.resize(flat.outer_bounds.size() * 2);
+      if (!flat.outer_bounds.empty()) std::memcpy(t->outer.data(), flat.outer_bounds.data(), t->outer.size() * sizeof(float));
+    }
     t->indices.assign(flat.indices.begin(), flat.indices.end());
     t->root_min.assign(flat.root_box.min(), flat.root_box.min() + dim);
     t->root_max.assign(flat.root_box.max(), flat.root_box.max() + dim);
@@ -1726,6 +1745,16 @@ int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t
     return fail(PTK_ERR_INVALID, "bad kd_tree stream: %s", e.what());
   }
   return finish_create(t, points, device, out);
+}
+
+int ptk_tree_create_from_stream(const float* points, uint64_t n_points, uint32_t dim, const void* stream,
+                                uint64_t stream_bytes, int32_t device, ptk_tree** out) {
+  return create_from_stream(points, n_points, dim, stream, stream_bytes, false, device, out);
+}
+
+int ptk_tree_create_from_topological_stream(const float* points, uint64_t n_points, uint32_t dim, const void* stream,
+                                            uint64_t stream_bytes, int32_t device, ptk_tree** out) {
+  return create_from_stream(points, n_points, dim, stream, stream_bytes, true, device, out);
 }
 
 int ptk_tree_set_outer_bounds(ptk_tree* t, const float* outer, uint64_t n_nodes) {

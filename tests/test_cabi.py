@@ -12,6 +12,7 @@ import subprocess
 import numpy as np
 import pytest
 
+import oracle
 import pico_tree_amd as pt
 from pico_tree_amd import datasets as ds
 
@@ -263,3 +264,24 @@ def test_the_reference_module_name_is_importable():
 
     assert pico_tree.KdTree is pt.KdTree and pico_tree.DArray is pt.DArray and pico_tree.Metric is pt.Metric
     assert pico_tree.load_kd_tree is pt.load_kd_tree and pico_tree.save_kd_tree is pt.save_kd_tree
+
+
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
+@pytest.mark.parametrize("metric,dim", [("SO2", 1), ("SE2Squared", 3)])
+def test_topological_tree_stream_is_the_reference_stream(tmp_path, metric, dim):
+    """kd_tree<space, metric_so2 | metric_se2_squared>::save writes four bounds per branch
+    (kd_tree_branch_double, internal/kd_tree_node.hpp:52-67): a tree built here serialises to the same bytes, and a
+    saved one loads straight into a handle with its outer bounds (no device needed for either)."""
+    pts = ds.uniform_cloud(6_000, dim, 17)
+    tree = pt.KdTree(pts, pt.Metric[metric], 10, device=pt.PTK_DEVICE_NONE)
+    ref = oracle.Oracle(pts, 10, "reference", metric)
+    stream = tree._serialize()
+    assert stream == ref.save_bytes()
+    path = str(tmp_path / "topological.pkd")
+    pt.save_kd_tree(tree, path)
+    again = pt.load_kd_tree(pts, path, device=pt.PTK_DEVICE_NONE)
+    assert again.metric_string == metric and again._serialize() == stream
+    for a, b in zip(tree.flat(), again.flat()):
+        assert np.array_equal(a, b)
+    plain = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
+    assert len(plain._serialize()) < len(stream)  # two bounds per branch fewer

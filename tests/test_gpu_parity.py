@@ -615,7 +615,7 @@ def test_multi_device_handle_on_the_devices_present(gpu, monkeypatch):
 
 @pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
 @pytest.mark.parametrize("metric", ["SO2", "SE2Squared"])
-def test_topological_metrics_on_the_device(gpu, metric):
+def test_topological_metrics_on_the_device(gpu, metric, tmp_path):
     """metric_so2 / metric_se2_squared (metric.hpp:186-257) searched on the device as
     search_nearest_topological does (kd_tree_search.hpp:115-229; four bounds per branch), against
     kd_tree<space, metric_so2 | metric_se2_squared> of the reference's own headers, wrap-around
@@ -644,6 +644,11 @@ def test_topological_metrics_on_the_device(gpu, metric):
     assert np.array_equal(got.offsets, off) and np.array_equal(got.flat["distance"], flat["distance"])
     knn = ref.search_knn(q, 4)
     assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # neighbours through the seam
+    # saved and loaded straight into a device handle (four bounds per branch in the stream)
+    path = str(tmp_path / "topological.pkd")
+    pt.save_kd_tree(tree, path)
+    again = pt.load_kd_tree(pts, path, device=gpu)
+    assert again.search_knn(q, 7).tobytes() == ref.search_knn(q, 7).tobytes()
     with pytest.raises(pt.PtkError):  # dimension check
         pt.KdTree(ds.uniform_cloud(100, 2, 1), pt.Metric[metric], 10, device=gpu)
 
