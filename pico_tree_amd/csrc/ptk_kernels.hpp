@@ -48,6 +48,9 @@
 #include <utility>
 
 // One batch of stack records per turn of the outer loop of traverse(); 0 = unwind to the next far child in one go.
+#ifndef PTK_KNN_ROW_TRANSPOSE
+#define PTK_KNN_ROW_TRANSPOSE 1
+#endif
 #ifndef PTK_SETTLE
 #define PTK_SETTLE 1
 #endif
@@ -1042,6 +1045,35 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
   KnnRegPolicy<K> pol;
   pol.init(k, e_inv);
   traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
+#if defined(__HIP_DEVICE_COMPILE__) && PTK_KNN_ROW_TRANSPOSE
+  // Full lists of a full wavefront leave through the LDS the stack no longer needs: a lane's K entries are one
+  // row of K x 8 bytes, and K lanes write it with ONE store (whole 64-byte sectors) instead of each lane writing
+  // 8 bytes of its own row K times over (64 partial lines per store: 1.83 GB of WRITE_SIZE for 0.92 GB of rows at
+  // knn = 16).  Slot (lane, j) sits at lane * K + ((j + lane) % K): the writes and the reads are conflict-free.
+  if constexpr (BLOCK == 64 && K <= S && (K & (K - 1)) == 0 && K >= 2) {
+    if (k == (uint32_t)K && (uint64_t)tile * 64u + 63u < nq) {  // (uniform)
+      LdsWord* rows = (LdsWord*)ptk_smem;
+      const uint32_t lane = threadIdx.x;
+#pragma unroll
+      for (int j = 0; j < K; ++j) {
+        Neighbor nb;
+        nb.index = pol.li[j];
+        nb.distance = pol.ld[j];
+        rows[lane * K + (((uint32_t)j + lane) & (K - 1))] = pack_neighbor(nb);
+      }
+      constexpr uint32_t kRowsPerStore = 64u / K;
+      const uint32_t e = lane & (K - 1), sub = lane / K;
+      unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(out);
+#pragma unroll
+      for (uint32_t r0 = 0; r0 < 64u; r0 += kRowsPerStore) {
+        const uint32_t r = r0 + sub;  // the lane whose row this is
+        const uint32_t q_r = (uint32_t)__shfl((int)(uint32_t)qi, (int)r);
+        dst[(uint64_t)q_r * K + e] = rows[r * K + ((e + r) & (K - 1))];
+      }
+      return;
+    }
+  }
+#endif
   pol.store(out + qi * k);
 }
 
