@@ -1165,7 +1165,13 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
 // Wavefronts the capture could not hold are listed, row by row, for radius_kernel<FILL>.
 constexpr int kLogUnroll = 4;
 // LDS bytes per wavefront: staged chunk, sorted chunk (+ 3 entries kept back per row), row tables, owner of each slot
-constexpr uint32_t kLogScatterLds = kLogChunk * 8u * 2u + 256u * 8u + 64u * 12u + kLogChunk + 256u;
+#ifndef PTK_LOG_KEEP
+#define PTK_LOG_KEEP 3
+#endif
+constexpr uint32_t kLogKeep = PTK_LOG_KEEP;  // entries a row may hold back: its runs end on boundaries of (kLogKeep + 1) x 8 bytes
+constexpr uint32_t kLogCarry = 64u * kLogKeep;  // room for them in the sorted chunk (rounded up below)
+constexpr uint32_t kLogSortedPad = (kLogCarry + 63u) & ~63u;
+constexpr uint32_t kLogScatterLds = kLogChunk * 8u * 2u + kLogSortedPad * 8u + 64u * 12u + kLogChunk + kLogSortedPad;
 template <int WAVES>
 __global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
     RadiusCapture cap, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out,
@@ -1186,7 +1192,7 @@ __global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
   unsigned char PTK_LDS* mine_lds = (unsigned char PTK_LDS*)ptk_smem + (size_t)(threadIdx.x / 64u) * kLogScatterLds;
   LdsWord* stage = (LdsWord*)mine_lds;
   LdsWord* sorted = stage + kLogChunk;
-  LdsWord* adj = sorted + kLogChunk + 256;
+  LdsWord* adj = sorted + kLogChunk + kLogSortedPad;
   uint32_t PTK_LDS* lim = (uint32_t PTK_LDS*)(adj + 64);
   unsigned char PTK_LDS* own = (unsigned char PTK_LDS*)(lim + 64);
   const unsigned long long* __restrict__ words = reinterpret_cast<const unsigned long long*>(cap.chunks);
@@ -1194,7 +1200,7 @@ __global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
   unsigned long long in[kPer];
 #pragma unroll
   for (uint32_t j = 0; j < kPer; ++j) in[j] = __builtin_nontemporal_load(words + (uint64_t)chunk * kLogChunk + j * 64u + lane);
-  unsigned long long kept[3] = {0ull, 0ull, 0ull};  // entries of this lane's row still to be written
+  unsigned long long kept[kLogKeep] = {};  // entries of this lane's row still to be written
   uint32_t n_kept = 0u;
   for (;;) {
 #pragma unroll
@@ -1231,12 +1237,12 @@ __global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
     adj[lane] = rowpos - (uint64_t)first;  // (row position of sorted slot f of this lane = adj + f; wraps are harmless)
     // What leaves now: up to the last 32-byte boundary of the row this chunk reaches (everything with the last chunk).
     const uint64_t row_end = rowpos + n_row;
-    const uint64_t stop = next == kLogEnd ? row_end : (row_end & ~3ull);
+    const uint64_t stop = next == kLogEnd ? row_end : (row_end & ~(uint64_t)kLogKeep);
     const uint32_t n_out = stop > rowpos ? (uint32_t)(stop - rowpos) : 0u;
     lim[lane] = first + n_out;
     // move
 #pragma unroll
-    for (uint32_t j = 0; j < 3u; ++j) {
+    for (uint32_t j = 0; j < kLogKeep; ++j) {
       if (j < n_kept) {
         sorted[c] = kept[j];
         own[c] = (unsigned char)lane;
@@ -1276,9 +1282,9 @@ __global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
       if (f < lim[o]) dst[adj[o] + f] = sorted[f];  // (not a non-temporal store: the runs of a row merge in the L2; 4.4 vs 5.2 ms)
     }
     rowpos += n_out;
-    n_kept = n_row - n_out;  // <= 3
+    n_kept = n_row - n_out;  // <= kLogKeep
 #pragma unroll
-    for (uint32_t j = 0; j < 3u; ++j) {
+    for (uint32_t j = 0; j < kLogKeep; ++j) {
       if (j < n_kept) kept[j] = sorted[first + n_out + j];
     }
     if (next == kLogEnd) break;
