@@ -32,6 +32,9 @@
 #include "ptk_hostio.hpp"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#ifndef PTK_KNN_LEAFB
+#define PTK_KNN_LEAFB PTK_GEN_LEAFB
+#endif
 #ifndef PTK_GEN_RING
 #define PTK_GEN_RING 16
 #endif
@@ -1919,7 +1922,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else if (k <= 32 && !short_tree) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(PTK_GEN_RING, (launch_knn_reg<PTK_GEN_RING, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    PTK_WITH_METRIC(PTK_WITH_OVF(PTK_GEN_RING, (launch_knn_reg<PTK_GEN_RING, OVF, 64, PTK_KNN_LEAFB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   } else {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   }
