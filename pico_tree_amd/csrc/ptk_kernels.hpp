@@ -51,6 +51,9 @@
 #ifndef PTK_KNN_ROW_TRANSPOSE
 #define PTK_KNN_ROW_TRANSPOSE 1
 #endif
+#ifndef PTK_SCALAR_LEAF
+#define PTK_SCALAR_LEAF 1
+#endif
 #ifndef PTK_SETTLE
 #define PTK_SETTLE 1
 #endif
@@ -104,8 +107,10 @@ struct Neighbor {
 // "All four words of this float4 are used here" (no instruction): keeps a 16-byte record load whole.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define PTK_KEEP4(P) asm volatile("" ::"v"((P).x), "v"((P).y), "v"((P).z), "v"((P).w))
+#define PTK_SCALAR(X) asm volatile("" : "+v"(X))
 #else
 #define PTK_KEEP4(P) ((void)0)
+#define PTK_SCALAR(X) ((void)0)
 #endif
 
 // LDS pointers carry their address space explicitly so that every stack / k-list access
@@ -805,7 +810,14 @@ __device__ __forceinline__ bool traverse(
           for (int u = 0; u < LEAFB; ++u) {
             PTK_KEEP4(p[u]);
             ids[u] = __float_as_int(p[u].w);
-            ds[u] = point_distance3<M>(f_sub(qx, p[u].x), f_sub(qy, p[u].y), f_sub(qz, p[u].z));
+            // (each difference pinned to a register of its own: left alone, the compiler pairs the arithmetic of two
+            // points into packed instructions and spends more on moving operands into pairs than it saves -- capture
+            // kernel 7.17 -> 6.84 ms without the pairing)
+            float dx = f_sub(qx, p[u].x), dy = f_sub(qy, p[u].y), dz = f_sub(qz, p[u].z);
+            PTK_SCALAR(dx);
+            PTK_SCALAR(dy);
+            PTK_SCALAR(dz);
+            ds[u] = point_distance3<M>(dx, dy, dz);
           }
           pol.template visit_round<LEAFB>(ids, ds, count - j);
           continue;
@@ -817,9 +829,14 @@ __device__ __forceinline__ bool traverse(
             // 16-byte load to 12 bytes and fetches the index with a second, dependent load inside
             // the branch that stores a hit (radius fill pass: +10 ms of 27 on BASELINE config 3).
             PTK_KEEP4(p[u]);
-            const float dx = f_sub(qx, p[u].x);
-            const float dy = f_sub(qy, p[u].y);
-            const float dz = f_sub(qz, p[u].z);
+            float dx = f_sub(qx, p[u].x);
+            float dy = f_sub(qy, p[u].y);
+            float dz = f_sub(qz, p[u].z);
+#if PTK_SCALAR_LEAF
+            PTK_SCALAR(dx);
+            PTK_SCALAR(dy);
+            PTK_SCALAR(dz);
+#endif
             pol.visit(__float_as_int(p[u].w), point_distance3<M>(dx, dy, dz));
           }
         }
