@@ -1212,22 +1212,27 @@ __global__ __launch_bounds__(64 * WAVES) void radius_log_scatter_kernel(
   LdsWord* adj = sorted + kLogChunk + kLogSortedPad;
   uint32_t PTK_LDS* lim = (uint32_t PTK_LDS*)(adj + 64);
   unsigned char PTK_LDS* own = (unsigned char PTK_LDS*)(lim + 64);
-  const unsigned long long* __restrict__ words = reinterpret_cast<const unsigned long long*>(cap.chunks);
   unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(out);
-  unsigned long long in[kPer];
+  // (two slots per lane and load: 16 bytes per lane, 1 KB per instruction)
+  typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+  const u64x2* __restrict__ pairs = reinterpret_cast<const u64x2*>(cap.chunks);
+  u64x2 in[kPer / 2];
 #pragma unroll
-  for (uint32_t j = 0; j < kPer; ++j) in[j] = __builtin_nontemporal_load(words + (uint64_t)chunk * kLogChunk + j * 64u + lane);
+  for (uint32_t j = 0; j < kPer / 2; ++j) in[j] = __builtin_nontemporal_load(pairs + (uint64_t)chunk * (kLogChunk / 2) + j * 64u + lane);
   unsigned long long kept[kLogKeep] = {};  // entries of this lane's row still to be written
   uint32_t n_kept = 0u;
   for (;;) {
 #pragma unroll
-    for (uint32_t j = 0; j < kPer; ++j) stage[j * 64u + lane] = in[j];
+    for (uint32_t j = 0; j < kPer / 2; ++j) {
+      stage[2u * (j * 64u + lane)] = in[j].x;
+      stage[2u * (j * 64u + lane) + 1u] = in[j].y;
+    }
     const unsigned long long head = stage[0];
     const uint32_t next = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)head);
     const uint32_t ng = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(head >> 32));
     if (next != kLogEnd) {
 #pragma unroll
-      for (uint32_t j = 0; j < kPer; ++j) in[j] = __builtin_nontemporal_load(words + (uint64_t)next * kLogChunk + j * 64u + lane);
+      for (uint32_t j = 0; j < kPer / 2; ++j) in[j] = __builtin_nontemporal_load(pairs + (uint64_t)next * (kLogChunk / 2) + j * 64u + lane);
     }
     // count
     uint32_t n_mine = 0u;
