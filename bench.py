@@ -671,8 +671,19 @@ def main():
             hdt = (time.perf_counter() - t0) / hsteps
             extras["host_buffers"] = {"value": round(nq / hdt / 1e6, 3), "unit": "Mqueries/s",
                                       "ms_per_step": round(hdt * 1e3, 4), "steps": hsteps,
-                                      "what": "ptk_search_knn on pageable numpy arrays: 86 MB up, search, 58 MB down",
+                                      "what": "ptk_search_knn on pageable numpy arrays: 86 MB up, search, 58 MB down; "
+                                              "the result array is a new one every call, as search_knn(pts, k) of the "
+                                              "reference's module returns it (first touch of its 58 MB included)",
                                       "rows_equal_device_run": bool(host_rows.tobytes() == res.tobytes())}
+            # the overload that fills the caller's array (search_knn(pts, k, nns), def_kd_tree.cpp): no allocation per call
+            tree.search_knn(q, 1, host_rows)
+            t0 = time.perf_counter()
+            for _ in range(hsteps):
+                tree.search_knn(q, 1, host_rows)
+            hdt2 = (time.perf_counter() - t0) / hsteps
+            extras["host_buffers"]["result_array_handed_in"] = {
+                "value": round(nq / hdt2 / 1e6, 3), "ms_per_step": round(hdt2 * 1e3, 4),
+                "rows_equal_device_run": bool(host_rows.tobytes() == res.tobytes())}
             del host_rows
             # (a2) one shard of configs[3] (strong scaling decided on one GPU) and its rows against the full batch
             sh8 = shard_entry(pt, oracle, pts, q, tree, args.leaf, 8, b_per_q)
