@@ -51,6 +51,9 @@
 #ifndef PTK_KNN_ROW_TRANSPOSE
 #define PTK_KNN_ROW_TRANSPOSE 1
 #endif
+#ifndef PTK_SCALAR_P1
+#define PTK_SCALAR_P1 1
+#endif
 #ifndef PTK_SCALAR_LEAF
 #define PTK_SCALAR_LEAF 1
 #endif
@@ -1494,9 +1497,14 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 #pragma unroll
       for (int u = 0; u < LEAFB; ++u) {
         if (j + u < count) {
-          const float dx = f_sub(qx, p[u].x);
-          const float dy = f_sub(qy, p[u].y);
-          const float dz = f_sub(qz, p[u].z);
+          float dx = f_sub(qx, p[u].x);
+          float dy = f_sub(qy, p[u].y);
+          float dz = f_sub(qz, p[u].z);
+#if PTK_SCALAR_P1
+          PTK_SCALAR(dx);
+          PTK_SCALAR(dy);
+          PTK_SCALAR(dz);
+#endif
           pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
         }
       }
@@ -1566,9 +1574,14 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
 #pragma unroll
           for (int u = 0; u < LEAFB; ++u) {
             if (j + u < count) {
-              const float dx = f_sub(qx, p[u].x);
-              const float dy = f_sub(qy, p[u].y);
-              const float dz = f_sub(qz, p[u].z);
+              float dx = f_sub(qx, p[u].x);
+              float dy = f_sub(qy, p[u].y);
+              float dz = f_sub(qz, p[u].z);
+#if PTK_SCALAR_P1
+              PTK_SCALAR(dx);
+              PTK_SCALAR(dy);
+              PTK_SCALAR(dz);
+#endif
               pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
             }
           }
