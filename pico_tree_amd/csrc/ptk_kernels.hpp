@@ -51,6 +51,9 @@
 #ifndef PTK_KNN_ROW_TRANSPOSE
 #define PTK_KNN_ROW_TRANSPOSE 1
 #endif
+#ifndef PTK_SCALAR_COOP
+#define PTK_SCALAR_COOP 1
+#endif
 #ifndef PTK_SCALAR_P1
 #define PTK_SCALAR_P1 1
 #endif
@@ -2202,9 +2205,14 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         uint32_t du = 0;
 #pragma unroll
         for (int u = 3; u >= 0; --u) {
-          const float dx = f_sub(qx, p[u].x);
-          const float dy = f_sub(qy, p[u].y);
-          const float dz = f_sub(qz, p[u].z);
+          float dx = f_sub(qx, p[u].x);
+          float dy = f_sub(qy, p[u].y);
+          float dz = f_sub(qz, p[u].z);
+#if PTK_SCALAR_COOP
+          PTK_SCALAR(dx);
+          PTK_SCALAR(dy);
+          PTK_SCALAR(dz);
+#endif
           const float du_d = (uint32_t)u < cnt ? f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)) : 3.402823466e+38f;
           const bool take = (uint32_t)u < cnt && du_d <= d;
           d_second = take ? d : (du_d < d_second ? du_d : d_second);
