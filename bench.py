@@ -195,7 +195,8 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
     port, on the host cores, on bounded samples: its OpenMP schedule(dynamic,128) loop on one pinned thread per
     physical core, and one thread alone; on the queries as given to the GPU and on a Morton-sorted copy (order alone
     moves a CPU kd-tree by an order of magnitude).  Every figure: one untimed warm-up pass over
-    a slice, then passes over fresh slices until the time budget is used, rate of the median pass."""
+    a slice, then passes over fresh slices until the time budget is used, rate of the fastest pass (slowest and
+    median alongside)."""
     import oracle
     from pico_tree_amd import datasets as ds
 
@@ -227,8 +228,11 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
             used += dt
             at += chunk
         rates.sort()
-        spreads.append((round(rates[0], 4), round(rates[-1], 4)))
-        return rates[len(rates) // 2], at - chunk, len(rates)
+        spreads.append((round(rates[0], 4), round(rates[len(rates) // 2], 4), round(rates[-1], 4)))
+        # The FASTEST pass: the hosts are shared, and one OpenMP thread losing its core to another tenant for a
+        # scheduler quantum makes a 5 ms pass a 90 ms pass (passes of one run: 3.8 ... 81.4 Mqueries/s) -- noise can
+        # only slow the baseline down, so its best pass is the figure that does it justice and that repeats.
+        return rates[-1], at - chunk, len(rates)
 
     omp, n_omp, p_omp = rate(q, cores, 400_000, seconds * 0.45)
     omp_sorted, n_omps, p_omps = rate(q_sorted, cores, 400_000, seconds * 0.15)
@@ -240,21 +244,22 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
             "threads": f"{cores} (one per physical core; OMP_PLACES={os.environ.get('OMP_PLACES')}, "
                        f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
             "sample": f"OpenMP schedule(dynamic,128): warm-up + {p_omp} passes of 400000 queries in the order given to "
-                      f"the GPU ({n_omp} queries), median pass",
+                      f"the GPU ({n_omp} queries), fastest pass",
             "morton_sorted_queries_value": round(omp_sorted, 4),
             "morton_sorted_queries_sample": f"the first {nsorted} queries Morton-sorted, warm-up + {p_omps} passes, "
-                                            f"median pass ({n_omps} queries)",
+                                            f"fastest pass ({n_omps} queries)",
             "single_thread_value": round(one, 4),
-            "single_thread_sample": f"warm-up + {p_one} passes of 50000 queries as given ({n_one} queries), median pass",
+            "single_thread_sample": f"warm-up + {p_one} passes of 50000 queries as given ({n_one} queries), fastest pass",
             "single_thread_morton_sorted_value": round(one_sorted, 4),
             "single_thread_morton_sorted_sample": f"warm-up + {p_ones} passes of 100000 sorted queries ({n_ones} queries)",
             "build_s": round(build_s, 3),
-            "slowest_fastest_pass": {"value": spreads[0], "morton_sorted_queries_value": spreads[1],
+            "slowest_median_fastest_pass": {"value": spreads[0], "morton_sorted_queries_value": spreads[1],
                                      "single_thread_value": spreads[2], "single_thread_morton_sorted_value": spreads[3]},
             "host_loadavg_before": load_before,
-            "note": "the bench boxes are shared (four GPU slots per host): with another tenant's job on the cores the "
-                    "memory-bound figure -- all cores, queries as given -- has been seen at 4.5 instead of 80 Mqueries/s "
-                    "while the cache-resident ones did not move (profiles/r03_notes.txt item 15)"}
+            "note": "every figure is the fastest pass: the bench boxes are shared (four GPU slots per host), and when one "
+                    "of the 128 pinned threads loses its core for a scheduler quantum a 5 ms pass takes 90 ms -- the "
+                    "median pass of the all-cores figure has been 4.5 or 80 Mqueries/s from run to run, the fastest "
+                    "79-86 (profiles/r03_notes.txt items 15, 26)"}
 
 
 def time_device_knn(tree, dq, k, steps, warmup=2):
