@@ -51,6 +51,9 @@
 #ifndef PTK_KNN_ROW_TRANSPOSE
 #define PTK_KNN_ROW_TRANSPOSE 1
 #endif
+#ifndef PTK_SCALAR_SUM
+#define PTK_SCALAR_SUM 1
+#endif
 #ifndef PTK_SCALAR_COOP
 #define PTK_SCALAR_COOP 1
 #endif
@@ -823,7 +826,15 @@ __device__ __forceinline__ bool traverse(
             PTK_SCALAR(dx);
             PTK_SCALAR(dy);
             PTK_SCALAR(dz);
+#if PTK_SCALAR_SUM
+            float dsum = M::one(dx);
+            PTK_SCALAR(dsum);
+            dsum = M::acc(dsum, dy);
+            PTK_SCALAR(dsum);
+            ds[u] = M::acc(dsum, dz);
+#else
             ds[u] = point_distance3<M>(dx, dy, dz);
+#endif
           }
           pol.template visit_round<LEAFB>(ids, ds, count - j);
           continue;
