@@ -32,6 +32,9 @@
 #include "ptk_hostio.hpp"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#ifndef PTK_P2_RING
+#define PTK_P2_RING 12  // LDS ring of the capped phase 2 (records per lane)
+#endif
 #ifndef PTK_KNN_LEAFB
 #define PTK_KNN_LEAFB PTK_GEN_LEAFB
 #endif
@@ -1290,7 +1293,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt items 10, 23); without it 16 slots
   // (r01l_notes item 8).
   if (cap) {
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<12, OVF, LEAFB>), p2_grid, dim3(64), (size_t)12 * 64 * 8, s, t->dev, qs,
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<PTK_P2_RING, OVF, LEAFB>), p2_grid, dim3(64), (size_t)PTK_P2_RING * 64 * 8, s, t->dev, qs,
                        e_inv, d_out, cont, ids_out, cap, ho);
   } else {
     hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
