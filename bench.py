@@ -486,7 +486,7 @@ def main():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    pt.device_count()  # (libptk starts loading its code object for this device now, beside the generation of the clouds)
+    pt.warmup(local_rank)  # (libptk starts loading its code object for THIS rank's device now, beside the generation of the clouds)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=dev)
@@ -702,7 +702,7 @@ def main():
             create["what"] = ("KdTree(points): build (partitions of the top levels on the device, the subtrees below by the "
                               "host threads of the library; phase host_build_s), re-encoding for the device, upload + "
                               "point gather; first = first handle of the process (the code object loads from "
-                              "device_count() on, beside the generation of the clouds)")
+                              "pt.warmup(device) on, beside the generation of the clouds)")
             del tree_b
             extras["create"] = create
             # (b) config 3 on the same clouds

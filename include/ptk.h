@@ -54,7 +54,7 @@
 extern "C" {
 #endif
 
-#define PTK_VERSION 100 /* 0.1.0 */
+#define PTK_VERSION 101 /* 0.1.1: ptk_warmup, ptk_profile_get_sized */
 
 typedef enum ptk_status {
   PTK_OK = 0,
@@ -125,7 +125,12 @@ enum { PTK_REORDER_AUTO = 0, PTK_REORDER_ON = 1, PTK_REORDER_OFF = 2 };
 /* ---- library ---------------------------------------------------------- */
 int ptk_version(void);
 const char* ptk_last_error(void); /* thread-local, never NULL */
-int ptk_device_count(void);       /* number of visible HIP devices, or < 0 */
+int ptk_device_count(void);       /* number of visible HIP devices, or < 0; no side effects */
+/* Starts loading the library's device code for `device` (< 0: the calling thread's current device)
+ * on a thread of the library and returns at once: the first ptk_tree_create* for that device then
+ * does not wait for it (~0.2 s).  Optional -- the first creation starts it itself; one load per
+ * device and process; PTK_EAGER_WARMUP=0 in the environment turns it off. */
+int ptk_warmup(int32_t device);
 
 /* ---- tree lifetime ---------------------------------------------------- */
 
@@ -398,6 +403,9 @@ typedef struct ptk_profile {
 } ptk_profile;
 int ptk_profile_enable(ptk_tree* tree, int on);
 int ptk_profile_get(const ptk_tree* tree, ptk_profile* out, int reset);
+/* The same for a caller built against another version of this header: writes the first `size`
+ * bytes of the record only (fields are only ever appended to ptk_profile). */
+int ptk_profile_get_sized(const ptk_tree* tree, void* out, uint64_t size, int reset);
 /* Counters of the last two-phase k = 1 search on the handle's default scratch block (synchronises
  * the device): counts[0] = queries that needed phase 2, [1] = queries phase 2 handed to the
  * cooperative search, [2] = queries that search could not certify (redone by the reference
@@ -410,6 +418,10 @@ int ptk_debug_create_phases(const ptk_tree* tree, double ms[3]);
  * first three axes; in proportion to how often a root-to-leaf path of this tree splits on each).  Works on handles
  * without a device replica too. */
 int ptk_debug_key_bits(const ptk_tree* tree, uint64_t nq, uint32_t bits[3]);
+/* What the last search on the handle's default scratch block did with the order of its batch: 0 = taken as it came
+ * (small batch, PTK_REORDER_OFF), 1 = sorted on the device, 2 = sampled, found coherent and searched in the caller's
+ * order (k = 1 under PTK_REORDER_AUTO; the reference's loop walks the rows as given, _pyco_tree/kd_tree.hpp:128-134). */
+int ptk_debug_batch_order(const ptk_tree* tree, int* how);
 
 #ifdef __cplusplus
 } /* extern "C" */

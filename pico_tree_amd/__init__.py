@@ -75,6 +75,7 @@ _SIGNATURES = {
     "ptk_version": (c_int, []),
     "ptk_last_error": (c_char_p, []),
     "ptk_device_count": (c_int, []),
+    "ptk_warmup": (c_int, [c_int32]),
     "ptk_tree_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_int32,
                                             POINTER(c_void_p)]),
     "ptk_tree_create": (c_int, [c_void_p, POINTER(c_void_p)]),
@@ -130,9 +131,11 @@ _SIGNATURES = {
                                              c_void_p]),
     "ptk_profile_enable": (c_int, [c_void_p, c_int]),
     "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
+    "ptk_profile_get_sized": (c_int, [c_void_p, c_void_p, c_uint64, c_int]),
     "ptk_debug_knn1_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ptk_debug_create_phases": (c_int, [c_void_p, POINTER(c_double)]),
     "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
+    "ptk_debug_batch_order": (c_int, [c_void_p, POINTER(c_int)]),
     "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
                                              POINTER(c_void_p)]),
     "ptk_multi_create": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p)]),
@@ -174,10 +177,6 @@ def _load():
             fn.restype = restype
             fn.argtypes = argtypes
         _lib = lib
-        # The first question about devices also starts loading the library's code object for the device on a thread of
-        # the library (0.17 s that would otherwise be paid by the first tree): ask now.
-        if os.environ.get("PTK_EAGER_WARMUP", "1") != "0":
-            lib.ptk_device_count()
     return _lib
 
 
@@ -188,6 +187,12 @@ def _check(status: int) -> None:
 
 def device_count() -> int:
     return int(_load().ptk_device_count())
+
+
+def warmup(device: int = -1) -> None:
+    """Starts loading the library's device code for ``device`` (default: the current one) in the background, so that
+    the first :class:`KdTree` for it does not wait for the load (``ptk_warmup``).  Optional."""
+    _check(_load().ptk_warmup(int(device)))
 
 
 class Metric(enum.Enum):
@@ -357,6 +362,8 @@ class KdTree:
         lib = _load()
         handle = c_void_p()
         dev = PTK_DEVICE_CURRENT if device is None else int(device)
+        if self._f64 and self._metric.name in ("SO2", "SE2Squared"):
+            raise ValueError("the topological metrics (SO2, SE2Squared) are available for float32 points only")
         self._fn = (lambda name: getattr(lib, name.replace("ptk_tree_", "ptk_tree64_").replace("ptk_search_", "ptk_search64_"))) \
             if self._f64 else (lambda name: getattr(lib, name))
         if _stream is None:
@@ -491,7 +498,7 @@ class KdTree:
         if enable is not None:
             _check(lib.ptk_profile_enable(self._h, int(enable)))
         p = _Profile()
-        _check(lib.ptk_profile_get(self._h, byref(p), int(reset)))
+        _check(lib.ptk_profile_get_sized(self._h, byref(p), ctypes.sizeof(p), int(reset)))
         return {name: getattr(p, name) for name, _ in _Profile._fields_}
 
     def create_phases(self) -> dict:
@@ -507,6 +514,14 @@ class KdTree:
         c = (c_uint32 * 4)()
         _check(_load().ptk_debug_knn1_counts(self._h, c))
         return {"phase2": int(c[0]), "cooperative": int(c[1]), "redone": int(c[2]), "dealt": int(c[3])}
+
+    def batch_order(self) -> int:
+        """What the last search did with the order of its batch: 0 as it came, 1 sorted on the device, 2 found
+        coherent and left alone (``ptk_debug_batch_order``)."""
+        self._float32_only("batch_order()")
+        how = c_int(0)
+        _check(_load().ptk_debug_batch_order(self._h, byref(how)))
+        return int(how.value)
 
     def key_bits(self, nq: int) -> tuple:
         """Bits of the Morton key per axis for a batch of ``nq`` queries (``ptk_debug_key_bits``)."""

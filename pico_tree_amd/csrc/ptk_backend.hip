@@ -32,18 +32,10 @@
 #include "ptk_hostio.hpp"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
-#ifndef PTK_P2_RING
-#define PTK_P2_RING 12  // LDS ring of the capped phase 2 (records per lane)
-#endif
-#ifndef PTK_KNN_LEAFB
-#define PTK_KNN_LEAFB PTK_GEN_LEAFB
-#endif
-#ifndef PTK_GEN_RING
-#define PTK_GEN_RING 16
-#endif
-#ifndef PTK_GEN_LEAFB
-#define PTK_GEN_LEAFB 5  // points per leaf round of the general searches (4 / 5 / 6: knn = 16 4.85 / 4.71 / 4.68 ms, radius capture 7.21 / 7.16 / 7.69)
-#endif
+// Geometry of the launches (measured optima, profiles/r02_notes.txt item 23, r03_notes.txt item 13):
+constexpr int kP2Ring = 12;   // LDS ring of the capped phase 2 (records per lane; 8 / 10 / 16: 1.335 / 1.329 / 1.308 vs 1.224 ms)
+constexpr int kGenRing = 16;  // LDS ring of the general searches (k > 1, radius)
+constexpr int kGenLeafB = 5;  // points per leaf round of the general searches (4 / 5 / 6: knn = 16 4.85 / 4.71 / 4.68 ms, radius capture 7.21 / 7.16 / 7.69)
 #include "ptk_build.hpp"
 #include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
@@ -121,6 +113,11 @@ struct Workspace {
   // (launch_knn1_two_phase); forked and joined with events, so the caller's stream still orders everything.
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
+  // The verdict of the coherence sample of a batch (ptk::coherence_sample_kernel): a pinned host copy and the event
+  // that says it has arrived.
+  uint8_t* h_sample = nullptr;
+  hipEvent_t sampled = nullptr;
+  int last_order = 0;  // the last batch on this block: 0 = taken as it came, 1 = sorted on the device, 2 = found coherent, not sorted
 
   // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
   // it must survive until the fill pass of the same batch while other searches reuse `base`.
@@ -381,6 +378,7 @@ int upload(ptk_tree& t, const float* points) {
     if (d_idx) (void)hipFree(d_idx);
     if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error while encoding the points: %s", hipGetErrorString(he));
   }
+  size_t cell_bytes = 0;
   {
     // The coarse grid of occupied cells (ptk::CellTable): about 32 tree points per cell on average, the cell bits
     // spread over the axes like the bits of the order key.  PTK_CELL_TABLE=0: none.
@@ -397,30 +395,38 @@ int upload(ptk_tree& t, const float* points) {
         inv[d] = ext > 0 ? (float)(1u << b[d]) / ext : 0.0f;
       }
       const size_t n_cells = (size_t)1 << (b[0] + b[1] + b[2]);
+      cell_bytes = n_cells;
       uint32_t* d_counts = nullptr;
       PTK_HIP(hipMalloc(&t.d_cells, n_cells));
       PTK_HIP(hipMalloc((void**)&d_counts, n_cells * 4));
-      PTK_HIP(hipMemsetAsync(d_counts, 0, n_cells * 4, nullptr));
+      {
+        const hipError_t he = hipMemsetAsync(d_counts, 0, n_cells * 4, nullptr);
+        if (he != hipSuccess) {
+          (void)hipFree(d_counts);
+          return fail(PTK_ERR_DEVICE, "hipMemsetAsync failed: %s", hipGetErrorString(he));
+        }
+      }
       const uint32_t blocks = (uint32_t)((t.n_points + ptk::kBlock - 1) / ptk::kBlock);
       hipLaunchKernelGGL(ptk::cell_count_kernel, dim3(blocks), dim3(ptk::kBlock), 0, nullptr,
                          static_cast<const float4*>(t.d_pts), t.n_points, make_float3(lo[0], lo[1], lo[2]),
                          make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]), d_counts);
       hipLaunchKernelGGL(ptk::cell_class_kernel, dim3((uint32_t)((n_cells + ptk::kBlock - 1) / ptk::kBlock)),
                          dim3(ptk::kBlock), 0, nullptr, d_counts, n_cells, static_cast<uint8_t*>(t.d_cells));
-      const hipError_t he = hipDeviceSynchronize();
+      hipError_t he = hipGetLastError();  // (a launch that failed)
+      const hipError_t he_sync = hipDeviceSynchronize();
+      if (he == hipSuccess) he = he_sync;
       (void)hipFree(d_counts);
       if (he != hipSuccess) return fail(PTK_ERR_DEVICE, "HIP error while counting the grid cells: %s", hipGetErrorString(he));
       t.cells.occ = static_cast<const uint8_t*>(t.d_cells);
       t.cells.inv = make_float3(inv[0], inv[1], inv[2]);
       t.cells.bits = make_uint3(b[0], b[1], b[2]);
-      t.device_bytes += n_cells;
     }
   }
   clock.lap("upload + gather points", 2);
   PTK_HIP(hipMalloc(&t.d_ranges, enc.ranges.size() * sizeof(ptk::EncRange)));
   PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), enc.ranges.size() * sizeof(ptk::EncRange), hipMemcpyHostToDevice));
   t.device_bytes = enc.nodes.size() * sizeof(uint4) + n_records * sizeof(float4) +
-                   enc.ranges.size() * sizeof(ptk::EncRange);
+                   enc.ranges.size() * sizeof(ptk::EncRange) + cell_bytes;
   t.dev.nodes = static_cast<const uint4*>(t.d_nodes);
   t.dev.pts = static_cast<const float4*>(t.d_pts);
   t.dev.root_ref = enc.root_ref;
@@ -431,35 +437,49 @@ int upload(ptk_tree& t, const float* points) {
   return PTK_OK;
 }
 
-// The first kernel launch of a process loads libptk's code object for the device (~10 MB: 0.17 s on the bench box,
-// profiles/r02_notes.txt item 13).  That load is started on a thread of its own as early as the library hears of a
-// device -- the first ptk_device_count() that finds one (the Python package asks when it loads the library), or the
-// first creation -- so that it runs beside whatever the caller does before its first tree (reading the points), and
-// beside the host part of that creation.  wait() before the first launch of the calling thread.
+// The first kernel launch on a device loads libptk's code object for it (~10 MB: 0.17 s on the bench box,
+// profiles/r02_notes.txt item 13).  That load can be started ahead of time on a thread of the library -- by
+// ptk_warmup(device), or by the first creation for the device -- so that it runs beside whatever the caller does before
+// its first tree (reading the points) and beside the host part of that creation.  One load per device and process;
+// wait(device) before the first launch of the calling thread.  PTK_EAGER_WARMUP=0: no thread, the first launch loads.
+// (A query about devices -- ptk_device_count() -- starts nothing: in a job of one process per GPU every rank counts the
+// devices before it picks its own, and none of them wants a context on device 0.)
 __global__ void ptk_warm_kernel() {}
 struct ProcessWarmup {
+  static constexpr int kMaxDevices = 64;
   std::mutex lock;
-  std::thread thread;
-  bool started = false;
+  std::thread threads[kMaxDevices];
+  bool started[kMaxDevices] = {};
   void start(int32_t device) {
-    std::lock_guard<std::mutex> hold(lock);
-    if (started || device == kDeviceNone) return;
-    started = true;
+    if (device == kDeviceNone) return;
+    const char* sw = std::getenv("PTK_EAGER_WARMUP");
+    if (sw != nullptr && std::atoi(sw) == 0) return;
     int dev = device;  // (the device the CALLER is on, not the new thread's default)
-    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) dev = 0;
-    thread = std::thread([dev] {
-      if (hipSetDevice(dev) != hipSuccess) return;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return;
+    if (dev < 0 || dev >= kMaxDevices) return;
+    std::lock_guard<std::mutex> hold(lock);
+    if (started[dev]) return;
+    started[dev] = true;
+    threads[dev] = std::thread([dev] {
+      if (hipSetDevice(dev) != hipSuccess) {
+        (void)hipGetLastError();
+        return;
+      }
       hipLaunchKernelGGL(ptk_warm_kernel, dim3(1), dim3(1), 0, nullptr);
       (void)hipDeviceSynchronize();
       (void)hipGetLastError();
     });
   }
-  void wait() {
+  void wait(int32_t device) {
+    int dev = device;
+    if (dev < 0 && hipGetDevice(&dev) != hipSuccess) return;
+    if (dev < 0 || dev >= kMaxDevices) return;
     std::lock_guard<std::mutex> hold(lock);
-    if (thread.joinable()) thread.join();
+    if (threads[dev].joinable()) threads[dev].join();
   }
   ~ProcessWarmup() {
-    if (thread.joinable()) thread.join();
+    for (auto& th : threads)
+      if (th.joinable()) th.join();
   }
 };
 ProcessWarmup g_warmup;
@@ -665,10 +685,12 @@ class Scratch {
     }
     ws_.used = 0;
     ws_.last_meta = nullptr;  // whatever the last k = 1 search left in the block is about to be overwritten (or freed)
+    ws_.last_order = 0;
     reserved_ = true;
     return PTK_OK;
   }
   void note_meta(const uint32_t* meta) { ws_.last_meta = meta; }
+  void note_order(int how) { ws_.last_order = how; }
   // The second stream of this scratch block and its two events (made on first use); false if they cannot be had.
   bool side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
     if (ws_.side == nullptr) {
@@ -687,6 +709,23 @@ class Scratch {
     *side = ws_.side;
     *fork = ws_.fork;
     *join = ws_.join;
+    return true;
+  }
+  // Pinned host bytes for the coherence sample of this block's batch and the event behind their copy.
+  bool sample_slot(uint8_t** host, hipEvent_t* arrived) {
+    if (ws_.h_sample == nullptr &&
+        hipHostMalloc((void**)&ws_.h_sample, ptk::kCoherenceWindows, hipHostMallocDefault) != hipSuccess) {
+      ws_.h_sample = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    if (ws_.sampled == nullptr && hipEventCreateWithFlags(&ws_.sampled, hipEventDisableTiming) != hipSuccess) {
+      ws_.sampled = nullptr;
+      (void)hipGetLastError();
+      return false;
+    }
+    *host = ws_.h_sample;
+    *arrived = ws_.sampled;
     return true;
   }
   template <class T>
@@ -823,15 +862,55 @@ bool own_sort(uint64_t nq) {
   return mode < 0 ? nq < (2ull << 20) : mode != 0;
 }
 
-size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, 30) + own_sort_bytes(nq); }
+size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, 30) + own_sort_bytes(nq) + 1024; }
 
 // Device-side Morton ordering of a batch: *perm (device, nq uint32, in `scratch`) lists the
 // query rows in launch order.
 // heavy_first (ptk::kCellsEmptyFirst / kCellsDenseFirst, 0 = plain Morton order): the queries that will be expensive
 // -- by the tree's coarse grid of cell occupancies, ptk::CellTable -- go to the front of the order: for the kernels that
 // run every query to its end in its lane.
+// may_skip: the batch is sampled first (ptk::coherence_sample_kernel: 256 windows of 64 consecutive rows); if it is
+// already in a coherent order -- a scan in scan order, a batch the caller sorted -- *perm stays null and the search
+// runs on the caller's order, as the reference does (_pyco_tree/kd_tree.hpp:128-134).  The verdict travels to the host
+// while the key kernel of the sort runs, so a batch that does need the sort waits for nothing.
+bool batch_is_coherent(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch, int bits,
+                       const float3& lo3, const float3& inv3, const uint3& b3, uint8_t** h_fail, hipEvent_t* arrived) {
+  *h_fail = nullptr;
+  if (nq < 8192 || env_int("PTK_COHERENCE_CHECK", 1) == 0) return false;
+  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
+    (void)hipGetLastError();
+    return false;  // (a captured stream cannot be waited on: the batch is sorted)
+  }
+  uint8_t* d_fail = scratch.take<uint8_t>(ptk::kCoherenceWindows);
+  if (d_fail == nullptr || !scratch.sample_slot(h_fail, arrived)) return false;
+  // 64 neighbours of a sorted batch cover about 2^bits x 64 / nq cells; five more bits of slack (the box of a window is
+  // rounded up per axis, and a window may sit across a cell boundary).
+  uint32_t lg = 0;
+  while ((128ull << lg) <= nq) ++lg;  // floor(log2(nq / 64))
+  const uint32_t max_log2 = (uint32_t)std::min(bits, std::max(bits - (int)lg, 0) + 5);
+  hipLaunchKernelGGL(ptk::coherence_sample_kernel, dim3(ptk::kCoherenceWindows), dim3(64), 0, s, d_q, t->dim, nq, lo3, inv3,
+                     b3, max_log2, d_fail);
+  if (hipMemcpyAsync(*h_fail, d_fail, ptk::kCoherenceWindows, hipMemcpyDeviceToHost, s) != hipSuccess ||
+      hipEventRecord(*arrived, s) != hipSuccess) {
+    (void)hipGetLastError();
+    *h_fail = nullptr;
+  }
+  return *h_fail != nullptr;
+}
+// (after the first kernel of the sort has been enqueued) true: skip the sort
+bool coherent_verdict(const uint8_t* h_fail, hipEvent_t arrived) {
+  if (hipEventSynchronize(arrived) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  uint32_t failing = 0;
+  for (uint32_t w = 0; w < ptk::kCoherenceWindows; ++w) failing += h_fail[w];
+  return failing * 100u <= ptk::kCoherenceWindows * 15u;  // up to 15 % of the windows may straddle a boundary
+}
+
 int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch,
-                     uint32_t** perm, uint32_t heavy_first = 0) {
+                     uint32_t** perm, uint32_t heavy_first = 0, bool may_skip = false) {
   *perm = nullptr;
   if (nq >= (1ull << 32)) return fail(PTK_ERR_UNSUPPORTED, "batches of 2^32 or more queries are not supported");
   Timer timer(t, s);
@@ -857,6 +936,11 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     cells.key_bits = (uint32_t)bits;
     cells.mode = heavy_first;
   }
+  uint8_t* h_fail = nullptr;
+  hipEvent_t arrived = nullptr;
+  const bool sampled = may_skip && batch_is_coherent(t, d_q, nq, s, scratch, bits, make_float3(lo[0], lo[1], lo[2]),
+                                                     make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]),
+                                                     &h_fail, &arrived);
   if (own_sort(nq)) {
     // Key + histogram kernel, then per 8-bit pass: scan of the digit-by-tile histogram, stable scatter (and the
     // histogram of the next digit): 3 launches per pass - 1... nothing to clear, no look-back (ptk_sort.hpp).
@@ -882,6 +966,12 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
       else
         hipLaunchKernelGGL((ptk::radix_hist_kernel<false>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
                            inv3, b3, keys, in, shift, tile, stride, hist, ptk::CellTable{});
+      if (first && sampled && coherent_verdict(h_fail, arrived)) {  // (the verdict came in beside the key kernel)
+        scratch.note_order(2);
+        PTK_HIP(hipGetLastError());
+        timer.stop(1, 0);
+        return PTK_OK;
+      }
       hipLaunchKernelGGL(ptk::radix_scan_kernel, dim3(ptk::kRadixBins), dim3(64), 0, s, hist, tiles, stride, totals);
 #define PTK_SCATTER(F, L)                                                                                              \
   hipLaunchKernelGGL((ptk::radix_scatter_kernel<F, L>), dim3(tiles), dim3(64), smem, s, keys, in, out, ids_out,        \
@@ -895,15 +985,31 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     }
     PTK_HIP(hipGetLastError());
     *perm = ids_out;
+    scratch.note_order(1);
     timer.stop(1, 0);
     return PTK_OK;
   }
-  const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
-  hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq,
-                     make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]),
-                     keys, ids, cells);
+  // (a sampled batch: the keys of the first third are computed while the verdict travels -- ~12 us of kernel hide
+  // the copy and the event -- and the rest once it says "sort")
+  const uint64_t head = sampled ? (nq / 3) & ~(uint64_t)(ptk::kBlock - 1) : nq;
+  for (int part = 0; part < 2; ++part) {
+    const uint64_t lo_row = part == 0 ? 0 : head, hi_row = part == 0 ? head : nq;
+    if (hi_row > lo_row) {
+      const uint32_t blocks = (uint32_t)((hi_row - lo_row + ptk::kBlock - 1) / ptk::kBlock);
+      hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, hi_row,
+                         make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]),
+                         make_uint3(b[0], b[1], b[2]), keys, ids, cells, lo_row);
+    }
+    if (part == 0 && sampled && coherent_verdict(h_fail, arrived)) {
+      scratch.note_order(2);
+      PTK_HIP(hipGetLastError());
+      timer.stop(1, 0);
+      return PTK_OK;
+    }
+  }
   PTK_HIP(rocprim::radix_sort_pairs<MortonSortConfig>(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
   *perm = ids_out;
+  scratch.note_order(1);
   timer.stop(1, 0);
   return PTK_OK;
 }
@@ -1293,7 +1399,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt items 10, 23); without it 16 slots
   // (r01l_notes item 8).
   if (cap) {
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<PTK_P2_RING, OVF, LEAFB>), p2_grid, dim3(64), (size_t)PTK_P2_RING * 64 * 8, s, t->dev, qs,
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<kP2Ring, OVF, LEAFB>), p2_grid, dim3(64), (size_t)kP2Ring * 64 * 8, s, t->dev, qs,
                        e_inv, d_out, cont, ids_out, cap, ho);
   } else {
     hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
@@ -1505,8 +1611,15 @@ const char* ptk_last_error(void) { return g_error.c_str(); }
 int ptk_device_count(void) {
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess) return -1;
-  if (count > 0) g_warmup.start(-1);  // the code object starts loading now (see ProcessWarmup)
   return count;
+}
+
+int ptk_warmup(int32_t device) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PTK_ERR_DEVICE, "no HIP device is visible");
+  if (device >= count) return fail(PTK_ERR_INVALID, "device %d out of range (%d visible)", device, count);
+  g_warmup.start(device);
+  return PTK_OK;
 }
 
 int ptk_tree_create(const ptk_tree_desc* d, ptk_tree** out) {
@@ -1563,7 +1676,7 @@ int ptk_tree_create_from_points(const float* points, uint64_t n_points, uint32_t
       int count = 0, dev = device;
       if (hipGetDeviceCount(&count) == hipSuccess && count > 0 && (dev >= 0 || hipGetDevice(&dev) == hipSuccess) && dev < count) {
         DeviceGuard guard(dev);
-        g_warmup.wait();
+        g_warmup.wait(dev);
         double ms[2] = {0, 0};
         const char* why = "hipSetDevice failed";
         if (guard.ok) built = ptk::device_top_build(points, n_points, dim, (size_t)max_leaf_size, build_threads(), view, flat, ms, &why);
@@ -1619,6 +1732,8 @@ void ptk_tree_destroy(ptk_tree* t) {
       if (w.fork) (void)hipEventDestroy(w.fork);
       if (w.join) (void)hipEventDestroy(w.join);
       if (w.side) (void)hipStreamDestroy(w.side);
+      if (w.sampled) (void)hipEventDestroy(w.sampled);
+      if (w.h_sample) (void)hipHostFree(w.h_sample);
     };
     drain_workspace(t->ws);
     drop_side(t->ws);
@@ -1915,7 +2030,10 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   uint32_t* perm = nullptr;
   if (reorder) {  // Morton order along the first three axes, whatever the dimension
     // (the general kernels run every query to its end in its lane: the expensive queries to the front of the launch)
-    rc = make_permutation(t, d_q, nq, s, scratch, &perm, t->dim <= 3 && !(k == 1 && l2) ? ptk::kCellsEmptyFirst : 0u);
+    // (the two-phase k = 1 search orders its own continuations: a batch that arrives coherent is not sorted again --
+    // REORDER_AUTO only; the general kernels want the expensive queries in front whatever the order)
+    const bool may_skip = k == 1 && l2 && t->dim <= 3 && t->reorder.load() == PTK_REORDER_AUTO;
+    rc = make_permutation(t, d_q, nq, s, scratch, &perm, t->dim <= 3 && !(k == 1 && l2) ? ptk::kCellsEmptyFirst : 0u, may_skip);
     if (rc != PTK_OK) return rc;
   }
   if (t->dim > 3) {
@@ -1925,7 +2043,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else if (k <= 32 && !short_tree) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(PTK_GEN_RING, (launch_knn_reg<PTK_GEN_RING, OVF, 64, PTK_KNN_LEAFB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_knn_reg<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   } else {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   }
@@ -2228,7 +2346,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
                                                                  reinterpret_cast<ptk::Neighbor*>(d_out), s, over_list,
                                                                  n_over))));
     } else {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, kGenLeafB, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
                                                                          s, n_over))));
     }
@@ -2309,7 +2427,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       if (nd) {
         PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd_capture<OVF, M>(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s))));
       } else {
-        PTK_WITH_METRIC(PTK_WITH_OVF(PTK_GEN_RING, (launch_radius_capture<PTK_GEN_RING, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, perm, nq, radius, e, d_counts,
+        PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_radius_capture<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, radius, e, d_counts,
                                                                                    ws.cap, s))));
       }
       if (rc == PTK_OK) {
@@ -2325,7 +2443,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
                                                                  reinterpret_cast<ptk::Neighbor*>(d_out), s, perm))));
     } else {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, PTK_GEN_LEAFB, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
+      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
                                                                          d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
     }
   }
@@ -2718,6 +2836,13 @@ int ptk_debug_create_phases(const ptk_tree* t, double ms[3]) {
   return PTK_OK;
 }
 
+int ptk_debug_batch_order(const ptk_tree* t, int* how) {
+  if (t == nullptr || how == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  std::lock_guard<std::mutex> lock(t->ws.mutex);
+  *how = t->ws.last_order;
+  return PTK_OK;
+}
+
 int ptk_debug_key_bits(const ptk_tree* t, uint64_t nq, uint32_t bits[3]) {
   if (t == nullptr || bits == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   axis_bits(t, morton_bits(nq), bits);
@@ -2732,7 +2857,11 @@ int ptk_profile_enable(ptk_tree* t, int on) {
 }
 
 int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
-  if (t == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  return ptk_profile_get_sized(t, out, sizeof(ptk_profile), reset);
+}
+
+int ptk_profile_get_sized(const ptk_tree* t, void* out_bytes, uint64_t size, int reset) {
+  if (t == nullptr || out_bytes == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lock(t->profile.mutex);
   for (PendingEvent& p : t->profile.pending) {
     float ms = 0;
@@ -2754,7 +2883,7 @@ int ptk_profile_get(const ptk_tree* t, ptk_profile* out, int reset) {
     if (!p.keep_b) t->profile.idle.push_back(p.b);
   }
   t->profile.pending.clear();
-  *out = t->profile.acc;
+  std::memcpy(out_bytes, &t->profile.acc, (size_t)std::min<uint64_t>(size, sizeof(ptk_profile)));
   if (reset) t->profile.acc = ptk_profile{};
   return PTK_OK;
 }

@@ -218,6 +218,7 @@ bool device_top_build(const float* points, uint64_t n, uint32_t dim, size_t max_
   const uint32_t blocks = (n32 + 256u) / 256u;  // covers position n as well
   hipLaunchKernelGGL(build_iota_kernel, dim3(blocks), dim3(256), 0, nullptr, b.idx, n32);
   hipLaunchKernelGGL(build_box_kernel, dim3(kBuildBoxBlocks), dim3(256), 0, nullptr, b.pts, n32, dim, b.partial);
+  if (!ok(hipGetLastError())) return false;  // (a launch that failed: the caller builds on the host instead)
   std::vector<float> partial((size_t)kBuildBoxBlocks * dim * 2);
   if (!ok(hipMemcpy(partial.data(), b.partial, partial.size() * sizeof(float), hipMemcpyDeviceToHost))) return false;
   box_type root(dim);
@@ -250,6 +251,7 @@ bool device_top_build(const float* points, uint64_t n, uint32_t dim, size_t max_
                        b.from_right);
     hipLaunchKernelGGL(build_swap_kernel, dim3(blocks), dim3(256), 0, nullptr, b.idx, b.segs, nsegs, n32, b.from_left,
                        b.from_right);
+    if (!ok(hipGetLastError())) return false;
     if (!ok(hipMemcpy(host_segs.data(), b.segs, nsegs * sizeof(BuildSeg), hipMemcpyDeviceToHost))) return false;
     for (uint32_t s = 0; s < nsegs; ++s) segments[s].cut = segments[s].begin + host_segs[s].m;
     return true;

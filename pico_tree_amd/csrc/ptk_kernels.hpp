@@ -47,32 +47,6 @@
 #include <type_traits>
 #include <utility>
 
-// One batch of stack records per turn of the outer loop of traverse(); 0 = unwind to the next far child in one go.
-#ifndef PTK_KNN_ROW_TRANSPOSE
-#define PTK_KNN_ROW_TRANSPOSE 1
-#endif
-#ifndef PTK_SCALAR_SUM
-#define PTK_SCALAR_SUM 1
-#endif
-#ifndef PTK_SCALAR_COOP
-#define PTK_SCALAR_COOP 1
-#endif
-#ifndef PTK_SCALAR_P1
-#define PTK_SCALAR_P1 1
-#endif
-#ifndef PTK_SCALAR_LEAF
-#define PTK_SCALAR_LEAF 1
-#endif
-#ifndef PTK_SETTLE
-#define PTK_SETTLE 1
-#endif
-#ifndef PTK_LOG_NT_STORE
-#define PTK_LOG_NT_STORE 1
-#endif
-#ifndef PTK_BOUND_UNWIND
-#define PTK_BOUND_UNWIND 1
-#endif
-
 namespace ptk {
 
 // ---- device tree --------------------------------------------------------------
@@ -257,10 +231,7 @@ struct Stack {
     lds[slot(top) * BLOCK] = pack_record(rec);
     ++top;
   }
-#ifndef PTK_UNWIND
-#define PTK_UNWIND 8
-#endif
-  static constexpr int kUnwind = PTK_UNWIND;
+  static constexpr int kUnwind = 8;  // records examined per turn (4 / 12: slower, profiles/r03_notes.txt item 13)
   // The newest records, rr[0] the newest; returns how many are valid (>= 1 unless empty).  They
   // stay on the stack until drop().
   __device__ __forceinline__ int peek(Record (&rr)[kUnwind]) {
@@ -342,7 +313,7 @@ struct NnPolicy {  // search_visitor.hpp:42-65 / :165-193
   __device__ __forceinline__ float max() const { return best_d; }
   // No later point can be accepted (a candidate must be STRICTLY nearer, search_visitor.hpp:55, and no distance is
   // below zero): the search may stop here, its answer is final.
-  __device__ __forceinline__ bool settled() const { return PTK_SETTLE && best_d == 0.0f; }
+  __device__ __forceinline__ bool settled() const { return best_d == 0.0f; }
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
     if (best_d > d) {
@@ -457,7 +428,7 @@ struct KnnRegPolicy {
     }
   }
   __device__ __forceinline__ float max() const { return ld[K - 1]; }
-  __device__ __forceinline__ bool settled() const { return PTK_SETTLE && ld[K - 1] == 0.0f; }  // k points AT the query: see NnPolicy
+  __device__ __forceinline__ bool settled() const { return ld[K - 1] == 0.0f; }  // k points AT the query: see NnPolicy
   __device__ __forceinline__ void visit(int32_t idx, float d) {
     d = f_mul(d, e_inv);
     if (ld[K - 1] > d) {
@@ -509,10 +480,7 @@ struct KnnRegPolicy {
 // could not grow is marked and its 64 rows are searched again by the ordinary fill kernel: a small pool costs time,
 // never correctness.  The order of the hits of one row is the order its lane found them in: the visit order of the
 // reference (search_visitor.hpp:127-156).
-#ifndef PTK_LOG_CHUNK
-#define PTK_LOG_CHUNK 1024
-#endif
-constexpr uint32_t kLogChunk = PTK_LOG_CHUNK;  // 8-byte slots per chunk (8 KB), header and masks included
+constexpr uint32_t kLogChunk = 1024;  // 8-byte slots per chunk (8 KB), header and masks included
 constexpr uint32_t kLogEnd = 0xFFFFFFFFu;    // header: no next chunk / cursor: the capture has failed
 constexpr uint32_t kCapSubPools = 256;
 constexpr uint32_t kCapCounterStride = 16;   // words between counters: one 64-byte line each
@@ -531,7 +499,7 @@ constexpr int kRadiusCount = 0, kRadiusFill = 1, kRadiusCapture = 2;
 // An entry of a capture log: written once, read once by another kernel -- it need not displace the tree in the L2
 // (non-temporal store: capture kernel 7.20 -> 6.86 ms on BASELINE config 3).
 __device__ __forceinline__ void store_entry(Neighbor* p, Neighbor nb) {
-#if defined(__HIP_DEVICE_COMPILE__) && PTK_LOG_NT_STORE
+#if defined(__HIP_DEVICE_COMPILE__)
   __builtin_nontemporal_store(pack_neighbor(nb), reinterpret_cast<unsigned long long*>(p));
 #else
   *p = nb;
@@ -826,15 +794,11 @@ __device__ __forceinline__ bool traverse(
             PTK_SCALAR(dx);
             PTK_SCALAR(dy);
             PTK_SCALAR(dz);
-#if PTK_SCALAR_SUM
             float dsum = M::one(dx);
             PTK_SCALAR(dsum);
             dsum = M::acc(dsum, dy);
             PTK_SCALAR(dsum);
             ds[u] = M::acc(dsum, dz);
-#else
-            ds[u] = point_distance3<M>(dx, dy, dz);
-#endif
           }
           pol.template visit_round<LEAFB>(ids, ds, count - j);
           continue;
@@ -849,11 +813,9 @@ __device__ __forceinline__ bool traverse(
             float dx = f_sub(qx, p[u].x);
             float dy = f_sub(qy, p[u].y);
             float dz = f_sub(qz, p[u].z);
-#if PTK_SCALAR_LEAF
             PTK_SCALAR(dx);
             PTK_SCALAR(dy);
             PTK_SCALAR(dz);
-#endif
             pol.visit(__float_as_int(p[u].w), point_distance3<M>(dx, dy, dz));
           }
         }
@@ -897,7 +859,6 @@ __device__ __forceinline__ bool traverse(
         }
       }
       st.drop(used);
-#if PTK_BOUND_UNWIND
       // ONE batch of records per turn of the outer loop: a lane with a long way back up --
       // above all the last unwind of a query, which pops what is left of the home path, some thirty records nearly
       // all rejected -- no longer holds the wavefront in this loop while the other lanes have leaves to scan (an
@@ -910,7 +871,6 @@ __device__ __forceinline__ bool traverse(
         ref = kLeafBit;
         break;
       }
-#endif
       if (enter) {
         if (CAPPED && ++entered > cap) {
           const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
@@ -981,10 +941,7 @@ __device__ __forceinline__ bool traverse(
 // with the expensive eighth: the radius search of BASELINE config 3 on the scan-like cloud took 32 ms with
 // contiguous eighths (the XCD that got the dense middle of the scan ran on alone) and 16.7 ms in runs of 8 - 32
 // wavefronts; knn = 16 7.65 -> 6.67 ms (profiles/r02_notes.txt item 21).
-#ifndef PTK_XCD_RUN_LOG2
-#define PTK_XCD_RUN_LOG2 4
-#endif
-constexpr uint32_t kXcdRunLog2 = PTK_XCD_RUN_LOG2;
+constexpr uint32_t kXcdRunLog2 = 4;
 // The general 3-D kernels (one launch, expensive queries first) take longer runs: knn = 16 with runs of 8 / 16 / 32 / 64
 // wavefronts 4.69 / 4.73 / 4.65 / 4.62 ms on cloud L, 5.06 / 5.01 / 4.94 / 4.88 on cloud U; the radius capture does not care.
 constexpr uint32_t kXcdRunGeneral = 6;
@@ -1079,7 +1036,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
   KnnRegPolicy<K> pol;
   pol.init(k, e_inv);
   traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
-#if defined(__HIP_DEVICE_COMPILE__) && PTK_KNN_ROW_TRANSPOSE
+#if defined(__HIP_DEVICE_COMPILE__)
   // Full lists of a full wavefront leave through the LDS the stack no longer needs: a lane's K entries are one
   // row of K x 8 bytes, and K lanes write it with ONE store (whole 64-byte sectors) instead of each lane writing
   // 8 bytes of its own row K times over (64 partial lines per store: 1.83 GB of WRITE_SIZE for 0.92 GB of rows at
@@ -1088,6 +1045,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
     if (k == (uint32_t)K && (uint64_t)tile * 64u + 63u < nq) {  // (uniform)
       LdsWord* rows = (LdsWord*)ptk_smem;
       const uint32_t lane = threadIdx.x;
+      __syncthreads();  // (one wavefront: every lane is out of the traversal before its stack slots are reused)
 #pragma unroll
       for (int j = 0; j < K; ++j) {
         Neighbor nb;
@@ -1176,6 +1134,9 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
   if (threadIdx.x == 0) pol.open_log(tile);
   traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   counts[qi] = pol.count;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __syncthreads();  // (one wavefront: every lane has appended its last group before the header is closed)
+#endif
   cap.captured[tile] = pol.close_log() ? 1 : 0;  // (every lane writes the same two values)
 }
 
@@ -1199,10 +1160,7 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
 // Wavefronts the capture could not hold are listed, row by row, for radius_kernel<FILL>.
 constexpr int kLogUnroll = 4;
 // LDS bytes per wavefront: staged chunk, sorted chunk (+ 3 entries kept back per row), row tables, owner of each slot
-#ifndef PTK_LOG_KEEP
-#define PTK_LOG_KEEP 3
-#endif
-constexpr uint32_t kLogKeep = PTK_LOG_KEEP;  // entries a row may hold back: its runs end on boundaries of (kLogKeep + 1) x 8 bytes
+constexpr uint32_t kLogKeep = 3;  // entries a row may hold back: its runs end on boundaries of (kLogKeep + 1) x 8 bytes
 constexpr uint32_t kLogCarry = 64u * kLogKeep;  // room for them in the sorted chunk (rounded up below)
 constexpr uint32_t kLogSortedPad = (kLogCarry + 63u) & ~63u;
 constexpr uint32_t kLogScatterLds = kLogChunk * 8u * 2u + kLogSortedPad * 8u + 64u * 12u + kLogChunk + kLogSortedPad;
@@ -1514,11 +1472,9 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
           float dx = f_sub(qx, p[u].x);
           float dy = f_sub(qy, p[u].y);
           float dz = f_sub(qz, p[u].z);
-#if PTK_SCALAR_P1
           PTK_SCALAR(dx);
           PTK_SCALAR(dy);
           PTK_SCALAR(dz);
-#endif
           pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
         }
       }
@@ -1591,11 +1547,9 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
               float dx = f_sub(qx, p[u].x);
               float dy = f_sub(qy, p[u].y);
               float dz = f_sub(qz, p[u].z);
-#if PTK_SCALAR_P1
               PTK_SCALAR(dx);
               PTK_SCALAR(dy);
               PTK_SCALAR(dz);
-#endif
               pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
             }
           }
@@ -2219,11 +2173,9 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
           float dx = f_sub(qx, p[u].x);
           float dy = f_sub(qy, p[u].y);
           float dz = f_sub(qz, p[u].z);
-#if PTK_SCALAR_COOP
           PTK_SCALAR(dx);
           PTK_SCALAR(dy);
           PTK_SCALAR(dz);
-#endif
           const float du_d = (uint32_t)u < cnt ? f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)) : 3.402823466e+38f;
           const bool take = (uint32_t)u < cnt && du_d <= d;
           d_second = take ? d : (du_d < d_second ? du_d : d_second);
@@ -2675,13 +2627,51 @@ __global__ __launch_bounds__(kBlock) void cell_class_kernel(const uint32_t* __re
 
 __global__ __launch_bounds__(kBlock) void morton_kernel(
     const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv, uint3 bits,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, CellTable cells = CellTable{}) {
-  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, CellTable cells = CellTable{}, uint64_t begin = 0) {
+  const uint64_t i = begin + (uint64_t)blockIdx.x * kBlock + threadIdx.x;  // rows [begin, nq) of the batch
   if (i >= nq) return;
   float x, y, z;
   load_query(queries, dim, i, x, y, z);
   keys[i] = order_key(x, y, z, lo, inv, bits, cells);
   ids[i] = (uint32_t)i;
+}
+
+// Is the batch already in a coherent order?  The reference walks the rows in the caller's order
+// (_pyco_tree/kd_tree.hpp:128-134) and real scans arrive in scan order: sorting such a batch again buys nothing.
+// kCoherenceWindows windows of 64 consecutive rows, evenly spread over the batch, one wavefront each:
+// fail[w] = 1 if the rows of window w spread over more than 2^max_log2 cells of the order-key grid (the product of
+// the per-axis extents of their bounding box, each rounded up to a power of two) -- 64 neighbours of a sorted batch of
+// nq rows cover about 2^(key bits) x 64 / nq cells.  The host decides from the 256 bytes (make_permutation).
+constexpr uint32_t kCoherenceWindows = 256;
+__global__ __launch_bounds__(64) void coherence_sample_kernel(const float* __restrict__ queries, uint32_t dim, uint64_t nq,
+                                                              float3 lo, float3 inv, uint3 bits, uint32_t max_log2,
+                                                              uint8_t* __restrict__ fail) {
+  const uint32_t w = blockIdx.x, lane = threadIdx.x;
+  const uint64_t start = gridDim.x > 1u ? (nq - 64u) * w / (gridDim.x - 1u) : 0u;  // (nq >= 64)
+  float x, y, z;
+  load_query(queries, dim, start + lane, x, y, z);
+  const uint32_t cx = (uint32_t)fminf(fmaxf((x - lo.x) * inv.x, 0.0f), (float)((1u << bits.x) - 1u));
+  const uint32_t cy = (uint32_t)fminf(fmaxf((y - lo.y) * inv.y, 0.0f), (float)((1u << bits.y) - 1u));
+  const uint32_t cz = (uint32_t)fminf(fmaxf((z - lo.z) * inv.z, 0.0f), (float)((1u << bits.z) - 1u));
+  uint32_t mn[3] = {cx, cy, cz}, mx[3] = {cx, cy, cz};
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t lo_o = (uint32_t)__shfl_xor((int)mn[a], d), hi_o = (uint32_t)__shfl_xor((int)mx[a], d);
+      mn[a] = lo_o < mn[a] ? lo_o : mn[a];
+      mx[a] = hi_o > mx[a] ? hi_o : mx[a];
+    }
+  }
+  if (lane == 0u) {
+    uint32_t log2_cells = 0;
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+      const uint32_t ext = mx[a] - mn[a];  // cells spanned - 1
+      log2_cells += ext == 0u ? 0u : 32u - (uint32_t)__builtin_clz(ext);
+    }
+    fail[w] = log2_cells > max_log2 ? 1 : 0;
+  }
 }
 
 // Inclusive-to-exclusive helper for the radius offsets: offsets[0] = 0 is written

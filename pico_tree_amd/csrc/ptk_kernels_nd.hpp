@@ -243,6 +243,9 @@ __global__ __launch_bounds__(64) void radius_nd_capture_kernel(
   if (threadIdx.x == 0) pol.open_log(tile);
   traverse_nd<M>(t, q, off, 64u, pol, st);
   counts[qi] = pol.count;
+#if defined(__HIP_DEVICE_COMPILE__)
+  __syncthreads();  // (one wavefront: every lane has appended its last group before the header is closed)
+#endif
   cap.captured[tile] = pol.close_log() ? 1 : 0;
 }
 

@@ -143,6 +143,7 @@ int multi_finish_create(ptk_multi* m, ptk_tree* host, const float* points, ptk_m
   d.max_depth = host->max_depth;
   m->dim = host->dim;
   int rc = PTK_OK;
+  for (int32_t dev : m->devices) g_warmup.start(dev);  // (every device loads the code object beside the first upload)
   for (size_t i = 0; i < m->devices.size() && rc == PTK_OK; ++i) {
     d.device = m->devices[i];
     ptk_tree* t = nullptr;

@@ -40,7 +40,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(lib, name), f"{name} is declared in ptk.h but not exported"
     assert set(pt.EXPORTED_SYMBOLS) == set(names), "Python binding table out of date"
-    assert pt._load().ptk_version() == 100
+    assert pt._load().ptk_version() == 101
 
 
 def test_host_only_handle_and_loud_failures():

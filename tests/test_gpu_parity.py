@@ -733,6 +733,37 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
         assert redone > 0
 
 
+@pytest.mark.parametrize("cloud", ["lidar", "uniform"])
+def test_batches_that_arrive_coherent_are_not_sorted_again(gpu, cloud):
+    """The reference walks the rows in the caller's order (_pyco_tree/kd_tree.hpp:128-134); the k = 1 search samples
+    the batch and skips its own Morton sort when the order it came in is already coherent.  Generated order (random
+    rays) must still be sorted; Morton-presorted, reversed and block-shuffled batches must not; rows always the
+    oracle's.  PTK_REORDER_ON sorts whatever comes."""
+    import torch
+
+    n, nq = 400_000, 300_000
+    pts, q = _clouds(cloud, n, nq)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    ref = oracle.Oracle(pts, 10, "port")
+    ref.set_threads(ref.max_threads())
+    order = ds.morton_order(q)
+    blocks = np.arange(nq).reshape(-1, 3000)[np.random.default_rng(3).permutation(nq // 3000)].ravel()
+    batches = {"generated": (q, 1), "presorted": (q[order], 2), "reversed": (q[order[::-1]], 2),
+               "block-shuffled": (q[order][blocks], 2)}
+    for name, (batch, how) in batches.items():
+        batch = np.ascontiguousarray(batch)
+        want = ref.search_knn(batch, 1)[:, 0]
+        got = tree.search_knn(torch.from_numpy(batch).to(f"cuda:{gpu}"), 1).numpy()
+        torch.cuda.synchronize()
+        assert got.tobytes() == want.tobytes(), name
+        assert tree.batch_order() == how, (name, tree.batch_order())
+    tree.set_reorder(pt.REORDER_ON)
+    batch = np.ascontiguousarray(q[order])
+    got = tree.search_knn(torch.from_numpy(batch).to(f"cuda:{gpu}"), 1).numpy()
+    torch.cuda.synchronize()
+    assert tree.batch_order() == 1 and got.tobytes() == ref.search_knn(batch, 1)[:, 0].tobytes()
+
+
 def test_config1_through_the_device_matches_the_committed_hashes(gpu):
     """BASELINE configs[0] (100 k / 100 k uniform, knn = 1, leaf 10): the reference's own CPU-runnable case, through
     the HIP path, against tests/golden/hashes.json (SHA-256 of the compiled reference's indices and distance bits)."""
