@@ -33,6 +33,66 @@ inline void ptk_check(int status, char const* what) {
   }
 }
 
+}  // namespace pico_tree::internal
+
+namespace pico_tree {
+
+//! \brief An array of page-locked host memory (ptk_host_alloc) for the query and result arrays of the batched
+//! members: `tree.search_knn(queries, k, rows.data())` then moves the rows straight into it, without staging and
+//! without the first touch of fresh pages a new std::vector pays on every call.  Keep it and reuse it.
+template <typename T_>
+class pinned_buffer {
+ public:
+  pinned_buffer() = default;
+  explicit pinned_buffer(std::size_t count) { resize(count); }
+  pinned_buffer(pinned_buffer const&) = delete;
+  pinned_buffer& operator=(pinned_buffer const&) = delete;
+  pinned_buffer(pinned_buffer&& o) noexcept : data_(o.data_), size_(o.size_), capacity_(o.capacity_) {
+    o.data_ = nullptr;
+    o.size_ = o.capacity_ = 0;
+  }
+  pinned_buffer& operator=(pinned_buffer&& o) noexcept {
+    if (this != &o) {
+      ptk_host_free(data_);
+      data_ = o.data_, size_ = o.size_, capacity_ = o.capacity_;
+      o.data_ = nullptr;
+      o.size_ = o.capacity_ = 0;
+    }
+    return *this;
+  }
+  ~pinned_buffer() { ptk_host_free(data_); }
+  //! Contents are NOT preserved when the buffer has to grow.
+  void resize(std::size_t count) {
+    static_assert(std::is_trivially_copyable_v<T_>, "plain records only");
+    if (count > capacity_) {
+      ptk_host_free(data_);
+      data_ = nullptr;
+      capacity_ = 0;
+      void* p = nullptr;
+      if (ptk_host_alloc(count * sizeof(T_), &p) != PTK_OK)
+        throw std::runtime_error(std::string("pico_tree backend: ptk_host_alloc: ") + ptk_last_error());
+      data_ = static_cast<T_*>(p);
+      capacity_ = count;
+    }
+    size_ = count;
+  }
+  T_* data() { return data_; }
+  T_ const* data() const { return data_; }
+  std::size_t size() const { return size_; }
+  T_& operator[](std::size_t i) { return data_[i]; }
+  T_ const& operator[](std::size_t i) const { return data_[i]; }
+  T_* begin() { return data_; }
+  T_* end() { return data_ + size_; }
+
+ private:
+  T_* data_ = nullptr;
+  std::size_t size_ = 0, capacity_ = 0;
+};
+
+}  // namespace pico_tree
+
+namespace pico_tree::internal {
+
 //! PTK_METRIC_* of a metric type the backend knows; -1 otherwise.
 template <typename Metric_>
 inline constexpr int ptk_metric_v = std::is_same_v<Metric_, metric_l2_squared> ? PTK_METRIC_L2_SQUARED

@@ -269,6 +269,13 @@ int ptk_search_box_fill_device(const ptk_tree* tree, const float* d_mins,
 
 void ptk_free(void* p);
 
+/* Page-locked host memory for query and result arrays of the host-buffer entry points.  ptk_search_knn copies to
+ * and from such arrays directly (no staging through the handle's pinned rings, no first touch of fresh pages per
+ * call): a binding that returns a new result array per call -- as _pyco_tree does, def_kd_tree.cpp:73-82 -- keeps a
+ * pool of these blocks and hands them out again (pico_tree_amd.KdTree does).  Usable from every device of the node. */
+int ptk_host_alloc(uint64_t bytes, void** out);
+void ptk_host_free(void* p);
+
 /* ---- double precision ---------------------------------------------------- */
 /* The reference's kd_tree is generic over the scalar type and its Python module
  * builds KdTree objects over float64 arrays too (dispatch on the array dtype:

@@ -109,6 +109,8 @@ _SIGNATURES = {
     "ptk_search_box_count_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
     "ptk_search_box_fill_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
     "ptk_free": (None, [c_void_p]),
+    "ptk_host_alloc": (c_int, [c_uint64, POINTER(c_void_p)]),
+    "ptk_host_free": (None, [c_void_p]),
     "ptk_tree64_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_int32, POINTER(c_void_p)]),
     "ptk_tree64_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
                                               POINTER(c_void_p)]),
@@ -193,6 +195,93 @@ def warmup(device: int = -1) -> None:
     """Starts loading the library's device code for ``device`` (default: the current one) in the background, so that
     the first :class:`KdTree` for it does not wait for the load (``ptk_warmup``).  Optional."""
     _check(_load().ptk_warmup(int(device)))
+
+
+class _PinnedBlock:
+    """One block of page-locked host memory out of :class:`_PinnedPool`; numpy arrays made from it keep it alive
+    (``__array_interface__``), and the block goes back to the pool when the last of them is gone."""
+
+    def __init__(self, pool, ptr: int, capacity: int, nbytes: int):
+        self._pool, self._ptr, self._capacity = pool, ptr, capacity
+        self.__array_interface__ = {"data": (ptr, False), "shape": (nbytes,), "typestr": "|u1", "version": 3}
+
+    def __del__(self):
+        pool, self._pool = self._pool, None
+        if pool is not None:
+            pool._give(self._ptr, self._capacity)
+
+
+class _PinnedPool:
+    """Result arrays of the host-buffer searches.  The reference's module returns a NEW array from every
+    ``search_knn(pts, k)`` (def_kd_tree.cpp:73-82); a fresh 58 MB numpy array costs its first touch on every call
+    (2-19 ms on the hosts of the GPU pool, profiles/r03_notes.txt item 24) and a staging copy on the way.  Here the
+    rows land in page-locked blocks (``ptk_host_alloc``) that the device writes directly and that are handed out again
+    once the array built on them has been garbage-collected.  ``PTK_PINNED_POOL_MB`` (default 4096) bounds what the
+    pool holds, in use and free; beyond it -- or for small results -- plain numpy arrays are returned."""
+
+    MIN_BYTES = 1 << 20
+
+    def __init__(self):
+        import threading
+        self._lock = threading.Lock()
+        self._free = {}   # capacity -> [ptr, ...]
+        self._held = 0    # bytes allocated (in use + free)
+
+    def _budget(self) -> int:
+        return int(os.environ.get("PTK_PINNED_POOL_MB", "4096")) << 20
+
+    def empty(self, shape, dtype) -> np.ndarray:
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape, dtype=np.int64)) * dtype.itemsize
+        if nbytes < self.MIN_BYTES:
+            return np.empty(shape, dtype=dtype)
+        capacity = (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1)
+        ptr = None
+        with self._lock:
+            stock = self._free.get(capacity)
+            if stock:
+                ptr = stock.pop()
+            elif self._held + capacity <= self._budget():
+                self._held += capacity
+                ptr = 0  # allocate outside the lock
+        if ptr is None:
+            return np.empty(shape, dtype=dtype)
+        if ptr == 0:
+            out = c_void_p()
+            if _load().ptk_host_alloc(capacity, byref(out)) != PTK_OK or not out.value:
+                with self._lock:
+                    self._held -= capacity
+                return np.empty(shape, dtype=dtype)
+            ptr = out.value
+        block = _PinnedBlock(self, ptr, capacity, nbytes)
+        return np.asarray(block).view(dtype).reshape(shape)
+
+    def _give(self, ptr: int, capacity: int) -> None:
+        try:
+            with self._lock:
+                self._free.setdefault(capacity, []).append(ptr)
+        except Exception:  # (interpreter shutdown)
+            pass
+
+    def trim(self) -> None:
+        """Frees the blocks that are not in use."""
+        with self._lock:
+            free, self._free = self._free, {}
+        lib = _load()
+        for capacity, stock in free.items():
+            for ptr in stock:
+                lib.ptk_host_free(ptr)
+                with self._lock:
+                    self._held -= capacity
+
+
+_pinned_pool = _PinnedPool()
+
+
+def empty_pinned(shape, dtype=np.float32) -> np.ndarray:
+    """An uninitialised numpy array in page-locked host memory (``ptk_host_alloc``): query arrays kept in one are
+    uploaded without staging.  Small arrays (< 1 MiB) are ordinary numpy arrays."""
+    return _pinned_pool.empty(shape, dtype)
 
 
 class Metric(enum.Enum):
@@ -547,7 +636,8 @@ class KdTree:
         shape = (nq,) if k == 1 else ((nq, k) if pts.flags.c_contiguous else (k, nq))
         NB = self._neighbor
         if nns is None:
-            nns = np.zeros(shape, dtype=NB) if self._f64 else np.empty(shape, dtype=NB)
+            # (float64 records carry 4 bytes of padding, zeroed; float32 rows land in a page-locked block of the pool)
+            nns = np.zeros(shape, dtype=NB) if self._f64 else _pinned_pool.empty(shape, NB)
         elif not isinstance(nns, np.ndarray) or nns.dtype != NB:
             raise ValueError("unexpected dtype_neighbor for data")
         elif nns.size != nq * k or not nns.flags.c_contiguous:

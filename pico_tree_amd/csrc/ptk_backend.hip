@@ -2066,24 +2066,48 @@ static int grow_device_block(char** p, size_t* capacity, size_t bytes) {
   return PTK_OK;
 }
 
-// Grow-only ring of pinned host pieces (the old contents are dropped).
-static int grow_pinned_ring(char* (&ring)[HostIo::kRing], size_t* capacity, size_t bytes) {
-  if (bytes <= *capacity) return PTK_OK;
-  for (char*& p : ring) {
-    if (p) (void)hipHostFree(p);
-    p = nullptr;
-  }
-  *capacity = 0;
-  const size_t want = (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1);
-  for (char*& p : ring) {
-    if (hipHostMalloc((void**)&p, want, hipHostMallocDefault) != hipSuccess) {
-      (void)hipGetLastError();
+// Grow-only ring of pinned host pieces (the old contents are dropped): the first `slots` entries, `bytes` each.
+static int grow_pinned_ring(char* (&ring)[HostIo::kRing], size_t* capacity, size_t bytes, int slots) {
+  bool have = bytes <= *capacity;
+  for (int i = 0; i < slots && have; ++i) have = ring[i] != nullptr;
+  if (have) return PTK_OK;
+  const size_t want = std::max(*capacity, (bytes + (size_t(1) << 20)) & ~((size_t(1) << 20) - 1));
+  if (want > *capacity) {  // (slots of another size are of no use)
+    for (char*& p : ring) {
+      if (p) (void)hipHostFree(p);
       p = nullptr;
+    }
+    *capacity = 0;
+  }
+  for (int i = 0; i < slots; ++i) {
+    if (ring[i] != nullptr) continue;
+    if (hipHostMalloc((void**)&ring[i], want, hipHostMallocDefault) != hipSuccess) {
+      (void)hipGetLastError();
+      ring[i] = nullptr;
       return fail(PTK_ERR_NOMEM, "out of pinned host memory (%zu bytes)", want);
     }
   }
   *capacity = want;
   return PTK_OK;
+}
+
+// Is [p, p + bytes) page-locked host memory the runtime knows (ptk_host_alloc, hipHostMalloc, hipHostRegister)?  Copies
+// to and from such memory need no staging.
+static bool is_pinned_host(const void* p, size_t bytes) {
+  hipPointerAttribute_t a{};
+  if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  if (a.type != hipMemoryTypeHost) return false;
+  if (bytes > 1) {
+    hipPointerAttribute_t z{};
+    if (hipPointerGetAttributes(&z, static_cast<const char*>(p) + bytes - 1) != hipSuccess || z.type != hipMemoryTypeHost) {
+      (void)hipGetLastError();
+      return false;
+    }
+  }
+  return true;
 }
 
 // The pieces a host-buffer batch goes through in: first rows of every piece (and nq at the end).
@@ -2115,7 +2139,17 @@ static std::vector<uint64_t> host_pieces(uint64_t nq, uint32_t k, bool two_phase
   return first;
 }
 
+static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, float e, ptk_neighbor* out);
 int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, float e, ptk_neighbor* out) {
+  try {  // (containers and threads of the pipeline may throw: nothing leaves through the C boundary)
+    return search_knn_host(t, q, nq, k, e, out);
+  } catch (const std::bad_alloc&) {
+    return fail(PTK_ERR_NOMEM, "out of host memory in the host-buffer search");
+  } catch (const std::exception& ex) {
+    return fail(PTK_ERR_DEVICE, "host-buffer search failed: %s", ex.what());
+  }
+}
+static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, float e, ptk_neighbor* out) {
   int rc = check_search(t, q, nq);
   if (rc != PTK_OK) return rc;
   if (k == 0) return fail(PTK_ERR_INVALID, "k must be >= 1");
@@ -2144,8 +2178,13 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
   }
   rc = grow_device_block(&io.d_in, &io.in_capacity, (size_t)nq * row_in);
   if (rc == PTK_OK) rc = grow_device_block(&io.d_out, &io.out_capacity, (size_t)nq * row_out);
+  if (rc != PTK_OK) return rc;
   const int n_search_streams = env_int("PTK_HOST_STREAMS", 2);
-  if (rc == PTK_OK) rc = grow_pinned_ring(io.h_in, &io.h_in_capacity, (size_t)piece * row_in);
+  // Arrays that are page-locked already (ptk_host_alloc: what the Python wrapper returns its rows in) are copied to
+  // and from directly; pageable ones go through the handle's pinned rings.
+  const bool in_pinned = env_int("PTK_HOST_DIRECT", 1) != 0 && is_pinned_host(q, (size_t)nq * row_in);
+  const bool out_pinned = env_int("PTK_HOST_DIRECT", 1) != 0 && is_pinned_host(out, (size_t)nq * row_out);
+  if (!in_pinned) rc = grow_pinned_ring(io.h_in, &io.h_in_capacity, (size_t)piece * row_in, (int)std::min<uint64_t>(pieces, HostIo::kRing));
   // The rows of a piece come down in chunks of at most 32 MB, each copied into the caller's array while the next
   // is on the link (a piece of knn = 16 rows is 300 MB: one copy per piece left the host copy exposed).
   const uint64_t out_chunk = std::max<uint64_t>(std::min<uint64_t>(piece, (size_t(32) << 20) / row_out), 1);
@@ -2156,7 +2195,22 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
   for (uint64_t pi = 0; pi < pieces; ++pi)
     for (uint64_t lo = first[pi]; lo < first[pi + 1]; lo += out_chunk)
       chunks.push_back(Chunk{pi, lo, std::min(out_chunk, first[pi + 1] - lo)});
-  if (rc == PTK_OK) rc = grow_pinned_ring(io.h_out, &io.h_out_capacity, (size_t)out_chunk * row_out);
+  if (rc == PTK_OK && !out_pinned)
+    rc = grow_pinned_ring(io.h_out, &io.h_out_capacity, (size_t)out_chunk * row_out,
+                          (int)std::min<uint64_t>(chunks.size(), HostIo::kRing));
+  if (rc == PTK_ERR_NOMEM) {
+    // No pinned memory to be had: the batch goes through piece by piece with plain (pageable) copies -- slower, not a failure.
+    for (uint64_t i = 0; i < pieces; ++i) {
+      const uint64_t lo = first[i], n = first[i + 1] - lo;
+      PTK_HIP(hipMemcpy(io.d_in + lo * row_in, reinterpret_cast<const char*>(q) + lo * row_in, (size_t)n * row_in, hipMemcpyHostToDevice));
+      rc = ptk_search_knn_device(t, reinterpret_cast<float*>(io.d_in) + lo * t->dim, n, k, e,
+                                 reinterpret_cast<ptk_neighbor*>(io.d_out) + lo * k, io.search[0]);
+      if (rc != PTK_OK) return rc;
+      PTK_HIP(hipStreamSynchronize(io.search[0]));
+      PTK_HIP(hipMemcpy(reinterpret_cast<char*>(out) + lo * row_out, io.d_out + lo * row_out, (size_t)n * row_out, hipMemcpyDeviceToHost));
+    }
+    return PTK_OK;
+  }
   if (rc != PTK_OK) return rc;
   if (io.pool == nullptr) {
     const unsigned hc = std::thread::hardware_concurrency();
@@ -2228,8 +2282,8 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
       if (can_enqueue) {
         const Chunk& ch = chunks[e_];
         const int slot = (int)(e_ % HostIo::kRing);
-        hipError_t he = hipMemcpyAsync(io.h_out[slot], io.d_out + ch.lo * row_out, (size_t)ch.n * row_out,
-                                       hipMemcpyDeviceToHost, io.down);
+        hipError_t he = hipMemcpyAsync(out_pinned ? dst + ch.lo * row_out : io.h_out[slot], io.d_out + ch.lo * row_out,
+                                       (size_t)ch.n * row_out, hipMemcpyDeviceToHost, io.down);
         if (he == hipSuccess) he = hipEventRecord(io.down_done[slot], io.down);
         if (he != hipSuccess) return bail(he);
         stamp("down: D2H enqueued", e_);
@@ -2242,31 +2296,49 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
       const hipError_t he = hipEventSynchronize(io.down_done[slot]);
       if (he != hipSuccess) return bail(he);
       stamp("down: copy out", c_);
-      io.pool->copy(dst + ch.lo * row_out, io.h_out[slot], (size_t)ch.n * row_out);
+      if (!out_pinned) io.pool->copy(dst + ch.lo * row_out, io.h_out[slot], (size_t)ch.n * row_out);
       stamp("down: copied", c_);
       ++c_;
     }
   });
 
+  // (whatever throws from here on: the download thread is told to stop and joined before the frame goes)
+  struct Joiner {
+    std::thread& th;
+    std::mutex& m;
+    std::condition_variable& cv;
+    bool& failed;
+    ~Joiner() {
+      if (!th.joinable()) return;
+      {
+        std::lock_guard<std::mutex> l(m);
+        failed = true;
+      }
+      cv.notify_all();
+      th.join();
+    }
+  } joiner{downloader, m, cv, failed};
   hipError_t he = hipSuccess;
   // The copy of piece i + 1 into its ring slot runs on the pool while piece i is issued.
   auto start_copy_in = [&](uint64_t i) {
     const uint64_t lo = first[i], n = first[i + 1] - lo;
+    if (in_pinned) return std::shared_ptr<CopyPool::Job>();
     return io.pool->start(io.h_in[i % HostIo::kRing], src + lo * row_in, (size_t)n * row_in);
   };
   std::shared_ptr<CopyPool::Job> copy_in = start_copy_in(0);
   for (uint64_t i = 0; i < pieces && he == hipSuccess && rc == PTK_OK; ++i) {
     const uint64_t lo = first[i], n = first[i + 1] - lo;
     const int slot = (int)(i % HostIo::kRing);
-    io.pool->finish(copy_in);
+    if (copy_in) io.pool->finish(copy_in);
     stamp("up: copied", i);
-    if (i + 1 < pieces) {
+    if (i + 1 < pieces && !in_pinned) {
       // (slot of piece i + 1: its last upload, of piece i + 1 - kRing, must have left it)
       if (i + 1 >= (uint64_t)HostIo::kRing) he = hipEventSynchronize(io.up_done[(i + 1) % HostIo::kRing]);
       if (he != hipSuccess) break;
       copy_in = start_copy_in(i + 1);
     }
-    he = hipMemcpyAsync(io.d_in + lo * row_in, io.h_in[slot], (size_t)n * row_in, hipMemcpyHostToDevice, io.up);
+    he = hipMemcpyAsync(io.d_in + lo * row_in, in_pinned ? src + lo * row_in : io.h_in[slot], (size_t)n * row_in,
+                        hipMemcpyHostToDevice, io.up);
     if (he == hipSuccess) he = hipEventRecord(io.up_done[slot], io.up);
     hipStream_t ss = io.search[n_search_streams > 1 ? (i & 1) : 0];  // consecutive pieces on two streams: the tail of one overlaps the next
     if (he == hipSuccess) he = hipStreamWaitEvent(ss, io.up_done[slot], 0);
@@ -2283,7 +2355,7 @@ int ptk_search_knn(const ptk_tree* t, const float* q, uint64_t nq, uint32_t k, f
     }
     cv.notify_all();
   }
-  io.pool->finish(copy_in);  // (a piece copied ahead when the loop was left early: the caller's array is still being read)
+  if (copy_in) io.pool->finish(copy_in);  // (a piece copied ahead when the loop was left early: the caller's array is still being read)
   {
     std::lock_guard<std::mutex> l(m);
     if (he != hipSuccess || rc != PTK_OK) failed = true;
@@ -2804,6 +2876,22 @@ int ptk_search_box(const ptk_tree* t, const float* mins, const float* maxs, uint
 }
 
 void ptk_free(void* p) { std::free(p); }
+
+int ptk_host_alloc(uint64_t bytes, void** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (bytes == 0) return PTK_OK;
+  if (hipHostMalloc(out, (size_t)bytes, hipHostMallocPortable) != hipSuccess) {
+    (void)hipGetLastError();
+    *out = nullptr;
+    return fail(PTK_ERR_NOMEM, "out of pinned host memory (%llu bytes)", (unsigned long long)bytes);
+  }
+  return PTK_OK;
+}
+
+void ptk_host_free(void* p) {
+  if (p != nullptr && hipHostFree(p) != hipSuccess) (void)hipGetLastError();
+}
 
 int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
   if (t == nullptr || counts == nullptr) return fail(PTK_ERR_INVALID, "null argument");

@@ -764,6 +764,45 @@ def test_batches_that_arrive_coherent_are_not_sorted_again(gpu, cloud):
     assert tree.batch_order() == 1 and got.tobytes() == ref.search_knn(batch, 1)[:, 0].tobytes()
 
 
+def test_rows_in_page_locked_blocks_of_the_pool(gpu):
+    """search_knn(pts, k) returns a NEW array per call like the reference's module (def_kd_tree.cpp:73-82); here it is
+    built on a page-locked block (ptk_host_alloc) the device writes directly, and the block is handed out again once
+    the array is gone.  Rows equal the oracle whichever way the arrays are held: pooled rows, a pageable array of
+    the caller, queries in page-locked memory too, no pinned memory at all (PTK_HOST_DIRECT=0)."""
+    import gc
+    import os
+
+    pts, q = _clouds("lidar", 200_000, 300_000)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    ref = oracle.Oracle(pts, 10, "port")
+    ref.set_threads(ref.max_threads())
+    want1, want4 = ref.search_knn(q, 1)[:, 0], ref.search_knn(q, 4)
+    a = tree.search_knn(q, 1)
+    addr_a = a.__array_interface__["data"][0]
+    b = tree.search_knn(q, 1)
+    assert a.tobytes() == want1.tobytes() and b.tobytes() == want1.tobytes()
+    assert addr_a != b.__array_interface__["data"][0]           # two arrays alive: two blocks
+    view = a[1000:2000]
+    del a
+    gc.collect()
+    c = tree.search_knn(q, 1)                                    # (the view keeps its block: not handed out again)
+    assert c.__array_interface__["data"][0] != addr_a and view.tobytes() == want1[1000:2000].tobytes()
+    del view, c
+    gc.collect()
+    d = tree.search_knn(q, 1)                                    # a freed block comes back
+    assert d.tobytes() == want1.tobytes()
+    own = np.empty((len(q), 4), dtype=pt.NEIGHBOR)
+    assert tree.search_knn(q, 4, own) is own and own.tobytes() == want4.tobytes()
+    qp = pt.empty_pinned(q.shape, q.dtype)
+    qp[...] = q
+    assert tree.search_knn(qp, 4).tobytes() == want4.tobytes()
+    os.environ["PTK_HOST_DIRECT"] = "0"
+    try:
+        assert tree.search_knn(qp, 1).tobytes() == want1.tobytes()
+    finally:
+        del os.environ["PTK_HOST_DIRECT"]
+
+
 def test_config1_through_the_device_matches_the_committed_hashes(gpu):
     """BASELINE configs[0] (100 k / 100 k uniform, knn = 1, leaf 10): the reference's own CPU-runnable case, through
     the HIP path, against tests/golden/hashes.json (SHA-256 of the compiled reference's indices and distance bits)."""
