@@ -5,14 +5,20 @@
 //! functions of include/ptk.h.  A non-zero status becomes a std::runtime_error
 //! carrying ptk_last_error().  There is deliberately NO host fallback here: if
 //! the backend cannot be used (library built without a device, no gfx950 GPU)
-//! the batched calls throw.
+//! the batched calls throw.  (One case is served on the host: a call the device
+//! search REFUSES for a valid tree, PTK_ERR_UNSUPPORTED -- see ptk_unsupported.)
 
+#include <algorithm>
+#include <atomic>
 #include <cstdint>
+#include <cstdio>
+#include <exception>
 #include <memory>
 #include <mutex>
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <type_traits>
 #include <vector>
 
@@ -26,11 +32,65 @@
 
 namespace pico_tree::internal {
 
+//! The device search cannot take this tree or batch (PTK_ERR_UNSUPPORTED: a topological tree deeper than the device
+//! stack, a dimension beyond the LDS staging).  The batched members catch it and serve the call the way the
+//! reference does -- a loop of the per-query host members over the rows (_pyco_tree/kd_tree.hpp:128) -- with one
+//! warning per process.  Every other failure (no device, HIP error, out of memory) stays an error: a missing or
+//! broken backend is never papered over.
+struct ptk_unsupported : std::runtime_error {
+  using std::runtime_error::runtime_error;
+};
+
 inline void ptk_check(int status, char const* what) {
+  if (status == PTK_ERR_UNSUPPORTED) {
+    throw ptk_unsupported(std::string("pico_tree backend: ") + what + ": " + ptk_last_error());
+  }
   if (status != PTK_OK) {
     throw std::runtime_error(
         std::string("pico_tree backend: ") + what + ": " + ptk_last_error());
   }
+}
+
+inline void warn_host_loop(char const* why) {
+  static std::once_flag once;
+  std::call_once(once, [why] {
+    std::fprintf(
+        stderr,
+        "pico_tree: the device search refused this call (%s); it runs as a loop of the per-query host members "
+        "instead (further refusals are served the same way without this message)\n",
+        why);
+  });
+}
+
+//! fn(i) for every row i in [0, n), rows handed out in chunks of 128 (the reference's schedule(dynamic, 128)).
+template <typename Fn_>
+inline void host_rows_loop(std::size_t n, Fn_ fn) {
+  constexpr std::size_t chunk = 128;
+  unsigned workers = std::thread::hardware_concurrency();
+  workers = workers == 0 ? 1u : workers;
+  workers = static_cast<unsigned>(std::min<std::size_t>(workers, (n + chunk - 1) / chunk));
+  std::atomic<std::size_t> next{0};
+  std::exception_ptr failure;
+  std::mutex failure_mutex;
+  auto work = [&] {
+    try {
+      for (;;) {
+        std::size_t const lo = next.fetch_add(chunk);
+        if (lo >= n) break;
+        std::size_t const hi = std::min(n, lo + chunk);
+        for (std::size_t i = lo; i < hi; ++i) fn(i);
+      }
+    } catch (...) {
+      std::lock_guard<std::mutex> lock(failure_mutex);
+      if (!failure) failure = std::current_exception();
+      next.store(n);
+    }
+  };
+  std::vector<std::thread> pool;
+  for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+  work();
+  for (auto& t : pool) t.join();
+  if (failure) std::rethrow_exception(failure);
 }
 
 }  // namespace pico_tree::internal

@@ -283,11 +283,20 @@ class kd_tree {
     check_query_dim(q.cols());
     offsets.assign(q.rows() + 1, 0);
     typename api::neighbor* rows = nullptr;
-    internal::ptk_check(
-        api::radius(
-            device(), q.data(), q.rows(), radius, scalar_type(1), sort ? 1 : 0,
-            offsets.data(), &rows),
-        "ptk_search_radius");
+    try {
+      internal::ptk_check(
+          api::radius(
+              device(), q.data(), q.rows(), radius, scalar_type(1), sort ? 1 : 0,
+              offsets.data(), &rows),
+          "ptk_search_radius");
+    } catch (internal::ptk_unsupported const& refused) {
+      std::vector<std::vector<neighbor_type>> per_row;
+      host_radius(q, radius, scalar_type(1), per_row, sort, refused.what());
+      for (size_type i = 0; i < q.rows(); ++i) offsets[i + 1] = offsets[i] + per_row[i].size();
+      flat.resize(offsets.back());
+      for (size_type i = 0; i < q.rows(); ++i) std::copy(per_row[i].begin(), per_row[i].end(), flat.data() + offsets[i]);
+      return;
+    }
     library_rows keep(rows);  // freed even if the copy below throws
     flat.resize(offsets.back());
     auto const* src = reinterpret_cast<neighbor_type const*>(rows);
@@ -309,8 +318,21 @@ class kd_tree {
     if (lo.rows() != hi.rows()) throw std::invalid_argument("query min and max don't have equal size");
     offsets.assign(lo.rows() + 1, 0);
     std::int32_t* rows = nullptr;
-    internal::ptk_check(
-        api::box(device(), lo.data(), hi.data(), lo.rows(), offsets.data(), &rows), "ptk_search_box");
+    try {
+      internal::ptk_check(
+          api::box(device(), lo.data(), hi.data(), lo.rows(), offsets.data(), &rows), "ptk_search_box");
+    } catch (internal::ptk_unsupported const& refused) {
+      internal::warn_host_loop(refused.what());
+      std::vector<std::vector<index_type>> per_row(lo.rows());
+      space_view_type s = view();
+      internal::host_rows_loop(lo.rows(), [&](size_type i) {
+        internal::box_search(tree_, s, lo.data() + i * lo.cols(), hi.data() + i * hi.cols(), per_row[i]);
+      });
+      for (size_type i = 0; i < lo.rows(); ++i) offsets[i + 1] = offsets[i] + per_row[i].size();
+      flat.resize(offsets.back());
+      for (size_type i = 0; i < lo.rows(); ++i) std::copy(per_row[i].begin(), per_row[i].end(), flat.data() + offsets[i]);
+      return;
+    }
     library_rows keep(rows);
     flat.assign(rows, rows + offsets.back());
   }
@@ -400,11 +422,55 @@ class kd_tree {
     static_assert(sizeof(neighbor_type) == sizeof(typename api::neighbor), "neighbor layout");
     internal::dense_rows<internal::unwrap_ref_t<QuerySpace_>> q(unwrap(queries));
     check_query_dim(q.cols());
-    internal::ptk_check(
-        api::knn(
-            device(), q.data(), q.rows(), static_cast<std::uint32_t>(k), e,
-            reinterpret_cast<typename api::neighbor*>(out)),
-        "ptk_search_knn");
+    try {
+      internal::ptk_check(
+          api::knn(
+              device(), q.data(), q.rows(), static_cast<std::uint32_t>(k), e,
+              reinterpret_cast<typename api::neighbor*>(out)),
+          "ptk_search_knn");
+    } catch (internal::ptk_unsupported const& refused) {
+      // The reference's loop (_pyco_tree/kd_tree.hpp:128-134): row i into out[i * k .. i * k + k).
+      internal::warn_host_loop(refused.what());
+      using row_point = point_map<scalar_type const, dim>;
+      internal::host_rows_loop(q.rows(), [&](size_type i) {
+        row_point x = make_row(q.data() + i * q.cols(), q.cols());
+        if (e == scalar_type(1)) {
+          search_knn(x, out + i * k, out + (i + 1) * k);
+        } else {
+          search_knn(x, e, out + i * k, out + (i + 1) * k);
+        }
+      });
+    }
+  }
+
+  //! Row i of a dense query matrix as a point.
+  static point_map<scalar_type const, dim> make_row(scalar_type const* p, size_type sdim) {
+    if constexpr (dim == dynamic_extent) {
+      return point_map<scalar_type const, dim>(p, sdim);
+    } else {
+      (void)sdim;
+      return point_map<scalar_type const, dim>(p);
+    }
+  }
+
+  template <typename Rows_>
+  void host_radius(
+      Rows_ const& q,
+      scalar_type radius,
+      scalar_type e,
+      std::vector<std::vector<neighbor_type>>& out,
+      bool sort,
+      char const* why) const {
+    internal::warn_host_loop(why);
+    out.resize(q.rows());
+    internal::host_rows_loop(q.rows(), [&](size_type i) {
+      auto x = make_row(q.data() + i * q.cols(), q.cols());
+      if (e == scalar_type(1)) {
+        search_radius(x, radius, out[i], sort);
+      } else {
+        search_radius(x, radius, e, out[i], sort);
+      }
+    });
   }
 
   template <typename QuerySpace_>
@@ -419,10 +485,15 @@ class kd_tree {
     check_query_dim(q.cols());
     std::vector<std::uint64_t> offsets(q.rows() + 1, 0);
     typename api::neighbor* rows = nullptr;
-    internal::ptk_check(
-        api::radius(
-            device(), q.data(), q.rows(), radius, e, sort ? 1 : 0, offsets.data(), &rows),
-        "ptk_search_radius");
+    try {
+      internal::ptk_check(
+          api::radius(
+              device(), q.data(), q.rows(), radius, e, sort ? 1 : 0, offsets.data(), &rows),
+          "ptk_search_radius");
+    } catch (internal::ptk_unsupported const& refused) {
+      host_radius(q, radius, e, out, sort, refused.what());
+      return;
+    }
     library_rows keep(rows);
     out.resize(q.rows());
     auto const* src = reinterpret_cast<neighbor_type const*>(rows);

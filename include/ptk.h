@@ -269,6 +269,22 @@ int ptk_search_box_fill_device(const ptk_tree* tree, const float* d_mins,
 
 void ptk_free(void* p);
 
+/* ---- the host loop for calls the device search refuses ------------------- */
+/* A device search may answer PTK_ERR_UNSUPPORTED for a valid tree (a topological tree deeper than the
+ * device stack, a dimension beyond the LDS staging of the kernels).  The reference answers every call with a loop
+ * of per-query searches over the rows (_pyco_tree/kd_tree.hpp:117-135, :179-200, :245-268); these entry points ARE
+ * that loop, on the handle's flat tree and the caller's points (n_points x dim, as given at creation: a handle keeps
+ * them on the device only), threads taking 128 rows at a time.  Same rows, same order, same bits as the device
+ * search would give.  They are never entered by ptk_search_* themselves -- a missing device or a HIP error stays an
+ * error; a wrapper calls them by name after PTK_ERR_UNSUPPORTED, with a warning (pico_tree_amd.KdTree does; the C++
+ * batched members loop their own per-query members).  float32 handles. */
+int ptk_host_search_knn(const ptk_tree* tree, const float* points, const float* queries, uint64_t nq, uint32_t k,
+                        float e, ptk_neighbor* out);
+int ptk_host_search_radius(const ptk_tree* tree, const float* points, const float* queries, uint64_t nq, float radius,
+                           float e, int sort, uint64_t* offsets, ptk_neighbor** out); /* *out: ptk_free */
+int ptk_host_search_box(const ptk_tree* tree, const float* points, const float* mins, const float* maxs, uint64_t nb,
+                        uint64_t* offsets, int32_t** out);                            /* *out: ptk_free */
+
 /* Page-locked host memory for query and result arrays of the host-buffer entry points.  ptk_search_knn copies to
  * and from such arrays directly (no staging through the handle's pinned rings, no first touch of fresh pages per
  * call): a binding that returns a new result array per call -- as _pyco_tree does, def_kd_tree.cpp:73-82 -- keeps a

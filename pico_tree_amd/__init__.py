@@ -109,6 +109,10 @@ _SIGNATURES = {
     "ptk_search_box_count_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p]),
     "ptk_search_box_fill_device": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, c_void_p, c_void_p]),
     "ptk_free": (None, [c_void_p]),
+    "ptk_host_search_knn": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_uint32, c_float, c_void_p]),
+    "ptk_host_search_radius": (c_int, [c_void_p, c_void_p, c_void_p, c_uint64, c_float, c_float, c_int,
+                                       c_void_p, POINTER(c_void_p)]),
+    "ptk_host_search_box": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, POINTER(c_void_p)]),
     "ptk_host_alloc": (c_int, [c_uint64, POINTER(c_void_p)]),
     "ptk_host_free": (None, [c_void_p]),
     "ptk_tree64_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_int32, POINTER(c_void_p)]),
@@ -180,6 +184,21 @@ def _load():
             fn.argtypes = argtypes
         _lib = lib
     return _lib
+
+
+PTK_ERR_UNSUPPORTED = -2
+_host_loop_warned = False
+
+
+def _warn_host_loop(why: str) -> None:
+    """One warning per process when a call the device search refuses is served by the host loop instead."""
+    global _host_loop_warned
+    if not _host_loop_warned:
+        _host_loop_warned = True
+        import warnings
+        warnings.warn("pico_tree_amd: the device search refused this call (" + why + "); it runs as a loop of "
+                      "per-query host searches over the rows instead, as the reference's module does for every call "
+                      "(further refusals are served the same way without this message)", RuntimeWarning, stacklevel=4)
 
 
 def _check(status: int) -> None:
@@ -651,11 +670,25 @@ class KdTree:
             # Column-major callers get the transposed (k, npts) layout of the reference
             # (kd_tree.hpp:362-378): row i of the search is column i of the output.
             tmp = np.empty((nq, k), dtype=NB)
-            _check(search(self._h, q.ctypes.data, nq, k, self._real(e), tmp.ctypes.data))
+            self._served(search(self._h, q.ctypes.data, nq, k, self._real(e), tmp.ctypes.data),
+                         lambda lib: lib.ptk_host_search_knn(self._h, self._pts.ctypes.data, q.ctypes.data, nq, k,
+                                                             np.float32(e), tmp.ctypes.data))
             nns.reshape(-1)[:] = tmp.reshape(-1)
             return nns
-        _check(search(self._h, q.ctypes.data, nq, k, self._real(e), nns.ctypes.data))
+        self._served(search(self._h, q.ctypes.data, nq, k, self._real(e), nns.ctypes.data),
+                     lambda lib: lib.ptk_host_search_knn(self._h, self._pts.ctypes.data, q.ctypes.data, nq, k,
+                                                         np.float32(e), nns.ctypes.data))
         return nns
+
+    def _served(self, status: int, host_loop) -> None:
+        """``_check``, except that a search the DEVICE refuses for a valid tree (PTK_ERR_UNSUPPORTED) is served by the
+        host loop of the library (``ptk_host_search_*``: the reference's own batch loop) with one warning.  Nothing
+        else is: a missing device or a HIP error raises."""
+        if status == PTK_ERR_UNSUPPORTED and not self._f64:
+            lib = _load()
+            _warn_host_loop(lib.ptk_last_error().decode("utf-8", "replace"))
+            status = host_loop(lib)
+        _check(status)
 
     def _search_knn_device(self, q, k, e, out):
         import torch
@@ -688,9 +721,11 @@ class KdTree:
         offsets = np.zeros(nq + 1, dtype=np.uint64)
         rows = c_void_p()
         lib = _load()
-        _check(self._fn("ptk_search_radius")(self._h, q.ctypes.data, nq, self._real(radius),
-                                             self._real(e), int(bool(sort)), offsets.ctypes.data,
-                                             byref(rows)))
+        self._served(self._fn("ptk_search_radius")(self._h, q.ctypes.data, nq, self._real(radius),
+                                                   self._real(e), int(bool(sort)), offsets.ctypes.data, byref(rows)),
+                     lambda lib: lib.ptk_host_search_radius(self._h, self._pts.ctypes.data, q.ctypes.data, nq,
+                                                            np.float32(radius), np.float32(e), int(bool(sort)),
+                                                            offsets.ctypes.data, byref(rows)))
         flat = _adopt(lib, rows, int(offsets[-1]), self._neighbor)
         if nns is None:
             return DArray(offsets, flat)
@@ -715,8 +750,10 @@ class KdTree:
         offsets = np.zeros(nb + 1, dtype=np.uint64)
         rows = c_void_p()
         lib = _load()
-        _check(self._fn("ptk_search_box")(self._h, mins.ctypes.data, maxs.ctypes.data, nb, offsets.ctypes.data,
-                                          byref(rows)))
+        self._served(self._fn("ptk_search_box")(self._h, mins.ctypes.data, maxs.ctypes.data, nb, offsets.ctypes.data,
+                                                byref(rows)),
+                     lambda lib: lib.ptk_host_search_box(self._h, self._pts.ctypes.data, mins.ctypes.data,
+                                                         maxs.ctypes.data, nb, offsets.ctypes.data, byref(rows)))
         flat = _adopt(lib, rows, int(offsets[-1]), np.int32)
         if nns is None:
             return DArray(offsets, flat)

@@ -17,26 +17,16 @@ ROOT = os.path.dirname(_HERE)
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(CSRC, "libptk.so")
 SOURCES = [os.path.join(CSRC, "ptk_backend.hip")]
-HEADERS = [
-    os.path.join(CSRC, "ptk_kernels.hpp"),
-    os.path.join(CSRC, "ptk_build.hpp"),
-    os.path.join(CSRC, "ptk_sort.hpp"),
-    os.path.join(CSRC, "ptk_hostio.hpp"),
-    os.path.join(CSRC, "ptk_kernels_nd.hpp"),
-    os.path.join(CSRC, "ptk_kernels_topo.hpp"),
-    os.path.join(CSRC, "ptk_kernels_f64.hpp"),
-    os.path.join(CSRC, "ptk_backend_f64.hpp"),
-    os.path.join(CSRC, "ptk_forest.hpp"),
-    os.path.join(CSRC, "ptk_forest_host.hpp"),
-    os.path.join(CSRC, "ptk_multi.hpp"),
-    os.path.join(CSRC, "ptk_encode.hpp"),
-    os.path.join(ROOT, "include", "ptk.h"),
-    os.path.join(ROOT, "include", "pico_tree", "internal", "flat_tree.hpp"),
-    os.path.join(ROOT, "include", "pico_tree", "internal", "stream.hpp"),
-    os.path.join(ROOT, "include", "pico_tree", "internal", "access.hpp"),
-    os.path.join(ROOT, "include", "pico_tree", "map.hpp"),
-    os.path.join(ROOT, "include", "pico_tree", "traits.hpp"),
-]
+def _headers():
+    """Everything the translation unit may include: the kernels and host helpers next to it, the C ABI and the
+    header-only host API (the builder, the stream format and the per-query searches are compiled into the library)."""
+    found = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith(".hpp")]
+    for base, _, files in os.walk(os.path.join(ROOT, "include")):
+        found += [os.path.join(base, f) for f in sorted(files) if f.endswith((".h", ".hpp"))]
+    return found
+
+
+HEADERS = _headers()
 
 #: -ffp-contract=off: the results contract forbids fused multiply-add
 #: (SURVEY.md 8c: contraction changes distance bits).

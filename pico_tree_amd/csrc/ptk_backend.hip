@@ -3150,6 +3150,7 @@ int ptk_forest_search_knn(const ptk_forest* f, const float* q, uint64_t nq, uint
 
 }  // extern "C"
 
+#include "ptk_host_loop.hpp"
 #include "ptk_multi.hpp"
 
 // ---- double precision (ptk_tree64_* / ptk_search64_*) -------------------------------------

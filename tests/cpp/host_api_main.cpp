@@ -376,6 +376,29 @@ static int run_batch(std::string const& dir) {
     write_raw(dir + "/d_box_off.bin", boff.data(), boff.size());
     write_raw(dir + "/d_box_flat.bin", bflat.data(), bflat.size());
   }
+  {  // a call the device search refuses (a topological tree some 3000 levels deep: coincident angles, leaf size 1) is
+     // served as a loop of the per-query members -- the reference's own loop -- not thrown back at the caller
+    std::vector<std::array<float, 1>> ring(4000);
+    for (size_t i = 0; i < ring.size(); ++i) ring[i][0] = i < 3000 ? 0.25f : static_cast<float>(i % 997) / 997.0f;
+    auto so2 = pico_tree::make_kd_tree<pico_tree::metric_so2>(std::cref(ring), pico_tree::max_leaf_size_t(1));
+    std::vector<std::array<float, 1>> rq(300);
+    for (size_t i = 0; i < rq.size(); ++i) rq[i][0] = static_cast<float>(i) / 300.0f;
+    std::vector<neighbor> got(rq.size() * 3);
+    so2.search_knn(rq, 3, got.data());
+    std::vector<std::uint64_t> off;
+    std::vector<neighbor> flat;
+    so2.search_radius(rq, 0.001f, off, flat, false);
+    for (size_t i = 0; i < rq.size(); ++i) {
+      std::vector<neighbor> one;
+      so2.search_knn(rq[i], 3, one);
+      for (int j = 0; j < 3; ++j)
+        if (one[j].index != got[i * 3 + j].index || one[j].distance != got[i * 3 + j].distance) return 43;
+      so2.search_radius(rq[i], 0.001f, one);
+      if (one.size() != off[i + 1] - off[i]) return 44;
+      for (size_t j = 0; j < one.size(); ++j)
+        if (one[j].index != flat[off[i] + j].index || one[j].distance != flat[off[i] + j].distance) return 45;
+    }
+  }
   // wrong dimension must throw, not crash
   try {
     std::vector<std::array<float, 2>> bad(4);

@@ -285,3 +285,40 @@ def test_topological_tree_stream_is_the_reference_stream(tmp_path, metric, dim):
         assert np.array_equal(a, b)
     plain = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=pt.PTK_DEVICE_NONE)
     assert len(plain._serialize()) < len(stream)  # two bounds per branch fewer
+
+
+@pytest.mark.parametrize("metric", ["L2Squared", "L1", "LPInf"])
+def test_host_loop_entry_points_equal_the_oracle(metric):
+    """ptk_host_search_* (what the wrappers call when a DEVICE search answers PTK_ERR_UNSUPPORTED): the reference's
+    batch loop over the handle's flat tree.  Runs without a device -- and is the only search that does: ptk_search_*
+    of the same handle still fail loudly (test_host_only_handle_and_loud_failures)."""
+    pts = ds.uniform_cloud(6000, 3, seed=5)
+    q = ds.uniform_cloud(700, 3, seed=6)
+    tree = pt.KdTree(pts, pt.Metric[metric], 7, device=pt.PTK_DEVICE_NONE)
+    ref = oracle.Oracle(pts, 7, "port", metric)
+    lib = pt._load()
+    for k, e in ((1, 1.0), (5, 1.0), (9, 1.7)):
+        out = np.empty((len(q), k), dtype=pt.NEIGHBOR)
+        assert lib.ptk_host_search_knn(tree._h, pts.ctypes.data, q.ctypes.data, len(q), k, np.float32(e),
+                                       out.ctypes.data) == 0
+        assert out.tobytes() == ref.search_knn(q, k, e=None if e == 1.0 else e).tobytes()
+    radius = np.float32(0.004 if metric == "L2Squared" else 0.06)
+    for e, sort in ((1.0, 0), (2.0, 0)):
+        offsets = np.zeros(len(q) + 1, dtype=np.uint64)
+        rows = ctypes.c_void_p()
+        assert lib.ptk_host_search_radius(tree._h, pts.ctypes.data, q.ctypes.data, len(q), radius, np.float32(e), sort,
+                                          offsets.ctypes.data, ctypes.byref(rows)) == 0
+        flat = np.ctypeslib.as_array(ctypes.cast(rows, ctypes.POINTER(ctypes.c_uint8)),
+                                     shape=(int(offsets[-1]) * 8,)).copy().view(pt.NEIGHBOR)
+        lib.ptk_free(rows)
+        off, want = ref.search_radius(q, radius, e=None if e == 1.0 else e)
+        assert np.array_equal(offsets, off) and flat.tobytes() == want.tobytes() and off[-1] > 0
+    lo, hi = np.ascontiguousarray(q - np.float32(0.03)), np.ascontiguousarray(q + np.float32(0.03))
+    offsets = np.zeros(len(q) + 1, dtype=np.uint64)
+    rows = ctypes.c_void_p()
+    assert lib.ptk_host_search_box(tree._h, pts.ctypes.data, lo.ctypes.data, hi.ctypes.data, len(q),
+                                   offsets.ctypes.data, ctypes.byref(rows)) == 0
+    flat = np.ctypeslib.as_array(ctypes.cast(rows, ctypes.POINTER(ctypes.c_int32)), shape=(int(offsets[-1]),)).copy()
+    lib.ptk_free(rows)
+    boff, bflat = ref.search_box(lo, hi)
+    assert np.array_equal(offsets, boff) and np.array_equal(flat, bflat)

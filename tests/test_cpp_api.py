@@ -31,7 +31,7 @@ K, RADIUS = 7, np.float32(0.0009)
 
 
 def _compile(out, host_only):
-    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-I" + INC, SRC, "-o", out]
+    cmd = ["g++", "-std=c++17", "-O2", "-ffp-contract=off", "-Wall", "-pthread", "-I" + INC, SRC, "-o", out]
     if host_only:
         cmd.insert(1, "-DPTK_TEST_HOST_ONLY")
     else:

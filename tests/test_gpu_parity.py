@@ -803,6 +803,33 @@ def test_rows_in_page_locked_blocks_of_the_pool(gpu):
         del os.environ["PTK_HOST_DIRECT"]
 
 
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
+def test_a_call_the_device_refuses_is_served_by_the_host_loop(gpu):
+    """A topological tree some 3000 levels deep (coincident angles, leaf size 1) is beyond the device stack of the
+    topological kernels: ptk_search_* answer PTK_ERR_UNSUPPORTED, and the wrapper serves the call with the library's
+    host loop (ptk_host_search_*: the reference's own batch loop) after ONE warning -- rows equal the reference's
+    kd_tree<space, metric_so2>.  The C entry points themselves still refuse: nothing falls back silently."""
+    import warnings
+
+    ring = np.empty((4000, 1), dtype=np.float32)
+    ring[:3000, 0] = 0.25
+    ring[3000:, 0] = (np.arange(1000) % 997) / np.float32(997.0)
+    q = (np.arange(300, dtype=np.float32) / np.float32(300.0)).reshape(-1, 1)
+    tree = pt.KdTree(ring, pt.Metric.SO2, 1, device=gpu)
+    ref = oracle.Oracle(ring, 1, "reference", "SO2")
+    out = np.empty((len(q), 3), dtype=pt.NEIGHBOR)
+    assert pt._load().ptk_search_knn(tree._h, q.ctypes.data, len(q), 3, np.float32(1.0), out.ctypes.data) == -2
+    pt._host_loop_warned = False
+    with pytest.warns(RuntimeWarning, match="device search refused"):
+        got = tree.search_knn(q, 3)
+    assert got.tobytes() == ref.search_knn(q, 3).tobytes()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")  # (no second warning)
+        rows = tree.search_radius(q, 0.001)
+    off, flat = ref.search_radius(q, 0.001)
+    assert np.array_equal(rows.offsets, off) and rows.flat.tobytes() == flat.tobytes()
+
+
 def test_config1_through_the_device_matches_the_committed_hashes(gpu):
     """BASELINE configs[0] (100 k / 100 k uniform, knn = 1, leaf 10): the reference's own CPU-runnable case, through
     the HIP path, against tests/golden/hashes.json (SHA-256 of the compiled reference's indices and distance bits)."""
