@@ -45,7 +45,12 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 #: The k = 1 traversal is phase 1, the capped phase 2 and the cooperative search of what the cap left
 #: (+ the usually empty redo pass); the algorithmic bytes cover all of them.
+# The traversal kernels of the k = 1 search, by the prefixes of their names in a rocprofv3 kernel trace, and those
+# names as `rocprofv3 --kernel-trace --stats` prints them for the default launch (profiles/r04*_stats.txt).
 TRAVERSAL_KERNELS = ("ptk::knn1_phase1", "ptk::knn1_phase2", "ptk::knn1_coop", "ptk::knn1_redo")
+TRAVERSAL_KERNEL_NAMES = ("ptk::knn1_phase1u_kernel<4>", "ptk::knn1_phase2_kernel<12, 64, 4>",
+                          "ptk::knn1_coop_kernel<32, 96, true>", "ptk::knn1_coop_kernel<16, 96, false>",
+                          "ptk::knn1_redo_kernel<16, 64, 4>")
 
 
 def log(*a):
@@ -330,7 +335,7 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     b = 12 + 8 * k + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
     kernel_ms = prof["search_ms"] / max(int(prof["launches"]), 1)
     r = roofline_of(b, nq, kernel_ms)
-    r["kernel"] = "ptk::knn_reg_kernel<16>"
+    r["kernel"] = "ptk::knn_reg_kernel<16, 16, 64, 64, 5, ptk::MetricL2>"
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
     res["knn16"] = {"value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms, 4), "steps": steps,
                     "parity_sample_ok": bool(got.tobytes() == want.tobytes()), "roofline": r}
@@ -359,7 +364,7 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     b = 12 + 8 * (hits / nq) + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
     kernel_ms = prof["search_ms"] / steps
     r = roofline_of(b, nq, kernel_ms)
-    r["kernel"] = "ptk::radius_capture_kernel + ptk::radius_log_scatter_kernel"
+    r["kernel"] = "ptk::radius_capture_kernel<16, 64, 64, 5, ptk::MetricL2> + ptk::radius_log_scatter_kernel<1>"
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
     res["radius"] = {"radius_squared": radius, "value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s",
                      "ms_per_step": round(ms, 4), "steps": steps, "hits_per_query": round(hits / nq, 2),
@@ -657,9 +662,10 @@ def main():
                     "frac": round(achieved / HBM_PEAK_GBS, 5),
                     "traffic": None if traffic is None else round(traffic / 1e9, 3),
                     "traffic_unit": "GB per launch (2 x FETCH_SIZE + WRITE_SIZE, rocprofv3 --pmc)",
-                    "traffic_source": traffic_src,
+                    "traffic_static": True,  # counters cannot be read inside the process: per-launch figure of the
+                    "traffic_source": traffic_src,  # committed rocprofv3 --pmc passes of this same command (that file)
                     "algorithmic_gb_per_launch": round(b_per_q * q_per_launch / 1e9, 3),
-                    "kernel": "+".join(TRAVERSAL_KERNELS) if k == 1 else "ptk::knn_kernel",
+                    "kernel": " + ".join(TRAVERSAL_KERNEL_NAMES) if k == 1 else "ptk::knn_reg_kernel / ptk::knn_kernel",
                     "kernel_ms": round(kernel_ms, 4), "reorder_ms": round(prof["reorder_ms"] / launches, 4),
                     "other_ms": round(prof["other_ms"] / launches, 4),
                     "bytes_per_query": round(b_per_q, 1), "queries_per_launch": int(q_per_launch),

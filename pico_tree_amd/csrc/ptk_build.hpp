@@ -153,6 +153,100 @@ __global__ __launch_bounds__(256) void build_swap_kernel(
   idx[r] = t;
 }
 
+// ---- the sliding step (std::nth_element) ---------------------------------------------------------------------------
+// When a partition leaves one side empty the reference slides the plane to the nearest point with std::nth_element
+// (internal/kd_tree_builder.hpp:255-275), and the permutation that call leaves is part of the tree.  libstdc++'s
+// nth_element is an introselect (bits/stl_algo.h:1964-1986): rounds of "median of three to the front, Hoare partition
+// of the rest around it, keep the side that holds nth" until at most three elements are left.  The first rounds --
+// the ones that touch a million indices -- are made here; the partition of a round is, like std::partition above,
+// a pairing by rank:
+//
+//   __unguarded_partition(first + 1, last, pivot = first) moves a left pointer up to the next element that is NOT
+//   below the pivot and a right pointer down to the next that is NOT above it, swaps the two and goes on, until the
+//   pointers meet; until then both pointers only see elements nobody has moved yet.  So the k-th "left stop"
+//   (positions with !(v < pivot), ascending) is swapped with the k-th "right stop" (positions with !(pivot < v),
+//   descending) for every k below K = the first k whose left stop is not left of its right stop; the function returns
+//   where the left pointer stands at the end (slide_pair_kernel).
+//
+// flags (both kinds, packed in one 64-bit word), one scan, the two rank lists, the pairs; the host reads the cut and
+// decides which side is kept, exactly as __introselect does.  Once the range is small the host finishes the SAME
+// call -- std::__introselect on what is left, with what is left of its depth limit -- so the outcome is libstdc++'s
+// to the last swap (tests/test_device_build.py: byte-identical trees on clouds whose planes slide).
+__global__ void slide_pivot_kernel(const float* __restrict__ pts, uint32_t dim, uint32_t axis, int32_t* __restrict__ idx,
+                                   uint32_t first, uint32_t last, float* __restrict__ pivot) {
+  // __move_median_to_first(result = first, a = first + 1, b = mid, c = last - 1)
+  const uint32_t a = first + 1u, b = first + (last - first) / 2u, c = last - 1u;
+  auto val = [&](uint32_t i) { return pts[(uint64_t)(uint32_t)idx[i] * dim + axis]; };
+  const float va = val(a), vb = val(b), vc = val(c);
+  uint32_t pick;
+  if (va < vb) {
+    if (vb < vc) pick = b;
+    else if (va < vc) pick = c;
+    else pick = a;
+  } else if (va < vc) {
+    pick = a;
+  } else if (vb < vc) {
+    pick = c;
+  } else {
+    pick = b;
+  }
+  const int32_t t = idx[first];
+  idx[first] = idx[pick];
+  idx[pick] = t;
+  *pivot = val(first);
+}
+
+// flags[i - lo] = {left stop, right stop << 32} for the positions [lo, hi); flags[hi - lo] = 0 (the scan's total).
+__global__ __launch_bounds__(256) void slide_flag_kernel(const float* __restrict__ pts, uint32_t dim, uint32_t axis,
+                                                         const int32_t* __restrict__ idx, uint32_t lo, uint32_t hi,
+                                                         const float* __restrict__ pivot,
+                                                         unsigned long long* __restrict__ flags) {
+  const uint32_t i = lo + blockIdx.x * 256u + threadIdx.x;
+  if (i > hi) return;
+  unsigned long long f = 0ull;
+  if (i < hi) {
+    const float v = pts[(uint64_t)(uint32_t)idx[i] * dim + axis], p = *pivot;
+    f = (!(v < p) ? 1ull : 0ull) | (!(p < v) ? 1ull << 32 : 0ull);
+  }
+  flags[i - lo] = f;
+}
+
+// left_list[k] = position of the k-th left stop (ascending), right_list[k] = position of the k-th right stop (descending).
+__global__ __launch_bounds__(256) void slide_list_kernel(const unsigned long long* __restrict__ flags,
+                                                         const unsigned long long* __restrict__ sums, uint32_t lo,
+                                                         uint32_t hi, uint32_t* __restrict__ left_list,
+                                                         uint32_t* __restrict__ right_list) {
+  const uint32_t i = lo + blockIdx.x * 256u + threadIdx.x;
+  if (i >= hi) return;
+  const unsigned long long f = flags[i - lo], before = sums[i - lo], total = sums[hi - lo];
+  if (f & 0xFFFFFFFFull) left_list[(uint32_t)before] = i;
+  if (f >> 32) right_list[(uint32_t)(total >> 32) - (uint32_t)(before >> 32) - 1u] = i;
+}
+
+// The pairs below K are swapped (K = the first k whose left stop is missing or not left of its right stop).  What
+// the function returns is where the left pointer stands then: it has moved on from left stop K - 1 to the next element
+// that is not below the pivot -- left stop K, unless it first meets the element it swapped into right stop K - 1:
+// *cut = min(left stop K, right stop K - 1)   (K = 0: left stop 0, which a median-of-three pivot guarantees).
+__global__ __launch_bounds__(256) void slide_pair_kernel(int32_t* __restrict__ idx, const unsigned long long* __restrict__ sums,
+                                                         uint32_t n_range, const uint32_t* __restrict__ left_list,
+                                                         const uint32_t* __restrict__ right_list, uint32_t* __restrict__ cut) {
+  const unsigned long long total = sums[n_range];
+  const uint32_t n_left = (uint32_t)total, n_right = (uint32_t)(total >> 32);
+  const uint32_t pairs = n_left < n_right ? n_left : n_right;
+  const uint32_t k = blockIdx.x * 256u + threadIdx.x;
+  if (k > pairs) return;
+  const bool active = k < pairs && left_list[k] < right_list[k];
+  if (active) {
+    const uint32_t l = left_list[k], r = right_list[k];
+    const int32_t t = idx[l];
+    idx[l] = idx[r];
+    idx[r] = t;
+  } else if (k == 0u || left_list[k - 1u] < right_list[k - 1u]) {  // k = K
+    const uint32_t l_k = k < n_left ? left_list[k] : 0xFFFFFFFFu;
+    *cut = k == 0u ? l_k : (l_k < right_list[k - 1u] ? l_k : right_list[k - 1u]);
+  }
+}
+
 // Device buffers of one build (freed on every path).
 struct BuildBuffers {
   float* pts = nullptr;
@@ -161,9 +255,14 @@ struct BuildBuffers {
   BuildSeg* segs = nullptr;
   float* partial = nullptr;
   void* scan_tmp = nullptr;
+  // the sliding step (allocated on the first slide)
+  unsigned long long *flags64 = nullptr, *sums64 = nullptr;
+  void* scan_tmp64 = nullptr;
+  size_t scan_bytes64 = 0;
+  float* pivot = nullptr;  // {pivot value, cut (as uint32)}
   ~BuildBuffers() {
     for (void* p : {(void*)pts, (void*)idx, (void*)flags, (void*)sums, (void*)from_left, (void*)from_right, (void*)segs,
-                    (void*)partial, scan_tmp})
+                    (void*)partial, scan_tmp, (void*)flags64, (void*)sums64, scan_tmp64, (void*)pivot})
       if (p != nullptr) (void)hipFree(p);
   }
 };
@@ -272,11 +371,62 @@ bool device_top_build(const float* points, uint64_t n, uint32_t dim, size_t max_
       std::chrono::steady_clock::time_point t0;
       ~on_exit() { sum += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); }
     } timer{slide_ms, t_in};
+    const uint32_t axis = seg.axis;
+    // The rounds of libstdc++'s introselect while the range is large (see slide_pivot_kernel): on the device.
+    constexpr size_t kHostBelow = 32768;
+    if (seg.end - seg.begin > kHostBelow && std::getenv("PTK_DEVICE_SLIDE_OFF") == nullptr) {
+      size_t first = seg.begin, last = seg.end;
+      const size_t nth_pos = seg.begin + nth;
+      long depth_limit = 2 * (long)std::__lg((long)(last - first));
+      if (b.flags64 == nullptr) {
+        if (!ok(rocprim::exclusive_scan(nullptr, b.scan_bytes64, b.flags64, b.sums64, 0ull, (size_t)n + 1,
+                                        rocprim::plus<unsigned long long>(), (hipStream_t) nullptr)) ||
+            !ok(hipMalloc((void**)&b.flags64, (n + 1) * 8)) || !ok(hipMalloc((void**)&b.sums64, (n + 1) * 8)) ||
+            !ok(hipMalloc(&b.scan_tmp64, b.scan_bytes64 + 256)) || !ok(hipMalloc((void**)&b.pivot, 16)))
+          return false;
+      }
+      uint32_t* d_cut = reinterpret_cast<uint32_t*>(b.pivot) + 1;
+      while (last - first > kHostBelow && depth_limit > 0) {
+        --depth_limit;
+        const uint32_t lo = (uint32_t)first + 1u, hi = (uint32_t)last, n_range = hi - lo;
+        const uint32_t none = 0xFFFFFFFFu;
+        if (!ok(hipMemcpyAsync(d_cut, &none, 4, hipMemcpyHostToDevice, nullptr))) return false;
+        hipLaunchKernelGGL(slide_pivot_kernel, dim3(1), dim3(1), 0, nullptr, b.pts, dim, axis, b.idx, (uint32_t)first,
+                           (uint32_t)last, b.pivot);
+        hipLaunchKernelGGL(slide_flag_kernel, dim3(n_range / 256u + 1u), dim3(256), 0, nullptr, b.pts, dim, axis, b.idx, lo,
+                           hi, b.pivot, b.flags64);
+        size_t bytes = b.scan_bytes64 + 256;
+        if (!ok(rocprim::exclusive_scan(b.scan_tmp64, bytes, b.flags64, b.sums64, 0ull, (size_t)n_range + 1,
+                                        rocprim::plus<unsigned long long>(), (hipStream_t) nullptr)))
+          return false;
+        hipLaunchKernelGGL(slide_list_kernel, dim3(n_range / 256u + 1u), dim3(256), 0, nullptr, b.flags64, b.sums64, lo, hi,
+                           b.from_left, b.from_right);
+        hipLaunchKernelGGL(slide_pair_kernel, dim3((n_range + 1u) / 256u + 1u), dim3(256), 0, nullptr, b.idx, b.sums64,
+                           n_range, b.from_left, b.from_right, d_cut);
+        if (!ok(hipGetLastError())) return false;
+        uint32_t cut = none;
+        if (!ok(hipMemcpy(&cut, d_cut, 4, hipMemcpyDeviceToHost))) return false;
+        if (cut == none || cut < lo || cut > hi) {
+          reason = "the partition of a sliding step found no cut";
+          return false;
+        }
+        if (cut <= nth_pos) first = cut;
+        else last = cut;
+      }
+      // What is left of the same call, on the host: the range that still holds nth, the depth limit that is left.
+      const size_t count = last - first;
+      slid.resize(count);
+      if (!ok(hipMemcpy(slid.data(), b.idx + first, count * 4, hipMemcpyDeviceToHost))) return false;
+      auto below = [&](int x, int y) { return points[(size_t)x * dim + axis] < points[(size_t)y * dim + axis]; };
+      std::__introselect(slid.begin(), slid.begin() + (nth_pos - first), slid.end(), depth_limit,
+                         __gnu_cxx::__ops::__iter_comp_iter(below));
+      seg.plane = points[(size_t)slid[nth_pos - first] * dim + axis];
+      return ok(hipMemcpy(b.idx + first, slid.data(), count * 4, hipMemcpyHostToDevice));
+    }
     const size_t count = seg.end - seg.begin;
     slid.resize(count);
     keyed.resize(count);
     if (!ok(hipMemcpy(slid.data(), b.idx + seg.begin, count * 4, hipMemcpyDeviceToHost))) return false;
-    const uint32_t axis = seg.axis;
     auto fill = [&](size_t lo, size_t hi) {
       for (size_t i = lo; i < hi; ++i) keyed[i] = std::make_pair(points[(size_t)slid[i] * dim + axis], slid[i]);
     };

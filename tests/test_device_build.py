@@ -42,15 +42,28 @@ def test_device_built_tree_is_the_host_built_tree(gpu, monkeypatch, threads):
             assert dev.search_knn(q, 4).tobytes() == host.search_knn(q, 4).tobytes(), name
 
 
-def test_planes_that_slide_in_the_top_levels(gpu, monkeypatch):
+@pytest.mark.parametrize("case", ["far-max", "far-min", "far-max-quantised", "far-min-duplicates"])
+def test_planes_that_slide_in_the_top_levels(gpu, monkeypatch, case):
     """Most of the root box empty along its longest side: the first partitions leave one side empty and the builder
-    slides the plane (std::nth_element): those ranges make a round trip to the host, the tree is the same."""
-    pts = ds.uniform_cloud(400_000, 3, 21)
+    slides the plane (std::nth_element).  The first rounds of libstdc++'s introselect run on the device (the Hoare
+    partitions of ptk_build.hpp: pairing of left and right stops by rank), the rest of the same call on the host:
+    the permutation -- and with it the tree -- must be the host's to the last index.  Far point beyond the maximum
+    (nth = last - 1: the ranges shrink from the left) and below the minimum (nth = first + 1: from the right);
+    coordinates on a grid (thousands of elements EQUAL to the pivot: both kinds of stop at once) and exact duplicates."""
+    pts = ds.uniform_cloud(1_500_000, 3, 21)
     pts[:, 0] *= np.float32(0.2)
-    pts[0, 0] = np.float32(50.0)  # one far point: the box is long in x, everything else sits in its first fifth
+    if "quantised" in case:
+        pts[:, 0] = np.round(pts[:, 0] / np.float32(0.002)) * np.float32(0.002)
+    if "duplicates" in case:
+        pts[1::5] = pts[::5][: len(pts[1::5])]
+    pts[0, 0] = np.float32(50.0) if "max" in case else np.float32(-50.0)  # the box is long in x, the cloud at one end
     monkeypatch.setenv("PTK_DEVICE_BUILD", "0")
     host = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
     monkeypatch.setenv("PTK_DEVICE_BUILD", "1")
     dev = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
     for x, y in zip(host.flat(), dev.flat()):
+        assert np.asarray(x).tobytes() == np.asarray(y).tobytes()
+    monkeypatch.setenv("PTK_DEVICE_SLIDE_OFF", "1")  # (the round trip to the host for the whole range: the same tree)
+    dev2 = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    for x, y in zip(host.flat(), dev2.flat()):
         assert np.asarray(x).tobytes() == np.asarray(y).tobytes()
