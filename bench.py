@@ -339,7 +339,7 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
     res["knn16"] = {"value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms, 4), "steps": steps,
                     "parity_sample_ok": bool(got.tobytes() == want.tobytes()), "roofline": r}
-    # ---- radius: count pass that captures the rows + scan + copy
+    # ---- radius: count pass that lists the leaves with hits + scan + fill pass that replays the lists
     radius, steps = 1.0, 3
     off, raw = tree.search_radius_device(dq, radius)
     torch.cuda.synchronize()
@@ -364,7 +364,7 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     b = 12 + 8 * (hits / nq) + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
     kernel_ms = prof["search_ms"] / steps
     r = roofline_of(b, nq, kernel_ms)
-    r["kernel"] = "ptk::radius_capture_kernel<16, 64, 64, 5, ptk::MetricL2> + ptk::radius_log_scatter_kernel<1>"
+    r["kernel"] = "ptk::radius_list_kernel<16, 64, 5, ptk::MetricL2> + ptk::radius_replay_kernel<8, 32, ptk::MetricL2>"
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
     res["radius"] = {"radius_squared": radius, "value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s",
                      "ms_per_step": round(ms, 4), "steps": steps, "hits_per_query": round(hits / nq, 2),

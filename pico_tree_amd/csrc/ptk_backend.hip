@@ -32,6 +32,7 @@
 #include "ptk_hostio.hpp"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#include "ptk_kernels_lists.hpp"
 // Geometry of the launches (measured optima, profiles/r02_notes.txt item 23, r03_notes.txt item 13):
 constexpr int kP2Ring = 12;   // LDS ring of the capped phase 2 (records per lane; 8 / 10 / 16: 1.335 / 1.329 / 1.308 vs 1.224 ms)
 constexpr int kGenRing = 16;  // LDS ring of the general searches (k > 1, radius)
@@ -125,6 +126,7 @@ struct Workspace {
   char* cap_base = nullptr;
   size_t cap_capacity = 0;
   bool cap_valid = false;
+  bool cap_lists = false;  // the capture holds leaf lists (ptk_kernels_lists.hpp), not a log of hits
   ptk::RadiusCapture cap{};
   const float* cap_q = nullptr;
   uint64_t cap_nq = 0;
@@ -1074,7 +1076,7 @@ int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   Timer timer(t, s);
   if (!fill) {
     hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, false, M>), dim3(blocks), dim3(BLOCK), smem, s,
-                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out);
+                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out, n_dev);
   } else {
     hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK), smem, s,
                        t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out, n_dev);
@@ -1099,6 +1101,39 @@ int launch_radius_capture(const ptk_tree* t, const float* d_q, const uint32_t* p
   return PTK_OK;
 }
 
+// The radius search of a 3-D tree with the rows made from leaf lists (ptk_kernels_lists.hpp): the count pass ...
+template <int S, int OVF, int LEAFB, class M = ptk::MetricL2>
+int launch_radius_list(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
+                       uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
+  const size_t smem = (size_t)S * 64 * 8 + ptk::kListLds;  // + the group buffers and the chunk table of the wavefront
+  Timer timer(t, s);
+  PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
+  hipLaunchKernelGGL((ptk::radius_list_kernel<S, OVF, LEAFB, M>), dim3(cap.n_static), dim3(64), smem, s, t->dev, d_q,
+                     t->dim, perm, nq, radius, inv_ratio(e), d_counts, cap);
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, nq);
+  return PTK_OK;
+}
+
+// ... and the fill pass.  n_over is zeroed here; the queries of wavefronts whose lists were lost are listed for
+// radius_kernel<FILL>.
+// Hits fetched together / entries a lane can hold back: (5, 16) 4.72 ms, (4, 16) 4.73, (5, 32) 4.49, (8, 32) 4.38 on
+// BASELINE config 3 -- fewer, larger rounds win although the ring of 32 halves the wavefronts per CU.
+constexpr int kReplayHits = 8, kReplayRing = 32;
+template <class M = ptk::MetricL2>
+int launch_radius_replay(const ptk_tree* t, const float* d_q, float e, const ptk::RadiusCapture& cap,
+                         const uint64_t* d_offsets, ptk::Neighbor* d_out, uint32_t* over_list, uint32_t* n_over,
+                         hipStream_t s) {
+  Timer timer(t, s);
+  PTK_HIP(hipMemsetAsync(n_over, 0, 4, s));
+  hipLaunchKernelGGL((ptk::radius_replay_kernel<kReplayHits, kReplayRing, M>), dim3(cap.n_static), dim3(64),
+                     ptk::replay_lds(kReplayRing), s, t->dev, d_q, t->dim, inv_ratio(e), cap, d_offsets, d_out, over_list,
+                     n_over);
+  PTK_HIP(hipGetLastError());
+  timer.stop(0, 0);
+  return PTK_OK;
+}
+
 // PTK_RADIUS_CAPTURE_MB: the most device memory the captured rows of a radius batch may take
 // (default 16384; 0 switches the capture off and every fill pass repeats the traversal).
 size_t capture_budget_bytes(const ptk_tree* t) {
@@ -1119,7 +1154,9 @@ bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
   const size_t chunk_bytes = (size_t)ptk::kLogChunk * sizeof(ptk::Neighbor);
   const size_t flags_at = (size_t)ptk::kCapSubPools * ptk::kCapCounterStride * 4;
   const size_t qids_at = flags_at + ((waves + 255) & ~(size_t)255);
-  const size_t head = (qids_at + waves * 64 * 4 + 4095) & ~(size_t)4095;
+  const size_t lens_at = qids_at + waves * 64 * 4;
+  const size_t tables_at = lens_at + waves * 64 * 4;
+  const size_t head = (tables_at + waves * ptk::kListMaxChunks * 4 + 4095) & ~(size_t)4095;
   if (head + waves * chunk_bytes > budget) return false;
   const size_t dyn = std::min<size_t>((budget - head - waves * chunk_bytes) / chunk_bytes, waves * 64 * 2);
   const int forced = env_int("PTK_RADIUS_CAPTURE_CHUNKS", -1);
@@ -1147,6 +1184,8 @@ bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
   ws.cap.counters = reinterpret_cast<uint32_t*>(ws.cap_base);
   ws.cap.captured = reinterpret_cast<uint8_t*>(ws.cap_base + flags_at);
   ws.cap.qids = reinterpret_cast<uint32_t*>(ws.cap_base + qids_at);
+  ws.cap.lens = reinterpret_cast<uint32_t*>(ws.cap_base + lens_at);
+  ws.cap.tables = reinterpret_cast<uint32_t*>(ws.cap_base + tables_at);
   ws.cap.chunks = reinterpret_cast<ptk::Neighbor*>(ws.cap_base + head);
   ws.cap.n_static = (uint32_t)waves;
   ws.cap.sub_cap = (uint32_t)sub_cap;
@@ -2400,7 +2439,11 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     uint32_t* over_list = scratch.take<uint32_t>(nq);
     uint32_t* n_over = scratch.take<uint32_t>(1);
     if (over_list == nullptr || n_over == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
-    {
+    if (ws.cap_lists) {  // (3-D trees: the rows are made from the leaf lists of the count pass)
+      PTK_WITH_METRIC((rc = launch_radius_replay<M>(t, d_q, e, ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
+                                                    over_list, n_over, s)));
+      if (rc != PTK_OK) return rc;
+    } else {
       Timer timer(t, s);
       PTK_HIP(hipMemsetAsync(n_over, 0, 4, s));
       constexpr int W = 1;  // (one wavefront per block: the LDS of a CU divides evenly)
@@ -2487,6 +2530,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     timer.stop(0, fill ? 0 : nq);
   } else {
     const bool capture = !fill && prepare_capture(t, nq, ws);
+    const bool lists = capture && !nd && env_int("PTK_RADIUS_LISTS", 1) != 0;
     if (!fill) ws.cap_valid = false;
     rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
     if (rc != PTK_OK) return rc;
@@ -2498,12 +2542,16 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     if (capture) {
       if (nd) {
         PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd_capture<OVF, M>(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s))));
+      } else if (lists) {  // the count pass lists the leaves with hits for the fill pass
+        PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_radius_list<kGenRing, OVF, kGenLeafB, M>(t, d_q, perm, nq, radius, e, d_counts,
+                                                                                ws.cap, s))));
       } else {
         PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_radius_capture<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, radius, e, d_counts,
                                                                                    ws.cap, s))));
       }
       if (rc == PTK_OK) {
         ws.cap_valid = true;
+        ws.cap_lists = lists;
         ws.cap_q = d_q;
         ws.cap_nq = nq;
         ws.cap_radius = radius;

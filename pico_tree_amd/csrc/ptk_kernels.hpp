@@ -492,6 +492,9 @@ struct RadiusCapture {
   uint32_t* qids;       // [n_static * 64] the query each lane of each wavefront searched (kLogEnd: none)
   uint32_t n_static;    // wavefronts of the launch
   uint32_t sub_cap;     // chunks per sub-pool
+  // The capture as LEAF LISTS (ptk_kernels_lists.hpp): the chunks then hold list entries, [slot][lane].
+  uint32_t* lens;       // [n_static * 64] entries listed by each lane
+  uint32_t* tables;     // [n_static * kListMaxChunks] the chunks of each wavefront, in order
 };
 
 constexpr int kRadiusCount = 0, kRadiusFill = 1, kRadiusCapture = 2;
@@ -527,6 +530,13 @@ template <class P, class = void>
 struct takes_rounds : std::false_type {};
 template <class P>
 struct takes_rounds<P, std::void_t<decltype(P::kRoundVisit)>> : std::integral_constant<bool, P::kRoundVisit> {};
+
+// Policies that want to know where a leaf begins and ends (leaf_begin(ref, tree) before its first point, leaf_end()
+// after its last) say so with kLeafHooks.
+template <class P, class = void>
+struct takes_leaf_hooks : std::false_type {};
+template <class P>
+struct takes_leaf_hooks<P, std::void_t<decltype(P::kLeafHooks)>> : std::integral_constant<bool, P::kLeafHooks> {};
 
 template <int MODE>
 struct RadiusPolicy {  // search_visitor.hpp:127-156 / :252-288
@@ -776,6 +786,9 @@ __device__ __forceinline__ bool traverse(
       const uint32_t lv = ref & 0x7FFFFFFFu;
       const uint32_t begin = lv >> t.cbits;
       const uint32_t count = lv & t.cmask;
+      if constexpr (takes_leaf_hooks<Policy>::value) {
+        if (count != 0u) pol.leaf_begin(ref, t);
+      }
       for (uint32_t j = 0; j < count; j += LEAFB) {
         float4 p[LEAFB];
 #pragma unroll
@@ -819,6 +832,9 @@ __device__ __forceinline__ bool traverse(
             pol.visit(__float_as_int(p[u].w), point_distance3<M>(dx, dy, dz));
           }
         }
+      }
+      if constexpr (takes_leaf_hooks<Policy>::value) {
+        if (count != 0u) pol.leaf_end();
       }
     }
 
@@ -1160,7 +1176,10 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
 // Wavefronts the capture could not hold are listed, row by row, for radius_kernel<FILL>.
 constexpr int kLogUnroll = 4;
 // LDS bytes per wavefront: staged chunk, sorted chunk (+ 3 entries kept back per row), row tables, owner of each slot
-constexpr uint32_t kLogKeep = 3;  // entries a row may hold back: its runs end on boundaries of (kLogKeep + 1) x 8 bytes
+#ifndef PTK_EXP_LOG_KEEP
+#define PTK_EXP_LOG_KEEP 3
+#endif
+constexpr uint32_t kLogKeep = PTK_EXP_LOG_KEEP;  // entries a row may hold back: its runs end on boundaries of (kLogKeep + 1) x 8 bytes
 constexpr uint32_t kLogCarry = 64u * kLogKeep;  // room for them in the sorted chunk (rounded up below)
 constexpr uint32_t kLogSortedPad = (kLogCarry + 63u) & ~63u;
 constexpr uint32_t kLogScatterLds = kLogChunk * 8u * 2u + kLogSortedPad * 8u + 64u * 12u + kLogChunk + kLogSortedPad;

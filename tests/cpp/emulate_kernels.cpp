@@ -26,6 +26,7 @@ thread_local dim3 blockDim;
 #include "ptk.h"
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
+#include "ptk_kernels_lists.hpp"
 #include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
 #include "ptk_kernels_topo.hpp"
@@ -109,6 +110,7 @@ struct Emu {
   std::vector<uint32_t> cap_counters;
   std::vector<uint8_t> cap_flags;
   std::vector<uint32_t> cap_qids;
+  std::vector<uint32_t> cap_lens, cap_tables;  // the capture as leaf lists (ptk_kernels_lists.hpp)
   uint64_t cap_nq = 0;
   ptk::RadiusCapture cap{};
 };
@@ -480,6 +482,52 @@ int64_t emu_radius_fill_captured(void* h, const float* q, uint64_t nq, float rad
     }, 64);
   }
   if (sort) for_each_lane(nq, [&] { ptk::sort_rows_kernel(nq, offsets, o); });
+  return (int64_t)n_over;
+}
+
+// The radius search with the rows made from leaf lists (ptk_kernels_lists.hpp).  Count pass (fill = 0): lane by lane
+// (the lanes of a wavefront share the chunk table).  Fill pass: 64 fibers per wavefront (ballots, the ring), then the
+// ordinary fill kernel for the queries of wavefronts whose lists were lost; returns their number (or a negative status).
+int64_t emu_radius_lists(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
+                         uint32_t sub_cap, int fill, uint64_t* counts, const uint64_t* offsets, ptk_neighbor* out) {
+  auto* t = static_cast<Emu*>(h);
+  if (t->dim > 3) return -3;
+  const size_t waves = (size_t)((nq + 63) / 64);
+  const float e_inv = 1.0f / e;
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  if (!fill) {
+    t->cap_chunks.assign((waves + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kLogChunk, ptk::Neighbor{-1, -1.0f});
+    t->cap_counters.assign(ptk::kCapSubPools * ptk::kCapCounterStride, 0u);
+    t->cap_flags.assign(waves, 2);
+    t->cap_qids.assign(waves * 64, 0u);
+    t->cap_lens.assign(waves * 64, 0u);
+    t->cap_tables.assign(waves * ptk::kListMaxChunks, 0xDEADBEEFu);
+    t->cap.chunks = t->cap_chunks.data();
+    t->cap.counters = t->cap_counters.data();
+    t->cap.captured = t->cap_flags.data();
+    t->cap.qids = t->cap_qids.data();
+    t->cap.lens = t->cap_lens.data();
+    t->cap.tables = t->cap_tables.data();
+    t->cap.n_static = (uint32_t)waves;
+    t->cap.sub_cap = sub_cap;
+    t->cap_nq = nq;
+    for_each_lane(waves * 64, [&] {
+      if (t->metric == 1) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL1>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
+      else ptk::radius_list_kernel<8, 2048, 4>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
+    }, 64);
+    return 0;
+  }
+  if (t->cap_nq != nq || t->cap_lens.empty()) return -1;
+  std::vector<uint32_t> over(nq + 1, 0u);
+  uint32_t n_over = 0;
+  for_each_wave((uint32_t)waves, [&] {
+    if (t->metric == 1) ptk::radius_replay_kernel<3, 32, ptk::MetricL1>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
+    else ptk::radius_replay_kernel<5, 16>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
+  });
+  for_each_lane(nq, [&] {
+    if (t->metric == 1) ptk::radius_kernel<16, 2048, 64, 4, true, ptk::MetricL1>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o, &n_over);
+    else ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o, &n_over);
+  }, 64);
   return (int64_t)n_over;
 }
 

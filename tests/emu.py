@@ -105,6 +105,25 @@ class EmulatedTree:
         assert redone >= 0
         return off, out, int(redone)
 
+    def search_radius_lists(self, q, radius, sort=False, e=None, perm=None, sub_cap=64):
+        """The radius search with the rows made from leaf lists: the listing count pass, then the replay
+        (+ the ordinary fill kernel for wavefronts whose lists were lost)."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        nq = len(q)
+        p = perm.ctypes.data if perm is not None else None
+        counts = np.zeros(nq + 1, dtype=np.uint64)
+        fn = self.lib.emu_radius_lists
+        fn.restype = ctypes.c_int64
+        fn.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_uint32, c_int, c_void_p, c_void_p,
+                       c_void_p]
+        assert fn(self.h, q.ctypes.data, nq, radius, e or 1.0, p, sub_cap, 0, counts.ctypes.data, None, None) == 0
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(counts[:nq])
+        out = np.zeros(int(off[-1]), dtype=pt.NEIGHBOR)
+        lost = fn(self.h, q.ctypes.data, nq, radius, e or 1.0, p, sub_cap, 1, None, off.ctypes.data, out.ctypes.data)
+        assert lost >= 0
+        return off, out, int(lost)
+
     # -- persistent (state machine + lane refill) kernels: 64 host threads per wavefront --
     def search_box(self, mins, maxs):
         from ctypes import c_uint64, c_void_p
