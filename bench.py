@@ -33,6 +33,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -88,6 +89,7 @@ def parse_args():
     ap.add_argument("--no-pipelined", action="store_true", help="skip the two-streams context measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--single-process-worker", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--cpu-seconds", type=float, default=16.0,
                     help="approximate budget of the CPU baseline samples (OpenMP and single thread, two query orders)")
     ap.add_argument("--counter-sample", type=int, default=200_000,
@@ -417,17 +419,20 @@ def shard_entry(pt, oracle, pts, q, tree, leaf, parts, b_per_q_full):
             "rows": got, "roofline": roofline_of(b_per_q_full, per, kernel_ms)}
 
 
-def quantised_entry(pt, ds, oracle, pts, q, leaf, grid, device, steps, sample):
+def quantised_entry(pt, ds, oracle, pts, q, leaf, grid, device, steps, sample, shift=0.0):
     """The headline search with every coordinate of points and queries snapped to a grid (what a scan stored with a
-    few decimals looks like: exact ties between distances, coincident points)."""
+    few decimals looks like: exact ties between distances, coincident points -- at a grid of 1.0 piles of hundreds of
+    them, which the reference's builder peels apart one level per point); shift: the queries moved that part of a
+    cell off the grid along every axis, so that none of them sits on a pile."""
     import torch
 
     p2 = np.ascontiguousarray(np.round(pts / grid) * grid, dtype=np.float32)
-    q2 = np.ascontiguousarray(np.round(q / grid) * grid, dtype=np.float32)
+    q2 = np.ascontiguousarray(np.round(q / grid) * grid + np.float32(shift * grid), dtype=np.float32)
     tree = pt.KdTree(p2, pt.Metric.L2Squared, leaf, device=device)
-    e = also_entry(pt, ds, oracle, f"L, coordinates snapped to a grid of {grid}", "generated", p2, q2, tree, leaf, steps,
-                   sample)
+    what = f"L, coordinates snapped to a grid of {grid}" + (f", queries {shift} of a cell off the grid" if shift else "")
+    e = also_entry(pt, ds, oracle, what, "generated", p2, q2, tree, leaf, steps, sample)
     e["tree_depth"] = int(tree.info()["max_depth"])
+    e["piles"] = tree.piles()
     e["counts"] = tree.knn1_counts()
     return e
 
@@ -471,10 +476,73 @@ def config5_entry(pt, ds, device):
                                  "the Infinity Cache, so this is an upper bound on the HBM share"}}
 
 
+def single_process_worker(args):
+    """The other form of BASELINE configs[3]: ONE process, the tree replicated on the first
+    `--single-process-worker` devices of the node, the batch on devices[0], its ranges and their rows moved over xGMI
+    by ptk_multi_search_knn_device (grouped RCCL send / recv inside libptk).  Run as a child of rank 0 with a time
+    limit, beside the idle ranks of the main run: whatever happens here cannot take the main line with it."""
+    import torch
+
+    import oracle
+    import pico_tree_amd as pt
+    from pico_tree_amd import datasets as ds
+
+    ndev = args.single_process_worker
+    pts, q = ds.config2_clouds(args.cloud, args.n or ds.CONFIG2_N, args.nq or ds.CONFIG2_NQ)
+    multi = pt.MultiKdTree(pts, args.leaf, devices=list(range(ndev)))
+    torch.cuda.set_device(0)
+    dq = torch.from_numpy(q).cuda()
+    for _ in range(max(1, args.warmup)):
+        out = multi.search_knn(dq, args.k)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = multi.search_knn(dq, args.k)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / args.steps * 1e3
+    sample = np.linspace(0, len(q) - 1, num=4096, dtype=np.int64)
+    ref = oracle.Oracle(pts, args.leaf, "port")
+    want = ref.search_knn(q[sample], args.k)
+    ref.close()
+    got = out.numpy()[sample]
+    got = got if args.k > 1 else got[:, None]
+    print(json.dumps({"devices": ndev, "value": round(len(q) / ms / 1e3, 3), "unit": "Mqueries/s",
+                      "ms_per_step": round(ms, 4), "steps": args.steps, "queries_per_step": len(q),
+                      "what": "one process, pt.MultiKdTree: queries and rows on devices[0], ranges over xGMI "
+                              "(ptk_multi_search_knn_device)",
+                      "parity_sample_ok": bool(got.tobytes() == want.tobytes())}), flush=True)
+    return 0
+
+
+def run_single_process_form(args, ndev, timeout_s=240):
+    """Rank 0: the single-process form as a child with a time limit; a dict either way."""
+    cmd = [sys.executable, os.path.abspath(__file__), "--single-process-worker", str(ndev), "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--cloud", args.cloud, "--k", str(args.k), "--leaf", str(args.leaf)]
+    if args.n:
+        cmd += ["--n", str(args.n)]
+    if args.nq:
+        cmd += ["--nq", str(args.nq)]
+    env = {k: v for k, v in os.environ.items()
+           if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR", "GROUP_RANK", "ROLE_RANK",
+                        "LOCAL_WORLD_SIZE", "ROLE_WORLD_SIZE", "TORCHELASTIC_RUN_ID")}
+    try:
+        done = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout_s)
+        lines = [ln for ln in done.stdout.splitlines() if ln.startswith("{")]
+        if done.returncode == 0 and lines:
+            return json.loads(lines[-1])
+        return {"devices": ndev, "error": (done.stderr or done.stdout)[-400:]}
+    except subprocess.TimeoutExpired:
+        return {"devices": ndev, "error": f"no result within {timeout_s} s"}
+    except Exception as exc:  # noqa: BLE001 -- context only, never the line
+        return {"devices": ndev, "error": repr(exc)[:400]}
+
+
 def main():
     args = parse_args()
     if args.cpu_baseline_worker:
         return cpu_baseline_worker(args)
+    if args.single_process_worker:
+        return single_process_worker(args)
     import torch
     import torch.distributed as dist
 
@@ -754,6 +822,9 @@ def main():
             del tree2, pts2, q2
             if args.cloud == "L":  # tie-prone data: every coordinate a multiple of 0.1
                 also.append(quantised_entry(pt, ds, oracle, pts, q, args.leaf, 0.1, local_rank, 10, 100_000))
+                # ... and of 1.0: piles of up to 600 coincident points (the k = 1 view without them, ptk_piles.hpp)
+                also.append(quantised_entry(pt, ds, oracle, pts, q, args.leaf, 1.0, local_rank, 10, 100_000))
+                also.append(quantised_entry(pt, ds, oracle, pts, q, args.leaf, 1.0, local_rank, 10, 100_000, shift=0.3))
             extras["also"] = also
             # (d) BASELINE configs[4]
             extras["config5"] = config5_entry(pt, ds, local_rank)
@@ -793,6 +864,9 @@ def main():
             result["weak" if other["weak"] else "strong"] = {
                 "value": round(other["value"], 3), "unit": "Mqueries/s", "ms_per_step": round(other["ms_per_step"], 4),
                 "queries_per_step": int(other["total"]), "parallelism": parallelism(other["weak"])}
+        if world > 1 and pt.device_count() >= world and not args.no_extras:
+            # (the other ranks wait at the barrier below with their devices idle)
+            result["single_process"] = run_single_process_form(args, world)
         result.update(extras)
         print(json.dumps(result), flush=True)
     if world > 1:

@@ -434,6 +434,11 @@ int ptk_profile_get_sized(const ptk_tree* tree, void* out, uint64_t size, int re
  * cooperative search, [2] = queries that search could not certify (redone by the reference
  * traversal from the root), [3] = queries of the classes dealt across wavefronts. */
 int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
+/* Piles -- subtrees all of whose points are one and the same point (the reference's builder peels one of them off per
+ * level, kd_tree_builder.hpp:255-275) -- of this handle's device replica (dim <= 3): out[0] = piles, [1] = points they
+ * hold, [2] = depth of the view without them that the k = 1 searches of the default metric traverse (0 piles: the tree
+ * itself is searched and [2] is its depth). */
+int ptk_debug_piles(const ptk_tree* tree, uint64_t out[3]);
 /* Where the creation of this handle went, in ms: [0] host build of the tree (ptk_tree_create_from_points only),
  * [1] re-encoding for the device and stream checks, [2] upload and the point gather on the device. */
 int ptk_debug_create_phases(const ptk_tree* tree, double ms[3]);

@@ -139,6 +139,7 @@ _SIGNATURES = {
     "ptk_profile_get": (c_int, [c_void_p, POINTER(_Profile), c_int]),
     "ptk_profile_get_sized": (c_int, [c_void_p, c_void_p, c_uint64, c_int]),
     "ptk_debug_knn1_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ptk_debug_piles": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
     "ptk_debug_create_phases": (c_int, [c_void_p, POINTER(c_double)]),
     "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
     "ptk_debug_batch_order": (c_int, [c_void_p, POINTER(c_int)]),
@@ -622,6 +623,14 @@ class KdTree:
         c = (c_uint32 * 4)()
         _check(_load().ptk_debug_knn1_counts(self._h, c))
         return {"phase2": int(c[0]), "cooperative": int(c[1]), "redone": int(c[2]), "dealt": int(c[3])}
+
+    def piles(self) -> dict:
+        """Subtrees of coincident points of the device replica (``ptk_debug_piles``): how many, the points they hold,
+        the depth of what a k = 1 search of the default metric traverses."""
+        self._float32_only("piles()")
+        c = (ctypes.c_uint64 * 3)()
+        _check(_load().ptk_debug_piles(self._h, c))
+        return {"piles": int(c[0]), "points": int(c[1]), "knn1_depth": int(c[2])}
 
     def batch_order(self) -> int:
         """What the last search did with the order of its batch: 0 as it came, 1 sorted on the device, 2 found

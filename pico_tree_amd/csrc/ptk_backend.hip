@@ -33,6 +33,7 @@
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_lists.hpp"
+#include "ptk_piles.hpp"
 // Geometry of the launches (measured optima, profiles/r02_notes.txt item 23, r03_notes.txt item 13):
 constexpr int kP2Ring = 12;   // LDS ring of the capped phase 2 (records per lane; 8 / 10 / 16: 1.335 / 1.329 / 1.308 vs 1.224 ms)
 constexpr int kGenRing = 16;  // LDS ring of the general searches (k > 1, radius)
@@ -188,6 +189,16 @@ struct ptk_tree {
   size_t lds_per_cu = 160 * 1024;     // LDS of one CU
   size_t lds_per_block = 160 * 1024;  // most dynamic LDS one workgroup may ask for
   size_t hbm_bytes = 0;               // device memory in total
+  // The k = 1 view of a tree that holds piles (ptk_piles.hpp; dim <= 3): branch records and subtree ranges of its
+  // own, the point array of the tree; null / zero when the tree has no pile.
+  ptk::DevTree dev1{};
+  void* d_nodes1 = nullptr;
+  void* d_ranges1 = nullptr;
+  void* d_pile_of_point = nullptr;
+  void* d_pile_recs = nullptr;
+  uint32_t n_piles = 0;
+  uint64_t pile_points = 0;
+  uint32_t max_depth1 = 0;
   void* d_cells = nullptr;  // dim <= 3: which cells of a coarse Morton grid hold tree points (ptk::CellTable)
   ptk::CellTable cells{};
   ptk::DevTreeND dev_nd{};
@@ -436,6 +447,44 @@ int upload(ptk_tree& t, const float* points) {
   t.dev.cmask = (1u << enc.cbits) - 1u;
   t.dev.n_points = (uint32_t)t.n_points;
   t.gpu_layout = true;
+  // Piles -- subtrees of one point many times over: the k = 1 search gets a view in which each is a leaf of one point
+  // (ptk_piles.hpp).  A tree of points in general position pays one pass over its branch records here.
+  if (env_int("PTK_PILE_VIEW", 1) != 0) {
+    ptk::PileView view;
+    ptk::build_pile_view(t.dim, t.n_points, points, t.nodes.data(), t.nodes.size(), t.indices.data(), view);
+    if (!view.empty()) {
+      ptk::TreeStats st1;
+      ptk::EncodedTree enc1;
+      bool unsup1 = false;
+      const std::string err1 = ptk::encode_tree(t.dim, t.n_points, nullptr, view.nodes.data(), view.nodes.size(), t.indices.data(),
+                                                st1, enc1, unsup1, /*with_points=*/false, view.single.data(), enc.cbits);
+      if (err1.empty()) {
+        static_assert(sizeof(ptk::PileRecord) == sizeof(ptk::DevPileRecord) && sizeof(ptk::PileRecord) == 48, "pile records");
+        const size_t nb = enc1.nodes.size() * sizeof(uint4), rb = enc1.ranges.size() * sizeof(ptk::EncRange),
+                     ob = view.pile_of_point.size() * 4, pb = view.piles.size() * sizeof(ptk::PileRecord);
+        PTK_HIP(hipMalloc(&t.d_nodes1, nb));
+        PTK_HIP(hipMalloc(&t.d_ranges1, rb));
+        PTK_HIP(hipMalloc(&t.d_pile_of_point, ob));
+        PTK_HIP(hipMalloc(&t.d_pile_recs, pb));
+        PTK_HIP(hipMemcpy(t.d_nodes1, enc1.nodes.data(), nb, hipMemcpyHostToDevice));
+        PTK_HIP(hipMemcpy(t.d_ranges1, enc1.ranges.data(), rb, hipMemcpyHostToDevice));
+        PTK_HIP(hipMemcpy(t.d_pile_of_point, view.pile_of_point.data(), ob, hipMemcpyHostToDevice));
+        PTK_HIP(hipMemcpy(t.d_pile_recs, view.piles.data(), pb, hipMemcpyHostToDevice));
+        t.dev1 = t.dev;
+        t.dev1.nodes = static_cast<const uint4*>(t.d_nodes1);
+        t.dev1.root_ref = enc1.root_ref;
+        t.n_piles = (uint32_t)view.piles.size();
+        t.pile_points = view.pile_points;
+        t.max_depth1 = st1.max_depth;
+        t.device_bytes += nb + rb + ob + pb;
+      }  // (a view that cannot be encoded is not needed: the full tree serves every search)
+      if (clock.on)
+        std::fprintf(stderr, "[ptk create] piles: %zu holding %llu points, view of %zu nodes, depth %u%s%s\n", view.piles.size(),
+                     (unsigned long long)view.pile_points, view.nodes.size(), st1.max_depth, err1.empty() ? "" : " -- not used: ",
+                     err1.c_str());
+    }
+    clock.lap("pile view", 1);
+  }
   return PTK_OK;
 }
 
@@ -752,8 +801,15 @@ class Scratch {
 // root path, either one pending record (went near, far child unexplored) or two
 // undo records (went far), so 2 * depth + 2 slots always suffice.
 constexpr int kDeepClass = 3;  // deeper than the private classes: spill to HBM, generic kernels only
-int ovf_class(const ptk_tree* t, int s_lds) {
-  const uint32_t need = 2 * t->max_depth + 2;
+// What a k = 1 search of the default metric traverses: the view without the piles if the tree has any.
+const ptk::DevTree& knn1_tree(const ptk_tree* t) { return t->n_piles ? t->dev1 : t->dev; }
+const uint2* knn1_ranges(const ptk_tree* t) { return static_cast<const uint2*>(t->n_piles ? t->d_ranges1 : t->d_ranges); }
+uint32_t knn1_depth(const ptk_tree* t) { return t->n_piles ? t->max_depth1 : t->max_depth; }
+
+int ovf_class_of(uint32_t depth, int s_lds);
+int ovf_class(const ptk_tree* t, int s_lds) { return ovf_class_of(t->max_depth, s_lds); }
+int ovf_class_of(uint32_t depth, int s_lds) {
+  const uint32_t need = 2 * depth + 2;
   if (need <= (uint32_t)s_lds + 64) return 0;
   if (need <= (uint32_t)s_lds + 256) return 1;
   if (need <= (uint32_t)s_lds + 2048) return 2;
@@ -1280,8 +1336,8 @@ int launch_knn1_coop_direct(const ptk_tree* t, const float4* qs, ptk::Neighbor* 
   static_assert(G >= kCoopLanes, "the spill block is sized for groups of kCoopLanes lanes");
   const int resident = t->cus * (int)std::max<size_t>(1, std::min<size_t>(32, t->lds_per_cu / (smem + 512)));
   const int waves = std::min(resident, coop_waves(t) * (G / kCoopLanes));
-  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, kCoopPool, true>), dim3(waves), dim3(64), smem, s, t->dev,
-                     static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, direct_ids, spill, kCoopSpill);
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, kCoopPool, true>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
+                     knn1_ranges(t), qs, d_out, cont, ho, redo_list, direct_ids, spill, kCoopSpill);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
@@ -1303,11 +1359,11 @@ int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, 
   // BASELINE config 2 overflow; the spill costs the step loop 5 %).  PTK_COOP_SPILL=1: with the spill all the same
   // (tie-prone data whose replays would be long chains).
   if (spill_cap != 0u && env_int("PTK_COOP_SPILL", 0) != 0)
-    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, true>), dim3(waves), dim3(64), smem, s, t->dev,
-                       static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, nullptr, spill, spill_cap);
+    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, true>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
+                       knn1_ranges(t), qs, d_out, cont, ho, redo_list, nullptr, spill, spill_cap);
   else
-    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, false>), dim3(waves), dim3(64), smem, s, t->dev,
-                       static_cast<const uint2*>(t->d_ranges), qs, d_out, cont, ho, redo_list, nullptr, spill, 0u);
+    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, false>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
+                       knn1_ranges(t), qs, d_out, cont, ho, redo_list, nullptr, spill, 0u);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
@@ -1394,7 +1450,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   // One chain of sections: search (phase 1) | other (class order) | search (phase 2, cooperative search, replay).
   Timer timer(t, s);
-  hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, t->dev, d_q, t->dim, perm, nq,
+  hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, knn1_tree(t), d_q, t->dim, perm, nq,
                      e_inv, d_out, cont, qs, tile_counts, cp.stride);
   timer.next(0, nq);
   if (cap) {
@@ -1438,10 +1494,10 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt items 10, 23); without it 16 slots
   // (r01l_notes item 8).
   if (cap) {
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<kP2Ring, OVF, LEAFB>), p2_grid, dim3(64), (size_t)kP2Ring * 64 * 8, s, t->dev, qs,
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<kP2Ring, OVF, LEAFB>), p2_grid, dim3(64), (size_t)kP2Ring * 64 * 8, s, knn1_tree(t), qs,
                        e_inv, d_out, cont, ids_out, cap, ho);
   } else {
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, knn1_tree(t), qs,
                        e_inv, d_out, cont, ids_out, 0u, ho);
   }
   PTK_HIP(hipGetLastError());
@@ -1454,8 +1510,17 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
       PTK_HIP(hipStreamWaitEvent(s, join, 0));
       side_guard.side = nullptr;
     }
-    hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(t->cus), dim3(64), (size_t)16 * 64 * 8, s, t->dev, qs,
+    hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(t->cus), dim3(64), (size_t)16 * 64 * 8, s, knn1_tree(t), qs,
                        e_inv, d_out, cont, redo_list);
+    PTK_HIP(hipGetLastError());
+  }
+  if (t->n_piles) {  // rows that name the stand-in of a pile get the point of it the reference reports (ptk_piles.hpp)
+    ptk::DevPiles piles;
+    piles.of_point = static_cast<const uint32_t*>(t->d_pile_of_point);
+    piles.recs = static_cast<const ptk::DevPileRecord*>(t->d_pile_recs);
+    piles.n_points = (uint32_t)t->n_points;
+    hipLaunchKernelGGL(ptk::resolve_piles_kernel, dim3((uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock)), dim3(ptk::kBlock), 0, s,
+                       d_q, t->dim, nq, piles, d_out);
     PTK_HIP(hipGetLastError());
   }
   timer.stop(3, 0);
@@ -1634,7 +1699,12 @@ int launch_radius_topo(const ptk_tree* t, const float* d_q, const uint32_t* perm
 int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                   ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   int rc = PTK_OK;
-  PTK_WITH_OVF(16, (launch_knn1_two_phase<OVF>(t, d_q, perm, nq, e, d_out, s, scratch)));
+  switch (ovf_class_of(knn1_depth(t), 16)) {  // (the depth of what is traversed: the view without the piles if there is one)
+    case 0: rc = launch_knn1_two_phase<64>(t, d_q, perm, nq, e, d_out, s, scratch); break;
+    case 1: rc = launch_knn1_two_phase<256>(t, d_q, perm, nq, e, d_out, s, scratch); break;
+    case 2: rc = launch_knn1_two_phase<2048>(t, d_q, perm, nq, e, d_out, s, scratch); break;
+    default: rc = fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", knn1_depth(t));
+  }
   return rc;
 }
 
@@ -1804,6 +1874,10 @@ void ptk_tree_destroy(ptk_tree* t) {
     if (t->d_index) (void)hipFree(t->d_index);
     if (t->d_outer) (void)hipFree(t->d_outer);
     if (t->d_cells) (void)hipFree(t->d_cells);
+    if (t->d_nodes1) (void)hipFree(t->d_nodes1);
+    if (t->d_ranges1) (void)hipFree(t->d_ranges1);
+    if (t->d_pile_of_point) (void)hipFree(t->d_pile_of_point);
+    if (t->d_pile_recs) (void)hipFree(t->d_pile_recs);
   }
   delete t;
 }
@@ -2021,7 +2095,8 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
     PTK_WITH_OVF(16, (launch_knn_topo<OVF>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree)));
     return rc;
   }
-  if (deep_tree(t)) {  // a few queries at a time, the record stacks spilling to HBM (any k, any metric)
+  const bool knn1_view = k == 1 && l2 && t->dim <= 3 && t->n_piles != 0 && ovf_class_of(knn1_depth(t), 16) != kDeepClass;
+  if (deep_tree(t) && !knn1_view) {  // a few queries at a time, the record stacks spilling to HBM (any k, any metric)
     const DeepPlan plan = deep_plan(t, nq);
     Scratch scratch(t, s, /*per_stream=*/true);
     rc = scratch.reserve(plan.bytes());
@@ -2205,7 +2280,8 @@ static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint3
     if (io.up_done[i] == nullptr) PTK_HIP(hipEventCreateWithFlags(&io.up_done[i], hipEventDisableTiming));
     if (io.down_done[i] == nullptr) PTK_HIP(hipEventCreateWithFlags(&io.down_done[i], hipEventDisableTiming));
   }
-  const bool two_phase = k == 1 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED && !deep_tree(t);
+  const bool two_phase = k == 1 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
+                         ovf_class_of(knn1_depth(t), 16) != kDeepClass;
   const std::vector<uint64_t> first = host_pieces(nq, k, two_phase);
   const uint64_t pieces = first.size() - 1;
   uint64_t piece = 0;  // the largest piece: the size of a ring slot
@@ -2963,6 +3039,15 @@ int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
   counts[1] = meta[ptk::kMetaHeavy];
   counts[2] = meta[ptk::kMetaRedo];
   counts[3] = meta[1];
+  return PTK_OK;
+}
+
+int ptk_debug_piles(const ptk_tree* t, uint64_t out[3]) {
+  if (t == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (t->device < 0) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
+  out[0] = t->n_piles;
+  out[1] = t->pile_points;
+  out[2] = knn1_depth(t);
   return PTK_OK;
 }
 

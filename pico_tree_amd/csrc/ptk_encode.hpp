@@ -135,9 +135,13 @@ inline std::string analyse_stream(
 // does not fit the 32-bit reference encoding.
 inline std::string encode_tree(
     uint32_t dim, uint64_t n_points, const float* points, const ptk_node* nodes, uint64_t n_nodes,
-    const int32_t* indices, TreeStats& st, EncodedTree& out, bool& unsupported, bool with_points = true) {
+    const int32_t* indices, TreeStats& st, EncodedTree& out, bool& unsupported, bool with_points = true,
+    const uint8_t* leaf_single = nullptr, uint32_t force_cbits = 0) {
   // with_points = false: the caller fills the point records itself (the backend gathers them on
   // the device: encode_points_kernel); `points` may then be null.
+  // leaf_single (per node; the k = 1 view of a tree with piles, ptk_piles.hpp): leaves marked 1 keep their range --
+  // the point records are the full tree's -- but are referenced with a count of one; force_cbits: the count bits of
+  // the full tree, whose point array the view shares.
   unsupported = false;
   if (dim == 0 || dim > 3) {
     unsupported = true;
@@ -158,7 +162,16 @@ inline std::string encode_tree(
     n_slots += ((uint64_t)(nd.b - nd.a) + kEncLeafAlign - 1) / kEncLeafAlign * kEncLeafAlign;
   }
   const uint64_t n_branch = n_nodes - st.n_leaves;
-  const uint32_t cbits = bits_for(st.max_leaf_count);
+  if (leaf_single != nullptr) {  // (the statistics are those of what a search visits)
+    st.max_leaf_count = 0;
+    for (uint64_t i = 0; i < n_nodes; ++i) {
+      if (nodes[i].right != PTK_LEAF) continue;
+      const uint32_t c = leaf_single[i] ? 1u : nodes[i].b - nodes[i].a;
+      if (c > st.max_leaf_count) st.max_leaf_count = c;
+    }
+  }
+  const uint32_t cbits = force_cbits ? force_cbits : bits_for(st.max_leaf_count);
+  if (bits_for(st.max_leaf_count) > cbits) return "a leaf does not fit the count bits asked for";
   const uint32_t bbits = bits_for(n_slots);
   if (cbits + bbits > 31) {
     unsupported = true;
@@ -172,7 +185,8 @@ inline std::string encode_tree(
 
   auto ref_of = [&](uint64_t i) -> uint32_t {
     const ptk_node& nd = nodes[i];
-    if (nd.right == PTK_LEAF) return kEncLeafBit | ((uint32_t)leaf_pos[i] << cbits) | (nd.b - nd.a);
+    if (nd.right == PTK_LEAF)
+      return kEncLeafBit | ((uint32_t)leaf_pos[i] << cbits) | (leaf_single != nullptr && leaf_single[i] ? 1u : nd.b - nd.a);
     return (nd.split_dim << 29) | branch_id[i];
   };
 

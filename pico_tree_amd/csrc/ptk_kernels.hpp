@@ -2550,6 +2550,39 @@ __global__ __launch_bounds__(kBlock) void encode_points_kernel(
 // ---- batch ordering ------------------------------------------------------------------------
 // Morton key of each query inside the tree's root box (clamped), plus the identity permutation
 // to be sorted along with it.  spread10 serves the float64 kernel (ten bits per axis).
+// ---- piles (ptk_piles.hpp): the rows of a k = 1 search on the view of a tree with piles ------------------------
+// A row whose index is the stand-in of a pile gets the index the reference reports: the pile's first-visited point
+// for the side of the query on each axis (the side test of traverse<> with both bounds at the pile's coordinate).
+struct DevPileRecord {  // == ptk::PileRecord
+  float c[3];
+  uint32_t count;
+  int32_t first[8];
+};
+struct DevPiles {
+  const uint32_t* of_point;  // [n_points] 1 + pile of the point that stands for it, else 0
+  const DevPileRecord* recs;
+  uint32_t n_points;
+};
+__global__ __launch_bounds__(kBlock) void resolve_piles_kernel(const float* __restrict__ queries, uint32_t dim, uint64_t nq,
+                                                                DevPiles piles, Neighbor* __restrict__ rows) {
+  const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
+  if (i >= nq) return;
+  const Neighbor nb = rows[i];
+  if ((uint32_t)nb.index >= piles.n_points) return;
+  const uint32_t p = piles.of_point[nb.index];
+  if (p == 0u) return;
+  const DevPileRecord& rec = piles.recs[p - 1u];
+  float q[3];
+  load_query(queries, dim, i, q[0], q[1], q[2]);
+  uint32_t bits = 0u;
+#pragma unroll
+  for (uint32_t a = 0; a < 3; ++a) {
+    const float s = f_sub(f_sub(f_add(rec.c[a], rec.c[a]), q[a]), q[a]);
+    if (a < dim && s > 0.0f) bits |= 1u << a;
+  }
+  rows[i].index = rec.first[bits];
+}
+
 __device__ __forceinline__ uint32_t spread10(uint32_t x) {
   x &= 0x3FFu;
   x = (x | (x << 16)) & 0x030000FFu;

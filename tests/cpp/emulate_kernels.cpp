@@ -27,6 +27,7 @@ thread_local dim3 blockDim;
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_lists.hpp"
+#include "ptk_piles.hpp"
 #include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
 #include "ptk_kernels_topo.hpp"
@@ -111,6 +112,8 @@ struct Emu {
   std::vector<uint8_t> cap_flags;
   std::vector<uint32_t> cap_qids;
   std::vector<uint32_t> cap_lens, cap_tables;  // the capture as leaf lists (ptk_kernels_lists.hpp)
+  ptk::PileView piles;     // emu_use_pile_view: the k = 1 view of a tree with piles (ptk_piles.hpp)
+  ptk::EncodedTree enc1;
   uint64_t cap_nq = 0;
   ptk::RadiusCapture cap{};
 };
@@ -294,6 +297,38 @@ void* emu_create(const float* points, uint64_t n, uint32_t dim, const ptk_node* 
 }
 
 void emu_destroy(void* h) { delete static_cast<Emu*>(h); }
+
+// Switches the handle to the k = 1 view of its tree (ptk_piles.hpp): branch records and subtree ranges of the stream
+// with every pile collapsed, the point records it already has.  Returns the number of piles (0: the tree has none and
+// nothing changes) or a negative status.  Only emu_knn1_two_phase + emu_resolve_piles are meaningful afterwards.
+int64_t emu_use_pile_view(void* h, const float* points, uint64_t n, const ptk_node* nodes, uint64_t n_nodes,
+                          const int32_t* indices) {
+  auto* e = static_cast<Emu*>(h);
+  if (e->dim > 3) return -3;
+  ptk::build_pile_view(e->dim, n, points, nodes, n_nodes, indices, e->piles);
+  if (e->piles.empty()) return 0;
+  ptk::TreeStats st1;
+  bool unsupported = false;
+  g_err = ptk::encode_tree(e->dim, n, nullptr, e->piles.nodes.data(), e->piles.nodes.size(), indices, st1, e->enc1, unsupported,
+                           /*with_points=*/false, e->piles.single.data(), e->enc.cbits);
+  if (!g_err.empty()) return -1;
+  e->dev.nodes = reinterpret_cast<const uint4*>(e->enc1.nodes.data());
+  e->dev.root_ref = e->enc1.root_ref;
+  e->enc.ranges = e->enc1.ranges;
+  e->st.max_depth = st1.max_depth;
+  return (int64_t)e->piles.piles.size();
+}
+
+// The pass over the rows of a k = 1 search on the view (resolve_piles_kernel).
+void emu_resolve_piles(void* h, const float* q, uint64_t nq, ptk_neighbor* out) {
+  auto* e = static_cast<Emu*>(h);
+  if (e->piles.empty()) return;
+  ptk::DevPiles piles;
+  piles.of_point = e->piles.pile_of_point.data();
+  piles.recs = reinterpret_cast<const ptk::DevPileRecord*>(e->piles.piles.data());
+  piles.n_points = (uint32_t)e->piles.pile_of_point.size();
+  for_each_lane(nq, [&] { ptk::resolve_piles_kernel(q, e->dim, nq, piles, reinterpret_cast<ptk::Neighbor*>(out)); });
+}
 
 // 0 L2 squared (default), 1 L1, 2 LPInf, 3 LNInf, 4 SO2, 5 SE2 squared: the metric of the searches that
 // follow (ptk_tree_set_metric).  The topological ones need emu_set_outer first.

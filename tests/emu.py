@@ -141,6 +141,17 @@ class EmulatedTree:
                                 off.ctypes.data, out.ctypes.data) == 0
         return off, out[:int(off[-1])]
 
+    def use_pile_view(self):
+        """Switches the handle to the k = 1 view of its tree (ptk_piles.hpp); returns the number of piles."""
+        nodes, idx, _, _ = self.host.flat()
+        fn = self.lib.emu_use_pile_view
+        fn.restype = ctypes.c_int64
+        fn.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p, c_uint64, c_void_p]
+        n = fn(self.h, self.pts.ctypes.data, len(self.pts), nodes.ctypes.data, len(nodes), idx.ctypes.data)
+        assert n >= 0
+        self._piles = int(n)
+        return self._piles
+
     def two_phase_knn1(self, q, e=None, perm=None, variant=5):
         """Returns (result (nq,1), number of continuations handed to phase 2)."""
         q = np.ascontiguousarray(q, dtype=np.float32)
@@ -149,6 +160,10 @@ class EmulatedTree:
                                          perm.ctypes.data if perm is not None else None, variant,
                                          out.ctypes.data)
         assert n2 >= 0
+        if getattr(self, "_piles", 0):
+            self.lib.emu_resolve_piles.restype = None
+            self.lib.emu_resolve_piles.argtypes = [c_void_p, c_void_p, c_uint64, c_void_p]
+            self.lib.emu_resolve_piles(self.h, q.ctypes.data, len(q), out.ctypes.data)
         return out, n2
 
     def last_coop(self):

@@ -764,6 +764,45 @@ def test_batches_that_arrive_coherent_are_not_sorted_again(gpu, cloud):
     assert tree.batch_order() == 1 and got.tobytes() == ref.search_knn(batch, 1)[:, 0].tobytes()
 
 
+@pytest.mark.parametrize("grid,shift", [(0.1, 0.0), (0.25, 0.3), (1.0, 0.0), (1.0, 0.3), (4.0, 0.0), (4.0, 0.3), (4.0, 0.5)])
+def test_coincident_points_k1_through_the_view_without_the_piles(gpu, monkeypatch, grid, shift):
+    """Coordinates snapped to a grid (tie-prone data; from 1.0 on piles of coincident points, which the builder peels
+    apart one level per point -- at 4.0 a 400 k-point tree is a thousand levels deep): the k = 1 search runs on the
+    view in which a pile is one point and reports the point of the pile the reference visits first (ptk_piles.hpp).
+    400 k points / 300 k queries on the grid, off the grid, and half a cell off it (several piles at exactly the same
+    distance); rows equal the oracle's, exact and approximate, device and host buffers, and the rows of the full tree
+    (PTK_PILE_VIEW=0); on the view next to nothing is replayed lane by lane."""
+    import torch
+
+    n, nq = 400_000, 300_000
+    pts, q = ds.config2_clouds("L", n, nq)
+    p2 = np.ascontiguousarray(np.round(pts / grid) * grid, dtype=np.float32)
+    q2 = np.ascontiguousarray(np.round(q / grid) * grid + np.float32(shift * grid), dtype=np.float32)
+    tree = pt.KdTree(p2, pt.Metric.L2Squared, 10, device=gpu)
+    piles = tree.piles()
+    ref = oracle.Oracle(p2, 10, "port")
+    ref.set_threads(ref.max_threads())
+    want = ref.search_knn(q2, 1)[:, 0]
+    dq = torch.from_numpy(q2).to(f"cuda:{gpu}")
+    got = tree.search_knn(dq, 1).numpy()
+    torch.cuda.synchronize()
+    assert got.tobytes() == want.tobytes()
+    if grid >= 4.0:
+        assert piles["piles"] > 1000 and piles["knn1_depth"] < 64 < tree.info()["max_depth"]
+        assert tree.knn1_counts()["redone"] <= 8
+    elif grid >= 1.0:
+        assert piles["piles"] >= 1 and piles["knn1_depth"] <= tree.info()["max_depth"]
+    else:
+        assert piles["piles"] == 0 and piles["knn1_depth"] == tree.info()["max_depth"]
+    assert tree.search_knn(q2[:50_000], 1).tobytes() == want[:50_000].tobytes()  # host buffers, in pieces
+    assert tree.search_knn(dq, 1, 1.25).numpy().tobytes() == ref.search_knn(q2, 1, e=1.25)[:, 0].tobytes()
+    if grid == 4.0 and shift == 0.3:  # the same rows the long way: every point of every pile visited
+        monkeypatch.setenv("PTK_PILE_VIEW", "0")
+        full = pt.KdTree(p2, pt.Metric.L2Squared, 10, device=gpu)
+        assert full.piles()["piles"] == 0
+        assert full.search_knn(dq[:20_000].contiguous(), 1).numpy().tobytes() == want[:20_000].tobytes()
+
+
 def test_rows_in_page_locked_blocks_of_the_pool(gpu):
     """search_knn(pts, k) returns a NEW array per call like the reference's module (def_kd_tree.cpp:73-82); here it is
     built on a page-locked block (ptk_host_alloc) the device writes directly, and the block is handed out again once

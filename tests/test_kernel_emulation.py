@@ -171,6 +171,40 @@ def test_emulated_two_phase_knn1_equals_oracle(case):
     assert got.tobytes() == ref.search_knn(q, 1, e=1.4).tobytes()
 
 
+def _pile_cloud(n, dim, grid, seed, heavy=0):
+    """Coordinates snapped to a grid: piles of coincident points (and `heavy` copies of one point on top)."""
+    p = np.round(ds.uniform_cloud(n, dim, seed) / grid) * grid
+    if heavy:
+        p[:heavy] = p[0]
+    return np.ascontiguousarray(p, dtype=np.float32)
+
+
+@pytest.mark.parametrize("dim,grid,shift", [(3, 0.25, 0.0), (3, 0.25, 0.3), (3, 0.5, 0.5), (2, 0.125, 0.3), (1, 0.05, 0.5)])
+def test_emulated_k1_search_on_the_view_without_the_piles(dim, grid, shift):
+    """Trees of coincident points (ptk_piles.hpp): the k = 1 search on the view in which every pile is a leaf of one
+    point, then the pass that gives a pile's row the point of it the reference visits first -- queries on the grid
+    (on top of the piles), moved off it (every pile at a distance, several at the same one when shift = 0.5), exact
+    and approximate, against the oracle; the full tree of the same handle gives the same rows the long way."""
+    pts = _pile_cloud(6_000, dim, grid, 11, heavy=300)
+    q = np.ascontiguousarray(np.round(ds.uniform_cloud(1_200, dim, 12) / grid) * grid + np.float32(shift * grid), dtype=np.float32)
+    ref = oracle.Oracle(pts, 10, "port")
+    want = ref.search_knn(q, 1)
+    full = EmulatedTree(pts, 10)
+    depth_full = full.host.info()["max_depth"]
+    assert full.two_phase_knn1(q, variant=5)[0].tobytes() == want.tobytes()
+    emu = EmulatedTree(pts, 10)
+    n_piles = emu.use_pile_view()
+    assert n_piles > 10 and depth_full > 300
+    perm, _ = emu.morton_permutation(q)
+    for variant, pm in ((5, None), (5, perm), (3, perm), (9, None)):
+        got, _ = emu.two_phase_knn1(q, perm=pm, variant=variant)
+        assert got.tobytes() == want.tobytes(), (variant, pm is None)
+    got, _ = emu.two_phase_knn1(q, e=1.3, perm=perm, variant=3)
+    assert got.tobytes() == ref.search_knn(q, 1, e=1.3).tobytes()
+    # a tree of points in general position has no pile: nothing to switch to
+    assert EmulatedTree(ds.uniform_cloud(2_000, 3, 5), 10).use_pile_view() == 0
+
+
 def _blind_disc_queries(n):
     """Queries inside the empty disc under the scanner of cloud L: the reference's depth-first search
     of such a query visits a long chain of leaves (the expensive queries of BASELINE config 2)."""
