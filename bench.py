@@ -241,8 +241,9 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
         # only slow the baseline down, so its best pass is the figure that does it justice and that repeats.
         return rates[-1], at - chunk, len(rates)
 
-    omp, n_omp, p_omp = rate(q, cores, 400_000, seconds * 0.45)
-    omp_sorted, n_omps, p_omps = rate(q_sorted, cores, 400_000, seconds * 0.15)
+    # (passes of the all-cores legs long enough -- tens of milliseconds -- that one descheduled thread does not decide them)
+    omp, n_omp, p_omp = rate(q, cores, 1_600_000, seconds * 0.45)
+    omp_sorted, n_omps, p_omps = rate(q_sorted, cores, 1_600_000, seconds * 0.15)
     one, n_one, p_one = rate(q, 1, 50_000, max(1.0, seconds * 0.25))
     one_sorted, n_ones, p_ones = rate(q_sorted, 1, 100_000, max(1.0, seconds * 0.15))
     cpu.close()
@@ -250,7 +251,7 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
             "cpu": model, "sockets": sockets, "logical_cpus": logical,
             "threads": f"{cores} (one per physical core; OMP_PLACES={os.environ.get('OMP_PLACES')}, "
                        f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
-            "sample": f"OpenMP schedule(dynamic,128): warm-up + {p_omp} passes of 400000 queries in the order given to "
+            "sample": f"OpenMP schedule(dynamic,128): warm-up + {p_omp} passes of up to 1600000 queries in the order given to "
                       f"the GPU ({n_omp} queries), fastest pass",
             "morton_sorted_queries_value": round(omp_sorted, 4),
             "morton_sorted_queries_sample": f"the first {nsorted} queries Morton-sorted, warm-up + {p_omps} passes, "
@@ -315,6 +316,29 @@ def also_entry(pt, ds, oracle, cloud, order, pts, q, tree, leaf, steps, sample):
             "ms_per_step": round(ms, 4), "steps": steps, "reorder_ms": round(prof["reorder_ms"] / steps, 4),
             "parity_sample_ok": bool(got.tobytes() == want.tobytes()),
             "roofline": roofline_of(b, len(q), kernel_ms)}
+
+
+def approximate_entry(pt, oracle, pts, q, tree, dq, leaf, e, steps, sample):
+    """The headline search as an approximate one, search_knn(pts, 1, e) (search_visitor.hpp:165-193): every candidate
+    distance divided by e before it is compared, so the answer depends on the visit order and phase 2 runs every
+    continuation to its end in the reference's order -- no cap, no cooperative tail."""
+    import torch
+
+    out = torch.empty((len(q), 1, 2), dtype=torch.int32, device=dq.device)
+    tree.search_knn(dq, 1, e, out)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        tree.search_knn(dq, 1, e, out)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    ref = oracle.Oracle(pts, leaf, "port")
+    cs = np.sort(np.random.default_rng(7).choice(len(q), size=min(sample, len(q)), replace=False))
+    want = ref.search_knn(q[cs], 1, e=e)
+    ref.close()
+    got = pt.DeviceNeighbors(out).numpy()[cs][:, None]
+    return {"e": e, "value": round(len(q) / ms / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms, 4), "steps": steps,
+            "parity_sample_ok": bool(got.tobytes() == want.tobytes())}
 
 
 def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
@@ -809,6 +833,8 @@ def main():
             # (b) config 3 on the same clouds
             if args.cloud == "L" and args.order == "generated":
                 extras["config3"] = config3_entries(pt, oracle, pts, q, tree, dq, args.leaf, 100_000)
+            if k == 1:
+                extras["approximate"] = approximate_entry(pt, oracle, pts, q, tree, dq, args.leaf, 1.05, 10, 20_000)
             # (c) the headline search on the other query order and on the other cloud
             also = []
             other_order = "morton" if args.order == "generated" else "generated"

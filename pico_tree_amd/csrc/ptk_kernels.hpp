@@ -1176,10 +1176,7 @@ __global__ __launch_bounds__(BLOCK) void radius_capture_kernel(
 // Wavefronts the capture could not hold are listed, row by row, for radius_kernel<FILL>.
 constexpr int kLogUnroll = 4;
 // LDS bytes per wavefront: staged chunk, sorted chunk (+ 3 entries kept back per row), row tables, owner of each slot
-#ifndef PTK_EXP_LOG_KEEP
-#define PTK_EXP_LOG_KEEP 3
-#endif
-constexpr uint32_t kLogKeep = PTK_EXP_LOG_KEEP;  // entries a row may hold back: its runs end on boundaries of (kLogKeep + 1) x 8 bytes
+constexpr uint32_t kLogKeep = 3;  // entries a row may hold back: its runs end on boundaries of (kLogKeep + 1) x 8 bytes
 constexpr uint32_t kLogCarry = 64u * kLogKeep;  // room for them in the sorted chunk (rounded up below)
 constexpr uint32_t kLogSortedPad = (kLogCarry + 63u) & ~63u;
 constexpr uint32_t kLogScatterLds = kLogChunk * 8u * 2u + kLogSortedPad * 8u + 64u * 12u + kLogChunk + kLogSortedPad;
