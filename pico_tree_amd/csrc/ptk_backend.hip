@@ -451,7 +451,7 @@ int upload(ptk_tree& t, const float* points) {
   // (ptk_piles.hpp).  A tree of points in general position pays one pass over its branch records here.
   if (env_int("PTK_PILE_VIEW", 1) != 0) {
     ptk::PileView view;
-    ptk::build_pile_view(t.dim, t.n_points, points, t.nodes.data(), t.nodes.size(), t.indices.data(), view);
+    ptk::build_pile_view(t.dim, t.n_points, points, t.nodes.data(), t.nodes.size(), t.indices.data(), view, build_threads());
     if (!view.empty()) {
       ptk::TreeStats st1;
       ptk::EncodedTree enc1;

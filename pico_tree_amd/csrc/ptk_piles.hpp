@@ -20,11 +20,13 @@
 // equal distances; radius and box rows) keeps the full tree.
 #pragma once
 
+#include <atomic>
 #include <cstdint>
 #include <cstring>
 #include <vector>
 
 #include "ptk.h"
+#include "ptk_encode.hpp"
 
 namespace ptk {
 
@@ -56,11 +58,10 @@ inline int32_t leaf_b(const ptk_node& nd) {
 }
 }  // namespace piles_detail
 
-// Finds the piles of a validated stream and builds the view; an empty view when there are none.  A tree without a
-// branch whose two bounds are the same number (every tree of points in general position) costs one pass over the
-// branch records and no look at the points.
+// Finds the piles of a validated stream and builds the view; an empty view when there are none.  A tree of distinct
+// points costs one threaded pass over the branch records (and a look at two points where the bounds of a branch meet).
 inline void build_pile_view(uint32_t dim, uint64_t n_points, const float* points, const ptk_node* nodes,
-                            uint64_t n_nodes, const int32_t* indices, PileView& out) {
+                            uint64_t n_nodes, const int32_t* indices, PileView& out, unsigned threads = 1) {
   using piles_detail::leaf_a;
   using piles_detail::leaf_b;
   out = PileView{};
@@ -72,10 +73,6 @@ inline void build_pile_view(uint32_t dim, uint64_t n_points, const float* points
     std::memcpy(&rm, &nd.b, 4);
     return lm == rm;
   };
-  bool candidate = false;
-  for (uint64_t i = 0; i < n_nodes && !candidate; ++i) candidate = nodes[i].right != PTK_LEAF && bounds_meet(nodes[i]);
-  if (!candidate) return;
-
   auto same_point = [&](int32_t p, int32_t q) {
     const float* x = points + (uint64_t)p * dim;
     const float* y = points + (uint64_t)q * dim;
@@ -83,6 +80,24 @@ inline void build_pile_view(uint32_t dim, uint64_t n_points, const float* points
       if (!(x[d] == y[d])) return false;
     return true;
   };
+  auto first_point = [&](uint64_t i) {  // of the subtree at node i: its leftmost leaf is the next leaf of the stream
+    while (nodes[i].right != PTK_LEAF) ++i;
+    return indices[leaf_a(nodes[i])];
+  };
+  // The one pass every tree pays, on `threads` threads: is there a branch whose bounds meet AND whose two sides begin
+  // with the same point?  (Bounds that meet are common -- the points of a floor share a coordinate --, sides that begin
+  // with the same point are a pile or next to one.)
+  std::atomic<bool> candidate{false};
+  parallel_chunks(n_nodes, threads, size_t(1) << 17, [&](size_t lo, size_t hi, unsigned) {
+    for (size_t i = lo; i < hi; ++i) {
+      if (nodes[i].right != PTK_LEAF && bounds_meet(nodes[i]) && same_point(first_point(i + 1), first_point(nodes[i].right))) {
+        candidate.store(true, std::memory_order_relaxed);
+        return;
+      }
+    }
+  });
+  if (!candidate.load()) return;
+
   // Bottom-up (children follow their parent in the stream): 1 = every point below is the same point, rep = one of them.
   // Leaves are looked at only below a branch that could be a pile.
   std::vector<uint8_t> same(n_nodes, 0);

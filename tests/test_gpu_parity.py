@@ -714,6 +714,8 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
     else:
         pts, q = _clouds(cloud, 120_000, 40_000)
     monkeypatch.setenv("PTK_COOP_DIRECT", direct)
+    if cloud == "ties":  # (the lattice cloud is all piles: on the view without them -- ptk_piles.hpp -- nothing is left to replay)
+        monkeypatch.setenv("PTK_PILE_VIEW", "0")
     tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
     ref = oracle.Oracle(pts, 10, "port")
     ref.set_threads(ref.max_threads())
@@ -731,6 +733,10 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
         redone += counts["redone"]
     if cloud == "ties":  # more exact ties per query than a lane resolves: the certificate fails, the replay runs
         assert redone > 0
+        monkeypatch.delenv("PTK_PILE_VIEW")
+        view = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+        assert view.piles()["piles"] > 0 and view.search_knn(dq, 1).numpy().tobytes() == want.tobytes()
+        assert view.knn1_counts()["redone"] == 0
 
 
 @pytest.mark.parametrize("cloud", ["lidar", "uniform"])
