@@ -84,6 +84,33 @@ def test_radius_bit_exact_traversal_order(trees, cloud, radius):
     assert off[-1] > 0
 
 
+@pytest.mark.parametrize("leaf", [1, 33, 100])
+def test_radius_rows_from_leaf_lists_with_other_leaf_sizes(gpu, leaf):
+    """The radius search of a 3-D tree lists, per query, the leaves with hits and the mask of the hits (32 points per
+    list entry: a larger leaf is listed in pieces) and makes the rows by replaying the lists
+    (ptk_kernels_lists.hpp).  Leaves of one point, of 33 and of 100; long rows (queries on top of dense spots), empty
+    rows, a partly empty last wavefront; exact, approximate and sorted -- rows equal the oracle's."""
+    import torch
+
+    pts, q = ds.lidar_cloud(150_000, seed=3), ds.lidar_cloud(20_000 - 37, seed=4, pose=(3.0, 1.5))
+    q[:500] = pts[:500]
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, leaf, device=gpu)
+    ref = oracle.Oracle(pts, leaf, "port")
+    ref.set_threads(ref.max_threads())
+    dq = torch.from_numpy(q).to(f"cuda:{gpu}")
+    most = 0
+    for radius, e in ((4.0, 1.0), (0.05, 1.0), (1.5, 1.4)):
+        want_off, want = ref.search_radius(q, radius, e=None if e == 1.0 else e)
+        off, raw = tree.search_radius_device(dq, radius, e)
+        assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off)
+        assert raw.cpu().numpy().tobytes() == want.tobytes()
+        most = max(most, int(want_off[-1]))
+    assert most > 5 * len(q), most
+    got = tree.search_radius(q, 4.0, sort=True)
+    _, want = ref.search_radius(q, 4.0, sort=True)
+    assert np.array_equal(got.flat["distance"], want["distance"])
+
+
 def test_radius_strict_and_sorted(trees):
     tree, ref, pts, q = trees("ties")
     radius = 0.03
