@@ -19,8 +19,8 @@
 //            the arithmetic of the leaf scan of traverse<> (same operations in the same order: bit-identical), and
 //            all lanes are busy for as long as the longest list of the wavefront lasts -- neighbours in the Morton
 //            order have lists of similar length.  The hits go to the row in list order = the reference's visit
-//            order.  A lane's hits wait in a ring of 16 entries in LDS until they complete a 64-byte line of the
-//            row; the complete lines of all lanes leave together, eight lanes to a line, so that HBM sees whole
+//            order.  A lane's hits wait in a ring of 32 entries in LDS until they complete a 64-byte line of the
+//            row; the complete lines of all lanes leave together, four lanes to a line, so that HBM sees whole
 //            lines: a row is written once, by whole lines but for its first and last one, and nothing else is
 //            written at all -- no log of hits.
 //
@@ -205,8 +205,8 @@ __global__ __launch_bounds__(64) void radius_list_kernel(
 #endif
 }
 
-// The ring of the fill pass: RING entries per lane, [slot][lane] with a row of 65 entries (the eight lanes that write
-// a line of one row read eight slots of one lane: a row of 64 would put them all in one bank).
+// The ring of the fill pass: RING entries per lane, [slot][lane] with a row of 65 entries (the four lanes that write
+// a line of one row read its eight slots of ONE lane: a row of 64 would put them all in one bank).
 constexpr uint32_t kRingRow = 65;
 constexpr uint32_t replay_lds(uint32_t ring) { return ring * kRingRow * 8u + 64u * 8u + 64u * 4u; }  // ring, {row}, {lane | count << 8} of the lines that leave
 

@@ -180,17 +180,4 @@ inline void build_pile_view(uint32_t dim, uint64_t n_points, const float* points
   }
 }
 
-// The index the reference reports for a query whose nearest point is pile `rec`: bit a of the pattern is the side
-// test of kd_tree_search.hpp:76 with both bounds at the pile's coordinate.
-inline int32_t pile_answer(const PileRecord& rec, const float* q, uint32_t dim) {
-  uint32_t bits = 0;
-  for (uint32_t a = 0; a < dim && a < 3; ++a) {
-    const volatile float twice = rec.c[a] + rec.c[a];
-    const volatile float once = twice - q[a];
-    const volatile float s = once - q[a];
-    if (s > 0.0f) bits |= 1u << a;
-  }
-  return rec.first[bits];
-}
-
 }  // namespace ptk
