@@ -28,5 +28,5 @@ for grid, shift in ((0.05, 0.0), (0.1, 0.0), (0.25, 0.0), (1.0, 0.0), (0.25, 0.3
     want = ref.search_knn(q2[sample], 1)
     ok = res[sample][:, None].tobytes() == want.tobytes()
     ref.close()
-    print(f"grid {grid} shift {shift}: depth {tree.info()['max_depth']}, {ms:.3f} ms per step, counts {tree.knn1_counts()}, parity on 20 k sample {ok}", flush=True)
+    print(f"grid {grid} shift {shift}: depth {tree.info()['max_depth']}, piles {tree.piles()}, {ms:.3f} ms per step, counts {tree.knn1_counts()}, parity on 20 k sample {ok}", flush=True)
     del tree
