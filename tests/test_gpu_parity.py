@@ -111,6 +111,22 @@ def test_radius_rows_from_leaf_lists_with_other_leaf_sizes(gpu, leaf):
     assert np.array_equal(got.flat["distance"], want["distance"])
 
 
+def test_radius_lists_longer_than_a_wavefront_may_hold(gpu):
+    """A query whose row draws on more than 1 024 leaves (kListMaxChunks chunks of 16 entries per lane) cannot be
+    listed: its wavefront is marked and its queries take the ordinary fill traversal, the wavefronts beside it the
+    replay -- rows equal the oracle's either way."""
+    pts = ds.uniform_cloud(100_000, 3, 21)
+    q = np.ascontiguousarray(np.concatenate([ds.uniform_cloud(640, 3, 22) * 0.2 + 0.4, ds.uniform_cloud(3_000, 3, 23)]))
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 2, device=gpu)
+    ref = oracle.Oracle(pts, 2, "port")
+    ref.set_threads(ref.max_threads())
+    for radius in (0.04, 0.0005):  # ~3 000 hits in ~1 500 leaves per central query / a handful
+        want_off, want = ref.search_radius(q, radius)
+        got = tree.search_radius(q, radius)
+        assert np.array_equal(got.offsets, want_off) and got.flat.tobytes() == want.tobytes()
+    assert int(np.diff(ref.search_radius(q[:640], 0.04)[0]).min()) > 2 * 1024
+
+
 def test_radius_strict_and_sorted(trees):
     tree, ref, pts, q = trees("ties")
     radius = 0.03
