@@ -107,6 +107,24 @@ def algorithmic_bytes(ref, q_sample, k, dim):
     return float(b), {"n_branch": float(mean[0]), "n_leaf": float(mean[1]), "n_pts": float(mean[2])}
 
 
+def measured_traffic_c3(prefixes):
+    """The same for the kernels of BASELINE configs[2] (profiles/*_c3_traffic.json, tools/pmc_cmd.sh on
+    tools/bench_config3.py): GB per launch of the kernels whose names start with one of `prefixes`, and the file."""
+    import glob
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_c3_traffic.json")))
+    if not files:
+        return None, None
+    try:
+        with open(files[-1]) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None, None
+    total = sum(rec["hbm_bytes_per_dispatch"] for name, rec in kernels.items()
+                if any(name.startswith(p) for p in prefixes) and "hbm_bytes_per_dispatch" in rec)
+    return (round(total / 1e9, 3), os.path.basename(files[-1])) if total else (None, None)
+
+
 def measured_traffic(prefixes):
     """HBM bytes per launch of the traversal kernels from the newest committed
     ``profiles/*_traffic.json`` (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same
@@ -362,6 +380,8 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     kernel_ms = prof["search_ms"] / max(int(prof["launches"]), 1)
     r = roofline_of(b, nq, kernel_ms)
     r["kernel"] = "ptk::knn_reg_kernel<16, 16, 64, 64, 5, ptk::MetricL2>"
+    r["traffic"], r["traffic_source"] = measured_traffic_c3(["ptk::knn_reg_kernel<16,"])
+    r["traffic_static"] = True  # (GB per launch, 2 x FETCH_SIZE + WRITE_SIZE of committed rocprofv3 --pmc passes, as above)
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
     res["knn16"] = {"value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms, 4), "steps": steps,
                     "parity_sample_ok": bool(got.tobytes() == want.tobytes()), "roofline": r}
@@ -391,6 +411,8 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     kernel_ms = prof["search_ms"] / steps
     r = roofline_of(b, nq, kernel_ms)
     r["kernel"] = "ptk::radius_list_kernel<16, 64, 5, ptk::MetricL2> + ptk::radius_replay_kernel<8, 32, ptk::MetricL2>"
+    r["traffic"], r["traffic_source"] = measured_traffic_c3(["ptk::radius_list_kernel", "ptk::radius_replay_kernel"])
+    r["traffic_static"] = True
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
     res["radius"] = {"radius_squared": radius, "value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s",
                      "ms_per_step": round(ms, 4), "steps": steps, "hits_per_query": round(hits / nq, 2),

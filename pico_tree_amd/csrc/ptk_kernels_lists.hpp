@@ -68,6 +68,7 @@ struct RadiusListPolicy {  // search_visitor.hpp:127-156 / :252-288, counting
   uint64_t count;
   uint32_t n;            // entries this lane has listed
   uint32_t first, pos, mask, cbits;  // the piece of a leaf being measured: its first point, points seen, hits among them
+  bool big_leaves;                   // the tree has leaves of more than kListMaskBits points
   unsigned long long* slots;  // the chunks
   unsigned long long b0, b1, b2, b3;  // the group of entries this lane is collecting
   uint32_t* counters;         // RadiusCapture::counters
@@ -128,7 +129,10 @@ struct RadiusListPolicy {  // search_visitor.hpp:127-156 / :252-288, counting
     if (n % kListGroup != 0u) write_group(n / kListGroup);  // (the slots behind entry n - 1 are never read)
   }
   __device__ __forceinline__ void close_piece() {
-    if (mask != 0u) append(pack_list_entry((first << cbits) | pos, mask));
+    if (mask != 0u) {
+      count += (uint32_t)__popcll((unsigned long long)mask);
+      append(pack_list_entry((first << cbits) | pos, mask));
+    }
     first += pos;
     pos = 0u;
     mask = 0u;
@@ -141,11 +145,9 @@ struct RadiusListPolicy {  // search_visitor.hpp:127-156 / :252-288, counting
   __device__ __forceinline__ void leaf_end() { close_piece(); }
   __device__ __forceinline__ void visit(int32_t, float d) {
     d = f_mul(d, e_inv);
-    if (radius > d) {  // strict
-      mask |= 1u << pos;
-      ++count;
-    }
-    if (++pos == kListMaskBits) close_piece();
+    mask |= (radius > d ? 1u : 0u) << pos;  // strict; the hits are counted when the piece is closed
+    ++pos;
+    if (big_leaves && pos == kListMaskBits) close_piece();  // (leaves of up to 32 points, the usual case: one piece)
   }
 };
 
@@ -177,6 +179,7 @@ __global__ __launch_bounds__(64) void radius_list_kernel(
     pol.e_inv = e_inv;
     pol.count = 0;
     pol.cbits = t.cbits;
+    pol.big_leaves = t.cmask >= kListMaskBits;  // (a count of 32 needs six bits)
     pol.slots = reinterpret_cast<unsigned long long*>(cap.chunks);
     pol.b0 = pol.b1 = pol.b2 = pol.b3 = 0ull;
     pol.counters = cap.counters;
