@@ -439,6 +439,10 @@ int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
  * hold, [2] = depth of the view without them that the k = 1 searches of the default metric traverse (0 piles: the tree
  * itself is searched and [2] is its depth). */
 int ptk_debug_piles(const ptk_tree* tree, uint64_t out[3]);
+/* The order a batch of nq query rows (device buffer) is searched in: d_perm[i] (device, nq words) = the row that is
+ * searched i-th -- a stable sort of the rows by their Morton keys (ptk_debug_key_bits says how the key bits are spread
+ * over the axes).  Synchronises the device. */
+int ptk_debug_batch_permutation(const ptk_tree* tree, const float* d_queries, uint64_t nq, uint32_t* d_perm);
 /* Where the creation of this handle went, in ms: [0] host build of the tree (ptk_tree_create_from_points only),
  * [1] re-encoding for the device and stream checks, [2] upload and the point gather on the device. */
 int ptk_debug_create_phases(const ptk_tree* tree, double ms[3]);

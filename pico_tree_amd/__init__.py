@@ -140,6 +140,7 @@ _SIGNATURES = {
     "ptk_profile_get_sized": (c_int, [c_void_p, c_void_p, c_uint64, c_int]),
     "ptk_debug_knn1_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ptk_debug_piles": (c_int, [c_void_p, POINTER(ctypes.c_uint64)]),
+    "ptk_debug_batch_permutation": (c_int, [c_void_p, c_void_p, c_uint64, c_void_p]),
     "ptk_debug_create_phases": (c_int, [c_void_p, POINTER(c_double)]),
     "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
     "ptk_debug_batch_order": (c_int, [c_void_p, POINTER(c_int)]),
@@ -631,6 +632,16 @@ class KdTree:
         c = (ctypes.c_uint64 * 3)()
         _check(_load().ptk_debug_piles(self._h, c))
         return {"piles": int(c[0]), "points": int(c[1]), "knn1_depth": int(c[2])}
+
+    def batch_permutation(self, q):
+        """The order the rows of a device batch would be searched in (``ptk_debug_batch_permutation``): a uint32 torch
+        tensor, entry i = the row searched i-th."""
+        import torch
+
+        self._float32_only("batch_permutation()")
+        perm = torch.empty((q.shape[0],), dtype=torch.int32, device=q.device)
+        _check(_load().ptk_debug_batch_permutation(self._h, q.data_ptr(), q.shape[0], perm.data_ptr()))
+        return perm
 
     def batch_order(self) -> int:
         """What the last search did with the order of its batch: 0 as it came, 1 sorted on the device, 2 found

@@ -907,17 +907,23 @@ uint32_t sort_tile(uint64_t nq) {
 }
 uint32_t sort_tiles(uint64_t nq) { return (uint32_t)((nq + sort_tile(nq) - 1) / sort_tile(nq)); }
 uint32_t sort_stride(uint64_t nq) { return (sort_tiles(nq) + 3u) & ~3u;  }  // row of the histogram: 16-byte steps
-size_t own_sort_bytes(uint64_t nq) {
-  return ((size_t)ptk::kRadixBins * sort_stride(nq) + ptk::kRadixBins) * 4 + 2 * nq * sizeof(uint2) + 1024;
+size_t own_sort_bytes(uint64_t nq) {  // (the histogram of whichever form has more tiles)
+  const size_t stride = std::max<size_t>(sort_stride(nq), ((nq + ptk::kSortTile - 1) / ptk::kSortTile + 3) & ~(size_t)3);
+  return ((size_t)ptk::kRadixBins * stride + ptk::kRadixBins) * 4 + 2 * nq * sizeof(uint2) + 1024;
 }
 
-// Which sort orders the batch: the library's own below 2 M queries (six launches and 58 us for a 900 k-query shard
-// against ten launches and 96 us), rocprim's onesweep above (7.2 M queries, three passes: 0.26 against 0.32 ms;
-// profiles/r03_notes.txt item 1).  PTK_SORT = 0 / 1 forces rocprim's / the library's own.
+// Which sort orders the batch: the library's own (ptk_sort.hpp) -- its passes with one wavefront per tile below 0.75 M
+// rows (six launches and 58 us for a 900 k-query shard against rocprim's ten launches and 96 us), with blocks of eight
+// wavefronts on tiles of 4 096 items from there on (reorder ms, one wavefront per tile / blocks / rocprim's onesweep:
+// 900 k rows 0.063 / 0.056 / 0.110, 2 M 0.144 / 0.093 / 0.158, 7.2 M 0.319 / 0.192 / 0.275; profiles/r04_notes.txt
+// item 13).  PTK_SORT = 0 forces rocprim's, PTK_SORT_BLOCK = 0 / 1 either form of the own.
+bool block_sort(uint64_t nq) {
+  const int mode = env_int("PTK_SORT_BLOCK", -1);
+  return mode < 0 ? nq >= (3ull << 18) : mode != 0 && nq >= ptk::kSortTile;
+}
 bool own_sort(uint64_t nq) {
-  const int mode = env_int("PTK_SORT", -1);
   if (nq >= (1ull << 31)) return false;
-  return mode < 0 ? nq < (2ull << 20) : mode != 0;
+  return env_int("PTK_SORT", 1) != 0;
 }
 
 size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, 30) + own_sort_bytes(nq) + 1024; }
@@ -1003,7 +1009,10 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     // Key + histogram kernel, then per 8-bit pass: scan of the digit-by-tile histogram, stable scatter (and the
     // histogram of the next digit): 3 launches per pass - 1... nothing to clear, no look-back (ptk_sort.hpp).
     // keys -> pairs A -> [pairs B ->] permutation; the arrays of the rocprim path serve (keys | keys_out + ids = A).
-    const uint32_t tile = sort_tile(nq), tiles = sort_tiles(nq), stride = sort_stride(nq);
+    const bool blocks = block_sort(nq);
+    const uint32_t tile = blocks ? ptk::kSortTile : sort_tile(nq);
+    const uint32_t tiles = blocks ? (uint32_t)((nq + tile - 1) / tile) : sort_tiles(nq);
+    const uint32_t stride = blocks ? (tiles + 3u) & ~3u : sort_stride(nq);
     uint32_t* hist = scratch.take<uint32_t>((size_t)ptk::kRadixBins * stride);
     uint32_t* totals = scratch.take<uint32_t>(ptk::kRadixBins);
     uint2* pairs_a = scratch.take<uint2>(nq);
@@ -1018,7 +1027,13 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
       const uint32_t shift = 8u * (uint32_t)p;
       const bool first = p == 0, last = p + 1 == passes;
       uint2* out = in == pairs_a ? pairs_b : pairs_a;
-      if (first)
+      if (blocks && first)
+        hipLaunchKernelGGL((ptk::radix_block_hist_kernel<true>), dim3(tiles), dim3(ptk::kSortBlock), smem, s, d_q, t->dim,
+                           (uint32_t)nq, lo3, inv3, b3, keys, in, shift, stride, hist, cells);
+      else if (blocks)
+        hipLaunchKernelGGL((ptk::radix_block_hist_kernel<false>), dim3(tiles), dim3(ptk::kSortBlock), smem, s, d_q, t->dim,
+                           (uint32_t)nq, lo3, inv3, b3, keys, in, shift, stride, hist, ptk::CellTable{});
+      else if (first)
         hipLaunchKernelGGL((ptk::radix_hist_kernel<true>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
                            inv3, b3, keys, in, shift, tile, stride, hist, cells);
       else
@@ -1032,8 +1047,12 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
       }
       hipLaunchKernelGGL(ptk::radix_scan_kernel, dim3(ptk::kRadixBins), dim3(64), 0, s, hist, tiles, stride, totals);
 #define PTK_SCATTER(F, L)                                                                                              \
-  hipLaunchKernelGGL((ptk::radix_scatter_kernel<F, L>), dim3(tiles), dim3(64), smem, s, keys, in, out, ids_out,        \
-                     (uint32_t)nq, shift, tile, stride, hist, totals)
+  if (blocks)                                                                                                          \
+    hipLaunchKernelGGL((ptk::radix_block_scatter_kernel<F, L>), dim3(tiles), dim3(ptk::kSortBlock),                    \
+                       ptk::kSortScatterLds, s, keys, in, out, ids_out, (uint32_t)nq, shift, stride, hist, totals);    \
+  else                                                                                                                 \
+    hipLaunchKernelGGL((ptk::radix_scatter_kernel<F, L>), dim3(tiles), dim3(64), smem, s, keys, in, out, ids_out,      \
+                       (uint32_t)nq, shift, tile, stride, hist, totals)
       if (first && last) PTK_SCATTER(true, true);
       else if (first) PTK_SCATTER(true, false);
       else if (last) PTK_SCATTER(false, true);
@@ -3061,6 +3080,23 @@ int ptk_debug_batch_order(const ptk_tree* t, int* how) {
   if (t == nullptr || how == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lock(t->ws.mutex);
   *how = t->ws.last_order;
+  return PTK_OK;
+}
+
+int ptk_debug_batch_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, uint32_t* d_perm) {
+  int rc = check_search(t, d_q, nq);
+  if (rc != PTK_OK) return rc;
+  if (d_perm == nullptr || nq == 0) return fail(PTK_ERR_INVALID, "null permutation buffer or empty batch");
+  DeviceGuard guard(t->device);
+  if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+  Scratch scratch(t, nullptr);
+  rc = scratch.reserve(permutation_scratch_bytes(nq));
+  if (rc != PTK_OK) return rc;
+  uint32_t* perm = nullptr;
+  rc = make_permutation(t, d_q, nq, nullptr, scratch, &perm);
+  if (rc != PTK_OK) return rc;
+  PTK_HIP(hipMemcpyAsync(d_perm, perm, nq * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
+  PTK_HIP(hipStreamSynchronize(nullptr));
   return PTK_OK;
 }
 

@@ -137,6 +137,15 @@ inline void lds_min_u32(uint32_t* p, uint32_t v) {
 }
 #endif
 
+// += on a 32-bit LDS word shared by the threads of a block (ds_add_u32).
+#if defined(__HIPCC__)
+__device__ __forceinline__ void lds_add_u32(PTK_LDS uint32_t* p, uint32_t v) {
+  __hip_atomic_fetch_add((uint32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+#else
+inline void lds_add_u32(uint32_t* p, uint32_t v) { *p += v; }
+#endif
+
 __device__ __forceinline__ float f_add(float a, float b) { return __fadd_rn(a, b); }
 __device__ __forceinline__ float f_sub(float a, float b) { return __fsub_rn(a, b); }
 __device__ __forceinline__ float f_mul(float a, float b) { return __fmul_rn(a, b); }

@@ -210,4 +210,169 @@ __global__ __launch_bounds__(64) void radix_scatter_kernel(
   }
 }
 
+// ---- the same passes with BLOCKS of eight wavefronts and tiles of 4 096 items (r04) --------------------------------
+//
+// What the one-wavefront scatter above pays for is its stores: every item goes to its place on its own, 8 bytes into a
+// 32-byte sector (7.2 M queries: 0.32 ms for three passes against 0.26 for rocprim's onesweep, whose blocks put a tile
+// in digit order in LDS first).  Here a tile is 4 096 items: the eight wavefronts of a block rank an eighth each (same
+// ballots, their digit counts side by side in LDS), the parts are joined by a prefix over the wavefronts, the
+// items are put in digit order in LDS and leave with consecutive lanes on consecutive items -- runs of 16 items of a
+// digit on average, whole sectors.  Histogram (LDS atomics: the order of counting does not matter), scan (the kernel
+// above) and scatter stay three launches per pass with nothing to clear and no look-back.  Stable like the passes above:
+// the permutation is the one a stable sort of the keys gives.
+// (threads x items per thread, reorder ms of 7.2 M rows: 256 x 16 0.205, 512 x 8 0.192, 512 x 12 0.211, 256 x 8 0.205)
+constexpr uint32_t kSortBlock = 512, kSortItems = 8, kSortTile = kSortBlock * kSortItems;
+constexpr uint32_t sort_scatter_lds(uint32_t block, uint32_t items) {
+  return ((block / 64u) * kRadixBins + 2u * kRadixBins + 32u) * 4u + block * items * 8u;
+}
+constexpr uint32_t kSortScatterLds = sort_scatter_lds(kSortBlock, kSortItems);
+
+// Exclusive prefix of `v` over the 256 values held by the first 256 threads of the block (tmp: 4 words of LDS; two
+// barriers; every thread of the block calls it, threads beyond 255 with v = 0).
+__device__ __forceinline__ uint32_t block_exclusive_sum(uint32_t v, uint32_t t, PTK_LDS uint32_t* tmp) {
+  const uint32_t lane = t & 63u, w = t >> 6;
+  const uint32_t incl = wave_inclusive_sum(v, lane);
+  if (lane == 63u && w < 4u) tmp[w] = incl;
+  __syncthreads();
+  uint32_t before = 0;
+#pragma unroll
+  for (uint32_t j = 0; j < 3; ++j) before += j < w ? tmp[j] : 0u;
+  __syncthreads();
+  return before + incl - v;
+}
+
+// Digit histogram of tile blockIdx.x -> hist[digit * stride + blockIdx.x]; FROM_QUERIES as radix_hist_kernel.
+template <bool FROM_QUERIES, uint32_t BLOCK = kSortBlock, uint32_t ITEMS = kSortItems>
+__global__ __launch_bounds__(BLOCK) void radix_block_hist_kernel(
+    const float* __restrict__ queries, uint32_t dim, uint32_t nq, float3 lo, float3 inv, uint3 bits,
+    uint32_t* __restrict__ keys, const uint2* __restrict__ pairs, uint32_t shift, uint32_t stride,
+    uint32_t* __restrict__ hist, CellTable cells = CellTable{}) {
+  typedef PTK_LDS uint32_t LdsU32;
+  LdsU32* cnt = (LdsU32*)ptk_smem;  // [256]
+  const uint32_t t = threadIdx.x;
+  if (t < kRadixBins) cnt[t] = 0u;
+  __syncthreads();
+  const uint32_t base = blockIdx.x * (BLOCK * ITEMS);
+  uint32_t key[ITEMS];
+  bool valid[ITEMS];
+  if (FROM_QUERIES) {
+#pragma unroll
+    for (uint32_t g = 0; g < ITEMS; g += 4u) {  // (four queries in flight per thread)
+      float x[4], y[4], z[4];
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        const uint32_t i = base + (g + u) * BLOCK + t;
+        valid[g + u] = i < nq;
+        load_query(queries, dim, valid[g + u] ? i : nq - 1u, x[u], y[u], z[u]);
+      }
+#pragma unroll
+      for (uint32_t u = 0; u < 4u; ++u) {
+        key[g + u] = order_key(x[u], y[u], z[u], lo, inv, bits, cells);
+        if (valid[g + u]) keys[base + (g + u) * BLOCK + t] = key[g + u];
+      }
+    }
+  } else {
+#pragma unroll
+    for (uint32_t j = 0; j < ITEMS; ++j) {
+      const uint32_t i = base + j * BLOCK + t;
+      valid[j] = i < nq;
+      key[j] = valid[j] ? pairs[i].x : 0u;
+    }
+  }
+#pragma unroll
+  for (uint32_t j = 0; j < ITEMS; ++j) {
+    if (valid[j]) lds_add_u32(&cnt[(key[j] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  if (t < kRadixBins) hist[t * stride + blockIdx.x] = cnt[t];
+}
+
+// The stable scatter of tile blockIdx.x; FIRST / LAST as radix_scatter_kernel.  hist and totals as the scan left them.
+template <bool FIRST, bool LAST, uint32_t BLOCK = kSortBlock, uint32_t ITEMS = kSortItems>
+__global__ __launch_bounds__(BLOCK) void radix_block_scatter_kernel(
+    const uint32_t* __restrict__ keys_in, const uint2* __restrict__ pairs_in, uint2* __restrict__ pairs_out,
+    uint32_t* __restrict__ vals_out, uint32_t n, uint32_t shift, uint32_t stride, const uint32_t* __restrict__ hist,
+    const uint32_t* __restrict__ totals) {
+  constexpr uint32_t WAVES = BLOCK / 64u, TILE = BLOCK * ITEMS;
+  static_assert(BLOCK >= kRadixBins && BLOCK % 64u == 0u, "a thread per digit");
+  typedef PTK_LDS uint32_t LdsU32;
+  LdsU32* wave_cnt = (LdsU32*)ptk_smem;            // [WAVES][256] digit counts of each wavefront's part, then their prefix
+  LdsU32* lbase = wave_cnt + WAVES * kRadixBins;    // [256] where a digit begins in the tile
+  LdsU32* gbase = lbase + kRadixBins;               // [256] where this tile's items of a digit begin in the output
+  LdsU32* tmp = gbase + kRadixBins;                 // [32]
+  LdsWord* buf = (LdsWord*)(tmp + 32);              // [TILE] the tile in digit order
+  const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
+  const uint32_t base = blockIdx.x * TILE;
+  for (uint32_t j = t; j < WAVES * kRadixBins; j += BLOCK) wave_cnt[j] = 0u;
+  // This wavefront's part of the tile, in index order: round r = items [w * ITEMS * 64 + r * 64, + 64).
+  uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
+  bool valid[ITEMS];
+#pragma unroll
+  for (uint32_t r = 0; r < ITEMS; ++r) {
+    const uint32_t i = base + w * (ITEMS * 64u) + r * 64u + lane;
+    valid[r] = i < n;
+    if (FIRST) {
+      key[r] = valid[r] ? keys_in[i] : 0u;
+      val[r] = i;
+    } else {
+      const uint2 p = valid[r] ? pairs_in[i] : make_uint2(0u, 0u);
+      key[r] = p.x;
+      val[r] = p.y;
+    }
+  }
+  __syncthreads();
+  // Rank among the items of the same digit in this part (the LDS operations of a wavefront are executed in order:
+  // a round reads what the round before wrote).
+  const uint64_t below = (1ull << lane) - 1ull;
+#pragma unroll
+  for (uint32_t r = 0; r < ITEMS; ++r) {
+    const uint32_t digit = (key[r] >> shift) & 255u;
+    const uint64_t peers = same_digit_lanes(digit, valid[r]);
+    const uint32_t before = wave_cnt[w * kRadixBins + (valid[r] ? digit : 0u)];
+    rank[r] = before + (uint32_t)__popcll(peers & below);
+    if (valid[r] && (peers >> lane) == 1ull) wave_cnt[w * kRadixBins + digit] = before + (uint32_t)__popcll(peers);
+  }
+  __syncthreads();
+  {
+    // digit t: the parts' counts become their prefix; the tile's count gives the digit's place in the tile; the totals
+    // and the scanned histogram its place in the output
+    uint32_t sum = 0;
+    if (t < kRadixBins) {
+#pragma unroll
+      for (uint32_t j = 0; j < WAVES; ++j) {
+        const uint32_t c = wave_cnt[j * kRadixBins + t];
+        wave_cnt[j * kRadixBins + t] = sum;
+        sum += c;
+      }
+    }
+    const uint32_t in_tile = block_exclusive_sum(t < kRadixBins ? sum : 0u, t, tmp);
+    const uint32_t in_all = block_exclusive_sum(t < kRadixBins ? totals[t] : 0u, t, tmp + 8);
+    if (t < kRadixBins) {
+      lbase[t] = in_tile;
+      gbase[t] = in_all + hist[t * stride + blockIdx.x];
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (uint32_t r = 0; r < ITEMS; ++r) {
+    if (valid[r]) {
+      const uint32_t digit = (key[r] >> shift) & 255u;
+      buf[lbase[digit] + wave_cnt[w * kRadixBins + digit] + rank[r]] = (unsigned long long)key[r] | ((unsigned long long)val[r] << 32);
+    }
+  }
+  __syncthreads();
+  const uint32_t held = n - base < TILE ? n - base : TILE;
+#pragma unroll
+  for (uint32_t j = 0; j < ITEMS; ++j) {
+    const uint32_t at = j * BLOCK + t;
+    if (at < held) {
+      const unsigned long long kv = buf[at];
+      const uint32_t digit = ((uint32_t)kv >> shift) & 255u;
+      const uint32_t dst = gbase[digit] + (at - lbase[digit]);
+      if (LAST) vals_out[dst] = (uint32_t)(kv >> 32);
+      else pairs_out[dst] = make_uint2((uint32_t)kv, (uint32_t)(kv >> 32));
+    }
+  }
+}
+
 }  // namespace ptk

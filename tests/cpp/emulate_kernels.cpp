@@ -72,7 +72,53 @@ void fiber_entry() {
 }
 }  // namespace
 
+// ---- blocks of several wavefronts ------------------------------------------------------------------------------------
+// The threads of one block run as fibers as well; a ballot or shuffle is a rendezvous of the caller's WAVEFRONT (64
+// consecutive threads), __syncthreads one of the whole block.  A wavefront whose live lanes have all parked at a ballot
+// goes on at once, whatever the other wavefronts are doing; the block goes on when every live thread waits at the barrier.
+namespace {
+struct BlockFibers {
+  static constexpr size_t kStack = 256 * 1024;
+  int n = 0;
+  ucontext_t scheduler;
+  std::vector<ucontext_t> ctx;
+  std::vector<unsigned char> stacks;
+  std::vector<char> done, runnable, at_barrier, pred;
+  std::vector<int> value, snapshot;
+  std::vector<unsigned long long> result;  // per wavefront
+  int current = -1;
+  std::function<void()> body;
+};
+BlockFibers* g_block = nullptr;
+
+void block_fiber_entry() {
+  BlockFibers* b = g_block;
+  b->body();
+  b->done[b->current] = 1;
+  swapcontext(&b->ctx[b->current], &b->scheduler);
+}
+}  // namespace
+
+void emu_barrier() {
+  if (g_block == nullptr) {
+    (void)emu_ballot(false);
+    return;
+  }
+  BlockFibers* b = g_block;
+  const int t = b->current;
+  b->at_barrier[t] = 1;
+  swapcontext(&b->ctx[t], &b->scheduler);
+}
+
 unsigned long long emu_ballot(bool pred) {
+  if (g_block != nullptr) {
+    BlockFibers* b = g_block;
+    const int t = b->current;
+    b->pred[t] = pred;
+    b->at_barrier[t] = 0;
+    swapcontext(&b->ctx[t], &b->scheduler);
+    return b->result[t / 64];
+  }
   WaveFibers* w = g_fibers;
   const int lane = w->current;
   w->pred[lane] = pred;
@@ -83,6 +129,15 @@ unsigned long long emu_ballot(bool pred) {
 // A shuffle is a rendezvous too: every live lane deposits its value, parks, and reads the
 // source lane's value from the snapshot taken when all had parked.
 int emu_shfl(int v, int src_lane) {
+  if (g_block != nullptr) {
+    BlockFibers* b = g_block;
+    const int t = b->current;
+    b->value[t] = v;
+    b->pred[t] = false;
+    b->at_barrier[t] = 0;
+    swapcontext(&b->ctx[t], &b->scheduler);
+    return b->snapshot[(t / 64) * 64 + (src_lane & 63)];
+  }
   WaveFibers* w = g_fibers;
   const int lane = w->current;
   w->value[lane] = v;
@@ -91,7 +146,7 @@ int emu_shfl(int v, int src_lane) {
   return w->snapshot[src_lane & 63];
 }
 
-int emu_lane() { return g_fibers->current; }
+int emu_lane() { return g_block != nullptr ? g_block->current & 63 : g_fibers->current; }
 
 namespace {
 
@@ -174,6 +229,93 @@ void for_each_wave(uint32_t blocks, F&& f) {
     }
   }
   g_fibers = nullptr;
+}
+
+// Runs `blocks` blocks of `threads` threads (a multiple of 64), one after the other, as fibers (see BlockFibers).
+template <typename F>
+void for_each_block(uint32_t blocks, uint32_t threads, F&& f) {
+  BlockFibers b;
+  b.n = (int)threads;
+  b.ctx.resize(threads);
+  b.stacks.resize((size_t)threads * BlockFibers::kStack);
+  b.result.assign(threads / 64, 0ull);
+  g_block = &b;
+  gridDim.x = blocks;
+  blockDim.x = threads;
+  for (uint32_t blk = 0; blk < blocks; ++blk) {
+    blockIdx.x = blk;
+    b.body = [&] { f(); };
+    b.done.assign(threads, 0);
+    b.runnable.assign(threads, 1);
+    b.at_barrier.assign(threads, 0);
+    b.pred.assign(threads, 0);
+    b.value.assign(threads, 0);
+    b.snapshot.assign(threads, 0);
+    for (uint32_t t = 0; t < threads; ++t) {
+      getcontext(&b.ctx[t]);
+      b.ctx[t].uc_stack.ss_sp = b.stacks.data() + (size_t)t * BlockFibers::kStack;
+      b.ctx[t].uc_stack.ss_size = BlockFibers::kStack;
+      b.ctx[t].uc_link = &b.scheduler;
+      makecontext(&b.ctx[t], block_fiber_entry, 0);
+    }
+    for (;;) {
+      bool ran = false;
+      for (uint32_t t = 0; t < threads; ++t) {
+        if (b.done[t] || !b.runnable[t]) continue;
+        b.runnable[t] = 0;
+        b.current = (int)t;
+        threadIdx.x = t;
+        swapcontext(&b.scheduler, &b.ctx[t]);
+        ran = true;
+      }
+      uint32_t live = 0, waiting = 0;
+      for (uint32_t t = 0; t < threads; ++t) {
+        live += b.done[t] ? 0u : 1u;
+        waiting += !b.done[t] && b.at_barrier[t] ? 1u : 0u;
+      }
+      if (live == 0) break;
+      bool released = false;
+      for (uint32_t w = 0; w < threads / 64; ++w) {  // wavefronts whose live lanes all wait at a ballot / shuffle
+        uint32_t wl = 0, wb = 0;
+        unsigned long long bits = 0;
+        for (uint32_t l = 0; l < 64; ++l) {
+          const uint32_t t = w * 64 + l;
+          if (b.done[t]) continue;
+          ++wl;
+          if (!b.at_barrier[t]) {
+            ++wb;
+            if (b.pred[t]) bits |= 1ull << l;
+          }
+        }
+        if (wl == 0 || wb == 0) continue;
+        if (wb != wl) {
+          std::fprintf(stderr, "emulator: a wavefront is split between a ballot and a barrier\n");
+          std::abort();
+        }
+        b.result[w] = bits;
+        for (uint32_t l = 0; l < 64; ++l) {
+          const uint32_t t = w * 64 + l;
+          b.snapshot[t] = b.value[t];
+          if (!b.done[t]) b.runnable[t] = 1;
+        }
+        released = true;
+      }
+      if (!released && waiting == live) {  // the barrier
+        for (uint32_t t = 0; t < threads; ++t) {
+          if (!b.done[t]) {
+            b.at_barrier[t] = 0;
+            b.runnable[t] = 1;
+          }
+        }
+        released = true;
+      }
+      if (!released && !ran) {
+        std::fprintf(stderr, "emulator: block of %u threads cannot go on\n", threads);
+        std::abort();
+      }
+    }
+  }
+  g_block = nullptr;
 }
 
 // The launch-order query records {x, y, z, bits(row)} phase 1 has to produce (host restatement).
@@ -880,6 +1022,44 @@ void emu_radix_sort(const float* q, uint32_t dim, uint64_t nq, const float* lo, 
         ptk::radix_scatter_kernel<false, true>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, tile, stride, hist.data(), totals.data());
       else
         ptk::radix_scatter_kernel<false, false>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, tile, stride, hist.data(), totals.data());
+    });
+    in = out;
+  }
+  std::memcpy(keys, k0.data(), nq * 4);
+  std::memcpy(perm, out_perm.data(), nq * 4);
+}
+
+// The same passes with blocks of four wavefronts on tiles of 4 096 items (radix_block_hist_kernel /
+// radix_block_scatter_kernel): 256 fibers per block, ballots per wavefront, barriers per block.
+void emu_radix_sort_blocks(const float* q, uint32_t dim, uint64_t nq, const float* lo, const float* inv,
+                           const uint32_t* bits, uint32_t key_bits, uint32_t* keys, uint32_t* perm) {
+  const float3 l = make_float3(lo[0], lo[1], lo[2]);
+  const float3 i = make_float3(inv[0], inv[1], inv[2]);
+  const uint3 b3 = make_uint3(bits[0], bits[1], bits[2]);
+  const uint32_t tiles = (uint32_t)((nq + ptk::kSortTile - 1) / ptk::kSortTile), stride = (tiles + 3u) & ~3u;
+  std::vector<uint32_t> hist((size_t)ptk::kRadixBins * stride, 0xEEEEEEEEu), totals(ptk::kRadixBins, 0xEEEEEEEEu);
+  std::vector<uint32_t> k0(nq, 0xEEEEEEEEu), out_perm(nq, 0xEEEEEEEEu);
+  std::vector<uint2> pa(nq, uint2{0xEEEEEEEEu, 0xEEEEEEEEu}), pb(nq, uint2{0xEEEEEEEEu, 0xEEEEEEEEu});
+  const uint32_t passes = (key_bits + 7) / 8;
+  const uint2* in = nullptr;
+  for (uint32_t p = 0; p < passes; ++p) {
+    const uint32_t shift = 8 * p;
+    const bool first = p == 0, last = p + 1 == passes;
+    uint2* out = in == pa.data() ? pb.data() : pa.data();
+    for_each_block(tiles, ptk::kSortBlock, [&] {
+      if (first) ptk::radix_block_hist_kernel<true>(q, dim, (uint32_t)nq, l, i, b3, k0.data(), in, shift, stride, hist.data());
+      else ptk::radix_block_hist_kernel<false>(q, dim, (uint32_t)nq, l, i, b3, k0.data(), in, shift, stride, hist.data());
+    });
+    for_each_wave(ptk::kRadixBins, [&] { ptk::radix_scan_kernel(hist.data(), tiles, stride, totals.data()); });
+    for_each_block(tiles, ptk::kSortBlock, [&] {
+      if (first && last)
+        ptk::radix_block_scatter_kernel<true, true>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, stride, hist.data(), totals.data());
+      else if (first)
+        ptk::radix_block_scatter_kernel<true, false>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, stride, hist.data(), totals.data());
+      else if (last)
+        ptk::radix_block_scatter_kernel<false, true>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, stride, hist.data(), totals.data());
+      else
+        ptk::radix_block_scatter_kernel<false, false>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, stride, hist.data(), totals.data());
     });
     in = out;
   }

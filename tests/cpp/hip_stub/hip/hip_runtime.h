@@ -65,7 +65,8 @@ inline int __shfl_xor(int v, int mask) { return emu_shfl(v, emu_lane() ^ mask); 
 inline float __shfl_xor(float v, int mask) { return __shfl(v, emu_lane() ^ mask); }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_shfl(v, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl(v, 0); }  // all lanes alive where it is used
-inline void __syncthreads() { (void)emu_ballot(false); }  // single-wave blocks only
+void emu_barrier();
+inline void __syncthreads() { emu_barrier(); }  // a rendezvous of the wavefront (for_each_wave) or of the block (for_each_block)
 
 // Lanes run one after the other (or as cooperative fibers), so a plain read-modify-write is atomic.
 template <typename T>

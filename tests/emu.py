@@ -199,7 +199,8 @@ class EmulatedTree:
 
     def radix_sorted_permutation(self, q, bits, tile=256):
         """The batch order from the library's own radix sort (ptk_sort.hpp) under the emulator:
-        (permutation, Morton keys).  `bits`: key bits per axis."""
+        (permutation, Morton keys).  `bits`: key bits per axis.  tile = 0: the passes with blocks of four wavefronts
+        on tiles of 4 096 items."""
         q = np.ascontiguousarray(q, dtype=np.float32)
         bits = np.asarray(list(bits) + [0] * 3, dtype=np.uint32)[:3]
         lo = np.zeros(3, dtype=np.float32)
@@ -210,6 +211,13 @@ class EmulatedTree:
         inv[:d] = np.where(ext > 0, np.exp2(bits[:d]).astype(np.float32) / ext, 0).astype(np.float32)
         keys = np.zeros(len(q), dtype=np.uint32)
         perm = np.zeros(len(q), dtype=np.uint32)
+        if tile == 0:
+            self.lib.emu_radix_sort_blocks.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32,
+                                                       c_void_p, c_void_p]
+            self.lib.emu_radix_sort_blocks.restype = None
+            self.lib.emu_radix_sort_blocks(q.ctypes.data, d, len(q), lo.ctypes.data, inv.ctypes.data, bits.ctypes.data,
+                                           int(bits.sum()), keys.ctypes.data, perm.ctypes.data)
+            return perm, keys
         self.lib.emu_radix_sort.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32,
                                             c_uint32, c_void_p, c_void_p]
         self.lib.emu_radix_sort.restype = None

@@ -852,6 +852,28 @@ def test_coincident_points_k1_through_the_view_without_the_piles(gpu, monkeypatc
         assert full.search_knn(dq[:20_000].contiguous(), 1).numpy().tobytes() == want[:20_000].tobytes()
 
 
+@pytest.mark.parametrize("form", ["0", "1"])
+@pytest.mark.parametrize("nq", [4_097, 70_000, 1_100_000, 2_300_000])
+def test_batch_order_is_the_stable_sort_of_the_morton_keys(gpu, monkeypatch, form, nq):
+    """The order a batch is searched in (ptk_debug_batch_permutation) is the permutation a stable sort of the Morton
+    keys gives -- whichever sort makes it: the library's passes with one wavefront per tile or with blocks of four
+    (PTK_SORT_BLOCK), rocprim's above 2 M rows -- compared with the keys of the emulated key kernel sorted by numpy.
+    Sizes: a tile and one item, a few tiles, 16-bit and 24-bit keys, a last tile that is partly empty."""
+    import torch
+    from tests.emu import EmulatedTree
+
+    monkeypatch.setenv("PTK_SORT_BLOCK", form)
+    pts = ds.lidar_cloud(200_000, seed=1)
+    q = ds.lidar_cloud(nq, seed=2, pose=(3.0, 1.5))
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    got = tree.batch_permutation(torch.from_numpy(q).to(f"cuda:{gpu}")).cpu().numpy().astype(np.uint32)
+    emu = EmulatedTree(pts, 10)
+    want, keys = emu.morton_permutation(q, bits=tree.key_bits(nq))
+    assert sorted(got[:: max(1, nq // 5000)].tolist()) == sorted(set(got[:: max(1, nq // 5000)].tolist()))
+    assert np.array_equal(keys[got], keys[want])  # sorted by key ...
+    assert np.array_equal(got, want)              # ... and stable
+
+
 def test_rows_in_page_locked_blocks_of_the_pool(gpu):
     """search_knn(pts, k) returns a NEW array per call like the reference's module (def_kd_tree.cpp:73-82); here it is
     built on a page-locked block (ptk_host_alloc) the device writes directly, and the block is handed out again once
