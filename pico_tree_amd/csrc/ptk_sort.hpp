@@ -256,20 +256,17 @@ __global__ __launch_bounds__(BLOCK) void radix_block_hist_kernel(
   uint32_t key[ITEMS];
   bool valid[ITEMS];
   if (FROM_QUERIES) {
+    float x[ITEMS], y[ITEMS], z[ITEMS];  // (all the rows of a thread in flight together)
 #pragma unroll
-    for (uint32_t g = 0; g < ITEMS; g += 4u) {  // (four queries in flight per thread)
-      float x[4], y[4], z[4];
+    for (uint32_t j = 0; j < ITEMS; ++j) {
+      const uint32_t i = base + j * BLOCK + t;
+      valid[j] = i < nq;
+      load_query(queries, dim, valid[j] ? i : nq - 1u, x[j], y[j], z[j]);
+    }
 #pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
-        const uint32_t i = base + (g + u) * BLOCK + t;
-        valid[g + u] = i < nq;
-        load_query(queries, dim, valid[g + u] ? i : nq - 1u, x[u], y[u], z[u]);
-      }
-#pragma unroll
-      for (uint32_t u = 0; u < 4u; ++u) {
-        key[g + u] = order_key(x[u], y[u], z[u], lo, inv, bits, cells);
-        if (valid[g + u]) keys[base + (g + u) * BLOCK + t] = key[g + u];
-      }
+    for (uint32_t j = 0; j < ITEMS; ++j) {
+      key[j] = order_key(x[j], y[j], z[j], lo, inv, bits, cells);
+      if (valid[j]) keys[base + j * BLOCK + t] = key[j];
     }
   } else {
 #pragma unroll
