@@ -916,11 +916,23 @@ def main():
                 "value": round(other["value"], 3), "unit": "Mqueries/s", "ms_per_step": round(other["ms_per_step"], 4),
                 "queries_per_step": int(other["total"]), "parallelism": parallelism(other["weak"])}
         if world > 1 and pt.device_count() >= world and not args.no_extras:
-            # (the other ranks wait at the barrier below with their devices idle)
+            # (the other ranks wait for the key below on the host, their devices idle: a collective barrier would
+            # keep a polling kernel on every one of them while the child measures)
             result["single_process"] = run_single_process_form(args, world)
         result.update(extras)
         print(json.dumps(result), flush=True)
     if world > 1:
+        if not args.no_extras:
+            try:
+                from datetime import timedelta
+
+                store = dist.distributed_c10d._get_default_store()
+                if rank == 0:
+                    store.set("ptk_bench_single_process_done", "1")
+                else:
+                    store.wait(["ptk_bench_single_process_done"], timedelta(seconds=400))
+            except Exception:  # noqa: BLE001 -- the barrier below orders the ranks either way
+                pass
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and result is not None and not result["parity_sample_ok"]:
