@@ -202,8 +202,42 @@ def cpu_baseline_subprocess(args):
         return None
 
 
+def interleave_memory():
+    """Spreads every page this process touches from now on round-robin over the NUMA nodes with memory (what
+    `numactl --interleave=all` does; the boxes have no numactl, so the set_mempolicy system call directly).  The
+    reference builds its tree on one thread: first touch would put all of it -- and the points, and the queries -- on that
+    thread's node, and the OpenMP threads of the other socket would search it across the socket link, faster or
+    slower by whichever socket the build thread happened to start on.  Returns a description for the bench line."""
+    import ctypes
+    try:
+        nodes = sorted(int(d[4:]) for d in os.listdir("/sys/devices/system/node") if d.startswith("node") and d[4:].isdigit())
+        with_memory = []
+        for nd in nodes:
+            try:
+                with open(f"/sys/devices/system/node/node{nd}/meminfo") as f:
+                    total = [ln for ln in f if "MemTotal" in ln]
+                if total and int(total[0].split()[-2]) > 0:
+                    with_memory.append(nd)
+            except OSError:
+                pass
+        if len(with_memory) < 2:
+            return f"one NUMA node with memory ({len(nodes)} listed): nothing to interleave"
+        mask_words = max(with_memory) // 64 + 1
+        mask = (ctypes.c_ulong * mask_words)()
+        for nd in with_memory:
+            mask[nd // 64] |= 1 << (nd % 64)
+        libc = ctypes.CDLL(None, use_errno=True)
+        MPOL_INTERLEAVE, SYS_set_mempolicy = 3, 238  # x86-64
+        if libc.syscall(SYS_set_mempolicy, MPOL_INTERLEAVE, ctypes.byref(mask), mask_words * 64 + 1) != 0:
+            return f"set_mempolicy(MPOL_INTERLEAVE) failed (errno {ctypes.get_errno()}): first-touch placement"
+        return f"pages interleaved over NUMA nodes {with_memory} (set_mempolicy(MPOL_INTERLEAVE), as numactl --interleave=all)"
+    except (OSError, ValueError) as exc:
+        return f"NUMA policy left alone ({exc!r})"
+
+
 def cpu_baseline_worker(args):
     model_cores = host_cpus()  # before any OpenMP runtime is loaded and binds this thread
+    numa = interleave_memory()  # before the clouds and the tree are allocated
     from pico_tree_amd import datasets as ds
 
     if args.points:
@@ -212,16 +246,16 @@ def cpu_baseline_worker(args):
         pts, q = ds.config2_clouds(args.cloud, args.n or ds.CONFIG2_N, args.nq or ds.CONFIG2_NQ)
     if args.order == "morton":
         q = np.ascontiguousarray(q[ds.morton_order(q)])
-    print(json.dumps(cpu_baseline(pts, q, args.k, args.leaf, args.cpu_seconds, model_cores)), flush=True)
+    print(json.dumps(cpu_baseline(pts, q, args.k, args.leaf, args.cpu_seconds, model_cores, numa)), flush=True)
 
 
-def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
+def cpu_baseline(pts, q, k, leaf, seconds, cpus=None, numa=None):
     """Times the reference (oracle/_ref, compiled from the reference's own headers) or, failing that, the oracle
     port, on the host cores, on bounded samples: its OpenMP schedule(dynamic,128) loop on one pinned thread per
     physical core, and one thread alone; on the queries as given to the GPU and on a Morton-sorted copy (order alone
     moves a CPU kd-tree by an order of magnitude).  Every figure: one untimed warm-up pass over
-    a slice, then passes over fresh slices until the time budget is used, rate of the fastest pass (slowest and
-    median alongside)."""
+    a slice, then passes over fresh slices until the time budget is used; the MEDIAN and the FASTEST pass are both
+    reported, with the host's load average when the leg began (the boxes are shared: four GPU slots per host)."""
     import oracle
     from pico_tree_amd import datasets as ds
 
@@ -234,15 +268,18 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
     nsorted = min(len(q), 2_000_000)
     q_sorted = np.ascontiguousarray(q[:nsorted][ds.morton_order(q[:nsorted])])
 
-    spreads = []  # (slowest, fastest) pass of every figure, in the order they are measured
-    try:
-        load_before = [round(x, 1) for x in os.getloadavg()]  # other tenants of the host show up here
-    except OSError:
-        load_before = None
+    def loadavg():
+        try:
+            return [round(x, 1) for x in os.getloadavg()]  # other tenants of the host show up here
+        except OSError:
+            return None
 
-    def rate(queries, threads, chunk, budget, min_passes=3):
+    legs = {}
+
+    def rate(name, queries, threads, chunk, budget, min_passes=3):
         cpu.set_threads(threads)
         chunk = max(1, min(chunk, len(queries) // (min_passes + 1)))
+        load = loadavg()
         cpu.search_knn(queries[:chunk], k)  # warm-up: pages touched, threads started
         rates, at, used = [], chunk, 0.0
         while (used < budget or len(rates) < min_passes) and at + chunk <= len(queries):
@@ -253,39 +290,42 @@ def cpu_baseline(pts, q, k, leaf, seconds, cpus=None):
             used += dt
             at += chunk
         rates.sort()
-        spreads.append((round(rates[0], 4), round(rates[len(rates) // 2], 4), round(rates[-1], 4)))
-        # The FASTEST pass: the hosts are shared, and one OpenMP thread losing its core to another tenant for a
-        # scheduler quantum makes a 5 ms pass a 90 ms pass (passes of one run: 3.8 ... 81.4 Mqueries/s) -- noise can
-        # only slow the baseline down, so its best pass is the figure that does it justice and that repeats.
-        return rates[-1], at - chunk, len(rates)
+        legs[name] = {"fastest": round(rates[-1], 4), "median": round(rates[len(rates) // 2], 4),
+                      "slowest": round(rates[0], 4), "passes": len(rates), "queries_per_pass": chunk,
+                      "threads": threads, "host_loadavg": load}
+        return legs[name]
 
-    # (passes of the all-cores legs long enough -- tens of milliseconds -- that one descheduled thread does not decide them)
-    omp, n_omp, p_omp = rate(q, cores, 1_600_000, seconds * 0.45)
-    omp_sorted, n_omps, p_omps = rate(q_sorted, cores, 1_600_000, seconds * 0.15)
-    one, n_one, p_one = rate(q, 1, 50_000, max(1.0, seconds * 0.25))
-    one_sorted, n_ones, p_ones = rate(q_sorted, 1, 100_000, max(1.0, seconds * 0.15))
+    # (passes of the all-cores legs long enough -- tens of milliseconds -- that one descheduled thread does not decide
+    # them; every pass takes a FRESH slice of the batch, so nothing is served from a cache warmed by the pass before)
+    omp = rate("value", q, cores, 1_600_000, seconds * 0.45)
+    omp_sorted = rate("morton_sorted_queries_value", q_sorted, cores, 400_000, seconds * 0.15)
+    one = rate("single_thread_value", q, 1, 50_000, max(1.0, seconds * 0.25))
+    one_sorted = rate("single_thread_morton_sorted_value", q_sorted, 1, 100_000, max(1.0, seconds * 0.15))
     cpu.close()
-    return {"value": round(omp, 4), "unit": "Mqueries/s", "cores": cores, "kind": kind,
+    return {"value": omp["fastest"], "value_median": omp["median"], "unit": "Mqueries/s", "cores": cores, "kind": kind,
             "cpu": model, "sockets": sockets, "logical_cpus": logical,
             "threads": f"{cores} (one per physical core; OMP_PLACES={os.environ.get('OMP_PLACES')}, "
                        f"OMP_PROC_BIND={os.environ.get('OMP_PROC_BIND')})",
-            "sample": f"OpenMP schedule(dynamic,128): warm-up + {p_omp} passes of up to 1600000 queries in the order given to "
-                      f"the GPU ({n_omp} queries), fastest pass",
-            "morton_sorted_queries_value": round(omp_sorted, 4),
-            "morton_sorted_queries_sample": f"the first {nsorted} queries Morton-sorted, warm-up + {p_omps} passes, "
-                                            f"fastest pass ({n_omps} queries)",
-            "single_thread_value": round(one, 4),
-            "single_thread_sample": f"warm-up + {p_one} passes of 50000 queries as given ({n_one} queries), fastest pass",
-            "single_thread_morton_sorted_value": round(one_sorted, 4),
-            "single_thread_morton_sorted_sample": f"warm-up + {p_ones} passes of 100000 sorted queries ({n_ones} queries)",
+            "numa": numa,
+            "sample": f"OpenMP schedule(dynamic,128): warm-up + {omp['passes']} passes of {omp['queries_per_pass']} fresh "
+                      f"queries each, in the order given to the GPU; `value` = fastest pass, `value_median` = median pass",
+            "morton_sorted_queries_value": omp_sorted["fastest"],
+            "morton_sorted_queries_value_median": omp_sorted["median"],
+            "morton_sorted_queries_sample": f"the first {nsorted} queries Morton-sorted, warm-up + {omp_sorted['passes']} passes "
+                                            f"of {omp_sorted['queries_per_pass']} fresh queries",
+            "single_thread_value": one["fastest"], "single_thread_value_median": one["median"],
+            "single_thread_sample": f"warm-up + {one['passes']} passes of {one['queries_per_pass']} queries as given",
+            "single_thread_morton_sorted_value": one_sorted["fastest"],
+            "single_thread_morton_sorted_value_median": one_sorted["median"],
+            "single_thread_morton_sorted_sample": f"warm-up + {one_sorted['passes']} passes of {one_sorted['queries_per_pass']} sorted queries",
             "build_s": round(build_s, 3),
-            "slowest_median_fastest_pass": {"value": spreads[0], "morton_sorted_queries_value": spreads[1],
-                                     "single_thread_value": spreads[2], "single_thread_morton_sorted_value": spreads[3]},
-            "host_loadavg_before": load_before,
-            "note": "every figure is the fastest pass: the bench boxes are shared (four GPU slots per host), and when one "
-                    "of the 128 pinned threads loses its core for a scheduler quantum a 5 ms pass takes 90 ms -- the "
-                    "median pass of the all-cores figure has been 4.5 or 80 Mqueries/s from run to run, the fastest "
-                    "79-86 (profiles/r03_notes.txt items 15, 26)"}
+            "legs": legs,
+            "note": "the hosts are shared and the as-given all-cores figure is cache- and NUMA-bound (7.7 M incoherent "
+                    "queries over a 163 MB tree): driver-run figures of earlier rounds were 77.5 (r03) and 31.4 (r04) "
+                    "Mqueries/s on the same code.  Since r05 the worker interleaves its pages over the NUMA nodes and "
+                    "reports median and fastest pass with the load average of each leg; the figure that repeats is the "
+                    "Morton-sorted one, and the GPU/CPU ratio of DESIGN.md section 8 is quoted against THAT (the "
+                    "reference's best case), never against the as-given figure"}
 
 
 def time_device_knn(tree, dq, k, steps, warmup=2):

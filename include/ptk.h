@@ -434,6 +434,13 @@ int ptk_profile_get_sized(const ptk_tree* tree, void* out, uint64_t size, int re
  * cooperative search, [2] = queries that search could not certify (redone by the reference
  * traversal from the root), [3] = queries of the classes dealt across wavefronts. */
 int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
+/* After a k-NN search with 1 < k <= 32 on a 3-D tree (default metric, exact): {queries the general kernel handed to the
+ * cooperative search because they had entered more than PTK_KNN_CAP far children, queries that search could not certify
+ * and the reference search redid, and why: a pool of subtrees and its spill that overflowed, more equal distances
+ * than the second sweep can rank, a box distance above the k-th distance on the way to a neighbour, a k-th distance
+ * outside [1e-30, 1e30]; last: queries whose equal distances a second sweep put in the reference's order}.
+ * Synchronises the device. */
+int ptk_debug_knn_coop_counts(const ptk_tree* tree, uint32_t counts[7]);
 /* Piles -- subtrees all of whose points are one and the same point (the reference's builder peels one of them off per
  * level, kd_tree_builder.hpp:255-275) -- of this handle's device replica (dim <= 3): out[0] = piles, [1] = points they
  * hold, [2] = depth of the view without them that the k = 1 searches of the default metric traverse (0 piles: the tree

@@ -144,6 +144,7 @@ _SIGNATURES = {
     "ptk_debug_create_phases": (c_int, [c_void_p, POINTER(c_double)]),
     "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
     "ptk_debug_batch_order": (c_int, [c_void_p, POINTER(c_int)]),
+    "ptk_debug_knn_coop_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
                                              POINTER(c_void_p)]),
     "ptk_multi_create": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p)]),
@@ -624,6 +625,15 @@ class KdTree:
         c = (c_uint32 * 4)()
         _check(_load().ptk_debug_knn1_counts(self._h, c))
         return {"phase2": int(c[0]), "cooperative": int(c[1]), "redone": int(c[2]), "dealt": int(c[3])}
+
+    def knn_coop_counts(self) -> dict:
+        """After a search with 1 < k <= 32: queries the general kernel handed to the cooperative search, queries that
+        search sent to the redo list and why (``ptk_debug_knn_coop_counts``)."""
+        self._float32_only("knn_coop_counts()")
+        c = (c_uint32 * 7)()
+        _check(_load().ptk_debug_knn_coop_counts(self._h, c))
+        return {"cooperative": int(c[0]), "redone": int(c[1]), "pool": int(c[2]), "ties": int(c[3]), "box": int(c[4]),
+                "range": int(c[5]), "tie_sweeps": int(c[6])}
 
     def piles(self) -> dict:
         """Subtrees of coincident points of the device replica (``ptk_debug_piles``): how many, the points they hold,

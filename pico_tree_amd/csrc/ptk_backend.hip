@@ -33,6 +33,7 @@
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_lists.hpp"
+#include "ptk_kernels_coopk.hpp"
 #include "ptk_piles.hpp"
 // Geometry of the launches (measured optima, profiles/r02_notes.txt item 23, r03_notes.txt item 13):
 constexpr int kP2Ring = 12;   // LDS ring of the capped phase 2 (records per lane; 8 / 10 / 16: 1.335 / 1.329 / 1.308 vs 1.224 ms)
@@ -1122,16 +1123,73 @@ int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64
   return PTK_OK;
 }
 
+// Far children a query of the general k-NN kernel may enter before it is handed to the cooperative search
+// (ptk_kernels_coopk.hpp; PTK_KNN_CAP, 0 = every query runs to its end in its lane).  Exact searches with the default
+// metric only: the argument that makes the merged result the reference's needs e = 1 and the error bounds of a sum of
+// squares.
+constexpr int kKnnCoopPool = 128;
+constexpr uint32_t kKnnCoopSpill = 2048;  // tasks a wavefront of the cooperative search can park in HBM
+uint32_t knn_coop_blocks(const ptk_tree* t) { return (uint32_t)t->cus * (uint32_t)std::max(1, env_int("PTK_KNN_COOP_WAVES", 24)); }
+uint32_t knn_cap(float e, uint64_t nq) {
+  if (e != 1.0f || nq < 4096) return 0;
+  return (uint32_t)std::max(0, env_int("PTK_KNN_CAP", 256));
+}
+uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 64, std::min<uint64_t>(nq, 8192)); }
+size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
+  return 3 * (nq * 4) + knn_max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + ptk::kMetaWords * 4 +
+         (size_t)knn_coop_blocks(t) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
+}
+
 // k <= 32: the k-list in registers (K = 4 / 8 / 16 / 32 slots compiled).
 template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
-                   ptk::Neighbor* d_out, hipStream_t s) {
+                   ptk::Neighbor* d_out, hipStream_t s, Scratch* scratch = nullptr) {
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
+  if constexpr (std::is_same<M, ptk::MetricL2>::value && BLOCK == 64) {
+    const uint32_t cap = scratch != nullptr ? knn_cap(e, nq) : 0u;
+    if (cap != 0u) {
+      // The capped launch, the cooperative search of what it handed over, the reference search of what that could
+      // not certify: three launches in stream order, the counts stay on the device.
+      ptk::Handover ho{};
+      ho.counter = ptk::kMetaHeavy;
+      ho.meta = scratch->take<uint32_t>(ptk::kMetaWords);
+      ho.heavy_list = scratch->take<uint32_t>(nq);
+      ho.ntasks = scratch->take<uint32_t>(nq);
+      ho.max_heavy = (uint32_t)knn_max_handover(nq);
+      ho.tasks = scratch->take<ptk::Task>((size_t)ho.max_heavy * ptk::kMaxTasks);
+      uint32_t* redo_list = scratch->take<uint32_t>(nq);
+      const uint32_t coop_blocks = knn_coop_blocks(t);
+      ptk::Task* spill = scratch->take<ptk::Task>((size_t)coop_blocks * kKnnCoopSpill);
+      if (!ho.meta || !ho.heavy_list || !ho.ntasks || !ho.tasks || !redo_list || !spill)
+        return fail(PTK_ERR_NOMEM, "scratch block too small");
+      scratch->note_meta(ho.meta);
+      PTK_HIP(hipMemsetAsync(ho.meta, 0, ptk::kMetaWords * 4, s));
+      const size_t coop_smem = (size_t)ptk::knn_coop_lds_words(kKnnCoopPool) * 4;
+      const uint2* ranges = static_cast<const uint2*>(t->d_ranges);
+#define PTK_LAUNCH_REG(KK)                                                                                              \
+  do {                                                                                                                  \
+    hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M, true>), dim3(blocks), dim3(BLOCK), smem, s,     \
+                       t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out, cap, ho);                                 \
+    hipLaunchKernelGGL((ptk::knn_coop_kernel<KK, kKnnCoopPool>), dim3(coop_blocks), dim3(64), coop_smem, s, t->dev,      \
+                       ranges, d_q, t->dim, k, d_out, ho, redo_list, ptk::kMetaRedo, spill, kKnnCoopSpill);             \
+    hipLaunchKernelGGL((ptk::knn_redo_kernel<KK, S, OVF, LEAFB, M>), dim3(t->cus), dim3(64), smem, s, t->dev, d_q,       \
+                       t->dim, k, inv_ratio(e), d_out, ho.meta, ptk::kMetaRedo, redo_list);                             \
+  } while (0)
+      if (k <= 4) PTK_LAUNCH_REG(4);
+      else if (k <= 8) PTK_LAUNCH_REG(8);
+      else if (k <= 16) PTK_LAUNCH_REG(16);
+      else PTK_LAUNCH_REG(32);
+#undef PTK_LAUNCH_REG
+      PTK_HIP(hipGetLastError());
+      timer.stop(0, nq);
+      return PTK_OK;
+    }
+  }
 #define PTK_LAUNCH_REG(KK)                                                                                          \
   hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q, \
-                     t->dim, perm, nq, k, inv_ratio(e), d_out)
+                     t->dim, perm, nq, k, inv_ratio(e), d_out, 0u, ptk::Handover{})
   if (k <= 4) PTK_LAUNCH_REG(4);
   else if (k <= 8) PTK_LAUNCH_REG(8);
   else if (k <= 16) PTK_LAUNCH_REG(16);
@@ -2158,7 +2216,8 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
-                       (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(t, nq) : 0));
+                       (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(t, nq) : 0) +
+                       (k > 1 && k <= 32 && l2 && t->dim <= 3 && knn_cap(e, nq) != 0u ? knn_coop_scratch_bytes(t, nq) : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
   if (reorder) {  // Morton order along the first three axes, whatever the dimension
@@ -2176,7 +2235,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else if (k <= 32 && !short_tree) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_knn_reg<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_knn_reg<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, &scratch))));
   } else {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
   }
@@ -3061,6 +3120,32 @@ int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
   return PTK_OK;
 }
 
+int ptk_debug_knn_coop_counts(const ptk_tree* t, uint32_t counts[7]) {
+  if (t == nullptr || counts == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (t->device < 0) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
+  DeviceGuard guard(t->device);
+  Workspace* holder = nullptr;
+  for (int i = 0; i <= ptk_tree::kExtraWs && holder == nullptr; ++i) {
+    Workspace& w = i == 0 ? t->ws : t->extra_ws[i - 1];
+    std::lock_guard<std::mutex> lock(w.mutex);
+    if (w.last_meta != nullptr) holder = &w;
+  }
+  if (holder == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle left no counters");
+  std::lock_guard<std::mutex> lock(holder->mutex);
+  if (holder->last_meta == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle left no counters");
+  uint32_t meta[ptk::kMetaWords];
+  PTK_HIP(hipDeviceSynchronize());
+  PTK_HIP(hipMemcpy(meta, holder->last_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  counts[0] = meta[ptk::kMetaHeavy];
+  counts[1] = meta[ptk::kMetaRedo];
+  counts[2] = meta[ptk::kKnnWhyPool];
+  counts[3] = meta[ptk::kKnnWhyTie];
+  counts[4] = meta[ptk::kKnnWhyBox];
+  counts[5] = meta[ptk::kKnnWhyRange];
+  counts[6] = meta[ptk::kKnnTieSweeps];
+  return PTK_OK;
+}
+
 int ptk_debug_piles(const ptk_tree* t, uint64_t out[3]) {
   if (t == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   if (t->device < 0) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
@@ -3075,6 +3160,16 @@ int ptk_debug_create_phases(const ptk_tree* t, double ms[3]) {
   for (int i = 0; i < 3; ++i) ms[i] = t->create_ms[i];
   return PTK_OK;
 }
+
+#if defined(PTK_WAVE_TRACE)
+// Experiment builds only (tools/wave_trace.py): where the general kernels leave {start, end, hardware id, cycles} of
+// every wavefront (device memory, 32 bytes per block of the next launch; null = off).  Not declared in ptk.h.
+int ptk_debug_wave_trace(void* d_trace) {
+  unsigned long long* p = static_cast<unsigned long long*>(d_trace);
+  PTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ptk::g_wave_trace), &p, sizeof(p)));
+  return PTK_OK;
+}
+#endif
 
 int ptk_debug_batch_order(const ptk_tree* t, int* how) {
   if (t == nullptr || how == nullptr) return fail(PTK_ERR_INVALID, "null argument");

@@ -1007,6 +1007,29 @@ __device__ __forceinline__ void pad_query(uint32_t dim, float& y, float& z) {
 
 extern __shared__ __attribute__((aligned(16))) unsigned char ptk_smem[];
 
+// Experiment builds only (PTK_EXTRA_FLAGS=-DPTK_WAVE_TRACE, tools/wave_trace.py): when and where every wavefront of
+// the general kernels ran -- {start, end} of the 100 MHz wall clock and the hardware id -- to tell a kernel that is
+// bound by its throughput from one that waits for a tail of slow wavefronts.  The shipped library has none of this.
+#if defined(PTK_WAVE_TRACE)
+__device__ unsigned long long* g_wave_trace = nullptr;  // [4 * blocks of the launch]
+#endif
+#if defined(PTK_WAVE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
+#define PTK_TRACE_BEGIN() const unsigned long long trace_t0_ = wall_clock64(); const unsigned long long trace_c0_ = clock64()
+#define PTK_TRACE_END()                                                                                  \
+  do {                                                                                                   \
+    if (g_wave_trace != nullptr && threadIdx.x == 0) {                                                   \
+      g_wave_trace[4ull * blockIdx.x + 0] = trace_t0_;                                                   \
+      g_wave_trace[4ull * blockIdx.x + 1] = wall_clock64();                                              \
+      g_wave_trace[4ull * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |  \
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32); /* HW_ID | XCC_ID << 32 */ \
+      g_wave_trace[4ull * blockIdx.x + 3] = clock64() - trace_c0_;                                         \
+    }                                                                                                    \
+  } while (0)
+#else
+#define PTK_TRACE_BEGIN() ((void)0)
+#define PTK_TRACE_END() ((void)0)
+#endif
+
 // ---- general k -------------------------------------------------------------------------
 // LIST_LDS: the k-list lives in LDS behind the stack ([slot][lane]) and is copied
 // to the output row at the end; otherwise the output row itself is the list.
@@ -1050,11 +1073,14 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   }
 }
 
-template <int K, int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2>
+// CAPPED: a query that has entered more than `cap` far children stops; its list (in its row, as always) and its
+// stack (`ho`) go to knn_coop_kernel (ptk_kernels_coopk.hpp), which finishes it with a whole wavefront.
+template <int K, int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2, bool CAPPED = false>
 __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
-    Neighbor* __restrict__ out) {
+    Neighbor* __restrict__ out, uint32_t cap = 0, Handover ho = Handover{}) {
+  PTK_TRACE_BEGIN();
   const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
   const uint64_t i = (uint64_t)tile * BLOCK + threadIdx.x;
   if (i >= nq) return;
@@ -1067,7 +1093,12 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
   st.init((LdsWord*)ptk_smem, threadIdx.x, spill);
   KnnRegPolicy<K> pol;
   pol.init(k, e_inv);
-  traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
+  if constexpr (CAPPED) {
+    ho.slot = (uint32_t)qi;
+    traverse<LEAFB, false, M, true>(t, qx, qy, qz, pol, st, cap, &ho);
+  } else {
+    traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
+  }
 #if defined(__HIP_DEVICE_COMPILE__)
   // Full lists of a full wavefront leave through the LDS the stack no longer needs: a lane's K entries are one
   // row of K x 8 bytes, and K lanes write it with ONE store (whole 64-byte sectors) instead of each lane writing
@@ -1094,6 +1125,7 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
         const uint32_t q_r = (uint32_t)__shfl((int)(uint32_t)qi, (int)r);
         dst[(uint64_t)q_r * K + e] = rows[r * K + ((e + r) & (K - 1))];
       }
+      PTK_TRACE_END();
       return;
     }
   }

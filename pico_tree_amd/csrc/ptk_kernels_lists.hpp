@@ -157,6 +157,7 @@ template <int S, int OVF, int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(64) void radius_list_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
     float radius, float e_inv, uint64_t* __restrict__ counts, RadiusCapture cap) {
+  PTK_TRACE_BEGIN();
   const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
   const uint64_t i = (uint64_t)tile * 64u + threadIdx.x;
   ListTable* table = (ListTable*)(ptk_smem + (size_t)S * 64 * 8);
@@ -200,6 +201,7 @@ __global__ __launch_bounds__(64) void radius_list_kernel(
   const uint32_t have = table[0];
   if (have != kLogEnd && threadIdx.x < have) cap.tables[(uint64_t)tile * kListMaxChunks + threadIdx.x] = table[1u + threadIdx.x];
   if (threadIdx.x == 0) cap.captured[tile] = have != kLogEnd ? 1 : 0;
+  PTK_TRACE_END();
 #else
   // (one lane at a time: the last lane's view of the table is the wavefront's)
   const uint32_t have = table[0];

@@ -27,6 +27,7 @@ thread_local dim3 blockDim;
 #include "ptk_encode.hpp"
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_lists.hpp"
+#include "ptk_kernels_coopk.hpp"
 #include "ptk_piles.hpp"
 #include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
@@ -398,6 +399,39 @@ void emu_radius_topo(Emu* t, const float* q, uint64_t nq, float radius, float e_
     for_each_lane(nq, [&] { ptk::radius_topo_kernel<16, 2048, true, T>(t->dev, q, t->dim, perm, nq, radius, e_inv, nullptr, offsets, o); }, 64);
 }
 
+// The general k-NN search with its long queries finished cooperatively (ptk_kernels_coopk.hpp): the capped launch
+// (lanes one after the other), knn_coop_kernel (64 fibers per wavefront: ballots, shuffles, the shared pool), the
+// reference search of what could not be certified.  counts = {queries handed over, queries redone}.
+// pool_small != 0: a pool of 64 subtrees (overflows on long searches: the redo path).
+template <int K>
+int emu_knn_capped_k(Emu* t, const float* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap, int pool_small,
+                     uint32_t max_heavy, ptk::Neighbor* o, uint32_t* counts) {
+  std::vector<uint32_t> meta(ptk::kMetaWords, 0), heavy(nq + 1), ntasks(nq + 1), redo(nq + 1);
+  std::vector<ptk::Task> tasks((size_t)std::max<uint32_t>(max_heavy, 1) * ptk::kMaxTasks);
+  ptk::Handover ho{};
+  ho.counter = ptk::kMetaHeavy;
+  ho.meta = meta.data();
+  ho.heavy_list = heavy.data();
+  ho.ntasks = ntasks.data();
+  ho.tasks = tasks.data();
+  ho.max_heavy = max_heavy;
+  for_each_lane(nq, [&] { ptk::knn_reg_kernel<K, 16, 2048, 64, 4, ptk::MetricL2, true>(t->dev, q, t->dim, perm, nq, k, 1.0f, o, cap, ho); }, 64);
+  // (pool_small: a pool of 64 subtrees and 40 spill slots per wavefront -- long searches park subtrees in HBM and a
+  // few overflow even that: the redo path)
+  const uint32_t spill_cap = pool_small ? 40u : 4096u;
+  std::vector<ptk::Task> spill((size_t)3 * spill_cap);
+  const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
+  for_each_wave(3, [&] {
+    if (pool_small) ptk::knn_coop_kernel<K, 64>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
+    else ptk::knn_coop_kernel<K, 128>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
+  });
+  for_each_lane(128, [&] { ptk::knn_redo_kernel<K, 16, 2048, 4>(t->dev, q, t->dim, k, 1.0f, o, meta.data(), ptk::kMetaRedo, redo.data()); }, 64);
+  counts[0] = meta[ptk::kMetaHeavy];
+  counts[1] = meta[ptk::kMetaRedo];
+  counts[2] = meta[ptk::kKnnTieSweeps];
+  return 0;
+}
+
 extern "C" {
 
 const char* emu_last_error() { return g_err.c_str(); }
@@ -548,6 +582,18 @@ int emu_knn(void* h, const float* q, uint64_t nq, uint32_t k, float e, const uin
     for_each_lane(nq, [&] { ptk::knn_kernel<16, 2048, 256, 8, false>(t->dev, q, t->dim, perm, nq, k, e_inv, o); }, 256);
   }
   return 0;
+}
+
+int emu_knn_capped(void* h, const float* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap, int pool_small,
+                   uint32_t max_heavy, ptk_neighbor* out, uint32_t* counts) {
+  auto* t = static_cast<Emu*>(h);
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  if (t->dim > 3 || t->metric != 0 || k < 1 || k > 32) return -2;
+  if (2 * t->st.max_depth + 2 > 16 + 2048) return -2;
+  if (k <= 4) return emu_knn_capped_k<4>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
+  if (k <= 8) return emu_knn_capped_k<8>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
+  if (k <= 16) return emu_knn_capped_k<16>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
+  return emu_knn_capped_k<32>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
 }
 
 int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,

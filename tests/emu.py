@@ -71,6 +71,22 @@ class EmulatedTree:
         assert rc == 0
         return out
 
+    def search_knn_capped(self, q, k, cap, perm=None, pool_small=False, max_heavy=None):
+        """The general k-NN kernel capped at `cap` far children per query, the cooperative search of what it handed
+        over and the reference search of what that could not certify (ptk_kernels_coopk.hpp).
+        Returns (rows, queries handed over, queries redone); `last_tie_sweeps` = queries that took the second sweep."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        out = np.zeros((len(q), k), dtype=pt.NEIGHBOR)
+        counts = np.zeros(3, dtype=np.uint32)
+        fn = self.lib.emu_knn_capped
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint32, c_int, c_uint32, c_void_p, c_void_p]
+        rc = fn(self.h, q.ctypes.data, len(q), k, perm.ctypes.data if perm is not None else None, cap,
+                int(pool_small), len(q) if max_heavy is None else max_heavy, out.ctypes.data, counts.ctypes.data)
+        assert rc == 0
+        self.last_tie_sweeps = int(counts[2])
+        return out, int(counts[0]), int(counts[1])
+
     def search_radius(self, q, radius, sort=False, e=None, perm=None):
         q = np.ascontiguousarray(q, dtype=np.float32)
         nq = len(q)

@@ -250,6 +250,42 @@ def test_emulated_capped_phase2_and_cooperative_search_equal_oracle(case):
         assert stats[5][0] == 0 and stats[5][1] == 0
 
 
+@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "ties", "lidar", "root-is-leaf", "dim2",
+                                                                  "leaf1")], ids=lambda c: c[0])
+def test_emulated_capped_knn_and_its_cooperative_search_equal_oracle(case):
+    """k > 1: the general kernel capped at a few far children per query, knn_coop_kernel (one wavefront of fibers per
+    query handed over, every lane a k-list of its own, merged at the end) and the reference search of what that
+    cannot certify -- equal distances within or at the edge of the k nearest (lattice clouds) must come back through
+    the redo list -- equal the reference for every k-list size compiled."""
+    name, pts, q, leaf, _ = case
+    q = q[:100] if name == "ties" else q[:200]
+    if name == "lidar":
+        q = np.concatenate([q[:100], _blind_disc_queries(100)])
+    emu = EmulatedTree(pts, leaf)
+    ref = oracle.Oracle(pts, leaf, "port")
+    perm, _ = emu.morton_permutation(q)
+    seen = {}
+    for k in (2, 7, 16, 20):
+        kk = min(k, len(pts))
+        want = ref.search_knn(q, kk)
+        for cap, p, small in ((2, None, False), (1, perm, True)):
+            got, heavy, redo = emu.search_knn_capped(q, kk, cap, perm=p, pool_small=small)
+            assert got.tobytes() == want.tobytes(), (name, k, cap)
+            seen[(k, cap)] = (heavy, redo)
+    # more hand-overs than the task block holds: the rest is searched again from the root
+    kk = min(7, len(pts))
+    got, heavy, redo = emu.search_knn_capped(q, kk, 1, max_heavy=3)
+    assert got.tobytes() == ref.search_knn(q, kk).tobytes(), (name, "max_heavy")
+    if name in ("uniform", "lidar"):
+        assert heavy > 3 and redo >= heavy - 3
+    if name in ("uniform", "lidar", "ties"):
+        assert seen[(16, 2)][0] > 0                                   # the cap does hand queries over
+    if name in ("uniform", "lidar"):
+        assert seen[(16, 2)][1] <= max(2, seen[(16, 2)][0] // 20)     # generic data: (almost) nothing to redo
+    if name == "ties":                        # equal distances everywhere: second sweeps, crowded ones redone, still exact
+        assert seen[(16, 2)][1] > 0 and emu.last_tie_sweeps > 0
+
+
 def test_emulated_direct_cooperative_search_parks_subtrees_in_hbm():
     """Variant 9 = the small-batch form: the ranked classes go straight from phase 1 to the cooperative search.  Its
     emulated launch has a pool of 12 subtrees per group, so the queries of the scanner's blind disc (hundreds of

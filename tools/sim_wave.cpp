@@ -52,19 +52,37 @@ struct Query {
 };
 
 // k-NN list as the reference keeps it (sorted, stable).
+// SIM_DEFER=Q (environment): accepted candidates wait in a queue of Q per lane and the bound the traversal prunes with
+// is the k-th distance as of the last insertion (stale, never too small); when the queue is full its oldest entry is
+// inserted (the wavefront-level policy -- one pass whenever ANY lane is full -- drains a lane sooner than this: the
+// model is the stalest the bound can get).
+static int g_defer = getenv("SIM_DEFER") ? atoi(getenv("SIM_DEFER")) : 0;
 struct KList {
   int k;
   std::vector<float> d;
+  std::vector<float> pend;
   explicit KList(int kk) : k(kk), d(kk, 3.402823466e+38f) {}
   float max() const { return d[k - 1]; }
-  bool visit(float x) {
-    if (!(d[k - 1] > x)) return false;
+  void insert(float x) {
+    if (!(d[k - 1] > x)) return;
     int j = k - 1;
     while (j > 0 && x < d[j - 1]) {
       d[j] = d[j - 1];
       --j;
     }
     d[j] = x;
+  }
+  bool visit(float x) {
+    if (!(d[k - 1] > x)) return false;
+    if (g_defer > 0) {
+      pend.push_back(x);
+      if ((int)pend.size() >= g_defer) {
+        insert(pend.front());
+        pend.erase(pend.begin());
+      }
+      return true;
+    }
+    insert(x);
     return true;
   }
 };
@@ -166,10 +184,11 @@ struct WaveStats {
   Region desc, round, visit, chain, unwind, enter;
   double turns = 0, lane_turns = 0;
   double chain_defer = 0;  // chain executions if a turn's accepted points were inserted max-per-lane at a time
+  Region chain_q;          // SIM_DEFER: passes of the wavefront-level queue policy (one pass whenever any lane is full)
   void operator+=(const WaveStats& o) {
     auto a = [](Region& x, const Region& y) { x.execs += y.execs; x.lanes += y.lanes; };
     a(desc, o.desc); a(round, o.round); a(visit, o.visit); a(chain, o.chain); a(unwind, o.unwind); a(enter, o.enter);
-    turns += o.turns; lane_turns += o.lane_turns; chain_defer += o.chain_defer;
+    turns += o.turns; lane_turns += o.lane_turns; chain_defer += o.chain_defer; a(chain_q, o.chain_q);
   }
 };
 
@@ -177,6 +196,13 @@ struct WaveStats {
 static WaveStats run_wave(const std::vector<const Query*>& lanes, const std::vector<uint32_t>& start) {
   WaveStats s;
   const int n = (int)lanes.size();
+  std::vector<int> pending(n, 0);
+  auto pass = [&]() {
+    int a = 0;
+    for (int l = 0; l < n; ++l)
+      if (pending[l] > 0) --pending[l], ++a;
+    s.chain_q.add(a);
+  };
   for (uint32_t t = 0;; ++t) {
     int alive = 0;
     uint32_t max_desc = 0, max_cnt = 0;
@@ -188,7 +214,15 @@ static WaveStats run_wave(const std::vector<const Query*>& lanes, const std::vec
       max_desc = std::max<uint32_t>(max_desc, u.ndesc);
       max_cnt = std::max<uint32_t>(max_cnt, u.count);
     }
-    if (!alive) break;
+    if (!alive) {
+      for (;;) {  // what is left when the last lane has finished
+        int mx = 0;
+        for (int l = 0; l < n; ++l) mx = std::max(mx, pending[l]);
+        if (mx == 0) break;
+        pass();
+      }
+      break;
+    }
     s.turns += 1;
     s.lane_turns += alive;
     for (uint32_t i = 0; i < max_desc; ++i) {
@@ -220,10 +254,18 @@ static WaveStats run_wave(const std::vector<const Query*>& lanes, const std::vec
           if (tt >= lanes[l]->turns.size()) continue;
           const Turn& x = lanes[l]->turns[tt];
           if (x.count > p) ++av;
-          if (x.accept & (1u << p)) ++ac;
+          if (x.accept & (1u << p)) ++ac, ++pending[l];
         }
         s.visit.add(av);
         s.chain.add(ac);
+        if (g_defer > 0) {
+          for (;;) {
+            bool full = false;
+            for (int l = 0; l < n; ++l) full = full || pending[l] >= g_defer;
+            if (!full) break;
+            pass();
+          }
+        }
       }
     }
     int ent = 0;
@@ -258,6 +300,10 @@ static void report(const char* name, const WaveStats& s, double waves, int K) {
   row("enter", s.enter, c_enter);
   printf("   est. vector instructions per wave %.0f, active-lane fraction %.3f; chain execs if deferred per turn: %.1f/wave\n",
          inst / waves, lanes / (64.0 * inst), s.chain_defer / waves);
+  if (g_defer > 0)
+    printf("   queue of %d per lane: %.1f passes/wave at %.1f lanes; est. instr/wave with the chain run per pass %.0f\n", g_defer,
+           s.chain_q.execs / waves, s.chain_q.execs ? s.chain_q.lanes / s.chain_q.execs : 0.0,
+           (inst - s.chain.execs * c_chain + s.chain_q.execs * (c_chain + 8) + s.visit.execs * 4 + s.round.execs * 4) / waves);
 }
 
 int main(int argc, char** argv) {
