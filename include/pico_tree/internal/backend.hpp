@@ -18,6 +18,7 @@
 #include <sstream>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <type_traits>
 #include <vector>
@@ -86,8 +87,20 @@ inline void host_rows_loop(std::size_t n, Fn_ fn) {
       next.store(n);
     }
   };
+  // (a thread that cannot be started is one worker fewer; the threads that did start are joined on every way out)
   std::vector<std::thread> pool;
-  for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+  struct join_all {
+    std::vector<std::thread>& threads;
+    ~join_all() {
+      for (auto& t : threads)
+        if (t.joinable()) t.join();
+    }
+  } joiner{pool};
+  try {
+    pool.reserve(workers);
+    for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+  } catch (std::system_error const&) {
+  }
   work();
   for (auto& t : pool) t.join();
   if (failure) std::rethrow_exception(failure);

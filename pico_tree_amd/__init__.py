@@ -31,7 +31,7 @@ import numpy as np
 from . import datasets  # noqa: F401  (re-export)
 
 __all__ = ["KdTree", "KdForest", "save_kd_tree", "load_kd_tree", "Metric", "NEIGHBOR", "NEIGHBOR64", "DArray", "DeviceNeighbors", "PtkError",
-           "library_path", "device_count", "datasets"]
+           "library_path", "device_count", "datasets", "trim_pinned_pool"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "csrc", "libptk.so")
@@ -238,19 +238,23 @@ class _PinnedPool:
     ``search_knn(pts, k)`` (def_kd_tree.cpp:73-82); a fresh 58 MB numpy array costs its first touch on every call
     (2-19 ms on the hosts of the GPU pool, profiles/r03_notes.txt item 24) and a staging copy on the way.  Here the
     rows land in page-locked blocks (``ptk_host_alloc``) that the device writes directly and that are handed out again
-    once the array built on them has been garbage-collected.  ``PTK_PINNED_POOL_MB`` (default 4096) bounds what the
-    pool holds, in use and free; beyond it -- or for small results -- plain numpy arrays are returned."""
+    once the array built on them has been garbage-collected.  ``PTK_PINNED_POOL_MB`` (default 2048) bounds what the
+    pool holds, in use and free; beyond it -- or for small results -- plain numpy arrays are returned.  A request is
+    served from the smallest idle block that holds it (within a factor of two: a workload whose batch sizes vary reuses
+    its blocks instead of pinning one per size), and when the budget is spent the idle blocks of other sizes are freed
+    before a pageable array is given out.  ``pico_tree_amd.trim_pinned_pool()`` frees every idle block."""
 
     MIN_BYTES = 1 << 20
 
     def __init__(self):
         import threading
-        self._lock = threading.Lock()
+        # (re-entrant: a block's __del__ may run -- cyclic garbage collection -- on the thread that holds the lock)
+        self._lock = threading.RLock()
         self._free = {}   # capacity -> [ptr, ...]
         self._held = 0    # bytes allocated (in use + free)
 
     def _budget(self) -> int:
-        return int(os.environ.get("PTK_PINNED_POOL_MB", "4096")) << 20
+        return int(os.environ.get("PTK_PINNED_POOL_MB", "2048")) << 20
 
     def empty(self, shape, dtype) -> np.ndarray:
         dtype = np.dtype(dtype)
@@ -259,13 +263,26 @@ class _PinnedPool:
             return np.empty(shape, dtype=dtype)
         capacity = (nbytes + (1 << 20) - 1) & ~((1 << 20) - 1)
         ptr = None
+        evict = []
         with self._lock:
-            stock = self._free.get(capacity)
-            if stock:
-                ptr = stock.pop()
-            elif self._held + capacity <= self._budget():
-                self._held += capacity
-                ptr = 0  # allocate outside the lock
+            # the smallest idle block that holds the request, if it is not more than twice as large
+            fits = sorted(c for c, stock in self._free.items() if stock and capacity <= c <= 2 * capacity)
+            if fits:
+                capacity = fits[0]
+                ptr = self._free[capacity].pop()
+            else:
+                if self._held + capacity > self._budget():  # idle blocks of other sizes make room first
+                    for c in sorted(self._free, reverse=True):
+                        while self._free[c] and self._held + capacity > self._budget():
+                            evict.append(self._free[c].pop())
+                            self._held -= c
+                if self._held + capacity <= self._budget():
+                    self._held += capacity
+                    ptr = 0  # allocate outside the lock
+        if evict:
+            lib = _load()
+            for p in evict:
+                lib.ptk_host_free(p)
         if ptr is None:
             return np.empty(shape, dtype=dtype)
         if ptr == 0:
@@ -289,15 +306,20 @@ class _PinnedPool:
         """Frees the blocks that are not in use."""
         with self._lock:
             free, self._free = self._free, {}
+            for capacity, stock in free.items():
+                self._held -= capacity * len(stock)
         lib = _load()
-        for capacity, stock in free.items():
+        for stock in free.values():
             for ptr in stock:
                 lib.ptk_host_free(ptr)
-                with self._lock:
-                    self._held -= capacity
 
 
 _pinned_pool = _PinnedPool()
+
+
+def trim_pinned_pool() -> None:
+    """Frees the page-locked result blocks that no array uses any more (the pool keeps them for the next call)."""
+    _pinned_pool.trim()
 
 
 def empty_pinned(shape, dtype=np.float32) -> np.ndarray:

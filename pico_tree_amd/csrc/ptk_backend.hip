@@ -18,6 +18,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <memory>
 #include <mutex>
 #include <new>
 #include <string>
@@ -116,11 +117,11 @@ struct Workspace {
   // (launch_knn1_two_phase); forked and joined with events, so the caller's stream still orders everything.
   hipStream_t side = nullptr;
   hipEvent_t fork = nullptr, join = nullptr;
-  // The verdict of the coherence sample of a batch (ptk::coherence_sample_kernel): a pinned host copy and the event
-  // that says it has arrived.
-  uint8_t* h_sample = nullptr;
-  hipEvent_t sampled = nullptr;
-  int last_order = 0;  // the last batch on this block: 0 = taken as it came, 1 = sorted on the device, 2 = found coherent, not sorted
+  // The coherence sample of a batch (ptk::coherence_sample_kernel): its state and verdict stay on the device.
+  uint32_t* d_sample = nullptr;             // device: {windows counted << 16 | windows failed, verdict}, zero between batches
+  const uint32_t* last_verdict = nullptr;   // the verdict word of the last batch on this block, if it was sampled
+  int last_order = 0;  // the last batch on this block: 0 = taken as it came, 1 = sorted on the device (2 = found coherent
+                       // and left alone is only known on the device: last_verdict, ptk_debug_batch_order)
 
   // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
   // it must survive until the fill pass of the same batch while other searches reuse `base`.
@@ -167,6 +168,10 @@ struct ptk_tree {
   std::vector<int32_t> indices;
   std::vector<float> root_min, root_max;
   std::vector<float> outer;  // per node {left_min, right_max} (topological metrics); may be empty
+  // The flat-tree view the host loop searches (ptk_host_loop.hpp), made on its first call and kept: the node and
+  // index arrays are copied ONCE per handle, not once per ptk_host_search_* call.  Dropped when `outer` changes.
+  mutable std::shared_ptr<const void> host_flat;
+  mutable std::mutex host_flat_mutex;
   double axis_splits[3] = {0, 0, 0};  // mean number of splits per axis on a root-to-leaf path (point-weighted)
   bool builder_made = false;  // nodes / indices come from the library's own builder: n_leaves, max_leaf_count, max_depth and
                               // axis_splits are set and the stream needs no validation
@@ -738,6 +743,7 @@ class Scratch {
     ws_.used = 0;
     ws_.last_meta = nullptr;  // whatever the last k = 1 search left in the block is about to be overwritten (or freed)
     ws_.last_order = 0;
+    ws_.last_verdict = nullptr;
     reserved_ = true;
     return PTK_OK;
   }
@@ -763,23 +769,19 @@ class Scratch {
     *join = ws_.join;
     return true;
   }
-  // Pinned host bytes for the coherence sample of this block's batch and the event behind their copy.
-  bool sample_slot(uint8_t** host, hipEvent_t* arrived) {
-    if (ws_.h_sample == nullptr &&
-        hipHostMalloc((void**)&ws_.h_sample, ptk::kCoherenceWindows, hipHostMallocDefault) != hipSuccess) {
-      ws_.h_sample = nullptr;
-      (void)hipGetLastError();
-      return false;
+  // The two device words of the coherence sample of this block's batches (made and zeroed on first use).
+  uint32_t* sample_state() {
+    if (ws_.d_sample == nullptr) {
+      if (hipMalloc((void**)&ws_.d_sample, 256) != hipSuccess || hipMemset(ws_.d_sample, 0, 256) != hipSuccess) {
+        (void)hipGetLastError();
+        if (ws_.d_sample) (void)hipFree(ws_.d_sample);
+        ws_.d_sample = nullptr;
+      }
     }
-    if (ws_.sampled == nullptr && hipEventCreateWithFlags(&ws_.sampled, hipEventDisableTiming) != hipSuccess) {
-      ws_.sampled = nullptr;
-      (void)hipGetLastError();
-      return false;
-    }
-    *host = ws_.h_sample;
-    *arrived = ws_.sampled;
-    return true;
+    return ws_.d_sample;
   }
+  void note_verdict(const uint32_t* verdict) { ws_.last_verdict = verdict; }
+  const uint32_t* batch_verdict() const { return ws_.last_verdict; }
   template <class T>
   T* take(size_t count) {
     const size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
@@ -935,43 +937,24 @@ size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_b
 // -- by the tree's coarse grid of cell occupancies, ptk::CellTable -- go to the front of the order: for the kernels that
 // run every query to its end in its lane.
 // may_skip: the batch is sampled first (ptk::coherence_sample_kernel: 256 windows of 64 consecutive rows); if it is
-// already in a coherent order -- a scan in scan order, a batch the caller sorted -- *perm stays null and the search
-// runs on the caller's order, as the reference does (_pyco_tree/kd_tree.hpp:128-134).  The verdict travels to the host
-// while the key kernel of the sort runs, so a batch that does need the sort waits for nothing.
-bool batch_is_coherent(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch, int bits,
-                       const float3& lo3, const float3& inv3, const uint3& b3, uint8_t** h_fail, hipEvent_t* arrived) {
-  *h_fail = nullptr;
-  if (nq < 8192 || env_int("PTK_COHERENCE_CHECK", 1) == 0) return false;
-  hipStreamCaptureStatus capturing = hipStreamCaptureStatusNone;
-  if (hipStreamIsCapturing(s, &capturing) != hipSuccess || capturing != hipStreamCaptureStatusNone) {
-    (void)hipGetLastError();
-    return false;  // (a captured stream cannot be waited on: the batch is sorted)
-  }
+// already in a coherent order -- a scan in scan order, a batch the caller sorted -- the kernels of the sort leave at
+// their first instruction and phase 1 of the search takes the rows in the caller's order, as the reference does
+// (_pyco_tree/kd_tree.hpp:128-134).  The verdict never leaves the device (two words of the workspace): the entry points
+// that take device buffers only enqueue, whatever the batch looks like (r04 waited for the verdict on the host).
+const uint32_t* sample_batch(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch, int bits,
+                             const float3& lo3, const float3& inv3, const uint3& b3) {
+  if (nq < 8192 || env_int("PTK_COHERENCE_CHECK", 1) == 0) return nullptr;
   uint8_t* d_fail = scratch.take<uint8_t>(ptk::kCoherenceWindows);
-  if (d_fail == nullptr || !scratch.sample_slot(h_fail, arrived)) return false;
+  uint32_t* state = scratch.sample_state();
+  if (d_fail == nullptr || state == nullptr) return nullptr;
   // 64 neighbours of a sorted batch cover about 2^bits x 64 / nq cells; five more bits of slack (the box of a window is
   // rounded up per axis, and a window may sit across a cell boundary).
   uint32_t lg = 0;
   while ((128ull << lg) <= nq) ++lg;  // floor(log2(nq / 64))
   const uint32_t max_log2 = (uint32_t)std::min(bits, std::max(bits - (int)lg, 0) + 5);
   hipLaunchKernelGGL(ptk::coherence_sample_kernel, dim3(ptk::kCoherenceWindows), dim3(64), 0, s, d_q, t->dim, nq, lo3, inv3,
-                     b3, max_log2, d_fail);
-  if (hipMemcpyAsync(*h_fail, d_fail, ptk::kCoherenceWindows, hipMemcpyDeviceToHost, s) != hipSuccess ||
-      hipEventRecord(*arrived, s) != hipSuccess) {
-    (void)hipGetLastError();
-    *h_fail = nullptr;
-  }
-  return *h_fail != nullptr;
-}
-// (after the first kernel of the sort has been enqueued) true: skip the sort
-bool coherent_verdict(const uint8_t* h_fail, hipEvent_t arrived) {
-  if (hipEventSynchronize(arrived) != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  uint32_t failing = 0;
-  for (uint32_t w = 0; w < ptk::kCoherenceWindows; ++w) failing += h_fail[w];
-  return failing * 100u <= ptk::kCoherenceWindows * 15u;  // up to 15 % of the windows may straddle a boundary
+                     b3, max_log2, d_fail, state);
+  return state + 1;
 }
 
 int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch,
@@ -1001,11 +984,12 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     cells.key_bits = (uint32_t)bits;
     cells.mode = heavy_first;
   }
-  uint8_t* h_fail = nullptr;
-  hipEvent_t arrived = nullptr;
-  const bool sampled = may_skip && batch_is_coherent(t, d_q, nq, s, scratch, bits, make_float3(lo[0], lo[1], lo[2]),
-                                                     make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]),
-                                                     &h_fail, &arrived);
+  // (only the library's own sort can leave early: the batch is sampled only when that sort runs)
+  const uint32_t* as_given = may_skip && own_sort(nq)
+                                 ? sample_batch(t, d_q, nq, s, scratch, bits, make_float3(lo[0], lo[1], lo[2]),
+                                                make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]))
+                                 : nullptr;
+  scratch.note_verdict(as_given);
   if (own_sort(nq)) {
     // Key + histogram kernel, then per 8-bit pass: scan of the digit-by-tile histogram, stable scatter (and the
     // histogram of the next digit): 3 launches per pass - 1... nothing to clear, no look-back (ptk_sort.hpp).
@@ -1030,30 +1014,26 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
       uint2* out = in == pairs_a ? pairs_b : pairs_a;
       if (blocks && first)
         hipLaunchKernelGGL((ptk::radix_block_hist_kernel<true>), dim3(tiles), dim3(ptk::kSortBlock), smem, s, d_q, t->dim,
-                           (uint32_t)nq, lo3, inv3, b3, keys, in, shift, stride, hist, cells);
+                           (uint32_t)nq, lo3, inv3, b3, keys, in, shift, stride, hist, cells, as_given);
       else if (blocks)
         hipLaunchKernelGGL((ptk::radix_block_hist_kernel<false>), dim3(tiles), dim3(ptk::kSortBlock), smem, s, d_q, t->dim,
-                           (uint32_t)nq, lo3, inv3, b3, keys, in, shift, stride, hist, ptk::CellTable{});
+                           (uint32_t)nq, lo3, inv3, b3, keys, in, shift, stride, hist, ptk::CellTable{}, as_given);
       else if (first)
         hipLaunchKernelGGL((ptk::radix_hist_kernel<true>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
-                           inv3, b3, keys, in, shift, tile, stride, hist, cells);
+                           inv3, b3, keys, in, shift, tile, stride, hist, cells, as_given);
       else
         hipLaunchKernelGGL((ptk::radix_hist_kernel<false>), dim3(tiles), dim3(64), smem, s, d_q, t->dim, (uint32_t)nq, lo3,
-                           inv3, b3, keys, in, shift, tile, stride, hist, ptk::CellTable{});
-      if (first && sampled && coherent_verdict(h_fail, arrived)) {  // (the verdict came in beside the key kernel)
-        scratch.note_order(2);
-        PTK_HIP(hipGetLastError());
-        timer.stop(1, 0);
-        return PTK_OK;
-      }
+                           inv3, b3, keys, in, shift, tile, stride, hist, ptk::CellTable{}, as_given);
+      // (the scan runs whatever the verdict: it reads `tiles` counters of every digit, whatever they hold)
       hipLaunchKernelGGL(ptk::radix_scan_kernel, dim3(ptk::kRadixBins), dim3(64), 0, s, hist, tiles, stride, totals);
 #define PTK_SCATTER(F, L)                                                                                              \
   if (blocks)                                                                                                          \
     hipLaunchKernelGGL((ptk::radix_block_scatter_kernel<F, L>), dim3(tiles), dim3(ptk::kSortBlock),                    \
-                       ptk::kSortScatterLds, s, keys, in, out, ids_out, (uint32_t)nq, shift, stride, hist, totals);    \
+                       ptk::kSortScatterLds, s, keys, in, out, ids_out, (uint32_t)nq, shift, stride, hist, totals,     \
+                       as_given);                                                                                      \
   else                                                                                                                 \
     hipLaunchKernelGGL((ptk::radix_scatter_kernel<F, L>), dim3(tiles), dim3(64), smem, s, keys, in, out, ids_out,      \
-                       (uint32_t)nq, shift, tile, stride, hist, totals)
+                       (uint32_t)nq, shift, tile, stride, hist, totals, as_given)
       if (first && last) PTK_SCATTER(true, true);
       else if (first) PTK_SCATTER(true, false);
       else if (last) PTK_SCATTER(false, true);
@@ -1067,23 +1047,11 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     timer.stop(1, 0);
     return PTK_OK;
   }
-  // (a sampled batch: the keys of the first third are computed while the verdict travels -- ~12 us of kernel hide
-  // the copy and the event -- and the rest once it says "sort")
-  const uint64_t head = sampled ? (nq / 3) & ~(uint64_t)(ptk::kBlock - 1) : nq;
-  for (int part = 0; part < 2; ++part) {
-    const uint64_t lo_row = part == 0 ? 0 : head, hi_row = part == 0 ? head : nq;
-    if (hi_row > lo_row) {
-      const uint32_t blocks = (uint32_t)((hi_row - lo_row + ptk::kBlock - 1) / ptk::kBlock);
-      hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, hi_row,
-                         make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]),
-                         make_uint3(b[0], b[1], b[2]), keys, ids, cells, lo_row);
-    }
-    if (part == 0 && sampled && coherent_verdict(h_fail, arrived)) {
-      scratch.note_order(2);
-      PTK_HIP(hipGetLastError());
-      timer.stop(1, 0);
-      return PTK_OK;
-    }
+  {
+    const uint32_t blocks = (uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock);
+    hipLaunchKernelGGL(ptk::morton_kernel, dim3(blocks), dim3(ptk::kBlock), 0, s, d_q, t->dim, nq,
+                       make_float3(lo[0], lo[1], lo[2]), make_float3(inv[0], inv[1], inv[2]),
+                       make_uint3(b[0], b[1], b[2]), keys, ids, cells, (uint64_t)0);
   }
   PTK_HIP(rocprim::radix_sort_pairs<MortonSortConfig>(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
   *perm = ids_out;
@@ -1241,8 +1209,16 @@ int launch_radius_list(const ptk_tree* t, const float* d_q, const uint32_t* perm
   const size_t smem = (size_t)S * 64 * 8 + ptk::kListLds;  // + the group buffers and the chunk table of the wavefront
   Timer timer(t, s);
   PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
-  hipLaunchKernelGGL((ptk::radius_list_kernel<S, OVF, LEAFB, M>), dim3(cap.n_static), dim3(64), smem, s, t->dev, d_q,
-                     t->dim, perm, nq, radius, inv_ratio(e), d_counts, cap);
+  // (leaves of more than kListMaskBits points -- a count of 32 needs six bits -- / an approximate search: see RadiusListPolicy)
+  const bool big = t->dev.cmask >= ptk::kListMaskBits, exact = e == 1.0f;
+#define PTK_LAUNCH_LIST(BIG, EXACT)                                                                                  \
+  hipLaunchKernelGGL((ptk::radius_list_kernel<S, OVF, LEAFB, M, BIG, EXACT>), dim3(cap.n_static), dim3(64), smem, s, \
+                     t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, cap)
+  if (big && exact) PTK_LAUNCH_LIST(true, true);
+  else if (big) PTK_LAUNCH_LIST(true, false);
+  else if (exact) PTK_LAUNCH_LIST(false, true);
+  else PTK_LAUNCH_LIST(false, false);
+#undef PTK_LAUNCH_LIST
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
   return PTK_OK;
@@ -1528,7 +1504,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // One chain of sections: search (phase 1) | other (class order) | search (phase 2, cooperative search, replay).
   Timer timer(t, s);
   hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, knn1_tree(t), d_q, t->dim, perm, nq,
-                     e_inv, d_out, cont, qs, tile_counts, cp.stride);
+                     e_inv, d_out, cont, qs, tile_counts, cp.stride, scratch.batch_verdict());
   timer.next(0, nq);
   if (cap) {
     // With the cap the order inside the heavy classes does not matter (no query runs long), only the three class
@@ -1918,8 +1894,7 @@ void ptk_tree_destroy(ptk_tree* t) {
       if (w.fork) (void)hipEventDestroy(w.fork);
       if (w.join) (void)hipEventDestroy(w.join);
       if (w.side) (void)hipStreamDestroy(w.side);
-      if (w.sampled) (void)hipEventDestroy(w.sampled);
-      if (w.h_sample) (void)hipHostFree(w.h_sample);
+      if (w.d_sample) (void)hipFree(w.d_sample);
     };
     drain_workspace(t->ws);
     drop_side(t->ws);
@@ -2074,6 +2049,10 @@ int ptk_tree_set_outer_bounds(ptk_tree* t, const float* outer, uint64_t n_nodes)
                                               (unsigned long long)n_nodes, t->nodes.size());
   try {
     t->outer.assign(outer, outer + 2 * n_nodes);
+    {
+      std::lock_guard<std::mutex> lock(t->host_flat_mutex);
+      t->host_flat.reset();
+    }
   } catch (const std::bad_alloc&) {
     return fail(PTK_ERR_NOMEM, "out of memory");
   }
@@ -3175,6 +3154,13 @@ int ptk_debug_batch_order(const ptk_tree* t, int* how) {
   if (t == nullptr || how == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   std::lock_guard<std::mutex> lock(t->ws.mutex);
   *how = t->ws.last_order;
+  if (t->ws.last_verdict != nullptr && t->device >= 0) {  // sampled: what it was found to be is on the device
+    DeviceGuard guard(t->device);
+    uint32_t coherent = 0;
+    PTK_HIP(hipDeviceSynchronize());
+    PTK_HIP(hipMemcpy(&coherent, t->ws.last_verdict, 4, hipMemcpyDeviceToHost));
+    if (coherent != 0u) *how = 2;
+  }
   return PTK_OK;
 }
 

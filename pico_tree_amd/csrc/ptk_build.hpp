@@ -374,7 +374,15 @@ bool device_top_build(const float* points, uint64_t n, uint32_t dim, size_t max_
     const uint32_t axis = seg.axis;
     // The rounds of libstdc++'s introselect while the range is large (see slide_pivot_kernel): on the device.
     constexpr size_t kHostBelow = 32768;
-    if (seg.end - seg.begin > kHostBelow && std::getenv("PTK_DEVICE_SLIDE_OFF") == nullptr) {
+    // (The device rounds replay libstdc++'s std::nth_element and hand what is left to its std::__introselect -- internals
+    // whose shape is pinned to the releases this was checked against.  Any other standard library, or a libstdc++ from
+    // after them, takes the whole range to the host's std::nth_element below: the same permutation, no device rounds.)
+#if defined(__GLIBCXX__) && defined(_GLIBCXX_RELEASE) && _GLIBCXX_RELEASE >= 9 && _GLIBCXX_RELEASE <= 15
+    constexpr bool kKnownIntroselect = true;
+#else
+    constexpr bool kKnownIntroselect = false;
+#endif
+    if (kKnownIntroselect && seg.end - seg.begin > kHostBelow && std::getenv("PTK_DEVICE_SLIDE_OFF") == nullptr) {
       size_t first = seg.begin, last = seg.end;
       const size_t nth_pos = seg.begin + nth;
       long depth_limit = 2 * (long)std::__lg((long)(last - first));
@@ -418,8 +426,14 @@ bool device_top_build(const float* points, uint64_t n, uint32_t dim, size_t max_
       slid.resize(count);
       if (!ok(hipMemcpy(slid.data(), b.idx + first, count * 4, hipMemcpyDeviceToHost))) return false;
       auto below = [&](int x, int y) { return points[(size_t)x * dim + axis] < points[(size_t)y * dim + axis]; };
+#if defined(__GLIBCXX__) && defined(_GLIBCXX_RELEASE) && _GLIBCXX_RELEASE >= 9 && _GLIBCXX_RELEASE <= 15
       std::__introselect(slid.begin(), slid.begin() + (nth_pos - first), slid.end(), depth_limit,
                          __gnu_cxx::__ops::__iter_comp_iter(below));
+#else
+      (void)below;
+      reason = "the device rounds of a sliding step need libstdc++'s introselect";
+      return false;
+#endif
       seg.plane = points[(size_t)slid[nth_pos - first] * dim + axis];
       return ok(hipMemcpy(b.idx + first, slid.data(), count * 4, hipMemcpyHostToDevice));
     }

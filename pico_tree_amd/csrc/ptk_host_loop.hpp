@@ -15,6 +15,7 @@
 
 #include <atomic>
 #include <exception>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -31,7 +32,7 @@ using view_t = internal::space_view<space_t>;
 using query_t = internal::point_view<point_map<float const, dynamic_extent>>;
 using neighbor_t = neighbor<int, float>;
 
-inline flat_t flat_of(const ptk_tree* t) {
+inline flat_t make_flat(const ptk_tree* t) {
   static_assert(sizeof(flat_t::node_type) == sizeof(ptk_node), "node layout");
   flat_t flat(t->dim);
   flat.indices.assign(t->indices.begin(), t->indices.end());
@@ -48,6 +49,12 @@ inline flat_t flat_of(const ptk_tree* t) {
     std::memcpy(static_cast<void*>(flat.outer_bounds.data()), t->outer.data(), t->outer.size() * sizeof(float));
   }
   return flat;
+}
+// The handle's flat view: built by the first host search, shared by the later ones (and by concurrent ones).
+inline std::shared_ptr<const flat_t> flat_of(const ptk_tree* t) {
+  std::lock_guard<std::mutex> lock(t->host_flat_mutex);
+  if (!t->host_flat) t->host_flat = std::make_shared<const flat_t>(make_flat(t));
+  return std::static_pointer_cast<const flat_t>(t->host_flat);
 }
 
 // fn(i) for every row, rows handed out 128 at a time.
@@ -74,8 +81,21 @@ inline void rows_loop(uint64_t n, Fn fn) {
       next.store(n);
     }
   };
+  // (a thread that cannot be started -- a limit of the process -- is simply one worker fewer: the rows are dealt out in
+  // chunks, whoever is there takes them; and the threads that did start are joined on every way out)
   std::vector<std::thread> pool;
-  for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+  struct join_all {
+    std::vector<std::thread>& threads;
+    ~join_all() {
+      for (auto& th : threads)
+        if (th.joinable()) th.join();
+    }
+  } joiner{pool};
+  try {
+    pool.reserve(workers);
+    for (unsigned w = 1; w < workers; ++w) pool.emplace_back(work);
+  } catch (const std::system_error&) {
+  }
   work();
   for (auto& th : pool) th.join();
   if (failure) std::rethrow_exception(failure);
@@ -118,7 +138,8 @@ int ptk_host_search_knn(const ptk_tree* t, const float* points, const float* q, 
   if (k == 0 || !(e > 0.0f)) return fail(PTK_ERR_INVALID, "k must be >= 1 and e > 0");
   try {
     using namespace ptk_host;
-    const flat_t flat = flat_of(t);
+    const std::shared_ptr<const flat_t> flat_holder = flat_of(t);
+    const flat_t& flat = *flat_holder;
     if (topological_without_bounds(t, flat)) return fail(PTK_ERR_INVALID, "this tree has no outer bounds (ptk_tree_set_outer_bounds)");
     space_t space(points, t->n_points, t->dim);
     view_t view(space);
@@ -149,7 +170,8 @@ int ptk_host_search_radius(const ptk_tree* t, const float* points, const float* 
   *out = nullptr;
   try {
     using namespace ptk_host;
-    const flat_t flat = flat_of(t);
+    const std::shared_ptr<const flat_t> flat_holder = flat_of(t);
+    const flat_t& flat = *flat_holder;
     if (topological_without_bounds(t, flat)) return fail(PTK_ERR_INVALID, "this tree has no outer bounds (ptk_tree_set_outer_bounds)");
     space_t space(points, t->n_points, t->dim);
     view_t view(space);
@@ -186,7 +208,8 @@ int ptk_host_search_box(const ptk_tree* t, const float* points, const float* min
   *out = nullptr;
   try {
     using namespace ptk_host;
-    const flat_t flat = flat_of(t);
+    const std::shared_ptr<const flat_t> flat_holder = flat_of(t);
+    const flat_t& flat = *flat_holder;
     space_t space(points, t->n_points, t->dim);
     view_t view(space);
     std::vector<std::vector<int>> per_row(nb);

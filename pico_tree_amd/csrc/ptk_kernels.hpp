@@ -86,6 +86,9 @@ struct Neighbor {
   int32_t index;
   float distance;
 };
+struct alignas(16) RowPair {  // two neighbours of a row, one 16-byte store
+  unsigned long long a, b;
+};
 
 // "All four words of this float4 are used here" (no instruction): keeps a 16-byte record load whole.
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -1116,14 +1119,30 @@ __global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
         nb.distance = pol.ld[j];
         rows[lane * K + (((uint32_t)j + lane) & (K - 1))] = pack_neighbor(nb);
       }
-      constexpr uint32_t kRowsPerStore = 64u / K;
-      const uint32_t e = lane & (K - 1), sub = lane / K;
       unsigned long long* __restrict__ dst = reinterpret_cast<unsigned long long*>(out);
+      if ((reinterpret_cast<uintptr_t>(out) & 15u) == 0u) {  // (uniform)
+        // Two entries -- 16 bytes -- per lane, K / 2 lanes to a row: a store instruction writes 128 / K whole rows.
+        // (With 8 bytes per lane the rows left as twice their size in WRITE_SIZE: 1.83 GB for the 0.92 GB of config 3.)
+        constexpr uint32_t kLanesPerRow = K / 2, kRowsPerStore = 64u / kLanesPerRow;
+        const uint32_t e2 = lane % kLanesPerRow, sub = lane / kLanesPerRow;
 #pragma unroll
-      for (uint32_t r0 = 0; r0 < 64u; r0 += kRowsPerStore) {
-        const uint32_t r = r0 + sub;  // the lane whose row this is
-        const uint32_t q_r = (uint32_t)__shfl((int)(uint32_t)qi, (int)r);
-        dst[(uint64_t)q_r * K + e] = rows[r * K + ((e + r) & (K - 1))];
+        for (uint32_t r0 = 0; r0 < 64u; r0 += kRowsPerStore) {
+          const uint32_t r = r0 + sub;  // the lane whose row this is
+          const uint32_t q_r = (uint32_t)__shfl((int)(uint32_t)qi, (int)r);
+          RowPair two;
+          two.a = rows[r * K + ((2u * e2 + r) & (K - 1))];
+          two.b = rows[r * K + ((2u * e2 + 1u + r) & (K - 1))];
+          *reinterpret_cast<RowPair*>(dst + (uint64_t)q_r * K + 2u * e2) = two;
+        }
+      } else {
+        constexpr uint32_t kRowsPerStore = 64u / K;
+        const uint32_t e = lane & (K - 1), sub = lane / K;
+#pragma unroll
+        for (uint32_t r0 = 0; r0 < 64u; r0 += kRowsPerStore) {
+          const uint32_t r = r0 + sub;  // the lane whose row this is
+          const uint32_t q_r = (uint32_t)__shfl((int)(uint32_t)qi, (int)r);
+          dst[(uint64_t)q_r * K + e] = rows[r * K + ((e + r) & (K - 1))];
+        }
       }
       PTK_TRACE_END();
       return;
@@ -1444,13 +1463,17 @@ template <int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
     float e_inv, Neighbor* __restrict__ out, Cont cont, float4* __restrict__ qs_out,
-    uint32_t* __restrict__ tile_counts = nullptr, uint32_t count_stride = 0) {
+    uint32_t* __restrict__ tile_counts = nullptr, uint32_t count_stride = 0,
+    const uint32_t* __restrict__ as_given = nullptr) {
   const uint64_t i0 = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
   const uint4* __restrict__ nodes = t.nodes;
   const float4* __restrict__ pts = t.pts;
   float qx, qy, qz;
+  // (as_given: the verdict of the coherence sample -- 1 = the batch came in a coherent order, the sort left at once
+  // and `perm` holds nothing)
+  if (as_given != nullptr && *as_given != 0u) perm = nullptr;
   const uint32_t qi = perm ? perm[i] : (uint32_t)i;
   load_query(queries, dim, qi, qx, qy, qz);
   if (valid) qs_out[i] = make_float4(qx, qy, qz, __uint_as_float(qi));
@@ -2738,11 +2761,16 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(
 // kCoherenceWindows windows of 64 consecutive rows, evenly spread over the batch, one wavefront each:
 // fail[w] = 1 if the rows of window w spread over more than 2^max_log2 cells of the order-key grid (the product of
 // the per-axis extents of their bounding box, each rounded up to a power of two) -- 64 neighbours of a sorted batch of
-// nq rows cover about 2^(key bits) x 64 / nq cells.  The host decides from the 256 bytes (make_permutation).
+// nq rows cover about 2^(key bits) x 64 / nq cells.
+// The verdict stays ON THE DEVICE (the entry points that take device buffers only enqueue: ptk.h): every window adds
+// {1 << 16 | its failure} to state[0]; the window that finds the other kCoherenceWindows - 1 counted writes
+// state[1] = 1 if at most 15 % of the windows failed (a window may straddle a cell boundary), else 0, and puts
+// state[0] back to 0 for the next batch.  The kernels of the sort and phase 1 of the search read state[1]: a coherent
+// batch leaves the sort's kernels at their first instruction and is searched in the caller's order.
 constexpr uint32_t kCoherenceWindows = 256;
 __global__ __launch_bounds__(64) void coherence_sample_kernel(const float* __restrict__ queries, uint32_t dim, uint64_t nq,
                                                               float3 lo, float3 inv, uint3 bits, uint32_t max_log2,
-                                                              uint8_t* __restrict__ fail) {
+                                                              uint8_t* __restrict__ fail, uint32_t* __restrict__ state = nullptr) {
   const uint32_t w = blockIdx.x, lane = threadIdx.x;
   const uint64_t start = gridDim.x > 1u ? (nq - 64u) * w / (gridDim.x - 1u) : 0u;  // (nq >= 64)
   float x, y, z;
@@ -2767,7 +2795,16 @@ __global__ __launch_bounds__(64) void coherence_sample_kernel(const float* __res
       const uint32_t ext = mx[a] - mn[a];  // cells spanned - 1
       log2_cells += ext == 0u ? 0u : 32u - (uint32_t)__builtin_clz(ext);
     }
-    fail[w] = log2_cells > max_log2 ? 1 : 0;
+    const uint32_t failed = log2_cells > max_log2 ? 1u : 0u;
+    fail[w] = (uint8_t)failed;
+    if (state != nullptr) {
+      const uint32_t before = atomicAdd(&state[0], (1u << 16) | failed);
+      if ((before >> 16) == gridDim.x - 1u) {  // the last window in
+        const uint32_t failing = (before & 0xFFFFu) + failed;
+        state[1] = failing * 100u <= gridDim.x * 15u ? 1u : 0u;
+        state[0] = 0u;
+      }
+    }
   }
 }
 

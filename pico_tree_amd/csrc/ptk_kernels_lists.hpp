@@ -61,6 +61,11 @@ __device__ __forceinline__ unsigned long long pack_list_entry(uint32_t ref, uint
   return (unsigned long long)ref | ((unsigned long long)mask << 32);
 }
 
+// BIG: the tree has leaves of more than kListMaskBits points (a leaf is then listed in pieces; the test for the end of
+// a piece is four instructions of every point visit).  EXACT: e = 1 -- the approximate visitor's multiplication by 1 / e
+// (:265) is the identity then and is left out.  The launch picks the instantiation (uniform for a tree and a call):
+// 8 % of the kernel's vector instructions on BASELINE config 3 are these two.
+template <bool BIG, bool EXACT>
 struct RadiusListPolicy {  // search_visitor.hpp:127-156 / :252-288, counting
   static constexpr bool kLeafHooks = true;
   float radius;  // already scaled by 1/e for the approximate search (:265)
@@ -68,7 +73,6 @@ struct RadiusListPolicy {  // search_visitor.hpp:127-156 / :252-288, counting
   uint64_t count;
   uint32_t n;            // entries this lane has listed
   uint32_t first, pos, mask, cbits;  // the piece of a leaf being measured: its first point, points seen, hits among them
-  bool big_leaves;                   // the tree has leaves of more than kListMaskBits points
   unsigned long long* slots;  // the chunks
   unsigned long long b0, b1, b2, b3;  // the group of entries this lane is collecting
   uint32_t* counters;         // RadiusCapture::counters
@@ -144,16 +148,18 @@ struct RadiusListPolicy {  // search_visitor.hpp:127-156 / :252-288, counting
   }
   __device__ __forceinline__ void leaf_end() { close_piece(); }
   __device__ __forceinline__ void visit(int32_t, float d) {
-    d = f_mul(d, e_inv);
+    if constexpr (!EXACT) d = f_mul(d, e_inv);
     mask |= (radius > d ? 1u : 0u) << pos;  // strict; the hits are counted when the piece is closed
     ++pos;
-    if (big_leaves && pos == kListMaskBits) close_piece();  // (leaves of up to 32 points, the usual case: one piece)
+    if constexpr (BIG) {
+      if (pos == kListMaskBits) close_piece();  // (leaves of up to 32 points, the usual case: one piece)
+    }
   }
 };
 
 // The count pass: see the head of this file.  One wavefront per block; LDS = the record stack and the chunk table.
 constexpr uint32_t kListLds = (1u + kListMaxChunks) * 4u;  // behind the record stack
-template <int S, int OVF, int LEAFB, class M = MetricL2>
+template <int S, int OVF, int LEAFB, class M = MetricL2, bool BIG = true, bool EXACT = false>
 __global__ __launch_bounds__(64) void radius_list_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
     float radius, float e_inv, uint64_t* __restrict__ counts, RadiusCapture cap) {
@@ -165,7 +171,7 @@ __global__ __launch_bounds__(64) void radius_list_kernel(
     table[0] = 1u;
     table[1] = tile;  // the static chunk
   }
-  RadiusListPolicy pol;
+  RadiusListPolicy<BIG, EXACT> pol;
   pol.n = 0u;
   if (i < nq) {
     const uint64_t qi = perm ? perm[i] : i;
@@ -180,7 +186,6 @@ __global__ __launch_bounds__(64) void radius_list_kernel(
     pol.e_inv = e_inv;
     pol.count = 0;
     pol.cbits = t.cbits;
-    pol.big_leaves = t.cmask >= kListMaskBits;  // (a count of 32 needs six bits)
     pol.slots = reinterpret_cast<unsigned long long*>(cap.chunks);
     pol.b0 = pol.b1 = pol.b2 = pol.b3 = 0ull;
     pol.counters = cap.counters;

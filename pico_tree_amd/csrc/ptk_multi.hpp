@@ -109,6 +109,10 @@ struct ptk_multi {
   hipEvent_t ready = nullptr;         // on devices[0]: the caller's queries are complete
   std::mutex mutex;                   // device-buffer calls on one handle are serialised
   uint32_t dim = 0;
+  // A device listed more than once (PTK_MULTI_ALLOW_REPLICAS=1, tests on a one-GPU box): every entry still gets its
+  // own replica, stream, event and staging, the rows are cut the same way, and the device-buffer form moves the ranges
+  // with copies on the entries' streams instead of RCCL (which wants one rank per device).
+  bool replicas = false;
 };
 
 namespace {
@@ -183,15 +187,20 @@ int multi_finish_create(ptk_multi* m, ptk_tree* host, const float* points, ptk_m
   return PTK_OK;
 }
 
-int multi_check_devices(const int32_t* devices, uint32_t n_devices) {
+int multi_check_devices(const int32_t* devices, uint32_t n_devices, bool* replicas) {
+  *replicas = false;
   if (devices == nullptr || n_devices == 0) return fail(PTK_ERR_INVALID, "empty device list");
   int count = 0;
   if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return fail(PTK_ERR_DEVICE, "no HIP device is visible");
+  const bool allow = env_int("PTK_MULTI_ALLOW_REPLICAS", 0) != 0;
   for (uint32_t i = 0; i < n_devices; ++i) {
     if (devices[i] < 0 || devices[i] >= count)
       return fail(PTK_ERR_INVALID, "device %d out of range (%d visible)", devices[i], count);
-    for (uint32_t j = 0; j < i; ++j)
-      if (devices[j] == devices[i]) return fail(PTK_ERR_INVALID, "device %d is listed twice", devices[i]);
+    for (uint32_t j = 0; j < i; ++j) {
+      if (devices[j] != devices[i]) continue;
+      if (!allow) return fail(PTK_ERR_INVALID, "device %d is listed twice", devices[i]);
+      *replicas = true;
+    }
   }
   return PTK_OK;
 }
@@ -204,7 +213,8 @@ int ptk_multi_create_from_points(const float* points, uint64_t n_points, uint32_
                                  const int32_t* devices, uint32_t n_devices, ptk_multi** out) {
   if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
   *out = nullptr;
-  int rc = multi_check_devices(devices, n_devices);
+  bool replicas = false;
+  int rc = multi_check_devices(devices, n_devices, &replicas);
   if (rc != PTK_OK) return rc;
   ptk_tree* host = nullptr;  // built once, on the host; every device gets the same nodes
   rc = ptk_tree_create_from_points(points, n_points, dim, max_leaf_size, PTK_DEVICE_NONE, &host);
@@ -215,13 +225,15 @@ int ptk_multi_create_from_points(const float* points, uint64_t n_points, uint32_
     return fail(PTK_ERR_NOMEM, "out of memory");
   }
   m->devices.assign(devices, devices + n_devices);
+  m->replicas = replicas;
   return multi_finish_create(m, host, points, out);
 }
 
 int ptk_multi_create(const ptk_tree_desc* d, const int32_t* devices, uint32_t n_devices, ptk_multi** out) {
   if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
   *out = nullptr;
-  int rc = multi_check_devices(devices, n_devices);
+  bool replicas = false;
+  int rc = multi_check_devices(devices, n_devices, &replicas);
   if (rc != PTK_OK) return rc;
   if (d == nullptr) return fail(PTK_ERR_INVALID, "null descriptor");
   ptk_tree_desc hd = *d;
@@ -235,6 +247,7 @@ int ptk_multi_create(const ptk_tree_desc* d, const int32_t* devices, uint32_t n_
     return fail(PTK_ERR_NOMEM, "out of memory");
   }
   m->devices.assign(devices, devices + n_devices);
+  m->replicas = replicas;
   return multi_finish_create(m, host, d->points, out);
 }
 
@@ -248,6 +261,10 @@ void ptk_multi_destroy(ptk_multi* m) {
   }
   if (!m->comms.empty() && rccl().ok)
     for (ncclComm_t c : m->comms) (void)rccl().CommDestroy(c);
+  // The replicas go BEFORE the streams: a replica's per-stream scratch block remembers the stream of its last search
+  // (the entry's stream, for every entry but the first) and waits for it when it is released.
+  for (ptk_tree* t : m->trees) ptk_tree_destroy(t);
+  m->trees.clear();
   for (size_t i = 0; i < m->devices.size(); ++i) {
     DeviceGuard guard(m->devices[i]);
     if (i < m->d_q.size() && m->d_q[i]) (void)hipFree(m->d_q[i]);
@@ -259,7 +276,6 @@ void ptk_multi_destroy(ptk_multi* m) {
     DeviceGuard guard(m->devices[0]);
     (void)hipEventDestroy(m->ready);
   }
-  for (ptk_tree* t : m->trees) ptk_tree_destroy(t);
   delete m;
 }
 
@@ -379,6 +395,49 @@ int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uin
   const bool self = env_int("PTK_MULTI_SELF_GATHER", 0) != 0;
   hipStream_t s0 = static_cast<hipStream_t>(stream);  // null = the default stream of devices[0], as everywhere in HIP
   int rc = PTK_OK;
+  if (m->replicas) {
+    // Entries of one device: the same row ranges, per-entry streams, events and staging; copies instead of RCCL.
+    const size_t rq = (size_t)m->dim * sizeof(float), ro = (size_t)k * sizeof(ptk_neighbor);
+    DeviceGuard guard(m->devices[0]);
+    for (uint32_t r = 1; r < n; ++r) {
+      uint64_t lo, hi;
+      shard_rows(nq, n, r, &lo, &hi);
+      rc = grow_device_block(&m->d_q[r], &m->q_cap[r], std::max<size_t>((hi - lo) * rq, 16));
+      if (rc == PTK_OK) rc = grow_device_block(&m->d_o[r], &m->o_cap[r], std::max<size_t>((hi - lo) * ro, 16));
+      if (rc != PTK_OK) return rc;
+    }
+    PTK_HIP(hipEventRecord(m->ready, s0));
+    for (uint32_t r = 0; r < n; ++r) {
+      uint64_t lo, hi;
+      shard_rows(nq, n, r, &lo, &hi);
+      if (hi == lo) continue;
+      if (r == 0) {
+        rc = ptk_search_knn_device(m->trees[0], d_q, hi - lo, k, e, d_out, s0);
+      } else {
+        DeviceGuard entry(m->devices[r]);
+        PTK_HIP(hipStreamWaitEvent(m->streams[r], m->ready, 0));
+        PTK_HIP(hipMemcpyAsync(m->d_q[r], d_q + lo * m->dim, (hi - lo) * rq, hipMemcpyDeviceToDevice, m->streams[r]));
+        rc = ptk_search_knn_device(m->trees[r], reinterpret_cast<const float*>(m->d_q[r]), hi - lo, k, e,
+                                   reinterpret_cast<ptk_neighbor*>(m->d_o[r]), m->streams[r]);
+        if (rc == PTK_OK) {
+          PTK_HIP(hipMemcpyAsync(d_out + lo * k, m->d_o[r], (hi - lo) * ro, hipMemcpyDeviceToDevice, m->streams[r]));
+          PTK_HIP(hipEventRecord(m->done[r], m->streams[r]));
+        }
+      }
+      if (rc != PTK_OK) {
+        const std::string keep = g_error;
+        for (uint32_t p = 1; p < n; ++p) (void)hipStreamSynchronize(m->streams[p]);
+        g_error = keep;
+        return rc;
+      }
+    }
+    for (uint32_t r = 1; r < n; ++r) {
+      uint64_t lo, hi;
+      shard_rows(nq, n, r, &lo, &hi);
+      if (hi > lo) PTK_HIP(hipStreamWaitEvent(s0, m->done[r], 0));
+    }
+    return PTK_OK;
+  }
   if (n > 1 || self) {
     rc = multi_comms(m);
     if (rc != PTK_OK) return rc;

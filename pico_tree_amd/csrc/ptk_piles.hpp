@@ -123,6 +123,15 @@ inline void build_pile_view(uint32_t dim, uint64_t n_points, const float* points
     if (!ls) continue;
     const bool rs = nodes[r].right == PTK_LEAF ? leaf_same(r) : same[r] != 0;
     if (!rs || !same_point(rep[l], rep[r])) continue;
+    // The planes must meet AT the pile: the side test of the searches is `left_max + right_min` against the query
+    // (kd_tree_search.hpp:76), the pile pass decides it from the pile's coordinate.  The reference's builder always
+    // puts them there (they are the tightened boxes of the two sides); a stream loaded from elsewhere need not.
+    {
+      float lm;
+      std::memcpy(&lm, &nd.a, 4);
+      const uint32_t axis = nd.split_dim;
+      if (axis >= dim || !(lm == points[(uint64_t)rep[l] * dim + axis])) continue;
+    }
     same[i] = 1;
     rep[i] = rep[l];
   }

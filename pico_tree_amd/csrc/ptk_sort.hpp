@@ -58,7 +58,8 @@ template <bool FROM_QUERIES>
 __global__ __launch_bounds__(64) void radix_hist_kernel(
     const float* __restrict__ queries, uint32_t dim, uint32_t nq, float3 lo, float3 inv, uint3 bits,
     uint32_t* __restrict__ keys, const uint2* __restrict__ pairs, uint32_t shift, uint32_t tile, uint32_t stride,
-    uint32_t* __restrict__ hist, CellTable cells = CellTable{}) {
+    uint32_t* __restrict__ hist, CellTable cells = CellTable{}, const uint32_t* __restrict__ as_given = nullptr) {
+  if (as_given != nullptr && *as_given != 0u) return;  // (uniform) a coherent batch is not sorted: coherence_sample_kernel
   typedef PTK_LDS uint32_t LdsU32;
   LdsU32* cnt = (LdsU32*)ptk_smem;  // [256]
   const uint32_t lane = threadIdx.x;
@@ -152,7 +153,8 @@ template <bool FIRST, bool LAST>
 __global__ __launch_bounds__(64) void radix_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint2* __restrict__ pairs_in, uint2* __restrict__ pairs_out,
     uint32_t* __restrict__ vals_out, uint32_t n, uint32_t shift, uint32_t tile, uint32_t stride,
-    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals) {
+    const uint32_t* __restrict__ hist, const uint32_t* __restrict__ totals, const uint32_t* __restrict__ as_given = nullptr) {
+  if (as_given != nullptr && *as_given != 0u) return;  // (uniform) a coherent batch is not sorted
   typedef PTK_LDS uint32_t LdsU32;
   LdsU32* pos = (LdsU32*)ptk_smem;  // [256] next free output position of every digit, for this tile
   const uint32_t lane = threadIdx.x;
@@ -246,7 +248,8 @@ template <bool FROM_QUERIES, uint32_t BLOCK = kSortBlock, uint32_t ITEMS = kSort
 __global__ __launch_bounds__(BLOCK) void radix_block_hist_kernel(
     const float* __restrict__ queries, uint32_t dim, uint32_t nq, float3 lo, float3 inv, uint3 bits,
     uint32_t* __restrict__ keys, const uint2* __restrict__ pairs, uint32_t shift, uint32_t stride,
-    uint32_t* __restrict__ hist, CellTable cells = CellTable{}) {
+    uint32_t* __restrict__ hist, CellTable cells = CellTable{}, const uint32_t* __restrict__ as_given = nullptr) {
+  if (as_given != nullptr && *as_given != 0u) return;  // (uniform) a coherent batch is not sorted: coherence_sample_kernel
   typedef PTK_LDS uint32_t LdsU32;
   LdsU32* cnt = (LdsU32*)ptk_smem;  // [256]
   const uint32_t t = threadIdx.x;
@@ -289,7 +292,8 @@ template <bool FIRST, bool LAST, uint32_t BLOCK = kSortBlock, uint32_t ITEMS = k
 __global__ __launch_bounds__(BLOCK) void radix_block_scatter_kernel(
     const uint32_t* __restrict__ keys_in, const uint2* __restrict__ pairs_in, uint2* __restrict__ pairs_out,
     uint32_t* __restrict__ vals_out, uint32_t n, uint32_t shift, uint32_t stride, const uint32_t* __restrict__ hist,
-    const uint32_t* __restrict__ totals) {
+    const uint32_t* __restrict__ totals, const uint32_t* __restrict__ as_given = nullptr) {
+  if (as_given != nullptr && *as_given != 0u) return;  // (uniform) a coherent batch is not sorted
   constexpr uint32_t WAVES = BLOCK / 64u, TILE = BLOCK * ITEMS;
   static_assert(BLOCK >= kRadixBins && BLOCK % 64u == 0u, "a thread per digit");
   typedef PTK_LDS uint32_t LdsU32;

@@ -734,9 +734,14 @@ int64_t emu_radius_lists(void* h, const float* q, uint64_t nq, float radius, flo
     t->cap.n_static = (uint32_t)waves;
     t->cap.sub_cap = sub_cap;
     t->cap_nq = nq;
+    // (the instantiations the backend picks between: leaves of more than 32 points or not, e = 1 or not)
+    const bool big = t->dev.cmask >= ptk::kListMaskBits, exact = e_inv == 1.0f;
     for_each_lane(waves * 64, [&] {
       if (t->metric == 1) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL1>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
-      else ptk::radius_list_kernel<8, 2048, 4>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
+      else if (big && exact) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, true, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
+      else if (big) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, true, false>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
+      else if (exact) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, false, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
+      else ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, false, false>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap);
     }, 64);
     return 0;
   }

@@ -960,6 +960,38 @@ def test_config1_through_the_device_matches_the_committed_hashes(gpu):
         assert int(rows["index"].astype(np.int64).sum()) == e["index_sum"]
 
 
+@pytest.mark.parametrize("n", [3, 8])
+def test_row_cutting_of_the_multi_device_library_with_replicas_on_one_gpu(gpu, monkeypatch, n):
+    """The C library's n > 1 path on the one-GPU test box (the loop of _pyco_tree/kd_tree.hpp:117-135 cut into n row
+    ranges): with PTK_MULTI_ALLOW_REPLICAS=1 the same device may be listed n times -- n replicas, n host threads / n
+    streams with their events and staging, ranges of ceil(nq / n) rows with a ragged (n = 8: EMPTY last ranges are
+    covered by the second batch) last one -- and only the transport differs from a node (copies instead of RCCL for
+    the device form).  k = 1 / 8 and the radius search against the oracle, nq not divisible by n."""
+    import torch
+
+    monkeypatch.setenv("PTK_MULTI_ALLOW_REPLICAS", "1")
+    pts, q = ds.lidar_cloud(120_000, 1), ds.lidar_cloud(50_021, 2, pose=(3.0, 1.5))
+    ref = oracle.Oracle(pts, 10, "port")
+    ref.set_threads(ref.max_threads())
+    multi = pt.MultiKdTree(pts, 10, devices=[0] * n)
+    assert multi.devices == [0] * n
+    for batch in (q, q[:5]):  # (5 rows on 8 entries: ranges of one row, the last three empty)
+        want1, want8 = ref.search_knn(batch, 1)[:, 0], ref.search_knn(batch, 8)
+        assert multi.search_knn(batch, 1).tobytes() == want1.tobytes()        # host buffers: one thread per entry
+        assert multi.search_knn(batch, 8).tobytes() == want8.tobytes()
+        dq = torch.from_numpy(batch).to("cuda:0")
+        for k, want in ((1, want1), (8, want8)):                             # device buffers: streams, events, staging
+            rows = multi.search_knn(dq, k).numpy()
+            torch.cuda.synchronize()
+            assert rows.reshape(want.shape).tobytes() == want.tobytes(), (n, k, len(batch))
+        got = multi.search_radius(batch, 0.02)
+        off, flat = ref.search_radius(batch, 0.02)
+        assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
+    monkeypatch.delenv("PTK_MULTI_ALLOW_REPLICAS")
+    with pytest.raises(Exception):
+        pt.MultiKdTree(pts, 10, devices=[0, 0])  # (without the switch a device listed twice is refused)
+
+
 def test_all_devices_of_the_node(gpu, monkeypatch):
     """With two or more GPUs visible: ptk_multi_* over ALL of them (real peer send / recv through RCCL, no
     self-gather) and one rank per GPU through pico_tree_amd.sharded over RCCL.  Skips on the one-GPU test box; runs
