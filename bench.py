@@ -419,12 +419,19 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     b = 12 + 8 * k + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
     kernel_ms = prof["search_ms"] / max(int(prof["launches"]), 1)
     r = roofline_of(b, nq, kernel_ms)
-    r["kernel"] = "ptk::knn_reg_kernel<16, 16, 64, 64, 5, ptk::MetricL2>"
-    r["traffic"], r["traffic_source"] = measured_traffic_c3(["ptk::knn_reg_kernel<16,"])
+    r["kernel"] = ("ptk::knn_reg_kernel<16, 16, 64, 64, 5, ptk::MetricL2, true> (capped) + ptk::knn_coop_kernel<16, 128> "
+                   "+ ptk::knn_redo_kernel<16, ...>: the three launches of a step, timed together")
+    r["traffic"], r["traffic_source"] = measured_traffic_c3(["ptk::knn_reg_kernel<16,", "ptk::knn_coop_kernel<16,",
+                                                             "ptk::knn_redo_kernel<16,"])
     r["traffic_static"] = True  # (GB per launch, 2 x FETCH_SIZE + WRITE_SIZE of committed rocprofv3 --pmc passes, as above)
     r["visits_per_query"] = {"n_branch": round(mean[0], 2), "n_leaf": round(mean[1], 2), "n_pts": round(mean[2], 2)}
+    try:
+        coop = tree.knn_coop_counts()  # queries finished by a wavefront each / redone by one lane, and why
+    except Exception as exc:  # noqa: BLE001
+        coop = str(exc)
     res["knn16"] = {"value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms, 4), "steps": steps,
-                    "parity_sample_ok": bool(got.tobytes() == want.tobytes()), "roofline": r}
+                    "parity_sample_ok": bool(got.tobytes() == want.tobytes()), "roofline": r,
+                    "long_searches": coop}
     # ---- radius: count pass that lists the leaves with hits + scan + fill pass that replays the lists
     radius, steps = 1.0, 3
     for _ in range(2):  # (the 6 GB of rows are a block of torch's allocator from the second call on)
@@ -526,6 +533,36 @@ def quantised_entry(pt, ds, oracle, pts, q, leaf, grid, device, steps, sample, s
     return e
 
 
+def forest_counter_fraction(ms_per_launch):
+    """HBM bytes per launch of ptk::forest_knn_kernel from the newest committed profiles/*_forest_pmc.txt (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE, tools/pmc_forest.sh; 2 x FETCH_SIZE + WRITE_SIZE, KiB units) over `ms_per_launch` and the
+    HBM peak; None without such a file."""
+    import glob
+    import re
+
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_forest_pmc.txt")))
+    if not files:
+        return None
+    fetch = write = None
+    try:
+        with open(files[-1]) as f:
+            for line in f:
+                if "forest_knn_kernel" not in line:
+                    continue
+                m = re.search(r"(FETCH_SIZE|WRITE_SIZE)\s+(\d+)\s+([0-9.]+)\s+([0-9.]+)", line)
+                if m and m.group(1) == "FETCH_SIZE":
+                    fetch = float(m.group(4)) * 1024.0
+                elif m:
+                    write = float(m.group(4)) * 1024.0
+    except OSError:
+        return None
+    if fetch is None:
+        return None
+    gb = (2.0 * fetch + (write or 0.0)) / 1e9
+    return {"hbm_gb_per_launch": round(gb, 2), "frac": round(gb / (ms_per_launch * 1e-3) / HBM_PEAK_GBS, 4),
+            "source": os.path.basename(files[-1]), "static": True}
+
+
 def config5_entry(pt, ds, device):
     """BASELINE configs[4]: approximate knn = 10 through the kd-forest (8 trees, leaf 32, 64 leaves per tree) on a
     SIFT-1M-shaped synthetic cloud; recall against brute force on the GPU (tools/bench_forest.py)."""
@@ -561,8 +598,11 @@ def config5_entry(pt, ds, device):
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel": "ptk::forest_knn_kernel",
                          "bytes_per_query": row_bytes,
-                         "note": "leaf rows only (every visited leaf's points, 512 B each); part of them is served by "
-                                 "the Infinity Cache, so this is an upper bound on the HBM share"}}
+                         "frac_by_counters": forest_counter_fraction(ms),
+                         "note": "`frac` prices the ALGORITHMIC leaf rows (every visited leaf's points, 512 B each); "
+                                 "`frac_by_counters` is what the HBM counters saw per launch (2 x FETCH_SIZE + WRITE_SIZE of "
+                                 "the newest committed profiles/*_forest_pmc.txt) over this run's launch time: the "
+                                 "difference is what the Infinity Cache and the L2s serve"}}
 
 
 def single_process_worker(args):
@@ -870,6 +910,20 @@ def main():
                 "value": round(nq / hdt3 / 1e6, 3), "ms_per_step": round(hdt3 * 1e3, 4),
                 "rows_equal_device_run": bool(pin_rows.tobytes() == res.tobytes())}
             del pin_rows
+            # ... and the caller's OWN pageable arrays page-locked in place for the duration (ptk_host_register): what an
+            # application with long-lived buffers does instead of allocating from ptk_host_alloc
+            nns_reg = np.empty(nq, dtype=pt.NEIGHBOR)
+            with pt.registered(q), pt.registered(nns_reg):
+                tree.search_knn(q, 1, nns_reg)
+                t0 = time.perf_counter()
+                for _ in range(hsteps):
+                    tree.search_knn(q, 1, nns_reg)
+                hdt4 = (time.perf_counter() - t0) / hsteps
+            extras["host_buffers"]["callers_arrays_registered"] = {
+                "value": round(nq / hdt4 / 1e6, 3), "ms_per_step": round(hdt4 * 1e3, 4),
+                "what": "search_knn(q, 1, nns) with the caller's numpy arrays page-locked in place (pt.registered)",
+                "rows_equal_device_run": bool(nns_reg.tobytes() == res.tobytes())}
+            del nns_reg
             # knn = 16 through the same entry (0.92 GB of rows down)
             warm = [tree.search_knn(q, 16) for _ in range(2)]
             del warm

@@ -291,6 +291,13 @@ int ptk_host_search_box(const ptk_tree* tree, const float* points, const float* 
  * pool of these blocks and hands them out again (pico_tree_amd.KdTree does).  Usable from every device of the node. */
 int ptk_host_alloc(uint64_t bytes, void** out);
 void ptk_host_free(void* p);
+/* Page-locks an array the CALLER owns, in place (hipHostRegister), and releases it again: a query or result array that
+ * lives as long as the application -- a ring of scan buffers -- is then moved by ptk_search_* without the staging copy
+ * a pageable array needs, exactly like memory from ptk_host_alloc.  The caller must unregister the range before it
+ * frees or unmaps it; the library never registers a caller's array on its own (a registration cached by address would
+ * outlive the array: an allocator hands the same address out again, and the device would read the old pages). */
+int ptk_host_register(void* p, uint64_t bytes);
+int ptk_host_unregister(void* p);
 
 /* ---- double precision ---------------------------------------------------- */
 /* The reference's kd_tree is generic over the scalar type and its Python module

@@ -31,10 +31,11 @@ import numpy as np
 from . import datasets  # noqa: F401  (re-export)
 
 __all__ = ["KdTree", "KdForest", "save_kd_tree", "load_kd_tree", "Metric", "NEIGHBOR", "NEIGHBOR64", "DArray", "DeviceNeighbors", "PtkError",
-           "library_path", "device_count", "datasets", "trim_pinned_pool"]
+           "library_path", "device_count", "datasets", "trim_pinned_pool", "registered", "empty_pinned"]
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "csrc", "libptk.so")
+#: (PTK_LIBRARY: another build of the same library -- the experiment builds of tools/)
+_LIB_PATH = os.environ.get("PTK_LIBRARY") or os.path.join(_HERE, "csrc", "libptk.so")
 
 #: Result record; identical to the reference binding's neighbor dtype.
 NEIGHBOR = np.dtype([("index", "<i4"), ("distance", "<f4")])
@@ -115,6 +116,8 @@ _SIGNATURES = {
     "ptk_host_search_box": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_uint64, c_void_p, POINTER(c_void_p)]),
     "ptk_host_alloc": (c_int, [c_uint64, POINTER(c_void_p)]),
     "ptk_host_free": (None, [c_void_p]),
+    "ptk_host_register": (c_int, [c_void_p, c_uint64]),
+    "ptk_host_unregister": (c_int, [c_void_p]),
     "ptk_tree64_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_int32, POINTER(c_void_p)]),
     "ptk_tree64_create_from_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
                                               POINTER(c_void_p)]),
@@ -320,6 +323,29 @@ _pinned_pool = _PinnedPool()
 def trim_pinned_pool() -> None:
     """Frees the page-locked result blocks that no array uses any more (the pool keeps them for the next call)."""
     _pinned_pool.trim()
+
+
+class registered:
+    """``with pico_tree_amd.registered(arr): ...`` page-locks a numpy array the caller owns for the duration of the
+    block (``ptk_host_register`` / ``ptk_host_unregister``): searches inside move it without a staging copy.  For arrays
+    that live long -- the buffers of a stream of scans; registering costs more than one staged copy."""
+
+    def __init__(self, arr: np.ndarray):
+        if not isinstance(arr, np.ndarray) or not arr.flags["C_CONTIGUOUS"]:
+            raise ValueError("a C-contiguous numpy array is required")
+        self._arr = arr
+        self._on = False
+
+    def __enter__(self):
+        _check(_load().ptk_host_register(self._arr.ctypes.data, self._arr.nbytes))
+        self._on = True
+        return self._arr
+
+    def __exit__(self, *exc):
+        if self._on:
+            self._on = False
+            _check(_load().ptk_host_unregister(self._arr.ctypes.data))
+        return False
 
 
 def empty_pinned(shape, dtype=np.float32) -> np.ndarray:

@@ -1076,10 +1076,16 @@ __global__ __launch_bounds__(BLOCK) void knn_kernel(
   }
 }
 
+// (experiments: -DPTK_KNN_WAVES=n asks the compiler to fit n wavefronts per SIMD)
+#if defined(PTK_KNN_WAVES) && defined(__HIP_DEVICE_COMPILE__)
+#define PTK_KNN_REG_WAVES __attribute__((amdgpu_waves_per_eu(PTK_KNN_WAVES, PTK_KNN_WAVES)))
+#else
+#define PTK_KNN_REG_WAVES
+#endif
 // CAPPED: a query that has entered more than `cap` far children stops; its list (in its row, as always) and its
 // stack (`ho`) go to knn_coop_kernel (ptk_kernels_coopk.hpp), which finishes it with a whole wavefront.
 template <int K, int S, int OVF, int BLOCK, int LEAFB, class M = MetricL2, bool CAPPED = false>
-__global__ __launch_bounds__(BLOCK) void knn_reg_kernel(
+__global__ __launch_bounds__(BLOCK) PTK_KNN_REG_WAVES void knn_reg_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim,
     const uint32_t* __restrict__ perm, uint64_t nq, uint32_t k, float e_inv,
     Neighbor* __restrict__ out, uint32_t cap = 0, Handover ho = Handover{}) {

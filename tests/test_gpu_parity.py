@@ -960,6 +960,21 @@ def test_config1_through_the_device_matches_the_committed_hashes(gpu):
         assert int(rows["index"].astype(np.int64).sum()) == e["index_sum"]
 
 
+def test_callers_arrays_page_locked_in_place(gpu):
+    """ptk_host_register / ptk_host_unregister: the caller's own query and result arrays page-locked for a block of
+    calls -- same rows as with pageable arrays; a pointer that is not registered is refused."""
+    pts, q = ds.lidar_cloud(60_000, 1), ds.lidar_cloud(300_000, 2, pose=(3.0, 1.5))
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=0)
+    want = tree.search_knn(q, 1)
+    nns = np.empty(len(q), dtype=pt.NEIGHBOR)
+    with pt.registered(q), pt.registered(nns):
+        tree.search_knn(q, 1, nns)
+        assert nns.tobytes() == want.tobytes()
+    tree.search_knn(q, 1, nns)  # (pageable again)
+    assert nns.tobytes() == want.tobytes()
+    assert pt._load().ptk_host_unregister(q.ctypes.data) != 0
+
+
 @pytest.mark.parametrize("n", [3, 8])
 def test_row_cutting_of_the_multi_device_library_with_replicas_on_one_gpu(gpu, monkeypatch, n):
     """The C library's n > 1 path on the one-GPU test box (the loop of _pyco_tree/kd_tree.hpp:117-135 cut into n row

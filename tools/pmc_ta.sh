@@ -8,13 +8,12 @@ mkdir -p $R/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 -L 2>/dev/null | grep -oE "\b(TA|TCP|TD|TCC)_[A-Za-z0-9_]+" | sort -u > $R/gpurun_out/${TAG}_ta_avail.txt
 i=0
-for c in "TA_TA_BUSY_sum TA_BUSY_avr TA_TOTAL_WAVEFRONTS_sum TA_FLAT_READ_WAVEFRONTS_sum GRBM_GUI_ACTIVE" \
-         "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum TA_ADDR_STALLED_BY_TD_CYCLES_sum" \
-         "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum" \
+# (the TA_* and TD_* sets stall rocprofv3 on this pool until the timeout kills the pass -- 4 minutes each, nothing
+# collected: profiles/r05a_c3_ta_tcp_pmc.txt has no TA / TD rows for that reason; the TCP sets answer the questions)
+for c in "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_ACCESSES_sum TCP_TOTAL_READ_sum" \
          "TCP_PENDING_STALL_CYCLES_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum" \
          "TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCR_TCP_STALL_CYCLES_sum TCP_TCC_READ_REQ_LATENCY_sum TCP_TCP_LATENCY_sum" \
          "TCP_TAGRAM0_REQ_sum TCP_TAGRAM1_REQ_sum TCP_TAGRAM2_REQ_sum TCP_TAGRAM3_REQ_sum" \
-         "TD_TD_BUSY_sum TD_LOAD_WAVEFRONT_sum TD_TC_STALL_sum" \
          "TCP_LFIFO_STALL_CYCLES_sum TCP_RFIFO_STALL_CYCLES_sum TCP_UTCL1_TRANSLATION_MISS_sum TCP_UTCL1_TRANSLATION_HIT_sum"; do
   i=$((i+1))
   timeout -k 5 240 rocprofv3 --kernel-trace --pmc $c -d /tmp/pmcta_${TAG}_$i -o pmc -- "$@" > /dev/null 2>> $R/gpurun_out/pmcta_$TAG.log
