@@ -910,10 +910,9 @@ uint32_t sort_tile(uint64_t nq) {
 }
 uint32_t sort_tiles(uint64_t nq) { return (uint32_t)((nq + sort_tile(nq) - 1) / sort_tile(nq)); }
 uint32_t sort_stride(uint64_t nq) { return (sort_tiles(nq) + 3u) & ~3u;  }  // row of the histogram: 16-byte steps
-size_t own_sort_bytes(uint64_t nq) {  // (the histogram of whichever form has more tiles; the counts and look-back words of the sweep form)
+size_t own_sort_bytes(uint64_t nq) {  // (the histogram of whichever form has more tiles)
   const size_t stride = std::max<size_t>(sort_stride(nq), ((nq + ptk::kSortTile - 1) / ptk::kSortTile + 3) & ~(size_t)3);
-  const size_t sweep = 2 * ((nq + ptk::kSortTile - 1) / ptk::kSortTile) * ptk::kSweepMaxPasses * ptk::kRadixBins * 4 + 8192;
-  return ((size_t)ptk::kRadixBins * stride + ptk::kRadixBins) * 4 + 2 * nq * sizeof(uint2) + sweep + 1024;
+  return ((size_t)ptk::kRadixBins * stride + ptk::kRadixBins) * 4 + 2 * nq * sizeof(uint2) + 1024;
 }
 
 // Which sort orders the batch: the library's own (ptk_sort.hpp) -- its passes with one wavefront per tile below 0.75 M
@@ -991,47 +990,6 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
                                                 make_float3(inv[0], inv[1], inv[2]), make_uint3(b[0], b[1], b[2]))
                                  : nullptr;
   scratch.note_verdict(as_given);
-  if (own_sort(nq) && block_sort(nq) && nq < (1ull << 30) && env_int("PTK_SORT_SWEEP", 1) != 0) {
-    // The passes with the scan folded in (ptk_sort.hpp, radix_sweep_*): keys + the digit counts of every pass, their
-    // totals, then ONE kernel per 8-bit pass (tickets + look-back): 5 launches for three passes instead of 10.
-    const uint32_t tiles = (uint32_t)((nq + ptk::kSortTile - 1) / ptk::kSortTile);
-    const uint32_t passes = (uint32_t)((bits + 7) / 8);
-    uint32_t* counts3 = scratch.take<uint32_t>((size_t)tiles * passes * ptk::kRadixBins);
-    uint32_t* state = scratch.take<uint32_t>((size_t)passes * tiles * ptk::kRadixBins);
-    uint32_t* totals3 = scratch.take<uint32_t>(ptk::kSweepMaxPasses * ptk::kRadixBins);
-    uint32_t* tickets = scratch.take<uint32_t>(ptk::kSweepMaxPasses);
-    uint2* pairs_a = scratch.take<uint2>(nq);
-    uint2* pairs_b = passes > 2 ? scratch.take<uint2>(nq) : pairs_a;
-    if (!counts3 || !state || !totals3 || !tickets || !pairs_a || !pairs_b || passes > ptk::kSweepMaxPasses)
-      return fail(PTK_ERR_NOMEM, "scratch block too small");
-    const float3 lo3 = make_float3(lo[0], lo[1], lo[2]), inv3 = make_float3(inv[0], inv[1], inv[2]);
-    const uint3 b3 = make_uint3(b[0], b[1], b[2]);
-    hipLaunchKernelGGL((ptk::radix_sweep_key_kernel<>), dim3(tiles), dim3(ptk::kSortBlock), passes * ptk::kRadixBins * 4, s,
-                       d_q, t->dim, (uint32_t)nq, lo3, inv3, b3, keys, passes, counts3, state, totals3, tickets, cells,
-                       as_given);
-    hipLaunchKernelGGL(ptk::radix_sweep_totals_kernel, dim3(std::min<uint32_t>(tiles, 64u)), dim3(256), 0, s, counts3, tiles,
-                       passes, totals3, as_given);
-    const uint2* in = nullptr;
-    for (uint32_t p = 0; p < passes; ++p) {
-      const bool first = p == 0, last = p + 1 == passes;
-      uint2* out = in == pairs_a ? pairs_b : pairs_a;
-      uint32_t* st = state + (size_t)p * tiles * ptk::kRadixBins;
-#define PTK_SWEEP(F, L)                                                                                                \
-  hipLaunchKernelGGL((ptk::radix_sweep_pass_kernel<F, L>), dim3(tiles), dim3(ptk::kSortBlock), ptk::kSortScatterLds, s, \
-                     keys, in, out, ids_out, (uint32_t)nq, 8u * p, st, totals3 + p * ptk::kRadixBins, tickets + p, as_given)
-      if (first && last) PTK_SWEEP(true, true);
-      else if (first) PTK_SWEEP(true, false);
-      else if (last) PTK_SWEEP(false, true);
-      else PTK_SWEEP(false, false);
-#undef PTK_SWEEP
-      in = out;
-    }
-    PTK_HIP(hipGetLastError());
-    *perm = ids_out;
-    scratch.note_order(1);
-    timer.stop(1, 0);
-    return PTK_OK;
-  }
   if (own_sort(nq)) {
     // Key + histogram kernel, then per 8-bit pass: scan of the digit-by-tile histogram, stable scatter (and the
     // histogram of the next digit): 3 launches per pass - 1... nothing to clear, no look-back (ptk_sort.hpp).

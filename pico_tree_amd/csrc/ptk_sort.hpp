@@ -11,7 +11,11 @@
 //   scatter     one wavefront per tile: position = (digits below) + (same digit in earlier tiles) + (same digit
 //               earlier in the tile); the rank inside a round of 64 items comes from eight ballots
 //
-// with nothing to clear, no look-back and no spinning: every dependency is a kernel boundary.  Stable, so the result
+// with nothing to clear, no look-back and no spinning: every dependency is a kernel boundary.  (r05 built the other form
+// -- digit totals of all passes counted beside the keys, then ONE kernel per pass that takes a ticket, publishes its
+// tile's digit counts and looks back over its predecessors' -- 5 launches instead of 10, every pass's input read once:
+// correct and SLOWER, 7.2 M rows 0.206 -> 0.266 ms, 2 M 0.098 -> 0.126, 900 k +5 us: a look-back step is an L2 round
+// trip across XCDs that every tile pays in line.  profiles/r05_notes.txt item 5; the code is in the history.)  Stable, so the result
 // is the permutation a stable sort of the keys gives (tests/test_kernel_emulation.py compares it with numpy).
 // The caller's row order is untouched -- results are written by original row; the order only decides which
 // queries share a wavefront, i.e. cache lines and the wave-uniform prefix of phase 1.
@@ -351,202 +355,6 @@ __global__ __launch_bounds__(BLOCK) void radix_block_scatter_kernel(
     if (t < kRadixBins) {
       lbase[t] = in_tile;
       gbase[t] = in_all + hist[t * stride + blockIdx.x];
-    }
-  }
-  __syncthreads();
-#pragma unroll
-  for (uint32_t r = 0; r < ITEMS; ++r) {
-    if (valid[r]) {
-      const uint32_t digit = (key[r] >> shift) & 255u;
-      buf[lbase[digit] + wave_cnt[w * kRadixBins + digit] + rank[r]] = (unsigned long long)key[r] | ((unsigned long long)val[r] << 32);
-    }
-  }
-  __syncthreads();
-  const uint32_t held = n - base < TILE ? n - base : TILE;
-#pragma unroll
-  for (uint32_t j = 0; j < ITEMS; ++j) {
-    const uint32_t at = j * BLOCK + t;
-    if (at < held) {
-      const unsigned long long kv = buf[at];
-      const uint32_t digit = ((uint32_t)kv >> shift) & 255u;
-      const uint32_t dst = gbase[digit] + (at - lbase[digit]);
-      if (LAST) vals_out[dst] = (uint32_t)(kv >> 32);
-      else pairs_out[dst] = make_uint2((uint32_t)kv, (uint32_t)(kv >> 32));
-    }
-  }
-}
-
-
-// ---- the passes with the scan folded in (r05) --------------------------------------------------------------------
-// The block passes above are three launches per digit (histogram of the tiles, scan, scatter) and read every pass's
-// input twice.  Here the digit totals of ALL passes are counted once, beside the keys, and a pass is ONE kernel: a
-// tile's place in the output = (digits below: from the totals) + (same digit in earlier tiles: a decoupled look-back
-// over the tiles' published counts) + (same digit earlier in the tile: the ranking of radix_block_scatter_kernel).
-//
-//   radix_sweep_key_kernel      tile t: Morton keys (stored), digit counts of every pass -> counts3[t][pass][256]; clears
-//                               the look-back words of tile t for every pass; block 0 clears the totals and the tickets
-//   radix_sweep_totals_kernel   totals[pass][digit] = sum over the tiles (columns are contiguous: coalesced)
-//   radix_sweep_pass_kernel     takes a TICKET (tiles are numbered in the order blocks start, so every predecessor of a
-//                               running tile is running or done: the look-back cannot wait for a block that has no
-//                               slot), counts its digits, publishes {flag | count} per digit in one 32-bit word,
-//                               looks back -- thread d over the words of digit d -- until it meets an inclusive prefix,
-//                               publishes its own inclusive prefix, scatters.
-// A look-back word is written once as LOCAL and once as INCLUSIVE, both with the value in the same word: no ordering
-// between words is needed.  Writers and readers run on different CUs and XCDs: agent-scope atomic stores and loads
-// (sc1: the L1 of the reader is bypassed, the per-XCD L2s are kept coherent for such accesses).
-// 5 launches for three passes instead of 10: 7.2 M rows 0.192 -> see profiles/r05_notes.txt item 5.
-constexpr uint32_t kSweepLocal = 1u << 30, kSweepInclusive = 2u << 30, kSweepValue = (1u << 30) - 1u;
-constexpr uint32_t kSweepMaxPasses = 3;
-
-__device__ __forceinline__ uint32_t agent_load_u32(const uint32_t* p) {
-#if defined(__HIPCC__)
-  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  return *p;
-#endif
-}
-__device__ __forceinline__ void agent_store_u32(uint32_t* p, uint32_t v) {
-#if defined(__HIPCC__)
-  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#else
-  *p = v;
-#endif
-}
-
-// counts3: [tiles][passes][256]; state: [passes][tiles][256]; totals: [passes][256]; tickets: [passes].
-template <uint32_t BLOCK = kSortBlock, uint32_t ITEMS = kSortItems>
-__global__ __launch_bounds__(BLOCK) void radix_sweep_key_kernel(
-    const float* __restrict__ queries, uint32_t dim, uint32_t nq, float3 lo, float3 inv, uint3 bits,
-    uint32_t* __restrict__ keys, uint32_t passes, uint32_t* __restrict__ counts3, uint32_t* __restrict__ state,
-    uint32_t* __restrict__ totals, uint32_t* __restrict__ tickets, CellTable cells = CellTable{},
-    const uint32_t* __restrict__ as_given = nullptr) {
-  if (as_given != nullptr && *as_given != 0u) return;  // (uniform) a coherent batch is not sorted: coherence_sample_kernel
-  typedef PTK_LDS uint32_t LdsU32;
-  LdsU32* cnt = (LdsU32*)ptk_smem;  // [passes][256]
-  const uint32_t t = threadIdx.x, tiles = gridDim.x;
-  for (uint32_t j = t; j < passes * kRadixBins; j += BLOCK) {
-    cnt[j] = 0u;
-    state[((uint64_t)(j / kRadixBins) * tiles + blockIdx.x) * kRadixBins + (j % kRadixBins)] = 0u;
-    if (blockIdx.x == 0u) totals[j] = 0u;
-  }
-  if (blockIdx.x == 0u && t < passes) tickets[t] = 0u;
-  __syncthreads();
-  const uint32_t base = blockIdx.x * (BLOCK * ITEMS);
-  float x[ITEMS], y[ITEMS], z[ITEMS];  // (all the rows of a thread in flight together)
-  bool valid[ITEMS];
-#pragma unroll
-  for (uint32_t j = 0; j < ITEMS; ++j) {
-    const uint32_t i = base + j * BLOCK + t;
-    valid[j] = i < nq;
-    load_query(queries, dim, valid[j] ? i : nq - 1u, x[j], y[j], z[j]);
-  }
-#pragma unroll
-  for (uint32_t j = 0; j < ITEMS; ++j) {
-    const uint32_t key = order_key(x[j], y[j], z[j], lo, inv, bits, cells);
-    if (valid[j]) {
-      keys[base + j * BLOCK + t] = key;
-      for (uint32_t p = 0; p < passes; ++p) lds_add_u32(&cnt[p * kRadixBins + ((key >> (8u * p)) & 255u)], 1u);
-    }
-  }
-  __syncthreads();
-  for (uint32_t j = t; j < passes * kRadixBins; j += BLOCK) counts3[(uint64_t)blockIdx.x * (passes * kRadixBins) + j] = cnt[j];
-}
-
-// grid = (slices); block = 256 x passes columns handled by BLOCK threads in turn.
-__global__ __launch_bounds__(256) void radix_sweep_totals_kernel(const uint32_t* __restrict__ counts3, uint32_t tiles,
-                                                                 uint32_t passes, uint32_t* __restrict__ totals,
-                                                                 const uint32_t* __restrict__ as_given = nullptr) {
-  if (as_given != nullptr && *as_given != 0u) return;
-  const uint32_t cols = passes * kRadixBins;
-  const uint32_t per = (tiles + gridDim.x - 1u) / gridDim.x;
-  const uint32_t t0 = blockIdx.x * per, t1 = t0 + per < tiles ? t0 + per : tiles;
-  for (uint32_t c = threadIdx.x; c < cols; c += 256u) {
-    uint32_t sum = 0;
-    for (uint32_t tile = t0; tile < t1; ++tile) sum += counts3[(uint64_t)tile * cols + c];
-    if (sum != 0u) atomicAdd(&totals[c], sum);
-  }
-}
-
-// One pass; FIRST / LAST as radix_scatter_kernel.  state / totals / ticket: of THIS pass.
-template <bool FIRST, bool LAST, uint32_t BLOCK = kSortBlock, uint32_t ITEMS = kSortItems>
-__global__ __launch_bounds__(BLOCK) void radix_sweep_pass_kernel(
-    const uint32_t* __restrict__ keys_in, const uint2* __restrict__ pairs_in, uint2* __restrict__ pairs_out,
-    uint32_t* __restrict__ vals_out, uint32_t n, uint32_t shift, uint32_t* __restrict__ state,
-    const uint32_t* __restrict__ totals, uint32_t* __restrict__ ticket, const uint32_t* __restrict__ as_given = nullptr) {
-  if (as_given != nullptr && *as_given != 0u) return;  // (uniform) a coherent batch is not sorted
-  constexpr uint32_t WAVES = BLOCK / 64u, TILE = BLOCK * ITEMS;
-  static_assert(BLOCK >= kRadixBins && BLOCK % 64u == 0u, "a thread per digit");
-  typedef PTK_LDS uint32_t LdsU32;
-  LdsU32* wave_cnt = (LdsU32*)ptk_smem;            // [WAVES][256] digit counts of each wavefront's part, then their prefix
-  LdsU32* lbase = wave_cnt + WAVES * kRadixBins;    // [256] where a digit begins in the tile
-  LdsU32* gbase = lbase + kRadixBins;               // [256] where this tile's items of a digit begin in the output
-  LdsU32* tmp = gbase + kRadixBins;                 // [32] (tmp[16]: the tile this block took)
-  LdsWord* buf = (LdsWord*)(tmp + 32);              // [TILE] the tile in digit order
-  const uint32_t t = threadIdx.x, lane = t & 63u, w = t >> 6;
-  if (t == 0u) tmp[16] = atomicAdd(ticket, 1u);
-  for (uint32_t j = t; j < WAVES * kRadixBins; j += BLOCK) wave_cnt[j] = 0u;
-  __syncthreads();
-  const uint32_t tile = tmp[16];
-  const uint32_t base = tile * TILE;
-  // This wavefront's part of the tile, in index order: round r = items [w * ITEMS * 64 + r * 64, + 64).
-  uint32_t key[ITEMS], val[ITEMS], rank[ITEMS];
-  bool valid[ITEMS];
-#pragma unroll
-  for (uint32_t r = 0; r < ITEMS; ++r) {
-    const uint32_t i = base + w * (ITEMS * 64u) + r * 64u + lane;
-    valid[r] = i < n;
-    if (FIRST) {
-      key[r] = valid[r] ? keys_in[i] : 0u;
-      val[r] = i;
-    } else {
-      const uint2 p = valid[r] ? pairs_in[i] : make_uint2(0u, 0u);
-      key[r] = p.x;
-      val[r] = p.y;
-    }
-  }
-  const uint64_t below = (1ull << lane) - 1ull;
-#pragma unroll
-  for (uint32_t r = 0; r < ITEMS; ++r) {
-    const uint32_t digit = (key[r] >> shift) & 255u;
-    const uint64_t peers = same_digit_lanes(digit, valid[r]);
-    const uint32_t before = wave_cnt[w * kRadixBins + (valid[r] ? digit : 0u)];
-    rank[r] = before + (uint32_t)__popcll(peers & below);
-    if (valid[r] && (peers >> lane) == 1ull) wave_cnt[w * kRadixBins + digit] = before + (uint32_t)__popcll(peers);
-  }
-  __syncthreads();
-  {
-    uint32_t sum = 0;
-    if (t < kRadixBins) {
-#pragma unroll
-      for (uint32_t j = 0; j < WAVES; ++j) {
-        const uint32_t c = wave_cnt[j * kRadixBins + t];
-        wave_cnt[j * kRadixBins + t] = sum;
-        sum += c;
-      }
-    }
-    // Digit t of this tile: published, then the same digit of the tiles before it summed up to an inclusive prefix.
-    uint32_t before_tiles = 0;
-    if (t < kRadixBins) {
-      uint32_t* mine = state + (uint64_t)tile * kRadixBins + t;
-      agent_store_u32(mine, (tile == 0u ? kSweepInclusive : kSweepLocal) | sum);
-      uint32_t p = tile;
-      while (p > 0u) {
-        --p;
-        const uint32_t* theirs = state + (uint64_t)p * kRadixBins + t;
-        uint32_t v;
-        do {
-          v = agent_load_u32(theirs);
-        } while ((v >> 30) == 0u);
-        before_tiles += v & kSweepValue;
-        if ((v >> 30) == 2u) break;
-      }
-      if (tile != 0u) agent_store_u32(mine, kSweepInclusive | (before_tiles + sum));
-    }
-    const uint32_t in_tile = block_exclusive_sum(t < kRadixBins ? sum : 0u, t, tmp);
-    const uint32_t in_all = block_exclusive_sum(t < kRadixBins ? totals[t] : 0u, t, tmp + 8);
-    if (t < kRadixBins) {
-      lbase[t] = in_tile;
-      gbase[t] = in_all + before_tiles;
     }
   }
   __syncthreads();

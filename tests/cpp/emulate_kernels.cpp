@@ -1118,45 +1118,6 @@ void emu_radix_sort_blocks(const float* q, uint32_t dim, uint64_t nq, const floa
   std::memcpy(perm, out_perm.data(), nq * 4);
 }
 
-// The passes with the scan folded in (radix_sweep_*): keys + the digit counts of every pass, their totals, one kernel per
-// pass with tickets and the look-back over the tiles' published counts (blocks run one after the other here, in ticket
-// order: a predecessor has always published).
-void emu_radix_sort_sweep(const float* q, uint32_t dim, uint64_t nq, const float* lo, const float* inv,
-                          const uint32_t* bits, uint32_t key_bits, uint32_t* keys, uint32_t* perm) {
-  const float3 l = make_float3(lo[0], lo[1], lo[2]);
-  const float3 i = make_float3(inv[0], inv[1], inv[2]);
-  const uint3 b3 = make_uint3(bits[0], bits[1], bits[2]);
-  const uint32_t tiles = (uint32_t)((nq + ptk::kSortTile - 1) / ptk::kSortTile);
-  const uint32_t passes = (key_bits + 7) / 8;
-  std::vector<uint32_t> counts3((size_t)tiles * passes * ptk::kRadixBins, 0xEEEEEEEEu);
-  std::vector<uint32_t> state((size_t)passes * tiles * ptk::kRadixBins, 0xEEEEEEEEu);
-  std::vector<uint32_t> totals(passes * ptk::kRadixBins, 0xEEEEEEEEu), tickets(ptk::kSweepMaxPasses, 0xEEEEEEEEu);
-  std::vector<uint32_t> k0(nq, 0xEEEEEEEEu), out_perm(nq, 0xEEEEEEEEu);
-  std::vector<uint2> pa(nq, uint2{0xEEEEEEEEu, 0xEEEEEEEEu}), pb(nq, uint2{0xEEEEEEEEu, 0xEEEEEEEEu});
-  for_each_block(tiles, ptk::kSortBlock, [&] {
-    ptk::radix_sweep_key_kernel<>(q, dim, (uint32_t)nq, l, i, b3, k0.data(), passes, counts3.data(), state.data(), totals.data(),
-                                  tickets.data());
-  });
-  for_each_lane(3 * 256, [&] { ptk::radix_sweep_totals_kernel(counts3.data(), tiles, passes, totals.data()); }, 256);
-  const uint2* in = nullptr;
-  for (uint32_t p = 0; p < passes; ++p) {
-    const uint32_t shift = 8 * p;
-    const bool first = p == 0, last = p + 1 == passes;
-    uint2* out = in == pa.data() ? pb.data() : pa.data();
-    uint32_t* st = state.data() + (size_t)p * tiles * ptk::kRadixBins;
-    uint32_t* tot = totals.data() + p * ptk::kRadixBins;
-    for_each_block(tiles, ptk::kSortBlock, [&] {
-      if (first && last) ptk::radix_sweep_pass_kernel<true, true>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, st, tot, &tickets[p]);
-      else if (first) ptk::radix_sweep_pass_kernel<true, false>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, st, tot, &tickets[p]);
-      else if (last) ptk::radix_sweep_pass_kernel<false, true>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, st, tot, &tickets[p]);
-      else ptk::radix_sweep_pass_kernel<false, false>(k0.data(), in, out, out_perm.data(), (uint32_t)nq, shift, st, tot, &tickets[p]);
-    });
-    in = out;
-  }
-  std::memcpy(keys, k0.data(), nq * 4);
-  std::memcpy(perm, out_perm.data(), nq * 4);
-}
-
 }  // extern "C"
 
 // ---- double precision (ptk_kernels_f64.hpp) ----------------------------------------------------

@@ -227,13 +227,6 @@ class EmulatedTree:
         inv[:d] = np.where(ext > 0, np.exp2(bits[:d]).astype(np.float32) / ext, 0).astype(np.float32)
         keys = np.zeros(len(q), dtype=np.uint32)
         perm = np.zeros(len(q), dtype=np.uint32)
-        if tile == -1:  # the passes with the scan folded in (tickets + look-back)
-            self.lib.emu_radix_sort_sweep.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32,
-                                                      c_void_p, c_void_p]
-            self.lib.emu_radix_sort_sweep.restype = None
-            self.lib.emu_radix_sort_sweep(q.ctypes.data, d, len(q), lo.ctypes.data, inv.ctypes.data, bits.ctypes.data,
-                                          int(bits.sum()), keys.ctypes.data, perm.ctypes.data)
-            return perm, keys
         if tile == 0:
             self.lib.emu_radix_sort_blocks.argtypes = [c_void_p, c_uint32, c_uint64, c_void_p, c_void_p, c_void_p, c_uint32,
                                                        c_void_p, c_void_p]

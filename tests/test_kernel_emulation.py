@@ -139,14 +139,12 @@ def test_morton_keys_follow_the_curve():
 @pytest.mark.parametrize("nq,bits,tile", [(4_000, (6, 5, 5), 256), (4_096, (8, 8, 8), 512), (777, (3, 2, 1), 64),
                                           (64, (8, 8, 0), 64), (1, (8, 8, 8), 256), (9_001, (11, 10, 3), 1024),
                                           (9_001, (11, 10, 3), 0), (4_096, (6, 5, 5), 0), (4_097, (3, 2, 1), 0),
-                                          (13_000, (8, 8, 0), 0), (100, (8, 8, 8), 0),
-                                          (9_001, (11, 10, 3), -1), (4_096, (6, 5, 5), -1), (4_097, (3, 2, 1), -1),
-                                          (13_000, (8, 8, 0), -1), (100, (8, 8, 8), -1)])
+                                          (13_000, (8, 8, 0), 0), (100, (8, 8, 8), 0)])
 def test_own_radix_sort_is_the_stable_sort_of_the_keys(nq, bits, tile):
     """ptk_sort.hpp (histogram / scan / scatter per 8-bit pass) against numpy's stable argsort of the same keys,
     incl. a ragged last tile, a last pass of fewer than 8 bits, heavy duplicates (6 key bits for 777 items).  tile = 0:
     the passes with blocks of four wavefronts on tiles of 4 096 items (256 fibers per block: ballots per wavefront,
-    barriers per block); tile = -1: the passes with the scan folded in (tickets, published counts, look-back)."""
+    barriers per block)."""
     pts = ds.lidar_cloud(3_000, seed=5)
     emu = EmulatedTree(pts, 10)
     q = ds.lidar_cloud(nq, seed=6, pose=(1.0, 0.5))
