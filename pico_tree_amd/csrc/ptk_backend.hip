@@ -1235,18 +1235,6 @@ int launch_radius_replay(const ptk_tree* t, const float* d_q, float e, const ptk
                          hipStream_t s) {
   Timer timer(t, s);
   PTK_HIP(hipMemsetAsync(n_over, 0, 4, s));
-  // PTK_REPLAY: 1 = a query per lane and the ring in LDS (r04), 2 = a wavefront per row (r05; the default)
-  if (env_int("PTK_REPLAY", 2) != 1) {
-    if (t->dev.cmask < 16u)
-      hipLaunchKernelGGL((ptk::radius_replay_rows_kernel<4, M>), dim3(cap.n_static), dim3(64), 0, s, t->dev, d_q, t->dim,
-                         inv_ratio(e), cap, d_offsets, d_out, over_list, n_over);
-    else
-      hipLaunchKernelGGL((ptk::radius_replay_rows_kernel<5, M>), dim3(cap.n_static), dim3(64), 0, s, t->dev, d_q, t->dim,
-                         inv_ratio(e), cap, d_offsets, d_out, over_list, n_over);
-    PTK_HIP(hipGetLastError());
-    timer.stop(0, 0);
-    return PTK_OK;
-  }
   hipLaunchKernelGGL((ptk::radius_replay_kernel<kReplayHits, kReplayRing, M>), dim3(cap.n_static), dim3(64),
                      ptk::replay_lds(kReplayRing), s, t->dev, d_q, t->dim, inv_ratio(e), cap, d_offsets, d_out, over_list,
                      n_over);

@@ -367,103 +367,4 @@ __global__ __launch_bounds__(64) void radius_replay_kernel(
   flush(true);
 }
 
-
-// ---- the fill pass with a wavefront per ROW (r05) ------------------------------------------------------------------
-// radius_replay_kernel keeps one query per lane: every lane gathers its own hits and the rows leave through a ring in
-// LDS that makes 64-byte lines of them -- 17 KB of LDS per wavefront (9 wavefronts per CU), 58 % of the wavefront
-// cycles waiting, bank conflicts in the ring (profiles/r04z_c3_pmc.txt).  Here the wavefront of tile w (the 64 queries
-// the count pass searched together) takes its queries ONE AFTER THE OTHER, and a row is written by all 64 lanes:
-//   the entries of the query (its list: 8 bytes per listed leaf) are loaded one per lane, 64 at a time;
-//   a round covers 64 >> SLOT_LOG2 entries: lane l looks at point `l % SLOTS` of entry `l / SLOTS` (two shuffles for the
-//   entry); the lanes whose point is a hit rank themselves with a ballot, fetch the point, measure it with the
-//   arithmetic of the leaf scan and store {index, distance} at row + hits so far + rank.
-// The hits of a round leave as ONE contiguous run of 8-byte stores -- the row is written in order, whole sectors but
-// for the seams between rounds, by the store instruction itself: no ring, no LDS, no flush, 30+ wavefronts per CU.
-// A list is in visit order and the points of an entry in index order, so is the row (search_visitor.hpp:127-156).
-// SLOT_LOG2 = 4 for trees whose leaves hold fewer than 16 points (an entry's mask then has 15 bits at most), else 5.
-template <int SLOT_LOG2, class M = MetricL2>
-__global__ __launch_bounds__(64) void radius_replay_rows_kernel(
-    DevTree t, const float* __restrict__ queries, uint32_t dim, float e_inv, RadiusCapture cap,
-    const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out, uint32_t* __restrict__ over_list,
-    uint32_t* __restrict__ n_over) {
-  constexpr uint32_t SLOTS = 1u << SLOT_LOG2, EPR = 64u >> SLOT_LOG2;  // points looked at per entry, entries per round
-  const uint32_t lane = threadIdx.x;
-  const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
-  const uint32_t qi = cap.qids[(uint64_t)tile * 64u + lane];
-  const bool valid = qi != kLogEnd;
-  if (!cap.captured[tile]) {  // (uniform)
-    if (valid) over_list[atomicAdd(n_over, 1u)] = qi;
-    return;
-  }
-  float qx_l, qy_l, qz_l;
-  load_query(queries, dim, valid ? qi : 0u, qx_l, qy_l, qz_l);
-  pad_query<M>(dim, qy_l, qz_l);
-  const uint32_t n_l = valid ? cap.lens[(uint64_t)tile * 64u + lane] : 0u;
-  const uint64_t row_l = valid ? offsets[qi] : 0ull;
-  const uint32_t my_chunk = cap.tables[(uint64_t)tile * kListMaxChunks + lane];  // lane c: chunk c of the wavefront
-  const unsigned long long* __restrict__ slots = reinterpret_cast<const unsigned long long*>(cap.chunks);
-  const float4* __restrict__ pts = t.pts;
-  const uint32_t src = lane >> SLOT_LOG2, bit = lane & (SLOTS - 1u);
-
-  // The entries of lane q's list from entry e0 on, one per lane (0 behind its end: an entry without hits).
-  auto load_entries = [&](uint32_t q, uint32_t n, uint32_t e0) -> unsigned long long {
-    const uint32_t j = e0 + lane;
-    const uint32_t g = j / kListGroup;
-    const uint32_t chunk = (uint32_t)__shfl((int)my_chunk, (int)((g / kListGroups) & 63u));
-    unsigned long long entry = 0ull;
-    if (j < n) entry = slots[list_group_at(chunk, g % kListGroups, q) + (j % kListGroup)];
-    return entry;
-  };
-  // (the first entries of the NEXT query with a list are on their way while this one's rows are written)
-  uint32_t q = 0;
-  while (q < 64u && (uint32_t)__shfl((int)n_l, (int)q) == 0u) ++q;  // (uniform)
-  unsigned long long ahead = q < 64u ? load_entries(q, (uint32_t)__shfl((int)n_l, (int)q), 0u) : 0ull;
-  while (q < 64u) {  // (uniform)
-    const uint32_t n = (uint32_t)__shfl((int)n_l, (int)q);
-    const float qx = __shfl(qx_l, (int)q), qy = __shfl(qy_l, (int)q), qz = __shfl(qz_l, (int)q);
-    uint64_t row = ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(row_l >> 32), (int)q) << 32) |
-                   (uint64_t)(uint32_t)__shfl((int)(uint32_t)row_l, (int)q);
-    uint32_t q_next = q + 1u;
-    while (q_next < 64u && (uint32_t)__shfl((int)n_l, (int)q_next) == 0u) ++q_next;  // (uniform)
-    for (uint32_t e0 = 0; e0 < n; e0 += 64u) {  // (uniform) the entries of lane q's list, 64 at a time
-      const unsigned long long entry = ahead;
-      if (e0 + 64u < n) ahead = load_entries(q, n, e0 + 64u);
-      else if (q_next < 64u) ahead = load_entries(q_next, (uint32_t)__shfl((int)n_l, (int)q_next), 0u);
-      const uint32_t first_j = ((uint32_t)entry & 0x7FFFFFFFu) >> t.cbits, mask_j = (uint32_t)(entry >> 32);
-      const uint32_t held = n - e0 < 64u ? n - e0 : 64u;
-      constexpr uint32_t U = 4;  // rounds whose points are fetched together
-      for (uint32_t r0 = 0; r0 < held; r0 += U * EPR) {  // (uniform)
-        uint64_t m[U];
-        float4 p[U];
-        bool hit[U];
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-          const uint32_t from = (r0 + u * EPR + src) & 63u;  // (beyond `held`: an entry without hits, or lane 63's)
-          const uint32_t first = (uint32_t)__shfl((int)first_j, (int)from);
-          const uint32_t mask = r0 + u * EPR < held ? (uint32_t)__shfl((int)mask_j, (int)from) : 0u;
-          hit[u] = ((mask >> bit) & 1u) != 0u;
-          m[u] = __ballot(hit[u]);
-          if (hit[u]) p[u] = pts[first + bit];
-        }
-#pragma unroll
-        for (uint32_t u = 0; u < U; ++u) {
-          if (hit[u]) {
-            PTK_KEEP4(p[u]);
-            float dx = f_sub(qx, p[u].x), dy = f_sub(qy, p[u].y), dz = f_sub(qz, p[u].z);
-            PTK_SCALAR(dx);
-            PTK_SCALAR(dy);
-            PTK_SCALAR(dz);
-            Neighbor nb;
-            nb.index = __float_as_int(p[u].w);
-            nb.distance = f_mul(point_distance3<M>(dx, dy, dz), e_inv);
-            out[row + lanes_below(m[u], lane)] = nb;
-          }
-          row += (uint64_t)__popcll(m[u]);
-        }
-      }
-    }
-    q = q_next;
-  }
-}
-
 }  // namespace ptk

@@ -749,15 +749,8 @@ int64_t emu_radius_lists(void* h, const float* q, uint64_t nq, float radius, flo
   std::vector<uint32_t> over(nq + 1, 0u);
   uint32_t n_over = 0;
   for_each_wave((uint32_t)waves, [&] {
-    if (fill == 2) {  // a wavefront per row (radius_replay_rows_kernel): 16 or 32 points looked at per entry
-      if (t->metric == 1) ptk::radius_replay_rows_kernel<5, ptk::MetricL1>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
-      else if (t->dev.cmask < 16u) ptk::radius_replay_rows_kernel<4>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
-      else ptk::radius_replay_rows_kernel<5>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
-    } else if (t->metric == 1) {
-      ptk::radius_replay_kernel<3, 32, ptk::MetricL1>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
-    } else {
-      ptk::radius_replay_kernel<5, 16>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
-    }
+    if (t->metric == 1) ptk::radius_replay_kernel<3, 32, ptk::MetricL1>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
+    else ptk::radius_replay_kernel<5, 16>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
   });
   for_each_lane(nq, [&] {
     if (t->metric == 1) ptk::radius_kernel<16, 2048, 64, 4, true, ptk::MetricL1>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o, &n_over);

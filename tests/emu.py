@@ -121,7 +121,7 @@ class EmulatedTree:
         assert redone >= 0
         return off, out, int(redone)
 
-    def search_radius_lists(self, q, radius, sort=False, e=None, perm=None, sub_cap=64, rows=False):
+    def search_radius_lists(self, q, radius, sort=False, e=None, perm=None, sub_cap=64):
         """The radius search with the rows made from leaf lists: the listing count pass, then the replay
         (+ the ordinary fill kernel for wavefronts whose lists were lost)."""
         q = np.ascontiguousarray(q, dtype=np.float32)
@@ -136,9 +136,7 @@ class EmulatedTree:
         off = np.zeros(nq + 1, dtype=np.uint64)
         off[1:] = np.cumsum(counts[:nq])
         out = np.zeros(int(off[-1]), dtype=pt.NEIGHBOR)
-        # (rows: the fill pass with a wavefront per row, radius_replay_rows_kernel, instead of a query per lane + the ring)
-        lost = fn(self.h, q.ctypes.data, nq, radius, e or 1.0, p, sub_cap, 2 if rows else 1, None, off.ctypes.data,
-                  out.ctypes.data)
+        lost = fn(self.h, q.ctypes.data, nq, radius, e or 1.0, p, sub_cap, 1, None, off.ctypes.data, out.ctypes.data)
         assert lost >= 0
         return off, out, int(lost)
 

@@ -429,7 +429,7 @@ def test_emulated_radius_capture(sub_cap):
 @pytest.mark.parametrize("sub_cap", [1024, 0])
 def test_emulated_radius_leaf_lists(sub_cap):
     """The radius search with the rows made from leaf lists (ptk_kernels_lists.hpp): the listing count pass, the
-    replay through the ring and the replay with a wavefront per row (64 fibers per wavefront) -- rows equal the oracle's whether every list fits its chunks or
+    replay through the ring (64 fibers per wavefront) -- rows equal the oracle's whether every list fits its chunks or
     the long ones are lost (static chunk only: 16 listed leaves per query) and go to the ordinary fill kernel."""
     pts, q = ds.uniform_cloud(20_000, 3, 41), ds.uniform_cloud(1_500, 3, 42)
     q[:200] = pts[:200]
@@ -440,9 +440,9 @@ def test_emulated_radius_leaf_lists(sub_cap):
     some_lost = False
     for radius, e in ((0.0004, None), (0.01, None), (0.03, None), (0.09, None), (0.02, 1.6)):
         want_off, want = ref.search_radius(q, radius, e=e)
-        for pm, rows in ((None, False), (perm, False), (perm, True)):  # (rows: the fill pass with a wavefront per row)
-            off, got, lost = emu.search_radius_lists(q, radius, e=e, perm=pm, sub_cap=sub_cap, rows=rows)
-            assert np.array_equal(off, want_off) and got.tobytes() == want.tobytes(), (radius, rows)
+        for pm in (None, perm):
+            off, got, lost = emu.search_radius_lists(q, radius, e=e, perm=pm, sub_cap=sub_cap)
+            assert np.array_equal(off, want_off) and got.tobytes() == want.tobytes()
             if sub_cap == 1024:
                 assert lost == 0
             some_lost |= lost > 0
@@ -450,15 +450,13 @@ def test_emulated_radius_leaf_lists(sub_cap):
     lidar, lq = ds.lidar_cloud(30_000, 1), ds.lidar_cloud(1_000, 2, pose=(3.0, 1.5))
     emu, ref = EmulatedTree(lidar, 40), oracle.Oracle(lidar, 40, "port")  # leaves of more than 32 points: listed in pieces
     want_off, want = ref.search_radius(lq, 1.0)
-    for rows in (False, True):
-        off, got, lost = emu.search_radius_lists(lq, 1.0, sub_cap=1024, rows=rows)
-        assert lost == 0 and np.array_equal(off, want_off) and got.tobytes() == want.tobytes(), rows
+    off, got, lost = emu.search_radius_lists(lq, 1.0, sub_cap=1024)
+    assert lost == 0 and np.array_equal(off, want_off) and got.tobytes() == want.tobytes()
     two = ds.uniform_cloud(5_000, 2, 7)
     emu, ref = EmulatedTree(two, 6), oracle.Oracle(two, 6, "port")
     want_off, want = ref.search_radius(two[:1_000], 0.002)
-    for rows in (False, True):
-        off, got, lost = emu.search_radius_lists(two[:1_000], 0.002, sub_cap=8, rows=rows)
-        assert np.array_equal(off, want_off) and got.tobytes() == want.tobytes(), rows
+    off, got, lost = emu.search_radius_lists(two[:1_000], 0.002, sub_cap=8)
+    assert np.array_equal(off, want_off) and got.tobytes() == want.tobytes()
 
 
 @pytest.mark.parametrize("sub_cap", [1024, 0, 1])
