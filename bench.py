@@ -432,6 +432,15 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     res["knn16"] = {"value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms, 4), "steps": steps,
                     "parity_sample_ok": bool(got.tobytes() == want.tobytes()), "roofline": r,
                     "long_searches": coop}
+    # ---- knn = 4 and knn = 8 through the same three launches (what capping the long searches buys is largest there)
+    for kk in (4, 8):
+        ms_k, prof_k, out_k = time_device_knn(tree, dq, kk, 5, warmup=1)
+        want_k = ref.search_knn(q[cs[:20_000]], kk)
+        got_k = pt.DeviceNeighbors(out_k).numpy()[cs[:20_000]]
+        del out_k
+        res[f"knn{kk}"] = {"value": round(nq / ms_k / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms_k, 4),
+                           "kernel_ms": round(prof_k["search_ms"] / max(int(prof_k["launches"]), 1), 4),
+                           "parity_sample_ok": bool(got_k.tobytes() == want_k.tobytes())}
     # ---- radius: count pass that lists the leaves with hits + scan + fill pass that replays the lists
     radius, steps = 1.0, 3
     for _ in range(2):  # (the 6 GB of rows are a block of torch's allocator from the second call on)

@@ -119,7 +119,10 @@ typedef struct ptk_tree_info {
 /* Query-order policy for the nearest-neighbour kernels.  Coherent (spatially
  * sorted) batches traverse the tree several times faster; with PTK_REORDER_ON
  * the backend sorts the batch along a Morton curve on the device and scatters
- * results back, so the caller-visible row order never changes. */
+ * results back, so the caller-visible row order never changes.  PTK_REORDER_AUTO
+ * (the default) sorts batches of 8 192 queries or more; a k = 1 batch is sampled on
+ * the device first and, if it already is in a coherent order (a scan in scan order),
+ * searched in the caller's order -- the verdict never travels to the host. */
 enum { PTK_REORDER_AUTO = 0, PTK_REORDER_ON = 1, PTK_REORDER_OFF = 2 };
 
 /* ---- library ---------------------------------------------------------- */
@@ -210,7 +213,9 @@ int ptk_search_knn(const ptk_tree* tree, const float* queries, uint64_t nq,
                    uint32_t k, float e, ptk_neighbor* out);
 
 /* Device buffers on the tree's device; asynchronous on `stream` (a hipStream_t,
- * NULL = the default stream).  No host synchronisation is performed. */
+ * NULL = the default stream).  No host synchronisation is performed: the call only
+ * enqueues -- the decisions that depend on the batch (is it already in a coherent order?
+ * which queries need the cooperative search?) are taken on the device. */
 int ptk_search_knn_device(const ptk_tree* tree, const float* d_queries,
                           uint64_t nq, uint32_t k, float e,
                           ptk_neighbor* d_out, void* stream);

@@ -3166,6 +3166,10 @@ int ptk_debug_wave_trace(void* d_trace) {
   PTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ptk::g_wave_trace), &p, sizeof(p)));
   return PTK_OK;
 }
+int ptk_debug_wave_trace_select(int kernel) {  // which of the k = 1 kernels records (ptk_kernels.hpp, PTK_TRACE_BEGIN_SEL)
+  PTK_HIP(hipMemcpyToSymbol(HIP_SYMBOL(ptk::g_wave_trace_sel), &kernel, sizeof(kernel)));
+  return PTK_OK;
+}
 #endif
 
 int ptk_debug_batch_order(const ptk_tree* t, int* how) {

@@ -1015,6 +1015,7 @@ extern __shared__ __attribute__((aligned(16))) unsigned char ptk_smem[];
 // bound by its throughput from one that waits for a tail of slow wavefronts.  The shipped library has none of this.
 #if defined(PTK_WAVE_TRACE)
 __device__ unsigned long long* g_wave_trace = nullptr;  // [4 * blocks of the launch]
+__device__ int g_wave_trace_sel = 0;                    // which of the k = 1 kernels records (0: none of them)
 #endif
 #if defined(PTK_WAVE_TRACE) && defined(__HIP_DEVICE_COMPILE__)
 #define PTK_TRACE_BEGIN() const unsigned long long trace_t0_ = wall_clock64(); const unsigned long long trace_c0_ = clock64()
@@ -1028,9 +1029,25 @@ __device__ unsigned long long* g_wave_trace = nullptr;  // [4 * blocks of the la
       g_wave_trace[4ull * blockIdx.x + 3] = clock64() - trace_c0_;                                         \
     }                                                                                                    \
   } while (0)
+// The k = 1 kernels (their lanes leave one by one): recorded only when g_wave_trace_sel names the kernel (1 = phase 1,
+// 2 = phase 2, 3 = the direct cooperative search, 4 = the cooperative search behind phase 2); the end is the last lane's.
+#define PTK_TRACE_BEGIN_SEL(ID)                                                      \
+  const bool trace_on_ = g_wave_trace != nullptr && g_wave_trace_sel == (ID);        \
+  const unsigned long long trace_t0_ = wall_clock64()
+#define PTK_TRACE_END_ANY()                                                                                   \
+  do {                                                                                                        \
+    if (trace_on_) {                                                                                          \
+      g_wave_trace[4ull * blockIdx.x + 0] = trace_t0_;                                                        \
+      atomicMax(&g_wave_trace[4ull * blockIdx.x + 1], (unsigned long long)wall_clock64());                    \
+      g_wave_trace[4ull * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |   \
+          ((unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 20) << 32);                             \
+    }                                                                                                         \
+  } while (0)
 #else
 #define PTK_TRACE_BEGIN() ((void)0)
 #define PTK_TRACE_END() ((void)0)
+#define PTK_TRACE_BEGIN_SEL(ID) ((void)0)
+#define PTK_TRACE_END_ANY() ((void)0)
 #endif
 
 // ---- general k -------------------------------------------------------------------------
@@ -1471,6 +1488,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     float e_inv, Neighbor* __restrict__ out, Cont cont, float4* __restrict__ qs_out,
     uint32_t* __restrict__ tile_counts = nullptr, uint32_t count_stride = 0,
     const uint32_t* __restrict__ as_given = nullptr) {
+  PTK_TRACE_BEGIN_SEL(1);
   const uint64_t i0 = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   const bool valid = i0 < nq;
   const uint64_t i = valid ? i0 : nq - 1;  // idle lanes shadow the last query: ballots stay full-width
@@ -1693,6 +1711,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
       if ((uint32_t)s < c) cont.record(e, (uint32_t)s) = keep[s];
     }
   }
+  PTK_TRACE_END_ANY();
 }
 
 // One thread, after the sort: where the tiers of the sorted list end.
@@ -1896,6 +1915,7 @@ template <int S, int OVF, int LEAFB>
 __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
     const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, Handover ho = Handover{}) {
+  PTK_TRACE_BEGIN_SEL(2);
   const uint32_t n2 = cont.meta[0];
   const uint32_t heavy = cont.meta[1];
   const uint32_t heavy_waves = cont.meta[2];
@@ -1964,6 +1984,7 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   } else {  // listed by the traversal; the cooperative search starts from the best so far
     cont.best[e] = make_uint4((uint32_t)pol.best_i, __float_as_uint(pol.best_d), cls, 0u);
   }
+  PTK_TRACE_END_ANY();
 }
 
 // ---- cooperative search of the queries phase 2 gave up on ---------------------------------------
@@ -2054,6 +2075,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
     Task* __restrict__ spill = nullptr, uint32_t spill_cap = 0) {
   static_assert(G == 8 || G == 16 || G == 32 || G == 64, "lanes per query");
   static_assert(DIRECT ? POOL >= 2 * kContSlots : POOL >= (int)kMaxTasks, "the pool must hold what a query starts with");
+  PTK_TRACE_BEGIN_SEL(DIRECT ? 3 : 4);
   constexpr int NG = 64 / G;
   typedef PTK_LDS uint32_t LdsU32;
   const uint4* __restrict__ nodes = t.nodes;
@@ -2405,6 +2427,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
       }
     }
   }
+  PTK_TRACE_END_ANY();
 }
 
 // The reference search from the root for the queries the cooperative search listed.

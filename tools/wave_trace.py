@@ -117,9 +117,55 @@ def run(cloud, out_path):
             print(json.dumps(r))
 
 
+def run_k1(cloud, out_path, nq_cut=None):
+    """The kernels of the two-phase k = 1 search, one traced step each (full batch, or its first nq_cut rows)."""
+    import ctypes
+    import torch
+    import pico_tree_amd as pt
+    from pico_tree_amd import datasets as ds
+
+    pt._LIB_PATH = LIB
+    lib = pt._load()
+    lib.ptk_debug_wave_trace.argtypes = [ctypes.c_void_p]
+    lib.ptk_debug_wave_trace_select.argtypes = [ctypes.c_int]
+    pts, q = ds.config2_clouds(cloud)
+    if nq_cut:
+        q = np.ascontiguousarray(q[:nq_cut])
+    nq = len(q)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=0)
+    dq = torch.from_numpy(q).cuda()
+    out = torch.empty((nq, 1, 2), dtype=torch.int32, device="cuda")
+    for _ in range(3):
+        tree.search_knn(dq, 1, out)
+    torch.cuda.synchronize()
+    blocks = nq // 64 + 8192
+    trace = torch.zeros((blocks, 4), dtype=torch.int64, device="cuda")
+    assert lib.ptk_debug_wave_trace(trace.data_ptr()) == 0
+    names = {1: "knn1_phase1u_kernel", 2: "knn1_phase2_kernel", 3: "knn1_coop_kernel<direct>", 4: "knn1_coop_kernel<tail>"}
+    slots = {1: 256 * 32, 2: 256 * 26, 3: 256 * 17, 4: 256 * 17}
+    with open(out_path, "w") as f:
+        for sel in (1, 2, 3, 4):
+            trace.zero_()
+            assert lib.ptk_debug_wave_trace_select(sel) == 0
+            tree.search_knn(dq, 1, out)
+            torch.cuda.synchronize()
+            tr = trace.cpu().numpy().view(np.uint64)
+            if not (tr[:, 1] > 0).any():
+                continue
+            r = analyse(f"{names[sel]} k=1 cloud {cloud} nq={nq}", tr, slots[sel])
+            f.write(json.dumps(r) + "\n")
+            print(json.dumps(r), flush=True)
+    lib.ptk_debug_wave_trace_select(0)
+    lib.ptk_debug_wave_trace(None)
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "build":
         build()
+    elif sys.argv[1] == "k1":
+        run_k1(sys.argv[2] if len(sys.argv) > 2 else "L",
+               sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "r05_wave_trace_k1.jsonl"),
+               int(sys.argv[4]) if len(sys.argv) > 4 else None)
     else:
         run(sys.argv[2] if len(sys.argv) > 2 else "L",
             sys.argv[3] if len(sys.argv) > 3 else os.path.join(ROOT, "gpurun_out", "r05_wave_trace.jsonl"))
