@@ -1099,7 +1099,8 @@ constexpr int kKnnCoopPool = 128;
 constexpr uint32_t kKnnCoopSpill = 2048;  // tasks a wavefront of the cooperative search can park in HBM
 uint32_t knn_coop_blocks(const ptk_tree* t) { return (uint32_t)t->cus * (uint32_t)std::max(1, env_int("PTK_KNN_COOP_WAVES", 32)); }
 uint32_t knn_cap(float e, uint64_t nq) {
-  if (e != 1.0f || nq < 4096) return 0;
+  // (PTK_KNN_CAP_MIN_NQ: tests -- the fuzzer's batches are small)
+  if (e != 1.0f || nq < (uint64_t)std::max(1, env_int("PTK_KNN_CAP_MIN_NQ", 4096))) return 0;
   return (uint32_t)std::max(0, env_int("PTK_KNN_CAP", 256));
 }
 uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 64, std::min<uint64_t>(nq, 8192)); }
