@@ -1021,7 +1021,7 @@ __device__ int g_wave_trace_sel = 0;                    // which of the k = 1 ke
 #define PTK_TRACE_BEGIN() const unsigned long long trace_t0_ = wall_clock64(); const unsigned long long trace_c0_ = clock64()
 #define PTK_TRACE_END()                                                                                  \
   do {                                                                                                   \
-    if (g_wave_trace != nullptr && threadIdx.x == 0) {                                                   \
+    if (g_wave_trace != nullptr && g_wave_trace_sel == 0 && threadIdx.x == 0) {                          \
       g_wave_trace[4ull * blockIdx.x + 0] = trace_t0_;                                                   \
       g_wave_trace[4ull * blockIdx.x + 1] = wall_clock64();                                              \
       g_wave_trace[4ull * blockIdx.x + 2] = (unsigned long long)__builtin_amdgcn_s_getreg((31 << 11) | 4) |  \

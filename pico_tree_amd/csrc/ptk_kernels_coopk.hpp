@@ -328,7 +328,11 @@ __device__ __forceinline__ bool knn_coop_sweep(
   return ok;
 }
 
-// grid: any number of one-wavefront blocks; block b takes entries b, b + grid, ... of the hand-over list.
+// grid: any number of one-wavefront blocks; block b takes entries b, b + grid, ... of the hand-over list.  (Handing
+// the entries out through a counter instead -- a free wavefront takes the next one -- was measured: every entry
+// through the counter 0.1 ms slower (thousands of returning atomics on one word at the start), only the entries past
+// the first grid through it no different; asking for 5 / 6 / 8 wavefronts per SIMD instead of the 4 its 118 VGPRs
+// allow: no different / slower / spills.  profiles/r05_notes.txt item 11.)
 // `redo_word`: the word of ho.meta that counts redo_list.  `ranges`: per branch, the record range of its subtree
 // (dfs_before).  What the pool (LDS) has no room for is parked in the wavefront's run of `spill_cap` tasks of `spill`
 // (HBM) and comes back when the pool has drained: 64 lanes keeping a far child each fill a pool of 128 in two steps
@@ -340,6 +344,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
     Neighbor* __restrict__ out, Handover ho, uint32_t* __restrict__ redo_list, uint32_t redo_word,
     Task* __restrict__ spill, uint32_t spill_cap) {
   static_assert(POOL >= (int)kMaxTasks, "the pool must hold what a query starts with");
+  PTK_TRACE_BEGIN_SEL(5);
   typedef PTK_LDS uint32_t LdsU32;
   Task* const spill_w = spill + (uint64_t)blockIdx.x * spill_cap;
   const uint32_t lane = threadIdx.x;
@@ -508,6 +513,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
       atomicAdd(&ho.meta[failed ? kKnnWhyPool : (crowded ? kKnnWhyTie : (box ? kKnnWhyBox : kKnnWhyRange))], 1u);
     }
   }
+  PTK_TRACE_END_ANY();
 }
 
 // The reference search from the root for the queries the cooperative search could not certify (rows as knn_reg_kernel

@@ -101,6 +101,17 @@ def run(cloud, out_path):
     torch.cuda.synchronize()
     reports.append(analyse(f"knn_reg_kernel k={k} cloud {cloud}", trace.cpu().numpy().view(np.uint64), 256 * 20))
     print(json.dumps(reports[-1]), flush=True)
+    # the cooperative search of the same step (selector 5; the general kernel writes the same words, so it runs untraced)
+    lib.ptk_debug_wave_trace_select.argtypes = [ctypes.c_int]
+    trace.zero_()
+    assert lib.ptk_debug_wave_trace_select(5) == 0
+    tree.search_knn(dq, k, out)
+    torch.cuda.synchronize()
+    tr = trace.cpu().numpy().view(np.uint64).copy()
+    lib.ptk_debug_wave_trace_select(0)
+    if (tr[:, 1] > 0).any():
+        reports.append(analyse(f"knn_coop_kernel k={k} cloud {cloud}", tr, 8192))
+        print(json.dumps(reports[-1]), flush=True)
     del out
     trace.zero_()
     res = tree.search_radius_device(dq, 1.0)
