@@ -175,7 +175,7 @@ inline constexpr int ptk_metric_v = std::is_same_v<Metric_, metric_l2_squared> ?
                                     : std::is_same_v<Metric_, metric_so2>      ? PTK_METRIC_SO2
                                     : std::is_same_v<Metric_, metric_se2_squared> ? PTK_METRIC_SE2_SQUARED
                                                                                : -1;
-//! The topological metrics: float points only, knn and radius searches (the tree carries four bounds per branch).
+//! The topological metrics (the tree carries four bounds per branch).
 template <typename Metric_>
 inline constexpr bool ptk_topological_v =
     std::is_same_v<Metric_, metric_so2> || std::is_same_v<Metric_, metric_se2_squared>;
@@ -185,7 +185,7 @@ inline constexpr bool ptk_topological_v =
 template <typename Metric_, typename Scalar_, typename Index_>
 inline constexpr bool is_accelerated_v =
     ptk_metric_v<Metric_> >= 0 &&
-    (std::is_same_v<Scalar_, float> || (std::is_same_v<Scalar_, double> && !ptk_topological_v<Metric_>)) &&
+    (std::is_same_v<Scalar_, float> || std::is_same_v<Scalar_, double>) &&
     std::is_same_v<Index_, int> && sizeof(int) == 4;
 
 //! The C entry points of one scalar type under one set of names.
@@ -316,10 +316,18 @@ class device_tree {
         std::ostringstream os(std::ios::out | std::ios::binary);
         write_flat_tree(tree, os);
         std::string const bytes = os.str();
-        ptk_check(
-            ptk_tree64_create_from_stream(
-                pts.data(), n, static_cast<std::uint32_t>(dim), bytes.data(), bytes.size(), PTK_DEVICE_CURRENT, &h),
-            "ptk_tree64_create_from_stream");
+        // (a tree over a topological space writes four bounds per branch: write_flat_tree, keep_outer_bounds)
+        if (tree.keep_outer_bounds) {
+          ptk_check(
+              ptk_tree64_create_from_topological_stream(
+                  pts.data(), n, static_cast<std::uint32_t>(dim), bytes.data(), bytes.size(), PTK_DEVICE_CURRENT, &h),
+              "ptk_tree64_create_from_topological_stream");
+        } else {
+          ptk_check(
+              ptk_tree64_create_from_stream(
+                  pts.data(), n, static_cast<std::uint32_t>(dim), bytes.data(), bytes.size(), PTK_DEVICE_CURRENT, &h),
+              "ptk_tree64_create_from_stream");
+        }
       }
       if (metric != PTK_METRIC_L2_SQUARED) {
         int const rc = api::set_metric(h, metric);

@@ -334,9 +334,23 @@ int ptk_tree64_create_from_stream(const double* points, uint64_t n_points,
                                   ptk_tree64** out);
 void ptk_tree64_destroy(ptk_tree64* tree);
 int ptk_tree64_get_info(const ptk_tree64* tree, ptk_tree_info* info);
+/* Any PTK_METRIC_* value.  The two topological metrics -- kd_tree<space of double points, metric_so2 |
+ * metric_se2_squared> (metric.hpp:186-257), searched as search_nearest_topological does
+ * (internal/kd_tree_search.hpp:115-229) -- need dim 1 / dim 3 and the four bounds per branch: a tree made by
+ * ptk_tree64_create_from_points or ptk_tree64_create_from_topological_stream has them, one read from a plain
+ * stream does not (PTK_ERR_INVALID). */
 int ptk_tree64_set_metric(ptk_tree64* tree, int metric);
 int ptk_tree64_serialize(const ptk_tree64* tree, void* buf, uint64_t cap,
                          uint64_t* size);
+/* As ptk_tree_serialize_topological / ptk_tree_create_from_topological_stream: the stream kd_tree<topological
+ * space of double points, ...>::save writes (kd_tree_branch_double records, kd_tree_node.hpp:52-67: 40 bytes). */
+int ptk_tree64_serialize_topological(const ptk_tree64* tree, void* buf,
+                                     uint64_t cap, uint64_t* size);
+int ptk_tree64_create_from_topological_stream(const double* points,
+                                              uint64_t n_points, uint32_t dim,
+                                              const void* stream,
+                                              uint64_t stream_bytes,
+                                              int32_t device, ptk_tree64** out);
 
 /* As ptk_search_knn / ptk_search_knn_device. */
 int ptk_search64_knn(const ptk_tree64* tree, const double* queries, uint64_t nq,

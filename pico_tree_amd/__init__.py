@@ -125,6 +125,9 @@ _SIGNATURES = {
     "ptk_tree64_get_info": (c_int, [c_void_p, POINTER(_Info)]),
     "ptk_tree64_set_metric": (c_int, [c_void_p, c_int]),
     "ptk_tree64_serialize": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
+    "ptk_tree64_serialize_topological": (c_int, [c_void_p, c_void_p, c_uint64, POINTER(c_uint64)]),
+    "ptk_tree64_create_from_topological_stream": (c_int, [c_void_p, c_uint64, c_uint32, c_void_p, c_uint64, c_int32,
+                                                          POINTER(c_void_p)]),
     "ptk_search64_knn": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_double, c_void_p]),
     "ptk_search64_knn_device": (c_int, [c_void_p, c_void_p, c_uint64, c_uint32, c_double, c_void_p, c_void_p]),
     "ptk_search64_radius": (c_int, [c_void_p, c_void_p, c_uint64, c_double, c_double, c_int, c_void_p,
@@ -521,8 +524,6 @@ class KdTree:
         lib = _load()
         handle = c_void_p()
         dev = PTK_DEVICE_CURRENT if device is None else int(device)
-        if self._f64 and self._metric.name in ("SO2", "SE2Squared"):
-            raise ValueError("the topological metrics (SO2, SE2Squared) are available for float32 points only")
         self._fn = (lambda name: getattr(lib, name.replace("ptk_tree_", "ptk_tree64_").replace("ptk_search_", "ptk_search64_"))) \
             if self._f64 else (lambda name: getattr(lib, name))
         if _stream is None:

@@ -16,7 +16,8 @@ struct ptk_tree64 {
   using flat_t = pico_tree::internal::flat_tree<int, double, pico_tree::dynamic_extent>;
   uint32_t dim = 0;
   uint64_t n_points = 0;
-  flat_t flat{1};  // host copy (DFS pre-order stream)
+  flat_t flat{1};  // host copy (DFS pre-order stream); its own outer_bounds stay empty:
+  std::vector<std::array<double, 2>> outer;  // per stream node {left_min, right_max} (topological metrics); may be empty
   uint64_t n_leaves = 0;
   uint32_t max_depth = 0;
   uint32_t max_leaf_count = 0;
@@ -28,6 +29,7 @@ struct ptk_tree64 {
   void* d_index = nullptr;
   void* d_ranges = nullptr;
   void* d_root = nullptr;  // root box: min[dim], max[dim]
+  void* d_outer = nullptr; // topological metrics only: double2 per branch (made by ptk_tree64_set_metric)
   uint64_t device_bytes = 0;
   uint32_t slots = 0;      // stack records a lane may need: 2 * depth + 4
   std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
@@ -229,6 +231,12 @@ int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipS
     } else if (metric_ == PTK_METRIC_LNINF) {           \
       using M = ptk::Metric64LNInf;                     \
       CALL;                                             \
+    } else if (metric_ == PTK_METRIC_SO2) {             \
+      using M = ptk::Topo64SO2;                         \
+      CALL;                                             \
+    } else if (metric_ == PTK_METRIC_SE2_SQUARED) {     \
+      using M = ptk::Topo64SE2;                         \
+      CALL;                                             \
     } else {                                            \
       using M = ptk::Metric64L2;                        \
       CALL;                                             \
@@ -259,7 +267,7 @@ int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, u
     else if (reg == 8) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 8, true>));
     else if (reg == 16) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 16, true>));
     else PTK_LAUNCH64((ptk::knn64_kernel<M, true>));
-  } else {
+  } else if constexpr (!M::kTopo) {  // (the topological metrics: dim 1 or 3)
     if (reg == 4) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 4, false>));
     else if (reg == 8) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 8, false>));
     else if (reg == 16) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 16, false>));
@@ -277,14 +285,14 @@ int launch_radius64(const ptk_tree64* t, const double* d_q, const uint32_t* perm
   const bool d3 = t->dim <= 3;
   const size_t smem = ptk::lds64_bytes(d3 ? 0 : 2, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
-  int rc = allow_lds(ptk::radius64_kernel<M, FILL, false>, smem);
+  int rc = allow_lds(ptk::radius64_kernel<M, FILL, M::kTopo>, smem);
   if (rc != PTK_OK) return rc;
   for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {
     const uint64_t n = std::min(lease.piece, nq - q0);
     if (d3) {
       hipLaunchKernelGGL((ptk::radius64_kernel<M, FILL, true>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
                          d_q, perm, q0, n, radius, 1.0 / e, d_counts, d_offsets, d_out, lease.stack, t->slots);
-    } else {
+    } else if constexpr (!M::kTopo) {
       hipLaunchKernelGGL((ptk::radius64_kernel<M, FILL, false>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
                          d_q, perm, q0, n, radius, 1.0 / e, d_counts, d_offsets, d_out, lease.stack, t->slots);
     }
@@ -298,13 +306,24 @@ int launch_box64(const ptk_tree64* t, const double* d_mins, const double* d_maxs
                  const uint64_t* d_offsets, int32_t* d_out, hipStream_t s, Stack64Lease& lease) {
   const size_t smem = ptk::lds64_bytes(4, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
-  int rc = allow_lds(ptk::box64_kernel<FILL>, smem);
+  // A topological tree: circle axes (metric_so2: axis 0; metric_se2_squared: axis 2), the four-bound tests.
+  const int metric = t->metric.load();
+  const bool topo = metric == PTK_METRIC_SO2 || metric == PTK_METRIC_SE2_SQUARED;
+  const uint32_t s1_mask = !topo ? 0u : (metric == PTK_METRIC_SO2 ? 1u : 4u);
+  if (topo && t->dev.outer == nullptr) return fail(PTK_ERR_INVALID, "this topological tree has no outer bounds on the device");
+  int rc = topo ? allow_lds(ptk::box64_kernel<FILL, true>, smem) : allow_lds(ptk::box64_kernel<FILL, false>, smem);
   if (rc != PTK_OK) return rc;
   for (uint64_t b0 = 0; b0 < nb; b0 += lease.piece) {
     const uint64_t n = std::min(lease.piece, nb - b0);
-    hipLaunchKernelGGL((ptk::box64_kernel<FILL>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
-                       static_cast<const double*>(t->d_root), d_mins, d_maxs, b0, n, d_counts, d_offsets, d_out,
-                       lease.stack, t->slots);
+    if (topo) {
+      hipLaunchKernelGGL((ptk::box64_kernel<FILL, true>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
+                         static_cast<const double*>(t->d_root), d_mins, d_maxs, b0, n, d_counts, d_offsets, d_out,
+                         lease.stack, t->slots, s1_mask);
+    } else {
+      hipLaunchKernelGGL((ptk::box64_kernel<FILL, false>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev,
+                         static_cast<const double*>(t->d_root), d_mins, d_maxs, b0, n, d_counts, d_offsets, d_out,
+                         lease.stack, t->slots, 0u);
+    }
   }
   PTK_HIP(hipGetLastError());
   return PTK_OK;
@@ -331,6 +350,68 @@ void adopt_flat64(ptk_tree64* t, Flat&& flat, uint32_t dim, uint64_t n_points) {
   t->dim = dim;
   t->n_points = n_points;
   t->flat = std::forward<Flat>(flat);
+  // The four-bound form lives beside the tree, so that ptk_tree64_serialize keeps writing the euclidean stream.
+  t->outer = std::move(t->flat.outer_bounds);
+  t->flat.outer_bounds.clear();
+  t->flat.keep_outer_bounds = false;
+}
+
+// What write_flat_tree reads of a tree, with the outer bounds of the handle (or none).
+struct FlatView64 {
+  using index_type = int;
+  using scalar_type = double;
+  const decltype(ptk_tree64::flat_t::root_box)& root_box;
+  const decltype(ptk_tree64::flat_t::indices)& indices;
+  const decltype(ptk_tree64::flat_t::nodes)& nodes;
+  bool keep_outer_bounds;
+  const std::vector<std::array<double, 2>>& outer_bounds;
+};
+
+int serialize64(const ptk_tree64* t, bool topological, void* buf, uint64_t cap, uint64_t* size) {
+  if (t == nullptr || size == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (topological && t->outer.size() != t->flat.nodes.size())
+    return fail(PTK_ERR_INVALID, "this tree has no outer bounds: it cannot be written as a topological tree");
+  try {
+    std::ostringstream os(std::ios::out | std::ios::binary);
+    const FlatView64 view{t->flat.root_box, t->flat.indices, t->flat.nodes, topological, t->outer};
+    pico_tree::internal::write_flat_tree(view, os);
+    const std::string bytes = os.str();
+    *size = bytes.size();
+    if (buf == nullptr) return PTK_OK;
+    if (cap < bytes.size()) return fail(PTK_ERR_INVALID, "buffer of %llu bytes, stream needs %llu",
+                                        (unsigned long long)cap, (unsigned long long)bytes.size());
+    std::memcpy(buf, bytes.data(), bytes.size());
+    return PTK_OK;
+  } catch (const std::bad_alloc&) {
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  }
+}
+
+int create_from_stream64(const double* points, uint64_t n_points, uint32_t dim, const void* stream, uint64_t stream_bytes,
+                         bool topological, int32_t device, ptk_tree64** out) {
+  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
+  *out = nullptr;
+  if (points == nullptr || stream == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (dim == 0 || n_points == 0) return fail(PTK_ERR_INVALID, "dim and n_points must be positive");
+  ptk_tree64* t = nullptr;
+  try {
+    std::istringstream is(std::string(static_cast<const char*>(stream), stream_bytes), std::ios::in | std::ios::binary);
+    ptk_tree64::flat_t flat = pico_tree::internal::read_flat_tree<ptk_tree64::flat_t>(is, topological, dim, n_points);
+    if (flat.root_box.size() != dim) return fail(PTK_ERR_INVALID, "stream is %zu-dimensional, points are %u-dimensional",
+                                                 (size_t)flat.root_box.size(), dim);
+    if (flat.indices.size() != n_points)
+      return fail(PTK_ERR_INVALID, "stream indexes %zu points, %llu were given", flat.indices.size(),
+                  (unsigned long long)n_points);
+    t = new ptk_tree64;
+    adopt_flat64(t, std::move(flat), dim, n_points);
+  } catch (const std::bad_alloc&) {
+    delete t;
+    return fail(PTK_ERR_NOMEM, "out of memory");
+  } catch (const std::exception& e) {
+    delete t;
+    return fail(PTK_ERR_INVALID, "bad kd_tree stream: %s", e.what());
+  }
+  return finish_create64(t, points, device, out);
 }
 
 }  // namespace
@@ -353,7 +434,7 @@ int ptk_tree64_create_from_points(const double* points, uint64_t n_points, uint3
     space_t space(points, n_points, dim);
     internal::space_view<space_t> view(space);
     adopt_flat64(t, internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf_size), bounds_from_space,
-                                                   sliding_midpoint_max_side, false, build_threads()),
+                                                   sliding_midpoint_max_side, true, build_threads()),
                  dim, n_points);
   } catch (const std::bad_alloc&) {
     delete t;
@@ -367,29 +448,12 @@ int ptk_tree64_create_from_points(const double* points, uint64_t n_points, uint3
 
 int ptk_tree64_create_from_stream(const double* points, uint64_t n_points, uint32_t dim, const void* stream,
                                   uint64_t stream_bytes, int32_t device, ptk_tree64** out) {
-  if (out == nullptr) return fail(PTK_ERR_INVALID, "null out pointer");
-  *out = nullptr;
-  if (points == nullptr || stream == nullptr) return fail(PTK_ERR_INVALID, "null argument");
-  if (dim == 0 || n_points == 0) return fail(PTK_ERR_INVALID, "dim and n_points must be positive");
-  ptk_tree64* t = nullptr;
-  try {
-    std::istringstream is(std::string(static_cast<const char*>(stream), stream_bytes), std::ios::in | std::ios::binary);
-    ptk_tree64::flat_t flat = pico_tree::internal::read_flat_tree<ptk_tree64::flat_t>(is, false, dim, n_points);
-    if (flat.root_box.size() != dim) return fail(PTK_ERR_INVALID, "stream is %zu-dimensional, points are %u-dimensional",
-                                                 (size_t)flat.root_box.size(), dim);
-    if (flat.indices.size() != n_points)
-      return fail(PTK_ERR_INVALID, "stream indexes %zu points, %llu were given", flat.indices.size(),
-                  (unsigned long long)n_points);
-    t = new ptk_tree64;
-    adopt_flat64(t, std::move(flat), dim, n_points);
-  } catch (const std::bad_alloc&) {
-    delete t;
-    return fail(PTK_ERR_NOMEM, "out of memory");
-  } catch (const std::exception& e) {
-    delete t;
-    return fail(PTK_ERR_INVALID, "bad kd_tree stream: %s", e.what());
-  }
-  return finish_create64(t, points, device, out);
+  return create_from_stream64(points, n_points, dim, stream, stream_bytes, false, device, out);
+}
+
+int ptk_tree64_create_from_topological_stream(const double* points, uint64_t n_points, uint32_t dim, const void* stream,
+                                              uint64_t stream_bytes, int32_t device, ptk_tree64** out) {
+  return create_from_stream64(points, n_points, dim, stream, stream_bytes, true, device, out);
 }
 
 void ptk_tree64_destroy(ptk_tree64* t) {
@@ -404,6 +468,7 @@ void ptk_tree64_destroy(ptk_tree64* t) {
     if (t->d_index) (void)hipFree(t->d_index);
     if (t->d_ranges) (void)hipFree(t->d_ranges);
     if (t->d_root) (void)hipFree(t->d_root);
+    if (t->d_outer) (void)hipFree(t->d_outer);
   }
   delete t;
 }
@@ -422,27 +487,39 @@ int ptk_tree64_get_info(const ptk_tree64* t, ptk_tree_info* info) {
 }
 
 int ptk_tree64_set_metric(ptk_tree64* t, int metric) {
-  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_LNINF)
+  if (t == nullptr || metric < PTK_METRIC_L2_SQUARED || metric > PTK_METRIC_SE2_SQUARED)
     return fail(PTK_ERR_INVALID, "bad metric");
+  if (metric == PTK_METRIC_SO2 || metric == PTK_METRIC_SE2_SQUARED) {
+    if (metric == PTK_METRIC_SO2 && t->dim != 1) return fail(PTK_ERR_INVALID, "metric_so2 is a metric of 1-dimensional points");
+    if (metric == PTK_METRIC_SE2_SQUARED && t->dim != 3)
+      return fail(PTK_ERR_INVALID, "metric_se2_squared is a metric of 3-dimensional points (x, y, angle)");
+    if (t->outer.size() != t->flat.nodes.size())
+      return fail(PTK_ERR_INVALID, "the topological metrics need the outer bounds of every branch "
+                                   "(ptk_tree64_create_from_points / ptk_tree64_create_from_topological_stream)");
+    std::lock_guard<std::mutex> lock(t->mutex);
+    if (t->device >= 0 && t->d_outer == nullptr) {  // branch order of the device records
+      std::vector<double> dev_outer;
+      std::string err = ptk::encode_outer64(t->dim, t->n_points, t->flat.nodes.data(), t->flat.nodes.size(),
+                                            t->outer.data(), dev_outer);
+      if (!err.empty()) return fail(PTK_ERR_INVALID, "%s", err.c_str());
+      DeviceGuard guard(t->device);
+      if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
+      PTK_HIP(hipMalloc(&t->d_outer, dev_outer.size() * sizeof(double)));
+      PTK_HIP(hipMemcpy(t->d_outer, dev_outer.data(), dev_outer.size() * sizeof(double), hipMemcpyHostToDevice));
+      t->dev.outer = static_cast<const double2*>(t->d_outer);
+      t->device_bytes += dev_outer.size() * sizeof(double);
+    }
+  }
   t->metric.store(metric);
   return PTK_OK;
 }
 
 int ptk_tree64_serialize(const ptk_tree64* t, void* buf, uint64_t cap, uint64_t* size) {
-  if (t == nullptr || size == nullptr) return fail(PTK_ERR_INVALID, "null argument");
-  try {
-    std::ostringstream os(std::ios::out | std::ios::binary);
-    pico_tree::internal::write_flat_tree(t->flat, os);
-    const std::string bytes = os.str();
-    *size = bytes.size();
-    if (buf == nullptr) return PTK_OK;
-    if (cap < bytes.size()) return fail(PTK_ERR_INVALID, "buffer of %llu bytes, stream needs %llu",
-                                        (unsigned long long)cap, (unsigned long long)bytes.size());
-    std::memcpy(buf, bytes.data(), bytes.size());
-    return PTK_OK;
-  } catch (const std::bad_alloc&) {
-    return fail(PTK_ERR_NOMEM, "out of memory");
-  }
+  return serialize64(t, false, buf, cap, size);
+}
+
+int ptk_tree64_serialize_topological(const ptk_tree64* t, void* buf, uint64_t cap, uint64_t* size) {
+  return serialize64(t, true, buf, cap, size);
 }
 
 int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq, uint32_t k, double e,

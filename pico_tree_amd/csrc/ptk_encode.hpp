@@ -471,4 +471,31 @@ inline std::string encode_tree64(
   return std::string();
 }
 
+// The two outer bounds of every branch -- {left_min, right_max}, per stream node in `outer` -- in the branch order of
+// encode_tree64's records (what the topological metrics read beside them).
+template <class NodeT, class PairT>
+inline std::string encode_outer64(uint32_t dim, uint64_t n_points, const NodeT* fn, uint64_t n_nodes, const PairT* outer,
+                                  std::vector<double>& out) {
+  std::vector<ptk_node> shape(n_nodes);
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    if (fn[i].is_leaf()) {
+      shape[i] = ptk_node{(uint32_t)fn[i].begin, (uint32_t)fn[i].end, PTK_LEAF, 0};
+    } else {
+      shape[i] = ptk_node{0, 0, fn[i].right, fn[i].split_dim};
+    }
+  }
+  TreeStats st;
+  std::vector<uint32_t> branch_id;
+  std::string err = analyse_stream(dim, n_points, shape.data(), n_nodes, st, &branch_id);
+  if (!err.empty()) return err;
+  const uint64_t n_branch = n_nodes - st.n_leaves;
+  out.assign(2 * (n_branch > 0 ? n_branch : 1), 0.0);
+  for (uint64_t i = 0; i < n_nodes; ++i) {
+    if (fn[i].is_leaf()) continue;
+    out[2 * (size_t)branch_id[i]] = outer[i][0];
+    out[2 * (size_t)branch_id[i] + 1] = outer[i][1];
+  }
+  return std::string();
+}
+
 }  // namespace ptk

@@ -54,6 +54,7 @@ struct DevTree64 {
   const double* pts;
   const int32_t* index;
   const uint2* ranges;  // per branch: position range of its whole subtree (box search)
+  const double2* outer; // per branch {left_min, right_max}: the topological metrics only (else null)
   uint32_t root_ref;
   uint32_t cbits;
   uint32_t cmask;
@@ -72,16 +73,19 @@ __device__ __forceinline__ double d_mul(double a, double b) { return __dmul_rn(a
 // metric.hpp:72-150, as MetricL2 / MetricL1 / MetricLInf of ptk_kernels.hpp.
 struct Metric64L2 {
   static constexpr bool kMin = false;
+  static constexpr bool kTopo = false;
   __device__ __forceinline__ static double one(double x) { return d_mul(x, x); }
   __device__ __forceinline__ static double acc(double d, double diff) { return d_add(d, d_mul(diff, diff)); }
 };
 struct Metric64L1 {
   static constexpr bool kMin = false;
+  static constexpr bool kTopo = false;
   __device__ __forceinline__ static double one(double x) { return fabs(x); }
   __device__ __forceinline__ static double acc(double d, double diff) { return d_add(d, fabs(diff)); }
 };
 struct Metric64LInf {
   static constexpr bool kMin = false;
+  static constexpr bool kTopo = false;
   __device__ __forceinline__ static double one(double x) { return fabs(x); }
   __device__ __forceinline__ static double acc(double d, double diff) {
     const double a = fabs(diff);
@@ -90,6 +94,7 @@ struct Metric64LInf {
 };
 struct Metric64LNInf {  // metric_lninf, as MetricLNInf of ptk_kernels.hpp
   static constexpr bool kMin = true;
+  static constexpr bool kTopo = false;
   __device__ __forceinline__ static double one(double x) { return fabs(x); }
   __device__ __forceinline__ static double acc(double d, double diff) {
     const double a = fabs(diff);
@@ -104,6 +109,48 @@ template <class M>
 __device__ __forceinline__ double metric64_pad() {
   return M::kMin ? __longlong_as_double(0x7FF0000000000000ll) : 0.0;
 }
+
+// The reference's topological metrics over double points (metric.hpp:186-257; ptk_kernels_topo.hpp is the float form):
+// distance.hpp:26-29 s1_distance, segment.hpp:38-46 segment_r1::distance, :77-99 segment_s1::distance.
+__device__ __forceinline__ double s1_distance64(double x, double y) {
+  const double d = fabs(d_sub(x, y));
+  const double w = d_sub(1.0, d);
+  return w < d ? w : d;  // std::min(d, 1 - d)
+}
+__device__ __forceinline__ double seg_r1_distance64(double mn, double mx, double x) {
+  return x < mn ? d_sub(mn, x) : (x > mx ? d_sub(x, mx) : 0.0);
+}
+__device__ __forceinline__ double seg_s1_distance64(double mn, double mx, double x) {
+  const double a = s1_distance64(x, mn), b = s1_distance64(x, mx);
+  const double m = b < a ? b : a;  // std::min(a, b)
+  if (mn <= mx) return (x < mn || x > mx) ? m : 0.0;
+  return (x < mx || x > mn) ? 0.0 : m;
+}
+struct Topo64SO2 {  // metric_so2, metric.hpp:197-220: dim 1, axis 0 on the circle
+  static constexpr bool kMin = false;
+  static constexpr bool kTopo = true;
+  static constexpr uint32_t kS1Mask = 1u;
+  __device__ __forceinline__ static double box(double mn, double mx, double v, uint32_t) {
+    return fabs(seg_s1_distance64(mn, mx, v));
+  }
+  __device__ __forceinline__ static double point(double q0, double, double, double p0, double, double) {
+    return s1_distance64(q0, p0);
+  }
+};
+struct Topo64SE2 {  // metric_se2_squared, metric.hpp:228-257: x, y on the line, the angle (axis 2) on the circle
+  static constexpr bool kMin = false;
+  static constexpr bool kTopo = true;
+  static constexpr uint32_t kS1Mask = 4u;
+  __device__ __forceinline__ static double box(double mn, double mx, double v, uint32_t axis) {
+    const double d = axis < 2u ? seg_r1_distance64(mn, mx, v) : seg_s1_distance64(mn, mx, v);
+    return d_mul(d, d);
+  }
+  __device__ __forceinline__ static double point(double q0, double q1, double q2, double p0, double p1, double p2) {
+    const double dx = d_sub(q0, p0), dy = d_sub(q1, p1);
+    const double a = s1_distance64(q2, p2);
+    return d_add(d_add(d_mul(dx, dx), d_mul(dy, dy)), d_mul(a, a));  // sum over x, y from 0, + squared_s1
+  }
+};
 
 typedef PTK_LDS uint32_t LdsU32;
 #ifndef PTK_RING64
@@ -473,12 +520,102 @@ __device__ __forceinline__ void traverse64_3(const DevTree64& t, double q0, doub
   }
 }
 
+// The walk of search_nearest_topological (internal/kd_tree_search.hpp:115-229) over double points: which child is
+// nearer and the far child's offset both come from the distance of the query coordinate to the two child intervals
+// [left_min, left_max] and [right_min, right_max] (t.outer holds the two bounds the euclidean record lacks).  dim <= 3
+// (metric_so2: 1, metric_se2_squared: 3), q and off in registers as traverse64_3; records as there.
+template <class T, class Policy>
+__device__ __forceinline__ void traverse64_topo(const DevTree64& t, double q0, double q1, double q2, Policy& pol, Stack64& st) {
+  const Node64* __restrict__ nodes = t.nodes;
+  const double2* __restrict__ outer = t.outer;
+  const double* __restrict__ pts = t.pts;
+  const int32_t* __restrict__ index = t.index;
+  const uint32_t last = t.n_points - 1;
+  uint32_t ref = t.root_ref;
+  double nbd = 0.0, o0 = 0.0, o1 = 0.0, o2 = 0.0;
+
+  for (;;) {
+    while (!(ref & kLeafBit)) {  // search.hpp:158-193
+      const Node64 nd = nodes[ref];
+      const double2 ob = outer[ref];  // {left_min, right_max}
+      const double v = sel3d(nd.axis, q0, q1, q2);
+      const double d1 = T::box(ob.x, nd.left_max, v, nd.axis);
+      const double d2 = T::box(nd.right_min, ob.y, v, nd.axis);
+      const bool go_left = d1 < d2;
+      const double new_off = go_left ? d2 : d1;
+      const double far_nbd = d_add(d_sub(nbd, sel3d(nd.axis, o0, o1, o2)), new_off);
+      if (pol.max() >= far_nbd) st.push(ref | (go_left ? kRecSide : 0u), far_nbd);
+      ref = go_left ? nd.left_ref : nd.right_ref;
+    }
+    {
+      const uint32_t lv = ref & 0x7FFFFFFFu;
+      const uint32_t begin = lv >> t.cbits;
+      const uint32_t count = lv & t.cmask;
+      for (uint32_t j = 0; j < count; j += kLeaf64) {
+        double px[kLeaf64], py[kLeaf64], pz[kLeaf64];
+        int32_t pi[kLeaf64];
+#pragma unroll
+        for (int u = 0; u < kLeaf64; ++u) {
+          const uint32_t pu = begin + j + u <= last ? begin + j + u : last;
+          const double* a = pts + (uint64_t)pu * 3;
+          px[u] = a[0];
+          py[u] = a[1];
+          pz[u] = a[2];
+          pi[u] = index[pu];
+        }
+#pragma unroll
+        for (int u = 0; u < kLeaf64; ++u) {
+          if (j + u < count) pol.visit(pi[u], T::point(q0, q1, q2, px[u], py[u], pz[u]));
+        }
+      }
+    }
+    for (;;) {
+      if (st.empty()) return;
+      const Rec64 r = st.pop();
+      if (r.x & kRecUndo) {
+        if (r.x & kRecSide) {
+          nbd = r.val;
+        } else {
+          const uint32_t axis = r.x & 0x3FFFFFFFu;
+          o0 = axis == 0 ? r.val : o0;
+          o1 = axis == 1 ? r.val : o1;
+          o2 = axis == 2 ? r.val : o2;
+        }
+        continue;
+      }
+      if (pol.max() >= r.val) {  // search.hpp:199
+        const uint32_t idx = r.x & 0x3FFFFFFFu;
+        const bool far_is_right = (r.x & kRecSide) != 0;
+        const Node64 nd = nodes[idx];
+        const double2 ob = outer[idx];
+        const double v = sel3d(nd.axis, q0, q1, q2);
+        const double new_off = far_is_right ? T::box(nd.right_min, ob.y, v, nd.axis) : T::box(ob.x, nd.left_max, v, nd.axis);
+        st.push(kRecUndo | nd.axis, sel3d(nd.axis, o0, o1, o2));
+        st.push(kRecUndo | kRecSide, nbd);
+        o0 = nd.axis == 0 ? new_off : o0;
+        o1 = nd.axis == 1 ? new_off : o1;
+        o2 = nd.axis == 2 ? new_off : o2;
+        nbd = r.val;
+        ref = far_is_right ? nd.right_ref : nd.left_ref;
+        break;
+      }
+    }
+  }
+}
+
 // One query's whole search under either layout: D3 (dim <= 3) or the run-time-dim form.
 template <class M, bool D3, class Policy>
 __device__ __forceinline__ void search64(
     const DevTree64& t, const double* __restrict__ queries, uint64_t qi, Policy& pol, Rec64* stack, uint32_t slots) {
   Stack64 st;
-  if constexpr (D3) {
+  if constexpr (M::kTopo) {  // (the points' missing axes are zero and no split uses them: a 1-D query is padded alike)
+    const double* row = queries + qi * t.dim;
+    const double q0 = row[0];
+    const double q1 = t.dim > 1 ? row[1] : 0.0;
+    const double q2 = t.dim > 2 ? row[2] : 0.0;
+    st.init(0, 0, stack, slots);
+    traverse64_topo<M>(t, q0, q1, q2, pol, st);
+  } else if constexpr (D3) {
     const double* row = queries + qi * t.dim;
     const double q0 = row[0];
     // (a missing axis: zero like the points' for sums and maxima, +inf for the minimum of metric_lninf)
@@ -614,11 +751,15 @@ __global__ __launch_bounds__(kBlock) void sort_rows64_kernel(
 // ---- box search (kd_tree_search.hpp:238-381), as box_nd_kernel of ptk_kernels_nd.hpp ----------
 // Records: pending-right {branch, val = box max of the axis to restore}, undo {kRecUndo | axis,
 // val = box min to restore}.  LDS: query min / max and the running node box min / max.
-template <bool FILL>
+// TOPO: the tree of a topological metric, as box_kernel<.., TOPO> of ptk_kernels.hpp -- on a circle axis (bit of
+// s1_mask) a query interval with min > max wraps through the seam (metric_box_map, box.hpp:300-376), and every axis
+// uses the four-bound intersection tests of kd_tree_search.hpp:311-327 (the two outer bounds from t.outer).
+template <bool FILL, bool TOPO = false>
 __global__ __launch_bounds__(64) void box64_kernel(
     DevTree64 t, const double* __restrict__ root, const double* __restrict__ mins,
     const double* __restrict__ maxs, uint64_t b0, uint64_t nb, uint64_t* __restrict__ counts,
-    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots) {
+    const uint64_t* __restrict__ offsets, int32_t* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots,
+    uint32_t s1_mask = 0) {
   const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nb) return;
   const uint64_t bi = b0 + i;
@@ -643,7 +784,12 @@ __global__ __launch_bounds__(64) void box64_kernel(
     bool in = true;
     for (uint32_t a = 0; a < dim; ++a) {
       const double lo = qn[a * 64], hi = qx[a * 64], bl = mn[a * 64], bh = mx[a * 64];
-      in = in && lo <= bl && bl <= hi && lo <= bh && bh <= hi;
+      if (TOPO) {  // segment_r1 / segment_s1::contains of an interval
+        const bool wrap = ((s1_mask >> a) & 1u) != 0u && !(lo <= hi);
+        in = in && (wrap ? (bl >= lo || bh <= hi) : (lo <= bl && bh <= hi));
+      } else {
+        in = in && lo <= bl && bl <= hi && lo <= bh && bh <= hi;
+      }
     }
     return in;
   };
@@ -669,7 +815,11 @@ __global__ __launch_bounds__(64) void box64_kernel(
     for (uint32_t j = 0; j < n; ++j) {
       const double* p = t.pts + (uint64_t)(begin + j) * t.stride;
       bool in = true;
-      for (uint32_t a = 0; a < dim; ++a) in = in && qn[a * 64] <= p[a] && p[a] <= qx[a * 64];
+      for (uint32_t a = 0; a < dim; ++a) {
+        const double lo = qn[a * 64], hi = qx[a * 64];
+        const bool wrap = TOPO && ((s1_mask >> a) & 1u) != 0u && !(lo <= hi);
+        in = in && (wrap ? (p[a] >= lo || p[a] <= hi) : (lo <= p[a] && p[a] <= hi));
+      }
       if (in) {
         if (FILL) row[count] = t.index[begin + j];
         ++count;
@@ -688,10 +838,12 @@ __global__ __launch_bounds__(64) void box64_kernel(
         const Node64 nd = nodes[ref];
         st.push(ref, mx[nd.axis * 64]);  // the right child comes later
         mx[nd.axis * 64] = nd.left_max;
+        bool enter_left = qn[nd.axis * 64] <= nd.left_max;  // intersects_left
+        if (TOPO) enter_left = enter_left || qx[nd.axis * 64] >= t.outer[ref].x;  // || query.max >= left_min
         if (inside()) {
           report(nd.left_ref);
           have = false;
-        } else if (qn[nd.axis * 64] <= nd.left_max) {  // intersects_left
+        } else if (enter_left) {
           ref = nd.left_ref;
         } else {
           have = false;
@@ -710,9 +862,11 @@ __global__ __launch_bounds__(64) void box64_kernel(
     mx[nd.axis * 64] = r.val;
     st.push(kRecUndo | nd.axis, mn[nd.axis * 64]);
     mn[nd.axis * 64] = nd.right_min;
+    bool enter_right = qx[nd.axis * 64] >= nd.right_min;  // intersects_right
+    if (TOPO) enter_right = enter_right || qn[nd.axis * 64] <= t.outer[r.x & 0x3FFFFFFFu].y;  // || query.min <= right_max
     if (inside()) {
       report(nd.right_ref);
-    } else if (qx[nd.axis * 64] >= nd.right_min) {  // intersects_right
+    } else if (enter_right) {
       ref = nd.right_ref;
       have = true;
     }

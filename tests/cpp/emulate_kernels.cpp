@@ -1131,9 +1131,10 @@ struct Emu64 {
   ptk::TreeStats st;
   ptk::DevTree64 dev;
   std::vector<double> root;
+  std::vector<double> outer;      // per branch {left_min, right_max}, the order of enc.nodes
   std::vector<ptk::Rec64> stack;  // one block's worth: blocks run one after the other
   uint32_t slots = 0;
-  int metric = 0;
+  int metric = 0;  // PTK_METRIC_* (4 / 5: the topological metrics)
 };
 
 template <class F>
@@ -1161,14 +1162,17 @@ void* emu64_create(const double* points, uint64_t n, uint32_t dim, uint64_t max_
   space_t space(points, n, dim);
   internal::space_view<space_t> view(space);
   e->flat = internal::build_flat_tree<int>(view, max_leaf_size_t(max_leaf), bounds_from_space, sliding_midpoint_max_side,
-                                           false, 1u);
+                                           true, 1u);
   bool unsupported = false;
   g_err = ptk::encode_tree64(dim, n, points, e->flat.nodes.data(), e->flat.nodes.size(), e->flat.indices.data(), e->st,
                              e->enc, unsupported);
+  if (g_err.empty())
+    g_err = ptk::encode_outer64(dim, n, e->flat.nodes.data(), e->flat.nodes.size(), e->flat.outer_bounds.data(), e->outer);
   if (!g_err.empty()) {
     delete e;
     return nullptr;
   }
+  e->dev.outer = reinterpret_cast<const double2*>(e->outer.data());
   e->dev.nodes = reinterpret_cast<const ptk::Node64*>(e->enc.nodes.data());
   e->dev.pts = e->enc.points.data();
   e->dev.index = e->flat.indices.data();
@@ -1191,7 +1195,9 @@ void emu64_set_metric(void* h, int metric) { static_cast<Emu64*>(h)->metric = me
 // The kd_tree::save stream of the tree (pico_tree/internal/stream.hpp); returns its size.
 uint64_t emu64_save(void* h, void* buf, uint64_t cap) {
   std::ostringstream os(std::ios::out | std::ios::binary);
-  pico_tree::internal::write_flat_tree(static_cast<Emu64*>(h)->flat, os);
+  auto* e = static_cast<Emu64*>(h);
+  e->flat.keep_outer_bounds = e->metric == 4 || e->metric == 5;  // the four-bound stream of a topological tree
+  pico_tree::internal::write_flat_tree(e->flat, os);
   const std::string bytes = os.str();
   if (buf != nullptr && cap >= bytes.size()) std::memcpy(buf, bytes.data(), bytes.size());
   return bytes.size();
@@ -1206,6 +1212,12 @@ uint64_t emu64_save(void* h, void* buf, uint64_t cap) {
     CALL;                                      \
   } else if (t->metric == 3) {                 \
     using M = ptk::Metric64LNInf;              \
+    CALL;                                      \
+  } else if (t->metric == 4) {                 \
+    using M = ptk::Topo64SO2;                  \
+    CALL;                                      \
+  } else if (t->metric == 5) {                 \
+    using M = ptk::Topo64SE2;                  \
     CALL;                                      \
   } else {                                     \
     using M = ptk::Metric64L2;                 \
@@ -1271,18 +1283,28 @@ int emu64_radius(void* h, const double* q, uint64_t nq, double radius, double e,
 int emu64_box(void* h, const double* mins, const double* maxs, uint64_t nb, uint64_t* offsets, int32_t* out) {
   auto* t = static_cast<Emu64*>(h);
   if (ptk::lds64_bytes(4, t->dev.dim) > sizeof(ptk::ptk_smem)) return -2;
+  const bool topo = t->metric == 4 || t->metric == 5;
+  const uint32_t s1_mask = !topo ? 0u : (t->metric == 4 ? 1u : 4u);
   if (out == nullptr) {
     std::vector<uint64_t> counts(nb + 1, 0);
     for_each_lane64(t, nb, [&](uint64_t b0, uint64_t m) {
-      ptk::box64_kernel<false>(t->dev, t->root.data(), mins, maxs, b0, m, counts.data(), nullptr, nullptr,
-                               t->stack.data(), t->slots);
+      if (topo)
+        ptk::box64_kernel<false, true>(t->dev, t->root.data(), mins, maxs, b0, m, counts.data(), nullptr, nullptr,
+                                       t->stack.data(), t->slots, s1_mask);
+      else
+        ptk::box64_kernel<false>(t->dev, t->root.data(), mins, maxs, b0, m, counts.data(), nullptr, nullptr,
+                                 t->stack.data(), t->slots);
     });
     offsets[0] = 0;
     for (uint64_t i = 0; i < nb; ++i) offsets[i + 1] = offsets[i] + counts[i];
     return 0;
   }
   for_each_lane64(t, nb, [&](uint64_t b0, uint64_t m) {
-    ptk::box64_kernel<true>(t->dev, t->root.data(), mins, maxs, b0, m, nullptr, offsets, out, t->stack.data(), t->slots);
+    if (topo)
+      ptk::box64_kernel<true, true>(t->dev, t->root.data(), mins, maxs, b0, m, nullptr, offsets, out, t->stack.data(),
+                                    t->slots, s1_mask);
+    else
+      ptk::box64_kernel<true>(t->dev, t->root.data(), mins, maxs, b0, m, nullptr, offsets, out, t->stack.data(), t->slots);
   });
   return 0;
 }

@@ -376,6 +376,45 @@ static int run_batch(std::string const& dir) {
     write_raw(dir + "/d_box_off.bin", boff.data(), boff.size());
     write_raw(dir + "/d_box_flat.bin", bflat.data(), bflat.size());
   }
+  {  // the topological metric_se2_squared over DOUBLE points, batched on the device (four bounds per branch cross the
+     // boundary in the reference's own stream: ptk_tree64_create_from_topological_stream)
+    using neighbor64 = pico_tree::neighbor<int, double>;
+    std::vector<std::array<double, 3>> sq(nq);
+    for (size_t i = 0; i < nq; ++i)
+      for (int d = 0; d < 3; ++d) sq[i][d] = static_cast<double>(qs[i][d]);
+    auto se2d = pico_tree::make_kd_tree<pico_tree::metric_se2_squared>(std::cref(sq), pico_tree::max_leaf_size_t(10));
+    std::vector<neighbor64> b(nq * k);
+    std::memset(static_cast<void*>(b.data()), 0, b.size() * sizeof(neighbor64));
+    se2d.search_knn(sq, k, b.data());
+    for (size_t i = 0; i < nq; i += 7) {  // the batched answer is the per-query member's answer
+      std::vector<neighbor64> one;
+      se2d.search_knn(sq[i], k, one);
+      for (size_t j = 0; j < k; ++j)
+        if (one[j].index != b[i * k + j].index || one[j].distance != b[i * k + j].distance) return 45;
+    }
+    std::vector<std::uint64_t> off, boff;
+    std::vector<neighbor64> flat;
+    std::vector<int> bflat;
+    se2d.search_radius(sq, 0.0009, off, flat, false);
+    auto lo = sq, hi = sq;
+    for (size_t i = 0; i < nq; ++i)
+      for (int d = 0; d < 3; ++d) {
+        lo[i][d] -= 0.02;
+        hi[i][d] += 0.02;
+      }
+    se2d.search_box(lo, hi, boff, bflat);
+    std::vector<int> idx(b.size()), ridx(flat.size());
+    std::vector<double> dist(b.size()), rdist(flat.size());
+    for (size_t i = 0; i < b.size(); ++i) idx[i] = b[i].index, dist[i] = b[i].distance;
+    for (size_t i = 0; i < flat.size(); ++i) ridx[i] = flat[i].index, rdist[i] = flat[i].distance;
+    write_raw(dir + "/d_se2_knn_idx.bin", idx.data(), idx.size());
+    write_raw(dir + "/d_se2_knn_dist.bin", dist.data(), dist.size());
+    write_raw(dir + "/d_se2_radius_off.bin", off.data(), off.size());
+    write_raw(dir + "/d_se2_radius_idx.bin", ridx.data(), ridx.size());
+    write_raw(dir + "/d_se2_radius_dist.bin", rdist.data(), rdist.size());
+    write_raw(dir + "/d_se2_box_off.bin", boff.data(), boff.size());
+    write_raw(dir + "/d_se2_box_flat.bin", bflat.data(), bflat.size());
+  }
   {  // a call the device search refuses (a topological tree some 3000 levels deep: coincident angles, leaf size 1) is
      // served as a loop of the per-query members -- the reference's own loop -- not thrown back at the caller
     std::vector<std::array<float, 1>> ring(4000);

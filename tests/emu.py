@@ -284,7 +284,7 @@ class EmulatedTree64:
         self.h = self.lib.emu64_create(self.pts.ctypes.data, len(self.pts), self.pts.shape[1], int(leaf))
         if not self.h:
             raise RuntimeError(self.lib.emu_last_error().decode())
-        self.lib.emu64_set_metric(self.h, {"L2Squared": 0, "L1": 1, "LPInf": 2, "LNInf": 3}[metric])
+        self.lib.emu64_set_metric(self.h, {"L2Squared": 0, "L1": 1, "LPInf": 2, "LNInf": 3, "SO2": 4, "SE2Squared": 5}[metric])
 
     def __del__(self):
         if getattr(self, "h", None):

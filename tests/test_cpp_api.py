@@ -172,3 +172,16 @@ def test_batched_members_match_oracle(workdir, gpu):
     boff, bflat = r64.search_box(qd - 0.02, qd + 0.02)
     assert np.array_equal(_load(d, "d_box_off.bin", np.uint64), boff)
     assert np.array_equal(_load(d, "d_box_flat.bin", np.int32), bflat)
+    if oracle.have_reference64():  # kd_tree<space of double points, metric_se2_squared> on the device
+        sq = q.astype(np.float64)
+        se2d = oracle.Oracle(sq, 10, "reference", "SE2Squared", dtype=np.float64)
+        want = se2d.search_knn(sq, K)
+        assert np.array_equal(_load(d, "d_se2_knn_idx.bin", np.int32).reshape(-1, K), want["index"])
+        assert _load(d, "d_se2_knn_dist.bin", np.float64).tobytes() == np.ascontiguousarray(want["distance"]).tobytes()
+        off, flat = se2d.search_radius(sq, 0.0009)
+        assert off[-1] > 0 and np.array_equal(_load(d, "d_se2_radius_off.bin", np.uint64), off)
+        assert np.array_equal(_load(d, "d_se2_radius_idx.bin", np.int32), flat["index"])
+        assert _load(d, "d_se2_radius_dist.bin", np.float64).tobytes() == np.ascontiguousarray(flat["distance"]).tobytes()
+        boff, bflat = se2d.search_box(sq - 0.02, sq + 0.02)
+        assert np.array_equal(_load(d, "d_se2_box_off.bin", np.uint64), boff)
+        assert np.array_equal(_load(d, "d_se2_box_flat.bin", np.int32), bflat)

@@ -100,6 +100,72 @@ def test_emulated_double_kernels_reproduce_the_goldens(name):
     assert same(t.search_knn(g["queries"], 3), g["knn_index"][:, :3], g["knn_distance"][:, :3])  # K = 4 registers
 
 
+def rows_equal(a, b):
+    """Index and distance BITS (the four padding bytes of a neighbor<int, double> are nobody's)."""
+    return np.array_equal(a["index"], b["index"]) and a["distance"].tobytes() == b["distance"].tobytes()
+
+
+def _without_padding(stream: bytes, n: int, dim: int) -> bytes:
+    """A four-bound double stream with the 4 padding bytes of every kd_tree_branch_double record (between its int and
+    its first double: written as they lie in memory, kd_tree_node.hpp:52-67) zeroed."""
+    b = bytearray(stream)
+    at = 16 + 4 * n + 16 * dim
+    while at < len(b):
+        leaf = b[at]
+        at += 1
+        if leaf:
+            at += 8
+        else:
+            b[at + 4:at + 8] = bytes(4)
+            at += 40
+    assert at == len(b)
+    return bytes(b)
+
+
+def _topological_case(metric, n, nq, seed):
+    """Points, queries (some next to the seam 0 ~ 1 of the circle axis), a radius and boxes (some through the seam)."""
+    rng = np.random.default_rng(seed)
+    dim = 1 if metric == "SO2" else 3
+    pts, q = rng.random((n, dim)), rng.random((nq, dim))
+    q[:nq // 20, -1] = 1e-5 * np.arange(nq // 20)
+    q[nq // 20:nq // 10, -1] = 1.0 - 1e-5 * np.arange(nq // 10 - nq // 20)
+    radius = (30.0 / n) if metric == "SO2" else (0.8 * (30.0 / n) ** (1.0 / 3.0)) ** 2
+    nb = max(nq // 2, 50)
+    mins = rng.random((nb, dim))
+    maxs = mins + (60.0 / n if metric == "SO2" else 0.06) * (1 + rng.random((nb, dim)))
+    wrap = maxs[:, -1] > 1.0  # intervals through the seam: max comes back below min
+    maxs[wrap, -1] -= 1.0
+    assert wrap.sum() > 3
+    return pts, q, radius, mins, maxs, wrap
+
+
+@pytest.mark.skipif(not oracle.have_reference64(), reason="compiled reference (double) not present")
+@pytest.mark.parametrize("metric", ["SO2", "SE2Squared"])
+def test_emulated_double_topological_kernels_equal_the_compiled_reference(metric):
+    """metric_so2 / metric_se2_squared over double points (metric.hpp:186-257) through traverse64_topo and
+    box64_kernel<.., TOPO> of ptk_kernels_f64.hpp, against kd_tree<space of double points, metric_so2 |
+    metric_se2_squared> of the reference's own headers (oracle/_ref): neighbours and boxes through the seam included."""
+    from tests import emu
+
+    pts, q, radius, mins, maxs, wrap = _topological_case(metric, 6_000 if metric == "SO2" else 20_000, 1_200, 71)
+    leaf = 6 if metric == "SO2" else 10
+    t = emu.EmulatedTree64(pts, leaf, metric)
+    ref = oracle.Oracle(pts, leaf, "reference", metric, dtype=np.float64)
+    # the four-bound stream (kd_tree_branch_double records)
+    assert _without_padding(t.save_bytes(), len(pts), pts.shape[1]) == _without_padding(ref.save_bytes(), len(pts), pts.shape[1])
+    for k, reg in ((1, True), (3, True), (7, True), (7, False), (40, True)):
+        assert rows_equal(t.search_knn(q, k, list_in_registers=reg), ref.search_knn(q, k)), (k, reg)
+    assert rows_equal(t.search_knn(q, 5, e=1.4), ref.search_knn(q, 5, e=1.4))
+    for kw in ({}, {"e": 1.5}):
+        a, b = t.search_radius(q, radius, **kw), ref.search_radius(q, radius, **kw)
+        assert b[0][-1] > 0 and np.array_equal(a[0], b[0]) and rows_equal(a[1], b[1])
+    (o1, f1), (o2, f2) = t.search_box(mins, maxs), ref.search_box(mins, maxs)
+    assert o2[-1] > 0 and np.array_equal(o1, o2) and np.array_equal(f1, f2)
+    assert np.diff(o2)[wrap].sum() > 0  # the boxes through the seam do find points
+    knn = ref.search_knn(q, 4)
+    assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # some neighbours are nearer through 0 ~ 1
+
+
 def test_host_only_double_handle_builds_the_reference_tree(tmp_path):
     g = load("g_f64_3d")
     t = pt.KdTree(g["points"], pt.Metric.L2Squared, int(g["max_leaf_size"]), device=pt.PTK_DEVICE_NONE)
@@ -139,6 +205,35 @@ def test_double_entry_points_validate_arguments():
     lib.ptk_tree64_destroy(h)
     garbage = ctypes.create_string_buffer(b"\x03" + b"\0" * 40, 41)
     assert lib.ptk_tree64_create_from_stream(pts.ctypes.data, 100, 3, garbage, 41, none, ctypes.byref(h)) == -1
+
+
+@pytest.mark.skipif(not oracle.have_reference64(), reason="compiled reference (double) not present")
+def test_host_only_double_topological_handle(tmp_path):
+    """The four-bound tree of a topological space over double points: built by the product's builder, written as
+    kd_tree<space, metric_se2_squared>::save writes it, loaded back; the dimension and outer-bound checks."""
+    pts = np.random.default_rng(5).random((3_000, 3))
+    none = pt.PTK_DEVICE_NONE
+    t = pt.KdTree(pts, pt.Metric.SE2Squared, 10, device=none)
+    ref = oracle.Oracle(pts, 10, "reference", "SE2Squared", dtype=np.float64)
+    assert _without_padding(t._serialize(), 3_000, 3) == _without_padding(ref.save_bytes(), 3_000, 3)
+    fn = str(tmp_path / "se2_64.bin")
+    pt.save_kd_tree(t, fn)
+    t2 = pt.load_kd_tree(pts, fn, device=none)
+    assert t2.metric_string == "SE2Squared" and t2._serialize() == t._serialize() and t2.metric(-2.0) == 4.0
+    for metric, bad in (("SO2", pts), ("SE2Squared", pts[:, :2].copy())):  # metric_so2: dim 1, metric_se2_squared: dim 3
+        with pytest.raises(pt.PtkError) as err:
+            pt.KdTree(bad, pt.Metric[metric], 10, device=none)
+        assert err.value.status == -1
+    # a tree read from a euclidean stream has two bounds per branch: not a topological tree
+    lib, h = pt._load(), ctypes.c_void_p()
+    plain = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=none)._serialize()
+    buf = ctypes.create_string_buffer(plain, len(plain))
+    assert lib.ptk_tree64_create_from_stream(pts.ctypes.data, 3_000, 3, buf, len(plain), none, ctypes.byref(h)) == 0
+    size = ctypes.c_uint64()
+    assert lib.ptk_tree64_set_metric(h, 5) == -1 and lib.ptk_tree64_serialize_topological(h, None, 0, ctypes.byref(size)) == -1
+    assert lib.ptk_tree64_serialize(h, None, 0, ctypes.byref(size)) == 0 and size.value == len(plain)
+    lib.ptk_tree64_destroy(h)
+    assert lib.ptk_tree64_create_from_topological_stream(pts.ctypes.data, 3_000, 3, buf, len(plain), none, ctypes.byref(h)) == -1
 
 
 # ---- GPU tier ------------------------------------------------------------------------------------
@@ -199,6 +294,48 @@ def test_gpu_double_equals_oracle(gpu, dim, n, nq, leaf):
     h = 50.0 * 0.5 * (200.0 / n) ** (1.0 / dim)
     (o1, f1), (o2, f2) = t.search_box(q[:5000] - h, q[:5000] + h), ref.search_box(q[:5000] - h, q[:5000] + h)
     assert np.array_equal(o1, o2) and np.array_equal(f1, f2) and o1[-1] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not oracle.have_reference64(), reason="compiled reference (double) not present")
+@pytest.mark.parametrize("metric", ["SO2", "SE2Squared"])
+def test_gpu_double_topological_metrics(gpu, metric, tmp_path):
+    """kd_tree<space of double points, metric_so2 | metric_se2_squared> (metric.hpp:186-257) on the device
+    (traverse64_topo, box64_kernel<.., TOPO>) against the reference's own headers compiled over double: knn, the
+    approximate search, radius, box -- neighbours and boxes through the seam 0 ~ 1 included -- and the file round trip."""
+    import torch
+
+    n, nq = (200_000, 30_000) if metric == "SO2" else (300_000, 30_000)
+    pts, q, radius, mins, maxs, wrap = _topological_case(metric, n, nq, 97)
+    leaf = 10
+    t = _GpuTree(pts, leaf, metric, device=gpu)
+    ref = oracle.Oracle(pts, leaf, "reference", metric, dtype=np.float64)
+    assert _without_padding(t.t._serialize(), n, pts.shape[1]) == _without_padding(ref.save_bytes(), n, pts.shape[1])
+    for k, e in ((1, None), (4, None), (7, None), (16, None), (40, None), (6, 1.3)):
+        assert rows_equal(t.search_knn(q, k, e=e), ref.search_knn(q, k, e=e)), (k, e)
+    (o1, f1), (o2, f2) = t.search_radius(q, radius), ref.search_radius(q, radius)
+    assert o2[-1] > nq and np.array_equal(o1, o2) and rows_equal(f1, f2)
+    (o1, f1), (o2, f2) = t.search_radius(q[:3000], radius, e=1.5, sort=True), ref.search_radius(q[:3000], radius, e=1.5, sort=True)
+    assert np.array_equal(o1, o2) and f1["distance"].tobytes() == f2["distance"].tobytes()
+    (o1, f1), (o2, f2) = t.search_box(mins, maxs), ref.search_box(mins, maxs)
+    assert o2[-1] > 0 and np.array_equal(o1, o2) and np.array_equal(f1, f2)
+    assert np.diff(o2)[wrap].sum() > 0  # the boxes through the seam do find points
+    knn = ref.search_knn(q, 4)
+    assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # neighbours through the seam
+    # device tensors in, device tensors out
+    dq = torch.from_numpy(q).to(f"cuda:{gpu}")
+    got = t.t.search_knn(dq, 7)
+    torch.cuda.synchronize()
+    assert rows_equal(got.numpy(), ref.search_knn(q, 7))
+    # saved and loaded straight into a device handle (four bounds per branch in the stream)
+    fn = str(tmp_path / "topological64.pkd")
+    pt.save_kd_tree(t.t, fn)
+    again = pt.load_kd_tree(pts, fn, device=gpu)
+    assert rows_equal(again.search_knn(q, 7).reshape(nq, 7), ref.search_knn(q, 7))
+    # a euclidean metric on the same handle afterwards, and back
+    lib = pt._load()
+    assert lib.ptk_tree64_set_metric(t.t._h, 0) == 0 and lib.ptk_tree64_set_metric(t.t._h, 4 if metric == "SO2" else 5) == 0
+    assert rows_equal(t.search_knn(q[:1000], 3), ref.search_knn(q[:1000], 3))
 
 
 @pytest.mark.gpu
