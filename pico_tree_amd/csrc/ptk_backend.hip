@@ -1098,12 +1098,26 @@ int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64
 constexpr int kKnnCoopPool = 128;
 constexpr uint32_t kKnnCoopSpill = 2048;  // tasks a wavefront of the cooperative search can park in HBM
 uint32_t knn_coop_blocks(const ptk_tree* t) { return (uint32_t)t->cus * (uint32_t)std::max(1, env_int("PTK_KNN_COOP_WAVES", 32)); }
-uint32_t knn_cap(float e, uint64_t nq) {
+// The cap follows the batch: a capped launch ends with the lanes that ran to their cap -- cap x ~7 us, a lonely lane's
+// price per far child -- however small the batch, so a batch the chip gets through in less than that wants a lower cap
+// and more hand-overs (kernel ms at caps of 16 / 64 / 256, knn = 16: 150 k queries 0.42 / 0.67 / 1.92, 600 k
+// -- / 0.94 / 1.93, 2.4 M -- / 2.07 / 1.93 [128: 1.82], 7.2 M 256: 3.96; knn = 4: 150 k 0.24 / 0.45 / 1.38 [8: 0.20],
+// 600 k [32: 0.42] / 0.54 / 1.35, 2.4 M [32: 0.99] / 0.94 / 1.52: profiles/r05_notes.txt item 13).  Linear in the batch
+// up to 576 k queries, slower beyond, 256 at BASELINE config 3; k <= 4 takes half the cap of k <= 16, k <= 32 twice it
+// (knn = 32 at a cap of 16: a quarter of 150 k queries handed over, 2.0 ms; knn = 8 at 8: 12 %, 0.67 ms against 0.52
+// at 600 k).  PTK_KNN_CAP = n: that cap for every batch (0: no cap).
+uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
   // (PTK_KNN_CAP_MIN_NQ: tests -- the fuzzer's batches are small)
   if (e != 1.0f || nq < (uint64_t)std::max(1, env_int("PTK_KNN_CAP_MIN_NQ", 4096))) return 0;
-  return (uint32_t)std::max(0, env_int("PTK_KNN_CAP", 256));
+  const int forced = env_int("PTK_KNN_CAP", -1);
+  if (forced >= 0) return (uint32_t)forced;
+  const double scale = k <= 4 ? 0.5 : (k <= 16 ? 1.0 : 2.0);  // (a query's far children grow with its k)
+  const double knee = 576000.0, x = (double)nq / knee;
+  const double cap = 64.0 * scale * (x <= 1.0 ? x : std::pow(x, k <= 4 ? 0.8 : 0.55));
+  return (uint32_t)std::min(256.0, std::max(16.0 * scale, cap));
 }
-uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 64, std::min<uint64_t>(nq, 8192)); }
+// Entries of the hand-over list (64 tasks of 24 bytes each): a query that finds it full goes on in its lane.
+uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 64, std::min<uint64_t>(nq, 16384)); }
 size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
   return 3 * (nq * 4) + knn_max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + ptk::kMetaWords * 4 +
          (size_t)knn_coop_blocks(t) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
@@ -1117,7 +1131,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
   if constexpr (std::is_same<M, ptk::MetricL2>::value && BLOCK == 64) {
-    const uint32_t cap = scratch != nullptr ? knn_cap(e, nq) : 0u;
+    const uint32_t cap = scratch != nullptr ? knn_cap(e, nq, k) : 0u;
     if (cap != 0u) {
       // The capped launch, the cooperative search of what it handed over, the reference search of what that could
       // not certify: three launches in stream order, the counts stay on the device.
@@ -1127,6 +1141,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
       ho.heavy_list = scratch->take<uint32_t>(nq);
       ho.ntasks = scratch->take<uint32_t>(nq);
       ho.max_heavy = (uint32_t)knn_max_handover(nq);
+      ho.full_keeps = 1u;
       ho.tasks = scratch->take<ptk::Task>((size_t)ho.max_heavy * ptk::kMaxTasks);
       uint32_t* redo_list = scratch->take<uint32_t>(nq);
       const uint32_t coop_blocks = knn_coop_blocks(t);
@@ -2197,7 +2212,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
                        (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(t, nq) : 0) +
-                       (k > 1 && k <= 32 && l2 && t->dim <= 3 && knn_cap(e, nq) != 0u ? knn_coop_scratch_bytes(t, nq) : 0));
+                       (k > 1 && k <= 32 && l2 && t->dim <= 3 && knn_cap(e, nq, k) != 0u ? knn_coop_scratch_bytes(t, nq) : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
   if (reorder) {  // Morton order along the first three axes, whatever the dimension
@@ -2291,14 +2306,19 @@ static bool is_pinned_host(const void* p, size_t bytes) {
 //           four 3.6, two 3.9; a small first and last piece around large ones (the downloads then queue behind long
 //           uploads) 3.8-4.3; uploads read by a kernel instead of the copy engine 5.2.
 //   k > 1   the general kernels end with the tail of their slowest queries (3.4 ms for ANY piece of config 3 at
-//           knn = 16), so a piece costs its tail: at most three pieces of at most 256 MB of rows.
+//           knn = 16), so a piece costs its tail: at most three pieces of at most 256 MB of rows.  Where the long
+//           queries are handed to the cooperative search (`capped`: exact, metric_l2_squared, k <= 32, with a cap that
+//           follows the piece -- knn_cap) a piece costs what its size costs, and the rows of the first one can leave
+//           a millisecond after the call: eight pieces as for k = 1 (ms per batch of BASELINE config 3, three pieces /
+//           eight: knn = 16 20.8 / 19.3 -- the 1 008 MB of the call at the 53 GB/s the link gives both directions
+//           together are 19.0 --, knn = 8 15.0 / 10.5, knn = 4 9.9 / 7.0; profiles/r05_notes.txt item 13).
 // PTK_HOST_PIECE = n: equal pieces of n queries (experiments).
-static std::vector<uint64_t> host_pieces(uint64_t nq, uint32_t k, bool two_phase) {
+static std::vector<uint64_t> host_pieces(uint64_t nq, uint32_t k, bool two_phase, bool capped) {
   std::vector<uint64_t> first;
   const int forced = env_int("PTK_HOST_PIECE", 0);
   if (forced > 0) {
     for (uint64_t lo = 0; lo < nq; lo += (uint64_t)forced) first.push_back(lo);
-  } else if (!two_phase) {
+  } else if (!two_phase && !capped) {
     const size_t obytes = (size_t)nq * k * sizeof(ptk_neighbor);
     const uint64_t pieces = std::min<uint64_t>(std::max<uint64_t>(obytes / (size_t(256) << 20), 1), 3);
     const uint64_t per = (nq + pieces - 1) / pieces;
@@ -2340,7 +2360,9 @@ static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint3
   }
   const bool two_phase = k == 1 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
                          ovf_class_of(knn1_depth(t), 16) != kDeepClass;
-  const std::vector<uint64_t> first = host_pieces(nq, k, two_phase);
+  const bool capped = !two_phase && k > 1 && k <= 32 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
+                      knn_cap(e, std::max<uint64_t>((nq + 7) / 8, uint64_t(1) << 18), k) != 0u;
+  const std::vector<uint64_t> first = host_pieces(nq, k, two_phase, capped);
   const uint64_t pieces = first.size() - 1;
   uint64_t piece = 0;  // the largest piece: the size of a ring slot
   for (uint64_t i = 0; i < pieces; ++i) piece = std::max(piece, first[i + 1] - first[i]);

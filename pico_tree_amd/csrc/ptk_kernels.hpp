@@ -754,6 +754,8 @@ struct Handover {
   Task* tasks;           // [max_heavy][kMaxTasks]
   uint32_t max_heavy;
   uint32_t slot;         // this query
+  uint32_t full_keeps;   // != 0: a query that finds the list full goes on in its lane (the consumer takes
+                         // min(count, max_heavy) entries); 0: it is listed without tasks (kTasksFromRoot)
 };
 
 // CAPPED: give up (return false) when more than `cap` far children have been entered: what is
@@ -900,8 +902,16 @@ __device__ __forceinline__ bool traverse(
         break;
       }
       if (enter) {
-        if (CAPPED && ++entered > cap) {
-          const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
+        bool hand_over = CAPPED && ++entered > cap;
+        uint32_t h = 0;
+        if (hand_over) {
+          h = atomicAdd(&ho->meta[ho->counter], 1u);
+          if (ho->full_keeps != 0u && h >= ho->max_heavy) {  // no room: this lane finishes its query itself
+            hand_over = false;
+            cap = 0xFFFFFFFFu;
+          }
+        }
+        if (hand_over) {
           ho->heavy_list[h] = ho->slot;
           Task* out = h < ho->max_heavy ? ho->tasks + (uint64_t)h * kMaxTasks : nullptr;
           uint32_t n = 0;

@@ -352,7 +352,8 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
   LdsU32* gbest = pool + 6 * POOL;   // bits of the smallest k-th distance any lane holds
   LdsU32* row = gbest + 1;           // the merged row: index [32], distance bits [32]
   LdsU32* ent = row + 64;            // second sweep: distance bits, tag, box distance bits [kKnnTieSlots] each
-  const uint32_t n_heavy = ho.meta[ho.counter];
+  // (queries that found the list full were not listed: they finished in their lanes, Handover::full_keeps)
+  const uint32_t n_heavy = ho.full_keeps != 0u && ho.meta[ho.counter] > ho.max_heavy ? ho.max_heavy : ho.meta[ho.counter];
   const float kInf = __uint_as_float(0x7F800000u);
 
   for (uint32_t entry = blockIdx.x; entry < n_heavy; entry += gridDim.x) {  // (uniform)

@@ -415,6 +415,7 @@ int emu_knn_capped_k(Emu* t, const float* q, uint64_t nq, uint32_t k, const uint
   ho.ntasks = ntasks.data();
   ho.tasks = tasks.data();
   ho.max_heavy = max_heavy;
+  ho.full_keeps = 1u;  // (as launch_knn_reg: a query that finds the list full finishes in its lane)
   for_each_lane(nq, [&] { ptk::knn_reg_kernel<K, 16, 2048, 64, 4, ptk::MetricL2, true>(t->dev, q, t->dim, perm, nq, k, 1.0f, o, cap, ho); }, 64);
   // (pool_small: a pool of 64 subtrees and 40 spill slots per wavefront -- long searches park subtrees in HBM and a
   // few overflow even that: the redo path)

@@ -272,12 +272,12 @@ def test_emulated_capped_knn_and_its_cooperative_search_equal_oracle(case):
             got, heavy, redo = emu.search_knn_capped(q, kk, cap, perm=p, pool_small=small)
             assert got.tobytes() == want.tobytes(), (name, k, cap)
             seen[(k, cap)] = (heavy, redo)
-    # more hand-overs than the task block holds: the rest is searched again from the root
+    # more queries at their cap than the hand-over list holds: the rest finish in their lanes (Handover::full_keeps)
     kk = min(7, len(pts))
     got, heavy, redo = emu.search_knn_capped(q, kk, 1, max_heavy=3)
     assert got.tobytes() == ref.search_knn(q, kk).tobytes(), (name, "max_heavy")
     if name in ("uniform", "lidar"):
-        assert heavy > 3 and redo >= heavy - 3
+        assert heavy > 3 and redo <= 3  # (`heavy` counts every query that asked for an entry)
     if name in ("uniform", "lidar", "ties"):
         assert seen[(16, 2)][0] > 0                                   # the cap does hand queries over
     if name in ("uniform", "lidar"):
