@@ -441,6 +441,22 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
         res[f"knn{kk}"] = {"value": round(nq / ms_k / 1e3, 3), "unit": "Mqueries/s", "ms_per_step": round(ms_k, 4),
                            "kernel_ms": round(prof_k["search_ms"] / max(int(prof_k["launches"]), 1), 4),
                            "parity_sample_ok": bool(got_k.tobytes() == want_k.tobytes())}
+    # ---- knn = 16 on one shard of configs[3] (the first eighth of the batch): a capped launch ends with the lanes that
+    # ran to their cap, so the cap follows the batch (knn_cap of ptk_backend.hip; at a fixed 256 this step took 1.9 ms)
+    per = (nq + 7) // 8
+    ms_s, prof_s, out_s = time_device_knn(tree, dq[:per], 16, 10, warmup=2)
+    head = cs[cs < per][:20_000]
+    got_s = pt.DeviceNeighbors(out_s).numpy()[head]
+    del out_s
+    try:
+        coop_s = tree.knn_coop_counts()
+    except Exception as exc:  # noqa: BLE001
+        coop_s = str(exc)
+    res["knn16_shard_of_8"] = {"queries": per, "value": round(per / ms_s / 1e3, 3), "unit": "Mqueries/s",
+                               "ms_per_step": round(ms_s, 4),
+                               "kernel_ms": round(prof_s["search_ms"] / max(int(prof_s["launches"]), 1), 4),
+                               "parity_sample_ok": bool(got_s.tobytes() == ref.search_knn(q[head], 16).tobytes()),
+                               "long_searches": coop_s}
     # ---- radius: count pass that lists the leaves with hits + scan + fill pass that replays the lists
     radius, steps = 1.0, 3
     for _ in range(2):  # (the 6 GB of rows are a block of torch's allocator from the second call on)

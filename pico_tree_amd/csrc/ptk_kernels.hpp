@@ -761,7 +761,9 @@ struct Handover {
 // CAPPED: give up (return false) when more than `cap` far children have been entered: what is
 // still on the stack goes to `ho` -- every pending far child that can still matter together with
 // the state it would be entered with, next-to-visit first.
-template <int LEAFB, bool RESUME = false, class M = MetricL2, bool CAPPED = false, class Policy, class StackT>
+// KEEPS (CAPPED only; Handover::full_keeps set): a query that finds the hand-over list full goes on in its lane.
+template <int LEAFB, bool RESUME = false, class M = MetricL2, bool CAPPED = false, bool KEEPS = false, class Policy,
+          class StackT>
 __device__ __forceinline__ bool traverse(
     const DevTree& t, float qx, float qy, float qz, Policy& pol, StackT& st, uint32_t cap = 0,
     const Handover* ho = nullptr) {
@@ -771,6 +773,7 @@ __device__ __forceinline__ bool traverse(
   float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
   uint32_t entered = 0;
   bool monotone = true;  // CAPPED: every far child entered so far had a box distance >= its parent's
+  bool on_its_own = false;  // KEEPS: the list was full when this query reached its cap
 
   for (;;) {
     // Down to a leaf through the nearer children.
@@ -902,13 +905,13 @@ __device__ __forceinline__ bool traverse(
         break;
       }
       if (enter) {
-        bool hand_over = CAPPED && ++entered > cap;
+        bool hand_over = CAPPED && !(KEEPS && on_its_own) && ++entered > cap;
         uint32_t h = 0;
         if (hand_over) {
           h = atomicAdd(&ho->meta[ho->counter], 1u);
-          if (ho->full_keeps != 0u && h >= ho->max_heavy) {  // no room: this lane finishes its query itself
+          if (KEEPS && h >= ho->max_heavy) {  // no room: this lane finishes its query itself
             hand_over = false;
-            cap = 0xFFFFFFFFu;
+            on_its_own = true;
           }
         }
         if (hand_over) {
@@ -1131,7 +1134,7 @@ __global__ __launch_bounds__(BLOCK) PTK_KNN_REG_WAVES void knn_reg_kernel(
   pol.init(k, e_inv);
   if constexpr (CAPPED) {
     ho.slot = (uint32_t)qi;
-    traverse<LEAFB, false, M, true>(t, qx, qy, qz, pol, st, cap, &ho);
+    traverse<LEAFB, false, M, true, true>(t, qx, qy, qz, pol, st, cap, &ho);
   } else {
     traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   }

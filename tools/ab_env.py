@@ -39,6 +39,10 @@ def main():
     import pico_tree_amd as pt
     from pico_tree_amd import datasets as ds
 
+    if os.environ.get("PTK_LIBRARY"):  # (tools/ab_libs.sh: a library of an older commit may lack the newest entry points)
+        import ctypes
+        probe = ctypes.CDLL(os.environ["PTK_LIBRARY"])
+        pt._SIGNATURES = {k: v for k, v in pt._SIGNATURES.items() if hasattr(probe, k)}
     n = args.n or ds.CONFIG2_N
     nq = args.nq or ds.CONFIG2_NQ
     pts, q = ds.config2_clouds(args.cloud, n, nq)
