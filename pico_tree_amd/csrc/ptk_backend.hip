@@ -1103,7 +1103,7 @@ uint32_t knn_coop_blocks(const ptk_tree* t) { return (uint32_t)t->cus * (uint32_
 // and more hand-overs (kernel ms at caps of 16 / 64 / 256, knn = 16: 150 k queries 0.42 / 0.67 / 1.92, 600 k
 // -- / 0.94 / 1.93, 2.4 M -- / 2.07 / 1.93 [128: 1.82], 7.2 M 256: 3.96; knn = 4: 150 k 0.24 / 0.45 / 1.38 [8: 0.20],
 // 600 k [32: 0.42] / 0.54 / 1.35, 2.4 M [32: 0.99] / 0.94 / 1.52: profiles/r05_notes.txt item 13).  Linear in the batch
-// up to 576 k queries, slower beyond, 256 at BASELINE config 3; k <= 4 takes half the cap of k <= 16, k <= 32 twice it
+// up to 576 k queries, slower beyond, 256-512 at BASELINE config 3; k <= 4 takes half the cap of k <= 16, k <= 32 twice it
 // (knn = 32 at a cap of 16: a quarter of 150 k queries handed over, 2.0 ms; knn = 8 at 8: 12 %, 0.67 ms against 0.52
 // at 600 k).  PTK_KNN_CAP = n: that cap for every batch (0: no cap).
 uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
@@ -1112,14 +1112,20 @@ uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
   const int forced = env_int("PTK_KNN_CAP", -1);
   if (forced >= 0) return (uint32_t)forced;
   const double scale = k <= 4 ? 0.5 : (k <= 16 ? 1.0 : 2.0);  // (a query's far children grow with its k)
+  // Beyond the knee towards the cap of BASELINE config 3 (7.2 M queries; two launches side by side there, see
+  // launch_knn_reg: the tail of the front hides behind the rest, so the longer lists want FEWER hand-overs --
+  // kernel ms at caps of 256 / 320 / 384 / 448 / 512: knn = 8 2.65 / 2.64 / 2.87 / 3.15 / 3.33, knn = 16 3.85 / 3.80 /
+  // 3.78 / 3.77 / 3.77, knn = 32 8.14 / 7.58 / 7.27 / 6.97 / 6.99; knn = 4: 192 / 256 / 320 2.18 / 2.17 / 2.44).
+  const double top = k <= 4 ? 256.0 : (k <= 8 ? 320.0 : (k <= 16 ? 448.0 : 512.0));
+  const double expo = k <= 4 ? 0.8 : (k <= 8 ? 0.64 : (k <= 16 ? 0.77 : 0.55));
   const double knee = 576000.0, x = (double)nq / knee;
-  const double cap = 64.0 * scale * (x <= 1.0 ? x : std::pow(x, k <= 4 ? 0.8 : 0.55));
-  return (uint32_t)std::min(256.0, std::max(16.0 * scale, cap));
+  const double cap = 64.0 * scale * (x <= 1.0 ? x : std::pow(x, expo));
+  return (uint32_t)std::min(top, std::max(16.0 * scale, cap));
 }
 // Entries of the hand-over list (64 tasks of 24 bytes each): a query that finds it full goes on in its lane.
 uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 64, std::min<uint64_t>(nq, 16384)); }
 size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
-  return 3 * (nq * 4) + knn_max_handover(nq) * ptk::kMaxTasks * sizeof(ptk::Task) + ptk::kMetaWords * 4 +
+  return 3 * (nq * 4) + (knn_max_handover(nq) + 16384) * ptk::kMaxTasks * sizeof(ptk::Task) + ptk::kMetaWords * 4 +
          (size_t)knn_coop_blocks(t) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
 }
 
@@ -1134,38 +1140,92 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
     const uint32_t cap = scratch != nullptr ? knn_cap(e, nq, k) : 0u;
     if (cap != 0u) {
       // The capped launch, the cooperative search of what it handed over, the reference search of what that could
-      // not certify: three launches in stream order, the counts stay on the device.
-      ptk::Handover ho{};
-      ho.counter = ptk::kMetaHeavy;
-      ho.meta = scratch->take<uint32_t>(ptk::kMetaWords);
-      ho.heavy_list = scratch->take<uint32_t>(nq);
-      ho.ntasks = scratch->take<uint32_t>(nq);
-      ho.max_heavy = (uint32_t)knn_max_handover(nq);
-      ho.full_keeps = 1u;
-      ho.tasks = scratch->take<ptk::Task>((size_t)ho.max_heavy * ptk::kMaxTasks);
-      uint32_t* redo_list = scratch->take<uint32_t>(nq);
+      // not certify: the counts stay on the device.  A batch of four million queries or more goes through as TWO capped
+      // launches side by side -- the front of the launch order (the expensive rows: `perm` puts them first) on a second
+      // stream, the rest on the caller's -- so that the cooperative search of what the front handed over runs BESIDE the
+      // rest instead of behind it (PTK_KNN_OVERLAP_PCT: the front's share of the rows, 0 = one launch).
       const uint32_t coop_blocks = knn_coop_blocks(t);
+      uint64_t n_front = 0;
+      hipStream_t side = nullptr;
+      hipEvent_t fork = nullptr, join = nullptr;
+      // (kernel ms, two launches / one: 7.2 M queries knn = 4 / 8 / 16 / 32 2.15 / 2.67 / 3.78 / 7.07 against 2.20 / 2.71 /
+      // 3.86 / 7.11, 4.8 M 1.58 / 2.01 / 2.75 / 5.00 against 1.59 / 1.95 / 2.86 / 5.23; at 2.4 M and below, and for
+      // knn = 2, the second launch costs more than the overlap returns: 1.82 against 1.67 at knn = 16)
+      if (perm != nullptr && nq >= (1ull << 22) && k > 2) {
+        const uint64_t pct = (uint64_t)std::min(90, std::max(0, env_int("PTK_KNN_OVERLAP_PCT", 20)));
+        n_front = (nq * pct / 100) / BLOCK * BLOCK;
+        if (n_front != 0 && !scratch->side_stream(&side, &fork, &join)) n_front = 0;
+      }
+      uint32_t* meta = scratch->take<uint32_t>(ptk::kMetaWords);
+      uint32_t* heavy_list = scratch->take<uint32_t>(nq);
+      uint32_t* ntasks = scratch->take<uint32_t>(nq);
+      const uint32_t cap_front = (uint32_t)knn_max_handover(n_front), cap_rest = (uint32_t)knn_max_handover(nq - n_front);
+      ptk::Task* tasks = scratch->take<ptk::Task>(((size_t)(n_front ? cap_front : 0) + cap_rest) * ptk::kMaxTasks);
+      uint32_t* redo_list = scratch->take<uint32_t>(nq);
       ptk::Task* spill = scratch->take<ptk::Task>((size_t)coop_blocks * kKnnCoopSpill);
-      if (!ho.meta || !ho.heavy_list || !ho.ntasks || !ho.tasks || !redo_list || !spill)
+      if (!meta || !heavy_list || !ntasks || !tasks || !redo_list || !spill)
         return fail(PTK_ERR_NOMEM, "scratch block too small");
-      scratch->note_meta(ho.meta);
-      PTK_HIP(hipMemsetAsync(ho.meta, 0, ptk::kMetaWords * 4, s));
+      scratch->note_meta(meta);
+      PTK_HIP(hipMemsetAsync(meta, 0, ptk::kMetaWords * 4, s));
       const size_t coop_smem = (size_t)ptk::knn_coop_lds_words(kKnnCoopPool) * 4;
       const uint2* ranges = static_cast<const uint2*>(t->d_ranges);
+      // One capped launch over launch-order rows [lo, lo + n) and the cooperative search of its hand-overs, on `st`
+      // (`word`: the counter of its list; `cb` wavefronts from `first_block` of the spill block).
+      auto part = [&](uint64_t lo, uint64_t n, uint32_t word, uint32_t max_heavy, ptk::Task* part_tasks, uint32_t cb,
+                      uint32_t first_block, hipStream_t st) {
+        ptk::Handover ho{};
+        ho.counter = word;
+        ho.meta = meta;
+        ho.heavy_list = heavy_list + lo;
+        ho.ntasks = ntasks + lo;
+        ho.max_heavy = max_heavy;
+        ho.full_keeps = 1u;
+        ho.tasks = part_tasks;
+        const uint32_t nb = (uint32_t)((n + BLOCK - 1) / BLOCK);
+        const uint32_t cap_n = cap;  // (of the whole batch: the two launches share the chip)
+        ptk::Task* sp = spill + (size_t)first_block * kKnnCoopSpill;
 #define PTK_LAUNCH_REG(KK)                                                                                              \
   do {                                                                                                                  \
-    hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M, true>), dim3(blocks), dim3(BLOCK), smem, s,     \
-                       t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out, cap, ho);                                 \
-    hipLaunchKernelGGL((ptk::knn_coop_kernel<KK, kKnnCoopPool>), dim3(coop_blocks), dim3(64), coop_smem, s, t->dev,      \
-                       ranges, d_q, t->dim, k, d_out, ho, redo_list, ptk::kMetaRedo, spill, kKnnCoopSpill);             \
-    hipLaunchKernelGGL((ptk::knn_redo_kernel<KK, S, OVF, LEAFB, M>), dim3(t->cus), dim3(64), smem, s, t->dev, d_q,       \
-                       t->dim, k, inv_ratio(e), d_out, ho.meta, ptk::kMetaRedo, redo_list);                             \
+    hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M, true>), dim3(nb), dim3(BLOCK), smem, st,        \
+                       t->dev, d_q, t->dim, perm ? perm + lo : nullptr, n, k, inv_ratio(e), d_out, cap_n, ho);          \
+    hipLaunchKernelGGL((ptk::knn_coop_kernel<KK, kKnnCoopPool>), dim3(cb), dim3(64), coop_smem, st, t->dev, ranges,      \
+                       d_q, t->dim, k, d_out, ho, redo_list, ptk::kMetaRedo, sp, kKnnCoopSpill);                        \
   } while (0)
-      if (k <= 4) PTK_LAUNCH_REG(4);
-      else if (k <= 8) PTK_LAUNCH_REG(8);
-      else if (k <= 16) PTK_LAUNCH_REG(16);
-      else PTK_LAUNCH_REG(32);
+        if (k <= 4) PTK_LAUNCH_REG(4);
+        else if (k <= 8) PTK_LAUNCH_REG(8);
+        else if (k <= 16) PTK_LAUNCH_REG(16);
+        else PTK_LAUNCH_REG(32);
 #undef PTK_LAUNCH_REG
+      };
+      if (n_front != 0) {
+        // (a failure between fork and join must not leave the second stream working on a scratch block the next call reuses)
+        struct SideGuard {
+          hipStream_t side = nullptr;
+          ~SideGuard() {
+            if (side) (void)hipStreamSynchronize(side);
+          }
+        } guard;
+        guard.side = side;
+        PTK_HIP(hipEventRecord(fork, s));
+        PTK_HIP(hipStreamWaitEvent(side, fork, 0));
+        const uint32_t half = std::max(1u, coop_blocks / 2);
+        part(0, n_front, ptk::kMetaHeavy, cap_front, tasks, half, 0u, side);
+        PTK_HIP(hipEventRecord(join, side));
+        part(n_front, nq - n_front, ptk::kMetaHeavyRest, cap_rest, tasks + (size_t)cap_front * ptk::kMaxTasks,
+             coop_blocks - half, half, s);
+        PTK_HIP(hipStreamWaitEvent(s, join, 0));
+        guard.side = nullptr;
+      } else {
+        part(0, nq, ptk::kMetaHeavy, cap_rest, tasks, coop_blocks, 0u, s);
+      }
+#define PTK_LAUNCH_REDO(KK)                                                                                             \
+  hipLaunchKernelGGL((ptk::knn_redo_kernel<KK, S, OVF, LEAFB, M>), dim3(t->cus), dim3(64), smem, s, t->dev, d_q, t->dim, \
+                     k, inv_ratio(e), d_out, meta, ptk::kMetaRedo, redo_list)
+      if (k <= 4) PTK_LAUNCH_REDO(4);
+      else if (k <= 8) PTK_LAUNCH_REDO(8);
+      else if (k <= 16) PTK_LAUNCH_REDO(16);
+      else PTK_LAUNCH_REDO(32);
+#undef PTK_LAUNCH_REDO
       PTK_HIP(hipGetLastError());
       timer.stop(0, nq);
       return PTK_OK;
@@ -3156,7 +3216,7 @@ int ptk_debug_knn_coop_counts(const ptk_tree* t, uint32_t counts[7]) {
   uint32_t meta[ptk::kMetaWords];
   PTK_HIP(hipDeviceSynchronize());
   PTK_HIP(hipMemcpy(meta, holder->last_meta, sizeof(meta), hipMemcpyDeviceToHost));
-  counts[0] = meta[ptk::kMetaHeavy];
+  counts[0] = meta[ptk::kMetaHeavy] + meta[ptk::kMetaHeavyRest];
   counts[1] = meta[ptk::kMetaRedo];
   counts[2] = meta[ptk::kKnnWhyPool];
   counts[3] = meta[ptk::kKnnWhyTie];

@@ -741,6 +741,7 @@ struct Task {
 // Counters in Cont::meta (zeroed by knn1_phase_meta_kernel): queries phase 2 gave up on, the next
 // entry of that list to hand to a group, queries the cooperative search could not certify.
 constexpr uint32_t kMetaHeavy = 24, kMetaRedo = 26, kMetaRanked = 3;
+constexpr uint32_t kMetaHeavyRest = 27;  // k > 1: the list of the second of two capped launches side by side
 constexpr uint32_t kMaxTasks = 64;               // tasks a capped traversal can hand over per query
 constexpr uint32_t kTasksFromRoot = 0xFFFFFFFFu;  // more than that (or no room): search again from the root
 constexpr uint32_t kTasksRedo = 0xFFFFFFFEu;      // non-monotone box distances met: only the reference order will do

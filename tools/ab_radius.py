@@ -12,11 +12,14 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--cloud", default="L")
     ap.add_argument("--radius", type=float, default=1.0)
+    ap.add_argument("--nq", type=int, default=None, help="only the first nq queries of the batch")
     args = ap.parse_args()
     import torch
     import pico_tree_amd as pt
     from pico_tree_amd import datasets as ds
     pts, q = ds.config2_clouds(args.cloud)
+    if args.nq:
+        q = np.ascontiguousarray(q[:args.nq])
     tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=0)
     dq = torch.from_numpy(q).cuda()
     configs = [c.strip() for c in args.configs.split(";")]
