@@ -120,8 +120,12 @@ def measured_traffic_c3(prefixes):
             kernels = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None, None
-    total = sum(rec["hbm_bytes_per_dispatch"] for name, rec in kernels.items()
-                if any(name.startswith(p) for p in prefixes) and "hbm_bytes_per_dispatch" in rec)
+    # (a step may launch a kernel more than once -- the two capped launches of a large k > 1 batch --: bytes per STEP,
+    # the kernel launched least often among the matched ones being the one a step launches once)
+    hit = [rec for name, rec in kernels.items()
+           if any(name.startswith(p) for p in prefixes) and "hbm_bytes_per_dispatch" in rec]
+    steps = min((rec.get("dispatches_FETCH_SIZE", 1) for rec in hit), default=1) or 1
+    total = sum(rec["hbm_bytes_per_dispatch"] * rec.get("dispatches_FETCH_SIZE", steps) / steps for rec in hit)
     return (round(total / 1e9, 3), os.path.basename(files[-1])) if total else (None, None)
 
 
@@ -132,7 +136,8 @@ def measured_traffic(prefixes):
     Counters cannot be collected from inside the process, hence the file; None if absent."""
     import glob
 
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json")))
+    files = sorted(f for f in glob.glob(os.path.join(ROOT, "profiles", "*_traffic.json"))
+                   if "_c3_" not in os.path.basename(f) and "_forest" not in os.path.basename(f))
     if not files:
         return None, None
     try:
