@@ -424,8 +424,9 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     b = 12 + 8 * k + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
     kernel_ms = prof["search_ms"] / max(int(prof["launches"]), 1)
     r = roofline_of(b, nq, kernel_ms)
-    r["kernel"] = ("ptk::knn_reg_kernel<16, 16, 64, 64, 5, ptk::MetricL2, true> (capped) + ptk::knn_coop_kernel<16, 128> "
-                   "+ ptk::knn_redo_kernel<16, ...>: the three launches of a step, timed together")
+    r["kernel"] = ("ptk::knn_reg_kernel<16, 16, 64, 64, 5, ptk::MetricL2, true> (capped; two launches side by side, the front "
+                   "fifth of the launch order on a second stream) + ptk::knn_coop_kernel<16, 128> behind each + "
+                   "ptk::knn_redo_kernel<16, ...>: the launches of a step, timed together from the first to the last")
     r["traffic"], r["traffic_source"] = measured_traffic_c3(["ptk::knn_reg_kernel<16,", "ptk::knn_coop_kernel<16,",
                                                              "ptk::knn_redo_kernel<16,"])
     r["traffic_static"] = True  # (GB per launch, 2 x FETCH_SIZE + WRITE_SIZE of committed rocprofv3 --pmc passes, as above)
