@@ -782,6 +782,48 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
         assert view.knn1_counts()["redone"] == 0
 
 
+def test_k_nearest_cap_follows_the_batch_and_large_batches_run_as_two_launches(gpu, monkeypatch):
+    """1 < k <= 32, exact, metric_l2_squared: the far children a query may enter before a wavefront takes it over follow
+    the size of the batch (knn_cap of ptk_backend.hip), a full hand-over list leaves a query in its lane, and a batch of
+    4 M queries or more goes through as two capped launches side by side.  Rows never depend on any of that: the
+    default form, one launch, a fixed cap, no cap at all (the reference traversal in every lane) and a hand-over list of
+    almost no entries agree byte for byte on a 4.3 M-query batch, and the small pieces equal the oracle."""
+    import torch
+
+    pts, q = ds.config2_clouds("L", 2_000_000, 4_300_000)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    dq = torch.from_numpy(q).to(f"cuda:{gpu}")
+    k = 5
+    out = torch.empty((len(q), k, 2), dtype=torch.int32, device=dq.device)
+
+    def rows(**env):
+        for name, value in env.items():
+            monkeypatch.setenv(name, value)
+        tree.search_knn(dq, k, out)
+        torch.cuda.synchronize()
+        counts = tree.knn_coop_counts() if env.get("PTK_KNN_CAP") != "0" else None
+        for name in env:
+            monkeypatch.delenv(name)
+        return out.cpu().numpy().tobytes(), counts
+
+    base, counts = rows()
+    assert counts["cooperative"] > 0 and counts["redone"] <= counts["cooperative"] // 50, counts
+    assert rows(PTK_KNN_OVERLAP_PCT="0")[0] == base        # one capped launch
+    assert rows(PTK_KNN_OVERLAP_PCT="50", PTK_KNN_CAP="24")[0] == base
+    assert rows(PTK_KNN_CAP="0")[0] == base                 # every query to its end in its lane
+    # (a cap of 3 hands most queries over; the list is a 64th of the batch: the rest goes on in its lanes)
+    got, counts = rows(PTK_KNN_CAP="3", PTK_KNN_OVERLAP_PCT="0")
+    assert got == base and counts["cooperative"] > len(q) // 64, counts
+    # pieces of a batch (a shard, a piece of a host-buffer call) get a cap of their own: against the oracle
+    ref = oracle.Oracle(pts, 10, "port")
+    ref.set_threads(ref.max_threads())
+    for n in (5_000, 70_000):
+        got = tree.search_knn(dq[:n], 16).numpy()
+        torch.cuda.synchronize()
+        assert got.tobytes() == ref.search_knn(q[:n], 16).tobytes(), n
+        assert tree.knn_coop_counts()["cooperative"] > 0
+
+
 @pytest.mark.parametrize("cloud", ["lidar", "uniform"])
 def test_batches_that_arrive_coherent_are_not_sorted_again(gpu, cloud):
     """The reference walks the rows in the caller's order (_pyco_tree/kd_tree.hpp:128-134); the k = 1 search samples
