@@ -223,27 +223,85 @@ class nearest_search_topological {
   std::vector<scalar> off_;
 };
 
+//! Which axes of a metric's space are circles (apply_dim_space of the topological metrics,
+//! reference metric.hpp:216-219, :249-256); a euclidean metric has none.
+struct no_circle_axes {
+  constexpr bool operator()(size_t) const { return false; }
+};
+template <typename Metric_>
+struct circle_axes_of {
+  Metric_ const& metric;
+  bool operator()(size_t axis) const {
+    bool circle = false;
+    metric.apply_dim_space(static_cast<int>(axis), [&](auto one_space) {
+      circle = std::is_same_v<decltype(one_space), one_space_s1>;
+    });
+    return circle;
+  }
+};
+
 //! All indices inside the closed box [qmin, qmax], in the reference's report
 //! order (internal/kd_tree_search.hpp:238-381): a node whose running box is
 //! fully inside the query is reported wholesale, a partially covered node is
 //! descended, left before right.
-template <typename Tree_, typename SpaceView_, typename Index_>
+//!
+//! Topological_ (a tree over a topological space: flat_tree::outer_bounds): the query is the
+//! reference's metric_box_map (box.hpp:300-376) -- on a circle axis (`is_circle(axis)`) an
+//! interval with min > max runs through the seam 0 ~ 1 and contains x iff x >= min || x <= max
+//! (segment_s1::contains, segment.hpp:61-75) -- and every axis takes the four-bound
+//! intersection tests of kd_tree_search.hpp:311-327.
+template <bool Topological_ = false, typename Tree_, typename SpaceView_, typename Index_,
+          typename CircleAxes_ = no_circle_axes>
 inline void box_search(
     Tree_ const& tree,
     SpaceView_ const& space,
     typename Tree_::scalar_type const* qmin,
     typename Tree_::scalar_type const* qmax,
-    std::vector<Index_>& out) {
+    std::vector<Index_>& out,
+    CircleAxes_ const& is_circle = CircleAxes_{}) {
   using scalar = typename Tree_::scalar_type;
   using box_type = typename Tree_::box_type;
   auto const* const nodes = tree.nodes.data();
   auto const* const indices = tree.indices.data();
   size_t const sdim = space.sdim();
 
-  box_type query(sdim);
+  // The query box with the containment tests of box_map (euclidean) or metric_box_map.
+  struct query_box {
+    box_type b;
+    std::vector<char> wraps;  // per axis: a circle axis whose interval runs through the seam
+    scalar& min(size_t i) { return b.min(i); }
+    scalar& max(size_t i) { return b.max(i); }
+    scalar min(size_t i) const { return b.min(i); }
+    scalar max(size_t i) const { return b.max(i); }
+    bool contains(scalar const* p) const {
+      if constexpr (!Topological_) {
+        return b.contains(p);
+      } else {
+        for (size_t i = 0; i < wraps.size(); ++i) {
+          scalar const x = p[i];
+          if (wraps[i] ? !(x >= b.min(i) || x <= b.max(i)) : !(b.min(i) <= x && x <= b.max(i))) return false;
+        }
+        return true;
+      }
+    }
+    bool contains(box_type const& x) const {
+      if constexpr (!Topological_) {
+        return b.contains(x);
+      } else {
+        for (size_t i = 0; i < wraps.size(); ++i) {
+          if (wraps[i] ? !(x.min(i) >= b.min(i) || x.max(i) <= b.max(i))
+                       : !(b.min(i) <= x.min(i) && x.max(i) <= b.max(i)))
+            return false;
+        }
+        return true;
+      }
+    }
+  };
+  query_box query{box_type(sdim), std::vector<char>(Topological_ ? sdim : 0, 0)};
   for (size_t i = 0; i < sdim; ++i) {
     query.min(i) = qmin[i];
     query.max(i) = qmax[i];
+    if constexpr (Topological_) query.wraps[i] = is_circle(i) && !(qmin[i] <= qmax[i]);
   }
   box_type box = tree.root_box;
 
@@ -284,9 +342,11 @@ inline void box_search(
       f.phase = 1;
       f.saved = box.max(axis);
       box.max(axis) = nd.left_max;
+      bool enter = query.min(axis) <= nd.left_max;  // intersects_left
+      if constexpr (Topological_) enter = enter || query.max(axis) >= tree.outer_bounds[f.node][0];  // || max >= left_min
       if (query.contains(box)) {
         report(f.node + 1);
-      } else if (query.min(axis) <= nd.left_max) {
+      } else if (enter) {
         stack.push_back(frame{f.node + 1, 0, scalar(0)});
       }
     } else if (f.phase == 1) {
@@ -294,9 +354,11 @@ inline void box_search(
       box.max(axis) = f.saved;
       f.saved = box.min(axis);
       box.min(axis) = nd.right_min;
+      bool enter = query.max(axis) >= nd.right_min;  // intersects_right
+      if constexpr (Topological_) enter = enter || query.min(axis) <= tree.outer_bounds[f.node][1];  // || min <= right_max
       if (query.contains(box)) {
         report(nd.right);
-      } else if (query.max(axis) >= nd.right_min) {
+      } else if (enter) {
         std::uint32_t const r = nd.right;
         stack.push_back(frame{r, 0, scalar(0)});
       }

@@ -215,12 +215,22 @@ class kd_tree {
       P_ const& min, P_ const& max, std::vector<index_type>& idxs) const {
     idxs.clear();
     space_view_type s = view();
-    internal::box_search(
-        tree_,
-        s,
-        internal::point_view<P_>(min).data(),
-        internal::point_view<P_>(max).data(),
-        idxs);
+    if constexpr (topological) {  // metric_box_map: intervals through the seam of a circle axis, four-bound tests
+      internal::box_search<true>(
+          tree_,
+          s,
+          internal::point_view<P_>(min).data(),
+          internal::point_view<P_>(max).data(),
+          idxs,
+          internal::circle_axes_of<metric_type>{metric_});
+    } else {
+      internal::box_search(
+          tree_,
+          s,
+          internal::point_view<P_>(min).data(),
+          internal::point_view<P_>(max).data(),
+          idxs);
+    }
   }
 
   // ---- batched searches (MI355X) -------------------------------------------
@@ -326,7 +336,11 @@ class kd_tree {
       std::vector<std::vector<index_type>> per_row(lo.rows());
       space_view_type s = view();
       internal::host_rows_loop(lo.rows(), [&](size_type i) {
-        internal::box_search(tree_, s, lo.data() + i * lo.cols(), hi.data() + i * hi.cols(), per_row[i]);
+        if constexpr (topological)
+          internal::box_search<true>(tree_, s, lo.data() + i * lo.cols(), hi.data() + i * hi.cols(), per_row[i],
+                                     internal::circle_axes_of<metric_type>{metric_});
+        else
+          internal::box_search(tree_, s, lo.data() + i * lo.cols(), hi.data() + i * hi.cols(), per_row[i]);
       });
       for (size_type i = 0; i < lo.rows(); ++i) offsets[i + 1] = offsets[i] + per_row[i].size();
       flat.resize(offsets.back());

@@ -213,7 +213,24 @@ int ptk_host_search_box(const ptk_tree* t, const float* points, const float* min
     space_t space(points, t->n_points, t->dim);
     view_t view(space);
     std::vector<std::vector<int>> per_row(nb);
-    rows_loop(nb, [&](uint64_t i) { internal::box_search(flat, view, mins + i * t->dim, maxs + i * t->dim, per_row[i]); });
+    const int metric = t->metric.load();
+    if (metric == PTK_METRIC_SO2 || metric == PTK_METRIC_SE2_SQUARED) {
+      // a tree over a topological space: the metric_box_map query of the reference (box.hpp:300-376) -- intervals
+      // through the seam of the circle axis, the four-bound intersection tests
+      if (topological_without_bounds(t, flat)) return fail(PTK_ERR_INVALID, "this tree has no outer bounds (ptk_tree_set_outer_bounds)");
+      const metric_so2 so2;
+      const metric_se2_squared se2;
+      rows_loop(nb, [&](uint64_t i) {
+        if (metric == PTK_METRIC_SO2)
+          internal::box_search<true>(flat, view, mins + i * t->dim, maxs + i * t->dim, per_row[i],
+                                     internal::circle_axes_of<metric_so2>{so2});
+        else
+          internal::box_search<true>(flat, view, mins + i * t->dim, maxs + i * t->dim, per_row[i],
+                                     internal::circle_axes_of<metric_se2_squared>{se2});
+      });
+    } else {
+      rows_loop(nb, [&](uint64_t i) { internal::box_search(flat, view, mins + i * t->dim, maxs + i * t->dim, per_row[i]); });
+    }
     offsets[0] = 0;
     for (uint64_t i = 0; i < nb; ++i) offsets[i + 1] = offsets[i] + per_row[i].size();
     auto* rows = static_cast<int32_t*>(std::malloc(std::max<size_t>(offsets[nb], 1) * sizeof(int32_t)));

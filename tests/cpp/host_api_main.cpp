@@ -231,6 +231,9 @@ static int run_host(std::string const& dir) {
         lo[d] -= 0.02f;
         hi[d] += 0.02f;
       }
+      // (the angle's interval through the seam 0 ~ 1: its min comes out above its max, box.hpp:300-376)
+      if (lo[2] < 0.0f) lo[2] += 1.0f;
+      if (hi[2] > 1.0f) hi[2] -= 1.0f;
       se2.search_box(lo, hi, brow);
       bflat.insert(bflat.end(), brow.begin(), brow.end());
       boff[i + 1] = bflat.size();

@@ -287,6 +287,37 @@ def test_topological_tree_stream_is_the_reference_stream(tmp_path, metric, dim):
     assert len(plain._serialize()) < len(stream)  # two bounds per branch fewer
 
 
+@pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
+@pytest.mark.parametrize("metric,dim", [("SO2", 1), ("SE2Squared", 3)])
+def test_host_loop_box_search_of_a_topological_tree(metric, dim):
+    """ptk_host_search_box on a tree over a topological space (what serves a box search the device refuses: a tree
+    deeper than its stack) is the reference's search_box with a metric_box_map query (box.hpp:300-376): an interval
+    of the circle axis may run through the seam 0 ~ 1 (min above max), and every axis takes the four-bound
+    intersection tests.  A lattice cloud: thousands of coincident angles, the deep tree of the case the fuzzer found."""
+    rng = np.random.default_rng(9)
+    pts = np.ascontiguousarray(np.round(rng.random((8_000, dim)) * 6) / 6, dtype=np.float32)
+    pts[:, -1] = np.where(pts[:, -1] >= 1, np.float32(0.0), pts[:, -1])
+    q = rng.random((400, dim)).astype(np.float32)
+    q[:100, -1] = (rng.random(100) * 1e-3).astype(np.float32)
+    lo, hi = q - np.float32(0.03), q + np.float32(0.03)
+    through = (lo[:, -1] < 0) | (hi[:, -1] > 1)
+    lo[:, -1] = np.where(lo[:, -1] < 0, lo[:, -1] + np.float32(1.0), lo[:, -1])
+    hi[:, -1] = np.where(hi[:, -1] > 1, hi[:, -1] - np.float32(1.0), hi[:, -1])
+    lo, hi = np.ascontiguousarray(lo), np.ascontiguousarray(hi)
+    tree = pt.KdTree(pts, pt.Metric[metric], 4, device=pt.PTK_DEVICE_NONE)
+    ref = oracle.Oracle(pts, 4, "reference", metric)
+    lib = pt._load()
+    offsets = np.zeros(len(q) + 1, dtype=np.uint64)
+    rows = ctypes.c_void_p()
+    assert lib.ptk_host_search_box(tree._h, pts.ctypes.data, lo.ctypes.data, hi.ctypes.data, len(q),
+                                   offsets.ctypes.data, ctypes.byref(rows)) == 0
+    flat = np.ctypeslib.as_array(ctypes.cast(rows, ctypes.POINTER(ctypes.c_int32)), shape=(int(offsets[-1]),)).copy()
+    lib.ptk_free(rows)
+    boff, bflat = ref.search_box(lo, hi)
+    assert np.array_equal(offsets, boff) and np.array_equal(flat, bflat)
+    assert through.sum() >= 100 and np.diff(boff)[through].sum() > 0
+
+
 @pytest.mark.parametrize("metric", ["L2Squared", "L1", "LPInf"])
 def test_host_loop_entry_points_equal_the_oracle(metric):
     """ptk_host_search_* (what the wrappers call when a DEVICE search answers PTK_ERR_UNSUPPORTED): the reference's

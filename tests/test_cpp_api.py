@@ -98,9 +98,14 @@ def test_topological_metrics_match_the_compiled_reference(workdir):
     off, flat = se2.search_radius(q, RADIUS)
     assert off[-1] > 0 and np.array_equal(_load(d, "t_se2_radius_off.bin", np.uint64), off)
     assert _load(d, "t_se2_radius_flat.bin", pt.NEIGHBOR).tobytes() == flat.tobytes()
-    boff, bflat = se2.search_box(q - np.float32(0.02), q + np.float32(0.02))
+    lo, hi = q - np.float32(0.02), q + np.float32(0.02)
+    through = (lo[:, 2] < 0) | (hi[:, 2] > 1)          # the angle's interval through the seam: min above max
+    lo[:, 2] = np.where(lo[:, 2] < 0, lo[:, 2] + np.float32(1.0), lo[:, 2])
+    hi[:, 2] = np.where(hi[:, 2] > 1, hi[:, 2] - np.float32(1.0), hi[:, 2])
+    boff, bflat = se2.search_box(np.ascontiguousarray(lo), np.ascontiguousarray(hi))
     assert np.array_equal(_load(d, "t_se2_box_off.bin", np.uint64), boff)
     assert np.array_equal(_load(d, "t_se2_box_flat.bin", np.int32), bflat)
+    assert through.sum() > 20 and np.diff(boff)[through].sum() > 0
     assert _load(d, "t_se2_save.bin", np.uint8).tobytes() == se2.save_bytes()
     # wrap-around really happens in this data: some neighbours are nearer through 0 ~ 1
     knn = _load(d, "t_so2_knn.bin", pt.NEIGHBOR).reshape(-1, K)

@@ -107,6 +107,54 @@ def one_case(rng, pt, oracle, torch, case):
     return desc, bad
 
 
+def one_topological_case(rng, pt, oracle, torch, case):
+    """metric_so2 (dim 1) / metric_se2_squared (dim 3) on coordinates in [0, 1], against the reference's own headers
+    (oracle kind "reference": the restatement covers the euclidean metrics only): knn, radius, boxes through the seam."""
+    metric = str(rng.choice(["SO2", "SE2Squared"]))
+    dim = 1 if metric == "SO2" else 3
+    n = int(rng.choice([2, 9, 100, 3000, 20000, 60000]))
+    nq = int(rng.choice([1, 63, 64, 65, 1000, 5000]))
+    leaf = int(rng.choice([1, 2, 5, 10, 16]))
+    kind = str(rng.choice(["uniform", "clustered", "lattice", "duplicates"]))
+    wrap01 = lambda a: np.ascontiguousarray(np.clip(a - np.floor(a), 0.0, 1.0).astype(DTYPE))
+    pts = wrap01(make_cloud(rng, kind, n, dim))
+    q = wrap01(make_cloud(rng, kind, nq, dim)) if rng.random() < 0.5 else \
+        wrap01(pts[rng.integers(0, n, nq)] + rng.normal(0, 1e-3, (nq, dim)) * (rng.random() < 0.7))
+    if nq > 4:  # next to the seam of the circle axis
+        q[: nq // 4, -1] = (rng.random(nq // 4) * 1e-3).astype(DTYPE)
+        q[nq // 4: nq // 2, -1] = (1.0 - rng.random(nq // 2 - nq // 4) * 1e-3).astype(DTYPE)
+    desc = f"case {case}: {metric} n {n} nq {nq} leaf {leaf} {kind} {np.dtype(DTYPE).name}"
+    if VERBOSE:
+        print(desc, flush=True)
+    tree = pt.KdTree(pts, pt.Metric[metric], leaf, device=0)
+    ref = oracle.Oracle(pts, leaf, "reference", metric, dtype=DTYPE)
+    bad = []
+    for k in {1, int(rng.integers(1, min(n, 48) + 1)), min(n, int(rng.choice([2, 8, 33])))}:
+        e = float(rng.choice([1.0, 1.0, 1.3]))
+        want = ref.search_knn(q, k, e=None if e == 1.0 else e)
+        got = tree.search_knn(q, k) if e == 1.0 else tree.search_knn(q, k, e)
+        if not same_rows(got, want):
+            bad.append(f"knn k={k} e={e}")
+    nn = ref.search_knn(q, min(n, 4))["distance"][:, -1]
+    radius = float(np.quantile(nn, rng.choice([0.1, 0.5, 0.9])) * rng.choice([1.0, 4.0])) or 1e-4
+    off, flat = ref.search_radius(q, radius)
+    got = tree.search_radius(q, radius)
+    if not np.array_equal(got.offsets, off) or not same_rows(got.flat, flat):
+        bad.append(f"radius r={radius}")
+    half = (rng.random((nq, dim)) * 0.05).astype(DTYPE)
+    mins, maxs = (q - half).astype(DTYPE), (q + half).astype(DTYPE)
+    mins[:, -1] = np.where(mins[:, -1] < 0, mins[:, -1] + 1, mins[:, -1])  # an interval through the seam: min > max
+    maxs[:, -1] = np.where(maxs[:, -1] > 1, maxs[:, -1] - 1, maxs[:, -1])
+    boxes = np.empty((2 * nq, dim), dtype=DTYPE)
+    boxes[0::2], boxes[1::2] = mins, maxs
+    boff, bflat = ref.search_box(np.ascontiguousarray(mins), np.ascontiguousarray(maxs))
+    b = tree.search_box(boxes)
+    if not np.array_equal(b.offsets, boff) or not np.array_equal(b.flat, bflat):
+        bad.append("box")
+    tree.close()
+    return desc, bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
@@ -114,6 +162,7 @@ def main():
     ap.add_argument("--case", type=int, default=-1, help="replay only this case")
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
+    ap.add_argument("--topological", action="store_true", help="metric_so2 / metric_se2_squared against the compiled reference")
     args = ap.parse_args()
     global DTYPE
     DTYPE = np.float64 if args.dtype == "float64" else np.float32
@@ -128,7 +177,7 @@ def main():
         if args.case >= 0 and case != args.case:
             continue
         try:
-            desc, bad = one_case(rng, pt, oracle, torch, case)
+            desc, bad = (one_topological_case if args.topological else one_case)(rng, pt, oracle, torch, case)
         except pt.PtkError as err:
             # The one limit left: a point set so degenerate that the BUILD stops (deeper than 8192 levels: thousands of
             # coincident points peeling one level each; the reference's recursive builder overflows its stack on such
