@@ -19,6 +19,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 VERBOSE = False
 DTYPE = np.float32  # --dtype float64: the double-precision entry points
+LNINF = False       # --lninf: metric_lninf among the metrics drawn (changes what a seed draws: off by default)
 
 
 def same_rows(got, want):
@@ -58,7 +59,7 @@ def one_case(rng, pt, oracle, torch, case):
     kind = str(rng.choice(["uniform", "clustered", "lattice", "duplicates", "line", "plane"]))
     scale = float(rng.choice([1.0, 1.0, 1e-6, 1e6, 37.5]))
     shift = float(rng.choice([0.0, 0.0, -0.5, 100.0]))
-    metric = str(rng.choice(["L2Squared", "L2Squared", "L1", "LPInf"]))
+    metric = str(rng.choice(["L2Squared", "L2Squared", "L1", "LPInf", "LNInf"] if LNINF else ["L2Squared", "L2Squared", "L1", "LPInf"]))
     pts = ((make_cloud(rng, kind, n, dim) + shift) * scale).astype(DTYPE)
     if rng.random() < 0.5:
         q = ((make_cloud(rng, kind, nq, dim) + shift) * scale).astype(DTYPE)
@@ -163,7 +164,10 @@ def main():
     ap.add_argument("--verbose", action="store_true", help="print every case before it runs")
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
     ap.add_argument("--topological", action="store_true", help="metric_so2 / metric_se2_squared against the compiled reference")
+    ap.add_argument("--lninf", action="store_true", help="metric_lninf among the metrics drawn")
     args = ap.parse_args()
+    global LNINF
+    LNINF = args.lninf
     global DTYPE
     DTYPE = np.float64 if args.dtype == "float64" else np.float32
     import torch
