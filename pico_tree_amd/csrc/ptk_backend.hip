@@ -1100,32 +1100,39 @@ constexpr uint32_t kKnnCoopSpill = 2048;  // tasks a wavefront of the cooperativ
 uint32_t knn_coop_blocks(const ptk_tree* t) { return (uint32_t)t->cus * (uint32_t)std::max(1, env_int("PTK_KNN_COOP_WAVES", 32)); }
 // The cap follows the batch: a capped launch ends with the lanes that ran to their cap -- cap x ~7 us, a lonely lane's
 // price per far child -- however small the batch, so a batch the chip gets through in less than that wants a lower cap
-// and more hand-overs (kernel ms at caps of 16 / 64 / 256, knn = 16: 150 k queries 0.42 / 0.67 / 1.92, 600 k
-// -- / 0.94 / 1.93, 2.4 M -- / 2.07 / 1.93 [128: 1.82], 7.2 M 256: 3.96; knn = 4: 150 k 0.24 / 0.45 / 1.38 [8: 0.20],
-// 600 k [32: 0.42] / 0.54 / 1.35, 2.4 M [32: 0.99] / 0.94 / 1.52: profiles/r05_notes.txt item 13).  Linear in the batch
-// up to 576 k queries, slower beyond, 256-512 at BASELINE config 3; k <= 4 takes half the cap of k <= 16, k <= 32 twice it
-// (knn = 32 at a cap of 16: a quarter of 150 k queries handed over, 2.0 ms; knn = 8 at 8: 12 %, 0.67 ms against 0.52
-// at 600 k).  PTK_KNN_CAP = n: that cap for every batch (0: no cap).
+// and more hand-overs (at a fixed 256 ANY batch of knn = 16 took 1.9 ms).  Fitted to a sweep of twelve caps at eight
+// batch sizes and four k (tools/sweep_knn_cap.sh, profiles/r05_knn_cap_sweep.jsonl; notes r05 item 13): the best cap
+// is linear in the batch -- it keeps the hand-overs at 7-15 thousand, what the cooperative search gets through beside
+// the capped launch's end -- with a slope that follows k (a query's far children grow with its k), steeper for the
+// largest batches of k = 8 / 16 (two launches side by side there, see launch_knn_reg: the tail of the front hides
+// behind the rest, so fewer hand-overs win), between a floor and a top per k:
+//   k <= 4  nq / 37 500                                  8 .. 256      k <= 16  nq / 16 000      16 .. 448
+//   k <= 8  max(nq / 30 000, (nq - 1.2 M) / 20 000)      12 .. 320     k <= 32  nq / 9 400       32 .. 512
+// (a cap that lets more queries through than the hand-over list holds is a cliff -- those queries finish alone in
+// their lanes -- so the slopes err towards the higher cap: knn = 8 at 900 k queries, caps 24 / 32: 0.94 / 0.63 ms)
+// PTK_KNN_CAP = n: that cap for every batch (0: no cap).
 uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
   // (PTK_KNN_CAP_MIN_NQ: tests -- the fuzzer's batches are small)
   if (e != 1.0f || nq < (uint64_t)std::max(1, env_int("PTK_KNN_CAP_MIN_NQ", 4096))) return 0;
   const int forced = env_int("PTK_KNN_CAP", -1);
   if (forced >= 0) return (uint32_t)forced;
-  const double scale = k <= 4 ? 0.5 : (k <= 16 ? 1.0 : 2.0);  // (a query's far children grow with its k)
-  // Beyond the knee towards the cap of BASELINE config 3 (7.2 M queries; two launches side by side there, see
-  // launch_knn_reg: the tail of the front hides behind the rest, so the longer lists want FEWER hand-overs --
-  // kernel ms at caps of 256 / 320 / 384 / 448 / 512: knn = 8 2.65 / 2.64 / 2.87 / 3.15 / 3.33, knn = 16 3.85 / 3.80 /
-  // 3.78 / 3.77 / 3.77, knn = 32 8.14 / 7.58 / 7.27 / 6.97 / 6.99; knn = 4: 192 / 256 / 320 2.18 / 2.17 / 2.44).
-  const double top = k <= 4 ? 256.0 : (k <= 8 ? 320.0 : (k <= 16 ? 448.0 : 512.0));
-  const double expo = k <= 4 ? 0.8 : (k <= 8 ? 0.64 : (k <= 16 ? 0.77 : 0.55));
-  const double knee = 576000.0, x = (double)nq / knee;
-  const double cap = 64.0 * scale * (x <= 1.0 ? x : std::pow(x, expo));
-  return (uint32_t)std::min(top, std::max(16.0 * scale, cap));
+  const double n = (double)nq;
+  double cap, lo, hi;
+  if (k <= 4) {
+    cap = n / 37500.0, lo = 8.0, hi = 256.0;
+  } else if (k <= 8) {
+    cap = std::max(n / 30000.0, (n - 1.2e6) / 20000.0), lo = 12.0, hi = 320.0;
+  } else if (k <= 16) {
+    cap = n / 16000.0, lo = 16.0, hi = 448.0;
+  } else {
+    cap = n / 9400.0, lo = 32.0, hi = 512.0;
+  }
+  return (uint32_t)std::min(hi, std::max(lo, cap));
 }
 // Entries of the hand-over list (64 tasks of 24 bytes each): a query that finds it full goes on in its lane.
-uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 64, std::min<uint64_t>(nq, 16384)); }
+uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
 size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
-  return 3 * (nq * 4) + (knn_max_handover(nq) + 16384) * ptk::kMaxTasks * sizeof(ptk::Task) + ptk::kMetaWords * 4 +
+  return 3 * (nq * 4) + (knn_max_handover(nq) + 24576) * ptk::kMaxTasks * sizeof(ptk::Task) + ptk::kMetaWords * 4 +
          (size_t)knn_coop_blocks(t) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
 }
 
