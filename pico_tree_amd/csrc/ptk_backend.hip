@@ -1112,8 +1112,9 @@ uint32_t knn_coop_blocks(const ptk_tree* t) { return (uint32_t)t->cus * (uint32_
 // their lanes -- so the slopes err towards the higher cap: knn = 8 at 900 k queries, caps 24 / 32: 0.94 / 0.63 ms)
 // PTK_KNN_CAP = n: that cap for every batch (0: no cap).
 uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
-  // (PTK_KNN_CAP_MIN_NQ: tests -- the fuzzer's batches are small)
-  if (e != 1.0f || nq < (uint64_t)std::max(1, env_int("PTK_KNN_CAP_MIN_NQ", 4096))) return 0;
+  // (below a few wavefronts of queries the two extra launches cost more than the tail: kernel ms with / without the
+  // cap at 64 / 500 / 3 000 queries, knn = 16 0.13 / 0.27 / 0.30 against 0.11 / 0.66 / 0.90.  PTK_KNN_CAP_MIN_NQ: tests)
+  if (e != 1.0f || nq < (uint64_t)std::max(1, env_int("PTK_KNN_CAP_MIN_NQ", 256))) return 0;
   const int forced = env_int("PTK_KNN_CAP", -1);
   if (forced >= 0) return (uint32_t)forced;
   const double n = (double)nq;
