@@ -151,6 +151,7 @@ _SIGNATURES = {
     "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
     "ptk_debug_batch_order": (c_int, [c_void_p, POINTER(c_int)]),
     "ptk_debug_knn_coop_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ptk_debug_knn_cap": (c_int, [c_uint64, c_uint32, c_float, POINTER(c_uint32), POINTER(c_uint64)]),
     "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
                                              POINTER(c_void_p)]),
     "ptk_multi_create": (c_int, [c_void_p, c_void_p, c_uint32, POINTER(c_void_p)]),

@@ -3234,6 +3234,13 @@ int ptk_debug_knn_coop_counts(const ptk_tree* t, uint32_t counts[7]) {
   return PTK_OK;
 }
 
+int ptk_debug_knn_cap(uint64_t nq, uint32_t k, float e, uint32_t* cap, uint64_t* list_entries) {
+  if (cap == nullptr || list_entries == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  *cap = (k > 1 && k <= 32) ? knn_cap(e, nq, k) : 0u;
+  *list_entries = *cap != 0u ? knn_max_handover(nq) : 0;
+  return PTK_OK;
+}
+
 int ptk_debug_piles(const ptk_tree* t, uint64_t out[3]) {
   if (t == nullptr || out == nullptr) return fail(PTK_ERR_INVALID, "null argument");
   if (t->device < 0) return fail(PTK_ERR_DEVICE, "this handle has no device replica");

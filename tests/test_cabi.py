@@ -287,6 +287,39 @@ def test_topological_tree_stream_is_the_reference_stream(tmp_path, metric, dim):
     assert len(plain._serialize()) < len(stream)  # two bounds per branch fewer
 
 
+def test_knn_cap_follows_the_batch(monkeypatch):
+    """ptk_debug_knn_cap: the far children a query of a k > 1 search may enter before a wavefront takes it over.  It
+    grows with the batch (a capped launch ends with the lanes at their cap, so a small batch wants a low one), between a
+    floor and a top that follow k; approximate searches, tiny batches and k outside 2 .. 32 run uncapped; the list of
+    hand-overs always has room for the first 24 576 (or all) queries."""
+    lib = pt._load()
+
+    def cap(nq, k, e=1.0):
+        c, entries = ctypes.c_uint32(), ctypes.c_uint64()
+        assert lib.ptk_debug_knn_cap(nq, k, np.float32(e), ctypes.byref(c), ctypes.byref(entries)) == 0
+        return c.value, entries.value
+
+    monkeypatch.delenv("PTK_KNN_CAP", raising=False)
+    monkeypatch.delenv("PTK_KNN_CAP_MIN_NQ", raising=False)
+    sizes = [256, 1_000, 20_000, 150_000, 600_000, 900_000, 2_400_000, 7_200_863, 50_000_000]
+    for k, floor, top in ((2, 8, 256), (4, 8, 256), (8, 12, 320), (16, 16, 448), (32, 32, 512)):
+        caps = [cap(nq, k)[0] for nq in sizes]
+        assert caps == sorted(caps) and caps[0] == floor and caps[-1] == top, (k, caps)
+    assert cap(7_200_863, 16)[0] == 448 and cap(900_000, 16)[0] == 56 and cap(900_000, 4)[0] == 24
+    assert cap(255, 16) == (0, 0) and cap(10_000, 16, e=1.5) == (0, 0) and cap(10_000, 1) == (0, 0) and cap(10_000, 33) == (0, 0)
+    for nq in sizes:
+        entries = cap(nq, 16)[1]
+        assert min(nq, 24_576) <= entries <= max(nq // 48, 24_576)
+    monkeypatch.setenv("PTK_KNN_CAP", "77")
+    assert cap(5_000, 16)[0] == 77 and cap(7_200_863, 4)[0] == 77
+    monkeypatch.setenv("PTK_KNN_CAP", "0")
+    assert cap(7_200_863, 16) == (0, 0)
+    monkeypatch.delenv("PTK_KNN_CAP")
+    monkeypatch.setenv("PTK_KNN_CAP_MIN_NQ", "1")
+    assert cap(3, 16)[0] == 16
+    assert lib.ptk_debug_knn_cap(10, 16, np.float32(1.0), None, None) == -1
+
+
 @pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
 @pytest.mark.parametrize("metric,dim", [("SO2", 1), ("SE2Squared", 3)])
 def test_host_loop_box_search_of_a_topological_tree(metric, dim):
