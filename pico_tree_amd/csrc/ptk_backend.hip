@@ -38,7 +38,10 @@
 #include "ptk_piles.hpp"
 // Geometry of the launches (measured optima, profiles/r02_notes.txt item 23, r03_notes.txt item 13):
 constexpr int kP2Ring = 12;   // LDS ring of the capped phase 2 (records per lane; 8 / 10 / 16: 1.335 / 1.329 / 1.308 vs 1.224 ms)
-constexpr int kGenRing = 16;  // LDS ring of the general searches (k > 1, radius)
+#ifndef PTK_GEN_RING
+#define PTK_GEN_RING 16
+#endif
+constexpr int kGenRing = PTK_GEN_RING;  // LDS ring of the general searches (k > 1, radius)
 constexpr int kGenLeafB = 5;  // points per leaf round of the general searches (4 / 5 / 6: knn = 16 4.85 / 4.71 / 4.68 ms, radius capture 7.21 / 7.16 / 7.69)
 #include "ptk_build.hpp"
 #include "ptk_sort.hpp"
