@@ -156,6 +156,45 @@ def one_topological_case(rng, pt, oracle, torch, case):
     return desc, bad
 
 
+def one_multi_case(rng, pt, oracle, torch, case):
+    """ptk_multi_* with n replicas on the one GPU (PTK_MULTI_ALLOW_REPLICAS=1: the C library's row cutting, threads,
+    streams, events and staging as on a node): random n, ragged and tiny batches, host and device buffers."""
+    n_dev = int(rng.choice([1, 2, 3, 5, 8]))
+    dim = int(rng.choice([1, 2, 3, 3]))
+    n = int(rng.choice([9, 100, 3000, 20000]))
+    nq = int(rng.choice([1, 2, 7, 63, 65, 1000, 5003]))
+    leaf = int(rng.choice([1, 5, 10, 16]))
+    kind = str(rng.choice(["uniform", "clustered", "lattice", "duplicates"]))
+    pts = make_cloud(rng, kind, n, dim).astype(np.float32)
+    q = make_cloud(rng, kind, nq, dim).astype(np.float32)
+    desc = f"case {case}: multi x{n_dev} dim {dim} n {n} nq {nq} leaf {leaf} {kind}"
+    if VERBOSE:
+        print(desc, flush=True)
+    multi = pt.MultiKdTree(pts, leaf, devices=[0] * n_dev)
+    ref = oracle.Oracle(pts, leaf, "port")
+    bad = []
+    for k in {1, min(n, int(rng.choice([2, 8, 20])))}:
+        e = float(rng.choice([1.0, 1.0, 1.5]))
+        want = ref.search_knn(q, k, e=None if e == 1.0 else e)
+        got = multi.search_knn(q, k) if e == 1.0 else multi.search_knn(q, k, e)
+        if not same_rows(got, want):
+            bad.append(f"knn (host buffers) k={k} e={e}")
+        if dim <= 3 or True:
+            rows = multi.search_knn(torch.from_numpy(q).cuda(), k) if e == 1.0 else multi.search_knn(torch.from_numpy(q).cuda(), k, e)
+            rows = rows.numpy()
+            torch.cuda.synchronize()
+            if not same_rows(rows, want):
+                bad.append(f"knn (device buffers) k={k} e={e}")
+    nn = ref.search_knn(q, min(n, 4))["distance"][:, -1]
+    radius = float(np.quantile(nn, 0.5) * rng.choice([1.0, 4.0])) or 0.01
+    off, flat = ref.search_radius(q, radius)
+    got = multi.search_radius(q, radius)
+    if not np.array_equal(got.offsets, off) or not same_rows(got.flat, flat):
+        bad.append(f"radius r={radius}")
+    del multi
+    return desc, bad
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--cases", type=int, default=100)
@@ -165,9 +204,12 @@ def main():
     ap.add_argument("--dtype", choices=["float32", "float64"], default="float32")
     ap.add_argument("--topological", action="store_true", help="metric_so2 / metric_se2_squared against the compiled reference")
     ap.add_argument("--lninf", action="store_true", help="metric_lninf among the metrics drawn")
+    ap.add_argument("--multi", action="store_true", help="ptk_multi_* with replicas on the one GPU")
     args = ap.parse_args()
     global LNINF
     LNINF = args.lninf
+    if args.multi:
+        os.environ["PTK_MULTI_ALLOW_REPLICAS"] = "1"
     global DTYPE
     DTYPE = np.float64 if args.dtype == "float64" else np.float32
     import torch
@@ -181,7 +223,8 @@ def main():
         if args.case >= 0 and case != args.case:
             continue
         try:
-            desc, bad = (one_topological_case if args.topological else one_case)(rng, pt, oracle, torch, case)
+            fn = one_topological_case if args.topological else (one_multi_case if args.multi else one_case)
+            desc, bad = fn(rng, pt, oracle, torch, case)
         except pt.PtkError as err:
             # The one limit left: a point set so degenerate that the BUILD stops (deeper than 8192 levels: thousands of
             # coincident points peeling one level each; the reference's recursive builder overflows its stack on such
