@@ -460,7 +460,7 @@ int ptk_profile_get_sized(const ptk_tree* tree, void* out, uint64_t size, int re
  * cooperative search, [2] = queries that search could not certify (redone by the reference
  * traversal from the root), [3] = queries of the classes dealt across wavefronts. */
 int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
-/* After a k-NN search with 1 < k <= 32 on a 3-D tree (default metric, exact): {queries the general kernel handed to the
+/* After a k-NN search with 1 < k <= 56 on a 3-D tree (default metric, exact): {queries the general kernel handed to the
  * cooperative search because they had entered more than PTK_KNN_CAP far children, queries that search could not certify
  * and the reference search redid, and why: a pool of subtrees and its spill that overflowed, more equal distances
  * than the second sweep can rank, a box distance above the k-th distance on the way to a neighbour, a k-th distance
@@ -469,7 +469,7 @@ int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
 int ptk_debug_knn_coop_counts(const ptk_tree* tree, uint32_t counts[7]);
 /* The far children a query of such a search may enter before a wavefront takes it over, for a batch of nq queries
  * (it follows the batch: a capped launch ends with the lanes that ran to their cap; 0 = this search runs uncapped --
- * e != 1, fewer than 256 queries, k outside 2 .. 32), and the entries of the hand-over list of that batch (a query that
+ * e != 1, fewer than 256 queries, k outside 2 .. 56), and the entries of the hand-over list of that batch (a query that
  * finds it full goes on in its lane).  No device needed; honours PTK_KNN_CAP / PTK_KNN_CAP_MIN_NQ. */
 int ptk_debug_knn_cap(uint64_t nq, uint32_t k, float e, uint32_t* cap, uint64_t* list_entries);
 /* Piles -- subtrees all of whose points are one and the same point (the reference's builder peels one of them off per

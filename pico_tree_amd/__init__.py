@@ -677,7 +677,7 @@ class KdTree:
         return {"phase2": int(c[0]), "cooperative": int(c[1]), "redone": int(c[2]), "dealt": int(c[3])}
 
     def knn_coop_counts(self) -> dict:
-        """After a search with 1 < k <= 32: queries the general kernel handed to the cooperative search, queries that
+        """After a search with 1 < k <= 56: queries the general kernel handed to the cooperative search, queries that
         search sent to the redo list and why (``ptk_debug_knn_coop_counts``)."""
         self._float32_only("knn_coop_counts()")
         c = (c_uint32 * 7)()

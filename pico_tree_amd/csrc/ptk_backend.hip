@@ -1130,8 +1130,16 @@ uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
     cap = std::max(n / 30000.0, (n - 1.2e6) / 20000.0), lo = 12.0, hi = 320.0;
   } else if (k <= 16) {
     cap = n / 16000.0, lo = 16.0, hi = 448.0;
-  } else {
+  } else if (k <= 32) {
     cap = n / 9400.0, lo = 32.0, hi = 512.0;
+  } else if (k <= 56) {
+    // (33 .. 56, lists of 64 slots: the cooperative kernel of that size fits one wavefront per SIMD, so it should see
+    // few queries -- kernel ms, rule / uncapped: knn = 40 at 150 k 2.0 / 5.5, 900 k 4.4 / 4.8, 7.2 M 15.9 / 15.6)
+    cap = n / 3500.0, lo = 64.0, hi = 768.0;
+  } else {
+    // (57 .. 64: the second sweep ranks at most 64 points, k of them are the handed-over entries -- nearly every tie
+    // would be redone by one lane, milliseconds each: these run uncapped)
+    return 0;
   }
   return (uint32_t)std::min(hi, std::max(lo, cap));
 }
@@ -1142,7 +1150,10 @@ size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
          (size_t)knn_coop_blocks(t) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
 }
 
-// k <= 32: the k-list in registers (K = 4 / 8 / 16 / 32 slots compiled).
+// The largest k whose list lives in registers: 32 slots for every metric, 64 for the default one (a list of 40 in LDS
+// took 74 ms on BASELINE config 3 where 32 in registers take 7: insert_sorted through LDS is a loop per lane).
+inline uint32_t knn_reg_max(bool l2) { return l2 ? 64u : 32u; }
+// k <= 64: the k-list in registers (K = 4 / 8 / 16 / 32 / 64 slots compiled).
 template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
                    ptk::Neighbor* d_out, hipStream_t s, Scratch* scratch = nullptr) {
@@ -1180,7 +1191,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
         return fail(PTK_ERR_NOMEM, "scratch block too small");
       scratch->note_meta(meta);
       PTK_HIP(hipMemsetAsync(meta, 0, ptk::kMetaWords * 4, s));
-      const size_t coop_smem = (size_t)ptk::knn_coop_lds_words(kKnnCoopPool) * 4;
+      const size_t coop_smem = (size_t)ptk::knn_coop_lds_words(kKnnCoopPool, k > 32 ? 64u : 32u) * 4;
       const uint2* ranges = static_cast<const uint2*>(t->d_ranges);
       // One capped launch over launch-order rows [lo, lo + n) and the cooperative search of its hand-overs, on `st`
       // (`word`: the counter of its list; `cb` wavefronts from `first_block` of the spill block).
@@ -1207,7 +1218,8 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
         if (k <= 4) PTK_LAUNCH_REG(4);
         else if (k <= 8) PTK_LAUNCH_REG(8);
         else if (k <= 16) PTK_LAUNCH_REG(16);
-        else PTK_LAUNCH_REG(32);
+        else if (k <= 32) PTK_LAUNCH_REG(32);
+        else PTK_LAUNCH_REG(64);
 #undef PTK_LAUNCH_REG
       };
       if (n_front != 0) {
@@ -1237,7 +1249,8 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
       if (k <= 4) PTK_LAUNCH_REDO(4);
       else if (k <= 8) PTK_LAUNCH_REDO(8);
       else if (k <= 16) PTK_LAUNCH_REDO(16);
-      else PTK_LAUNCH_REDO(32);
+      else if (k <= 32) PTK_LAUNCH_REDO(32);
+      else PTK_LAUNCH_REDO(64);
 #undef PTK_LAUNCH_REDO
       PTK_HIP(hipGetLastError());
       timer.stop(0, nq);
@@ -1250,7 +1263,9 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
   if (k <= 4) PTK_LAUNCH_REG(4);
   else if (k <= 8) PTK_LAUNCH_REG(8);
   else if (k <= 16) PTK_LAUNCH_REG(16);
-  else PTK_LAUNCH_REG(32);
+  else if (k <= 32) PTK_LAUNCH_REG(32);
+  else if constexpr (std::is_same<M, ptk::MetricL2>::value && BLOCK == 64) PTK_LAUNCH_REG(64);  // (33 .. 64: knn_reg_max)
+  else return fail(PTK_ERR_INVALID, "k beyond the register lists of this metric");
 #undef PTK_LAUNCH_REG
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
@@ -2285,7 +2300,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
                        (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(t, nq) : 0) +
-                       (k > 1 && k <= 32 && l2 && t->dim <= 3 && knn_cap(e, nq, k) != 0u ? knn_coop_scratch_bytes(t, nq) : 0));
+                       (k > 1 && k <= 64 && l2 && t->dim <= 3 && knn_cap(e, nq, k) != 0u ? knn_coop_scratch_bytes(t, nq) : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
   if (reorder) {  // Morton order along the first three axes, whatever the dimension
@@ -2302,7 +2317,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   }
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
-  } else if (k <= 32 && !short_tree) {
+  } else if (k <= knn_reg_max(l2) && !short_tree) {
     PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_knn_reg<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, &scratch))));
   } else {
     PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
@@ -2433,7 +2448,7 @@ static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint3
   }
   const bool two_phase = k == 1 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
                          ovf_class_of(knn1_depth(t), 16) != kDeepClass;
-  const bool capped = !two_phase && k > 1 && k <= 32 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
+  const bool capped = !two_phase && k > 1 && k <= 64 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
                       knn_cap(e, std::max<uint64_t>((nq + 7) / 8, uint64_t(1) << 18), k) != 0u;
   const std::vector<uint64_t> first = host_pieces(nq, k, two_phase, capped);
   const uint64_t pieces = first.size() - 1;
@@ -3241,7 +3256,7 @@ int ptk_debug_knn_coop_counts(const ptk_tree* t, uint32_t counts[7]) {
 
 int ptk_debug_knn_cap(uint64_t nq, uint32_t k, float e, uint32_t* cap, uint64_t* list_entries) {
   if (cap == nullptr || list_entries == nullptr) return fail(PTK_ERR_INVALID, "null argument");
-  *cap = (k > 1 && k <= 32) ? knn_cap(e, nq, k) : 0u;
+  *cap = (k > 1 && k <= 64) ? knn_cap(e, nq, k) : 0u;
   *list_entries = *cap != 0u ? knn_max_handover(nq) : 0;
   return PTK_OK;
 }

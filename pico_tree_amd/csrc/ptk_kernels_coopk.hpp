@@ -1,4 +1,4 @@
-// ptk_kernels_coopk.hpp -- k > 1 (k <= 32): the long searches of a batch finished by a whole wavefront each.
+// ptk_kernels_coopk.hpp -- k > 1 (k <= 64): the long searches of a batch finished by a whole wavefront each.
 //
 // What this is for (profiles/r05_notes.txt item 2, tools/wave_trace.py).  knn_reg_kernel runs every query to its end
 // in its lane, and a lane takes ~4.4 us per leaf it visits once its wavefront's other lanes have finished (two or
@@ -105,8 +105,11 @@ __device__ __forceinline__ float wave_min_f32(float v) {
 }
 
 // LDS of a wavefront of the cooperative search, in 32-bit words: the pool [6][POOL], the shared bound, the row the merge
-// produced {index, distance}[32], the entries of the second sweep {distance, tag, box distance}[kKnnTieSlots].
-constexpr uint32_t knn_coop_lds_words(uint32_t pool) { return 6u * pool + 1u + 64u + 3u * kKnnTieSlots; }
+// produced {index, distance}[max(K, 32)], the entries of the second sweep {distance, tag, box distance}[kKnnTieSlots].
+constexpr uint32_t knn_coop_row(uint32_t K) { return K > 32u ? K : 32u; }  // entries of the merged row
+constexpr uint32_t knn_coop_lds_words(uint32_t pool, uint32_t K = 32u) {
+  return 6u * pool + 1u + 2u * knn_coop_row(K) + 3u * kKnnTieSlots;
+}
 
 // One sweep of a query's pending subtrees by the 64 lanes of the wavefront (see the head of this file).
 //   COLLECT = false: every lane keeps a k-list (`pol`), the shared bound *gbest follows the smallest k-th distance
@@ -350,8 +353,9 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
   const uint32_t lane = threadIdx.x;
   LdsU32* pool = (LdsU32*)ptk_smem;  // [field][slot]
   LdsU32* gbest = pool + 6 * POOL;   // bits of the smallest k-th distance any lane holds
-  LdsU32* row = gbest + 1;           // the merged row: index [32], distance bits [32]
-  LdsU32* ent = row + 64;            // second sweep: distance bits, tag, box distance bits [kKnnTieSlots] each
+  constexpr uint32_t kRow = knn_coop_row((uint32_t)K);
+  LdsU32* row = gbest + 1;           // the merged row: index [kRow], distance bits [kRow]
+  LdsU32* ent = row + 2u * kRow;     // second sweep: distance bits, tag, box distance bits [kKnnTieSlots] each
   // (queries that found the list full were not listed: they finished in their lanes, Handover::full_keeps)
   const uint32_t n_heavy = ho.full_keeps != 0u && ho.meta[ho.counter] > ho.max_heavy ? ho.max_heavy : ho.meta[ho.counter];
   const float kInf = __uint_as_float(0x7F800000u);
@@ -411,7 +415,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
       g_all = g0 > g_all ? g0 : g_all;
       if (lane == 0) {
         row[r] = (uint32_t)i0;
-        row[32u + r] = __float_as_uint(m);
+        row[kRow + r] = __float_as_uint(m);
       }
       if (mine) {  // the head leaves this lane's list
 #pragma unroll
@@ -505,7 +509,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
       if (__ballot(lane < k) != 0ull && lane < k) {
         Neighbor nb;
         nb.index = (int32_t)row[lane];
-        nb.distance = __uint_as_float(row[32u + lane]);
+        nb.distance = __uint_as_float(row[kRow + lane]);
         out[(uint64_t)qi * k + lane] = nb;
       }
     }

@@ -589,12 +589,13 @@ int emu_knn_capped(void* h, const float* q, uint64_t nq, uint32_t k, const uint3
                    uint32_t max_heavy, ptk_neighbor* out, uint32_t* counts) {
   auto* t = static_cast<Emu*>(h);
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
-  if (t->dim > 3 || t->metric != 0 || k < 1 || k > 32) return -2;
+  if (t->dim > 3 || t->metric != 0 || k < 1 || k > 64) return -2;
   if (2 * t->st.max_depth + 2 > 16 + 2048) return -2;
   if (k <= 4) return emu_knn_capped_k<4>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
   if (k <= 8) return emu_knn_capped_k<8>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
   if (k <= 16) return emu_knn_capped_k<16>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
-  return emu_knn_capped_k<32>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
+  if (k <= 32) return emu_knn_capped_k<32>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
+  return emu_knn_capped_k<64>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
 }
 
 int emu_radius_count(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,

@@ -290,7 +290,7 @@ def test_topological_tree_stream_is_the_reference_stream(tmp_path, metric, dim):
 def test_knn_cap_follows_the_batch(monkeypatch):
     """ptk_debug_knn_cap: the far children a query of a k > 1 search may enter before a wavefront takes it over.  It
     grows with the batch (a capped launch ends with the lanes at their cap, so a small batch wants a low one), between a
-    floor and a top that follow k; approximate searches, tiny batches and k outside 2 .. 32 run uncapped; the list of
+    floor and a top that follow k; approximate searches, tiny batches and k outside 2 .. 56 run uncapped; the list of
     hand-overs always has room for the first 24 576 (or all) queries."""
     lib = pt._load()
 
@@ -302,11 +302,11 @@ def test_knn_cap_follows_the_batch(monkeypatch):
     monkeypatch.delenv("PTK_KNN_CAP", raising=False)
     monkeypatch.delenv("PTK_KNN_CAP_MIN_NQ", raising=False)
     sizes = [256, 1_000, 20_000, 150_000, 600_000, 900_000, 2_400_000, 7_200_863, 50_000_000]
-    for k, floor, top in ((2, 8, 256), (4, 8, 256), (8, 12, 320), (16, 16, 448), (32, 32, 512)):
+    for k, floor, top in ((2, 8, 256), (4, 8, 256), (8, 12, 320), (16, 16, 448), (32, 32, 512), (56, 64, 768)):
         caps = [cap(nq, k)[0] for nq in sizes]
         assert caps == sorted(caps) and caps[0] == floor and caps[-1] == top, (k, caps)
     assert cap(7_200_863, 16)[0] == 448 and cap(900_000, 16)[0] == 56 and cap(900_000, 4)[0] == 24
-    assert cap(255, 16) == (0, 0) and cap(10_000, 16, e=1.5) == (0, 0) and cap(10_000, 1) == (0, 0) and cap(10_000, 33) == (0, 0)
+    assert cap(255, 16) == (0, 0) and cap(10_000, 16, e=1.5) == (0, 0) and cap(10_000, 1) == (0, 0) and cap(10_000, 57) == (0, 0)
     for nq in sizes:
         entries = cap(nq, 16)[1]
         assert min(nq, 24_576) <= entries <= max(nq // 48, 24_576)

@@ -265,7 +265,7 @@ def test_emulated_capped_knn_and_its_cooperative_search_equal_oracle(case):
     ref = oracle.Oracle(pts, leaf, "port")
     perm, _ = emu.morton_permutation(q)
     seen = {}
-    for k in ((2, 7, 16, 20) if name == "uniform" else (3, 16)):  # (K = 4 / 8 / 16 / 32 slots compiled)
+    for k in ((2, 7, 16, 20, 40) if name == "uniform" else ((3, 16, 64) if name == "lidar" else (3, 16))):  # (K = 4 .. 64 slots compiled)
         kk = min(k, len(pts))
         want = ref.search_knn(q, kk)
         for cap, p, small in ((2, None, False), (1, perm, True)):
