@@ -1081,10 +1081,15 @@ int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
   const size_t stack_bytes = (size_t)S * BLOCK * 8;
   const size_t list_bytes = (size_t)k * BLOCK * 8;
-  // The k-list goes to LDS while a block stays under 1/4 of a CU's 160 KiB.
-  const bool list_lds = stack_bytes + list_bytes <= 40 * 1024;
+  // The k-list goes to LDS while a wavefront's block stays under 48 KiB (k <= 80); beyond that the output row itself is
+  // the list.  (Kernel ms on 900 k queries of config 3, list in LDS / in the row: knn = 65 47 / 71, knn = 100 138 / 138,
+  // knn = 200 881 / 409 -- a list that leaves a CU two wavefronts loses to one in HBM.  PTK_KNN_LIST_LDS_KB: the limit,
+  // for experiments.  Both forms are insert_sorted as a loop per lane: k beyond 64 wants a design of its own.)
+  const bool list_lds = stack_bytes + list_bytes <= (size_t)std::min(156, std::max(0, env_int("PTK_KNN_LIST_LDS_KB", 48))) * 1024;
   Timer timer(t, s);
   if (list_lds) {
+    const int lds_rc = allow_lds(ptk::knn_kernel<S, OVF, BLOCK, LEAFB, true, M>, stack_bytes + list_bytes);
+    if (lds_rc != PTK_OK) return lds_rc;
     hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK),
                        stack_bytes + list_bytes, s, t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out);
   } else {
