@@ -1155,9 +1155,9 @@ size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
          (size_t)knn_coop_blocks(t) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
 }
 
-// The largest k whose list lives in registers: 32 slots for every metric, 64 for the default one (a list of 40 in LDS
-// took 74 ms on BASELINE config 3 where 32 in registers take 7: insert_sorted through LDS is a loop per lane).
-inline uint32_t knn_reg_max(bool l2) { return l2 ? 64u : 32u; }
+// The largest k whose list lives in registers (3-D kernels, every metric): 64 slots (a list of 40 in LDS took 74 ms on
+// BASELINE config 3 where 32 in registers take 7: insert_sorted through LDS is a loop per lane).
+inline uint32_t knn_reg_max(bool) { return 64u; }
 // k <= 64: the k-list in registers (K = 4 / 8 / 16 / 32 / 64 slots compiled).
 template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
 int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
@@ -1269,8 +1269,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
   else if (k <= 8) PTK_LAUNCH_REG(8);
   else if (k <= 16) PTK_LAUNCH_REG(16);
   else if (k <= 32) PTK_LAUNCH_REG(32);
-  else if constexpr (std::is_same<M, ptk::MetricL2>::value && BLOCK == 64) PTK_LAUNCH_REG(64);  // (33 .. 64: knn_reg_max)
-  else return fail(PTK_ERR_INVALID, "k beyond the register lists of this metric");
+  else PTK_LAUNCH_REG(64);  // (33 .. 64: knn_reg_max)
 #undef PTK_LAUNCH_REG
   PTK_HIP(hipGetLastError());
   timer.stop(0, nq);
