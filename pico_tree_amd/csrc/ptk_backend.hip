@@ -1700,7 +1700,7 @@ int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
   const size_t base = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
   if (base > t->lds_per_block)
     return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-  if (k <= 32 && !no_register_list) {  // k-list in registers (K = 4 / 8 / 16 / 32 slots compiled)
+  if (k <= 64 && !no_register_list) {  // k-list in registers (K = 4 / 8 / 16 / 32 / 64 slots compiled)
     Timer timer(t, s);
     int rc = PTK_OK;
 #define PTK_LAUNCH_ND_REG(KK)                                                                                       \
@@ -1713,7 +1713,8 @@ int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
     if (k <= 4) PTK_LAUNCH_ND_REG(4);
     else if (k <= 8) PTK_LAUNCH_ND_REG(8);
     else if (k <= 16) PTK_LAUNCH_ND_REG(16);
-    else PTK_LAUNCH_ND_REG(32);
+    else if (k <= 32) PTK_LAUNCH_ND_REG(32);
+    else PTK_LAUNCH_ND_REG(64);
 #undef PTK_LAUNCH_ND_REG
     if (rc != PTK_OK) return rc;
     PTK_HIP(hipGetLastError());
@@ -1824,11 +1825,12 @@ int launch_knn_topo(const ptk_tree* t, const float* d_q, const uint32_t* perm, u
 #define PTK_LAUNCH_TOPO_REG(KK)                                                                                         \
   PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::knn_topo_reg_kernel<KK, 16, OVF, T>), dim3(blocks), dim3(64), smem, s, t->dev, \
                                      d_q, t->dim, perm, nq, k, inv_ratio(e), d_out); })
-  if (k <= 32 && !short_tree) {
+  if (k <= 64 && !short_tree) {
     if (k <= 4) { PTK_LAUNCH_TOPO_REG(4); }
     else if (k <= 8) { PTK_LAUNCH_TOPO_REG(8); }
     else if (k <= 16) { PTK_LAUNCH_TOPO_REG(16); }
-    else { PTK_LAUNCH_TOPO_REG(32); }
+    else if (k <= 32) { PTK_LAUNCH_TOPO_REG(32); }
+    else { PTK_LAUNCH_TOPO_REG(64); }
   } else {
     PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::knn_topo_kernel<16, OVF, T>), dim3(blocks), dim3(64), smem, s, t->dev, d_q,
                                        t->dim, perm, nq, k, inv_ratio(e), d_out); });

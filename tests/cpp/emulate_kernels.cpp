@@ -1252,6 +1252,10 @@ int emu64_knn(void* h, const double* q, uint64_t nq, uint32_t k, double e, int l
     EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
       ptk::knn64_reg_kernel<M, 16, D3>(t->dev, q, perm, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);
     }));
+  } else if (list_in_registers && k > 1 && k <= 32) {
+    EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+      ptk::knn64_reg_kernel<M, 32, D3>(t->dev, q, perm, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);
+    }));
   } else {
     EMU64_WITH_METRIC(for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
       ptk::knn64_kernel<M, D3>(t->dev, q, perm, q0, m, k, 1.0 / e, out, t->stack.data(), t->slots);

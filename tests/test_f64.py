@@ -98,6 +98,10 @@ def test_emulated_double_kernels_reproduce_the_goldens(name):
     # the k-list kept in the output row (k > 16 on the device) instead of in registers
     assert same(t.search_knn(g["queries"], int(g["k"]), list_in_registers=False), g["knn_index"], g["knn_distance"])
     assert same(t.search_knn(g["queries"], 3), g["knn_index"][:, :3], g["knn_distance"][:, :3])  # K = 4 registers
+    # K = 32 registers (17 <= k <= 32), against the oracle's double build
+    ref = oracle.Oracle(g["points"], leaf, "port", dtype=np.float64)
+    want = ref.search_knn(g["queries"], 23)
+    assert same(t.search_knn(g["queries"], 23), want["index"], want["distance"])
 
 
 def rows_equal(a, b):
