@@ -250,8 +250,8 @@ int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, u
   const size_t smem = ptk::lds64_bytes(d3 ? 0 : 2, t->dim);
   if (smem > 160 * 1024) return fail(PTK_ERR_UNSUPPORTED, "dim %u needs %zu bytes of LDS per wavefront (> 160 KiB)", t->dim, smem);
   int rc = PTK_OK;
-  // k-list in registers for 1 < k <= 32 (it assumes every slot gets filled: not for k > n_points).
-  const int reg = (k > 1 && k <= 32 && !short_tree) ? (k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 16 ? 16 : 32))) : 0;
+  // k-list in registers for 1 < k <= 64 (it assumes every slot gets filled: not for k > n_points).
+  const int reg = (k > 1 && k <= 64 && !short_tree) ? (k <= 4 ? 4 : (k <= 8 ? 8 : (k <= 16 ? 16 : (k <= 32 ? 32 : 64)))) : 0;
 #define PTK_LAUNCH64(KERNEL)                                                                                          \
   do {                                                                                                                \
     rc = allow_lds(KERNEL, smem);                                                                                     \
@@ -267,12 +267,14 @@ int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, u
     else if (reg == 8) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 8, true>));
     else if (reg == 16) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 16, true>));
     else if (reg == 32) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 32, true>));
+    else if (reg == 64) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 64, true>));
     else PTK_LAUNCH64((ptk::knn64_kernel<M, true>));
   } else if constexpr (!M::kTopo) {  // (the topological metrics: dim 1 or 3)
     if (reg == 4) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 4, false>));
     else if (reg == 8) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 8, false>));
     else if (reg == 16) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 16, false>));
     else if (reg == 32) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 32, false>));
+    else if (reg == 64) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 64, false>));
     else PTK_LAUNCH64((ptk::knn64_kernel<M, false>));
   }
 #undef PTK_LAUNCH64

@@ -15,7 +15,7 @@
 //                     slot), older ones spilled to HBM scratch ([block][slot][lane], 16-byte records:
 //                     a wave's spill / refill is one coalesced 1 KiB access); 2 * depth + 2 slots
 //                     always suffice.
-//   k-list            registers for k <= 32 (Knn64RegPolicy, as KnnRegPolicy of ptk_kernels.hpp),
+//   k-list            registers for k <= 64 (Knn64RegPolicy, as KnnRegPolicy of ptk_kernels.hpp),
 //                     else the caller's output row itself (neighbor<int, double>, 16 bytes)
 // Layouts (ptk_backend_f64.hpp, encode64):
 //   nodes : 32 B per branch {left_max, right_min, left_ref, right_ref, axis, 0}
@@ -263,7 +263,7 @@ struct Knn64Policy {  // :83-123 / :198-247
   }
 };
 
-// Sorted k-list in registers for k <= K <= 32: K branch-free compare / select steps per accepted
+// Sorted k-list in registers for k <= K <= 64: K branch-free compare / select steps per accepted
 // candidate, insert_sorted (:24-38) exactly -- strict `<` keeps a new entry behind equal distances;
 // slots start at DBL_MAX (the sentinel of :102).  See KnnRegPolicy in ptk_kernels.hpp.
 template <int K>
@@ -664,7 +664,7 @@ __global__ __launch_bounds__(64) void knn64_kernel(
   pol.end_query();
 }
 
-// 1 < k <= K <= 32, k <= n_points (enforced by the caller, kd_tree.hpp:193: every slot below k ends up real).
+// 1 < k <= K <= 64, k <= n_points (enforced by the caller, kd_tree.hpp:193: every slot below k ends up real).
 template <class M, int K, bool D3>
 __global__ __launch_bounds__(64) void knn64_reg_kernel(
     DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
