@@ -274,8 +274,7 @@ int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, u
     else if (reg == 8) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 8, false>));
     else if (reg == 16) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 16, false>));
     else if (reg == 32) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 32, false>));
-    else if (reg == 64) PTK_LAUNCH64((ptk::knn64_reg_kernel<M, 64, false>));
-    else PTK_LAUNCH64((ptk::knn64_kernel<M, false>));
+    else PTK_LAUNCH64((ptk::knn64_kernel<M, false>));  // (64 slots: dim <= 3 only -- 252 VGPRs with q / off in registers)
   }
 #undef PTK_LAUNCH64
   PTK_HIP(hipGetLastError());
