@@ -490,7 +490,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
           rank += have && first_j ? 1u : 0u;
         }
         const bool chosen = have && rank < k;
-        box = __ballot(chosen && !(g_i <= dk)) != 0ull;
+        box = __ballot(chosen && !(g_i <= d_i)) != 0ull;
         // (every index is fetched before any row entry is written: the handed-over ones come from the row itself)
         int32_t idx_i = 0;
         if (chosen) {

@@ -286,6 +286,37 @@ def test_emulated_capped_knn_and_its_cooperative_search_equal_oracle(case):
         assert seen[(16, 2)][1] > 0 and emu.last_tie_sweeps > 0
 
 
+def test_emulated_cooperative_knn_on_a_line_of_points_with_drifting_box_distances():
+    """The case the fuzz soak of r05 failed on (profiles/r05_notes.txt item 24): 60 000 points on a line in the plane,
+    leaves of one point, queries off the line -- thousands of points at nearly the same distance, a tree a hundred levels
+    deep whose incrementally updated box distances drift above the distances of the points inside.  The reference
+    leaves such a point out; the second sweep of the cooperative search used to let it in (its box distances were
+    below the k-th distance, but above its OWN): now such a query goes to the reference search.  Every list size."""
+    # the draws of case 760, seed 802 of tools/fuzz_parity.py (one_case), in their order
+    rng = np.random.default_rng([802, 760])
+    dim = int(rng.choice([1, 2, 3, 3, 3, 4, 5, 7]))
+    n = int(rng.choice([1, 2, 9, 100, 3000, 20000, 60000]))
+    nq = int(rng.choice([1, 63, 64, 65, 1000, 5000]))
+    leaf = int(rng.choice([1, 2, 5, 10, 16, 24]))
+    kind = str(rng.choice(["uniform", "clustered", "lattice", "duplicates", "line", "plane"]))
+    scale = float(rng.choice([1.0, 1.0, 1e-6, 1e6, 37.5]))
+    shift = float(rng.choice([0.0, 0.0, -0.5, 100.0]))
+    rng.choice(["L2Squared", "L2Squared", "L1", "LPInf"])
+    assert (dim, n, nq, leaf, kind, scale, shift) == (2, 60000, 64, 1, "line", 37.5, 0.0)
+    pts = (((rng.random((n, 1)) * rng.random((1, dim)) + 0.25) + shift) * scale).astype(np.float32)
+    assert rng.random() < 0.5
+    q = (((rng.random((nq, 1)) * rng.random((1, dim)) + 0.25) + shift) * scale).astype(np.float32)[[15, 18, 26]]
+    emu = EmulatedTree(pts, 1)
+    ref = oracle.Oracle(pts, 1, "port")
+    sweeps = 0
+    for k in (16, 33):  # (rows 15 and 18 were wrong at k = 16, row 26 at k = 32 / 33 before the fix)
+        got, heavy, redo = emu.search_knn_capped(q, k, 8)
+        assert got.tobytes() == ref.search_knn(q, k).tobytes(), k
+        sweeps += emu.last_tie_sweeps
+        assert heavy > 0
+    assert sweeps > 0  # equal distances at the edge of the list: second sweeps did run
+
+
 def test_emulated_direct_cooperative_search_parks_subtrees_in_hbm():
     """Variant 9 = the small-batch form: the ranked classes go straight from phase 1 to the cooperative search.  Its
     emulated launch has a pool of 12 subtrees per group, so the queries of the scanner's blind disc (hundreds of
