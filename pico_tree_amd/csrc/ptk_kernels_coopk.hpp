@@ -490,6 +490,10 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
           rank += have && first_j ? 1u : 0u;
         }
         const bool chosen = have && rank < k;
+        // Certificate of the second sweep: no box distance on the way to a chosen point above that point's OWN distance
+        // (the reference enters every far child on the way as long as its k-th distance is at least the point's).  The
+        // runner-up form of the first sweep -- box distances up to D -- is not enough here: on a line of points with
+        // drifting box distances the reference left out a point it would have admitted (profiles/r05_notes.txt item 24).
         box = __ballot(chosen && !(g_i <= d_i)) != 0ull;
         // (every index is fetched before any row entry is written: the handed-over ones come from the row itself)
         int32_t idx_i = 0;
