@@ -345,7 +345,7 @@ template <int K, int POOL>
 __global__ __launch_bounds__(64) void knn_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float* __restrict__ queries, uint32_t dim, uint32_t k,
     Neighbor* __restrict__ out, Handover ho, uint32_t* __restrict__ redo_list, uint32_t redo_word,
-    Task* __restrict__ spill, uint32_t spill_cap) {
+    Task* __restrict__ spill, uint32_t spill_cap, uint32_t own_distance = 0u) {
   static_assert(POOL >= (int)kMaxTasks, "the pool must hold what a query starts with");
   PTK_TRACE_BEGIN_SEL(5);
   typedef PTK_LDS uint32_t LdsU32;
@@ -389,6 +389,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
     // equal heads with one index are one point), k + 1 rounds: the last one looks at the runner-up.
     bool tie = false;
     float prev = -1.0f, g_all = 0.0f, runner_up = kInf;
+    bool own_fail = false;
     for (uint32_t r = 0; r <= k; ++r) {  // (uniform)
       float hd = kInf, hg = 0.0f;
       int32_t hi = 0;
@@ -413,6 +414,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
       const float g0 = __shfl(hg, first);
       if (__ballot(mine && hi != i0) != 0ull) tie = true;
       g_all = g0 > g_all ? g0 : g_all;
+      own_fail = own_fail || g0 > m;  // (a box distance on the way to this point above its own distance)
       if (lane == 0) {
         row[r] = (uint32_t)i0;
         row[kRow + r] = __float_as_uint(m);
@@ -449,7 +451,9 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
       d_next = runner_up < d_next ? runner_up : d_next;
       d_next = d_next < dk ? dk : d_next;
     }
-    bool box = !(g_all <= d_next);
+    // own_distance (trees 64 levels deep or more: lines and lattices, where the incrementally updated box distances
+    // drift furthest): the first sweep, too, asks what the second one asks -- profiles/r05_notes.txt item 24.
+    bool box = own_distance != 0u ? own_fail : !(g_all <= d_next);
     bool crowded = false;
 
     if (tie && !failed && !range) {
