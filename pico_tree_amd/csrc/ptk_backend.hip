@@ -1218,8 +1218,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
     hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M, true>), dim3(nb), dim3(BLOCK), smem, st,        \
                        t->dev, d_q, t->dim, perm ? perm + lo : nullptr, n, k, inv_ratio(e), d_out, cap_n, ho);          \
     hipLaunchKernelGGL((ptk::knn_coop_kernel<KK, kKnnCoopPool>), dim3(cb), dim3(64), coop_smem, st, t->dev, ranges,      \
-                       d_q, t->dim, k, d_out, ho, redo_list, ptk::kMetaRedo, sp, kKnnCoopSpill,                         \
-                       t->max_depth >= 64u ? 1u : 0u);                                                                  \
+                       d_q, t->dim, k, d_out, ho, redo_list, ptk::kMetaRedo, sp, kKnnCoopSpill);                        \
   } while (0)
         if (k <= 4) PTK_LAUNCH_REG(4);
         else if (k <= 8) PTK_LAUNCH_REG(8);

@@ -40,8 +40,25 @@
 // equal distances (in one round, in consecutive rounds, or turned away at the edge of a lane's list) gets a SECOND
 // sweep of its subtrees with the bound fixed at D: every point at a distance <= D is collected (there are k of them
 // plus the ties), ranked by (distance, handed-over entries in their order, then depth-first order), and the first k
-// are the row.  By the argument above -- read with "nearer, or as far and earlier" for "nearer" -- that is the
-// reference's row.
+// are the row.  By the argument above -- read with "nearer, or as far and earlier" for "nearer", and with D' = the
+// distance of the (k + 1)-th entry of that ranking (or D, the bound everything was collected under, when the ranking has
+// only k entries) -- that is the reference's row: before the reference has reached a chosen point p its list holds k
+// OTHER points or fewer, its bound is therefore at least D', so (b) `gmax(p) <= D'` makes it enter every far child on
+// the way to p; it then accepts p (fewer than k points are ahead of p in the ranking, so its k-th entry then is
+// strictly farther) and nothing displaces p afterwards.
+//
+// What (b) must NOT be compared with (the parity failure of profiles/r05_notes.txt item 24, closed in
+// profiles/r06_notes.txt item 1): the value `dk` of the merge's k-th ROUND.  A round takes the smallest head of all
+// lanes and pops every lane whose head equals it -- several different points of one distance count as one round -- so
+// with ties dk lies ABOVE the true k-th distance (60 000 points on a line, knn = 33: 55 points within dk, 43 ulps above
+// the 33rd distance T).  dk is a sound bound to collect the second sweep's entries with, and nothing else.  The box
+// distances themselves never differ between the two searches: a node's box distance is a function of its root path
+// alone (`nbd - old_offset + new_offset` with the offsets the path set, kd_tree_search.hpp:91-99), and Task carries
+// {nbd, off[3]} down every path exactly as traverse<> does (tools/trace_box_distance.py replays the reference in numpy
+// and prints both per far child of a point's root path: equal on every step; the reference turns away from the leaf
+// of point 3505 because that leaf's box distance has drifted one ulp above T, which `gmax(p) <= D' = T` detects --
+// the query is then searched by knn_redo_kernel).  The first sweep's certificate never had the flaw: without ties
+// every round pops exactly one point, so its D and D' are the true k-th and (k + 1)-th distances.
 //
 // When (b) cannot be shown, or a bound is in the denormal or overflow range, or the pool and its HBM spill (or the
 // 64 slots of the second sweep: points on a grid) overflowed, the query goes to knn_redo_kernel: the reference search
@@ -345,7 +362,7 @@ template <int K, int POOL>
 __global__ __launch_bounds__(64) void knn_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float* __restrict__ queries, uint32_t dim, uint32_t k,
     Neighbor* __restrict__ out, Handover ho, uint32_t* __restrict__ redo_list, uint32_t redo_word,
-    Task* __restrict__ spill, uint32_t spill_cap, uint32_t own_distance = 0u) {
+    Task* __restrict__ spill, uint32_t spill_cap) {
   static_assert(POOL >= (int)kMaxTasks, "the pool must hold what a query starts with");
   PTK_TRACE_BEGIN_SEL(5);
   typedef PTK_LDS uint32_t LdsU32;
@@ -389,7 +406,6 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
     // equal heads with one index are one point), k + 1 rounds: the last one looks at the runner-up.
     bool tie = false;
     float prev = -1.0f, g_all = 0.0f, runner_up = kInf;
-    bool own_fail = false;
     for (uint32_t r = 0; r <= k; ++r) {  // (uniform)
       float hd = kInf, hg = 0.0f;
       int32_t hi = 0;
@@ -414,7 +430,6 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
       const float g0 = __shfl(hg, first);
       if (__ballot(mine && hi != i0) != 0ull) tie = true;
       g_all = g0 > g_all ? g0 : g_all;
-      own_fail = own_fail || g0 > m;  // (a box distance on the way to this point above its own distance)
       if (lane == 0) {
         row[r] = (uint32_t)i0;
         row[kRow + r] = __float_as_uint(m);
@@ -451,9 +466,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
       d_next = runner_up < d_next ? runner_up : d_next;
       d_next = d_next < dk ? dk : d_next;
     }
-    // own_distance (trees 64 levels deep or more: lines and lattices, where the incrementally updated box distances
-    // drift furthest): the first sweep, too, asks what the second one asks -- profiles/r05_notes.txt item 24.
-    bool box = own_distance != 0u ? own_fail : !(g_all <= d_next);
+    bool box = !(g_all <= d_next);
     bool crowded = false;
 
     if (tie && !failed && !range) {
@@ -494,11 +507,17 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
           rank += have && first_j ? 1u : 0u;
         }
         const bool chosen = have && rank < k;
-        // Certificate of the second sweep: no box distance on the way to a chosen point above that point's OWN distance
-        // (the reference enters every far child on the way as long as its k-th distance is at least the point's).  The
-        // runner-up form of the first sweep -- box distances up to D -- is not enough here: on a line of points with
-        // drifting box distances the reference left out a point it would have admitted (profiles/r05_notes.txt item 24).
-        box = __ballot(chosen && !(g_i <= d_i)) != 0ull;
+        // Certificate of the second sweep -- (b) again, with the runner-up taken from the ranking: D2 = the distance
+        // of the first entry NOT chosen (rank k), or dk when every entry is chosen (whatever was not collected lies
+        // beyond dk).  Before the reference has reached a chosen point p its list holds k other points or fewer, so
+        // its bound is at least the distance of the (k + 1)-th entry of the ranking: D2.  `dk` itself is NOT that
+        // bound: it is the value of the merge's k-th ROUND, and a round that pops several different points of one
+        // distance counts them once -- with ties dk lies above the true k-th distance (it is a sound bound to COLLECT
+        // with, no more).  Comparing box distances with dk is the parity failure of profiles/r05_notes.txt item 24 (a
+        // line of points: the reference turns away from a leaf whose box distance has drifted one ulp above its k-th
+        // distance T; dk was 43 ulps above T); traced in profiles/r06_notes.txt item 1, tools/trace_box_distance.py.
+        const float d2 = wave_min_f32(have && !chosen ? d_i : dk);
+        box = __ballot(chosen && !(g_i <= d2)) != 0ull;
         // (every index is fetched before any row entry is written: the handed-over ones come from the row itself)
         int32_t idx_i = 0;
         if (chosen) {

@@ -423,9 +423,8 @@ int emu_knn_capped_k(Emu* t, const float* q, uint64_t nq, uint32_t k, const uint
   std::vector<ptk::Task> spill((size_t)3 * spill_cap);
   const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
   for_each_wave(3, [&] {
-    const uint32_t own = t->st.max_depth >= 64u ? 1u : 0u;  // (as launch_knn_reg)
-    if (pool_small) ptk::knn_coop_kernel<K, 64>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap, own);
-    else ptk::knn_coop_kernel<K, 128>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap, own);
+    if (pool_small) ptk::knn_coop_kernel<K, 64>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
+    else ptk::knn_coop_kernel<K, 128>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
   });
   for_each_lane(128, [&] { ptk::knn_redo_kernel<K, 16, 2048, 4>(t->dev, q, t->dim, k, 1.0f, o, meta.data(), ptk::kMetaRedo, redo.data()); }, 64);
   counts[0] = meta[ptk::kMetaHeavy];

@@ -824,6 +824,69 @@ def test_k_nearest_cap_follows_the_batch_and_large_batches_run_as_two_launches(g
         assert tree.knn_coop_counts()["cooperative"] > 0
 
 
+def _line_family_case(rng, kind, jitter):
+    """One cloud of tools/fuzz_lines.py: points on a line (or a coarse lattice) in 2-D / 3-D, tiny leaves, queries off
+    the line or next to tree points -- thousands of points nearly equally far, box distances that drift by rounding."""
+    dim = int(rng.choice([2, 3]))
+    n = int(rng.choice([3000, 20000, 60000]))
+    nq = int(rng.choice([64, 300]))
+    leaf = int(rng.choice([1, 2, 5]))
+    scale = float(rng.choice([1.0, 37.5, 1e3]))
+    if kind == "line":
+        pts = ((rng.random((n, 1)) * rng.random((1, dim)) + 0.25) * scale).astype(np.float32)
+    else:  # lattice: equal distances by the hundred
+        pts = ((np.round(rng.random((n, dim)) * 24) / 24 + 0.25) * scale).astype(np.float32)
+    if jitter:  # (no two distances equal: the long searches end in the FIRST sweep's certificate)
+        pts = (pts + rng.normal(0, jitter, pts.shape) * scale).astype(np.float32)
+    if rng.random() < 0.5:
+        q = ((rng.random((nq, 1)) * rng.random((1, dim)) + 0.25) * scale).astype(np.float32)
+    else:
+        q = (pts[rng.integers(0, n, nq)] + rng.normal(0, 1e-3, (nq, dim)) * scale).astype(np.float32)
+    ks = sorted({int(rng.choice([2, 5, 16])), int(rng.choice([24, 32, 33, 48, 56]))})
+    return pts, q, leaf, ks
+
+
+@pytest.mark.parametrize("kind,jitter", [("line", 0.0), ("line", 1e-5), ("lattice", 0.0), ("lattice", 1e-5)])
+def test_capped_k_nearest_on_lines_and_lattices_equals_the_compiled_reference(gpu, monkeypatch, kind, jitter):
+    """The adversarial family of the cooperative k > 1 search (ptk_kernels_coopk.hpp; profiles/r05_notes.txt item 24,
+    profiles/r06_notes.txt item 1): lines and lattices, leaves of 1 / 2 / 5 points, k = 2 .. 56, with and without a
+    jitter that removes the equal distances, THE CAP ON FOR EVERY BATCH (PTK_KNN_CAP_MIN_NQ=1) and low, so nearly
+    every query is handed over, merged, second-swept or redone.  Byte-equal to the compiled reference
+    (oracle/_ref; the restatement where that is absent).  The first case of the line family is the cloud the
+    fuzz soak of r05 failed on (seed 802, case 760: 60 000 points, knn = 16 / 32 / 33)."""
+    monkeypatch.setenv("PTK_KNN_CAP_MIN_NQ", "1")
+    how = "reference" if oracle.have_reference() else "port"
+    handed = swept = redone = 0
+    cases = []
+    if kind == "line" and jitter == 0.0:
+        rng = np.random.default_rng([802, 760])
+        for _ in range(8):
+            rng.choice([1, 2])  # (the draws of tools/fuzz_parity.py before the cloud: dim .. metric)
+        pts = ((rng.random((60000, 1)) * rng.random((1, 2)) + 0.25) * 37.5).astype(np.float32)
+        rng.random()
+        q = ((rng.random((64, 1)) * rng.random((1, 2)) + 0.25) * 37.5).astype(np.float32)
+        cases.append((pts, q, 1, [16, 32, 33]))
+    for case in range(10):
+        cases.append(_line_family_case(np.random.default_rng([606, case, int(jitter * 1e7), kind == "line"]), kind, jitter))
+    for pts, q, leaf, ks in cases:
+        tree = pt.KdTree(pts, pt.Metric.L2Squared, leaf, device=gpu)
+        ref = oracle.Oracle(pts, leaf, how)
+        for k in ks:
+            for cap in ("4", "32"):
+                monkeypatch.setenv("PTK_KNN_CAP", cap)
+                got = tree.search_knn(q, k)
+                assert got.tobytes() == ref.search_knn(q, k).tobytes(), (kind, jitter, len(pts), leaf, k, cap)
+                c = tree.knn_coop_counts()
+                handed += c["cooperative"]
+                swept += c["tie_sweeps"]
+                redone += c["redone"]
+        tree.close()
+        ref.close()
+    assert handed > 500, handed            # the cap did hand queries over
+    if jitter == 0.0:
+        assert swept > 0                   # equal distances: second sweeps ran
+
+
 @pytest.mark.parametrize("cloud", ["lidar", "uniform"])
 def test_batches_that_arrive_coherent_are_not_sorted_again(gpu, cloud):
     """The reference walks the rows in the caller's order (_pyco_tree/kd_tree.hpp:128-134); the k = 1 search samples
