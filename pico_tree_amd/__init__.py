@@ -273,13 +273,15 @@ class _PinnedPool:
         evict = []
         with self._lock:
             # the smallest idle block that holds the request, if it is not more than twice as large
-            fits = sorted(c for c, stock in self._free.items() if stock and capacity <= c <= 2 * capacity)
+            # (snapshots of the dict: a block's __del__ may re-enter _give() on this thread -- garbage collection inside
+            # the loop -- and add a capacity key: 'dictionary changed size during iteration')
+            fits = sorted(c for c, stock in list(self._free.items()) if stock and capacity <= c <= 2 * capacity)
             if fits:
                 capacity = fits[0]
                 ptr = self._free[capacity].pop()
             else:
                 if self._held + capacity > self._budget():  # idle blocks of other sizes make room first
-                    for c in sorted(self._free, reverse=True):
+                    for c in sorted(list(self._free), reverse=True):
                         while self._free[c] and self._held + capacity > self._budget():
                             evict.append(self._free[c].pop())
                             self._held -= c
@@ -313,7 +315,7 @@ class _PinnedPool:
         """Frees the blocks that are not in use."""
         with self._lock:
             free, self._free = self._free, {}
-            for capacity, stock in free.items():
+            for capacity, stock in list(free.items()):
                 self._held -= capacity * len(stock)
         lib = _load()
         for stock in free.values():
@@ -322,6 +324,26 @@ class _PinnedPool:
 
 
 _pinned_pool = _PinnedPool()
+
+
+def set_test_knobs(**knobs) -> None:
+    """Test hooks of libptk.so: ``set_test_knobs(knn_cap=4, knn_cap_min_nq=1)`` writes ``name=value`` pairs into the
+    environment variable ``PTK_TEST_KNOBS`` (the library reads it on every call); ``name=None`` removes one,
+    ``set_test_knobs()`` with no arguments removes all.  The hooks force a path a test wants to see taken (a cap on every
+    batch, one of the two sorts, the hand-over list of a small batch ...); DESIGN.md section 11 lists them."""
+    if not knobs:
+        os.environ.pop("PTK_TEST_KNOBS", None)
+        return
+    have = dict(item.split("=", 1) for item in os.environ.get("PTK_TEST_KNOBS", "").split(",") if "=" in item)
+    for name, value in knobs.items():
+        if value is None:
+            have.pop(name, None)
+        else:
+            have[name] = str(int(value))
+    if have:
+        os.environ["PTK_TEST_KNOBS"] = ",".join(f"{k}={v}" for k, v in have.items())
+    else:
+        os.environ.pop("PTK_TEST_KNOBS", None)
 
 
 def trim_pinned_pool() -> None:

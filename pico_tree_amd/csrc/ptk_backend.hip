@@ -6,255 +6,16 @@
 // path in this file: without a usable device every search entry point fails with
 // PTK_ERR_DEVICE.
 
-#include <hip/hip_runtime.h>
-
-#include <algorithm>
-#include <atomic>
-#include <chrono>
-#include <cmath>
-#include <cstdarg>
-#include <cstddef>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <limits>
-#include <memory>
-#include <mutex>
-#include <new>
-#include <string>
-#include <random>
-#include <sstream>
-#include <vector>
-
-#include <rocprim/device/device_radix_sort.hpp>
-#include <rocprim/device/device_scan.hpp>
-
-#include "ptk.h"
-#include "ptk_hostio.hpp"
-#include "ptk_encode.hpp"
-#include "ptk_kernels.hpp"
+#include "ptk_families.hpp"
 #include "ptk_kernels_lists.hpp"
-#include "ptk_kernels_coopk.hpp"
 #include "ptk_piles.hpp"
-// Geometry of the launches (measured optima, profiles/r02_notes.txt item 23, r03_notes.txt item 13):
-constexpr int kP2Ring = 12;   // LDS ring of the capped phase 2 (records per lane; 8 / 10 / 16: 1.335 / 1.329 / 1.308 vs 1.224 ms)
-#ifndef PTK_GEN_RING
-#define PTK_GEN_RING 16
-#endif
-constexpr int kGenRing = PTK_GEN_RING;  // LDS ring of the general searches (k > 1, radius)
-constexpr int kGenLeafB = 5;  // points per leaf round of the general searches (4 / 5 / 6: knn = 16 4.85 / 4.71 / 4.68 ms, radius capture 7.21 / 7.16 / 7.69)
 #include "ptk_build.hpp"
 #include "ptk_sort.hpp"
-#include "ptk_kernels_nd.hpp"
-#include "ptk_kernels_topo.hpp"
 #include "ptk_forest.hpp"
 
-// Host-side builder: the product's own header-only flat-tree builder.
-#include "pico_tree/internal/flat_tree.hpp"
-#include "pico_tree/internal/stream.hpp"
-#include "pico_tree/map.hpp"
-
-static_assert(sizeof(ptk_neighbor) == 8 && sizeof(ptk::Neighbor) == 8, "neighbor layout");
-static_assert(sizeof(ptk_node) == 16, "node layout");
-static_assert(
-    sizeof(pico_tree::internal::flat_node<int, float>) == sizeof(ptk_node), "flat node layout");
-
 namespace {
 
-thread_local std::string g_error = "";
-
-int fail(int status, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_error = buf;
-  return status;
-}
-
-#define PTK_HIP(expr)                                                              \
-  do {                                                                             \
-    hipError_t e_ = (expr);                                                        \
-    if (e_ != hipSuccess) {                                                        \
-      return fail(PTK_ERR_DEVICE, "%s failed: %s", #expr, hipGetErrorString(e_));  \
-    }                                                                              \
-  } while (0)
-
-constexpr int kDeviceNone = -2;  // handle without a device replica (host tools, CPU-only tests)
-
-struct PendingEvent {
-  hipEvent_t a, b;
-  int kind;  // 0 search, 1 reorder, 2 other, 3 search (continuation of the same launch)
-  uint64_t queries;
-  bool keep_b;  // `b` is also the `a` of the next section (Timer::next), which recycles it
-};
-
-struct Profile {
-  std::mutex mutex;
-  std::atomic<bool> enabled{false};
-  ptk_profile acc{};
-  std::vector<PendingEvent> pending;  // recorded, not yet read back
-  std::vector<hipEvent_t> idle;       // events ready for reuse (hipEventCreate is slow)
-};
-
-// Device scratch of a handle: ONE grow-only HBM block, bump-allocated per search call.
-// A batch of BASELINE config 2 needs ~0.8 GB of transient arrays (packed queries, sort
-// double buffers, continuation records); asking the runtime for them on every call left
-// the GPU idle for ~0.6 ms per step (profiles/r01c_two_phase_timeline.txt), so they are
-// kept.  Calls on one handle enqueue under `mutex`; the block is reused in stream order,
-// and a call that arrives on a DIFFERENT stream first waits for everything the last stream
-// holds: the event for that is recorded on the last stream when the switch happens, not at
-// the end of every call (an event between two calls costs the GPU ~4 us of a 0.3 ms
-// search).  A stream searches were issued on has to be synchronised before it is destroyed.
-struct Workspace {
-  std::mutex mutex;
-  char* base = nullptr;
-  size_t capacity = 0;
-  size_t used = 0;
-  hipStream_t last_stream = nullptr;
-  hipEvent_t done = nullptr;
-  bool has_work = false;
-  const uint32_t* last_meta = nullptr;  // Cont::meta of the last two-phase k = 1 search (ptk_debug_knn1_counts)
-  // Second stream of a small k = 1 batch: the cooperative search of the ranked classes runs beside phase 2
-  // (launch_knn1_two_phase); forked and joined with events, so the caller's stream still orders everything.
-  hipStream_t side = nullptr;
-  hipEvent_t fork = nullptr, join = nullptr;
-  // The coherence sample of a batch (ptk::coherence_sample_kernel): its state and verdict stay on the device.
-  uint32_t* d_sample = nullptr;             // device: {windows counted << 16 | windows failed, verdict}, zero between batches
-  const uint32_t* last_verdict = nullptr;   // the verdict word of the last batch on this block, if it was sampled
-  int last_order = 0;  // the last batch on this block: 0 = taken as it came, 1 = sorted on the device (2 = found coherent
-                       // and left alone is only known on the device: last_verdict, ptk_debug_batch_order)
-
-  // Rows captured by the last radius count pass (ptk::RadiusCapture): a block of its own, because
-  // it must survive until the fill pass of the same batch while other searches reuse `base`.
-  // The key is what the fill pass must repeat to be served from it.
-  char* cap_base = nullptr;
-  size_t cap_capacity = 0;
-  bool cap_valid = false;
-  bool cap_lists = false;  // the capture holds leaf lists (ptk_kernels_lists.hpp), not a log of hits
-  ptk::RadiusCapture cap{};
-  const float* cap_q = nullptr;
-  uint64_t cap_nq = 0;
-  float cap_radius = 0.0f, cap_e = 0.0f;
-  int cap_metric = 0;
-  hipStream_t cap_stream = nullptr;
-};
-
-// Staging of the host-buffer entry points (ptk_search_knn with host pointers, see ptk_hostio.hpp): device blocks
-// for a whole batch, rings of pinned host pieces, streams, events and the copy threads, kept with the handle so that
-// a call costs copies and searches, not allocations (hipFree synchronises the device; pinning memory takes
-// milliseconds).  Calls that use it are serialised by `mutex`.
-struct HostIo {
-  static constexpr int kRing = 3;  // pinned pieces per direction
-  std::mutex mutex;
-  hipStream_t up = nullptr, down = nullptr;
-  hipStream_t search[2] = {nullptr, nullptr};
-  hipEvent_t up_done[kRing] = {}, down_done[kRing] = {};
-  std::vector<hipEvent_t> searched;  // one per piece of the batch in flight
-  char* d_in = nullptr;
-  char* d_out = nullptr;
-  size_t in_capacity = 0, out_capacity = 0;
-  char* h_in[kRing] = {};
-  char* h_out[kRing] = {};
-  size_t h_in_capacity = 0, h_out_capacity = 0;  // bytes per ring slot
-  std::unique_ptr<CopyPool> pool;
-};
-
-}  // namespace
-
-struct ptk_tree {
-  // host copy of the flat tree (DFS stream as handed in / built)
-  uint32_t dim = 0;
-  uint64_t n_points = 0;
-  std::vector<ptk_node> nodes;
-  std::vector<int32_t> indices;
-  std::vector<float> root_min, root_max;
-  std::vector<float> outer;  // per node {left_min, right_max} (topological metrics); may be empty
-  // The flat-tree view the host loop searches (ptk_host_loop.hpp), made on its first call and kept: the node and
-  // index arrays are copied ONCE per handle, not once per ptk_host_search_* call.  Dropped when `outer` changes.
-  mutable std::shared_ptr<const void> host_flat;
-  mutable std::mutex host_flat_mutex;
-  double axis_splits[3] = {0, 0, 0};  // mean number of splits per axis on a root-to-leaf path (point-weighted)
-  bool builder_made = false;  // nodes / indices come from the library's own builder: n_leaves, max_leaf_count, max_depth and
-                              // axis_splits are set and the stream needs no validation
-  uint32_t max_depth = 0;
-  uint64_t n_leaves = 0;
-  uint32_t max_leaf_count = 0;
-  double create_ms[3] = {0, 0, 0};  // host build | re-encoding + checks | upload + point gather (ptk_debug_create_phases)
-
-  // device replica
-  int device = kDeviceNone;
-  ptk::DevTree dev{};
-  void* d_nodes = nullptr;
-  void* d_pts = nullptr;
-  void* d_ranges = nullptr; // dim <= 3: subtree ranges for the box search
-  void* d_axes = nullptr;   // dim > 3 only
-  void* d_index = nullptr;  // dim > 3 only
-  void* d_outer = nullptr;  // topological metrics only: float2 per branch
-  // What the device is (hipDeviceProp_t at creation): launches are sized from this, not from "an MI355X has 256 CUs
-  // of 160 KiB" -- a partitioned device (CPX: 32 CUs per logical GPU) or another part must not be oversubscribed.
-  int cus = 256;                      // compute units
-  size_t lds_per_cu = 160 * 1024;     // LDS of one CU
-  size_t lds_per_block = 160 * 1024;  // most dynamic LDS one workgroup may ask for
-  size_t hbm_bytes = 0;               // device memory in total
-  // The k = 1 view of a tree that holds piles (ptk_piles.hpp; dim <= 3): branch records and subtree ranges of its
-  // own, the point array of the tree; null / zero when the tree has no pile.
-  ptk::DevTree dev1{};
-  void* d_nodes1 = nullptr;
-  void* d_ranges1 = nullptr;
-  void* d_pile_of_point = nullptr;
-  void* d_pile_recs = nullptr;
-  uint32_t n_piles = 0;
-  uint64_t pile_points = 0;
-  uint32_t max_depth1 = 0;
-  void* d_cells = nullptr;  // dim <= 3: which cells of a coarse Morton grid hold tree points (ptk::CellTable)
-  ptk::CellTable cells{};
-  ptk::DevTreeND dev_nd{};
-  uint64_t device_bytes = 0;
-  bool gpu_layout = false;
-
-  std::atomic<int> reorder{PTK_REORDER_AUTO};
-  std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
-  mutable Profile profile;
-  mutable Workspace ws;
-  // k-NN calls arriving on other HIP streams get a scratch block of their own (up to kExtraWs
-  // streams per handle; further ones share `ws` in stream order), so that batches issued on several
-  // streams overlap: the tail of one batch's phase 2 is a few long dependent chains with the machine
-  // mostly idle (profiles/r01n_streams.jsonl).  slot_stream[i] is the stream slot i belongs to.
-  static constexpr int kExtraWs = 3;
-  mutable Workspace extra_ws[kExtraWs];
-  mutable std::mutex slot_mutex;
-  mutable hipStream_t slot_stream[1 + kExtraWs] = {};
-  mutable bool slot_taken[1 + kExtraWs] = {};
-  mutable HostIo io;
-};
-
-namespace {
-
-struct DeviceGuard {
-  int prev = -1;
-  bool ok = false;
-  explicit DeviceGuard(int dev) {
-    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
-    ok = hipSetDevice(dev) == hipSuccess;
-  }
-  ~DeviceGuard() {
-    if (prev >= 0) (void)hipSetDevice(prev);
-  }
-};
-
-int env_int(const char* name, int fallback);  // defined with the launch helpers below
 void axis_bits(const ptk_tree* t, int bits, uint32_t b[3]);
-
-// Host threads for the tree build (the result does not depend on it): PTK_BUILD_THREADS, else the
-// hardware concurrency capped at 32.
-unsigned build_threads() {
-  const int v = env_int("PTK_BUILD_THREADS", 0);
-  if (v > 0) return (unsigned)v;
-  const unsigned hc = std::thread::hardware_concurrency();
-  return hc == 0 ? 1u : (hc > 32u ? 32u : hc);
-}
 
 // PTK_CREATE_TIMING=1: the phases of a tree creation on stderr (tools/time_build.py).
 struct CreateClock {
@@ -403,11 +164,11 @@ int upload(ptk_tree& t, const float* points) {
   size_t cell_bytes = 0;
   {
     // The coarse grid of occupied cells (ptk::CellTable): about 32 tree points per cell on average, the cell bits
-    // spread over the axes like the bits of the order key.  PTK_CELL_TABLE=0: none.
+    // spread over the axes like the bits of the order key.
     int cb = 0;
     while ((64ull << cb) <= t.n_points) ++cb;  // floor(log2(n / 32))
     cb = std::min(std::max(cb, 6), 22);
-    if (env_int("PTK_CELL_TABLE", 1) != 0) {
+    {
       uint32_t b[3];
       axis_bits(&t, cb, b);
       float lo[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
@@ -458,7 +219,7 @@ int upload(ptk_tree& t, const float* points) {
   t.gpu_layout = true;
   // Piles -- subtrees of one point many times over: the k = 1 search gets a view in which each is a leaf of one point
   // (ptk_piles.hpp).  A tree of points in general position pays one pass over its branch records here.
-  if (env_int("PTK_PILE_VIEW", 1) != 0) {
+  if (knob_int("pile_view", 1) != 0) {
     ptk::PileView view;
     ptk::build_pile_view(t.dim, t.n_points, points, t.nodes.data(), t.nodes.size(), t.indices.data(), view, build_threads());
     if (!view.empty()) {
@@ -526,6 +287,12 @@ struct ProcessWarmup {
         return;
       }
       hipLaunchKernelGGL(ptk_warm_kernel, dim3(1), dim3(1), 0, nullptr);
+      // (one code object per translation unit: each family loads its own)
+      ptkf::warm_knn();
+      ptkf::warm_radius();
+      ptkf::warm_nd();
+      ptkf::warm_topo();
+      ptkf::warm_f64();
       (void)hipDeviceSynchronize();
       (void)hipGetLastError();
     });
@@ -603,262 +370,6 @@ int finish_create(ptk_tree* t, const float* points, int32_t device, ptk_tree** o
   return PTK_OK;
 }
 
-// ---- launch helpers ---------------------------------------------------------------
-
-// Optional HIP-event bracket around one kernel.  Recording is asynchronous: the
-// pair is queued on the handle and only read back (with a synchronisation) by
-// ptk_profile_get, so profiling may stay enabled inside a timed region.
-struct Timer {
-  const ptk_tree* t;
-  hipStream_t s;
-  hipEvent_t a = nullptr, b = nullptr;
-  bool on;
-  Timer(const ptk_tree* tree, hipStream_t stream) : t(tree), s(stream) {
-    on = tree->profile.enabled;
-    if (on) {
-      {
-        std::lock_guard<std::mutex> lock(t->profile.mutex);
-        std::vector<hipEvent_t>& idle = t->profile.idle;
-        if (idle.size() >= 2) {
-          a = idle.back();
-          idle.pop_back();
-          b = idle.back();
-          idle.pop_back();
-        }
-      }
-      // Timing only: no system-scope fence when the event completes (the default event makes the device write
-      // its caches back, which costs the kernels around it: 0.042 ms per k = 1 search with ten such events).
-      if (a == nullptr)
-        on = hipEventCreateWithFlags(&a, hipEventDisableSystemFence) == hipSuccess &&
-             hipEventCreateWithFlags(&b, hipEventDisableSystemFence) == hipSuccess;
-      if (on) (void)hipEventRecord(a, s);
-    }
-  }
-  void stop(int kind, uint64_t queries) {
-    if (!on) return;
-    (void)hipEventRecord(b, s);
-    std::lock_guard<std::mutex> lock(t->profile.mutex);
-    t->profile.pending.push_back(PendingEvent{a, b, kind, queries, false});
-    a = b = nullptr;
-    on = false;
-  }
-  // Ends a section and begins the next at the same instant: ONE event between two kernels instead of two
-  // (an event between dependent launches costs ~3 us of idle device).
-  void next(int kind, uint64_t queries) {
-    if (!on) return;
-    (void)hipEventRecord(b, s);
-    hipEvent_t fresh = nullptr;
-    {
-      std::lock_guard<std::mutex> lock(t->profile.mutex);
-      t->profile.pending.push_back(PendingEvent{a, b, kind, queries, true});
-      if (!t->profile.idle.empty()) {
-        fresh = t->profile.idle.back();
-        t->profile.idle.pop_back();
-      }
-    }
-    a = b;  // ours now: the section that ended does not recycle it
-    b = fresh;
-    if (b == nullptr && hipEventCreateWithFlags(&b, hipEventDisableSystemFence) != hipSuccess) {
-      b = nullptr;
-      on = false;  // (the destructor drops `a`; the ended section only reads it before that if it is resolved first)
-    }
-  }
-  ~Timer() {  // only reached with events in hand when a search failed half-way
-    if (a) {
-      // After next() `a` is also the end of the section before (kept there with keep_b): that section takes it
-      // over instead of being left with a destroyed event.
-      std::lock_guard<std::mutex> lock(t->profile.mutex);
-      for (auto it = t->profile.pending.rbegin(); it != t->profile.pending.rend(); ++it)
-        if (it->b == a && it->keep_b) {
-          it->keep_b = false;
-          a = nullptr;
-          break;
-        }
-    }
-    if (a) (void)hipEventDestroy(a);
-    if (b) (void)hipEventDestroy(b);
-  }
-};
-
-// One search call's view of the handle's scratch block (see Workspace).
-// The scratch block a call on stream `s` uses: the handle's main one, or -- k-NN calls only (the
-// radius capture lives in the main block) -- the one assigned to that stream.
-inline Workspace& workspace_for(const ptk_tree* t, hipStream_t s, bool per_stream) {
-  if (!per_stream) return t->ws;
-  std::lock_guard<std::mutex> lock(t->slot_mutex);
-  for (int i = 0; i <= ptk_tree::kExtraWs; ++i)
-    if (t->slot_taken[i] && t->slot_stream[i] == s) return i == 0 ? t->ws : t->extra_ws[i - 1];
-  for (int i = 0; i <= ptk_tree::kExtraWs; ++i)
-    if (!t->slot_taken[i]) {
-      t->slot_taken[i] = true;
-      t->slot_stream[i] = s;
-      return i == 0 ? t->ws : t->extra_ws[i - 1];
-    }
-  return t->ws;
-}
-
-// Everything enqueued for the block's last user has finished (host wait).
-inline void drain_workspace(Workspace& ws) {
-  if (!ws.has_work) return;
-  if (hipStreamSynchronize(ws.last_stream) != hipSuccess) {  // (the stream is gone: whatever it held is waited for)
-    (void)hipGetLastError();
-    (void)hipDeviceSynchronize();
-  }
-  ws.has_work = false;
-}
-
-class Scratch {
- public:
-  Scratch(const ptk_tree* t, hipStream_t s, bool per_stream = false)
-      : ws_(workspace_for(t, s, per_stream)), lock_(ws_.mutex), s_(s) {}
-  ~Scratch() {
-    if (!reserved_) return;
-    ws_.last_stream = s_;
-    ws_.has_work = true;
-  }
-  // Room for `bytes` in total over all take() calls of this search; orders the call
-  // after the previous user of the block.
-  int reserve(size_t bytes) {
-    bytes += 64 * kAlign;  // alignment slack of the individual arrays
-    if (bytes > ws_.capacity) {
-      drain_workspace(ws_);
-      if (ws_.base) (void)hipFree(ws_.base);
-      ws_.base = nullptr;
-      ws_.capacity = 0;
-      ws_.has_work = false;
-      const size_t want = (bytes + (size_t(32) << 20)) & ~((size_t(32) << 20) - 1);
-      if (hipMalloc((void**)&ws_.base, want) != hipSuccess) {
-        (void)hipGetLastError();  // not sticky: the next launch must not report this again
-        ws_.base = nullptr;
-        return fail(PTK_ERR_NOMEM, "out of device memory (%zu bytes of search scratch)", want);
-      }
-      ws_.capacity = want;
-    }
-    if (ws_.has_work && ws_.last_stream != s_) {  // the block changes streams: behind all the last one holds
-      bool ordered = ws_.done != nullptr || hipEventCreateWithFlags(&ws_.done, hipEventDisableTiming) == hipSuccess;
-      ordered = ordered && hipEventRecord(ws_.done, ws_.last_stream) == hipSuccess &&
-                hipStreamWaitEvent(s_, ws_.done, 0) == hipSuccess;
-      if (!ordered) {
-        (void)hipGetLastError();
-        drain_workspace(ws_);
-      }
-    }
-    ws_.used = 0;
-    ws_.last_meta = nullptr;  // whatever the last k = 1 search left in the block is about to be overwritten (or freed)
-    ws_.last_order = 0;
-    ws_.last_verdict = nullptr;
-    reserved_ = true;
-    return PTK_OK;
-  }
-  void note_meta(const uint32_t* meta) { ws_.last_meta = meta; }
-  void note_order(int how) { ws_.last_order = how; }
-  // The second stream of this scratch block and its two events (made on first use); false if they cannot be had.
-  bool side_stream(hipStream_t* side, hipEvent_t* fork, hipEvent_t* join) {
-    if (ws_.side == nullptr) {
-      // (at the device's highest stream priority instead: measured, no different -- shard 0.228 / 0.228 ms, the
-      // headline 1.23 / 1.23, knn = 16 3.76 / 3.76: profiles/r05_notes.txt item 18)
-      if (hipStreamCreateWithFlags(&ws_.side, hipStreamNonBlocking) != hipSuccess) {
-        ws_.side = nullptr;
-        (void)hipGetLastError();
-        return false;
-      }
-    }
-    if (ws_.fork == nullptr && hipEventCreateWithFlags(&ws_.fork, hipEventDisableTiming) != hipSuccess) ws_.fork = nullptr;
-    if (ws_.join == nullptr && hipEventCreateWithFlags(&ws_.join, hipEventDisableTiming) != hipSuccess) ws_.join = nullptr;
-    if (ws_.fork == nullptr || ws_.join == nullptr) {
-      (void)hipGetLastError();
-      return false;
-    }
-    *side = ws_.side;
-    *fork = ws_.fork;
-    *join = ws_.join;
-    return true;
-  }
-  // The two device words of the coherence sample of this block's batches (made and zeroed on first use).
-  uint32_t* sample_state() {
-    if (ws_.d_sample == nullptr) {
-      if (hipMalloc((void**)&ws_.d_sample, 256) != hipSuccess || hipMemset(ws_.d_sample, 0, 256) != hipSuccess) {
-        (void)hipGetLastError();
-        if (ws_.d_sample) (void)hipFree(ws_.d_sample);
-        ws_.d_sample = nullptr;
-      }
-    }
-    return ws_.d_sample;
-  }
-  void note_verdict(const uint32_t* verdict) { ws_.last_verdict = verdict; }
-  const uint32_t* batch_verdict() const { return ws_.last_verdict; }
-  template <class T>
-  T* take(size_t count) {
-    const size_t bytes = (count * sizeof(T) + kAlign - 1) & ~(kAlign - 1);
-    if (!reserved_ || ws_.used + bytes > ws_.capacity) return nullptr;  // reserve() was too small: a bug
-    T* p = reinterpret_cast<T*>(ws_.base + ws_.used);
-    ws_.used += bytes;
-    return p;
-  }
-  static constexpr size_t kAlign = 256;
-
- private:
-  Workspace& ws_;
-  std::unique_lock<std::mutex> lock_;
-  hipStream_t s_;
-  bool reserved_ = false;
-};
-
-// Stack geometry: the newest S records of a lane live in an LDS ring, older ones
-// spill to OVF private-scratch slots.  A traversal holds, per level of the current
-// root path, either one pending record (went near, far child unexplored) or two
-// undo records (went far), so 2 * depth + 2 slots always suffice.
-constexpr int kDeepClass = 3;  // deeper than the private classes: spill to HBM, generic kernels only
-// What a k = 1 search of the default metric traverses: the view without the piles if the tree has any.
-const ptk::DevTree& knn1_tree(const ptk_tree* t) { return t->n_piles ? t->dev1 : t->dev; }
-const uint2* knn1_ranges(const ptk_tree* t) { return static_cast<const uint2*>(t->n_piles ? t->d_ranges1 : t->d_ranges); }
-uint32_t knn1_depth(const ptk_tree* t) { return t->n_piles ? t->max_depth1 : t->max_depth; }
-
-int ovf_class_of(uint32_t depth, int s_lds);
-int ovf_class(const ptk_tree* t, int s_lds) { return ovf_class_of(t->max_depth, s_lds); }
-int ovf_class_of(uint32_t depth, int s_lds) {
-  const uint32_t need = 2 * depth + 2;
-  if (need <= (uint32_t)s_lds + 64) return 0;
-  if (need <= (uint32_t)s_lds + 256) return 1;
-  if (need <= (uint32_t)s_lds + 2048) return 2;
-  return kDeepClass;
-}
-bool deep_tree(const ptk_tree* t) { return ovf_class(t, 16) == kDeepClass; }
-
-// A deep tree's launches: `cap` spill records per lane, `piece` queries per launch so that the
-// block stays within PTK_DEEP_SPILL_MB (default 2048).
-struct DeepPlan {
-  uint32_t cap;
-  uint64_t piece;
-  size_t bytes() const { return (size_t)piece * cap * sizeof(ptk::Record); }
-};
-DeepPlan deep_plan(const ptk_tree* t, uint64_t n) {
-  DeepPlan p;
-  p.cap = 2 * t->max_depth + 2;
-  const size_t budget = (size_t)std::max(1, env_int("PTK_DEEP_SPILL_MB", 2048)) << 20;
-  uint64_t piece = (budget / ((size_t)p.cap * sizeof(ptk::Record))) & ~(uint64_t)63;
-  if (piece < 64) piece = 64;
-  const uint64_t all = (n + 63) & ~(uint64_t)63;
-  p.piece = piece < all ? piece : all;
-  return p;
-}
-
-// Dynamic LDS above 64 KiB must be opted into per kernel.
-template <typename K>
-int allow_lds(K kernel, size_t bytes) {
-  if (bytes > 64 * 1024) {
-    PTK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes));
-  }
-  return PTK_OK;
-}
-
-// An integer from the environment (the memory caps and test switches listed in INTEGRATION.md section 6).
-int env_int(const char* name, int fallback) {
-  const char* v = std::getenv(name);
-  return v ? std::atoi(v) : fallback;
-}
-
 bool want_reorder(const ptk_tree* t, uint64_t nq) {
   const int mode = t->reorder.load();
   if (mode == PTK_REORDER_ON) return nq > 1;
@@ -908,10 +419,10 @@ size_t sort_tmp_bytes(uint64_t nq, int bits) {
 
 // The library's own radix sort (ptk_sort.hpp): tiles of `tile` items, one wavefront each.  At most 4096 tiles
 // (a row of the digit-by-tile histogram is scanned by one wavefront), at least 512 items per tile (256 / 512 / 1024:
-// 68 / 58 / 60 us for 900 k queries; PTK_SORT_TILE for experiments).
+// 68 / 58 / 60 us for 900 k queries).
 uint32_t sort_tile(uint64_t nq) {
   const uint64_t t = ((nq + 4095) / 4096 + 63) & ~(uint64_t)63;
-  return (uint32_t)std::max<uint64_t>(t, (uint64_t)std::max(64, env_int("PTK_SORT_TILE", 512)) & ~(uint64_t)63);
+  return (uint32_t)std::max<uint64_t>(t, (uint64_t)512);
 }
 uint32_t sort_tiles(uint64_t nq) { return (uint32_t)((nq + sort_tile(nq) - 1) / sort_tile(nq)); }
 uint32_t sort_stride(uint64_t nq) { return (sort_tiles(nq) + 3u) & ~3u;  }  // row of the histogram: 16-byte steps
@@ -926,12 +437,12 @@ size_t own_sort_bytes(uint64_t nq) {  // (the histogram of whichever form has mo
 // 900 k rows 0.063 / 0.056 / 0.110, 2 M 0.144 / 0.093 / 0.158, 7.2 M 0.319 / 0.192 / 0.275; profiles/r04_notes.txt
 // item 13).  PTK_SORT = 0 forces rocprim's, PTK_SORT_BLOCK = 0 / 1 either form of the own.
 bool block_sort(uint64_t nq) {
-  const int mode = env_int("PTK_SORT_BLOCK", -1);
+  const int mode = knob_int("sort_block", -1);
   return mode < 0 ? nq >= (3ull << 18) : mode != 0 && nq >= ptk::kSortTile;
 }
 bool own_sort(uint64_t nq) {
   if (nq >= (1ull << 31)) return false;
-  return env_int("PTK_SORT", 1) != 0;
+  return knob_int("sort", 1) != 0;
 }
 
 size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_bytes(nq, 30) + own_sort_bytes(nq) + 1024; }
@@ -948,7 +459,7 @@ size_t permutation_scratch_bytes(uint64_t nq) { return 4 * (nq * 4) + sort_tmp_b
 // that take device buffers only enqueue, whatever the batch looks like (r04 waited for the verdict on the host).
 const uint32_t* sample_batch(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream_t s, Scratch& scratch, int bits,
                              const float3& lo3, const float3& inv3, const uint3& b3) {
-  if (nq < 8192 || env_int("PTK_COHERENCE_CHECK", 1) == 0) return nullptr;
+  if (nq < 8192) return nullptr;
   uint8_t* d_fail = scratch.take<uint8_t>(ptk::kCoherenceWindows);
   uint32_t* state = scratch.sample_state();
   if (d_fail == nullptr || state == nullptr) return nullptr;
@@ -984,7 +495,7 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
     inv[d] = ext > 0 ? (float)(1u << b[d]) / ext : 0.0f;
   }
   ptk::CellTable cells{};
-  if (heavy_first != 0u && t->cells.occ != nullptr && env_int("PTK_HEAVY_FIRST", 1) != 0) {
+  if (heavy_first != 0u && t->cells.occ != nullptr) {
     cells = t->cells;
     cells.key_bits = (uint32_t)bits;
     cells.mode = heavy_first;
@@ -1065,292 +576,6 @@ int make_permutation(const ptk_tree* t, const float* d_q, uint64_t nq, hipStream
   return PTK_OK;
 }
 
-int check_search(const ptk_tree* t, const void* q, uint64_t nq) {
-  if (t == nullptr) return fail(PTK_ERR_INVALID, "null tree");
-  if (nq > 0 && q == nullptr) return fail(PTK_ERR_INVALID, "null query buffer");
-  if (t->device == kDeviceNone) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
-  if (!t->gpu_layout) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
-  return PTK_OK;
-}
-
-float inv_ratio(float e) { return 1.0f / e; }
-
-template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
-int launch_knn(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
-               ptk::Neighbor* d_out, hipStream_t s) {
-  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  const size_t stack_bytes = (size_t)S * BLOCK * 8;
-  const size_t list_bytes = (size_t)k * BLOCK * 8;
-  // The k-list goes to LDS while a wavefront's block stays under 48 KiB (k <= 80); beyond that the output row itself is
-  // the list.  (Kernel ms on 900 k queries of config 3, list in LDS / in the row: knn = 65 47 / 71, knn = 100 138 / 138,
-  // knn = 200 881 / 409 -- a list that leaves a CU two wavefronts loses to one in HBM.  PTK_KNN_LIST_LDS_KB: the limit,
-  // for experiments.  Both forms are insert_sorted as a loop per lane: k beyond 64 wants a design of its own.)
-  const bool list_lds = stack_bytes + list_bytes <= (size_t)std::min(156, std::max(0, env_int("PTK_KNN_LIST_LDS_KB", 48))) * 1024;
-  Timer timer(t, s);
-  if (list_lds) {
-    const int lds_rc = allow_lds(ptk::knn_kernel<S, OVF, BLOCK, LEAFB, true, M>, stack_bytes + list_bytes);
-    if (lds_rc != PTK_OK) return lds_rc;
-    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK),
-                       stack_bytes + list_bytes, s, t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out);
-  } else {
-    hipLaunchKernelGGL((ptk::knn_kernel<S, OVF, BLOCK, LEAFB, false, M>), dim3(blocks), dim3(BLOCK), stack_bytes, s,
-                       t->dev, d_q, t->dim, perm, nq, k, inv_ratio(e), d_out);
-  }
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
-
-// Far children a query of the general k-NN kernel may enter before it is handed to the cooperative search
-// (ptk_kernels_coopk.hpp; PTK_KNN_CAP, 0 = every query runs to its end in its lane).  Exact searches with the default
-// metric only: the argument that makes the merged result the reference's needs e = 1 and the error bounds of a sum of
-// squares.
-constexpr int kKnnCoopPool = 128;
-constexpr uint32_t kKnnCoopSpill = 2048;  // tasks a wavefront of the cooperative search can park in HBM
-uint32_t knn_coop_blocks(const ptk_tree* t) { return (uint32_t)t->cus * (uint32_t)std::max(1, env_int("PTK_KNN_COOP_WAVES", 32)); }
-// The cap follows the batch: a capped launch ends with the lanes that ran to their cap -- cap x ~7 us, a lonely lane's
-// price per far child -- however small the batch, so a batch the chip gets through in less than that wants a lower cap
-// and more hand-overs (at a fixed 256 ANY batch of knn = 16 took 1.9 ms).  Fitted to a sweep of twelve caps at eight
-// batch sizes and four k (tools/sweep_knn_cap.sh, profiles/r05_knn_cap_sweep.jsonl; notes r05 item 13): the best cap
-// is linear in the batch -- it keeps the hand-overs at 7-15 thousand, what the cooperative search gets through beside
-// the capped launch's end -- with a slope that follows k (a query's far children grow with its k), steeper for the
-// largest batches of k = 8 / 16 (two launches side by side there, see launch_knn_reg: the tail of the front hides
-// behind the rest, so fewer hand-overs win), between a floor and a top per k:
-//   k <= 4  nq / 37 500                                  8 .. 256      k <= 16  nq / 16 000      16 .. 448
-//   k <= 8  max(nq / 30 000, (nq - 1.2 M) / 20 000)      12 .. 320     k <= 32  nq / 9 400       32 .. 512
-// (a cap that lets more queries through than the hand-over list holds is a cliff -- those queries finish alone in
-// their lanes -- so the slopes err towards the higher cap: knn = 8 at 900 k queries, caps 24 / 32: 0.94 / 0.63 ms)
-// PTK_KNN_CAP = n: that cap for every batch (0: no cap).
-uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
-  // (below a few wavefronts of queries the two extra launches cost more than the tail: kernel ms with / without the
-  // cap at 64 / 500 / 3 000 queries, knn = 16 0.13 / 0.27 / 0.30 against 0.11 / 0.66 / 0.90.  PTK_KNN_CAP_MIN_NQ: tests)
-  if (e != 1.0f || nq < (uint64_t)std::max(1, env_int("PTK_KNN_CAP_MIN_NQ", 256))) return 0;
-  const int forced = env_int("PTK_KNN_CAP", -1);
-  if (forced >= 0) return (uint32_t)forced;
-  const double n = (double)nq;
-  double cap, lo, hi;
-  if (k <= 4) {
-    cap = n / 37500.0, lo = 8.0, hi = 256.0;
-  } else if (k <= 8) {
-    cap = std::max(n / 30000.0, (n - 1.2e6) / 20000.0), lo = 12.0, hi = 320.0;
-  } else if (k <= 16) {
-    cap = n / 16000.0, lo = 16.0, hi = 448.0;
-  } else if (k <= 32) {
-    cap = n / 9400.0, lo = 32.0, hi = 512.0;
-  } else if (k <= 56) {
-    // (33 .. 56, lists of 64 slots: the cooperative kernel of that size fits one wavefront per SIMD, so it should see
-    // few queries -- kernel ms, rule / uncapped: knn = 40 at 150 k 2.0 / 5.5, 900 k 4.4 / 4.8, 7.2 M 15.9 / 15.6)
-    cap = n / 3500.0, lo = 64.0, hi = 768.0;
-  } else {
-    // (57 .. 64: the second sweep ranks at most 64 points, k of them are the handed-over entries -- nearly every tie
-    // would be redone by one lane, milliseconds each: these run uncapped)
-    return 0;
-  }
-  return (uint32_t)std::min(hi, std::max(lo, cap));
-}
-// Entries of the hand-over list (64 tasks of 24 bytes each): a query that finds it full goes on in its lane.
-uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
-size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
-  return 3 * (nq * 4) + (knn_max_handover(nq) + 24576) * ptk::kMaxTasks * sizeof(ptk::Task) + ptk::kMetaWords * 4 +
-         (size_t)knn_coop_blocks(t) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
-}
-
-// The largest k whose list lives in registers (3-D kernels, every metric): 64 slots (a list of 40 in LDS took 74 ms on
-// BASELINE config 3 where 32 in registers take 7: insert_sorted through LDS is a loop per lane).
-inline uint32_t knn_reg_max(bool) { return 64u; }
-// k <= 64: the k-list in registers (K = 4 / 8 / 16 / 32 / 64 slots compiled).
-template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
-int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
-                   ptk::Neighbor* d_out, hipStream_t s, Scratch* scratch = nullptr) {
-  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  const size_t smem = (size_t)S * BLOCK * 8;
-  Timer timer(t, s);
-  if constexpr (std::is_same<M, ptk::MetricL2>::value && BLOCK == 64) {
-    const uint32_t cap = scratch != nullptr ? knn_cap(e, nq, k) : 0u;
-    if (cap != 0u) {
-      // The capped launch, the cooperative search of what it handed over, the reference search of what that could
-      // not certify: the counts stay on the device.  A batch of four million queries or more goes through as TWO capped
-      // launches side by side -- the front of the launch order (the expensive rows: `perm` puts them first) on a second
-      // stream, the rest on the caller's -- so that the cooperative search of what the front handed over runs BESIDE the
-      // rest instead of behind it (PTK_KNN_OVERLAP_PCT: the front's share of the rows, 0 = one launch).
-      const uint32_t coop_blocks = knn_coop_blocks(t);
-      uint64_t n_front = 0;
-      hipStream_t side = nullptr;
-      hipEvent_t fork = nullptr, join = nullptr;
-      // (kernel ms, two launches / one: 7.2 M queries knn = 4 / 8 / 16 / 32 2.15 / 2.67 / 3.78 / 7.07 against 2.20 / 2.71 /
-      // 3.86 / 7.11, 4.8 M 1.58 / 2.01 / 2.75 / 5.00 against 1.59 / 1.95 / 2.86 / 5.23; at 2.4 M and below, and for
-      // knn = 2, the second launch costs more than the overlap returns: 1.82 against 1.67 at knn = 16)
-      if (perm != nullptr && nq >= (1ull << 22) && k > 2) {
-        const uint64_t pct = (uint64_t)std::min(90, std::max(0, env_int("PTK_KNN_OVERLAP_PCT", 20)));
-        n_front = (nq * pct / 100) / BLOCK * BLOCK;
-        if (n_front != 0 && !scratch->side_stream(&side, &fork, &join)) n_front = 0;
-      }
-      uint32_t* meta = scratch->take<uint32_t>(ptk::kMetaWords);
-      uint32_t* heavy_list = scratch->take<uint32_t>(nq);
-      uint32_t* ntasks = scratch->take<uint32_t>(nq);
-      const uint32_t cap_front = (uint32_t)knn_max_handover(n_front), cap_rest = (uint32_t)knn_max_handover(nq - n_front);
-      ptk::Task* tasks = scratch->take<ptk::Task>(((size_t)(n_front ? cap_front : 0) + cap_rest) * ptk::kMaxTasks);
-      uint32_t* redo_list = scratch->take<uint32_t>(nq);
-      ptk::Task* spill = scratch->take<ptk::Task>((size_t)coop_blocks * kKnnCoopSpill);
-      if (!meta || !heavy_list || !ntasks || !tasks || !redo_list || !spill)
-        return fail(PTK_ERR_NOMEM, "scratch block too small");
-      scratch->note_meta(meta);
-      PTK_HIP(hipMemsetAsync(meta, 0, ptk::kMetaWords * 4, s));
-      const size_t coop_smem = (size_t)ptk::knn_coop_lds_words(kKnnCoopPool, k > 32 ? 64u : 32u) * 4;
-      const uint2* ranges = static_cast<const uint2*>(t->d_ranges);
-      // One capped launch over launch-order rows [lo, lo + n) and the cooperative search of its hand-overs, on `st`
-      // (`word`: the counter of its list; `cb` wavefronts from `first_block` of the spill block).
-      auto part = [&](uint64_t lo, uint64_t n, uint32_t word, uint32_t max_heavy, ptk::Task* part_tasks, uint32_t cb,
-                      uint32_t first_block, hipStream_t st) {
-        ptk::Handover ho{};
-        ho.counter = word;
-        ho.meta = meta;
-        ho.heavy_list = heavy_list + lo;
-        ho.ntasks = ntasks + lo;
-        ho.max_heavy = max_heavy;
-        ho.full_keeps = 1u;
-        ho.tasks = part_tasks;
-        const uint32_t nb = (uint32_t)((n + BLOCK - 1) / BLOCK);
-        const uint32_t cap_n = cap;  // (of the whole batch: the two launches share the chip)
-        ptk::Task* sp = spill + (size_t)first_block * kKnnCoopSpill;
-#define PTK_LAUNCH_REG(KK)                                                                                              \
-  do {                                                                                                                  \
-    hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M, true>), dim3(nb), dim3(BLOCK), smem, st,        \
-                       t->dev, d_q, t->dim, perm ? perm + lo : nullptr, n, k, inv_ratio(e), d_out, cap_n, ho);          \
-    hipLaunchKernelGGL((ptk::knn_coop_kernel<KK, kKnnCoopPool>), dim3(cb), dim3(64), coop_smem, st, t->dev, ranges,      \
-                       d_q, t->dim, k, d_out, ho, redo_list, ptk::kMetaRedo, sp, kKnnCoopSpill);                        \
-  } while (0)
-        if (k <= 4) PTK_LAUNCH_REG(4);
-        else if (k <= 8) PTK_LAUNCH_REG(8);
-        else if (k <= 16) PTK_LAUNCH_REG(16);
-        else if (k <= 32) PTK_LAUNCH_REG(32);
-        else PTK_LAUNCH_REG(64);
-#undef PTK_LAUNCH_REG
-      };
-      if (n_front != 0) {
-        // (a failure between fork and join must not leave the second stream working on a scratch block the next call reuses)
-        struct SideGuard {
-          hipStream_t side = nullptr;
-          ~SideGuard() {
-            if (side) (void)hipStreamSynchronize(side);
-          }
-        } guard;
-        guard.side = side;
-        PTK_HIP(hipEventRecord(fork, s));
-        PTK_HIP(hipStreamWaitEvent(side, fork, 0));
-        const uint32_t half = std::max(1u, coop_blocks / 2);
-        part(0, n_front, ptk::kMetaHeavy, cap_front, tasks, half, 0u, side);
-        PTK_HIP(hipEventRecord(join, side));
-        part(n_front, nq - n_front, ptk::kMetaHeavyRest, cap_rest, tasks + (size_t)cap_front * ptk::kMaxTasks,
-             coop_blocks - half, half, s);
-        PTK_HIP(hipStreamWaitEvent(s, join, 0));
-        guard.side = nullptr;
-      } else {
-        part(0, nq, ptk::kMetaHeavy, cap_rest, tasks, coop_blocks, 0u, s);
-      }
-#define PTK_LAUNCH_REDO(KK)                                                                                             \
-  hipLaunchKernelGGL((ptk::knn_redo_kernel<KK, S, OVF, LEAFB, M>), dim3(t->cus), dim3(64), smem, s, t->dev, d_q, t->dim, \
-                     k, inv_ratio(e), d_out, meta, ptk::kMetaRedo, redo_list)
-      if (k <= 4) PTK_LAUNCH_REDO(4);
-      else if (k <= 8) PTK_LAUNCH_REDO(8);
-      else if (k <= 16) PTK_LAUNCH_REDO(16);
-      else if (k <= 32) PTK_LAUNCH_REDO(32);
-      else PTK_LAUNCH_REDO(64);
-#undef PTK_LAUNCH_REDO
-      PTK_HIP(hipGetLastError());
-      timer.stop(0, nq);
-      return PTK_OK;
-    }
-  }
-#define PTK_LAUNCH_REG(KK)                                                                                          \
-  hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s, t->dev, d_q, \
-                     t->dim, perm, nq, k, inv_ratio(e), d_out, 0u, ptk::Handover{})
-  if (k <= 4) PTK_LAUNCH_REG(4);
-  else if (k <= 8) PTK_LAUNCH_REG(8);
-  else if (k <= 16) PTK_LAUNCH_REG(16);
-  else if (k <= 32) PTK_LAUNCH_REG(32);
-  else PTK_LAUNCH_REG(64);  // (33 .. 64: knn_reg_max)
-#undef PTK_LAUNCH_REG
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
-
-template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
-int launch_radius(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
-                  bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out,
-                  hipStream_t s, const uint32_t* n_dev = nullptr) {
-  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  const size_t smem = (size_t)S * BLOCK * 8;
-  Timer timer(t, s);
-  if (!fill) {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, false, M>), dim3(blocks), dim3(BLOCK), smem, s,
-                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out, n_dev);
-  } else {
-    hipLaunchKernelGGL((ptk::radius_kernel<S, OVF, BLOCK, LEAFB, true, M>), dim3(blocks), dim3(BLOCK), smem, s,
-                       t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out, n_dev);
-  }
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, n_dev ? 0 : nq);
-  return PTK_OK;
-}
-
-// The count pass that also captures the rows.
-template <int S, int OVF, int BLOCK, int LEAFB, class M = ptk::MetricL2>
-int launch_radius_capture(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
-                          float e, uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
-  const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
-  const size_t smem = (size_t)S * BLOCK * 8 + 16;  // + the cursor of the wavefront's log
-  Timer timer(t, s);
-  PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
-  hipLaunchKernelGGL((ptk::radius_capture_kernel<S, OVF, BLOCK, LEAFB, M>), dim3(blocks), dim3(BLOCK), smem, s,
-                     t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, cap);
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
-
-// The radius search of a 3-D tree with the rows made from leaf lists (ptk_kernels_lists.hpp): the count pass ...
-template <int S, int OVF, int LEAFB, class M = ptk::MetricL2>
-int launch_radius_list(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
-                       uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
-  const size_t smem = (size_t)S * 64 * 8 + ptk::kListLds;  // + the group buffers and the chunk table of the wavefront
-  Timer timer(t, s);
-  PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
-  // (leaves of more than kListMaskBits points -- a count of 32 needs six bits -- / an approximate search: see RadiusListPolicy)
-  const bool big = t->dev.cmask >= ptk::kListMaskBits, exact = e == 1.0f;
-#define PTK_LAUNCH_LIST(BIG, EXACT)                                                                                  \
-  hipLaunchKernelGGL((ptk::radius_list_kernel<S, OVF, LEAFB, M, BIG, EXACT>), dim3(cap.n_static), dim3(64), smem, s, \
-                     t->dev, d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, cap)
-  if (big && exact) PTK_LAUNCH_LIST(true, true);
-  else if (big) PTK_LAUNCH_LIST(true, false);
-  else if (exact) PTK_LAUNCH_LIST(false, true);
-  else PTK_LAUNCH_LIST(false, false);
-#undef PTK_LAUNCH_LIST
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
-
-// ... and the fill pass.  n_over is zeroed here; the queries of wavefronts whose lists were lost are listed for
-// radius_kernel<FILL>.
-// Hits fetched together / entries a lane can hold back: (5, 16) 4.72 ms, (4, 16) 4.73, (5, 32) 4.49, (8, 32) 4.38 on
-// BASELINE config 3 -- fewer, larger rounds win although the ring of 32 halves the wavefronts per CU.
-constexpr int kReplayHits = 8, kReplayRing = 32;
-template <class M = ptk::MetricL2>
-int launch_radius_replay(const ptk_tree* t, const float* d_q, float e, const ptk::RadiusCapture& cap,
-                         const uint64_t* d_offsets, ptk::Neighbor* d_out, uint32_t* over_list, uint32_t* n_over,
-                         hipStream_t s) {
-  Timer timer(t, s);
-  PTK_HIP(hipMemsetAsync(n_over, 0, 4, s));
-  hipLaunchKernelGGL((ptk::radius_replay_kernel<kReplayHits, kReplayRing, M>), dim3(cap.n_static), dim3(64),
-                     ptk::replay_lds(kReplayRing), s, t->dev, d_q, t->dim, inv_ratio(e), cap, d_offsets, d_out, over_list,
-                     n_over);
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, 0);
-  return PTK_OK;
-}
-
 // PTK_RADIUS_CAPTURE_MB: the most device memory the captured rows of a radius batch may take
 // (default 16384; 0 switches the capture off and every fill pass repeats the traversal).
 size_t capture_budget_bytes(const ptk_tree* t) {
@@ -1376,7 +601,7 @@ bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
   const size_t head = (tables_at + waves * ptk::kListMaxChunks * 4 + 4095) & ~(size_t)4095;
   if (head + waves * chunk_bytes > budget) return false;
   const size_t dyn = std::min<size_t>((budget - head - waves * chunk_bytes) / chunk_bytes, waves * 64 * 2);
-  const int forced = env_int("PTK_RADIUS_CAPTURE_CHUNKS", -1);
+  const int forced = knob_int("radius_capture_chunks", -1);
   size_t sub_cap = forced >= 0 ? (size_t)forced : dyn / ptk::kCapSubPools;
   // (a slot of the log is addressed with 32 bits)
   const size_t max_chunks = ((1ull << 32) - 1) / ptk::kLogChunk;
@@ -1446,7 +671,7 @@ ClassPlan class_plan(uint64_t nq) {
   p.stride = (p.ntiles + 3u) & ~3u;
   p.seg = 1024u * std::max<uint32_t>(1u, (p.ntiles + 1024u * ptk::kClassMaxSegs - 1u) / (1024u * ptk::kClassMaxSegs));
   p.segs = (p.ntiles + p.seg - 1u) / p.seg;
-  p.per = (uint32_t)std::max(64, env_int("PTK_CLASS_PER", nq < (2ull << 20) ? 512 : 1792)) & ~63u;
+  p.per = nq < (2ull << 20) ? 512u : 1792u;
   p.chunks = (uint32_t)((nq + p.per - 1) / p.per);
   return p;
 }
@@ -1482,7 +707,7 @@ size_t two_phase_scratch_bytes(const ptk_tree* t, uint64_t nq) {
 // kernels, 7.2 M queries 8 / 12 / 16 / 24 / 32 = 1.287 / 1.268 / 1.255 / 1.238 / 1.271 (profiles/r03_notes.txt item 3).
 uint32_t phase2_cap(float e, uint64_t nq) {
   if (e != 1.0f) return 0;
-  const int cap = env_int("PTK_P2_CAP", nq >= (4ull << 20) ? 24 : 8);
+  const int cap = knob_int("p2_cap", nq >= (4ull << 20) ? 24 : 8);
   return cap < 0 ? 0u : (uint32_t)cap;
 }
 
@@ -1510,20 +735,13 @@ int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, 
   const int waves = coop_waves(t);
   const uint32_t spill_cap = spill ? kCoopSpill : 0u;
   if (direct_ids != nullptr) {
-    switch (env_int("PTK_COOP_DIRECT_LANES", 32)) {
-      case 32: return launch_knn1_coop_direct<32>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
-      case 64: return launch_knn1_coop_direct<64>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
-      default: return launch_knn1_coop_direct<16>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
-    }
+    // (32 lanes per query: 16 / 64 were measured, 1.91 / slower vs 1.72 ms of traversal kernels, profiles/r03_notes.txt item 3)
+    return launch_knn1_coop_direct<32>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
   }
   // What phase 2 hands over has been tightened by its first far children: a pool of 96 holds it (0 of 152 k queries of
-  // BASELINE config 2 overflow; the spill costs the step loop 5 %).  PTK_COOP_SPILL=1: with the spill all the same
-  // (tie-prone data whose replays would be long chains).
-  if (spill_cap != 0u && env_int("PTK_COOP_SPILL", 0) != 0)
-    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, true>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
-                       knn1_ranges(t), qs, d_out, cont, ho, redo_list, nullptr, spill, spill_cap);
-  else
-    hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, false>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
+  // BASELINE config 2 overflow; with the spill the step loop is 5 % slower): no spill here.
+  (void)spill_cap;
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, false>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
                        knn1_ranges(t), qs, d_out, cont, ho, redo_list, nullptr, spill, 0u);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
@@ -1545,7 +763,7 @@ int coop_direct_mode(const ptk_tree* t, uint64_t nq) {
   uint32_t balanced = 0;
   while ((1ull << balanced) < t->n_leaves) ++balanced;
   const bool deep = t->max_depth >= balanced + 6u;
-  return env_int("PTK_COOP_DIRECT", deep || nq < (1ull << 20) ? 2 : 0);
+  return knob_int("coop_direct", deep || nq < (1ull << 20) ? 2 : 0);
 }
 
 // The k = 1 search under the default metric (ptk_kernels.hpp, "the two-phase k = 1 search"): phase 1 (which also
@@ -1585,7 +803,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   ptk::Task* spill_a = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes(t)));
   ptk::Task* spill_b = reinterpret_cast<ptk::Task*>(scratch.take<char>(coop_spill_bytes(t)));
   if (!spill_a || !spill_b) return fail(PTK_ERR_NOMEM, "scratch block too small");
-  scratch.note_meta(cont.meta);
+  scratch.note_meta(cont.meta, 1);
   const uint32_t blocks = (uint32_t)((nq + 63) / 64);
   const float e_inv = inv_ratio(e);
   const uint32_t cap = phase2_cap(e, nq);
@@ -1692,173 +910,6 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
 // LDS per 64-lane block: record ring + q[dim] + off[dim] (+ the k-list while it fits).
 // (the most dynamic LDS a block may ask for is the handle's lds_per_block, from the device's properties)
 
-template <int OVF, class M = ptk::MetricL2>
-int launch_knn_nd(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
-                  ptk::Neighbor* d_out, hipStream_t s, bool no_register_list = false) {
-  constexpr int S = 16;
-  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-  const size_t base = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
-  if (base > t->lds_per_block)
-    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-  if (k <= 64 && !no_register_list) {  // k-list in registers (K = 4 / 8 / 16 / 32 / 64 slots compiled)
-    Timer timer(t, s);
-    int rc = PTK_OK;
-#define PTK_LAUNCH_ND_REG(KK)                                                                                       \
-  do {                                                                                                              \
-    rc = allow_lds(ptk::knn_nd_reg_kernel<KK, S, OVF, M>, base);                                                    \
-    if (rc == PTK_OK)                                                                                               \
-      hipLaunchKernelGGL((ptk::knn_nd_reg_kernel<KK, S, OVF, M>), dim3(blocks), dim3(64), base, s, t->dev_nd, d_q,  \
-                         perm, nq, k, inv_ratio(e), d_out);                                                         \
-  } while (0)
-    if (k <= 4) PTK_LAUNCH_ND_REG(4);
-    else if (k <= 8) PTK_LAUNCH_ND_REG(8);
-    else if (k <= 16) PTK_LAUNCH_ND_REG(16);
-    else if (k <= 32) PTK_LAUNCH_ND_REG(32);
-    else PTK_LAUNCH_ND_REG(64);
-#undef PTK_LAUNCH_ND_REG
-    if (rc != PTK_OK) return rc;
-    PTK_HIP(hipGetLastError());
-    timer.stop(0, nq);
-    return PTK_OK;
-  }
-  const size_t list_bytes = (size_t)k * 64 * 8;
-  const bool list_lds = base + list_bytes <= 64 * 1024;
-  const size_t smem = base + (list_lds ? list_bytes : 0);
-  Timer timer(t, s);
-  if (list_lds) {
-    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, true, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, perm, nq, k,
-                       inv_ratio(e), d_out);
-  } else {
-    int rc = allow_lds(ptk::knn_nd_kernel<S, OVF, false, M>, smem);
-    if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::knn_nd_kernel<S, OVF, false, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, perm, nq, k,
-                       inv_ratio(e), d_out);
-  }
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
-
-template <int OVF, class M = ptk::MetricL2>
-int launch_radius_nd(const ptk_tree* t, const float* d_q, uint64_t nq, float radius, float e, bool fill,
-                     uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out, hipStream_t s,
-                     const uint32_t* perm = nullptr, const uint32_t* n_dev = nullptr) {
-  constexpr int S = 16;
-  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-  const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8;
-  if (smem > t->lds_per_block)
-    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-  Timer timer(t, s);
-  if (!fill) {
-    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, false, M>, smem);
-    if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, false, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
-                       radius, inv_ratio(e), d_counts, d_offsets, d_out, perm, nullptr);
-  } else {
-    int rc = allow_lds(ptk::radius_nd_kernel<S, OVF, true, M>, smem);
-    if (rc != PTK_OK) return rc;
-    hipLaunchKernelGGL((ptk::radius_nd_kernel<S, OVF, true, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, nq,
-                       radius, inv_ratio(e), d_counts, d_offsets, d_out, perm, n_dev);
-  }
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, n_dev ? 0 : nq);
-  return PTK_OK;
-}
-
-template <int OVF, class M = ptk::MetricL2>
-int launch_radius_nd_capture(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius,
-                             float e, uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s) {
-  constexpr int S = 16;
-  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-  const size_t smem = (size_t)S * 64 * 8 + (size_t)t->dim * 64 * 8 + 16;  // + the cursor of the wavefront's log
-  if (smem > t->lds_per_block)
-    return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-  Timer timer(t, s);
-  int rc = allow_lds(ptk::radius_nd_capture_kernel<S, OVF, M>, smem);
-  if (rc != PTK_OK) return rc;
-  PTK_HIP(hipMemsetAsync(cap.counters, 0, ptk::kCapSubPools * ptk::kCapCounterStride * 4, s));
-  hipLaunchKernelGGL((ptk::radius_nd_capture_kernel<S, OVF, M>), dim3(blocks), dim3(64), smem, s, t->dev_nd, d_q, perm,
-                     nq, radius, inv_ratio(e), d_counts, cap);
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
-
-// Runs CALL with OVF bound to the spill capacity the tree's depth needs.
-#define PTK_WITH_OVF(SLDS, CALL)                                                                            \
-  switch (ovf_class(t, SLDS)) {                                                                             \
-    case 0: { constexpr int OVF = 64; rc = CALL; } break;                                                   \
-    case 1: { constexpr int OVF = 256; rc = CALL; } break;                                                  \
-    case 2: { constexpr int OVF = 2048; rc = CALL; } break;                                                 \
-    default: rc = fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth); \
-  }
-
-// Runs CALL with M bound to the metric of the handle (other than L2 squared).
-#define PTK_WITH_METRIC(CALL)                                              \
-  switch (t->metric.load()) {                                             \
-    case PTK_METRIC_L1: { using M = ptk::MetricL1; CALL; } break;         \
-    case PTK_METRIC_LPINF: { using M = ptk::MetricLInf; CALL; } break;    \
-    case PTK_METRIC_LNINF: { using M = ptk::MetricLNInf; CALL; } break;   \
-    default: { using M = ptk::MetricL2; CALL; } break;                    \
-  }
-
-// ---- topological metrics (ptk_kernels_topo.hpp) ------------------------------------------------
-bool topological(const ptk_tree* t) {
-  const int m = t->metric.load();
-  return m == PTK_METRIC_SO2 || m == PTK_METRIC_SE2_SQUARED;
-}
-#define PTK_WITH_TOPO(CALL)                                         \
-  if (t->metric.load() == PTK_METRIC_SO2) {                         \
-    using T = ptk::TopoSO2;                                         \
-    CALL;                                                           \
-  } else {                                                          \
-    using T = ptk::TopoSE2;                                         \
-    CALL;                                                           \
-  }
-
-template <int OVF>
-int launch_knn_topo(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, uint32_t k, float e,
-                    ptk::Neighbor* d_out, hipStream_t s, bool short_tree) {
-  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-  const size_t smem = (size_t)16 * 64 * 8;
-  Timer timer(t, s);
-#define PTK_LAUNCH_TOPO_REG(KK)                                                                                         \
-  PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::knn_topo_reg_kernel<KK, 16, OVF, T>), dim3(blocks), dim3(64), smem, s, t->dev, \
-                                     d_q, t->dim, perm, nq, k, inv_ratio(e), d_out); })
-  if (k <= 64 && !short_tree) {
-    if (k <= 4) { PTK_LAUNCH_TOPO_REG(4); }
-    else if (k <= 8) { PTK_LAUNCH_TOPO_REG(8); }
-    else if (k <= 16) { PTK_LAUNCH_TOPO_REG(16); }
-    else if (k <= 32) { PTK_LAUNCH_TOPO_REG(32); }
-    else { PTK_LAUNCH_TOPO_REG(64); }
-  } else {
-    PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::knn_topo_kernel<16, OVF, T>), dim3(blocks), dim3(64), smem, s, t->dev, d_q,
-                                       t->dim, perm, nq, k, inv_ratio(e), d_out); });
-  }
-#undef PTK_LAUNCH_TOPO_REG
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, nq);
-  return PTK_OK;
-}
-
-template <int OVF>
-int launch_radius_topo(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
-                       bool fill, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor* d_out, hipStream_t s) {
-  const uint32_t blocks = (uint32_t)((nq + 63) / 64);
-  const size_t smem = (size_t)16 * 64 * 8;
-  Timer timer(t, s);
-  if (fill) {
-    PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::radius_topo_kernel<16, OVF, true, T>), dim3(blocks), dim3(64), smem, s, t->dev,
-                                       d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out); });
-  } else {
-    PTK_WITH_TOPO({ hipLaunchKernelGGL((ptk::radius_topo_kernel<16, OVF, false, T>), dim3(blocks), dim3(64), smem, s, t->dev,
-                                       d_q, t->dim, perm, nq, radius, inv_ratio(e), d_counts, d_offsets, d_out); });
-  }
-  PTK_HIP(hipGetLastError());
-  timer.stop(0, fill ? 0 : nq);
-  return PTK_OK;
-}
-
 int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                   ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   int rc = PTK_OK;
@@ -1872,6 +923,17 @@ int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uin
 }
 
 }  // namespace
+
+namespace ptkf {
+int morton_bits(uint64_t nq) { return ::morton_bits(nq); }
+size_t sort_tmp_bytes(uint64_t nq, int bits) { return ::sort_tmp_bytes(nq, bits); }
+size_t permutation_scratch_bytes(uint64_t nq) { return ::permutation_scratch_bytes(nq); }
+int sort_pairs_u32(void* tmp, size_t tmp_bytes, uint32_t* keys, uint32_t* keys_out, uint32_t* ids, uint32_t* ids_out,
+                   uint64_t nq, int bits, hipStream_t s) {
+  PTK_HIP(rocprim::radix_sort_pairs<MortonSortConfig>(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
+  return PTK_OK;
+}
+}  // namespace ptkf
 
 // =====================================================================================
 extern "C" {
@@ -2004,7 +1066,6 @@ void ptk_tree_destroy(ptk_tree* t) {
       if (w.fork) (void)hipEventDestroy(w.fork);
       if (w.join) (void)hipEventDestroy(w.join);
       if (w.side) (void)hipStreamDestroy(w.side);
-      if (w.d_sample) (void)hipFree(w.d_sample);
     };
     drain_workspace(t->ws);
     drop_side(t->ws);
@@ -2258,8 +1319,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
       rc = make_permutation(t, d_q, nq, s, scratch, &perm);
       if (rc != PTK_OK) return rc;
     }
-    PTK_WITH_OVF(16, (launch_knn_topo<OVF>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree)));
-    return rc;
+    return ptkf::knn_topo(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree);
   }
   const bool knn1_view = k == 1 && l2 && t->dim <= 3 && t->n_piles != 0 && ovf_class_of(knn1_depth(t), 16) != kDeepClass;
   if (deep_tree(t) && !knn1_view) {  // a few queries at a time, the record stacks spilling to HBM (any k, any metric)
@@ -2273,30 +1333,18 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
     Timer timer(t, s);
     for (uint64_t lo = 0; lo < nq; lo += plan.piece) {
       const uint64_t n = std::min<uint64_t>(plan.piece, nq - lo);
-      const uint32_t blocks = (uint32_t)((n + 63) / 64);
       if (t->dim > 3) {
         ptk::DevTreeND dev = t->dev_nd;
         dev.deep_spill = spill;
         dev.deep_cap = plan.cap;
-        const size_t smem = (size_t)16 * 64 * 8 + (size_t)t->dim * 64 * 8;
-        if (smem > t->lds_per_block)
-          return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-        PTK_WITH_METRIC({
-          rc = allow_lds(ptk::knn_nd_kernel<16, -1, false, M>, smem);
-          if (rc == PTK_OK)
-            hipLaunchKernelGGL((ptk::knn_nd_kernel<16, -1, false, M>), dim3(blocks), dim3(64), smem, s, dev,
-                               d_q + lo * t->dim, nullptr, n, k, inv_ratio(e), o + lo * k);
-        });
-        if (rc != PTK_OK) return rc;
+        rc = ptkf::knn_nd_deep(t, dev, d_q + lo * t->dim, n, k, e, o + lo * k, s);
       } else {
         ptk::DevTree dev = t->dev;
         dev.deep_spill = spill;
         dev.deep_cap = plan.cap;
-        PTK_WITH_METRIC({
-          hipLaunchKernelGGL((ptk::knn_kernel<16, -1, 64, 4, false, M>), dim3(blocks), dim3(64), (size_t)16 * 64 * 8, s,
-                             dev, d_q + lo * t->dim, t->dim, nullptr, n, k, inv_ratio(e), o + lo * k);
-        });
+        rc = ptkf::knn_deep(t, dev, d_q + lo * t->dim, n, k, e, o + lo * k, s);
       }
+      if (rc != PTK_OK) return rc;
       PTK_HIP(hipGetLastError());
     }
     timer.stop(0, nq);
@@ -2318,15 +1366,14 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
     if (rc != PTK_OK) return rc;
   }
   if (t->dim > 3) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn_nd<OVF, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree))));
-    return rc;
+    return ptkf::knn_nd(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree);
   }
   if (k == 1 && l2) {  // the two-phase search is built for the default metric
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else if (k <= knn_reg_max(l2) && !short_tree) {
-    PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_knn_reg<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, &scratch))));
+    rc = ptkf::knn_reg(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, &scratch);
   } else {
-    PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_knn<16, OVF, 64, 4, M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+    rc = ptkf::knn_rows(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s);
   }
   return rc;
 }
@@ -2409,7 +1456,7 @@ static bool is_pinned_host(const void* p, size_t bytes) {
 // PTK_HOST_PIECE = n: equal pieces of n queries (experiments).
 static std::vector<uint64_t> host_pieces(uint64_t nq, uint32_t k, bool two_phase, bool capped) {
   std::vector<uint64_t> first;
-  const int forced = env_int("PTK_HOST_PIECE", 0);
+  const int forced = knob_int("host_piece", 0);
   if (forced > 0) {
     for (uint64_t lo = 0; lo < nq; lo += (uint64_t)forced) first.push_back(lo);
   } else if (!two_phase && !capped) {
@@ -2468,11 +1515,11 @@ static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint3
   rc = grow_device_block(&io.d_in, &io.in_capacity, (size_t)nq * row_in);
   if (rc == PTK_OK) rc = grow_device_block(&io.d_out, &io.out_capacity, (size_t)nq * row_out);
   if (rc != PTK_OK) return rc;
-  const int n_search_streams = env_int("PTK_HOST_STREAMS", 2);
+  const int n_search_streams = 2;
   // Arrays that are page-locked already (ptk_host_alloc: what the Python wrapper returns its rows in) are copied to
   // and from directly; pageable ones go through the handle's pinned rings.
-  const bool in_pinned = env_int("PTK_HOST_DIRECT", 1) != 0 && is_pinned_host(q, (size_t)nq * row_in);
-  const bool out_pinned = env_int("PTK_HOST_DIRECT", 1) != 0 && is_pinned_host(out, (size_t)nq * row_out);
+  const bool in_pinned = knob_int("host_direct", 1) != 0 && is_pinned_host(q, (size_t)nq * row_in);
+  const bool out_pinned = knob_int("host_direct", 1) != 0 && is_pinned_host(out, (size_t)nq * row_out);
   if (!in_pinned) rc = grow_pinned_ring(io.h_in, &io.h_in_capacity, (size_t)piece * row_in, (int)std::min<uint64_t>(pieces, HostIo::kRing));
   // The rows of a piece come down in chunks of at most 32 MB, each copied into the caller's array while the next
   // is on the link (a piece of knn = 16 rows is 300 MB: one copy per piece left the host copy exposed).
@@ -2503,7 +1550,7 @@ static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint3
   if (rc != PTK_OK) return rc;
   if (io.pool == nullptr) {
     const unsigned hc = std::thread::hardware_concurrency();
-    const int want = env_int("PTK_IO_THREADS", hc >= 16 ? 8 : (hc >= 4 ? (int)hc / 2 : 1));
+    const int want = hc >= 16 ? 8 : (hc >= 4 ? (int)hc / 2 : 1);
     io.pool.reset(new CopyPool((unsigned)std::max(0, want - 1)));  // (the calling threads copy too)
   }
   float* d_q = reinterpret_cast<float*>(io.d_in);
@@ -2511,7 +1558,7 @@ static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint3
   const char* src = reinterpret_cast<const char*>(q);
   char* dst = reinterpret_cast<char*>(out);
 
-  const bool trace = env_int("PTK_HOST_TRACE", 0) != 0;
+  const bool trace = knob_int("host_trace", 0) != 0;
   const auto t_begin = std::chrono::steady_clock::now();
   auto stamp = [&](const char* what, uint64_t i) {
     if (!trace) return;
@@ -2690,30 +1737,19 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     uint32_t* n_over = scratch.take<uint32_t>(1);
     if (over_list == nullptr || n_over == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
     if (ws.cap_lists) {  // (3-D trees: the rows are made from the leaf lists of the count pass)
-      PTK_WITH_METRIC((rc = launch_radius_replay<M>(t, d_q, e, ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
-                                                    over_list, n_over, s)));
+      rc = ptkf::radius_replay(t, d_q, e, ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over, s);
       if (rc != PTK_OK) return rc;
     } else {
-      Timer timer(t, s);
-      PTK_HIP(hipMemsetAsync(n_over, 0, 4, s));
-      constexpr int W = 1;  // (one wavefront per block: the LDS of a CU divides evenly)
-      const size_t hold = (size_t)W * ptk::kLogScatterLds;  // a staged and a sorted chunk per wavefront
-      rc = allow_lds(ptk::radius_log_scatter_kernel<W>, hold);
+      rc = ptkf::radius_log_scatter(t, ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over, s);
       if (rc != PTK_OK) return rc;
-      hipLaunchKernelGGL((ptk::radius_log_scatter_kernel<W>), dim3((ws.cap.n_static + W - 1) / W), dim3(64 * W), hold, s,
-                         ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over);
-      PTK_HIP(hipGetLastError());
-      timer.stop(0, 0);
     }
     // Rows the capture could not hold (possibly none: the blocks then leave at once).
     if (nd) {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, true, nullptr, d_offsets,
-                                                                 reinterpret_cast<ptk::Neighbor*>(d_out), s, over_list,
-                                                                 n_over))));
+      rc = ptkf::radius_nd(t, d_q, nq, radius, e, true, nullptr, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s,
+                           over_list, n_over);
     } else {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, kGenLeafB, M>(t, d_q, over_list, nq, radius, e, true, nullptr,
-                                                                         d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out),
-                                                                         s, n_over))));
+      rc = ptkf::radius_traverse(t, d_q, over_list, nq, radius, e, true, nullptr, d_offsets,
+                                 reinterpret_cast<ptk::Neighbor*>(d_out), s, n_over);
     }
   } else if (topological(t)) {  // count pass and fill pass both traverse (no capture)
     if (deep_tree(t)) return fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth);
@@ -2725,8 +1761,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       rc = make_permutation(t, d_q, nq, s, scratch, &perm);
       if (rc != PTK_OK) return rc;
     }
-    PTK_WITH_OVF(16, (launch_radius_topo<OVF>(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
-                                              reinterpret_cast<ptk::Neighbor*>(d_out), s)));
+    rc = ptkf::radius_topo(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s);
   } else if (deep_tree(t)) {  // record stacks spilling to HBM, a few queries per launch, no capture
     if (!fill) ws.cap_valid = false;
     const DeepPlan plan = deep_plan(t, nq);
@@ -2738,49 +1773,26 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     Timer timer(t, s);
     for (uint64_t lo = 0; lo < nq; lo += plan.piece) {
       const uint64_t n = std::min<uint64_t>(plan.piece, nq - lo);
-      const uint32_t blocks = (uint32_t)((n + 63) / 64);
       uint64_t* c = fill ? nullptr : d_counts + lo;
       const uint64_t* of = fill ? d_offsets + lo : nullptr;
       if (nd) {
         ptk::DevTreeND dev = t->dev_nd;
         dev.deep_spill = spill;
         dev.deep_cap = plan.cap;
-        const size_t smem = (size_t)16 * 64 * 8 + (size_t)t->dim * 64 * 8;
-        if (smem > t->lds_per_block)
-          return fail(PTK_ERR_UNSUPPORTED, "dimension %u does not fit the LDS staging of the device search", t->dim);
-        PTK_WITH_METRIC({
-          if (fill) {
-            rc = allow_lds(ptk::radius_nd_kernel<16, -1, true, M>, smem);
-            if (rc == PTK_OK)
-              hipLaunchKernelGGL((ptk::radius_nd_kernel<16, -1, true, M>), dim3(blocks), dim3(64), smem, s, dev,
-                                 d_q + lo * t->dim, n, radius, inv_ratio(e), c, of, o, nullptr, nullptr);
-          } else {
-            rc = allow_lds(ptk::radius_nd_kernel<16, -1, false, M>, smem);
-            if (rc == PTK_OK)
-              hipLaunchKernelGGL((ptk::radius_nd_kernel<16, -1, false, M>), dim3(blocks), dim3(64), smem, s, dev,
-                                 d_q + lo * t->dim, n, radius, inv_ratio(e), c, of, o, nullptr, nullptr);
-          }
-        });
-        if (rc != PTK_OK) return rc;
+        rc = ptkf::radius_nd_deep(t, dev, d_q + lo * t->dim, n, radius, e, fill, c, of, o, s);
       } else {
         ptk::DevTree dev = t->dev;
         dev.deep_spill = spill;
         dev.deep_cap = plan.cap;
-        PTK_WITH_METRIC({
-          if (fill)
-            hipLaunchKernelGGL((ptk::radius_kernel<16, -1, 64, 4, true, M>), dim3(blocks), dim3(64), (size_t)16 * 64 * 8, s,
-                               dev, d_q + lo * t->dim, t->dim, nullptr, n, radius, inv_ratio(e), c, of, o, nullptr);
-          else
-            hipLaunchKernelGGL((ptk::radius_kernel<16, -1, 64, 4, false, M>), dim3(blocks), dim3(64), (size_t)16 * 64 * 8, s,
-                               dev, d_q + lo * t->dim, t->dim, nullptr, n, radius, inv_ratio(e), c, of, o, nullptr);
-        });
+        rc = ptkf::radius_deep(t, dev, d_q + lo * t->dim, n, radius, e, fill, c, of, o, s);
       }
+      if (rc != PTK_OK) return rc;
       PTK_HIP(hipGetLastError());
     }
     timer.stop(0, fill ? 0 : nq);
   } else {
     const bool capture = !fill && prepare_capture(t, nq, ws);
-    const bool lists = capture && !nd && env_int("PTK_RADIUS_LISTS", 1) != 0;
+    const bool lists = capture && !nd && knob_int("radius_lists", 1) != 0;
     if (!fill) ws.cap_valid = false;
     rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
     if (rc != PTK_OK) return rc;
@@ -2791,13 +1803,11 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     }
     if (capture) {
       if (nd) {
-        PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd_capture<OVF, M>(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s))));
+        rc = ptkf::radius_nd_capture(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s);
       } else if (lists) {  // the count pass lists the leaves with hits for the fill pass
-        PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_radius_list<kGenRing, OVF, kGenLeafB, M>(t, d_q, perm, nq, radius, e, d_counts,
-                                                                                ws.cap, s))));
+        rc = ptkf::radius_list(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s);
       } else {
-        PTK_WITH_METRIC(PTK_WITH_OVF(kGenRing, (launch_radius_capture<kGenRing, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, radius, e, d_counts,
-                                                                                   ws.cap, s))));
+        rc = ptkf::radius_capture(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s);
       }
       if (rc == PTK_OK) {
         ws.cap_valid = true;
@@ -2810,11 +1820,10 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
         ws.cap_stream = s;
       }
     } else if (nd) {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius_nd<OVF, M>(t, d_q, nq, radius, e, fill, d_counts, d_offsets,
-                                                                 reinterpret_cast<ptk::Neighbor*>(d_out), s, perm))));
+      rc = ptkf::radius_nd(t, d_q, nq, radius, e, fill, d_counts, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s, perm);
     } else {
-      PTK_WITH_METRIC(PTK_WITH_OVF(16, (launch_radius<16, OVF, 64, kGenLeafB, M>(t, d_q, perm, nq, radius, e, fill, d_counts,
-                                                                         d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s))));
+      rc = ptkf::radius_traverse(t, d_q, perm, nq, radius, e, fill, d_counts, d_offsets,
+                                 reinterpret_cast<ptk::Neighbor*>(d_out), s);
     }
   }
   if (rc == PTK_OK && fill && sort) {
@@ -3223,7 +2232,8 @@ int ptk_debug_knn1_counts(const ptk_tree* t, uint32_t counts[4]) {
   }
   if (holder == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle was not a two-phase k = 1 search");
   std::lock_guard<std::mutex> lock(holder->mutex);
-  if (holder->last_meta == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle was not a two-phase k = 1 search");
+  if (holder->last_meta == nullptr || holder->last_meta_kind != 1)
+    return fail(PTK_ERR_INVALID, "the last search of this handle was not a two-phase k = 1 search");
   uint32_t meta[ptk::kMetaWords];
   PTK_HIP(hipDeviceSynchronize());
   PTK_HIP(hipMemcpy(meta, holder->last_meta, sizeof(meta), hipMemcpyDeviceToHost));
@@ -3246,11 +2256,14 @@ int ptk_debug_knn_coop_counts(const ptk_tree* t, uint32_t counts[7]) {
   }
   if (holder == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle left no counters");
   std::lock_guard<std::mutex> lock(holder->mutex);
-  if (holder->last_meta == nullptr) return fail(PTK_ERR_INVALID, "the last search of this handle left no counters");
+  if (holder->last_meta == nullptr || holder->last_meta_kind != 2)
+    return fail(PTK_ERR_INVALID, "the last search of this handle was not a capped k > 1 search");
   uint32_t meta[ptk::kMetaWords];
   PTK_HIP(hipDeviceSynchronize());
   PTK_HIP(hipMemcpy(meta, holder->last_meta, sizeof(meta), hipMemcpyDeviceToHost));
-  counts[0] = meta[ptk::kMetaHeavy] + meta[ptk::kMetaHeavyRest];
+  // (a query that found its list full went on in its lane, Handover::full_keeps: the counters run past the lists)
+  counts[0] = std::min(meta[ptk::kMetaHeavy], holder->last_meta_cap[0]) +
+              std::min(meta[ptk::kMetaHeavyRest], holder->last_meta_cap[1]);
   counts[1] = meta[ptk::kMetaRedo];
   counts[2] = meta[ptk::kKnnWhyPool];
   counts[3] = meta[ptk::kKnnWhyTie];
@@ -3549,5 +2562,3 @@ int ptk_forest_search_knn(const ptk_forest* f, const float* q, uint64_t nq, uint
 #include "ptk_host_loop.hpp"
 #include "ptk_multi.hpp"
 
-// ---- double precision (ptk_tree64_* / ptk_search64_*) -------------------------------------
-#include "ptk_backend_f64.hpp"

@@ -185,7 +185,7 @@ struct Stack64Lease {
 };
 
 bool want_reorder64(uint64_t nq) { return nq >= 8192 && nq < (1ull << 32); }
-size_t permutation64_bytes(uint64_t nq) { return want_reorder64(nq) ? permutation_scratch_bytes(nq) + 5 * 256 : 0; }
+size_t permutation64_bytes(uint64_t nq) { return want_reorder64(nq) ? ptkf::permutation_scratch_bytes(nq) + 5 * 256 : 0; }
 
 // Device-side Morton ordering of a batch (make_permutation of the float32 side): *perm lists the
 // query rows in launch order; it lives in the lease's aux block.
@@ -193,8 +193,8 @@ int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipS
                        const uint32_t** perm) {
   *perm = nullptr;
   if (!want_reorder64(nq)) return PTK_OK;
-  const int bits = morton_bits(nq);
-  size_t tmp_bytes = sort_tmp_bytes(nq, bits);
+  const int bits = ptkf::morton_bits(nq);
+  size_t tmp_bytes = ptkf::sort_tmp_bytes(nq, bits);
   auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
   char* p = lease.aux;
   uint32_t* keys = reinterpret_cast<uint32_t*>(p);
@@ -214,7 +214,8 @@ int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipS
   }
   hipLaunchKernelGGL(ptk::morton64_kernel, dim3((uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock)), dim3(ptk::kBlock), 0, s,
                      d_q, t->dim, nq, box, (uint32_t)(30 - bits), keys, ids);
-  PTK_HIP(rocprim::radix_sort_pairs(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, 0, bits, s));
+  const int rc_sort = ptkf::sort_pairs_u32(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, bits, s);
+  if (rc_sort != PTK_OK) return rc_sort;
   *perm = ids_out;
   return PTK_OK;
 }

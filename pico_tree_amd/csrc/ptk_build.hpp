@@ -41,6 +41,13 @@
 
 #include "pico_tree/internal/flat_tree.hpp"
 
+// A kernel that is not a template is defined in a header several translation units include (ptk_backend_core.hpp):
+// internal linkage, so every unit that launches it has its own and the units that do not emit nothing.
+#ifndef PTK_GLOBAL
+#define PTK_GLOBAL static __global__
+#endif
+
+
 namespace ptk {
 
 struct BuildSeg {
@@ -54,13 +61,13 @@ struct BuildSeg {
 constexpr uint32_t kBuildMaxDim = 8;
 constexpr uint32_t kBuildBoxBlocks = 1024;
 
-__global__ __launch_bounds__(256) void build_iota_kernel(int32_t* __restrict__ idx, uint32_t n) {
+PTK_GLOBAL __launch_bounds__(256) void build_iota_kernel(int32_t* __restrict__ idx, uint32_t n) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
   if (i < n) idx[i] = (int32_t)i;
 }
 
 // Per block: min and max of every coordinate over a slice of the points (exact: any grouping gives the same box).
-__global__ __launch_bounds__(256) void build_box_kernel(
+PTK_GLOBAL __launch_bounds__(256) void build_box_kernel(
     const float* __restrict__ pts, uint32_t n, uint32_t dim, float* __restrict__ partial) {
   __shared__ float lo[256], hi[256];
   for (uint32_t a = 0; a < dim; ++a) {
@@ -100,7 +107,7 @@ __device__ __forceinline__ uint32_t build_find(const BuildSeg* __restrict__ segs
   return i < segs[lo - 1].end ? lo - 1 : nsegs;
 }
 
-__global__ __launch_bounds__(256) void build_flag_kernel(
+PTK_GLOBAL __launch_bounds__(256) void build_flag_kernel(
     const float* __restrict__ pts, uint32_t dim, const int32_t* __restrict__ idx, const BuildSeg* __restrict__ segs,
     uint32_t nsegs, uint32_t n, uint32_t* __restrict__ flags) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void build_flag_kernel(
   flags[i] = f;  // (flags[n] = 0: the scan then also yields the total)
 }
 
-__global__ void build_cut_kernel(const uint32_t* __restrict__ sums, BuildSeg* __restrict__ segs, uint32_t nsegs) {
+PTK_GLOBAL void build_cut_kernel(const uint32_t* __restrict__ sums, BuildSeg* __restrict__ segs, uint32_t nsegs) {
   const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nsegs) return;
   const uint32_t b = segs[s].begin;
@@ -122,7 +129,7 @@ __global__ void build_cut_kernel(const uint32_t* __restrict__ sums, BuildSeg* __
   segs[s].pass_left = sums[b + m] - sums[b];
 }
 
-__global__ __launch_bounds__(256) void build_list_kernel(
+PTK_GLOBAL __launch_bounds__(256) void build_list_kernel(
     const uint32_t* __restrict__ flags, const uint32_t* __restrict__ sums, const BuildSeg* __restrict__ segs,
     uint32_t nsegs, uint32_t n, uint32_t* __restrict__ from_left, uint32_t* __restrict__ from_right) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -138,7 +145,7 @@ __global__ __launch_bounds__(256) void build_list_kernel(
   }
 }
 
-__global__ __launch_bounds__(256) void build_swap_kernel(
+PTK_GLOBAL __launch_bounds__(256) void build_swap_kernel(
     int32_t* __restrict__ idx, const BuildSeg* __restrict__ segs, uint32_t nsegs, uint32_t n,
     const uint32_t* __restrict__ from_left, const uint32_t* __restrict__ from_right) {
   const uint32_t i = blockIdx.x * 256u + threadIdx.x;
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(256) void build_swap_kernel(
 // decides which side is kept, exactly as __introselect does.  Once the range is small the host finishes the SAME
 // call -- std::__introselect on what is left, with what is left of its depth limit -- so the outcome is libstdc++'s
 // to the last swap (tests/test_device_build.py: byte-identical trees on clouds whose planes slide).
-__global__ void slide_pivot_kernel(const float* __restrict__ pts, uint32_t dim, uint32_t axis, int32_t* __restrict__ idx,
+PTK_GLOBAL void slide_pivot_kernel(const float* __restrict__ pts, uint32_t dim, uint32_t axis, int32_t* __restrict__ idx,
                                    uint32_t first, uint32_t last, float* __restrict__ pivot) {
   // __move_median_to_first(result = first, a = first + 1, b = mid, c = last - 1)
   const uint32_t a = first + 1u, b = first + (last - first) / 2u, c = last - 1u;
@@ -197,7 +204,7 @@ __global__ void slide_pivot_kernel(const float* __restrict__ pts, uint32_t dim, 
 }
 
 // flags[i - lo] = {left stop, right stop << 32} for the positions [lo, hi); flags[hi - lo] = 0 (the scan's total).
-__global__ __launch_bounds__(256) void slide_flag_kernel(const float* __restrict__ pts, uint32_t dim, uint32_t axis,
+PTK_GLOBAL __launch_bounds__(256) void slide_flag_kernel(const float* __restrict__ pts, uint32_t dim, uint32_t axis,
                                                          const int32_t* __restrict__ idx, uint32_t lo, uint32_t hi,
                                                          const float* __restrict__ pivot,
                                                          unsigned long long* __restrict__ flags) {
@@ -212,7 +219,7 @@ __global__ __launch_bounds__(256) void slide_flag_kernel(const float* __restrict
 }
 
 // left_list[k] = position of the k-th left stop (ascending), right_list[k] = position of the k-th right stop (descending).
-__global__ __launch_bounds__(256) void slide_list_kernel(const unsigned long long* __restrict__ flags,
+PTK_GLOBAL __launch_bounds__(256) void slide_list_kernel(const unsigned long long* __restrict__ flags,
                                                          const unsigned long long* __restrict__ sums, uint32_t lo,
                                                          uint32_t hi, uint32_t* __restrict__ left_list,
                                                          uint32_t* __restrict__ right_list) {
@@ -227,7 +234,7 @@ __global__ __launch_bounds__(256) void slide_list_kernel(const unsigned long lon
 // the function returns is where the left pointer stands then: it has moved on from left stop K - 1 to the next element
 // that is not below the pivot -- left stop K, unless it first meets the element it swapped into right stop K - 1:
 // *cut = min(left stop K, right stop K - 1)   (K = 0: left stop 0, which a median-of-three pivot guarantees).
-__global__ __launch_bounds__(256) void slide_pair_kernel(int32_t* __restrict__ idx, const unsigned long long* __restrict__ sums,
+PTK_GLOBAL __launch_bounds__(256) void slide_pair_kernel(int32_t* __restrict__ idx, const unsigned long long* __restrict__ sums,
                                                          uint32_t n_range, const uint32_t* __restrict__ left_list,
                                                          const uint32_t* __restrict__ right_list, uint32_t* __restrict__ cut) {
   const unsigned long long total = sums[n_range];
@@ -382,7 +389,7 @@ bool device_top_build(const float* points, uint64_t n, uint32_t dim, size_t max_
 #else
     constexpr bool kKnownIntroselect = false;
 #endif
-    if (kKnownIntroselect && seg.end - seg.begin > kHostBelow && std::getenv("PTK_DEVICE_SLIDE_OFF") == nullptr) {
+    if (kKnownIntroselect && seg.end - seg.begin > kHostBelow && knob_int("device_slide_off", 0) == 0) {
       size_t first = seg.begin, last = seg.end;
       const size_t nth_pos = seg.begin + nth;
       long depth_limit = 2 * (long)std::__lg((long)(last - first));

@@ -47,6 +47,12 @@
 #include <type_traits>
 #include <utility>
 
+// A kernel that is not a template is defined in a header several translation units include (ptk_backend_core.hpp):
+// internal linkage, so every unit that launches it has its own and the units that do not emit nothing.
+#ifndef PTK_GLOBAL
+#define PTK_GLOBAL static __global__
+#endif
+
 namespace ptk {
 
 // ---- device tree --------------------------------------------------------------
@@ -742,6 +748,11 @@ struct Task {
 // entry of that list to hand to a group, queries the cooperative search could not certify.
 constexpr uint32_t kMetaHeavy = 24, kMetaRedo = 26, kMetaRanked = 3;
 constexpr uint32_t kMetaHeavyRest = 27;  // k > 1: the list of the second of two capped launches side by side
+// Words of the counters block (Handover::meta) the cooperative search adds to: why a query went to the redo list
+// (pool / spill overflow or a hand-over it cannot start from; more equal distances than the second sweep holds; a box
+// distance above the k-th distance on the way to a neighbour; a k-th distance outside [1e-30, 1e30]) and how many
+// queries took the second sweep.
+constexpr uint32_t kKnnWhyPool = 8, kKnnWhyTie = 9, kKnnWhyBox = 10, kKnnWhyRange = 11, kKnnTieSweeps = 12;
 constexpr uint32_t kMaxTasks = 64;               // tasks a capped traversal can hand over per query
 constexpr uint32_t kTasksFromRoot = 0xFFFFFFFFu;  // more than that (or no room): search again from the root
 constexpr uint32_t kTasksRedo = 0xFFFFFFFEu;      // non-monotone box distances met: only the reference order will do
@@ -1780,7 +1791,7 @@ __device__ inline void write_phase_meta(const Cont& cont, uint32_t n2, uint32_t 
 
 // Behind a full 16-bit radix sort of the keys (searches without the cap): the boundaries by binary search.
 static_assert(kHeavyClass < kRankedClass && kHeavyClass >= 1u, "the dealt tier begins inside the unranked classes");
-__global__ void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, uint32_t nq, Cont cont,
+PTK_GLOBAL void knn1_phase_meta_kernel(const ContKey* __restrict__ sorted_key, uint32_t nq, Cont cont,
                                        TierSpec tiers, uint32_t max_narrow_waves) {
   auto first_at_least = [&](uint32_t k) {  // sorted_key is ascending
     uint32_t lo = 0, hi = nq;
@@ -1814,7 +1825,7 @@ constexpr uint32_t kClassBuckets = 8;
 //                         bucket-major table of segment totals, at most 128 words) + the prefix of its first tile
 constexpr uint32_t kClassMaxSegs = 16;
 
-__global__ __launch_bounds__(64) void class_scan_kernel(uint32_t* __restrict__ counts, uint32_t ntiles, uint32_t stride,
+PTK_GLOBAL __launch_bounds__(64) void class_scan_kernel(uint32_t* __restrict__ counts, uint32_t ntiles, uint32_t stride,
                                                         uint32_t seg, uint32_t* __restrict__ seg_totals) {
   const uint32_t lane = threadIdx.x;
   const uint32_t segs = gridDim.x / kClassBuckets;
@@ -1863,7 +1874,7 @@ __global__ __launch_bounds__(64) void class_scan_kernel(uint32_t* __restrict__ c
 }
 
 // `prefix` = the counts after class_scan_kernel.  per: slots per chunk, a multiple of 64.
-__global__ __launch_bounds__(64) void class_order_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
+PTK_GLOBAL __launch_bounds__(64) void class_order_kernel(const ContKey* __restrict__ keys, uint32_t nq, uint32_t per,
                                                          const uint32_t* __restrict__ prefix, uint32_t stride,
                                                          uint32_t seg, uint32_t segs,
                                                          const uint32_t* __restrict__ seg_totals,
@@ -2617,7 +2628,7 @@ __global__ __launch_bounds__(64) void box_kernel(
 // Sorts every row ascending by distance (heap sort, in place, one row per lane).
 // std::sort in the reference is unstable, so the order among equal distances is
 // unspecified on both sides.
-__global__ __launch_bounds__(kBlock) void sort_rows_kernel(
+PTK_GLOBAL __launch_bounds__(kBlock) void sort_rows_kernel(
     uint64_t nq, const uint64_t* __restrict__ offsets, Neighbor* __restrict__ out) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nq) return;
@@ -2647,7 +2658,7 @@ __global__ __launch_bounds__(kBlock) void sort_rows_kernel(
 
 // Point records of the device tree: pts[pos] = {point indices[pos], bits(indices[pos])} in leaf
 // order, the kLeafPad records behind the last point repeat it (see ptk_encode.hpp).
-__global__ __launch_bounds__(kBlock) void encode_points_kernel(
+PTK_GLOBAL __launch_bounds__(kBlock) void encode_points_kernel(
     const float* __restrict__ points, uint32_t dim, const int32_t* __restrict__ indices, uint64_t n,
     float4* __restrict__ pts) {
   const uint64_t pos = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -2674,7 +2685,7 @@ struct DevPiles {
   const DevPileRecord* recs;
   uint32_t n_points;
 };
-__global__ __launch_bounds__(kBlock) void resolve_piles_kernel(const float* __restrict__ queries, uint32_t dim, uint64_t nq,
+PTK_GLOBAL __launch_bounds__(kBlock) void resolve_piles_kernel(const float* __restrict__ queries, uint32_t dim, uint64_t nq,
                                                                 DevPiles piles, Neighbor* __restrict__ rows) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nq) return;
@@ -2761,7 +2772,7 @@ __device__ __forceinline__ uint32_t order_key(float x, float y, float z, float3 
 // Points per cell of the coarse grid (at creation), then its class byte.  The points come in leaf order, so the
 // lanes of a wavefront hold runs of the same cell: one atomic per run (its first lane adds the run's length) instead of
 // one per point (7.7 M atomics on 262 k words took 4.6 ms, the dense cells serialising).
-__global__ __launch_bounds__(kBlock) void cell_count_kernel(const float4* __restrict__ pts, uint64_t n, float3 lo, float3 inv,
+PTK_GLOBAL __launch_bounds__(kBlock) void cell_count_kernel(const float4* __restrict__ pts, uint64_t n, float3 lo, float3 inv,
                                                             uint3 bits, uint32_t* __restrict__ counts) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   const bool valid = i < n;
@@ -2778,7 +2789,7 @@ __global__ __launch_bounds__(kBlock) void cell_count_kernel(const float4* __rest
     atomicAdd(&counts[cell], len);
   }
 }
-__global__ __launch_bounds__(kBlock) void cell_class_kernel(const uint32_t* __restrict__ counts, uint64_t n_cells,
+PTK_GLOBAL __launch_bounds__(kBlock) void cell_class_kernel(const uint32_t* __restrict__ counts, uint64_t n_cells,
                                                             uint8_t* __restrict__ occ) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= n_cells) return;
@@ -2788,7 +2799,7 @@ __global__ __launch_bounds__(kBlock) void cell_class_kernel(const uint32_t* __re
   occ[i] = (uint8_t)v;
 }
 
-__global__ __launch_bounds__(kBlock) void morton_kernel(
+PTK_GLOBAL __launch_bounds__(kBlock) void morton_kernel(
     const float* __restrict__ queries, uint32_t dim, uint64_t nq, float3 lo, float3 inv, uint3 bits,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, CellTable cells = CellTable{}, uint64_t begin = 0) {
   const uint64_t i = begin + (uint64_t)blockIdx.x * kBlock + threadIdx.x;  // rows [begin, nq) of the batch
@@ -2811,7 +2822,7 @@ __global__ __launch_bounds__(kBlock) void morton_kernel(
 // state[0] back to 0 for the next batch.  The kernels of the sort and phase 1 of the search read state[1]: a coherent
 // batch leaves the sort's kernels at their first instruction and is searched in the caller's order.
 constexpr uint32_t kCoherenceWindows = 256;
-__global__ __launch_bounds__(64) void coherence_sample_kernel(const float* __restrict__ queries, uint32_t dim, uint64_t nq,
+PTK_GLOBAL __launch_bounds__(64) void coherence_sample_kernel(const float* __restrict__ queries, uint32_t dim, uint64_t nq,
                                                               float3 lo, float3 inv, uint3 bits, uint32_t max_log2,
                                                               uint8_t* __restrict__ fail, uint32_t* __restrict__ state = nullptr) {
   const uint32_t w = blockIdx.x, lane = threadIdx.x;

@@ -71,11 +71,8 @@
 
 namespace ptk {
 
-// Words of the counters block (Handover::meta) the cooperative search adds to: why a query went to the redo list
-// (pool / spill overflow or a hand-over it cannot start from; more equal distances than the second sweep holds; a box
-// distance above the k-th distance on the way to a neighbour; a k-th distance outside [1e-30, 1e30]) and how many
-// queries took the second sweep.
-constexpr uint32_t kKnnWhyPool = 8, kKnnWhyTie = 9, kKnnWhyBox = 10, kKnnWhyRange = 11, kKnnTieSweeps = 12;
+// (the words of the counters block this search adds to -- kKnnWhyPool .. kKnnTieSweeps -- are named in ptk_kernels.hpp,
+// next to the other counters: the unit that reads them back does not include this file)
 constexpr uint32_t kKnnTieSlots = 64;        // points at a distance <= D the second sweep can rank
 constexpr uint32_t kKnnPosFlag = 0x80000000u;  // second sweep: the entry is a record position (else: its rank in the handed-over list)
 

@@ -701,7 +701,7 @@ __global__ __launch_bounds__(64) void radius64_kernel(
 struct Morton64Box {
   double lo[3], inv[3];
 };
-__global__ __launch_bounds__(kBlock) void morton64_kernel(
+PTK_GLOBAL __launch_bounds__(kBlock) void morton64_kernel(
     const double* __restrict__ queries, uint32_t dim, uint64_t nq, Morton64Box box, uint32_t drop,
     uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
@@ -717,7 +717,7 @@ __global__ __launch_bounds__(kBlock) void morton64_kernel(
 
 // Rows ascending by distance (kd_tree.hpp:263-265: std::sort, ties in unspecified order; here
 // ties go by index so the result is deterministic).  One lane per row, heap sort in place.
-__global__ __launch_bounds__(kBlock) void sort_rows64_kernel(
+PTK_GLOBAL __launch_bounds__(kBlock) void sort_rows64_kernel(
     const uint64_t* __restrict__ offsets, uint64_t nq, Neighbor64* __restrict__ out) {
   const uint64_t qi = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (qi >= nq) return;

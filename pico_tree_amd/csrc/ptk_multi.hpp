@@ -392,7 +392,7 @@ int ptk_multi_search_knn_device(ptk_multi* m, const float* d_q, uint64_t nq, uin
   const uint32_t n = (uint32_t)m->devices.size();
   // PTK_MULTI_SELF_GATHER=1 (tests on a one-GPU box): devices[0] sends its own rows to itself too,
   // so that the RCCL path runs whatever the number of devices.
-  const bool self = env_int("PTK_MULTI_SELF_GATHER", 0) != 0;
+  const bool self = knob_int("multi_self_gather", 0) != 0;
   hipStream_t s0 = static_cast<hipStream_t>(stream);  // null = the default stream of devices[0], as everywhere in HIP
   int rc = PTK_OK;
   if (m->replicas) {

@@ -111,7 +111,7 @@ __global__ __launch_bounds__(64) void radix_hist_kernel(
 // Row blockIdx.x of hist (one digit: `tiles` counters, row stride a multiple of 4): exclusive prefix in place, row
 // total -> totals[blockIdx.x].  1024 counters per step: a lane takes 16 consecutive ones (four 16-byte loads), one
 // wavefront scan joins the 64 runs.
-__global__ __launch_bounds__(64) void radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t tiles, uint32_t stride,
+PTK_GLOBAL __launch_bounds__(64) void radix_scan_kernel(uint32_t* __restrict__ hist, uint32_t tiles, uint32_t stride,
                                                         uint32_t* __restrict__ totals) {
   const uint32_t lane = threadIdx.x;
   uint4* row = reinterpret_cast<uint4*>(hist + (uint64_t)blockIdx.x * stride);

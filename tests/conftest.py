@@ -51,3 +51,10 @@ def gpu():
     if not have_gpu():
         pytest.skip("no GPU visible")
     return 0
+
+
+@pytest.fixture(autouse=True)
+def _no_test_knobs_left_behind():
+    """The test hooks of the library (pico_tree_amd.set_test_knobs -> PTK_TEST_KNOBS) never outlive the test that set them."""
+    yield
+    os.environ.pop("PTK_TEST_KNOBS", None)

@@ -299,8 +299,7 @@ def test_knn_cap_follows_the_batch(monkeypatch):
         assert lib.ptk_debug_knn_cap(nq, k, np.float32(e), ctypes.byref(c), ctypes.byref(entries)) == 0
         return c.value, entries.value
 
-    monkeypatch.delenv("PTK_KNN_CAP", raising=False)
-    monkeypatch.delenv("PTK_KNN_CAP_MIN_NQ", raising=False)
+    monkeypatch.delenv("PTK_TEST_KNOBS", raising=False)
     sizes = [256, 1_000, 20_000, 150_000, 600_000, 900_000, 2_400_000, 7_200_863, 50_000_000]
     for k, floor, top in ((2, 8, 256), (4, 8, 256), (8, 12, 320), (16, 16, 448), (32, 32, 512), (56, 64, 768)):
         caps = [cap(nq, k)[0] for nq in sizes]
@@ -310,12 +309,11 @@ def test_knn_cap_follows_the_batch(monkeypatch):
     for nq in sizes:
         entries = cap(nq, 16)[1]
         assert min(nq, 24_576) <= entries <= max(nq // 48, 24_576)
-    monkeypatch.setenv("PTK_KNN_CAP", "77")
+    pt.set_test_knobs(knn_cap=77)
     assert cap(5_000, 16)[0] == 77 and cap(7_200_863, 4)[0] == 77
-    monkeypatch.setenv("PTK_KNN_CAP", "0")
+    pt.set_test_knobs(knn_cap=0)
     assert cap(7_200_863, 16) == (0, 0)
-    monkeypatch.delenv("PTK_KNN_CAP")
-    monkeypatch.setenv("PTK_KNN_CAP_MIN_NQ", "1")
+    pt.set_test_knobs(knn_cap=None, knn_cap_min_nq=1)
     assert cap(3, 16)[0] == 16
     assert lib.ptk_debug_knn_cap(10, 16, np.float32(1.0), None, None) == -1
 

@@ -63,7 +63,7 @@ def test_planes_that_slide_in_the_top_levels(gpu, monkeypatch, case):
     dev = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
     for x, y in zip(host.flat(), dev.flat()):
         assert np.asarray(x).tobytes() == np.asarray(y).tobytes()
-    monkeypatch.setenv("PTK_DEVICE_SLIDE_OFF", "1")  # (the round trip to the host for the whole range: the same tree)
+    pt.set_test_knobs(device_slide_off=1)  # (the round trip to the host for the whole range: the same tree)
     dev2 = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
     for x, y in zip(host.flat(), dev2.flat()):
         assert np.asarray(x).tobytes() == np.asarray(y).tobytes()

@@ -350,7 +350,7 @@ def test_metric_round_trips_through_saved_file(gpu, tmp_path):
     assert again.search_knn(q, 4).tobytes() == oracle.Oracle(pts, 8, "port", "L1").search_knn(q, 4).tobytes()
 
 
-@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "1"},
+@pytest.mark.parametrize("env", [{}, {"radius_capture_chunks": 0}, {"radius_capture_chunks": 1},
                                  {"PTK_RADIUS_CAPTURE_MB": "0"}, {"PTK_RADIUS_CAPTURE_MB": "2"}],
                          ids=["default", "static-chunk-only", "pool-runs-dry", "capture-off", "budget-too-small"])
 @pytest.mark.parametrize("cloud,radius", [("lidar", 1.0), ("ties", 0.03)])
@@ -358,8 +358,11 @@ def test_radius_rows_captured_in_the_count_pass(trees, monkeypatch, env, cloud, 
     """The count pass captures the rows and the fill pass copies them (RadiusCapture in
     ptk_kernels.hpp); rows that did not fit are searched again.  Same bytes in every regime."""
     import torch
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    for name, value in env.items():  # (an environment switch of the library, or one of its test hooks)
+        if name.startswith("PTK_"):
+            monkeypatch.setenv(name, value)
+        else:
+            pt.set_test_knobs(**{name: value})
     tree, ref, _, q = trees(cloud)
     want_off, want = ref.search_radius(q, radius)
     got = tree.search_radius(q, radius)
@@ -545,12 +548,15 @@ def test_randomised_differential_sweep(gpu, dtype):
     assert ran >= 60
 
 
-@pytest.mark.parametrize("env", [{}, {"PTK_RADIUS_CAPTURE_CHUNKS": "0"}, {"PTK_RADIUS_CAPTURE_CHUNKS": "1"},
+@pytest.mark.parametrize("env", [{}, {"radius_capture_chunks": 0}, {"radius_capture_chunks": 1},
                                  {"PTK_RADIUS_CAPTURE_MB": "0"}], ids=["default", "static-chunk-only", "pool-runs-dry", "off"])
 @pytest.mark.parametrize("dim,radius", [(5, 0.06), (16, 1.1)])
 def test_radius_capture_any_dimension(gpu, monkeypatch, env, dim, radius):
-    for k, v in env.items():
-        monkeypatch.setenv(k, v)
+    for name, value in env.items():  # (an environment switch of the library, or one of its test hooks)
+        if name.startswith("PTK_"):
+            monkeypatch.setenv(name, value)
+        else:
+            pt.set_test_knobs(**{name: value})
     pts, q = ds.uniform_cloud(30_000, dim, 91), ds.uniform_cloud(6_000, dim, 92)
     tree = pt.KdTree(pts, pt.Metric.L2Squared, 9, device=gpu)
     ref = oracle.Oracle(pts, 9, "port")
@@ -635,7 +641,7 @@ def test_box_search_on_device_buffers(gpu, dim):
 
 def test_multi_device_handle_on_the_devices_present(gpu, monkeypatch):
     """ptk_multi_* with every visible device (one on the test box): host form (ranges moved by the
-    devices themselves) and device form; with PTK_MULTI_SELF_GATHER=1 devices[0] sends its rows to
+    devices themselves) and device form; with the test hook multi_self_gather=1 devices[0] sends its rows to
     itself, so the grouped ncclSend / ncclRecv path runs on a one-GPU box too."""
     import torch
     pts, q = ds.lidar_cloud(60_000, 1), ds.lidar_cloud(30_001, 2, pose=(3.0, 1.5))
@@ -649,7 +655,7 @@ def test_multi_device_handle_on_the_devices_present(gpu, monkeypatch):
     assert np.array_equal(got.offsets, off) and got.flat.tobytes() == flat.tobytes()
     dq = torch.from_numpy(q).to(f"cuda:{multi.devices[0]}")
     for self_gather in ("0", "1"):
-        monkeypatch.setenv("PTK_MULTI_SELF_GATHER", self_gather)
+        pt.set_test_knobs(multi_self_gather=int(self_gather))
         for k, want in ((1, want1), (8, want8)):
             rows = multi.search_knn(dq, k).numpy()
             torch.cuda.synchronize()
@@ -744,7 +750,7 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
     children nearly every continuation is handed to the cooperative search; on a lattice cloud (exact ties beyond
     the tie budget) the certificate FAILS for some queries and they come back through the replay; the queries of the
     scanner's blind disc (on a grid of 0.5) are the long chains the cooperative search exists for.  Both forms: the
-    ranked classes through phase 2 first (PTK_COOP_DIRECT=0) and straight from phase 1 on a second stream (2, with
+    ranked classes through phase 2 first (test hook coop_direct=0) and straight from phase 1 on a second stream (2, with
     the HBM spill of the subtree pool).  Counters say the paths ran; rows equal the oracle."""
     import torch
 
@@ -756,9 +762,9 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
         q = np.ascontiguousarray(np.round(q / grid) * grid, dtype=np.float32)
     else:
         pts, q = _clouds(cloud, 120_000, 40_000)
-    monkeypatch.setenv("PTK_COOP_DIRECT", direct)
+    pt.set_test_knobs(coop_direct=int(direct))
     if cloud == "ties":  # (the lattice cloud is all piles: on the view without them -- ptk_piles.hpp -- nothing is left to replay)
-        monkeypatch.setenv("PTK_PILE_VIEW", "0")
+        pt.set_test_knobs(pile_view=0)
     tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
     ref = oracle.Oracle(pts, 10, "port")
     ref.set_threads(ref.max_threads())
@@ -766,7 +772,7 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
     dq = torch.from_numpy(q).to(f"cuda:{gpu}")
     redone = 0
     for cap in ("1", "2"):
-        monkeypatch.setenv("PTK_P2_CAP", cap)
+        pt.set_test_knobs(p2_cap=int(cap))
         got = tree.search_knn(dq, 1).numpy()
         torch.cuda.synchronize()
         counts = tree.knn1_counts()
@@ -776,7 +782,7 @@ def test_capped_phase2_cooperative_search_and_replay_really_run(gpu, monkeypatch
         redone += counts["redone"]
     if cloud == "ties":  # more exact ties per query than a lane resolves: the certificate fails, the replay runs
         assert redone > 0
-        monkeypatch.delenv("PTK_PILE_VIEW")
+        pt.set_test_knobs(pile_view=None)
         view = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
         assert view.piles()["piles"] > 0 and view.search_knn(dq, 1).numpy().tobytes() == want.tobytes()
         assert view.knn1_counts()["redone"] == 0
@@ -797,22 +803,21 @@ def test_k_nearest_cap_follows_the_batch_and_large_batches_run_as_two_launches(g
     out = torch.empty((len(q), k, 2), dtype=torch.int32, device=dq.device)
 
     def rows(**env):
-        for name, value in env.items():
-            monkeypatch.setenv(name, value)
+        if env:
+            pt.set_test_knobs(**env)
         tree.search_knn(dq, k, out)
         torch.cuda.synchronize()
-        counts = tree.knn_coop_counts() if env.get("PTK_KNN_CAP") != "0" else None
-        for name in env:
-            monkeypatch.delenv(name)
+        counts = tree.knn_coop_counts() if env.get("knn_cap") != 0 else None
+        pt.set_test_knobs()
         return out.cpu().numpy().tobytes(), counts
 
     base, counts = rows()
     assert counts["cooperative"] > 0 and counts["redone"] <= counts["cooperative"] // 50, counts
-    assert rows(PTK_KNN_OVERLAP_PCT="0")[0] == base        # one capped launch
-    assert rows(PTK_KNN_OVERLAP_PCT="50", PTK_KNN_CAP="24")[0] == base
-    assert rows(PTK_KNN_CAP="0")[0] == base                 # every query to its end in its lane
+    assert rows(knn_overlap_pct=0)[0] == base        # one capped launch
+    assert rows(knn_overlap_pct=50, knn_cap=24)[0] == base
+    assert rows(knn_cap=0)[0] == base                 # every query to its end in its lane
     # (a cap of 3 hands most queries over; the list is a 64th of the batch: the rest goes on in its lanes)
-    got, counts = rows(PTK_KNN_CAP="3", PTK_KNN_OVERLAP_PCT="0")
+    got, counts = rows(knn_cap=3, knn_overlap_pct=0)
     assert got == base and counts["cooperative"] > len(q) // 64, counts
     # pieces of a batch (a shard, a piece of a host-buffer call) get a cap of their own: against the oracle
     ref = oracle.Oracle(pts, 10, "port")
@@ -850,11 +855,11 @@ def _line_family_case(rng, kind, jitter):
 def test_capped_k_nearest_on_lines_and_lattices_equals_the_compiled_reference(gpu, monkeypatch, kind, jitter):
     """The adversarial family of the cooperative k > 1 search (ptk_kernels_coopk.hpp; profiles/r05_notes.txt item 24,
     profiles/r06_notes.txt item 1): lines and lattices, leaves of 1 / 2 / 5 points, k = 2 .. 56, with and without a
-    jitter that removes the equal distances, THE CAP ON FOR EVERY BATCH (PTK_KNN_CAP_MIN_NQ=1) and low, so nearly
+    jitter that removes the equal distances, THE CAP ON FOR EVERY BATCH (test hook knn_cap_min_nq=1) and low, so nearly
     every query is handed over, merged, second-swept or redone.  Byte-equal to the compiled reference
     (oracle/_ref; the restatement where that is absent).  The first case of the line family is the cloud the
     fuzz soak of r05 failed on (seed 802, case 760: 60 000 points, knn = 16 / 32 / 33)."""
-    monkeypatch.setenv("PTK_KNN_CAP_MIN_NQ", "1")
+    pt.set_test_knobs(knn_cap_min_nq=1)
     how = "reference" if oracle.have_reference() else "port"
     handed = swept = redone = 0
     cases = []
@@ -873,7 +878,7 @@ def test_capped_k_nearest_on_lines_and_lattices_equals_the_compiled_reference(gp
         ref = oracle.Oracle(pts, leaf, how)
         for k in ks:
             for cap in ("4", "32"):
-                monkeypatch.setenv("PTK_KNN_CAP", cap)
+                pt.set_test_knobs(knn_cap=int(cap))
                 got = tree.search_knn(q, k)
                 assert got.tobytes() == ref.search_knn(q, k).tobytes(), (kind, jitter, len(pts), leaf, k, cap)
                 c = tree.knn_coop_counts()
@@ -925,7 +930,7 @@ def test_coincident_points_k1_through_the_view_without_the_piles(gpu, monkeypatc
     view in which a pile is one point and reports the point of the pile the reference visits first (ptk_piles.hpp).
     400 k points / 300 k queries on the grid, off the grid, and half a cell off it (several piles at exactly the same
     distance); rows equal the oracle's, exact and approximate, device and host buffers, and the rows of the full tree
-    (PTK_PILE_VIEW=0); on the view next to nothing is replayed lane by lane."""
+    (test hook pile_view=0); on the view next to nothing is replayed lane by lane."""
     import torch
 
     n, nq = 400_000, 300_000
@@ -951,7 +956,7 @@ def test_coincident_points_k1_through_the_view_without_the_piles(gpu, monkeypatc
     assert tree.search_knn(q2[:50_000], 1).tobytes() == want[:50_000].tobytes()  # host buffers, in pieces
     assert tree.search_knn(dq, 1, 1.25).numpy().tobytes() == ref.search_knn(q2, 1, e=1.25)[:, 0].tobytes()
     if grid == 4.0 and shift == 0.3:  # the same rows the long way: every point of every pile visited
-        monkeypatch.setenv("PTK_PILE_VIEW", "0")
+        pt.set_test_knobs(pile_view=0)
         full = pt.KdTree(p2, pt.Metric.L2Squared, 10, device=gpu)
         assert full.piles()["piles"] == 0
         assert full.search_knn(dq[:20_000].contiguous(), 1).numpy().tobytes() == want[:20_000].tobytes()
@@ -962,12 +967,12 @@ def test_coincident_points_k1_through_the_view_without_the_piles(gpu, monkeypatc
 def test_batch_order_is_the_stable_sort_of_the_morton_keys(gpu, monkeypatch, form, nq):
     """The order a batch is searched in (ptk_debug_batch_permutation) is the permutation a stable sort of the Morton
     keys gives -- whichever sort makes it: the library's passes with one wavefront per tile or with blocks of four
-    (PTK_SORT_BLOCK), rocprim's above 2 M rows -- compared with the keys of the emulated key kernel sorted by numpy.
+    (test hook sort_block), rocprim's above 2 M rows -- compared with the keys of the emulated key kernel sorted by numpy.
     Sizes: a tile and one item, a few tiles, 16-bit and 24-bit keys, a last tile that is partly empty."""
     import torch
     from tests.emu import EmulatedTree
 
-    monkeypatch.setenv("PTK_SORT_BLOCK", form)
+    pt.set_test_knobs(sort_block=int(form))
     pts = ds.lidar_cloud(200_000, seed=1)
     q = ds.lidar_cloud(nq, seed=2, pose=(3.0, 1.5))
     tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
@@ -983,7 +988,7 @@ def test_rows_in_page_locked_blocks_of_the_pool(gpu):
     """search_knn(pts, k) returns a NEW array per call like the reference's module (def_kd_tree.cpp:73-82); here it is
     built on a page-locked block (ptk_host_alloc) the device writes directly, and the block is handed out again once
     the array is gone.  Rows equal the oracle whichever way the arrays are held: pooled rows, a pageable array of
-    the caller, queries in page-locked memory too, no pinned memory at all (PTK_HOST_DIRECT=0)."""
+    the caller, queries in page-locked memory too, no pinned memory at all (test hook host_direct=0)."""
     import gc
     import os
 
@@ -1011,11 +1016,11 @@ def test_rows_in_page_locked_blocks_of_the_pool(gpu):
     qp = pt.empty_pinned(q.shape, q.dtype)
     qp[...] = q
     assert tree.search_knn(qp, 4).tobytes() == want4.tobytes()
-    os.environ["PTK_HOST_DIRECT"] = "0"
+    pt.set_test_knobs(host_direct=0)
     try:
         assert tree.search_knn(qp, 1).tobytes() == want1.tobytes()
     finally:
-        del os.environ["PTK_HOST_DIRECT"]
+        pt.set_test_knobs(host_direct=None)
 
 
 @pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")

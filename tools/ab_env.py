@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Within-process A/B of environment-selected forms of the k-NN search.
 
-    python tools/ab_env.py --configs "PTK_P2_CAP=0;PTK_P2_CAP=16;PTK_P2_CAP=64" --rounds 5 [--cloud L] [--k 1]
+    python tools/ab_env.py --configs "PTK_TEST_KNOBS=p2_cap=0;PTK_TEST_KNOBS=p2_cap=16;PTK_TEST_KNOBS=p2_cap=64" --rounds 5 [--cloud L] [--k 1]
 
 Each ';'-separated config is a ','-separated list of NAME=VALUE settings (libptk reads its knobs
 at every call).  The configs are interleaved over several rounds in ONE process on the same

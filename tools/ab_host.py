@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Within-process A/B of the host-buffer entry (ptk_search_knn on numpy arrays) under environment settings.
-python tools/ab_host.py --configs "PTK_HOST_PIECE=900108;PTK_HOST_PIECE=1800216" [--k 1] [--rounds 5]"""
+python tools/ab_host.py --configs "PTK_TEST_KNOBS=host_piece=900108;PTK_TEST_KNOBS=host_piece=1800216" [--k 1] [--rounds 5]"""
 import argparse, json, os, statistics, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

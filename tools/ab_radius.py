@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Within-process A/B of environment-selected forms of the radius search on BASELINE config 3 (cloud L, r^2 = 1):
-    python tools/ab_radius.py --configs "PTK_RADIUS_LISTS=0;PTK_RADIUS_LISTS=1" [--rounds 3]
+    python tools/ab_radius.py --configs "PTK_TEST_KNOBS=radius_lists=0;PTK_TEST_KNOBS=radius_lists=1" [--rounds 3]
 Per config: median kernel ms (count pass + scan + fill, HIP events inside libptk), step ms, rows equal to the first."""
 import argparse, json, os, statistics, sys, time
 import numpy as np

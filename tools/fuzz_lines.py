@@ -5,7 +5,7 @@ rounding.  k > 1 with the cap on every batch, against the oracle."""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-os.environ.setdefault("PTK_KNN_CAP_MIN_NQ", "1")
+os.environ.setdefault("PTK_TEST_KNOBS", "knn_cap_min_nq=1")
 import oracle
 import pico_tree_amd as pt
 

@@ -4,11 +4,11 @@ cd /root/repo
 S=${1:-700}
 run() { echo "## $*"; timeout 1500 "$@" 2>&1 | grep -E "^FAIL|^fuzz:|Error|error" | tail -12; }
 run python tools/fuzz_parity.py --cases 2500 --seed $((S+1))
-PTK_KNN_CAP_MIN_NQ=1 run python tools/fuzz_parity.py --cases 1200 --seed $((S+2))
-PTK_KNN_CAP_MIN_NQ=1 PTK_KNN_CAP=2 PTK_KNN_COOP_WAVES=1 run python tools/fuzz_parity.py --cases 600 --seed $((S+3))
+PTK_TEST_KNOBS=knn_cap_min_nq=1 run python tools/fuzz_parity.py --cases 1200 --seed $((S+2))
+PTK_TEST_KNOBS=knn_cap_min_nq=1,knn_cap=2 run python tools/fuzz_parity.py --cases 600 --seed $((S+3))
 run python tools/fuzz_parity.py --lninf --cases 800 --seed $((S+4))
 run python tools/fuzz_parity.py --dtype float64 --lninf --cases 1000 --seed $((S+5))
 run python tools/fuzz_parity.py --topological --cases 800 --seed $((S+6))
 run python tools/fuzz_parity.py --topological --dtype float64 --cases 800 --seed $((S+7))
 run python tools/fuzz_parity.py --multi --cases 500 --seed $((S+8))
-PTK_SORT_BLOCK=1 PTK_P2_CAP=2 run python tools/fuzz_parity.py --cases 800 --seed $((S+9))
+PTK_TEST_KNOBS=sort_block=1,p2_cap=2 run python tools/fuzz_parity.py --cases 800 --seed $((S+9))

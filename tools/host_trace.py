@@ -8,6 +8,6 @@ tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=0)
 for k in (1, 16):
     out = np.empty((len(q), k) if k > 1 else (len(q),), dtype=pt.NEIGHBOR)
     tree.search_knn(q, k, out); tree.search_knn(q, k, out)
-    os.environ["PTK_HOST_TRACE"] = "1"
+    os.environ["PTK_TEST_KNOBS"] = "host_trace=1"
     t0 = time.perf_counter(); tree.search_knn(q, k, out); print("k", k, (time.perf_counter() - t0) * 1e3, "ms", flush=True)
-    os.environ["PTK_HOST_TRACE"] = "0"
+    os.environ["PTK_TEST_KNOBS"] = "host_trace=0"

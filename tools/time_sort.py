@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""The batch order of a k = 1 search against the batch size, for the three sorts that can make it (PTK_SORT = 0: rocprim's
-onesweep; 1: the library's passes with one wavefront per tile; PTK_SORT_BLOCK = 1: with blocks of eight wavefronts on tiles of 4 096 rows):
+"""The batch order of a k = 1 search against the batch size, for the three sorts that can make it (test hook sort = 0: rocprim's
+onesweep; 1: the library's passes with one wavefront per tile; sort_block = 1: with blocks of eight wavefronts on tiles of 4 096 rows):
 reorder ms and step ms per size (HIP events inside the library).  python tools/time_sort.py [sizes ...]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -11,8 +11,8 @@ from pico_tree_amd import datasets as ds
 pts, q = ds.config2_clouds("L")
 tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=0)
 sizes = [int(a) for a in sys.argv[1:]] or [100_000, 300_000, 900_108, 2_000_000, 3_600_000, len(q)]
-forms = {"rocprim": {"PTK_SORT": "0", "PTK_SORT_BLOCK": "0"}, "one wavefront per tile": {"PTK_SORT": "1", "PTK_SORT_BLOCK": "0"},
-         "blocks of eight wavefronts": {"PTK_SORT": "1", "PTK_SORT_BLOCK": "1"}}
+forms = {"rocprim": {"PTK_TEST_KNOBS": "sort=0,sort_block=0"}, "one wavefront per tile": {"PTK_TEST_KNOBS": "sort=1,sort_block=0"},
+         "blocks of eight wavefronts": {"PTK_TEST_KNOBS": "sort=1,sort_block=1"}}
 for nq in sizes:
     dq = torch.from_numpy(np.ascontiguousarray(q[:nq])).cuda()
     out = torch.empty((nq, 1, 2), dtype=torch.int32, device="cuda")

@@ -27,8 +27,9 @@ LIB = os.path.join(ROOT, "tools", "bin", "libptk_trace.so")
 def build():
     from pico_tree_amd import build as b
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = ["/opt/rocm/bin/hipcc"] + b.FLAGS + ["-DPTK_WAVE_TRACE", "-I" + os.path.join(ROOT, "include"), "-I" + b.CSRC,
-                                               "-o", LIB] + b.SOURCES
+    # (all units in one command: an experiment build, compiled once)
+    cmd = ["/opt/rocm/bin/hipcc"] + b.FLAGS + ["-shared", "-DPTK_WAVE_TRACE", "-I" + os.path.join(ROOT, "include"),
+                                               "-I" + b.CSRC, "-o", LIB] + b.SOURCES
     subprocess.check_call(cmd)
     print(LIB)
 
