@@ -486,6 +486,9 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     for j in range(0, len(rs), 37):
         a = rawn[offs[rs[j]]:offs[rs[j] + 1]].view(pt.NEIGHBOR)[:, 0]
         ok = ok and a.tobytes() == flat[int(o2[j]):int(o2[j + 1])].tobytes()
+    import hashlib
+    small = {"shard_of_8": per, "20k": 20_000}
+    prefix = {name: (int(offs[n]), hashlib.sha256(rawn[:int(offs[n])].tobytes()).hexdigest()) for name, n in small.items()}
     del raw, rawn
     mean = rcnt.astype(np.float64).mean(axis=0)
     b = 12 + 8 * (hits / nq) + 16 * mean[0] + 8 * mean[1] + 16 * mean[2]
@@ -498,6 +501,30 @@ def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     res["radius"] = {"radius_squared": radius, "value": round(nq / ms / 1e3, 3), "unit": "Mqueries/s",
                      "ms_per_step": round(ms, 4), "steps": steps, "hits_per_query": round(hits / nq, 2),
                      "parity_sample_ok": bool(ok), "roofline": r}
+    # ---- the radius search on one shard of configs[3] and on 20 k queries: the list pass capped, the long queries counted
+    # and filled by a wavefront each (ptk_kernels_coopr.hpp; before, ANY batch of this cloud took 2.2 ms -- its longest query)
+    for name, n in small.items():
+        d = dq[:n]
+        for _ in range(2):
+            off_s, raw_s = tree.search_radius_device(d, radius)
+        torch.cuda.synchronize()
+        same = (int(off_s[-1].item()), hashlib.sha256(raw_s.cpu().numpy().tobytes()).hexdigest()) == prefix[name]
+        tree.profile(enable=True, reset=True)
+        t0 = time.perf_counter()
+        for _ in range(10):
+            off_s = raw_s = None
+            off_s, raw_s = tree.search_radius_device(d, radius)
+        torch.cuda.synchronize()
+        ms_s = (time.perf_counter() - t0) / 10 * 1e3
+        prof_s = tree.profile(enable=False, reset=True)
+        try:
+            coop_r = tree.radius_coop_counts()
+        except Exception as exc:  # noqa: BLE001
+            coop_r = str(exc)
+        res[f"radius_{name}"] = {"queries": n, "ms_per_step": round(ms_s, 4), "kernel_ms": round(prof_s["search_ms"] / 10, 4),
+                                 "value": round(n / ms_s / 1e3, 3), "unit": "Mqueries/s", "rows_equal_full_batch": bool(same),
+                                 "long_searches": coop_r}
+        del off_s, raw_s
     ref.close()
     return res
 

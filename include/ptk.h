@@ -461,12 +461,17 @@ int ptk_profile_get_sized(const ptk_tree* tree, void* out, uint64_t size, int re
  * traversal from the root), [3] = queries of the classes dealt across wavefronts. */
 int ptk_debug_knn1_counts(const ptk_tree* tree, uint32_t counts[4]);
 /* After a k-NN search with 1 < k <= 56 on a 3-D tree (default metric, exact): {queries the general kernel handed to the
- * cooperative search because they had entered more than PTK_KNN_CAP far children, queries that search could not certify
+ * cooperative search because they had entered more than the cap of far children (ptk_debug_knn_cap), queries that search could not certify
  * and the reference search redid, and why: a pool of subtrees and its spill that overflowed, more equal distances
  * than the second sweep can rank, a box distance above the k-th distance on the way to a neighbour, a k-th distance
  * outside [1e-30, 1e30]; last: queries whose equal distances a second sweep put in the reference's order}.
  * Synchronises the device. */
 int ptk_debug_knn_coop_counts(const ptk_tree* tree, uint32_t counts[7]);
+/* After a radius count pass on a 3-D tree whose rows are kept as leaf lists: {queries the list pass handed to a
+ * wavefront because they had entered more than its cap of far children (ptk_kernels_coopr.hpp), rows that search could
+ * not finish and one lane counted again from the root, sorted leaf entries the fill pass will read}.  Zeros when the
+ * pass ran uncapped.  Synchronises the device. */
+int ptk_debug_radius_coop_counts(const ptk_tree* tree, uint32_t counts[3]);
 /* The far children a query of such a search may enter before a wavefront takes it over, for a batch of nq queries
  * (it follows the batch: a capped launch ends with the lanes that ran to their cap; 0 = this search runs uncapped --
  * e != 1, fewer than 256 queries, k outside 2 .. 56), and the entries of the hand-over list of that batch (a query that

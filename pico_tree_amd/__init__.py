@@ -151,6 +151,7 @@ _SIGNATURES = {
     "ptk_debug_key_bits": (c_int, [c_void_p, c_uint64, POINTER(c_uint32)]),
     "ptk_debug_batch_order": (c_int, [c_void_p, POINTER(c_int)]),
     "ptk_debug_knn_coop_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ptk_debug_radius_coop_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ptk_debug_knn_cap": (c_int, [c_uint64, c_uint32, c_float, POINTER(c_uint32), POINTER(c_uint64)]),
     "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
                                              POINTER(c_void_p)]),
@@ -706,6 +707,15 @@ class KdTree:
         _check(_load().ptk_debug_knn_coop_counts(self._h, c))
         return {"cooperative": int(c[0]), "redone": int(c[1]), "pool": int(c[2]), "ties": int(c[3]), "box": int(c[4]),
                 "range": int(c[5]), "tie_sweeps": int(c[6])}
+
+    def radius_coop_counts(self) -> dict:
+        """After a radius count pass on the device (``search_radius_device`` / the count half of ``search_radius``):
+        queries the list pass handed to a wavefront, rows recounted from the root, leaf entries kept for the fill pass
+        (``ptk_debug_radius_coop_counts``)."""
+        self._float32_only("radius_coop_counts()")
+        c = (c_uint32 * 3)()
+        _check(_load().ptk_debug_radius_coop_counts(self._h, c))
+        return {"cooperative": int(c[0]), "recounted": int(c[1]), "entries": int(c[2])}
 
     def piles(self) -> dict:
         """Subtrees of coincident points of the device replica (``ptk_debug_piles``): how many, the points they hold,

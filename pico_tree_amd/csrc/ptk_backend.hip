@@ -589,7 +589,9 @@ size_t capture_budget_bytes(const ptk_tree* t) {
 // Layout: counters | captured flags (one per wavefront) | query of every lane | chunks.  Every wavefront of the
 // launch owns one static chunk; the dynamic pool is sized for 1024 hits per row when the budget allows (the
 // scan-like cloud of BASELINE config 3 averages 105); PTK_RADIUS_CAPTURE_CHUNKS overrides chunks per sub-pool (tests).
-bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
+// with_heavy: room for what a capped list pass keeps of its hand-overs until the fill pass (ptk::RadiusHeavy: counters,
+// four words per hand-over, the sorted entries), between the tables and the chunks.
+bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws, bool with_heavy = false) {
   const size_t budget = capture_budget_bytes(t);
   if (budget == 0 || nq == 0 || nq >= (1ull << 31)) return false;
   const size_t waves = (size_t)((nq + 63) / 64);
@@ -598,7 +600,10 @@ bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
   const size_t qids_at = flags_at + ((waves + 255) & ~(size_t)255);
   const size_t lens_at = qids_at + waves * 64 * 4;
   const size_t tables_at = lens_at + waves * 64 * 4;
-  const size_t head = (tables_at + waves * ptk::kListMaxChunks * 4 + 4095) & ~(size_t)4095;
+  const size_t heavy_at = (tables_at + waves * ptk::kListMaxChunks * 4 + 255) & ~(size_t)255;
+  const size_t mh = with_heavy ? (size_t)radius_max_handover(nq) : 0, ecap = with_heavy ? (size_t)radius_entry_cap(nq) : 0;
+  const size_t heavy_bytes = with_heavy ? 256 + 4 * ((mh * 4 + 255) & ~(size_t)255) + ecap * 8 : 0;
+  const size_t head = (heavy_at + heavy_bytes + 4095) & ~(size_t)4095;
   if (head + waves * chunk_bytes > budget) return false;
   const size_t dyn = std::min<size_t>((budget - head - waves * chunk_bytes) / chunk_bytes, waves * 64 * 2);
   const int forced = knob_int("radius_capture_chunks", -1);
@@ -631,6 +636,19 @@ bool prepare_capture(const ptk_tree* t, uint64_t nq, Workspace& ws) {
   ws.cap.chunks = reinterpret_cast<ptk::Neighbor*>(ws.cap_base + head);
   ws.cap.n_static = (uint32_t)waves;
   ws.cap.sub_cap = (uint32_t)sub_cap;
+  ws.cap_heavy = ptk::RadiusHeavy{};
+  if (with_heavy) {
+    const size_t row = (mh * 4 + 255) & ~(size_t)255;
+    char* p = ws.cap_base + heavy_at;
+    ws.cap_heavy.meta = reinterpret_cast<uint32_t*>(p);
+    ws.cap_heavy.rows = reinterpret_cast<uint32_t*>(p + 256);
+    ws.cap_heavy.own = reinterpret_cast<uint32_t*>(p + 256 + row);
+    ws.cap_heavy.run_at = reinterpret_cast<uint32_t*>(p + 256 + 2 * row);
+    ws.cap_heavy.run_n = reinterpret_cast<uint32_t*>(p + 256 + 3 * row);
+    ws.cap_heavy.entries = reinterpret_cast<unsigned long long*>(p + 256 + 4 * row);
+    ws.cap_heavy.max_heavy = (uint32_t)mh;
+    ws.cap_heavy.entry_cap = (uint32_t)std::min<size_t>(ecap, 0xFFFFFFFFu);
+  }
   return true;
 }
 
@@ -1731,13 +1749,16 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
   const bool from_capture = fill && ws.cap_valid && ws.cap_q == d_q && ws.cap_nq == nq && ws.cap_radius == radius &&
                             ws.cap_e == e && ws.cap_metric == metric && ws.cap_stream == s;
   if (from_capture) {
-    rc = scratch.reserve(nq * 4 + 256);
+    // (rows to search again: those of wavefronts whose lists were lost, and handed-over rows whose entries were)
+    const uint64_t n_over_max = nq + ws.cap_heavy.max_heavy;
+    rc = scratch.reserve(n_over_max * 4 + 256);
     if (rc != PTK_OK) return rc;
-    uint32_t* over_list = scratch.take<uint32_t>(nq);
+    uint32_t* over_list = scratch.take<uint32_t>(n_over_max);
     uint32_t* n_over = scratch.take<uint32_t>(1);
     if (over_list == nullptr || n_over == nullptr) return fail(PTK_ERR_NOMEM, "scratch block too small");
     if (ws.cap_lists) {  // (3-D trees: the rows are made from the leaf lists of the count pass)
-      rc = ptkf::radius_replay(t, d_q, e, ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over, s);
+      rc = ptkf::radius_replay(t, d_q, e, ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over, s,
+                               ws.cap_heavy.max_heavy != 0u ? &ws.cap_heavy : nullptr);
       if (rc != PTK_OK) return rc;
     } else {
       rc = ptkf::radius_log_scatter(t, ws.cap, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), over_list, n_over, s);
@@ -1748,7 +1769,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       rc = ptkf::radius_nd(t, d_q, nq, radius, e, true, nullptr, d_offsets, reinterpret_cast<ptk::Neighbor*>(d_out), s,
                            over_list, n_over);
     } else {
-      rc = ptkf::radius_traverse(t, d_q, over_list, nq, radius, e, true, nullptr, d_offsets,
+      rc = ptkf::radius_traverse(t, d_q, over_list, n_over_max, radius, e, true, nullptr, d_offsets,
                                  reinterpret_cast<ptk::Neighbor*>(d_out), s, n_over);
     }
   } else if (topological(t)) {  // count pass and fill pass both traverse (no capture)
@@ -1791,10 +1812,12 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
     }
     timer.stop(0, fill ? 0 : nq);
   } else {
-    const bool capture = !fill && prepare_capture(t, nq, ws);
+    // (the long queries of a list pass are handed to wavefronts: ptk_kernels_coopr.hpp)
+    const uint32_t far_cap = !fill && !nd && knob_int("radius_lists", 1) != 0 ? radius_cap(t, nq) : 0u;
+    const bool capture = !fill && prepare_capture(t, nq, ws, far_cap != 0u);
     const bool lists = capture && !nd && knob_int("radius_lists", 1) != 0;
     if (!fill) ws.cap_valid = false;
-    rc = scratch.reserve(reorder ? permutation_scratch_bytes(nq) : 0);
+    rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) + (lists && far_cap ? radius_coop_scratch_bytes(t, nq) : 0));
     if (rc != PTK_OK) return rc;
     uint32_t* perm = nullptr;
     if (reorder) {  // (a query costs what it finds: the densest cells to the front of the launch)
@@ -1805,7 +1828,7 @@ static int radius_pass_device(const ptk_tree* t, const float* d_q, uint64_t nq, 
       if (nd) {
         rc = ptkf::radius_nd_capture(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s);
       } else if (lists) {  // the count pass lists the leaves with hits for the fill pass
-        rc = ptkf::radius_list(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s);
+        rc = ptkf::radius_list(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s, far_cap, &scratch, &ws.cap_heavy);
       } else {
         rc = ptkf::radius_capture(t, d_q, perm, nq, radius, e, d_counts, ws.cap, s);
       }
@@ -2270,6 +2293,22 @@ int ptk_debug_knn_coop_counts(const ptk_tree* t, uint32_t counts[7]) {
   counts[4] = meta[ptk::kKnnWhyBox];
   counts[5] = meta[ptk::kKnnWhyRange];
   counts[6] = meta[ptk::kKnnTieSweeps];
+  return PTK_OK;
+}
+
+int ptk_debug_radius_coop_counts(const ptk_tree* t, uint32_t counts[3]) {
+  if (t == nullptr || counts == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (t->device < 0) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
+  DeviceGuard guard(t->device);
+  std::lock_guard<std::mutex> lock(t->ws.mutex);
+  counts[0] = counts[1] = counts[2] = 0;
+  if (!t->ws.cap_valid || !t->ws.cap_lists || t->ws.cap_heavy.max_heavy == 0u) return PTK_OK;
+  uint32_t meta[ptk::kMetaWords];
+  PTK_HIP(hipDeviceSynchronize());
+  PTK_HIP(hipMemcpy(meta, t->ws.cap_heavy.meta, sizeof(meta), hipMemcpyDeviceToHost));
+  counts[0] = std::min(meta[ptk::kMetaHeavy], t->ws.cap_heavy.max_heavy);
+  counts[1] = meta[ptk::kMetaRedo];
+  counts[2] = meta[28];  // ptk::kMetaRcEntries (ptk_kernels_coopr.hpp)
   return PTK_OK;
 }
 

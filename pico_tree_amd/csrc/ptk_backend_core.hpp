@@ -136,6 +136,7 @@ struct Workspace {
   size_t cap_capacity = 0;
   bool cap_valid = false;
   bool cap_lists = false;  // the capture holds leaf lists (ptk_kernels_lists.hpp), not a log of hits
+  ptk::RadiusHeavy cap_heavy{};  // ... and what the capped list pass handed to wavefronts (ptk_kernels_coopr.hpp); max_heavy == 0: nothing
   ptk::RadiusCapture cap{};
   const float* cap_q = nullptr;
   uint64_t cap_nq = 0;
@@ -612,6 +613,37 @@ inline uint64_t knn_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 4
 inline size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
   return 3 * (nq * 4) + (knn_max_handover(nq) + (nq >= (1ull << 22) ? 24576 : 0)) * ptk::kMaxTasks * sizeof(ptk::Task) +
          ptk::kMetaWords * 4 + (size_t)knn_coop_blocks(t, nq) * kKnnCoopSpill * sizeof(ptk::Task) + 1024;
+}
+
+// ---- the capped list pass of the radius search (ptk_kernels_coopr.hpp) ----
+// Far children a query of the radius list pass may enter before a wavefront takes it over; 0 = every query runs to its
+// end in its lane.  A capped launch ends with the lanes that ran to their cap (~7 us per far child for a lonely lane),
+// so the cap follows the batch as the k-NN one does (knn_cap): what it keeps roughly constant is the number of
+// hand-overs.  Trees deeper than a key has bits for (kRcMaxDepth) and batches of a few wavefronts run uncapped.  Test
+// hook radius_cap: that cap for every batch (0: none).
+constexpr int kRadiusCoopPool = 128;
+constexpr uint32_t kRadiusCoopSpill = 2048;  // tasks a wavefront of the cooperative count can park in HBM
+inline uint32_t radius_cap(const ptk_tree* t, uint64_t nq) {
+  if (t->dim > 3 || t->max_depth > 51u) return 0;  // (51 = ptk::kRcMaxDepth: static_assert in ptk_family_radius.hip)
+  const int forced = knob_int("radius_cap", -1);
+  if (forced >= 0) return (uint32_t)forced;
+  // Measured on BASELINE config 3's cloud (tools/time_radius_sizes.py, profiles/r06_notes.txt item 3; count + fill ms,
+  // best cap against no cap): 20 k queries 0.37 (cap 8) / 2.27, 150 k 1.09 (64) / 2.41, 900 k 2.86 (256) / 3.10; at 2.4 M
+  // and beyond the bulk of the launch hides the tail and every cap loses (4.23 (256) / 4.05; 7.2 M 11.4 / 10.2: no query
+  // of that cloud enters 384 far children, 1.2 % enter more than 256).  What the best caps have in common is 8-17 thousand
+  // hand-overs -- what the wavefronts of the cooperative count get through while the capped launch ends.
+  if (nq < 256 || nq >= 1500000) return 0;
+  return (uint32_t)std::min(256.0, std::max(8.0, (double)nq / 2400.0));
+}
+inline uint64_t radius_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
+inline uint64_t radius_entry_cap(uint64_t nq) { return radius_max_handover(nq) * 192; }  // entries of all hand-overs together
+inline uint32_t radius_coop_blocks(const ptk_tree* t, uint64_t nq) {
+  return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 8u, std::max<uint64_t>(64, radius_max_handover(nq)));
+}
+// Transient arrays of a capped list pass (the hand-over list with its tasks, the redo list, the spill runs).
+inline size_t radius_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
+  const uint64_t mh = radius_max_handover(nq);
+  return 3 * (mh * 4) + mh * ptk::kMaxTasks * sizeof(ptk::Task) + (size_t)radius_coop_blocks(t, nq) * kRadiusCoopSpill * 32 + 2048;
 }
 
 // The largest k whose list lives in registers (3-D kernels, every metric): 64 slots (a list of 40 in LDS took 74 ms on

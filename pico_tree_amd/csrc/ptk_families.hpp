@@ -26,10 +26,14 @@ int radius_traverse(const ptk_tree* t, const float* d_q, const uint32_t* perm, u
                     const uint32_t* n_dev = nullptr);
 int radius_capture(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
                    uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s);
+// (far_cap != 0: the capped list pass + the cooperative count of what it hands over; `heavy` is where the batch keeps
+// that for the fill pass, `scratch` has radius_coop_scratch_bytes() left)
 int radius_list(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float radius, float e,
-                uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s);
+                uint64_t* d_counts, const ptk::RadiusCapture& cap, hipStream_t s, uint32_t far_cap = 0,
+                ptkb::Scratch* scratch = nullptr, const ptk::RadiusHeavy* heavy = nullptr);
 int radius_replay(const ptk_tree* t, const float* d_q, float e, const ptk::RadiusCapture& cap, const uint64_t* d_offsets,
-                  ptk::Neighbor* d_out, uint32_t* over_list, uint32_t* n_over, hipStream_t s);
+                  ptk::Neighbor* d_out, uint32_t* over_list, uint32_t* n_over, hipStream_t s,
+                  const ptk::RadiusHeavy* heavy = nullptr);
 int radius_log_scatter(const ptk_tree* t, const ptk::RadiusCapture& cap, const uint64_t* d_offsets, ptk::Neighbor* d_out,
                        uint32_t* over_list, uint32_t* n_over, hipStream_t s);
 int radius_deep(const ptk_tree* t, const ptk::DevTree& dev, const float* d_q, uint64_t n, float radius, float e, bool fill,

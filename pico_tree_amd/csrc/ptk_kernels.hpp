@@ -515,6 +515,19 @@ struct RadiusCapture {
   uint32_t* tables;     // [n_static * kListMaxChunks] the chunks of each wavefront, in order
 };
 
+// What a radius batch keeps of its handed-over queries from the count pass to the fill pass (inside the capture block; ptk_kernels_coopr.hpp).
+struct RadiusHeavy {
+  uint32_t* meta;        // [kMetaWords] counters: kMetaHeavy = queries handed over, kMetaRedo = rows recounted from the
+                         // root, kMetaRcEntries = entries handed out
+  uint32_t* rows;        // [max_heavy] the row (query index) of hand-over h
+  uint32_t* own;         // [max_heavy] hits its lane had found before it stopped (they are in the lane's list)
+  uint32_t* run_at;      // [max_heavy] where its sorted entries begin in `entries`
+  uint32_t* run_n;       // [max_heavy] how many (kRcLost: none -- the row is searched again)
+  unsigned long long* entries;  // [entry_cap] {(first point << cbits) | points, mask of the hits}, as the lane lists hold them
+  uint32_t max_heavy;
+  uint32_t entry_cap;
+};
+
 constexpr int kRadiusCount = 0, kRadiusFill = 1, kRadiusCapture = 2;
 
 // An entry of a capture log: written once, read once by another kernel -- it need not displace the tree in the L2

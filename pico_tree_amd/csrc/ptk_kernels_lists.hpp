@@ -159,10 +159,13 @@ struct RadiusListPolicy {  // search_visitor.hpp:127-156 / :252-288, counting
 
 // The count pass: see the head of this file.  One wavefront per block; LDS = the record stack and the chunk table.
 constexpr uint32_t kListLds = (1u + kListMaxChunks) * 4u;  // behind the record stack
-template <int S, int OVF, int LEAFB, class M = MetricL2, bool BIG = true, bool EXACT = false>
+// CAPPED (ptk_kernels_coopr.hpp): a query that has entered more than `far_cap` far children stops -- its list and its
+// count so far stay, its pending subtrees go to `ho` and a wavefront finishes it (radius_coop_count_kernel).
+template <int S, int OVF, int LEAFB, class M = MetricL2, bool BIG = true, bool EXACT = false, bool CAPPED = false>
 __global__ __launch_bounds__(64) void radius_list_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
-    float radius, float e_inv, uint64_t* __restrict__ counts, RadiusCapture cap) {
+    float radius, float e_inv, uint64_t* __restrict__ counts, RadiusCapture cap, uint32_t far_cap = 0u,
+    Handover ho = Handover{}) {
   PTK_TRACE_BEGIN();
   const uint32_t tile = xcd_runs(blockIdx.x, gridDim.x, kXcdRunGeneral);
   const uint64_t i = (uint64_t)tile * 64u + threadIdx.x;
@@ -194,7 +197,12 @@ __global__ __launch_bounds__(64) void radius_list_kernel(
     pol.sub_cap = cap.sub_cap;
     pol.n_static = cap.n_static;
     pol.lane = threadIdx.x;
-    traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
+    if constexpr (CAPPED) {
+      ho.slot = (uint32_t)qi;
+      traverse<LEAFB, false, M, true, true>(t, qx, qy, qz, pol, st, far_cap, &ho);
+    } else {
+      traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
+    }
     pol.finish();
     counts[qi] = pol.count;
   } else {

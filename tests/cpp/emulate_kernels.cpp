@@ -28,6 +28,7 @@ thread_local dim3 blockDim;
 #include "ptk_kernels.hpp"
 #include "ptk_kernels_lists.hpp"
 #include "ptk_kernels_coopk.hpp"
+#include "ptk_kernels_coopr.hpp"
 #include "ptk_piles.hpp"
 #include "ptk_sort.hpp"
 #include "ptk_kernels_nd.hpp"
@@ -168,6 +169,9 @@ struct Emu {
   std::vector<uint8_t> cap_flags;
   std::vector<uint32_t> cap_qids;
   std::vector<uint32_t> cap_lens, cap_tables;  // the capture as leaf lists (ptk_kernels_lists.hpp)
+  ptk::RadiusHeavy hv{};                       // ... and what a capped list pass handed over (ptk_kernels_coopr.hpp)
+  std::vector<uint32_t> hv_meta, hv_words;
+  std::vector<uint64_t> hv_entries;
   ptk::PileView piles;     // emu_use_pile_view: the k = 1 view of a tree with piles (ptk_piles.hpp)
   ptk::EncodedTree enc1;
   uint64_t cap_nq = 0;
@@ -758,6 +762,103 @@ int64_t emu_radius_lists(void* h, const float* q, uint64_t nq, float radius, flo
     if (t->metric == 1) ptk::radius_kernel<16, 2048, 64, 4, true, ptk::MetricL1>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o, &n_over);
     else ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, over.data(), nq, radius, e_inv, nullptr, offsets, o, &n_over);
   }, 64);
+  return (int64_t)n_over;
+}
+
+// The radius search with the long queries of the list pass finished by a wavefront each (ptk_kernels_coopr.hpp): the
+// capped list pass, the cooperative count of what it handed over, the recount of what that could not finish; then the
+// replay of the lists, the cooperative replay of the handed-over tails and the ordinary fill kernel for what was
+// lost.  pool_small != 0: a pool of 64 subtrees and 8 spill slots (overflows on long searches: the redo path).
+// stats (fill pass) = {queries handed over, rows recounted from the root, rows filled by radius_kernel<FILL>}.
+int64_t emu_radius_lists_capped(void* h, const float* q, uint64_t nq, float radius, float e, const uint32_t* perm,
+                                uint32_t sub_cap, uint32_t far_cap, int pool_small, uint32_t max_heavy, uint32_t entry_cap,
+                                int fill, uint64_t* counts, const uint64_t* offsets, ptk_neighbor* out, uint32_t* stats) {
+  auto* t = static_cast<Emu*>(h);
+  if (t->dim > 3) return -3;
+  const size_t waves = (size_t)((nq + 63) / 64);
+  const float e_inv = 1.0f / e;
+  auto* o = reinterpret_cast<ptk::Neighbor*>(out);
+  if (!fill) {
+    t->cap_chunks.assign((waves + (size_t)sub_cap * ptk::kCapSubPools) * ptk::kLogChunk, ptk::Neighbor{-1, -1.0f});
+    t->cap_counters.assign(ptk::kCapSubPools * ptk::kCapCounterStride, 0u);
+    t->cap_flags.assign(waves, 2);
+    t->cap_qids.assign(waves * 64, 0u);
+    t->cap_lens.assign(waves * 64, 0u);
+    t->cap_tables.assign(waves * ptk::kListMaxChunks, 0xDEADBEEFu);
+    t->cap.chunks = t->cap_chunks.data();
+    t->cap.counters = t->cap_counters.data();
+    t->cap.captured = t->cap_flags.data();
+    t->cap.qids = t->cap_qids.data();
+    t->cap.lens = t->cap_lens.data();
+    t->cap.tables = t->cap_tables.data();
+    t->cap.n_static = (uint32_t)waves;
+    t->cap.sub_cap = sub_cap;
+    t->cap_nq = nq;
+    t->hv_meta.assign(ptk::kMetaWords, 0u);
+    t->hv_words.assign((size_t)4 * std::max<uint32_t>(max_heavy, 1), 0xDEADBEEFu);
+    t->hv_entries.assign(std::max<uint32_t>(entry_cap, 1), ~0ull);
+    t->hv.meta = t->hv_meta.data();
+    t->hv.rows = t->hv_words.data();
+    t->hv.own = t->hv_words.data() + max_heavy;
+    t->hv.run_at = t->hv_words.data() + 2 * (size_t)max_heavy;
+    t->hv.run_n = t->hv_words.data() + 3 * (size_t)max_heavy;
+    t->hv.entries = reinterpret_cast<unsigned long long*>(t->hv_entries.data());
+    t->hv.max_heavy = max_heavy;
+    t->hv.entry_cap = entry_cap;
+    std::vector<uint32_t> heavy(max_heavy + 1), ntasks(max_heavy + 1), redo(max_heavy + 1);
+    std::vector<ptk::Task> tasks((size_t)std::max<uint32_t>(max_heavy, 1) * ptk::kMaxTasks);
+    ptk::Handover ho{};
+    ho.counter = ptk::kMetaHeavy;
+    ho.meta = t->hv_meta.data();
+    ho.heavy_list = heavy.data();
+    ho.ntasks = ntasks.data();
+    ho.tasks = tasks.data();
+    ho.max_heavy = max_heavy;
+    ho.full_keeps = 1u;
+    const bool big = t->dev.cmask >= ptk::kListMaskBits, exact = e_inv == 1.0f;
+    for_each_lane(waves * 64, [&] {
+      if (t->metric == 1) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL1, true, false, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap, far_cap, ho);
+      else if (big && exact) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, true, true, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap, far_cap, ho);
+      else if (big) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, true, false, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap, far_cap, ho);
+      else if (exact) ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, false, true, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap, far_cap, ho);
+      else ptk::radius_list_kernel<8, 2048, 4, ptk::MetricL2, false, false, true>(t->dev, q, t->dim, perm, nq, radius, e_inv, counts, t->cap, far_cap, ho);
+    }, 64);
+    const uint32_t spill_cap = pool_small ? 8u : 2048u;
+    std::vector<char> spill((size_t)3 * spill_cap * 32);
+    auto* sp = reinterpret_cast<ptk::Task*>(spill.data());
+    for_each_wave(3, [&] {
+      if (t->metric == 1) ptk::radius_coop_count_kernel<128, ptk::MetricL1, false>(t->dev, q, t->dim, radius, e_inv, counts, ho, t->hv, redo.data(), sp, spill_cap);
+      else if (pool_small && exact) ptk::radius_coop_count_kernel<64, ptk::MetricL2, true>(t->dev, q, t->dim, radius, e_inv, counts, ho, t->hv, redo.data(), sp, spill_cap);
+      else if (pool_small) ptk::radius_coop_count_kernel<64, ptk::MetricL2, false>(t->dev, q, t->dim, radius, e_inv, counts, ho, t->hv, redo.data(), sp, spill_cap);
+      else if (exact) ptk::radius_coop_count_kernel<128, ptk::MetricL2, true>(t->dev, q, t->dim, radius, e_inv, counts, ho, t->hv, redo.data(), sp, spill_cap);
+      else ptk::radius_coop_count_kernel<128, ptk::MetricL2, false>(t->dev, q, t->dim, radius, e_inv, counts, ho, t->hv, redo.data(), sp, spill_cap);
+    });
+    for_each_lane(max_heavy, [&] {
+      if (t->metric == 1) ptk::radius_kernel<8, 2048, 64, 4, false, ptk::MetricL1>(t->dev, q, t->dim, redo.data(), max_heavy, radius, e_inv, counts, nullptr, nullptr, t->hv_meta.data() + ptk::kMetaRedo);
+      else ptk::radius_kernel<8, 2048, 64, 4, false>(t->dev, q, t->dim, redo.data(), max_heavy, radius, e_inv, counts, nullptr, nullptr, t->hv_meta.data() + ptk::kMetaRedo);
+    }, 64);
+    return 0;
+  }
+  if (t->cap_nq != nq || t->cap_lens.empty() || t->hv_meta.empty()) return -1;
+  std::vector<uint32_t> over(nq + t->hv.max_heavy + 1, 0u);
+  uint32_t n_over = 0;
+  for_each_wave((uint32_t)waves, [&] {
+    if (t->metric == 1) ptk::radius_replay_kernel<3, 32, ptk::MetricL1>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
+    else ptk::radius_replay_kernel<5, 16>(t->dev, q, t->dim, e_inv, t->cap, offsets, o, over.data(), &n_over);
+  });
+  for_each_wave(3, [&] {
+    if (t->metric == 1) ptk::radius_coop_replay_kernel<ptk::MetricL1>(t->dev, q, t->dim, e_inv, t->hv, offsets, o, over.data(), &n_over);
+    else ptk::radius_coop_replay_kernel<ptk::MetricL2>(t->dev, q, t->dim, e_inv, t->hv, offsets, o, over.data(), &n_over);
+  });
+  for_each_lane(nq + t->hv.max_heavy, [&] {
+    if (t->metric == 1) ptk::radius_kernel<16, 2048, 64, 4, true, ptk::MetricL1>(t->dev, q, t->dim, over.data(), nq + t->hv.max_heavy, radius, e_inv, nullptr, offsets, o, &n_over);
+    else ptk::radius_kernel<16, 2048, 64, 4, true>(t->dev, q, t->dim, over.data(), nq + t->hv.max_heavy, radius, e_inv, nullptr, offsets, o, &n_over);
+  }, 64);
+  if (stats != nullptr) {
+    stats[0] = std::min(t->hv_meta[ptk::kMetaHeavy], t->hv.max_heavy);
+    stats[1] = t->hv_meta[ptk::kMetaRedo];
+    stats[2] = n_over;
+  }
   return (int64_t)n_over;
 }
 

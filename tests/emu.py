@@ -140,6 +140,31 @@ class EmulatedTree:
         assert lost >= 0
         return off, out, int(lost)
 
+    def search_radius_lists_capped(self, q, radius, far_cap, e=None, perm=None, sub_cap=64, pool_small=False,
+                                   max_heavy=None, entry_cap=None):
+        """The radius search with its long queries finished by a wavefront each (ptk_kernels_coopr.hpp): the list pass
+        capped at `far_cap` far children per query, the cooperative count, the recount of what was lost; the replay, the
+        cooperative replay, the ordinary fill kernel for what was lost.
+        Returns (offsets, rows, {handed over, recounted from the root, rows filled by the ordinary kernel})."""
+        q = np.ascontiguousarray(q, dtype=np.float32)
+        nq = len(q)
+        p = perm.ctypes.data if perm is not None else None
+        counts = np.zeros(nq + 1, dtype=np.uint64)
+        mh = nq if max_heavy is None else max_heavy
+        ec = mh * 1024 if entry_cap is None else entry_cap
+        fn = self.lib.emu_radius_lists_capped
+        fn.restype = ctypes.c_int64
+        fn.argtypes = [c_void_p, c_void_p, c_uint64, c_float, c_float, c_void_p, c_uint32, c_uint32, c_int, c_uint32,
+                       c_uint32, c_int, c_void_p, c_void_p, c_void_p, c_void_p]
+        args = (self.h, q.ctypes.data, nq, radius, e or 1.0, p, sub_cap, far_cap, int(pool_small), mh, ec)
+        assert fn(*args, 0, counts.ctypes.data, None, None, None) == 0
+        off = np.zeros(nq + 1, dtype=np.uint64)
+        off[1:] = np.cumsum(counts[:nq])
+        out = np.zeros(int(off[-1]), dtype=pt.NEIGHBOR)
+        stats = np.zeros(3, dtype=np.uint32)
+        assert fn(*args, 1, None, off.ctypes.data, out.ctypes.data, stats.ctypes.data) >= 0
+        return off, out, {"handed_over": int(stats[0]), "recounted": int(stats[1]), "refilled": int(stats[2])}
+
     # -- persistent (state machine + lane refill) kernels: 64 host threads per wavefront --
     def search_box(self, mins, maxs):
         from ctypes import c_uint64, c_void_p

@@ -829,6 +829,43 @@ def test_k_nearest_cap_follows_the_batch_and_large_batches_run_as_two_launches(g
         assert tree.knn_coop_counts()["cooperative"] > 0
 
 
+@pytest.mark.parametrize("cloud,radius,leaf", [("scan", 1.0, 10), ("scan", 6.0, 10), ("ties", 0.05, 10), ("uniform", 0.002, 1),
+                                               ("uniform", 0.004, 40)])
+def test_radius_search_with_long_queries_finished_by_wavefronts(gpu, cloud, radius, leaf):
+    """ptk_kernels_coopr.hpp: the list pass of the radius search capped (test hook radius_cap: 2 and 24 far children per
+    query, then the rule of the batch), the queries it hands over counted and filled by a wavefront each in the
+    reference's row order, rows it cannot finish (more than 1 024 leaves with hits) searched again by one lane.  Offsets
+    and rows byte-equal to the oracle; exact and approximate; device buffers and host buffers."""
+    import torch
+
+    if cloud == "scan":
+        pts, q = ds.lidar_cloud(400_000, seed=1, unit_scale=4.0), ds.lidar_cloud(30_000, seed=2, pose=(3.0, 1.5), unit_scale=4.0)
+    elif cloud == "ties":
+        pts, q = _clouds("ties", 60_000, 20_000)
+    else:
+        pts, q = ds.uniform_cloud(200_000, 3, 11), ds.uniform_cloud(20_000, 3, 12)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, leaf, device=gpu)
+    ref = oracle.Oracle(pts, leaf, "port")
+    ref.set_threads(ref.max_threads())
+    dq = torch.from_numpy(q).to(f"cuda:{gpu}")
+    handed = 0
+    for e in (None, 1.5):
+        want_off, want = ref.search_radius(q, np.float32(radius), e=e)
+        for cap in (2, 24, None):
+            pt.set_test_knobs(radius_cap=cap)
+            off, raw = tree.search_radius_device(dq, np.float32(radius), e=e or 1.0)
+            torch.cuda.synchronize()
+            assert np.array_equal(off.cpu().numpy().astype(np.uint64), want_off), (cloud, radius, e, cap)
+            assert raw.cpu().numpy().tobytes() == want.tobytes(), (cloud, radius, e, cap)
+            if cap == 2:
+                handed += tree.radius_coop_counts()["cooperative"]
+                got = tree.search_radius(q, np.float32(radius), e) if e else tree.search_radius(q, np.float32(radius))
+                assert np.array_equal(got.offsets, want_off) and got.flat.tobytes() == want.tobytes(), (cloud, radius, e, "host")
+    pt.set_test_knobs()
+    # (the lattice cloud has heaps of coincident points: a tree deeper than a key has bits for runs uncapped)
+    assert handed > 0 or cloud == "ties"
+
+
 def _line_family_case(rng, kind, jitter):
     """One cloud of tools/fuzz_lines.py: points on a line (or a coarse lattice) in 2-D / 3-D, tiny leaves, queries off
     the line or next to tree points -- thousands of points nearly equally far, box distances that drift by rounding."""

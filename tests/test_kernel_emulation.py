@@ -317,6 +317,46 @@ def test_emulated_cooperative_knn_on_a_line_of_points_with_drifting_box_distance
     assert sweeps > 0  # equal distances at the edge of the list: second sweeps did run
 
 
+@pytest.mark.parametrize("name", ["scan", "scan-lost", "uniform-leaf1", "ties", "approximate"])
+def test_emulated_capped_radius_search_and_its_cooperative_finish_equal_oracle(name):
+    """The radius search with its long queries finished by a wavefront each (ptk_kernels_coopr.hpp): the list pass capped at a
+    few far children per query, the cooperative count of what it handed over (any order; leaf entries keyed by their
+    place in the reference's depth-first order, sorted), the recount from the root of what that could not finish (pool
+    and spill full, more than 1 024 leaves with hits, the entry block exhausted); then the replay of the lanes' lists,
+    the cooperative replay of the handed-over tails, and the ordinary fill kernel for what was lost.  Offsets and rows
+    byte-equal to the reference's traversal-order rows in every regime."""
+    kw, e = {}, None
+    if name.startswith("scan"):
+        pts = ds.lidar_cloud(120_000, seed=1, unit_scale=2.5)
+        q = ds.lidar_cloud(150, seed=2, pose=(3.0, 1.5), unit_scale=2.5)
+        leaf, radius, caps = 10, np.float32(1.0), (1, 8)
+        if name == "scan-lost":  # a pool of 64 subtrees and 8 spill slots; room for 3 000 entries in all
+            q, radius, caps, kw = q[:60], np.float32(4.0), (2,), {"pool_small": True, "entry_cap": 3000, "max_heavy": 50}
+    elif name == "uniform-leaf1":  # more than 1 024 leaves with hits per query: recounted and refilled by one lane
+        pts, q, leaf, radius, caps = ds.uniform_cloud(30_000, 3, 11), ds.uniform_cloud(40, 3, 12), 1, np.float32(0.05), (4,)
+    elif name == "ties":
+        pts = (np.round(ds.uniform_cloud(20_000, 3, 5) * 8) / 8).astype(np.float32)
+        q = (np.round(ds.uniform_cloud(100, 3, 6) * 16) / 16).astype(np.float32)
+        leaf, radius, caps = 10, np.float32(0.03), (1, 4)
+    else:
+        pts, q, leaf, radius, caps, e = ds.uniform_cloud(30_000, 3, 11), ds.uniform_cloud(40, 3, 12), 2, np.float32(0.02), (4,), 2.0
+    emu = EmulatedTree(pts, leaf)
+    ref = oracle.Oracle(pts, leaf, "port")
+    want_off, want = ref.search_radius(q, radius, e=e)
+    perm, _ = emu.morton_permutation(q)
+    seen = {}
+    for cap in caps:
+        for p in (None, perm):
+            off, rows, stats = emu.search_radius_lists_capped(q, radius, cap, e=e, perm=p, **kw)
+            assert np.array_equal(off, want_off) and rows.tobytes() == want.tobytes(), (name, cap)
+            seen[cap] = stats
+    assert seen[caps[0]]["handed_over"] > 0
+    if name in ("scan-lost", "uniform-leaf1"):
+        assert seen[caps[0]]["recounted"] > 0 and seen[caps[0]]["refilled"] >= seen[caps[0]]["recounted"]
+    else:
+        assert seen[caps[0]]["recounted"] == 0
+
+
 def test_emulated_direct_cooperative_search_parks_subtrees_in_hbm():
     """Variant 9 = the small-batch form: the ranked classes go straight from phase 1 to the cooperative search.  Its
     emulated launch has a pool of 12 subtrees per group, so the queries of the scanner's blind disc (hundreds of
