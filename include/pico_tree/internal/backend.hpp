@@ -34,10 +34,11 @@
 namespace pico_tree::internal {
 
 //! The device search cannot take this tree or batch (PTK_ERR_UNSUPPORTED: a topological tree deeper than the device
-//! stack, a dimension beyond the LDS staging).  The batched members catch it and serve the call the way the
-//! reference does -- a loop of the per-query host members over the rows (_pyco_tree/kd_tree.hpp:128) -- with one
-//! warning per process.  Every other failure (no device, HIP error, out of memory) stays an error: a missing or
-//! broken backend is never papered over.
+//! stack, a dimension beyond the LDS staging).  The batched members THROW it like every other failure of the backend
+//! (no device, HIP error, out of memory): the batched path has no CPU fallback.  A caller who wants such a call served
+//! the way the reference serves every call -- a loop of the per-query host members over the rows
+//! (_pyco_tree/kd_tree.hpp:128) -- says so once per process with pico_tree::allow_host_loop(true); the members then
+//! catch the refusal, print one message and run that loop.  Off by default.
 struct ptk_unsupported : std::runtime_error {
   using std::runtime_error::runtime_error;
 };
@@ -50,6 +51,11 @@ inline void ptk_check(int status, char const* what) {
     throw std::runtime_error(
         std::string("pico_tree backend: ") + what + ": " + ptk_last_error());
   }
+}
+
+inline std::atomic<bool>& host_loop_flag() {
+  static std::atomic<bool> allowed{false};
+  return allowed;
 }
 
 inline void warn_host_loop(char const* why) {

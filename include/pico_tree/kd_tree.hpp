@@ -37,6 +37,11 @@
 
 namespace pico_tree {
 
+//! Off by default: a batched search the device refuses for a valid tree (PTK_ERR_UNSUPPORTED) throws.  With
+//! allow_host_loop(true) such a call is served by the loop of per-query host members the reference runs for every call
+//! (_pyco_tree/kd_tree.hpp:128), after one message on stderr.  Process-wide.
+inline void allow_host_loop(bool on) { internal::host_loop_flag().store(on); }
+
 template <typename Space_, typename Metric_ = metric_l2_squared, typename Index_ = int>
 class kd_tree {
   static_assert(
@@ -300,6 +305,7 @@ class kd_tree {
               offsets.data(), &rows),
           "ptk_search_radius");
     } catch (internal::ptk_unsupported const& refused) {
+      if (!internal::host_loop_flag().load()) throw;  // (the batched path has no CPU fallback unless asked for)
       std::vector<std::vector<neighbor_type>> per_row;
       host_radius(q, radius, scalar_type(1), per_row, sort, refused.what());
       for (size_type i = 0; i < q.rows(); ++i) offsets[i + 1] = offsets[i] + per_row[i].size();
@@ -332,6 +338,7 @@ class kd_tree {
       internal::ptk_check(
           api::box(device(), lo.data(), hi.data(), lo.rows(), offsets.data(), &rows), "ptk_search_box");
     } catch (internal::ptk_unsupported const& refused) {
+      if (!internal::host_loop_flag().load()) throw;  // (the batched path has no CPU fallback unless asked for)
       internal::warn_host_loop(refused.what());
       std::vector<std::vector<index_type>> per_row(lo.rows());
       space_view_type s = view();
@@ -443,6 +450,7 @@ class kd_tree {
               reinterpret_cast<typename api::neighbor*>(out)),
           "ptk_search_knn");
     } catch (internal::ptk_unsupported const& refused) {
+      if (!internal::host_loop_flag().load()) throw;  // (the batched path has no CPU fallback unless asked for)
       // The reference's loop (_pyco_tree/kd_tree.hpp:128-134): row i into out[i * k .. i * k + k).
       internal::warn_host_loop(refused.what());
       using row_point = point_map<scalar_type const, dim>;
@@ -505,6 +513,7 @@ class kd_tree {
               device(), q.data(), q.rows(), radius, e, sort ? 1 : 0, offsets.data(), &rows),
           "ptk_search_radius");
     } catch (internal::ptk_unsupported const& refused) {
+      if (!internal::host_loop_flag().load()) throw;  // (the batched path has no CPU fallback unless asked for)
       host_radius(q, radius, e, out, sort, refused.what());
       return;
     }

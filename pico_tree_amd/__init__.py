@@ -199,6 +199,17 @@ def _load():
 
 PTK_ERR_UNSUPPORTED = -2
 _host_loop_warned = False
+_host_loop_allowed = False
+
+
+def allow_host_loop(on: bool = True) -> None:
+    """Off by default: a batched search the DEVICE refuses for a valid tree (``PTK_ERR_UNSUPPORTED`` -- a topological
+    tree deeper than the device stack, a dimension beyond the LDS staging) raises :class:`PtkError`, like every other
+    failure of the backend: the batched path has no CPU fallback.  ``allow_host_loop(True)`` lets the wrapper serve such a
+    call with the library's host loop (``ptk_host_search_*``: the reference's own batch loop over the per-query search)
+    after one ``RuntimeWarning``.  Process-wide."""
+    global _host_loop_allowed
+    _host_loop_allowed = bool(on)
 
 
 def _warn_host_loop(why: str) -> None:
@@ -793,10 +804,10 @@ class KdTree:
         return nns
 
     def _served(self, status: int, host_loop) -> None:
-        """``_check``, except that a search the DEVICE refuses for a valid tree (PTK_ERR_UNSUPPORTED) is served by the
-        host loop of the library (``ptk_host_search_*``: the reference's own batch loop) with one warning.  Nothing
-        else is: a missing device or a HIP error raises."""
-        if status == PTK_ERR_UNSUPPORTED and not self._f64:
+        """``_check``: every failure raises.  Only after ``allow_host_loop(True)`` is a search the DEVICE refuses for a
+        valid tree (PTK_ERR_UNSUPPORTED) served by the host loop of the library (``ptk_host_search_*``: the reference's
+        own batch loop) with one warning; a missing device or a HIP error raises regardless."""
+        if status == PTK_ERR_UNSUPPORTED and not self._f64 and _host_loop_allowed:
             lib = _load()
             _warn_host_loop(lib.ptk_last_error().decode("utf-8", "replace"))
             status = host_loop(lib)

@@ -1061,11 +1061,12 @@ def test_rows_in_page_locked_blocks_of_the_pool(gpu):
 
 
 @pytest.mark.skipif(not oracle.have_reference(), reason="compiled reference not present")
-def test_a_call_the_device_refuses_is_served_by_the_host_loop(gpu):
+def test_a_call_the_device_refuses_raises_unless_the_host_loop_is_asked_for(gpu):
     """A topological tree some 3000 levels deep (coincident angles, leaf size 1) is beyond the device stack of the
-    topological kernels: ptk_search_* answer PTK_ERR_UNSUPPORTED, and the wrapper serves the call with the library's
-    host loop (ptk_host_search_*: the reference's own batch loop) after ONE warning -- rows equal the reference's
-    kd_tree<space, metric_so2>.  The C entry points themselves still refuse: nothing falls back silently."""
+    topological kernels: ptk_search_* answer PTK_ERR_UNSUPPORTED and the wrapper RAISES -- the batched path has no CPU
+    fallback.  Only after pico_tree_amd.allow_host_loop(True) is the call served by the library's host loop
+    (ptk_host_search_*: the reference's own batch loop) after ONE warning -- rows equal the reference's
+    kd_tree<space, metric_so2>."""
     import warnings
 
     ring = np.empty((4000, 1), dtype=np.float32)
@@ -1076,15 +1077,23 @@ def test_a_call_the_device_refuses_is_served_by_the_host_loop(gpu):
     ref = oracle.Oracle(ring, 1, "reference", "SO2")
     out = np.empty((len(q), 3), dtype=pt.NEIGHBOR)
     assert pt._load().ptk_search_knn(tree._h, q.ctypes.data, len(q), 3, np.float32(1.0), out.ctypes.data) == -2
-    pt._host_loop_warned = False
-    with pytest.warns(RuntimeWarning, match="device search refused"):
-        got = tree.search_knn(q, 3)
-    assert got.tobytes() == ref.search_knn(q, 3).tobytes()
-    with warnings.catch_warnings():
-        warnings.simplefilter("error")  # (no second warning)
-        rows = tree.search_radius(q, 0.001)
-    off, flat = ref.search_radius(q, 0.001)
-    assert np.array_equal(rows.offsets, off) and rows.flat.tobytes() == flat.tobytes()
+    with pytest.raises(pt.PtkError, match="too deep"):
+        tree.search_knn(q, 3)
+    with pytest.raises(pt.PtkError, match="too deep"):
+        tree.search_radius(q, 0.001)
+    pt.allow_host_loop(True)
+    try:
+        pt._host_loop_warned = False
+        with pytest.warns(RuntimeWarning, match="device search refused"):
+            got = tree.search_knn(q, 3)
+        assert got.tobytes() == ref.search_knn(q, 3).tobytes()
+        with warnings.catch_warnings():
+            warnings.simplefilter("error")  # (no second warning)
+            rows = tree.search_radius(q, 0.001)
+        off, flat = ref.search_radius(q, 0.001)
+        assert np.array_equal(rows.offsets, off) and rows.flat.tobytes() == flat.tobytes()
+    finally:
+        pt.allow_host_loop(False)
 
 
 def test_config1_through_the_device_matches_the_committed_hashes(gpu):
