@@ -419,13 +419,20 @@ static int run_batch(std::string const& dir) {
     write_raw(dir + "/d_se2_box_flat.bin", bflat.data(), bflat.size());
   }
   {  // a call the device search refuses (a topological tree some 3000 levels deep: coincident angles, leaf size 1) is
-     // served as a loop of the per-query members -- the reference's own loop -- not thrown back at the caller
+     // THROWN back at the caller -- the batched path has no CPU fallback -- unless the caller has asked, once, for such
+     // calls to be served as a loop of the per-query members (the reference's own loop): pico_tree::allow_host_loop
     std::vector<std::array<float, 1>> ring(4000);
     for (size_t i = 0; i < ring.size(); ++i) ring[i][0] = i < 3000 ? 0.25f : static_cast<float>(i % 997) / 997.0f;
     auto so2 = pico_tree::make_kd_tree<pico_tree::metric_so2>(std::cref(ring), pico_tree::max_leaf_size_t(1));
     std::vector<std::array<float, 1>> rq(300);
     for (size_t i = 0; i < rq.size(); ++i) rq[i][0] = static_cast<float>(i) / 300.0f;
     std::vector<neighbor> got(rq.size() * 3);
+    try {
+      so2.search_knn(rq, 3, got.data());
+      return 46;  // (refused calls must not be served silently)
+    } catch (std::runtime_error const&) {
+    }
+    pico_tree::allow_host_loop(true);
     so2.search_knn(rq, 3, got.data());
     std::vector<std::uint64_t> off;
     std::vector<neighbor> flat;
@@ -440,6 +447,7 @@ static int run_batch(std::string const& dir) {
       for (size_t j = 0; j < one.size(); ++j)
         if (one[j].index != flat[off[i] + j].index || one[j].distance != flat[off[i] + j].distance) return 45;
     }
+    pico_tree::allow_host_loop(false);
   }
   // wrong dimension must throw, not crash
   try {
