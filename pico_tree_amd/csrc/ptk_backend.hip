@@ -731,7 +731,7 @@ uint32_t phase2_cap(float e, uint64_t nq) {
 
 // direct_ids == nullptr: the list is `ho`'s.  Otherwise it is the ranked head of the class-sorted entries, searched
 // straight from the continuation records of phase 1 (knn1_coop_kernel<.., DIRECT>), `lanes` lanes per query.
-template <int G>
+template <int G, class M = ptk::MetricL2>
 int launch_knn1_coop_direct(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
                             const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
                             const uint32_t* direct_ids) {
@@ -740,12 +740,13 @@ int launch_knn1_coop_direct(const ptk_tree* t, const float4* qs, ptk::Neighbor* 
   static_assert(G >= kCoopLanes, "the spill block is sized for groups of kCoopLanes lanes");
   const int resident = t->cus * (int)std::max<size_t>(1, std::min<size_t>(32, t->lds_per_cu / (smem + 512)));
   const int waves = std::min(resident, coop_waves(t) * (G / kCoopLanes));
-  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, kCoopPool, true>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<G, kCoopPool, true, true, M>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
                      knn1_ranges(t), qs, d_out, cont, ho, redo_list, direct_ids, spill, kCoopSpill);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
 
+template <class M = ptk::MetricL2>
 int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, const ptk::Cont& cont,
                      const ptk::Handover& ho, uint32_t* redo_list, hipStream_t s, ptk::Task* spill,
                      const uint32_t* direct_ids = nullptr) {
@@ -754,12 +755,12 @@ int launch_knn1_coop(const ptk_tree* t, const float4* qs, ptk::Neighbor* d_out, 
   const uint32_t spill_cap = spill ? kCoopSpill : 0u;
   if (direct_ids != nullptr) {
     // (32 lanes per query: 16 / 64 were measured, 1.91 / slower vs 1.72 ms of traversal kernels, profiles/r03_notes.txt item 3)
-    return launch_knn1_coop_direct<32>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
+    return launch_knn1_coop_direct<32, M>(t, qs, d_out, cont, ho, redo_list, s, spill, direct_ids);
   }
   // What phase 2 hands over has been tightened by its first far children: a pool of 96 holds it (0 of 152 k queries of
   // BASELINE config 2 overflow; with the spill the step loop is 5 % slower): no spill here.
   (void)spill_cap;
-  hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, false>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
+  hipLaunchKernelGGL((ptk::knn1_coop_kernel<kCoopLanes, kCoopPool, false, false, M>), dim3(waves), dim3(64), smem, s, knn1_tree(t),
                        knn1_ranges(t), qs, d_out, cont, ho, redo_list, nullptr, spill, 0u);
   PTK_HIP(hipGetLastError());
   return PTK_OK;
@@ -787,7 +788,7 @@ int coop_direct_mode(const ptk_tree* t, uint64_t nq) {
 // The k = 1 search under the default metric (ptk_kernels.hpp, "the two-phase k = 1 search"): phase 1 (which also
 // packs the launch-order records), the class order of the continuations, phase 2, and for exact searches the
 // cooperative search of what phase 2 handed over plus the replay of what that could not certify.
-template <int OVF>
+template <int OVF, class M = ptk::MetricL2>
 int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
                           ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   constexpr int LEAFB = 4;  // points fetched per round trip
@@ -847,7 +848,7 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   }
   // One chain of sections: search (phase 1) | other (class order) | search (phase 2, cooperative search, replay).
   Timer timer(t, s);
-  hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB>), dim3(blocks), dim3(64), 0, s, knn1_tree(t), d_q, t->dim, perm, nq,
+  hipLaunchKernelGGL((ptk::knn1_phase1u_kernel<LEAFB, M>), dim3(blocks), dim3(64), 0, s, knn1_tree(t), d_q, t->dim, perm, nq,
                      e_inv, d_out, cont, qs, tile_counts, cp.stride, scratch.batch_verdict());
   timer.next(0, nq);
   if (cap) {
@@ -879,11 +880,11 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
     side_guard.side = side;
     PTK_HIP(hipEventRecord(fork, s));
     PTK_HIP(hipStreamWaitEvent(side, fork, 0));
-    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, side, spill_a, ids_out);
+    int rc = launch_knn1_coop<M>(t, qs, d_out, cont, ho, redo_list, side, spill_a, ids_out);
     if (rc != PTK_OK) return rc;
     PTK_HIP(hipEventRecord(join, side));
   } else if (direct == 1) {
-    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s, spill_a, ids_out);
+    int rc = launch_knn1_coop<M>(t, qs, d_out, cont, ho, redo_list, s, spill_a, ids_out);
     if (rc != PTK_OK) return rc;
   }
   const dim3 p2_grid(blocks + 1 + extra_waves);
@@ -891,23 +892,23 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
   // 16 (20 waves) and 8 (40 waves) on both clouds (profiles/r02_notes.txt items 10, 23); without it 16 slots
   // (r01l_notes item 8).
   if (cap) {
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<kP2Ring, OVF, LEAFB>), p2_grid, dim3(64), (size_t)kP2Ring * 64 * 8, s, knn1_tree(t), qs,
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<kP2Ring, OVF, LEAFB, M>), p2_grid, dim3(64), (size_t)kP2Ring * 64 * 8, s, knn1_tree(t), qs,
                        e_inv, d_out, cont, ids_out, cap, ho);
   } else {
-    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, knn1_tree(t), qs,
+    hipLaunchKernelGGL((ptk::knn1_phase2_kernel<16, OVF, LEAFB, M>), p2_grid, dim3(64), (size_t)16 * 64 * 8, s, knn1_tree(t), qs,
                        e_inv, d_out, cont, ids_out, 0u, ho);
   }
   PTK_HIP(hipGetLastError());
   if (cap) {  // the queries phase 2 gave up on, then whatever the cooperative search could not certify
     // (the two cooperative launches may run side by side: each has its own spill block, and they append to the one
     // redo list through one atomic counter)
-    int rc = launch_knn1_coop(t, qs, d_out, cont, ho, redo_list, s, spill_b);
+    int rc = launch_knn1_coop<M>(t, qs, d_out, cont, ho, redo_list, s, spill_b);
     if (rc != PTK_OK) return rc;
     if (direct == 2) {  // join: the replay needs both lists complete
       PTK_HIP(hipStreamWaitEvent(s, join, 0));
       side_guard.side = nullptr;
     }
-    hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB>), dim3(t->cus), dim3(64), (size_t)16 * 64 * 8, s, knn1_tree(t), qs,
+    hipLaunchKernelGGL((ptk::knn1_redo_kernel<16, OVF, LEAFB, M>), dim3(t->cus), dim3(64), (size_t)16 * 64 * 8, s, knn1_tree(t), qs,
                        e_inv, d_out, cont, redo_list);
     PTK_HIP(hipGetLastError());
   }
@@ -928,16 +929,23 @@ int launch_knn1_two_phase(const ptk_tree* t, const float* d_q, const uint32_t* p
 // LDS per 64-lane block: record ring + q[dim] + off[dim] (+ the k-list while it fits).
 // (the most dynamic LDS a block may ask for is the handle's lds_per_block, from the device's properties)
 
-int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
-                  ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
+template <class M>
+int dispatch_knn1_of(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
+                     ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
   int rc = PTK_OK;
   switch (ovf_class_of(knn1_depth(t), 16)) {  // (the depth of what is traversed: the view without the piles if there is one)
-    case 0: rc = launch_knn1_two_phase<64>(t, d_q, perm, nq, e, d_out, s, scratch); break;
-    case 1: rc = launch_knn1_two_phase<256>(t, d_q, perm, nq, e, d_out, s, scratch); break;
-    case 2: rc = launch_knn1_two_phase<2048>(t, d_q, perm, nq, e, d_out, s, scratch); break;
+    case 0: rc = launch_knn1_two_phase<64, M>(t, d_q, perm, nq, e, d_out, s, scratch); break;
+    case 1: rc = launch_knn1_two_phase<256, M>(t, d_q, perm, nq, e, d_out, s, scratch); break;
+    case 2: rc = launch_knn1_two_phase<2048, M>(t, d_q, perm, nq, e, d_out, s, scratch); break;
     default: rc = fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", knn1_depth(t));
   }
   return rc;
+}
+// The two-phase k = 1 search: metric_l2_squared, and (r06) metric_l1 on trees without piles (see knn1_two_phase()).
+int dispatch_knn1(const ptk_tree* t, const float* d_q, const uint32_t* perm, uint64_t nq, float e,
+                  ptk::Neighbor* d_out, hipStream_t s, Scratch& scratch) {
+  if (t->metric.load() == PTK_METRIC_L1) return dispatch_knn1_of<ptk::MetricL1>(t, d_q, perm, nq, e, d_out, s, scratch);
+  return dispatch_knn1_of<ptk::MetricL2>(t, d_q, perm, nq, e, d_out, s, scratch);
 }
 
 }  // namespace
@@ -1326,6 +1334,11 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   // (on the tree's device, once per piece: a null stream is the null stream of THAT device)
   if (short_tree) PTK_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(ptk_neighbor), s));
   const bool l2 = t->metric.load() == PTK_METRIC_L2_SQUARED;
+  // k = 1 takes the two-phase search (phase 1, class order, capped phase 2, cooperative search) under the default metric
+  // and under metric_l1 on a tree without piles: both are sums of per-axis terms, so the box distance the reference
+  // keeps is a lower bound of the point distances below it -- what the cooperative search's certificate needs.  (The
+  // pile view resolves its stand-ins for the default metric only.)
+  const bool two_phase = k == 1 && t->dim <= 3 && (l2 || (t->metric.load() == PTK_METRIC_L1 && t->n_piles == 0));
   if (topological(t)) {
     if (deep_tree(t)) return fail(PTK_ERR_UNSUPPORTED, "tree depth %u is too deep for the device stack", t->max_depth);
     const bool reorder = want_reorder(t, nq);
@@ -1371,7 +1384,7 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   const bool reorder = want_reorder(t, nq);
   Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
-                       (k == 1 && l2 && t->dim <= 3 ? two_phase_scratch_bytes(t, nq) : 0) +
+                       (two_phase ? two_phase_scratch_bytes(t, nq) : 0) +
                        (k > 1 && k <= 64 && l2 && t->dim <= 3 && knn_cap(e, nq, k) != 0u ? knn_coop_scratch_bytes(t, nq) : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
@@ -1379,14 +1392,14 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
     // (the general kernels run every query to its end in its lane: the expensive queries to the front of the launch)
     // (the two-phase k = 1 search orders its own continuations: a batch that arrives coherent is not sorted again --
     // REORDER_AUTO only; the general kernels want the expensive queries in front whatever the order)
-    const bool may_skip = k == 1 && l2 && t->dim <= 3 && t->reorder.load() == PTK_REORDER_AUTO;
-    rc = make_permutation(t, d_q, nq, s, scratch, &perm, t->dim <= 3 && !(k == 1 && l2) ? ptk::kCellsEmptyFirst : 0u, may_skip);
+    const bool may_skip = two_phase && t->reorder.load() == PTK_REORDER_AUTO;
+    rc = make_permutation(t, d_q, nq, s, scratch, &perm, t->dim <= 3 && !two_phase ? ptk::kCellsEmptyFirst : 0u, may_skip);
     if (rc != PTK_OK) return rc;
   }
   if (t->dim > 3) {
     return ptkf::knn_nd(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, short_tree);
   }
-  if (k == 1 && l2) {  // the two-phase search is built for the default metric
+  if (two_phase) {
     rc = dispatch_knn1(t, d_q, perm, nq, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, scratch);
   } else if (k <= knn_reg_max(l2) && !short_tree) {
     rc = ptkf::knn_reg(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor*>(d_out), s, &scratch);

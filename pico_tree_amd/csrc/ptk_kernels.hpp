@@ -1520,7 +1520,12 @@ __device__ __forceinline__ uint32_t uniform_value(uint32_t v) {
 
 // The launch-order query records {x, y, z, bits(row)} of phase 2 are made here as well (gather through `perm`,
 // or the identity if it is null, + one coalesced 16-byte store) instead of by a packing pass of their own.
-template <int LEAFB>
+// M: metric_l2_squared, or (r06) metric_l1 -- the per-axis term of a split offset and of a point distance is the
+// metric's, everything else (the tree, `nbd - old + new`, the strict compares) is metric-free.  The cooperative search
+// and its certificate need a box distance that is a lower bound of the point distances of the subtree: true of the two
+// sums, NOT of metric_lpinf / metric_lninf (the reference sums the per-axis offsets for every Lp metric,
+// kd_tree_search.hpp:91-92, while their point distance is a maximum / minimum): those keep the general kernel.
+template <int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     DevTree t, const float* __restrict__ queries, uint32_t dim, const uint32_t* __restrict__ perm, uint64_t nq,
     float e_inv, Neighbor* __restrict__ out, Cont cont, float4* __restrict__ qs_out,
@@ -1564,7 +1569,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
     const float v = sel3(axis, qx, qy, qz);
     const float dv = f_sub(go_left ? right_min : left_max, v);
     // Descent state: box distance 0, offsets 0 => (0 - 0) + new_off, as the reference computes it.
-    const float d = f_add(f_sub(0.0f, 0.0f), f_mul(dv, dv));
+    const float d = f_add(f_sub(0.0f, 0.0f), M::one(dv));
     const uint32_t m = idx | (axis << 28) | (go_left ? kRecSide : 0u);
 #pragma unroll
     for (int j = kCand - 1; j >= 1; --j) {
@@ -1624,7 +1629,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
           PTK_SCALAR(dx);
           PTK_SCALAR(dy);
           PTK_SCALAR(dz);
-          pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
+          pol.visit(__float_as_int(p[u].w), point_distance3<M>(dx, dy, dz));
         }
       }
     }
@@ -1699,7 +1704,7 @@ __global__ __launch_bounds__(64) void knn1_phase1u_kernel(
               PTK_SCALAR(dx);
               PTK_SCALAR(dy);
               PTK_SCALAR(dz);
-              pol.visit(__float_as_int(p[u].w), f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)));
+              pol.visit(__float_as_int(p[u].w), point_distance3<M>(dx, dy, dz));
             }
           }
         }
@@ -1949,7 +1954,7 @@ PTK_GLOBAL __launch_bounds__(64) void class_order_kernel(const ContKey* __restri
 // left stops here -- its best so far goes back to cont.best and its slot onto heavy_list, for the
 // cooperative search below.  The few thousand queries this concerns are dependent chains of
 // hundreds of leaf visits which used to decide the duration of the whole launch.
-template <int S, int OVF, int LEAFB>
+template <int S, int OVF, int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn1_phase2_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
     const uint32_t* __restrict__ sorted_ids, uint32_t cap = 0, Handover ho = Handover{}) {
@@ -2005,8 +2010,8 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
   ho.slot = e;
   if (cls == kContOverflow) {
     pol.begin_query(qi);
-    finished = cap ? traverse<LEAFB, false, MetricL2, true>(t, qx, qy, qz, pol, st, cap, &ho)
-                   : traverse<LEAFB, false>(t, qx, qy, qz, pol, st);
+    finished = cap ? traverse<LEAFB, false, M, true>(t, qx, qy, qz, pol, st, cap, &ho)
+                   : traverse<LEAFB, false, M>(t, qx, qy, qz, pol, st);
   } else {
     pol.best_i = (int32_t)start.x;
     pol.best_d = __uint_as_float(start.y);
@@ -2014,8 +2019,8 @@ __global__ __launch_bounds__(64) void knn1_phase2_kernel(
       const Record r = cont.record(e, j);
       st.push(r.x, __uint_as_float(r.y));
     }
-    finished = cap ? traverse<LEAFB, true, MetricL2, true>(t, qx, qy, qz, pol, st, cap, &ho)
-                   : traverse<LEAFB, true>(t, qx, qy, qz, pol, st);
+    finished = cap ? traverse<LEAFB, true, M, true>(t, qx, qy, qz, pol, st, cap, &ho)
+                   : traverse<LEAFB, true, M>(t, qx, qy, qz, pol, st);
   }
   if (finished) {
     pol.end_query(qi);
@@ -2106,7 +2111,7 @@ constexpr uint32_t kCoopTieBudget = 6;  // exact ties a lane resolves per query 
 // that starts from the home-leaf bound only (DIRECT) keeps many more subtrees alive than one that a capped
 // traversal has tightened first: without the spill 39 of 12 139 ranked queries of a 900 k-query shard overflowed
 // a pool of 96 and their single-lane replays took 1.3 ms (profiles/r03_notes.txt item 3).
-template <int G, int POOL, bool DIRECT = false, bool SPILL = DIRECT>
+template <int G, int POOL, bool DIRECT = false, bool SPILL = DIRECT, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn1_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float4* __restrict__ qs, Neighbor* __restrict__ out, Cont cont,
     Handover ho, uint32_t* __restrict__ redo_list, const uint32_t* __restrict__ sorted_ids = nullptr,
@@ -2296,7 +2301,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
         const bool near_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
         const bool go_left = fresh ? (ref & kRecSide) != 0u : near_left;  // near side left = far child right (the record's side bit)
         const float dv = f_sub(go_left ? right_min : left_max, v);
-        const float new_off = f_mul(dv, dv);
+        const float new_off = M::one(dv);
         const uint32_t far_ref = go_left ? w0.w : w0.z;
         if (fresh) {
           off0 = axis == 0 ? new_off : off0;
@@ -2329,7 +2334,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
           PTK_SCALAR(dx);
           PTK_SCALAR(dy);
           PTK_SCALAR(dz);
-          const float du_d = (uint32_t)u < cnt ? f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz)) : 3.402823466e+38f;
+          const float du_d = (uint32_t)u < cnt ? point_distance3<M>(dx, dy, dz) : 3.402823466e+38f;
           const bool take = (uint32_t)u < cnt && du_d <= d;
           d_second = take ? d : (du_d < d_second ? du_d : d_second);
           d = take ? du_d : d;
@@ -2469,7 +2474,7 @@ __global__ __launch_bounds__(64) void knn1_coop_kernel(
 }
 
 // The reference search from the root for the queries the cooperative search listed.
-template <int S, int OVF, int LEAFB>
+template <int S, int OVF, int LEAFB, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn1_redo_kernel(
     DevTree t, const float4* __restrict__ qs, float e_inv, Neighbor* __restrict__ out, Cont cont,
     const uint32_t* __restrict__ redo_list) {
@@ -2484,7 +2489,7 @@ __global__ __launch_bounds__(64) void knn1_redo_kernel(
     pol.e_inv = e_inv;
     pol.out = out;
     pol.begin_query(qi);
-    traverse<LEAFB, false>(t, qrec.x, qrec.y, qrec.z, pol, st);
+    traverse<LEAFB, false, M>(t, qrec.x, qrec.y, qrec.z, pol, st);
     pol.end_query(qi);
   }
 }

@@ -879,7 +879,10 @@ void emu_last_coop(uint32_t* heavy, uint32_t* redo) {
   *heavy = g_last_heavy;
   *redo = g_last_redo;
 }
-int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint32_t* perm, int variant,
+}  // extern "C"
+
+template <class M>
+int emu_knn1_two_phase_m(void* h, const float* q, uint64_t nq, float e, const uint32_t* perm, int variant,
                        ptk_neighbor* out) {
   auto* t = static_cast<Emu*>(h);
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
@@ -903,11 +906,11 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     std::vector<float4> packed(nq);  // written by the kernel itself
     for_each_wave((uint32_t)((nq + 63) / 64), [&] {
       if (variant >= 5)
-        ptk::knn1_phase1u_kernel<4>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data(), tile_counts.data(), cstride);
+        ptk::knn1_phase1u_kernel<4, M>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data(), tile_counts.data(), cstride);
       else if (variant != 4)
-        ptk::knn1_phase1u_kernel<4>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
+        ptk::knn1_phase1u_kernel<4, M>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
       else
-        ptk::knn1_phase1u_kernel<1>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
+        ptk::knn1_phase1u_kernel<1, M>(t->dev, q, t->dim, perm, nq, e_inv, o, cont, packed.data());
     });
     for (uint64_t i = 0; i < nq; ++i) {
       if (std::memcmp(&packed[i], &qs[i], sizeof(float4)) != 0) return -4;
@@ -986,7 +989,7 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
   if (variant == 9) {  // the ranked classes straight from phase 1 to the cooperative search, phase 2 without them
     direct_listed = meta[ptk::kMetaRanked];
     for_each_wave(3, [&] {
-      ptk::knn1_coop_kernel<16, 12, true>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), sorted.data(),
+      ptk::knn1_coop_kernel<16, 12, true, true, M>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), sorted.data(),
                                           spill.data(), spill_cap);
     });
   }
@@ -997,24 +1000,24 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
     for (uint32_t l = 0; l < 64; ++l) {
       threadIdx.x = l;
       if (variant == 4)
-        ptk::knn1_phase2_kernel<4, 2048, 1>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+        ptk::knn1_phase2_kernel<4, 2048, 1, M>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
       else if (variant == 3)
-        ptk::knn1_phase2_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
+        ptk::knn1_phase2_kernel<16, 2048, 4, M>(t->dev, qs.data(), e_inv, o, cont, sorted.data());
       else
-        ptk::knn1_phase2_kernel<12, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho);
+        ptk::knn1_phase2_kernel<12, 2048, 4, M>(t->dev, qs.data(), e_inv, o, cont, sorted.data(), cap, ho);
     }
   }
   g_last_heavy = meta[ptk::kMetaHeavy] + direct_listed;
   g_last_redo = 0;
   if (cap) {
     for_each_wave(3, [&] {
-      if (variant == 5) ptk::knn1_coop_kernel<16, 96>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      if (variant == 5) ptk::knn1_coop_kernel<16, 96, false, false, M>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
       else if (variant == 9)
-        ptk::knn1_coop_kernel<16, 64, false>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), nullptr, spill.data(),
+        ptk::knn1_coop_kernel<16, 64, false, false, M>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data(), nullptr, spill.data(),
                                              spill_cap);
-      else if (variant == 6) ptk::knn1_coop_kernel<64, 192>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
-      else if (variant == 7) ptk::knn1_coop_kernel<8, 64>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
-      else ptk::knn1_coop_kernel<32, 128>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      else if (variant == 6) ptk::knn1_coop_kernel<64, 192, false, false, M>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      else if (variant == 7) ptk::knn1_coop_kernel<8, 64, false, false, M>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
+      else ptk::knn1_coop_kernel<32, 128, false, false, M>(t->dev, ranges, qs.data(), o, cont, ho, redo_list.data());
     });
   }
   g_last_spilled = 0;
@@ -1026,11 +1029,20 @@ int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint
       blockIdx.x = b;
       for (uint32_t l = 0; l < 64; ++l) {
         threadIdx.x = l;
-        ptk::knn1_redo_kernel<16, 2048, 4>(t->dev, qs.data(), e_inv, o, cont, redo_list.data());
+        ptk::knn1_redo_kernel<16, 2048, 4, M>(t->dev, qs.data(), e_inv, o, cont, redo_list.data());
       }
     }
   }
   return (int)meta[0];
+}
+
+extern "C" {
+
+int emu_knn1_two_phase(void* h, const float* q, uint64_t nq, float e, const uint32_t* perm, int variant,
+                       ptk_neighbor* out) {
+  // (the two-phase search is shipped for metric_l2_squared and metric_l1: ptk_search_knn_device)
+  if (static_cast<Emu*>(h)->metric == 1) return emu_knn1_two_phase_m<ptk::MetricL1>(h, q, nq, e, perm, variant, out);
+  return emu_knn1_two_phase_m<ptk::MetricL2>(h, q, nq, e, perm, variant, out);
 }
 
 // Box search: count pass then fill pass; offsets must hold nb + 1 entries, out is resized by the caller

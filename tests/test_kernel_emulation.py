@@ -15,6 +15,7 @@ import numpy as np
 import pytest
 
 import oracle
+import pico_tree_amd as pt
 from pico_tree_amd import datasets as ds
 from tests.emu import EmulatedTree
 from tests.test_oracle import check_against_golden, load
@@ -171,6 +172,27 @@ def test_emulated_two_phase_knn1_equals_oracle(case):
         for p in (None, perm):
             got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
             assert got.tobytes() == want.tobytes()
+    got, _ = emu.two_phase_knn1(q, e=1.4, perm=perm, variant=3)
+    assert got.tobytes() == ref.search_knn(q, 1, e=1.4).tobytes()
+
+
+@pytest.mark.parametrize("case", [c for c in _cases() if c[0] in ("uniform", "self", "lidar", "dim2", "leaf1")],
+                         ids=lambda c: c[0])
+def test_emulated_two_phase_knn1_under_metric_l1_equals_oracle(case):
+    """The two-phase k = 1 search instantiated over metric_l1 (r06: ptk_search_knn_device takes it for L1 trees without
+    piles): uncapped (3), one-point leaf batches and narrow tiers (4), capped at 2 far children with the cooperative
+    search, its certificate and the redo pass (5), cap 1 with 8 lanes per query (7), and the ranked classes straight
+    from phase 1 to the cooperative search (9) -- every form bit-identical to the reference's kd_tree<space, metric_l1>."""
+    _, pts, q, leaf, _ = case
+    q = q[:1500]
+    emu = EmulatedTree(pts, leaf, pt.Metric.L1)
+    ref = oracle.Oracle(pts, leaf, "port", "L1")
+    perm, _ = emu.morton_permutation(q)
+    want = ref.search_knn(q, 1)
+    for variant in (3, 4, 5, 7, 9):
+        for p in (None, perm):
+            got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
+            assert got.tobytes() == want.tobytes(), variant
     got, _ = emu.two_phase_knn1(q, e=1.4, perm=perm, variant=3)
     assert got.tobytes() == ref.search_knn(q, 1, e=1.4).tobytes()
 
