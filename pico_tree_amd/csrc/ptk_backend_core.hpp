@@ -621,7 +621,7 @@ inline size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
 // so the cap follows the batch as the k-NN one does (knn_cap): what it keeps roughly constant is the number of
 // hand-overs.  Trees deeper than a key has bits for (kRcMaxDepth) and batches of a few wavefronts run uncapped.  Test
 // hook radius_cap: that cap for every batch (0: none).
-constexpr int kRadiusCoopPool = 128;
+constexpr int kRadiusCoopPool = 64;
 constexpr uint32_t kRadiusCoopSpill = 2048;  // tasks a wavefront of the cooperative count can park in HBM
 inline uint32_t radius_cap(const ptk_tree* t, uint64_t nq) {
   if (t->dim > 3 || t->max_depth > 51u) return 0;  // (51 = ptk::kRcMaxDepth: static_assert in ptk_family_radius.hip)
@@ -638,7 +638,7 @@ inline uint32_t radius_cap(const ptk_tree* t, uint64_t nq) {
 inline uint64_t radius_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
 inline uint64_t radius_entry_cap(uint64_t nq) { return radius_max_handover(nq) * 192; }  // entries of all hand-overs together
 inline uint32_t radius_coop_blocks(const ptk_tree* t, uint64_t nq) {
-  return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 8u, std::max<uint64_t>(64, radius_max_handover(nq)));
+  return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 16u, std::max<uint64_t>(64, radius_max_handover(nq)));
 }
 // Transient arrays of a capped list pass (the hand-over list with its tasks, the redo list, the spill runs).
 inline size_t radius_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {

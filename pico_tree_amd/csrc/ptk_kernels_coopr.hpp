@@ -25,12 +25,12 @@
 // belongs to (they are handed over next-to-visit first), then one bit per branch below it, 0 for the child the
 // reference enters first, 1 for the other -- and the leaves with hits are listed as {key, leaf entry} in whatever
 // order the lanes meet them.  Leaves are never ancestors of one another, so the left-aligned keys are distinct and
-// their numeric order IS the reference's visit order: a bitonic sort of the wavefront's entries (at most 1 024, in
+// their numeric order IS the reference's visit order: a bitonic sort of the wavefront's entries (at most 512, in
 // LDS) restores it.  The sorted entries are a contiguous run in HBM; the fill pass (radius_coop_replay_kernel) gives
 // the row's tail to a wavefront again: 64 entries at a time, a prefix sum over their hit counts, every lane writes
 // the hits of its entry -- same arithmetic as the leaf scan (bit-identical distances).
 //
-// What cannot be finished here (more than 1 024 leaves with hits, pool and spill full, the entry block exhausted, a
+// What cannot be finished here (more than 512 leaves with hits, pool and spill full, the entry block exhausted, a
 // hand-over without tasks) is searched again from the root by one lane: the count pass recounts such a row with
 // radius_kernel<COUNT> over the redo list, the fill pass lists it for radius_kernel<FILL> (over_list) -- the same
 // values at the same places the other writers of that row put them.
@@ -40,7 +40,7 @@
 
 namespace ptk {
 
-constexpr uint32_t kRcMaxEntries = 1024;     // leaves with hits of one query the sort holds (LDS: 16 KB)
+constexpr uint32_t kRcMaxEntries = 512;      // leaves with hits of one query the sort holds (LDS: 8 KB)
 constexpr uint32_t kRcLost = 0xFFFFFFFFu;    // RadiusHeavy::run_n: this query's entries are not here (searched again)
 constexpr uint32_t kRcKeyTop = 57;           // the first path bit of a key (bits 63:58 = the task)
 constexpr uint32_t kRcKeyLow = 6;            // bits 5:0 = the piece of a large leaf

@@ -834,7 +834,7 @@ def test_k_nearest_cap_follows_the_batch_and_large_batches_run_as_two_launches(g
 def test_radius_search_with_long_queries_finished_by_wavefronts(gpu, cloud, radius, leaf):
     """ptk_kernels_coopr.hpp: the list pass of the radius search capped (test hook radius_cap: 2 and 24 far children per
     query, then the rule of the batch), the queries it hands over counted and filled by a wavefront each in the
-    reference's row order, rows it cannot finish (more than 1 024 leaves with hits) searched again by one lane.  Offsets
+    reference's row order, rows it cannot finish (more than 512 leaves with hits) searched again by one lane.  Offsets
     and rows byte-equal to the oracle; exact and approximate; device buffers and host buffers."""
     import torch
 

@@ -344,7 +344,7 @@ def test_emulated_capped_radius_search_and_its_cooperative_finish_equal_oracle(n
     """The radius search with its long queries finished by a wavefront each (ptk_kernels_coopr.hpp): the list pass capped at a
     few far children per query, the cooperative count of what it handed over (any order; leaf entries keyed by their
     place in the reference's depth-first order, sorted), the recount from the root of what that could not finish (pool
-    and spill full, more than 1 024 leaves with hits, the entry block exhausted); then the replay of the lanes' lists,
+    and spill full, more than 512 leaves with hits, the entry block exhausted); then the replay of the lanes' lists,
     the cooperative replay of the handed-over tails, and the ordinary fill kernel for what was lost.  Offsets and rows
     byte-equal to the reference's traversal-order rows in every regime."""
     kw, e = {}, None
@@ -354,7 +354,7 @@ def test_emulated_capped_radius_search_and_its_cooperative_finish_equal_oracle(n
         leaf, radius, caps = 10, np.float32(1.0), (1, 8)
         if name == "scan-lost":  # a pool of 64 subtrees and 8 spill slots; room for 3 000 entries in all
             q, radius, caps, kw = q[:60], np.float32(4.0), (2,), {"pool_small": True, "entry_cap": 3000, "max_heavy": 50}
-    elif name == "uniform-leaf1":  # more than 1 024 leaves with hits per query: recounted and refilled by one lane
+    elif name == "uniform-leaf1":  # more than 512 leaves with hits per query: recounted and refilled by one lane
         pts, q, leaf, radius, caps = ds.uniform_cloud(30_000, 3, 11), ds.uniform_cloud(40, 3, 12), 1, np.float32(0.05), (4,)
     elif name == "ties":
         pts = (np.round(ds.uniform_cloud(20_000, 3, 5) * 8) / 8).astype(np.float32)
