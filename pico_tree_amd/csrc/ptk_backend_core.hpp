@@ -622,7 +622,8 @@ inline size_t knn_coop_scratch_bytes(const ptk_tree* t, uint64_t nq) {
 // hand-overs.  Trees deeper than a key has bits for (kRcMaxDepth) and batches of a few wavefronts run uncapped.  Test
 // hook radius_cap: that cap for every batch (0: none).
 constexpr int kRadiusCoopPool = 64;
-constexpr uint32_t kRadiusCoopSpill = 2048;  // tasks a wavefront of the cooperative count can park in HBM
+constexpr uint32_t kRadiusCoopSpill = 1024;  // tasks a wavefront of the cooperative count can park in HBM (32 KB each with their keys:
+                                             // 134 MB for the 4 096 wavefronts of a full launch; what overflows is recounted by one lane)
 inline uint32_t radius_cap(const ptk_tree* t, uint64_t nq) {
   if (t->dim > 3 || t->max_depth > 51u) return 0;  // (51 = ptk::kRcMaxDepth: static_assert in ptk_family_radius.hip)
   const int forced = knob_int("radius_cap", -1);
