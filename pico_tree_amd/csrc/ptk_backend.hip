@@ -1385,7 +1385,9 @@ int ptk_search_knn_device(const ptk_tree* t, const float* d_q, uint64_t nq, uint
   Scratch scratch(t, s, /*per_stream=*/true);
   rc = scratch.reserve((reorder ? permutation_scratch_bytes(nq) : 0) +
                        (two_phase ? two_phase_scratch_bytes(t, nq) : 0) +
-                       (k > 1 && k <= 64 && l2 && t->dim <= 3 && knn_cap(e, nq, k) != 0u ? knn_coop_scratch_bytes(t, nq) : 0));
+                       (k > 1 && k <= 64 && (l2 || t->metric.load() == PTK_METRIC_L1) && t->dim <= 3 && knn_cap(e, nq, k) != 0u
+                            ? knn_coop_scratch_bytes(t, nq)
+                            : 0));
   if (rc != PTK_OK) return rc;
   uint32_t* perm = nullptr;
   if (reorder) {  // Morton order along the first three axes, whatever the dimension
@@ -1532,7 +1534,8 @@ static int search_knn_host(const ptk_tree* t, const float* q, uint64_t nq, uint3
   }
   const bool two_phase = k == 1 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
                          ovf_class_of(knn1_depth(t), 16) != kDeepClass;
-  const bool capped = !two_phase && k > 1 && k <= 64 && t->dim <= 3 && t->metric.load() == PTK_METRIC_L2_SQUARED &&
+  const bool capped = !two_phase && k > 1 && k <= 64 && t->dim <= 3 &&
+                      (t->metric.load() == PTK_METRIC_L2_SQUARED || t->metric.load() == PTK_METRIC_L1) &&
                       knn_cap(e, std::max<uint64_t>((nq + 7) / 8, uint64_t(1) << 18), k) != 0u;
   const std::vector<uint64_t> first = host_pieces(nq, k, two_phase, capped);
   const uint64_t pieces = first.size() - 1;

@@ -583,7 +583,7 @@ inline uint32_t knn_coop_blocks(const ptk_tree* t, uint64_t nq) {
 inline uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
   // (below a few wavefronts of queries the two extra launches cost more than the tail: kernel ms with / without the
   // cap at 64 / 500 / 3 000 queries, knn = 16 0.13 / 0.27 / 0.30 against 0.11 / 0.66 / 0.90.  PTK_KNN_CAP_MIN_NQ: tests)
-  if (e != 1.0f || nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 256))) return 0;
+  if (k < 2 || e != 1.0f || nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 256))) return 0;  // (k = 1 has the two-phase search; where it does not apply -- metric_l1 on a tree with piles -- the general kernel runs uncapped)
   const int forced = knob_int("knn_cap", -1);
   if (forced >= 0) return (uint32_t)forced;
   const double n = (double)nq;

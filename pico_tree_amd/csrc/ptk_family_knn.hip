@@ -38,7 +38,8 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
   const uint32_t blocks = (uint32_t)((nq + BLOCK - 1) / BLOCK);
   const size_t smem = (size_t)S * BLOCK * 8;
   Timer timer(t, s);
-  if constexpr (std::is_same<M, ptk::MetricL2>::value && BLOCK == 64) {
+  // (the capped launch + cooperative search: the default metric and metric_l1, whose box distances are lower bounds)
+  if constexpr ((std::is_same<M, ptk::MetricL2>::value || std::is_same<M, ptk::MetricL1>::value) && BLOCK == 64) {
     const uint32_t cap = scratch != nullptr ? knn_cap(e, nq, k) : 0u;
     if (cap != 0u) {
       // The capped launch, the cooperative search of what it handed over, the reference search of what that could
@@ -90,7 +91,7 @@ int launch_knn_reg(const ptk_tree* t, const float* d_q, const uint32_t* perm, ui
   do {                                                                                                                  \
     hipLaunchKernelGGL((ptk::knn_reg_kernel<KK, S, OVF, BLOCK, LEAFB, M, true>), dim3(nb), dim3(BLOCK), smem, st,        \
                        t->dev, d_q, t->dim, perm ? perm + lo : nullptr, n, k, inv_ratio(e), d_out, cap_n, ho);          \
-    hipLaunchKernelGGL((ptk::knn_coop_kernel<KK, kKnnCoopPool>), dim3(cb), dim3(64), coop_smem, st, t->dev, ranges,      \
+    hipLaunchKernelGGL((ptk::knn_coop_kernel<KK, kKnnCoopPool, M>), dim3(cb), dim3(64), coop_smem, st, t->dev, ranges,      \
                        d_q, t->dim, k, d_out, ho, redo_list, ptk::kMetaRedo, sp, kKnnCoopSpill);                        \
   } while (0)
         if (k <= 4) PTK_LAUNCH_REG(4);

@@ -131,7 +131,7 @@ constexpr uint32_t knn_coop_lds_words(uint32_t pool, uint32_t K = 32u) {
 //   COLLECT = true:  the bound stays at `fixed` (= D); every point at a distance <= D becomes an entry
 //                    {distance, position | kKnnPosFlag, box distance} behind the n_ent entries already there.
 // Returns false if a subtree was lost (pool and spill full).
-template <int K, int POOL, bool COLLECT>
+template <int K, int POOL, bool COLLECT, class M = MetricL2>
 __device__ __forceinline__ bool knn_coop_sweep(
     const DevTree& t, float qx, float qy, float qz, const Task* __restrict__ src, uint32_t nt, PTK_LDS uint32_t* pool,
     PTK_LDS uint32_t* gbest, Task* __restrict__ spill_w, uint32_t spill_cap, KnnCertPolicy<K>& pol, float& tie_d,
@@ -226,7 +226,7 @@ __device__ __forceinline__ bool knn_coop_sweep(
         const bool near_left = f_sub(f_sub(f_add(left_max, right_min), v), v) > 0.0f;
         const bool go_left = fresh ? (ref & kRecSide) != 0u : near_left;
         const float dv = f_sub(go_left ? right_min : left_max, v);
-        const float new_off = f_mul(dv, dv);
+        const float new_off = M::one(dv);
         const uint32_t far_ref = go_left ? w0.w : w0.z;
         if (fresh) {
           off0 = axis == 0 ? new_off : off0;
@@ -264,7 +264,7 @@ __device__ __forceinline__ bool knn_coop_sweep(
             PTK_SCALAR(dx);
             PTK_SCALAR(dy);
             PTK_SCALAR(dz);
-            const float d = f_add(f_add(f_mul(dx, dx), f_mul(dy, dy)), f_mul(dz, dz));
+            const float d = point_distance3<M>(dx, dy, dz);
             if constexpr (COLLECT) {
               hit[u] = d <= fixed;
               hit_d[u] = d;
@@ -355,7 +355,10 @@ __device__ __forceinline__ bool knn_coop_sweep(
 // (HBM) and comes back when the pool has drained: 64 lanes keeping a far child each fill a pool of 128 in two steps
 // while the bound is still wide, and a query that loses a subtree has to be searched again from the root by ONE lane
 // -- the long searches this kernel exists for.
-template <int K, int POOL>
+// M: metric_l2_squared or (r06) metric_l1 -- both box distances are sums of per-axis terms and lower bounds of the point
+// distances below them, which is all the argument at the head of this file uses (see knn1_phase1u_kernel for why
+// metric_lpinf / metric_lninf cannot come here).
+template <int K, int POOL, class M = MetricL2>
 __global__ __launch_bounds__(64) void knn_coop_kernel(
     DevTree t, const uint2* __restrict__ ranges, const float* __restrict__ queries, uint32_t dim, uint32_t k,
     Neighbor* __restrict__ out, Handover ho, uint32_t* __restrict__ redo_list, uint32_t redo_word,
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
     float drop_min = kInf, prune_min = kInf;  // the nearest point this lane let go of / box distance it pruned at
     uint32_t n_ent = 0;
     if (!failed)
-      failed = !knn_coop_sweep<K, POOL, false>(t, qx, qy, qz, src, nt, pool, gbest, spill_w, spill_cap, pol, tie_d,
+      failed = !knn_coop_sweep<K, POOL, false, M>(t, qx, qy, qz, src, nt, pool, gbest, spill_w, spill_cap, pol, tie_d,
                                                drop_min, prune_min, 0.0f, ent, n_ent);
 
     // The k nearest of what the lanes hold (the handed-over entries are in every list that has not displaced them:
@@ -478,7 +481,7 @@ __global__ __launch_bounds__(64) void knn_coop_kernel(
         ent[2 * kKnnTieSlots + at] = 0u;
       }
       n_ent = (uint32_t)__popcll(sm);
-      failed = !knn_coop_sweep<K, POOL, true>(t, qx, qy, qz, src, nt, pool, gbest, spill_w, spill_cap, pol, tie_d,
+      failed = !knn_coop_sweep<K, POOL, true, M>(t, qx, qy, qz, src, nt, pool, gbest, spill_w, spill_cap, pol, tie_d,
                                               drop_min, prune_min, dk, ent, n_ent);
       crowded = n_ent > kKnnTieSlots;
       if (lane == 0) atomicAdd(&ho.meta[kKnnTieSweeps], 1u);

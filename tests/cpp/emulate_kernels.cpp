@@ -407,8 +407,8 @@ void emu_radius_topo(Emu* t, const float* q, uint64_t nq, float radius, float e_
 // (lanes one after the other), knn_coop_kernel (64 fibers per wavefront: ballots, shuffles, the shared pool), the
 // reference search of what could not be certified.  counts = {queries handed over, queries redone}.
 // pool_small != 0: a pool of 64 subtrees (overflows on long searches: the redo path).
-template <int K>
-int emu_knn_capped_k(Emu* t, const float* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap, int pool_small,
+template <int K, class M>
+int emu_knn_capped_km(Emu* t, const float* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap, int pool_small,
                      uint32_t max_heavy, ptk::Neighbor* o, uint32_t* counts) {
   std::vector<uint32_t> meta(ptk::kMetaWords, 0), heavy(nq + 1), ntasks(nq + 1), redo(nq + 1);
   std::vector<ptk::Task> tasks((size_t)std::max<uint32_t>(max_heavy, 1) * ptk::kMaxTasks);
@@ -420,21 +420,29 @@ int emu_knn_capped_k(Emu* t, const float* q, uint64_t nq, uint32_t k, const uint
   ho.tasks = tasks.data();
   ho.max_heavy = max_heavy;
   ho.full_keeps = 1u;  // (as launch_knn_reg: a query that finds the list full finishes in its lane)
-  for_each_lane(nq, [&] { ptk::knn_reg_kernel<K, 16, 2048, 64, 4, ptk::MetricL2, true>(t->dev, q, t->dim, perm, nq, k, 1.0f, o, cap, ho); }, 64);
+  for_each_lane(nq, [&] { ptk::knn_reg_kernel<K, 16, 2048, 64, 4, M, true>(t->dev, q, t->dim, perm, nq, k, 1.0f, o, cap, ho); }, 64);
   // (pool_small: a pool of 64 subtrees and 40 spill slots per wavefront -- long searches park subtrees in HBM and a
   // few overflow even that: the redo path)
   const uint32_t spill_cap = pool_small ? 40u : 4096u;
   std::vector<ptk::Task> spill((size_t)3 * spill_cap);
   const auto* ranges = reinterpret_cast<const uint2*>(t->enc.ranges.data());
   for_each_wave(3, [&] {
-    if (pool_small) ptk::knn_coop_kernel<K, 64>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
-    else ptk::knn_coop_kernel<K, 128>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
+    if (pool_small) ptk::knn_coop_kernel<K, 64, M>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
+    else ptk::knn_coop_kernel<K, 128, M>(t->dev, ranges, q, t->dim, k, o, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
   });
-  for_each_lane(128, [&] { ptk::knn_redo_kernel<K, 16, 2048, 4>(t->dev, q, t->dim, k, 1.0f, o, meta.data(), ptk::kMetaRedo, redo.data()); }, 64);
+  for_each_lane(128, [&] { ptk::knn_redo_kernel<K, 16, 2048, 4, M>(t->dev, q, t->dim, k, 1.0f, o, meta.data(), ptk::kMetaRedo, redo.data()); }, 64);
   counts[0] = meta[ptk::kMetaHeavy];
   counts[1] = meta[ptk::kMetaRedo];
   counts[2] = meta[ptk::kKnnTieSweeps];
   return 0;
+}
+
+// (the capped k > 1 search is shipped for metric_l2_squared and metric_l1: launch_knn_reg of ptk_family_knn.hip)
+template <int K>
+int emu_knn_capped_k(Emu* t, const float* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap, int pool_small,
+                     uint32_t max_heavy, ptk::Neighbor* o, uint32_t* counts) {
+  if (t->metric == 1) return emu_knn_capped_km<K, ptk::MetricL1>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
+  return emu_knn_capped_km<K, ptk::MetricL2>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
 }
 
 extern "C" {
@@ -593,7 +601,7 @@ int emu_knn_capped(void* h, const float* q, uint64_t nq, uint32_t k, const uint3
                    uint32_t max_heavy, ptk_neighbor* out, uint32_t* counts) {
   auto* t = static_cast<Emu*>(h);
   auto* o = reinterpret_cast<ptk::Neighbor*>(out);
-  if (t->dim > 3 || t->metric != 0 || k < 1 || k > 64) return -2;
+  if (t->dim > 3 || t->metric > 1 || k < 1 || k > 64) return -2;  // (metric_l2_squared or metric_l1)
   if (2 * t->st.max_depth + 2 > 16 + 2048) return -2;
   if (k <= 4) return emu_knn_capped_k<4>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);
   if (k <= 8) return emu_knn_capped_k<8>(t, q, nq, k, perm, cap, pool_small, max_heavy, o, counts);

@@ -308,6 +308,27 @@ def test_emulated_capped_knn_and_its_cooperative_search_equal_oracle(case):
         assert seen[(16, 2)][1] > 0 and emu.last_tie_sweeps > 0
 
 
+@pytest.mark.parametrize("name", ["uniform", "lidar", "ties"])
+def test_emulated_capped_knn_under_metric_l1_equals_oracle(name):
+    """The capped k > 1 search and its cooperative finish instantiated over metric_l1 (r06: launch_knn_reg takes it for
+    L1 trees): hand-overs, second sweeps on the lattice cloud, redo -- rows bit-identical to kd_tree<space, metric_l1>."""
+    pts, q, leaf = {"uniform": (ds.uniform_cloud(20_000, 3, 1), ds.uniform_cloud(300, 3, 2), 10),
+                    "lidar": (ds.lidar_cloud(30_000, 1), ds.lidar_cloud(300, 2, pose=(3.0, 1.5)), 10),
+                    "ties": ((np.round(ds.uniform_cloud(20_000, 3, 5) * 8) / 8).astype(np.float32),
+                             (np.round(ds.uniform_cloud(100, 3, 6) * 16) / 16).astype(np.float32), 10)}[name]
+    emu = EmulatedTree(pts, leaf, pt.Metric.L1)
+    ref = oracle.Oracle(pts, leaf, "port", "L1")
+    handed = swept = 0
+    for k in (3, 16, 40):
+        want = ref.search_knn(q, k)
+        for cap in (1, 2):
+            got, heavy, _ = emu.search_knn_capped(q, k, cap, pool_small=(cap == 1))
+            assert got.tobytes() == want.tobytes(), (name, k, cap)
+            handed += heavy
+            swept += emu.last_tie_sweeps
+    assert handed > 0 and (name != "ties" or swept > 0)
+
+
 def test_emulated_cooperative_knn_on_a_line_of_points_with_drifting_box_distances():
     """The case the fuzz soak of r05 failed on (profiles/r05_notes.txt item 24): 60 000 points on a line in the plane,
     leaves of one point, queries off the line -- thousands of points at nearly the same distance, a tree a hundred levels

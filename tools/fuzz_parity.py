@@ -215,6 +215,8 @@ def main():
     import torch
     import oracle
     import pico_tree_amd as pt
+    pt.allow_host_loop(True)  # (a search the device refuses -- a topological tree thousands of levels deep -- is part of what
+                              # is fuzzed: served by the library's host loop, which must equal the oracle too; off by default)
     global VERBOSE
     VERBOSE = args.verbose
     failures = unsupported = 0
