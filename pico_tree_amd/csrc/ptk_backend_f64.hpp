@@ -30,6 +30,8 @@ struct ptk_tree64 {
   void* d_ranges = nullptr;
   void* d_root = nullptr;  // root box: min[dim], max[dim]
   void* d_outer = nullptr; // topological metrics only: double2 per branch (made by ptk_tree64_set_metric)
+  void* d_occ = nullptr;   // which cells of the coarse Morton grid hold tree points (morton64_kernel): k-NN batches start
+                           // their long searches first
   uint64_t device_bytes = 0;
   uint32_t slots = 0;      // stack records a lane may need: 2 * depth + 4
   std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
@@ -81,7 +83,34 @@ int encode64(ptk_tree64& t, const double* points) {
   PTK_HIP(hipMemcpy(t.d_index, t.flat.indices.data(), ib, hipMemcpyHostToDevice));
   PTK_HIP(hipMemcpy(t.d_ranges, enc.ranges.data(), rb, hipMemcpyHostToDevice));
   PTK_HIP(hipMemcpy(t.d_root, root.data(), bb, hipMemcpyHostToDevice));
-  t.device_bytes = nb + pb + ib + rb + bb;
+  {  // the occupancy of the coarse grid (the key arithmetic of morton64_kernel, on the host: once per tree)
+    std::vector<uint8_t> occ(size_t(1) << ptk::kMorton64CellBits, 0);
+    double lo[3] = {0, 0, 0}, inv[3] = {0, 0, 0};
+    for (uint32_t d = 0; d < t.dim && d < 3; ++d) {
+      lo[d] = t.flat.root_box.min()[d];
+      const double ext = t.flat.root_box.max()[d] - t.flat.root_box.min()[d];
+      inv[d] = ext > 0 ? 1024.0 / ext : 0.0;
+    }
+    auto spread = [](uint32_t v) {  // spread10 of ptk_kernels.hpp
+      v &= 0x3FFu;
+      v = (v | (v << 16)) & 0x030000FFu;
+      v = (v | (v << 8)) & 0x0300F00Fu;
+      v = (v | (v << 4)) & 0x030C30C3u;
+      v = (v | (v << 2)) & 0x09249249u;
+      return v;
+    };
+    for (uint64_t i = 0; i < t.n_points; ++i) {
+      uint32_t key = 0;
+      for (uint32_t a = 0; a < 3 && a < t.dim; ++a) {
+        const double f = std::fmin(std::fmax((points[i * t.dim + a] - lo[a]) * inv[a], 0.0), 1023.0);
+        key |= spread((uint32_t)f) << a;
+      }
+      occ[key >> (30u - ptk::kMorton64CellBits)] = 1;
+    }
+    PTK_HIP(hipMalloc(&t.d_occ, occ.size()));
+    PTK_HIP(hipMemcpy(t.d_occ, occ.data(), occ.size(), hipMemcpyHostToDevice));
+  }
+  t.device_bytes = nb + pb + ib + rb + bb + (size_t(1) << ptk::kMorton64CellBits);
   t.dev.nodes = static_cast<const ptk::Node64*>(t.d_nodes);
   t.dev.pts = static_cast<const double*>(t.d_pts);
   t.dev.index = static_cast<const int32_t*>(t.d_index);
@@ -189,8 +218,9 @@ size_t permutation64_bytes(uint64_t nq) { return want_reorder64(nq) ? ptkf::perm
 
 // Device-side Morton ordering of a batch (make_permutation of the float32 side): *perm lists the
 // query rows in launch order; it lives in the lease's aux block.
+// long_first (k-NN): the queries in empty cells of the tree's occupancy grid to the front of the launch.
 int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipStream_t s, Stack64Lease& lease,
-                       const uint32_t** perm) {
+                       const uint32_t** perm, bool long_first = false) {
   *perm = nullptr;
   if (!want_reorder64(nq)) return PTK_OK;
   const int bits = ptkf::morton_bits(nq);
@@ -213,7 +243,8 @@ int make_permutation64(const ptk_tree64* t, const double* d_q, uint64_t nq, hipS
     box.inv[d] = ext > 0 ? 1024.0 / ext : 0.0;
   }
   hipLaunchKernelGGL(ptk::morton64_kernel, dim3((uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock)), dim3(ptk::kBlock), 0, s,
-                     d_q, t->dim, nq, box, (uint32_t)(30 - bits), keys, ids);
+                     d_q, t->dim, nq, box, (uint32_t)(30 - bits), keys, ids,
+                     long_first ? static_cast<const uint8_t*>(t->d_occ) : nullptr);
   const int rc_sort = ptkf::sort_pairs_u32(tmp, tmp_bytes, keys, keys_out, ids, ids_out, nq, bits, s);
   if (rc_sort != PTK_OK) return rc_sort;
   *perm = ids_out;
@@ -473,6 +504,7 @@ void ptk_tree64_destroy(ptk_tree64* t) {
     if (t->d_ranges) (void)hipFree(t->d_ranges);
     if (t->d_root) (void)hipFree(t->d_root);
     if (t->d_outer) (void)hipFree(t->d_outer);
+    if (t->d_occ) (void)hipFree(t->d_occ);
   }
   delete t;
 }
@@ -545,7 +577,7 @@ int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq,
   rc = lease.acquire(nq, permutation64_bytes(nq));
   if (rc != PTK_OK) return rc;
   const uint32_t* perm = nullptr;
-  rc = make_permutation64(t, d_q, nq, s, lease, &perm);
+  rc = make_permutation64(t, d_q, nq, s, lease, &perm, /*long_first=*/true);
   if (rc != PTK_OK) return rc;
   PTK_WITH_METRIC64(rc = launch_knn64<M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease,
                                          short_tree));

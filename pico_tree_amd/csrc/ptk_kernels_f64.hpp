@@ -701,9 +701,15 @@ __global__ __launch_bounds__(64) void radius64_kernel(
 struct Morton64Box {
   double lo[3], inv[3];
 };
+// occ (k-NN searches; r06): one byte per cell of the coarse grid the top kMorton64CellBits bits of the 30-bit key
+// address -- 1 = the cell holds a tree point.  A search is long where the query sits in EMPTY space (ptk_kernels.hpp,
+// CellTable): with the table the top bit of the order key says "the query's cell holds tree points", so the searches
+// that will be long start first and run beside the bulk of the batch instead of behind it.  Only the launch order
+// depends on it.
+constexpr uint32_t kMorton64CellBits = 18;
 PTK_GLOBAL __launch_bounds__(kBlock) void morton64_kernel(
     const double* __restrict__ queries, uint32_t dim, uint64_t nq, Morton64Box box, uint32_t drop,
-    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids) {
+    uint32_t* __restrict__ keys, uint32_t* __restrict__ ids, const uint8_t* __restrict__ occ = nullptr) {
   const uint64_t i = (uint64_t)blockIdx.x * kBlock + threadIdx.x;
   if (i >= nq) return;
   uint32_t key = 0;
@@ -711,7 +717,12 @@ PTK_GLOBAL __launch_bounds__(kBlock) void morton64_kernel(
     const double f = fmin(fmax((queries[i * dim + a] - box.lo[a]) * box.inv[a], 0.0), 1023.0);
     key |= spread10((uint32_t)f) << a;
   }
-  keys[i] = key >> drop;
+  uint32_t out = key >> drop;
+  if (occ != nullptr) {
+    const uint32_t cheap = occ[key >> (30u - kMorton64CellBits)] != 0 ? 1u : 0u;
+    out = (cheap << (29u - drop)) | (out >> 1);  // (the lowest Morton bit makes room: the key keeps its width)
+  }
+  keys[i] = out;
   ids[i] = (uint32_t)i;
 }
 
