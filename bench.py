@@ -426,6 +426,64 @@ def approximate_entry(pt, oracle, pts, q, tree, dq, leaf, e, steps, sample):
             "parity_sample_ok": bool(got.tobytes() == want.tobytes())}
 
 
+def metrics_and_f64_entries(pt, oracle, pts, q, leaf, device, steps, sample):
+    """The headline clouds under the other metrics of the reference's Python module (metric_l1, metric_lpinf:
+    ``ptk_tree_set_metric``) and over float64 points (``ptk_tree64_*``): knn = 1 and knn = 16, device-resident, each with a
+    parity sample against the oracle under that metric / dtype.  metric_l1 takes the two-phase k = 1 search and the capped
+    k > 1 search since r06; metric_lpinf cannot and runs the general kernel."""
+    import torch
+
+    nq = len(q)
+    cs = np.sort(np.random.default_rng(11).choice(nq, size=min(sample, nq), replace=False))
+    res = {"metrics": {}, "f64": {}}
+
+    def time_knn(tree, dq, k, rows):
+        out = torch.empty((nq, k, 2), dtype=rows, device=dq.device)
+        for _ in range(2):
+            tree.search_knn(dq, k, out)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            tree.search_knn(dq, k, out)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / steps * 1e3, out
+
+    dq = torch.from_numpy(q).to(f"cuda:{device}")
+    for metric in ("L1", "LPInf"):
+        tree = pt.KdTree(pts, pt.Metric[metric], leaf, device=device)
+        ref = oracle.Oracle(pts, leaf, "port", metric)
+        ref.set_threads(ref.max_threads())
+        entry = {}
+        for k in (1, 16):
+            ms, out = time_knn(tree, dq, k, torch.int32)
+            got = pt.DeviceNeighbors(out).numpy()[cs]
+            want = ref.search_knn(q[cs], k)
+            entry[f"knn{k}"] = {"value": round(nq / ms / 1e3, 1), "unit": "Mqueries/s", "ms_per_step": round(ms, 4),
+                                "parity_sample_ok": bool(got.reshape(want.shape).tobytes() == want.tobytes())}
+            del out
+        res["metrics"][metric] = entry
+        ref.close()
+        tree.close()
+    del dq
+    p64, q64 = pts.astype(np.float64), q.astype(np.float64)
+    tree = pt.KdTree(p64, pt.Metric.L2Squared, leaf, device=device)
+    ref = oracle.Oracle(p64, leaf, "port", dtype=np.float64)
+    ref.set_threads(ref.max_threads())
+    dq = torch.from_numpy(q64).to(f"cuda:{device}")
+    for k in (1, 16):
+        ms, out = time_knn(tree, dq, k, torch.int64)
+        got = pt.DeviceNeighbors(out).numpy()[cs]
+        want = ref.search_knn(q64[cs], k)
+        ok = np.array_equal(got["index"].reshape(want["index"].shape), want["index"]) and \
+            np.ascontiguousarray(got["distance"]).tobytes() == np.ascontiguousarray(want["distance"]).tobytes()
+        res["f64"][f"knn{k}"] = {"value": round(nq / ms / 1e3, 1), "unit": "Mqueries/s", "ms_per_step": round(ms, 4),
+                                 "parity_sample_ok": bool(ok)}
+        del out
+    ref.close()
+    tree.close()
+    return res
+
+
 def config3_entries(pt, oracle, pts, q, tree, dq, leaf, sample):
     """BASELINE configs[2] on the headline clouds: knn = 16 and search_radius r = 1.0 (squared radius 1.0)."""
     import torch
@@ -1034,6 +1092,11 @@ def main():
                 extras["config3"] = config3_entries(pt, oracle, pts, q, tree, dq, args.leaf, 100_000)
             if k == 1:
                 extras["approximate"] = approximate_entry(pt, oracle, pts, q, tree, dq, args.leaf, 1.05, 10, 20_000)
+            if args.cloud == "L" and args.order == "generated":  # (the other metrics and float64 on the headline clouds)
+                try:
+                    extras.update(metrics_and_f64_entries(pt, oracle, pts, q, args.leaf, local_rank, 5, 20_000))
+                except Exception as exc:  # noqa: BLE001 -- a leg that fails says so instead of taking the line with it
+                    extras["metrics"] = {"error": repr(exc)}
             # (c) the headline search on the other query order and on the other cloud
             also = []
             other_order = "morton" if args.order == "generated" else "generated"
