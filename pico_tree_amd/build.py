@@ -9,7 +9,11 @@ The library is one translation unit per kernel family (``csrc/ptk_backend_core.h
 lists them): the units compile side by side, each into ``csrc/_obj/<unit>.o`` with a
 compiler-written dependency file next to it, and only the units that include what
 changed are compiled again (an edit of ``ptk_kernels_lists.hpp`` rebuilds the radius
-unit and the core, not the k-NN, any-dimension, topological or double units).
+unit and the core, not the k-NN, any-dimension, topological or double units).  "Changed"
+is decided by CONTENT (a SHA-256 of the flags and of every repository file a unit
+includes, kept next to its object), not by modification times: the objects travel with
+the snapshot to the GPU box, where the copy has shuffled the times, and nothing is
+compiled again there.
 """
 
 from __future__ import annotations
@@ -62,26 +66,36 @@ def _deps(depfile: str) -> list:
     return shlex.split(rest)
 
 
+def _signature(unit: str, flags_line: str) -> str:
+    """What an object was made from: the flags and the CONTENTS of every repository file its dependency file lists (the
+    toolchain's own headers are taken as given).  Contents, not modification times: a copy of the tree -- the snapshot
+    that travels to the GPU box -- keeps the bytes and shuffles the times, and a unit must not be compiled again there."""
+    import hashlib
+
+    # (the flags without the place the tree happens to lie at: the GPU box runs a copy under another path)
+    h = hashlib.sha256(flags_line.replace(os.path.realpath(ROOT), "<root>").replace(ROOT, "<root>").encode())
+    deps = sorted(set(os.path.realpath(p) for p in _deps(os.path.join(OBJ, unit + ".d"))))
+    root = os.path.realpath(ROOT) + os.sep
+    mine = [p for p in deps if p.startswith(root)]
+    if not mine:
+        return ""
+    for p in mine:
+        try:
+            with open(p, "rb") as f:
+                h.update(p[len(root):].encode() + b"\0" + f.read())
+        except OSError:  # a header that is gone
+            return ""
+    return h.hexdigest()
+
+
 def _unit_stale(unit: str, flags_line: str) -> bool:
     obj = os.path.join(OBJ, unit + ".o")
-    dep = os.path.join(OBJ, unit + ".d")
-    cmdfile = os.path.join(OBJ, unit + ".cmd")
-    if not (os.path.exists(obj) and os.path.exists(dep) and os.path.exists(cmdfile)):
+    sigfile = os.path.join(OBJ, unit + ".sig")
+    if not (os.path.exists(obj) and os.path.exists(sigfile)):
         return True
-    with open(cmdfile) as f:
-        if f.read() != flags_line:  # other flags (an experiment build): compile again
-            return True
-    built = os.path.getmtime(obj)
-    deps = _deps(dep)
-    if not deps:
-        return True
-    for p in deps:
-        try:
-            if os.path.getmtime(p) > built:
-                return True
-        except OSError:  # a header that is gone
-            return True
-    return False
+    with open(sigfile) as f:
+        recorded = f.read().strip()
+    return recorded == "" or recorded != _signature(unit, flags_line)
 
 
 def _compile(unit: str, flags: list, flags_line: str, verbose: bool) -> None:
@@ -92,15 +106,15 @@ def _compile(unit: str, flags: list, flags_line: str, verbose: bool) -> None:
     if verbose:
         print(" ".join(cmd), file=sys.stderr)
     subprocess.check_call(cmd)
-    with open(os.path.join(OBJ, unit + ".cmd"), "w") as f:
-        f.write(flags_line)
+    with open(os.path.join(OBJ, unit + ".sig"), "w") as f:
+        f.write(_signature(unit, flags_line))
 
 
 def build(force: bool = False, verbose: bool = False, lib: str = LIB) -> str:
     """Compile what is out of date and link; returns the path of libptk.so."""
-    os.makedirs(OBJ, exist_ok=True)
     flags = _compile_flags()
     flags_line = " ".join(flags)
+    os.makedirs(OBJ, exist_ok=True)
     todo = [u for u in UNITS if force or _unit_stale(u, flags_line)]
     if todo:
         jobs = max(1, min(len(todo), int(os.environ.get("PTK_BUILD_JOBS", os.cpu_count() or 4))))
@@ -108,12 +122,18 @@ def build(force: bool = False, verbose: bool = False, lib: str = LIB) -> str:
             for _ in pool.map(lambda u: _compile(u, flags, flags_line, verbose), todo):
                 pass
     objs = [os.path.join(OBJ, u + ".o") for u in UNITS]
-    if todo or not os.path.exists(lib) or any(os.path.getmtime(o) > os.path.getmtime(lib) for o in objs):
+    # (the link is remembered the same way: the signatures of the objects the library was linked from)
+    linked = os.path.join(OBJ, os.path.basename(lib) + ".sig")
+    want = "\n".join(open(os.path.join(OBJ, u + ".sig")).read() for u in UNITS)
+    have = open(linked).read() if os.path.exists(linked) else None
+    if todo or not os.path.exists(lib) or have != want:
         hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         subprocess.check_call(cmd)
+        with open(linked, "w") as f:
+            f.write(want)
     return lib
 
 
