@@ -625,7 +625,9 @@ constexpr int kRadiusCoopPool = 64;
 constexpr uint32_t kRadiusCoopSpill = 1024;  // tasks a wavefront of the cooperative count can park in HBM (32 KB each with their keys:
                                              // 134 MB for the 4 096 wavefronts of a full launch; what overflows is recounted by one lane)
 inline uint32_t radius_cap(const ptk_tree* t, uint64_t nq) {
-  if (t->dim > 3 || t->max_depth > 51u) return 0;  // (51 = ptk::kRcMaxDepth: static_assert in ptk_family_radius.hip)
+  // (51 = ptk::kRcMaxDepth, the branches a key has bits for: static_assert in ptk_family_radius.hip; a leaf of more than
+  // 64 pieces of 32 points would run out of the key's piece bits)
+  if (t->dim > 3 || t->max_depth > 51u || t->max_leaf_count > 2048u) return 0;
   const int forced = knob_int("radius_cap", -1);
   if (forced >= 0) return (uint32_t)forced;
   // Measured on BASELINE config 3's cloud (tools/time_radius_sizes.py, profiles/r06_notes.txt item 3; count + fill ms,

@@ -360,7 +360,7 @@ def test_emulated_cooperative_knn_on_a_line_of_points_with_drifting_box_distance
     assert sweeps > 0  # equal distances at the edge of the list: second sweeps did run
 
 
-@pytest.mark.parametrize("name", ["scan", "scan-lost", "uniform-leaf1", "ties", "approximate"])
+@pytest.mark.parametrize("name", ["scan", "scan-lost", "uniform-leaf1", "big-leaves", "ties", "approximate"])
 def test_emulated_capped_radius_search_and_its_cooperative_finish_equal_oracle(name):
     """The radius search with its long queries finished by a wavefront each (ptk_kernels_coopr.hpp): the list pass capped at a
     few far children per query, the cooperative count of what it handed over (any order; leaf entries keyed by their
@@ -377,6 +377,8 @@ def test_emulated_capped_radius_search_and_its_cooperative_finish_equal_oracle(n
             q, radius, caps, kw = q[:60], np.float32(4.0), (2,), {"pool_small": True, "entry_cap": 3000, "max_heavy": 50}
     elif name == "uniform-leaf1":  # more than 512 leaves with hits per query: recounted and refilled by one lane
         pts, q, leaf, radius, caps = ds.uniform_cloud(30_000, 3, 11), ds.uniform_cloud(40, 3, 12), 1, np.float32(0.05), (4,)
+    elif name == "big-leaves":  # leaves of up to 40 points are listed in pieces of 32 (the key's piece bits order them)
+        pts, q, leaf, radius, caps = ds.uniform_cloud(30_000, 3, 11), ds.uniform_cloud(200, 3, 12), 40, np.float32(0.01), (1, 4)
     elif name == "ties":
         pts = (np.round(ds.uniform_cloud(20_000, 3, 5) * 8) / 8).astype(np.float32)
         q = (np.round(ds.uniform_cloud(100, 3, 6) * 16) / 16).astype(np.float32)
