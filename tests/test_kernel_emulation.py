@@ -217,7 +217,7 @@ def test_emulated_k1_search_on_the_view_without_the_piles(dim, grid, shift):
     want = ref.search_knn(q, 1)
     full = EmulatedTree(pts, 10)
     depth_full = full.host.info()["max_depth"]
-    assert full.two_phase_knn1(q, variant=5)[0].tobytes() == want.tobytes()
+    assert full.two_phase_knn1(q[:300], variant=5)[0].tobytes() == want[:300].tobytes()  # (the long way: depth > 300)
     emu = EmulatedTree(pts, 10)
     n_piles = emu.use_pile_view()
     assert n_piles > 10 and depth_full > 300
@@ -258,7 +258,8 @@ def test_emulated_capped_phase2_and_cooperative_search_equal_oracle(case):
     want = ref.search_knn(q, 1)
     stats = {}
     for variant in (5, 6, 7, 8, 9):  # (9: the ranked classes straight from phase 1 to the cooperative search)
-        for p in (None, perm):
+        # (the lattice of `ties` redoes most of its hand-overs lane by lane: the generated order once is enough there)
+        for p in ((None, perm) if name != "ties" or variant == 5 else (perm,)):
             got, _ = emu.two_phase_knn1(q, perm=p, variant=variant)
             assert got.tobytes() == want.tobytes(), (name, variant)
         stats[variant] = emu.last_coop()
