@@ -472,6 +472,10 @@ int ptk_debug_knn_coop_counts(const ptk_tree* tree, uint32_t counts[7]);
  * not finish and one lane counted again from the root, sorted leaf entries the fill pass will read}.  Zeros when the
  * pass ran uncapped.  Synchronises the device. */
 int ptk_debug_radius_coop_counts(const ptk_tree* tree, uint32_t counts[3]);
+/* ptk_debug_knn_coop_counts for the double-precision tree: the counters of the last k-NN call that ran capped (exact,
+ * dim <= 3, metric_l2_squared / metric_l1, k <= 32, 256 queries or more: ptk_kernels_coop64.hpp); zeros if none has
+ * since the stack block was last re-allocated.  Synchronises the device. */
+int ptk_tree64_debug_knn_coop_counts(const ptk_tree64* tree, uint32_t counts[7]);
 /* The far children a query of such a search may enter before a wavefront takes it over, for a batch of nq queries
  * (it follows the batch: a capped launch ends with the lanes that ran to their cap; 0 = this search runs uncapped --
  * e != 1, fewer than 256 queries, k outside 2 .. 56), and the entries of the hand-over list of that batch (a query that

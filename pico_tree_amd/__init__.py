@@ -152,6 +152,7 @@ _SIGNATURES = {
     "ptk_debug_batch_order": (c_int, [c_void_p, POINTER(c_int)]),
     "ptk_debug_knn_coop_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ptk_debug_radius_coop_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
+    "ptk_tree64_debug_knn_coop_counts": (c_int, [c_void_p, POINTER(c_uint32)]),
     "ptk_debug_knn_cap": (c_int, [c_uint64, c_uint32, c_float, POINTER(c_uint32), POINTER(c_uint64)]),
     "ptk_multi_create_from_points": (c_int, [c_void_p, c_uint64, c_uint32, c_uint64, c_void_p, c_uint32,
                                              POINTER(c_void_p)]),
@@ -713,9 +714,11 @@ class KdTree:
     def knn_coop_counts(self) -> dict:
         """After a search with 1 < k <= 56: queries the general kernel handed to the cooperative search, queries that
         search sent to the redo list and why (``ptk_debug_knn_coop_counts``)."""
-        self._float32_only("knn_coop_counts()")
         c = (c_uint32 * 7)()
-        _check(_load().ptk_debug_knn_coop_counts(self._h, c))
+        if self._f64:
+            _check(_load().ptk_tree64_debug_knn_coop_counts(self._h, c))
+        else:
+            _check(_load().ptk_debug_knn_coop_counts(self._h, c))
         return {"cooperative": int(c[0]), "redone": int(c[1]), "pool": int(c[2]), "ties": int(c[3]), "box": int(c[4]),
                 "range": int(c[5]), "tie_sweeps": int(c[6])}
 

@@ -9,6 +9,7 @@
 #pragma once
 
 #include "ptk_kernels_f64.hpp"
+#include "ptk_kernels_coop64.hpp"
 
 static_assert(sizeof(ptk_neighbor64) == 16 && offsetof(ptk_neighbor64, distance) == 8, "neighbor<int, double> layout");
 
@@ -34,6 +35,9 @@ struct ptk_tree64 {
                            // their long searches first
   uint64_t device_bytes = 0;
   uint32_t slots = 0;      // stack records a lane may need: 2 * depth + 4
+  int cus = 256;           // compute units of the device
+  // counters of the last capped k-NN call (ptk_tree64_debug_knn_counts): they live in the stack block
+  mutable uint32_t* last_meta = nullptr;
   std::atomic<int> metric{PTK_METRIC_L2_SQUARED};
 
   // The record stacks of a launch live in one grow-only HBM block; calls on one handle enqueue under
@@ -140,6 +144,10 @@ int finish_create64(ptk_tree64* t, const double* points, int32_t device, ptk_tre
     }
   }
   t->device = dev;
+  if (dev != kDeviceNone) {
+    int n_cu = 0;
+    if (hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n_cu > 0) t->cus = n_cu;
+  }
   int rc;
   if (dev == kDeviceNone) {
     rc = encode64(*t, points);
@@ -173,6 +181,7 @@ struct Stack64Lease {
   char* aux = nullptr; // aux_bytes of scratch for the caller (the launch-order permutation)
   ptk::Rec64* stack = nullptr;
   int acquire(uint64_t n, size_t aux_bytes = 0) {
+    t->last_meta = nullptr;  // (the aux block is about to be written again: the last capped call's counters go with it)
     const size_t per_block = (size_t)t->slots * 64 * sizeof(ptk::Rec64);
     uint64_t blocks = (n + 63) / 64;
     const uint64_t max_blocks = std::max<uint64_t>(1, stack64_bytes() / per_block);
@@ -183,6 +192,7 @@ struct Stack64Lease {
       if (t->has_work) (void)hipEventSynchronize(t->done);
       if (t->stack) (void)hipFree(t->stack);
       t->stack = nullptr;
+      t->last_meta = nullptr;
       t->stack_capacity = 0;
       t->has_work = false;
       if (hipMalloc((void**)&t->stack, bytes) != hipSuccess) {
@@ -309,6 +319,108 @@ int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, u
     else PTK_LAUNCH64((ptk::knn64_kernel<M, false>));  // (64 slots: dim <= 3 only -- 252 VGPRs with q / off in registers)
   }
 #undef PTK_LAUNCH64
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+
+// ---- the capped k-NN launch + the cooperative search of what it hands over (ptk_kernels_coop64.hpp) ----
+// Far children a query may enter before a wavefront takes it over; 0 = every query runs to its end in its lane.  Exact
+// searches, dim <= 3, metric_l2_squared / metric_l1 (box distances that are lower bounds: knn_coop_kernel), k <= 32 (the
+// cooperative kernel's k-list is three registers per slot and double), trees of k points or more.  As knn_cap of the
+// float32 side the cap follows the batch -- a capped launch ends with the lanes that ran to their cap -- and k = 1 is
+// capped as well: there is no two-phase search in double.  Test hook knn64_cap: that cap for every batch (0: none).
+constexpr int kKnn64CoopPool = 128;
+constexpr uint32_t kKnn64CoopSpill = 1024;  // tasks a wavefront of the cooperative search can park in HBM (48 KB)
+inline uint32_t knn64_cap(const ptk_tree64* t, double e, uint64_t nq, uint32_t k, bool short_tree) {
+  const int m = t->metric.load();
+  if (t->dim > 3 || (m != PTK_METRIC_L2_SQUARED && m != PTK_METRIC_L1) || e != 1.0 || k > 32 || short_tree) return 0;
+  if (nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 256)) || nq >= (1ull << 32)) return 0;
+  const int forced = knob_int("knn64_cap", -1);
+  if (forced >= 0) return (uint32_t)forced;
+  // Fitted to tools/sweep_knn64_cap.py on BASELINE config 2's cloud L (profiles/r06_knn64_cap_sweep.jsonl; step ms, best
+  // cap against no cap):  k = 1   20 k 0.27 (4) / 1.74, 150 k 0.41 (4) / 2.91, 900 k 0.97 (16) / 3.41, 3.6 M 2.37 (64) / 3.99,
+  // 7.2 M 4.21 (128) / 5.03;  k = 4  0.37 (4) / 2.09, 0.59 (8) / 3.48, 1.32 (32) / 3.96, 3.32 (64) / 5.15, 5.99 (128) / 6.78;
+  // k = 16  0.69 (8) / 2.50, 1.10 (16) / 4.32, 2.75 (64) / 5.41, 7.14 (128) / 8.06, 11.9 (512) / 10.8;  k = 32  2.2 (8) / 3.8,
+  // 6.1 (32) / 6.4, 7.9 (512) / 6.8.  A cap too LOW is a cliff (k = 16, 150 k queries, cap 8: 69 k hand-overs, 3.2 ms), so
+  // the floors err upwards; the capped instantiation costs the bulk of a batch 5-10 % (more registers, a longer unwind
+  // loop), which the tail it removes no longer pays for at k > 8 on the largest batches and at k > 16 from 300 k on.
+  const double n = (double)nq;
+  double cap, lo, hi;
+  if (k == 1) {
+    cap = n / 56000.0, lo = 4.0, hi = 128.0;
+  } else if (k <= 4) {
+    cap = n / 56000.0, lo = 8.0, hi = 128.0;
+  } else if (k <= 8) {
+    cap = n / 28000.0, lo = 12.0, hi = 192.0;
+  } else if (k <= 16) {
+    if (nq >= 5000000) return 0;
+    cap = n / 14000.0, lo = 16.0, hi = 256.0;
+  } else {
+    if (nq >= 300000) return 0;
+    cap = n / 4700.0, lo = 8.0, hi = 32.0;
+  }
+  return (uint32_t)std::min(hi, std::max(lo, cap));
+}
+inline uint64_t knn64_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
+inline uint32_t knn64_coop_blocks(const ptk_tree64* t, uint64_t nq) {
+  return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 16u, std::max<uint64_t>(64, knn64_max_handover(nq)));
+}
+// Transient arrays of a capped call (behind the permutation in the lease's aux block): counters, the hand-over list
+// with its tasks, the redo list, the spill runs.
+inline size_t knn64_coop_scratch_bytes(const ptk_tree64* t, uint64_t nq) {
+  const uint64_t mh = knn64_max_handover(nq);
+  return ptk::kMetaWords * 4 + 3 * (mh * 4) + mh * ptk::kMaxTasks * sizeof(ptk::Task64) +
+         (size_t)knn64_coop_blocks(t, nq) * kKnn64CoopSpill * sizeof(ptk::Task64) + 2048;
+}
+
+template <class M>
+int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* perm, uint64_t nq, uint32_t k,
+                        uint32_t cap, ptk::Neighbor64* d_out, hipStream_t s, Stack64Lease& lease, char* scratch) {
+  auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const uint64_t mh = knn64_max_handover(nq);
+  const uint32_t coop_blocks = knn64_coop_blocks(t, nq);
+  char* p = scratch;
+  uint32_t* meta = reinterpret_cast<uint32_t*>(p);
+  p += align(ptk::kMetaWords * 4);
+  uint32_t* heavy_list = reinterpret_cast<uint32_t*>(p);
+  p += align(mh * 4);
+  uint32_t* ntasks = reinterpret_cast<uint32_t*>(p);
+  p += align(mh * 4);
+  uint32_t* redo_list = reinterpret_cast<uint32_t*>(p);
+  p += align(mh * 4);
+  ptk::Task64* tasks = reinterpret_cast<ptk::Task64*>(p);
+  p += align(mh * ptk::kMaxTasks * sizeof(ptk::Task64));
+  ptk::Task64* spill = reinterpret_cast<ptk::Task64*>(p);
+  PTK_HIP(hipMemsetAsync(meta, 0, ptk::kMetaWords * 4, s));
+  t->last_meta = meta;
+  ptk::Handover64 ho{};
+  ho.counter = ptk::kMetaHeavy;
+  ho.meta = meta;
+  ho.heavy_list = heavy_list;
+  ho.ntasks = ntasks;
+  ho.tasks = tasks;
+  ho.max_heavy = (uint32_t)mh;
+  const size_t smem = ptk::lds64_bytes(0, t->dim);
+  const size_t coop_smem = ptk::knn64_coop_lds_bytes(kKnn64CoopPool);
+  const uint32_t redo_blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->cus, std::max<uint64_t>(1, lease.piece / 64));
+#define PTK_LAUNCH64C(KK)                                                                                             \
+  do {                                                                                                                \
+    for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {                                                               \
+      const uint64_t n = std::min(lease.piece, nq - q0);                                                              \
+      hipLaunchKernelGGL((ptk::knn64_capped_kernel<M, KK>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, \
+                         d_q, perm, q0, n, k, d_out, lease.stack, t->slots, cap, ho);                                 \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((ptk::knn64_coop_kernel<KK, kKnn64CoopPool, M>), dim3(coop_blocks), dim3(64), coop_smem, s,     \
+                       t->dev, d_q, k, d_out, ho, redo_list, ptk::kMetaRedo, spill, kKnn64CoopSpill);                 \
+    hipLaunchKernelGGL((ptk::knn64_redo_kernel<M, KK>), dim3(redo_blocks), dim3(64), smem, s, t->dev, d_q, k, d_out,   \
+                       meta, ptk::kMetaRedo, redo_list, lease.stack, t->slots);                                       \
+  } while (0)
+  if (k == 1) PTK_LAUNCH64C(1);
+  else if (k <= 4) PTK_LAUNCH64C(4);
+  else if (k <= 8) PTK_LAUNCH64C(8);
+  else if (k <= 16) PTK_LAUNCH64C(16);
+  else PTK_LAUNCH64C(32);
+#undef PTK_LAUNCH64C
   PTK_HIP(hipGetLastError());
   return PTK_OK;
 }
@@ -574,14 +686,43 @@ int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq,
   const bool short_tree = k > t->n_points;
   if (short_tree) PTK_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(ptk_neighbor64), s));
   Stack64Lease lease(t, s);
-  rc = lease.acquire(nq, permutation64_bytes(nq));
+  const uint32_t cap = knn64_cap(t, e, nq, k, short_tree);
+  const size_t perm_bytes = (permutation64_bytes(nq) + 255) & ~size_t(255);
+  rc = lease.acquire(nq, perm_bytes + (cap != 0u ? knn64_coop_scratch_bytes(t, nq) : 0));
   if (rc != PTK_OK) return rc;
   const uint32_t* perm = nullptr;
   rc = make_permutation64(t, d_q, nq, s, lease, &perm, /*long_first=*/true);
   if (rc != PTK_OK) return rc;
+  if (cap != 0u) {
+    if (t->metric.load() == PTK_METRIC_L1)
+      return launch_knn64_capped<ptk::Metric64L1>(t, d_q, perm, nq, k, cap, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease,
+                                                 lease.aux + perm_bytes);
+    return launch_knn64_capped<ptk::Metric64L2>(t, d_q, perm, nq, k, cap, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease,
+                                               lease.aux + perm_bytes);
+  }
   PTK_WITH_METRIC64(rc = launch_knn64<M>(t, d_q, perm, nq, k, e, reinterpret_cast<ptk::Neighbor64*>(d_out), s, lease,
                                          short_tree));
   return rc;
+}
+
+int ptk_tree64_debug_knn_coop_counts(const ptk_tree64* t, uint32_t counts[7]) {
+  if (t == nullptr || counts == nullptr) return fail(PTK_ERR_INVALID, "null argument");
+  if (t->device == kDeviceNone) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
+  DeviceGuard guard(t->device);
+  std::lock_guard<std::mutex> lock(t->mutex);
+  for (int i = 0; i < 7; ++i) counts[i] = 0;
+  if (t->last_meta == nullptr) return PTK_OK;
+  uint32_t meta[ptk::kMetaWords];
+  PTK_HIP(hipDeviceSynchronize());
+  PTK_HIP(hipMemcpy(meta, t->last_meta, sizeof(meta), hipMemcpyDeviceToHost));
+  counts[0] = meta[ptk::kMetaHeavy];
+  counts[1] = meta[ptk::kMetaRedo];
+  counts[2] = meta[ptk::kKnnWhyPool];
+  counts[3] = meta[ptk::kKnnWhyTie];
+  counts[4] = meta[ptk::kKnnWhyBox];
+  counts[5] = meta[ptk::kKnnWhyRange];
+  counts[6] = meta[ptk::kKnnTieSweeps];
+  return PTK_OK;
 }
 
 int ptk_search64_knn(const ptk_tree64* t, const double* q, uint64_t nq, uint32_t k, double e, ptk_neighbor64* out) {

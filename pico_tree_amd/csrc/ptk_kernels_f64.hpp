@@ -442,14 +442,82 @@ __device__ __forceinline__ void stage_query64(
 __device__ __forceinline__ double sel3d(uint32_t axis, double a0, double a1, double a2) {
   return axis == 0 ? a0 : (axis == 1 ? a1 : a2);
 }
-template <class M, class Policy>
-__device__ __forceinline__ void traverse64_3(const DevTree64& t, double q0, double q1, double q2, Policy& pol, Stack64& st) {
+// A subtree still to be searched, as the cooperative search (ptk_kernels_coop64.hpp) keeps it: Task of ptk_kernels.hpp
+// in double.  `gmax` = the largest box distance of a far child on the path down to it; its sign bit marks a subtree
+// handed over by a capped traversal in the form of its pending record (`ref` = the record's {parent branch | side}, the
+// offset of the split axis still the parent's: entering it reads the parent branch).
+struct Task64 {
+  uint32_t ref, pad_;
+  double nbd, off0, off1, off2, gmax;
+};
+static_assert(sizeof(Task64) == 48, "Task64");
+// Where a capped traversal leaves its unfinished work (Handover of ptk_kernels.hpp; a query that finds the list full
+// goes on in its lane).
+struct Handover64 {
+  uint32_t counter;      // word of `meta` that counts this list
+  uint32_t* meta;        // [kMetaWords] counters
+  uint32_t* heavy_list;  // [max_heavy] rows of the queries handed over
+  uint32_t* ntasks;      // [max_heavy] tasks of list entry h (or kTasksFromRoot / kTasksRedo)
+  Task64* tasks;         // [max_heavy][kMaxTasks]
+  uint32_t max_heavy;
+};
+
+// The hand-over itself (once per long query; everything by value: the traversal ends here).
+__device__ __forceinline__ void hand_over64(
+    const Handover64* ho, uint32_t row, uint32_t h, uint32_t meta0, double val0, double nbd, double o0, double o1, double o2,
+    Stack64 st, double bound, bool monotone) {
+  ho->heavy_list[h] = row;
+  Task64* out = ho->tasks + (uint64_t)h * kMaxTasks;
+  uint32_t n = 0;
+  auto emit = [&](uint32_t meta, double val) {
+    if (n < kMaxTasks) {
+      Task64 k;
+      k.ref = meta;
+      k.pad_ = 0;
+      k.nbd = val;
+      k.off0 = o0;
+      k.off1 = o1;
+      k.off2 = o2;
+      // (while `monotone` holds the largest box distance on the path so far is the current one)
+      k.gmax = __longlong_as_double(__double_as_longlong(nbd < val ? val : nbd) | (long long)0x8000000000000000ull);  // (the sign: the pending-record form)
+      out[n] = k;
+    }
+    ++n;
+  };
+  emit(meta0, val0);
+  while (!st.empty()) {
+    const Rec64 u = st.pop();
+    if (u.x & kRecUndo) {
+      if (u.x & kRecSide) {
+        nbd = u.val;
+      } else {
+        const uint32_t axis = u.x & 0x3FFFFFFFu;
+        o0 = axis == 0 ? u.val : o0;
+        o1 = axis == 1 ? u.val : o1;
+        o2 = axis == 2 ? u.val : o2;
+      }
+    } else if (bound >= u.val) {
+      emit(u.x, u.val);
+    }
+  }
+  ho->ntasks[h] = !monotone ? kTasksRedo : (n > kMaxTasks ? kTasksFromRoot : n);
+}
+
+// CAPPED (k-NN, exact; r06): a query that has entered more than `cap` far children stops (returns false) -- what is
+// still on its stack goes to `ho` as traverse<.., CAPPED> of ptk_kernels.hpp hands it over: every pending far child
+// that can still matter with the state it would be entered with, next-to-visit first.
+template <class M, class Policy, bool CAPPED = false>
+__device__ __forceinline__ bool traverse64_3(const DevTree64& t, double q0, double q1, double q2, Policy& pol, Stack64& st,
+                                             uint32_t cap = 0, const Handover64* ho = nullptr, uint32_t row = 0) {
   const Node64* __restrict__ nodes = t.nodes;
   const double* __restrict__ pts = t.pts;
   const int32_t* __restrict__ index = t.index;
   const uint32_t last = t.n_points - 1;
   uint32_t ref = t.root_ref;
   double nbd = 0.0, o0 = 0.0, o1 = 0.0, o2 = 0.0;  // search.hpp:47
+  uint32_t entered = 0;
+  bool monotone = true;    // CAPPED: every far child entered so far had a box distance >= its parent's
+  bool on_its_own = false; // CAPPED: the hand-over list was full
 
   for (;;) {
     while (!(ref & kLeafBit)) {
@@ -488,7 +556,7 @@ __device__ __forceinline__ void traverse64_3(const DevTree64& t, double q0, doub
       }
     }
     for (;;) {
-      if (st.empty()) return;
+      if (st.empty()) return true;
       const Rec64 r = st.pop();
       if (r.x & kRecUndo) {
         if (r.x & kRecSide) {
@@ -502,6 +570,18 @@ __device__ __forceinline__ void traverse64_3(const DevTree64& t, double q0, doub
         continue;
       }
       if (pol.max() >= r.val) {  // the authoritative test of search.hpp:99
+        if constexpr (CAPPED) {
+          if (!on_its_own && ++entered > cap) {
+            const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
+            if (h >= ho->max_heavy) {
+              on_its_own = true;  // no room: this lane finishes its query itself
+            } else {
+              hand_over64(ho, row, h, r.x, r.val, nbd, o0, o1, o2, st, pol.max(), monotone);
+              return false;
+            }
+          }
+          if (r.val < nbd) monotone = false;
+        }
         const uint32_t idx = r.x & 0x3FFFFFFFu;
         const bool far_is_right = (r.x & kRecSide) != 0;
         const Node64 nd = nodes[idx];

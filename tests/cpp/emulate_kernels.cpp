@@ -34,6 +34,7 @@ thread_local dim3 blockDim;
 #include "ptk_kernels_nd.hpp"
 #include "ptk_kernels_topo.hpp"
 #include "ptk_kernels_f64.hpp"
+#include "ptk_kernels_coop64.hpp"
 #include "pico_tree/internal/flat_tree.hpp"
 #include "pico_tree/internal/stream.hpp"
 #include "pico_tree/map.hpp"
@@ -1383,6 +1384,67 @@ int emu64_knn(void* h, const double* q, uint64_t nq, uint32_t k, double e, int l
     }));
   }
   return 0;
+}
+
+}  // extern "C"
+
+// The double k-NN search with its long queries finished cooperatively (ptk_kernels_coop64.hpp): the capped launch
+// (lanes one after the other), knn64_coop_kernel (64 fibers per wavefront), the reference search of what could not be
+// certified.  counts = {queries handed over, queries redone, second sweeps}.  pool_small != 0: 40 spill slots per
+// wavefront (long searches overflow them: the redo path).
+namespace {
+template <int K, class M>
+int emu64_knn_capped_km(Emu64* t, const double* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap,
+                        int pool_small, uint32_t max_heavy, ptk::Neighbor64* out, uint32_t* counts) {
+  std::vector<uint32_t> meta(ptk::kMetaWords, 0), heavy(max_heavy + 1), ntasks(max_heavy + 1), redo(nq + 1);
+  std::vector<ptk::Task64> tasks((size_t)std::max<uint32_t>(max_heavy, 1) * ptk::kMaxTasks);
+  ptk::Handover64 ho{};
+  ho.counter = ptk::kMetaHeavy;
+  ho.meta = meta.data();
+  ho.heavy_list = heavy.data();
+  ho.ntasks = ntasks.data();
+  ho.tasks = tasks.data();
+  ho.max_heavy = max_heavy;
+  for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+    ptk::knn64_capped_kernel<M, K>(t->dev, q, perm, q0, m, k, out, t->stack.data(), t->slots, cap, ho);
+  });
+  const uint32_t spill_cap = pool_small ? 40u : 4096u;
+  std::vector<ptk::Task64> spill((size_t)3 * spill_cap);
+  for_each_wave(3, [&] {
+    ptk::knn64_coop_kernel<K, 64, M>(t->dev, q, k, out, ho, redo.data(), ptk::kMetaRedo, spill.data(), spill_cap);
+  });
+  gridDim.x = 1;
+  blockDim.x = 64;
+  blockIdx.x = 0;
+  for (uint32_t l = 0; l < 64; ++l) {
+    threadIdx.x = l;
+    ptk::knn64_redo_kernel<M, K>(t->dev, q, k, out, meta.data(), ptk::kMetaRedo, redo.data(), t->stack.data(), t->slots);
+  }
+  counts[0] = meta[ptk::kMetaHeavy];
+  counts[1] = meta[ptk::kMetaRedo];
+  counts[2] = meta[ptk::kKnnTieSweeps];
+  return 0;
+}
+template <int K>
+int emu64_knn_capped_k(Emu64* t, const double* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap, int pool_small,
+                       uint32_t max_heavy, ptk::Neighbor64* out, uint32_t* counts) {
+  if (t->metric == 1) return emu64_knn_capped_km<K, ptk::Metric64L1>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
+  return emu64_knn_capped_km<K, ptk::Metric64L2>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
+}
+}  // namespace
+
+extern "C" {
+
+// dim <= 3, metric_l2_squared / metric_l1, k <= 32 (what launch_knn64 caps).
+int emu64_knn_capped(void* h, const double* q, uint64_t nq, uint32_t k, const uint32_t* perm, uint32_t cap, int pool_small,
+                     uint32_t max_heavy, ptk::Neighbor64* out, uint32_t* counts) {
+  auto* t = static_cast<Emu64*>(h);
+  if (t->dev.dim > 3 || t->metric > 1 || k == 0 || k > 32) return -2;
+  if (k == 1) return emu64_knn_capped_k<1>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
+  if (k <= 4) return emu64_knn_capped_k<4>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
+  if (k <= 8) return emu64_knn_capped_k<8>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
+  if (k <= 16) return emu64_knn_capped_k<16>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
+  return emu64_knn_capped_k<32>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
 }
 
 // out == nullptr: count pass (offsets filled); otherwise the fill pass (+ optional row sort).

@@ -64,6 +64,16 @@ inline int __shfl_up(int v, int delta) { const int l = emu_lane(); return emu_sh
 inline float __shfl_up(float v, int delta) { const int l = emu_lane(); return __shfl(v, l >= delta ? l - delta : l); }
 inline int __shfl_xor(int v, int mask) { return emu_shfl(v, emu_lane() ^ mask); }
 inline float __shfl_xor(float v, int mask) { return __shfl(v, emu_lane() ^ mask); }
+inline double __shfl(double v, int src_lane) {  // (two rendezvous: every lane of the wavefront calls both)
+  int w[2];
+  std::memcpy(w, &v, 8);
+  w[0] = emu_shfl(w[0], src_lane);
+  w[1] = emu_shfl(w[1], src_lane);
+  std::memcpy(&v, w, 8);
+  return v;
+}
+inline double __shfl_xor(double v, int mask) { return __shfl(v, emu_lane() ^ mask); }
+inline long long __double_as_longlong(double f) { long long i; std::memcpy(&i, &f, 8); return i; }
 inline int __builtin_amdgcn_readlane(int v, int lane) { return emu_shfl(v, lane); }
 inline int __builtin_amdgcn_readfirstlane(int v) { return emu_shfl(v, 0); }  // all lanes alive where it is used
 void emu_barrier();

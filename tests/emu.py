@@ -329,6 +329,24 @@ class EmulatedTree64:
                                   out.ctypes.data) == 0
         return out
 
+    def search_knn_capped(self, q, k, cap, perm=None, pool_small=False, max_heavy=None):
+        """The capped double k-NN kernel, the cooperative search of what it handed over and the reference search of what
+        that could not certify (ptk_kernels_coop64.hpp).  Returns (rows, queries handed over, queries redone);
+        `last_tie_sweeps` = queries that took the second sweep."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        out = np.zeros((len(q), k), dtype=self.neighbor)
+        counts = np.zeros(3, dtype=np.uint32)
+        fn = self.lib.emu64_knn_capped
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_uint64, c_uint32, c_void_p, c_uint32, c_int, c_uint32, c_void_p, c_void_p]
+        if perm is not None:
+            perm = np.ascontiguousarray(perm, dtype=np.uint32)
+        rc = fn(self.h, q.ctypes.data, len(q), k, perm.ctypes.data if perm is not None else None, cap,
+                int(pool_small), len(q) if max_heavy is None else max_heavy, out.ctypes.data, counts.ctypes.data)
+        assert rc == 0
+        self.last_tie_sweeps = int(counts[2])
+        return out, int(counts[0]), int(counts[1])
+
     def search_radius(self, q, radius, e=None, sort=False):
         q = np.ascontiguousarray(q, dtype=np.float64)
         off = np.zeros(len(q) + 1, dtype=np.uint64)

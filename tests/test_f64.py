@@ -20,6 +20,7 @@ import pytest
 
 import oracle
 import pico_tree_amd as pt
+from pico_tree_amd import datasets as ds
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 SETS = ["g_f64_3d", "g_f64_6d"]
@@ -168,6 +169,51 @@ def test_emulated_double_topological_kernels_equal_the_compiled_reference(metric
     assert np.diff(o2)[wrap].sum() > 0  # the boxes through the seam do find points
     knn = ref.search_knn(q, 4)
     assert (np.abs(pts[knn["index"], -1] - q[:, -1:]) > 0.5).any()  # some neighbours are nearer through 0 ~ 1
+
+
+
+def _blind_disc_queries64(n):
+    """Queries inside the empty disc under the scanner of cloud L (the long searches of BASELINE config 2)."""
+    u = ds.raw_uniform24(11, 2 * n).reshape(n, 2)
+    r = 12.0 * np.sqrt(u[:, 0])
+    a = 2.0 * np.pi * u[:, 1]
+    return np.ascontiguousarray(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(n)], axis=1))
+
+
+def _capped_cases64():
+    yield "lidar", ds.lidar_cloud(20_000, 1).astype(np.float64), np.concatenate(
+        [ds.lidar_cloud(200, 2, pose=(3.0, 1.5)).astype(np.float64), _blind_disc_queries64(120)]), 10
+    yield "ties", (np.round(ds.uniform_cloud(3_000, 3, 6) * 16) / 16).astype(np.float64), \
+        (np.round(ds.uniform_cloud(150, 3, 7) * 16) / 16).astype(np.float64), 10
+    rng = np.random.default_rng(5)
+    line = ((rng.random((6_000, 1)) * rng.random((1, 2)) + 0.25) * 37.5).astype(np.float32).astype(np.float64)
+    yield "line", line, ((rng.random((80, 1)) * rng.random((1, 2)) + 0.25) * 37.5).astype(np.float32).astype(np.float64), 1
+    yield "dim1", ds.uniform_cloud(3_000, 1, 8).astype(np.float64), ds.uniform_cloud(150, 1, 9).astype(np.float64), 4
+
+
+@pytest.mark.parametrize("case", list(_capped_cases64()), ids=lambda c: c[0])
+def test_emulated_double_capped_knn_and_its_cooperative_search_equal_oracle(case):
+    """ptk_kernels_coop64.hpp in the emulator: the capped double kernel (lanes one after the other), the cooperative
+    search of what it handed over (64 fibers per wavefront), the reference search of what that could not certify --
+    k = 1 included (no two-phase search in double), both metrics it is shipped for, a cap of 0 / 2 far children and a
+    small spill (the redo path); equal distances (a lattice, points on a line) must come out in the reference's order."""
+    name, pts, q, leaf = case
+    for metric in ("L2Squared", "L1"):
+        from tests import emu
+
+        t = emu.EmulatedTree64(pts, leaf, metric)
+        ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
+        handed = sweeps = 0
+        for k in (1, 3, 16, 32):
+            want = ref.search_knn(q, k)
+            for cap, small in ((0, False), (2, True)):
+                got, nh, nr = t.search_knn_capped(q, k, cap, pool_small=small)
+                assert same(got, want["index"], want["distance"]), (name, metric, k, cap)
+                handed += nh
+                sweeps += t.last_tie_sweeps
+        assert handed > 0, (name, metric)
+        if name == "ties":  # (in double the distances along a line of float32 coordinates rarely coincide)
+            assert sweeps > 0, (name, metric)
 
 
 def test_host_only_double_handle_builds_the_reference_tree(tmp_path):
@@ -380,6 +426,40 @@ def test_gpu_double_device_tensors_and_python_api(gpu, tmp_path):
     rf = t.search_knn(qf, k)
     assert rf.shape == (k, len(g["queries"])) and np.array_equal(rf.reshape(-1)["index"], g["knn_index"].reshape(-1))
 
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(_capped_cases64()) + [("big", None, None, 10)], ids=lambda c: c[0])
+def test_gpu_double_capped_knn_and_its_cooperative_search(gpu, case):
+    """The capped double k-NN launch + knn64_coop_kernel + knn64_redo_kernel on the device (every exact k <= 32 search of
+    256 queries or more with dim <= 3 under metric_l2_squared / metric_l1 takes it): a low cap forced through the test
+    hooks so that nearly every query is handed over, the rule's own cap, and no cap -- all three the oracle's rows."""
+    name, pts, q, leaf = case
+    if name == "big":
+        pts = ds.lidar_cloud(300_000, 1).astype(np.float64)
+        q = np.concatenate([ds.lidar_cloud(40_000, 2, pose=(3.0, 1.5)).astype(np.float64), _blind_disc_queries64(4_000)])
+    else:
+        q = np.concatenate([q] * 4)  # (256 queries or more: below that the launch is not capped)
+    for metric in ("L2Squared", "L1"):
+        ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
+        ref.set_threads(os.cpu_count() or 1)
+        t = _GpuTree(pts, leaf, metric, device=gpu)
+        handed = 0
+        for k in (1, 4, 16, 32):
+            want = ref.search_knn(q, k)
+            for knobs in ({"knn64_cap": 1}, {}, {"knn64_cap": 0}):
+                pt.set_test_knobs(**knobs)
+                try:
+                    got = t.search_knn(q, k)
+                    c = t.t.knn_coop_counts()
+                finally:
+                    pt.set_test_knobs(**{n: None for n in knobs})
+                assert same(got, want["index"], want["distance"]), (name, metric, k, knobs)
+                if knobs.get("knn64_cap") == 1:
+                    handed += c.get("cooperative", 0)
+                if knobs.get("knn64_cap") == 0:
+                    assert c.get("cooperative", 0) == 0
+        assert handed > 0, (name, metric)
 
 @pytest.mark.gpu
 def test_gpu_double_k_larger_than_the_tree(gpu):
