@@ -369,7 +369,7 @@ inline uint32_t knn64_coop_blocks(const ptk_tree64* t, uint64_t nq) {
 // with its tasks, the redo list, the spill runs.
 inline size_t knn64_coop_scratch_bytes(const ptk_tree64* t, uint64_t nq) {
   const uint64_t mh = knn64_max_handover(nq);
-  return ptk::kMetaWords * 4 + 3 * (mh * 4) + mh * ptk::kMaxTasks * sizeof(ptk::Task64) +
+  return ptk::kMetaWords * 4 + 256 + 3 * (mh * 4) + mh * ptk::kMaxTasks * sizeof(ptk::Task64) +
          (size_t)knn64_coop_blocks(t, nq) * kKnn64CoopSpill * sizeof(ptk::Task64) + 2048;
 }
 
@@ -382,6 +382,8 @@ int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* 
   char* p = scratch;
   uint32_t* meta = reinterpret_cast<uint32_t*>(p);
   p += align(ptk::kMetaWords * 4);
+  ptk::Handover64* d_ho = reinterpret_cast<ptk::Handover64*>(p);
+  p += align(sizeof(ptk::Handover64));
   uint32_t* heavy_list = reinterpret_cast<uint32_t*>(p);
   p += align(mh * 4);
   uint32_t* ntasks = reinterpret_cast<uint32_t*>(p);
@@ -391,7 +393,6 @@ int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* 
   ptk::Task64* tasks = reinterpret_cast<ptk::Task64*>(p);
   p += align(mh * ptk::kMaxTasks * sizeof(ptk::Task64));
   ptk::Task64* spill = reinterpret_cast<ptk::Task64*>(p);
-  PTK_HIP(hipMemsetAsync(meta, 0, ptk::kMetaWords * 4, s));
   t->last_meta = meta;
   ptk::Handover64 ho{};
   ho.counter = ptk::kMetaHeavy;
@@ -400,6 +401,8 @@ int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* 
   ho.ntasks = ntasks;
   ho.tasks = tasks;
   ho.max_heavy = (uint32_t)mh;
+  static_assert(ptk::kMetaWords <= 64, "knn64_handover_init_kernel: one wavefront zeroes the counters");
+  hipLaunchKernelGGL(ptk::knn64_handover_init_kernel, dim3(1), dim3(64), 0, s, ho, d_ho);
   const size_t smem = ptk::lds64_bytes(0, t->dim);
   const size_t coop_smem = ptk::knn64_coop_lds_bytes(kKnn64CoopPool);
   const uint32_t redo_blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->cus, std::max<uint64_t>(1, lease.piece / 64));
@@ -408,7 +411,7 @@ int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* 
     for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {                                                               \
       const uint64_t n = std::min(lease.piece, nq - q0);                                                              \
       hipLaunchKernelGGL((ptk::knn64_capped_kernel<M, KK>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, \
-                         d_q, perm, q0, n, k, d_out, lease.stack, t->slots, cap, ho);                                 \
+                         d_q, perm, q0, n, k, d_out, lease.stack, t->slots, cap, d_ho);                               \
     }                                                                                                                 \
     hipLaunchKernelGGL((ptk::knn64_coop_kernel<KK, kKnn64CoopPool, M>), dim3(coop_blocks), dim3(64), coop_smem, s,     \
                        t->dev, d_q, k, d_out, ho, redo_list, ptk::kMetaRedo, spill, kKnn64CoopSpill);                 \

@@ -317,12 +317,19 @@ __device__ __forceinline__ bool knn64_coop_sweep(
   return ok;
 }
 
+// Before the capped launch: the counters zeroed, the description of the hand-over list where the kernels read it.
+PTK_GLOBAL __launch_bounds__(64) void knn64_handover_init_kernel(Handover64 ho, Handover64* __restrict__ at) {
+  if (threadIdx.x < kMetaWords) ho.meta[threadIdx.x] = 0u;
+  if (threadIdx.x == 0) *at = ho;
+}
+
 // The capped launch: one query per lane, the reference traversal with the k-list in registers (Knn64RegPolicy<K>) --
 // the row is stored either way; a query that stops leaves its list there for the cooperative search to start from.
 template <class M, int K>
 __global__ __launch_bounds__(64) void knn64_capped_kernel(
     DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
-    uint32_t k, Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots, uint32_t cap, Handover64 ho) {
+    uint32_t k, Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots, uint32_t cap,
+    const Handover64* __restrict__ ho) {
   const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
   if (i >= nq) return;
   const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
@@ -334,7 +341,21 @@ __global__ __launch_bounds__(64) void knn64_capped_kernel(
   const double x2 = t.dim > 2 ? row[2] : metric64_pad<M>();
   Stack64 st;
   st.init(0, 0, stack, slots);
-  traverse64_3<M, Knn64RegPolicy<K>, true>(t, x0, x1, x2, pol, st, cap, &ho, (uint32_t)qi);
+  Trav64State ts{};
+  bool resume = false;
+  for (;;) {
+    if (traverse64_3<M, Knn64RegPolicy<K>, true>(t, x0, x1, x2, pol, st, cap, &ts, resume)) break;
+    // (the list's description is read here, where a query stops, and not held in scalar registers through the
+    // traversal: as a kernel argument by value its ten words were -- knn64_capped_kernel<16> 103 scalar registers against
+    // the uncapped kernel's 74, the k-list's compare masks competing for them, and 6-9 % of its time)
+    const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
+    if (h < ho->max_heavy) {
+      hand_over64(ho, (uint32_t)qi, h, ts, st, pol.max());
+      break;
+    }
+    cap = 0xFFFFFFFFu;  // no room in the list: this lane finishes its query itself
+    resume = true;
+  }
   pol.store(out + qi * k);
 }
 

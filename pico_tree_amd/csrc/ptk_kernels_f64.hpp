@@ -462,53 +462,65 @@ struct Handover64 {
   uint32_t max_heavy;
 };
 
-// The hand-over itself (once per long query; everything by value: the traversal ends here).
-__device__ __forceinline__ void hand_over64(
-    const Handover64* ho, uint32_t row, uint32_t h, uint32_t meta0, double val0, double nbd, double o0, double o1, double o2,
-    Stack64 st, double bound, bool monotone) {
+// What a capped traversal that stopped was in the middle of (traverse64_3<.., CAPPED>): the box distance state it would
+// unwind with; the far child it was about to enter is back on the stack.
+struct Trav64State {
+  double nbd, o0, o1, o2;
+};
+// The hand-over itself (once per long query): every pending far child that can still matter with the state it would
+// be entered with, next-to-visit first -- as traverse<.., CAPPED> of ptk_kernels.hpp hands over.
+__device__ __forceinline__ void hand_over64(const Handover64* ho, uint32_t row, uint32_t h, Trav64State ts, Stack64 st,
+                                            double bound) {
   ho->heavy_list[h] = row;
   Task64* out = ho->tasks + (uint64_t)h * kMaxTasks;
   uint32_t n = 0;
-  auto emit = [&](uint32_t meta, double val) {
-    if (n < kMaxTasks) {
-      Task64 k;
-      k.ref = meta;
-      k.pad_ = 0;
-      k.nbd = val;
-      k.off0 = o0;
-      k.off1 = o1;
-      k.off2 = o2;
-      // (while `monotone` holds the largest box distance on the path so far is the current one)
-      k.gmax = __longlong_as_double(__double_as_longlong(nbd < val ? val : nbd) | (long long)0x8000000000000000ull);  // (the sign: the pending-record form)
-      out[n] = k;
-    }
-    ++n;
-  };
-  emit(meta0, val0);
+  // `gmax` of a task = the largest box distance of a far child on the path from the root to it.  The far children on
+  // the path are the ones the stack still holds an undo record of; while each of them had a box distance >= its
+  // parent's (`monotone`: the restored value never exceeds the one it replaces) the largest one is the current one.
+  // (Far children entered and left again are on nobody's path: the traversal itself keeps no such flag -- updating one
+  // per far child cost the k = 1 kernel 5 % of its time.)
+  bool monotone = true;
   while (!st.empty()) {
     const Rec64 u = st.pop();
     if (u.x & kRecUndo) {
       if (u.x & kRecSide) {
-        nbd = u.val;
+        if (u.val > ts.nbd) monotone = false;
+        ts.nbd = u.val;
       } else {
         const uint32_t axis = u.x & 0x3FFFFFFFu;
-        o0 = axis == 0 ? u.val : o0;
-        o1 = axis == 1 ? u.val : o1;
-        o2 = axis == 2 ? u.val : o2;
+        ts.o0 = axis == 0 ? u.val : ts.o0;
+        ts.o1 = axis == 1 ? u.val : ts.o1;
+        ts.o2 = axis == 2 ? u.val : ts.o2;
       }
     } else if (bound >= u.val) {
-      emit(u.x, u.val);
+      if (n < kMaxTasks) {
+        Task64 k;
+        k.ref = u.x;
+        k.pad_ = 0;
+        k.nbd = u.val;
+        k.off0 = ts.o0;
+        k.off1 = ts.o1;
+        k.off2 = ts.o2;
+        // (while `monotone` holds the largest box distance on the path so far is the current one; the sign: the
+        // pending-record form)
+        k.gmax = __longlong_as_double(__double_as_longlong(ts.nbd < u.val ? u.val : ts.nbd) | (long long)0x8000000000000000ull);
+        out[n] = k;
+      }
+      ++n;
     }
   }
   ho->ntasks[h] = !monotone ? kTasksRedo : (n > kMaxTasks ? kTasksFromRoot : n);
 }
 
-// CAPPED (k-NN, exact; r06): a query that has entered more than `cap` far children stops (returns false) -- what is
-// still on its stack goes to `ho` as traverse<.., CAPPED> of ptk_kernels.hpp hands it over: every pending far child
-// that can still matter with the state it would be entered with, next-to-visit first.
+// CAPPED (k-NN, exact; r06): a query that has entered more than `cap` far children stops (returns false): the far
+// child it was about to enter goes back on the stack, the state it would unwind with to *ts -- the caller hands the
+// stack over (hand_over64) or, when the list is full, calls again with `resume` and no cap.  The stop leaves through
+// the traversal's one exit (the test for an empty stack): an exit of its own inside the unwind loop -- hand-over and
+// return in place -- cost every capped kernel 7-8 % of its time on the bulk of a batch that never stops (knn = 16,
+// 7.2 M queries: 11.7 against 10.8 ms; profiles/r06_notes.txt item 12).
 template <class M, class Policy, bool CAPPED = false>
 __device__ __forceinline__ bool traverse64_3(const DevTree64& t, double q0, double q1, double q2, Policy& pol, Stack64& st,
-                                             uint32_t cap = 0, const Handover64* ho = nullptr, uint32_t row = 0) {
+                                             uint32_t cap = 0, Trav64State* ts = nullptr, bool resume = false) {
   const Node64* __restrict__ nodes = t.nodes;
   const double* __restrict__ pts = t.pts;
   const int32_t* __restrict__ index = t.index;
@@ -516,8 +528,16 @@ __device__ __forceinline__ bool traverse64_3(const DevTree64& t, double q0, doub
   uint32_t ref = t.root_ref;
   double nbd = 0.0, o0 = 0.0, o1 = 0.0, o2 = 0.0;  // search.hpp:47
   uint32_t entered = 0;
-  bool monotone = true;    // CAPPED: every far child entered so far had a box distance >= its parent's
-  bool on_its_own = false; // CAPPED: the hand-over list was full
+  bool stopped = false;
+  if constexpr (CAPPED) {
+    if (resume) {  // (an empty leaf: falls through to the unwind)
+      ref = kLeafBit;
+      nbd = ts->nbd;
+      o0 = ts->o0;
+      o1 = ts->o1;
+      o2 = ts->o2;
+    }
+  }
 
   for (;;) {
     while (!(ref & kLeafBit)) {
@@ -556,7 +576,15 @@ __device__ __forceinline__ bool traverse64_3(const DevTree64& t, double q0, doub
       }
     }
     for (;;) {
-      if (st.empty()) return true;
+      if (st.empty() || (CAPPED && stopped)) {
+        if constexpr (CAPPED) {
+          ts->nbd = nbd;
+          ts->o0 = o0;
+          ts->o1 = o1;
+          ts->o2 = o2;
+        }
+        return !stopped;
+      }
       const Rec64 r = st.pop();
       if (r.x & kRecUndo) {
         if (r.x & kRecSide) {
@@ -571,16 +599,11 @@ __device__ __forceinline__ bool traverse64_3(const DevTree64& t, double q0, doub
       }
       if (pol.max() >= r.val) {  // the authoritative test of search.hpp:99
         if constexpr (CAPPED) {
-          if (!on_its_own && ++entered > cap) {
-            const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
-            if (h >= ho->max_heavy) {
-              on_its_own = true;  // no room: this lane finishes its query itself
-            } else {
-              hand_over64(ho, row, h, r.x, r.val, nbd, o0, o1, o2, st, pol.max(), monotone);
-              return false;
-            }
+          if (++entered > cap) {
+            ++st.top;  // (the record goes back: pop() left it in its ring slot)
+            stopped = true;
+            continue;
           }
-          if (r.val < nbd) monotone = false;
         }
         const uint32_t idx = r.x & 0x3FFFFFFFu;
         const bool far_is_right = (r.x & kRecSide) != 0;

@@ -1406,7 +1406,7 @@ int emu64_knn_capped_km(Emu64* t, const double* q, uint64_t nq, uint32_t k, cons
   ho.tasks = tasks.data();
   ho.max_heavy = max_heavy;
   for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
-    ptk::knn64_capped_kernel<M, K>(t->dev, q, perm, q0, m, k, out, t->stack.data(), t->slots, cap, ho);
+    ptk::knn64_capped_kernel<M, K>(t->dev, q, perm, q0, m, k, out, t->stack.data(), t->slots, cap, &ho);
   });
   const uint32_t spill_cap = pool_small ? 40u : 4096u;
   std::vector<ptk::Task64> spill((size_t)3 * spill_cap);
