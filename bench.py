@@ -438,7 +438,7 @@ def metrics_and_f64_entries(pt, oracle, pts, q, leaf, device, steps, sample):
     res = {"metrics": {}, "f64": {}}
 
     def time_knn(tree, dq, k, rows):
-        out = torch.empty((nq, k, 2), dtype=rows, device=dq.device)
+        out = torch.empty((dq.shape[0], k, 2), dtype=rows, device=dq.device)
         for _ in range(2):
             tree.search_knn(dq, k, out)
         torch.cuda.synchronize()
@@ -476,9 +476,21 @@ def metrics_and_f64_entries(pt, oracle, pts, q, leaf, device, steps, sample):
         want = ref.search_knn(q64[cs], k)
         ok = np.array_equal(got["index"].reshape(want["index"].shape), want["index"]) and \
             np.ascontiguousarray(got["distance"]).tobytes() == np.ascontiguousarray(want["distance"]).tobytes()
+        coop = tree.knn_coop_counts()  # (the capped launch + cooperative finish of ptk_kernels_coop64.hpp: 0 = it ran uncapped)
         res["f64"][f"knn{k}"] = {"value": round(nq / ms / 1e3, 1), "unit": "Mqueries/s", "ms_per_step": round(ms, 4),
-                                 "parity_sample_ok": bool(ok)}
+                                 "parity_sample_ok": bool(ok), "handed_over": coop["cooperative"], "redone": coop["redone"]}
         del out
+        # every 48th query: a batch the size of a piece of a host-buffer call (before r06 any double batch took as long
+        # as the longest search of the cloud -- 2.9 / 4.3 ms here)
+        dqs = dq[::48].contiguous()
+        ms_s, out_s = time_knn(tree, dqs, k, torch.int64)
+        got_s = pt.DeviceNeighbors(out_s).numpy()
+        want_s = ref.search_knn(q64[::48], k)
+        ok_s = np.array_equal(got_s["index"].reshape(want_s["index"].shape), want_s["index"]) and \
+            np.ascontiguousarray(got_s["distance"]).tobytes() == np.ascontiguousarray(want_s["distance"]).tobytes()
+        res["f64"][f"knn{k}_150k"] = {"queries": int(dqs.shape[0]), "ms_per_step": round(ms_s, 4), "rows_equal": bool(ok_s),
+                                      "handed_over": tree.knn_coop_counts()["cooperative"]}
+        del out_s, dqs
     ref.close()
     tree.close()
     return res

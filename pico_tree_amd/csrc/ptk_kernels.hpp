@@ -797,7 +797,6 @@ __device__ __forceinline__ bool traverse(
   uint32_t ref = RESUME ? kLeafBit : t.root_ref;  // RESUME: an empty leaf, falls through to the unwind
   float nbd = 0.0f, off0 = 0.0f, off1 = 0.0f, off2 = 0.0f;
   uint32_t entered = 0;
-  bool monotone = true;  // CAPPED: every far child entered so far had a box distance >= its parent's
   bool on_its_own = false;  // KEEPS: the list was full when this query reached its cap
 
   for (;;) {
@@ -957,12 +956,19 @@ __device__ __forceinline__ bool traverse(
             }
             ++n;
           };
+          // `gmax` of a task = the largest box distance of a far child on the path from the root to it.  The far
+          // children on that path are the ones the stack still holds an undo record of; while each of them had a box
+          // distance >= its parent's (`monotone`: a restored value never exceeds the one it replaces) the largest is the
+          // current one.  Far children entered and left again are on nobody's path, so the traversal keeps no flag
+          // (r06: one updated per far child cost the double k = 1 kernel 5 % of its time, profiles/r06_notes.txt item 12).
+          bool monotone = true;
           emit(enter_meta, enter_val);
           while (!st.empty()) {
             const Record r = st.pop();
             const float val = __uint_as_float(r.y);
             if (r.x & kRecUndo) {
               if (r.x & kRecSide) {
+                if (val > nbd) monotone = false;
                 nbd = val;
               } else {
                 const uint32_t axis = (r.x >> 28) & 3u;
@@ -978,7 +984,6 @@ __device__ __forceinline__ bool traverse(
           return false;
         }
         const float val = enter_val;
-        if (CAPPED && val < nbd) monotone = false;
         const uint32_t idx = enter_meta & kRecIdxMask;
         const uint32_t axis = (enter_meta >> 28) & 3u;
         const bool far_is_right = (enter_meta & kRecSide) != 0;
