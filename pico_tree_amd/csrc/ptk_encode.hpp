@@ -400,11 +400,12 @@ struct EncNode64 {  // == ptk::Node64
 };
 static_assert(sizeof(EncNode64) == 32, "device record size");
 
+constexpr uint32_t kStride64D3 = 4;  // doubles per point record of a double tree with dim <= 3: {x, y, z, index}
 struct EncodedTree64 {
   std::vector<EncNode64> nodes;   // per branch
   std::vector<EncRange> ranges;   // per branch: position range [begin, end) of its whole subtree
   std::vector<double> points;     // leaf order, row-major (n_points x stride)
-  uint32_t stride = 0;            // doubles per point: 3 for dim <= 3 (unused axes zero), else dim
+  uint32_t stride = 0;            // doubles per point: 4 for dim <= 3 (unused axes zero, the index in the fourth), else dim
   uint32_t root_ref = 0;
   uint32_t cbits = 0;
 };
@@ -459,12 +460,19 @@ inline std::string encode_tree64(
       out.ranges[branch_id[i]] = of_node[i];
     }
   }
-  out.stride = dim <= 3 ? 3 : dim;
+  // dim <= 3: a point is one 32-byte record {x, y, z, original index} -- a lane fetches it with one aligned gather
+  // instead of 24 bytes that straddle sectors plus a word of the index array (r06).  The index sits in the low 32 bits
+  // of the fourth double; the kernels never read that double as a number.
+  out.stride = dim <= 3 ? kStride64D3 : dim;
   out.points.assign((size_t)n_points * out.stride, 0.0);
   for (uint64_t pos = 0; pos < n_points; ++pos) {
     const int32_t idx = indices[pos];
     if (idx < 0 || (uint64_t)idx >= n_points) return "index out of range in the permutation";
     std::memcpy(&out.points[pos * out.stride], points + (uint64_t)idx * dim, dim * sizeof(double));
+    if (dim <= 3) {
+      const int64_t tag = idx;
+      std::memcpy(&out.points[pos * out.stride + 3], &tag, sizeof(tag));
+    }
   }
   out.root_ref = ref_of(0);
   out.cbits = cbits;

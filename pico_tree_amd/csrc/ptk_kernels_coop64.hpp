@@ -138,7 +138,6 @@ __device__ __forceinline__ bool knn64_coop_sweep(
     double& drop_min, double& prune_min, double fixed, LdsF64* ent_d, LdsU32* ent_tag, LdsF64* ent_g, uint32_t& n_ent) {
   const Node64* __restrict__ nodes = t.nodes;
   const double* __restrict__ pts = t.pts;
-  const int32_t* __restrict__ index = t.index;
   const uint32_t last = t.n_points - 1;
   const uint32_t lane = threadIdx.x;
   const uint64_t below = (1ull << lane) - 1ull;
@@ -238,11 +237,11 @@ __device__ __forceinline__ bool knn64_coop_sweep(
 #pragma unroll
         for (int u = 0; u < U; ++u) {  // every load of the round before the first use
           const uint32_t pu = begin + u <= last ? begin + u : last;  // in range past the leaf's end too
-          const double* a = pts + (uint64_t)pu * 3;
-          px[u] = a[0];
-          py[u] = a[1];
-          pz[u] = a[2];
-          pi[u] = index[pu];
+          const double4 a = *reinterpret_cast<const double4*>(pts + (uint64_t)pu * kStride64D3);  // {x, y, z, index}
+          px[u] = a.x;
+          py[u] = a.y;
+          pz[u] = a.z;
+          pi[u] = (int32_t)__double_as_longlong(a.w);
         }
         hit_pos = begin;
 #pragma unroll

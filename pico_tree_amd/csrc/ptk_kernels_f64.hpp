@@ -20,8 +20,8 @@
 // Layouts (ptk_backend_f64.hpp, encode64):
 //   nodes : 32 B per branch {left_max, right_min, left_ref, right_ref, axis, 0}
 //   ref   : bit 31 = leaf; leaf = (begin << cbits) | count; branch = branch index
-//   pts   : leaf order, row-major, `stride` doubles per point (stride = 3 for dim <= 3, the unused
-//           axes zero: they add an exact +0 to every distance; else stride = dim); index[]:
+//   pts   : leaf order, row-major, `stride` doubles per point (dim <= 3: 4 = {x, y, z, original index in the
+//           low word of the fourth}, the unused axes zero: they add an exact +0 to every distance; else stride = dim); index[]:
 //           original index per position
 //   record: x = bit 31 undo | bit 30 (pending: far child is the right one; undo: nbd) |
 //               bits 29:0 (pending: branch index; undo_off: axis),  val = double
@@ -30,6 +30,7 @@
 
 #pragma once
 
+#include "ptk_encode.hpp"  // kStride64D3
 #include "ptk_kernels_nd.hpp"
 
 namespace ptk {
@@ -438,7 +439,7 @@ __device__ __forceinline__ void stage_query64(
   }
 }
 
-// dim <= 3 (stride 3): the same walk with q and off in registers.
+// dim <= 3 (32-byte point records): the same walk with q and off in registers.
 __device__ __forceinline__ double sel3d(uint32_t axis, double a0, double a1, double a2) {
   return axis == 0 ? a0 : (axis == 1 ? a1 : a2);
 }
@@ -523,7 +524,6 @@ __device__ __forceinline__ bool traverse64_3(const DevTree64& t, double q0, doub
                                              uint32_t cap = 0, Trav64State* ts = nullptr, bool resume = false) {
   const Node64* __restrict__ nodes = t.nodes;
   const double* __restrict__ pts = t.pts;
-  const int32_t* __restrict__ index = t.index;
   const uint32_t last = t.n_points - 1;
   uint32_t ref = t.root_ref;
   double nbd = 0.0, o0 = 0.0, o1 = 0.0, o2 = 0.0;  // search.hpp:47
@@ -560,11 +560,11 @@ __device__ __forceinline__ bool traverse64_3(const DevTree64& t, double q0, doub
 #pragma unroll
         for (int u = 0; u < kLeaf64; ++u) {  // every load of the round before the first use
           const uint32_t pu = begin + j + u <= last ? begin + j + u : last;  // in range past the leaf's end too
-          const double* a = pts + (uint64_t)pu * 3;
-          px[u] = a[0];
-          py[u] = a[1];
-          pz[u] = a[2];
-          pi[u] = index[pu];
+          const double4 a = *reinterpret_cast<const double4*>(pts + (uint64_t)pu * kStride64D3);  // {x, y, z, index}
+          px[u] = a.x;
+          py[u] = a.y;
+          pz[u] = a.z;
+          pi[u] = (int32_t)__double_as_longlong(a.w);
         }
 #pragma unroll
         for (int u = 0; u < kLeaf64; ++u) {
@@ -632,7 +632,6 @@ __device__ __forceinline__ void traverse64_topo(const DevTree64& t, double q0, d
   const Node64* __restrict__ nodes = t.nodes;
   const double2* __restrict__ outer = t.outer;
   const double* __restrict__ pts = t.pts;
-  const int32_t* __restrict__ index = t.index;
   const uint32_t last = t.n_points - 1;
   uint32_t ref = t.root_ref;
   double nbd = 0.0, o0 = 0.0, o1 = 0.0, o2 = 0.0;
@@ -660,11 +659,11 @@ __device__ __forceinline__ void traverse64_topo(const DevTree64& t, double q0, d
 #pragma unroll
         for (int u = 0; u < kLeaf64; ++u) {
           const uint32_t pu = begin + j + u <= last ? begin + j + u : last;
-          const double* a = pts + (uint64_t)pu * 3;
-          px[u] = a[0];
-          py[u] = a[1];
-          pz[u] = a[2];
-          pi[u] = index[pu];
+          const double4 a = *reinterpret_cast<const double4*>(pts + (uint64_t)pu * kStride64D3);  // {x, y, z, index}
+          px[u] = a.x;
+          py[u] = a.y;
+          pz[u] = a.z;
+          pi[u] = (int32_t)__double_as_longlong(a.w);
         }
 #pragma unroll
         for (int u = 0; u < kLeaf64; ++u) {

@@ -21,6 +21,7 @@ struct uint3 { uint32_t x, y, z; };
 struct uint4 { uint32_t x, y, z, w; };
 struct float2 { float x, y; };
 struct double2 { double x, y; };
+struct double4 { double x, y, z, w; };
 struct float3 { float x, y, z; };
 struct float4 { float x, y, z, w; };
 struct dim3 { uint32_t x = 1, y = 1, z = 1; };
