@@ -461,6 +461,64 @@ def test_gpu_double_capped_knn_and_its_cooperative_search(gpu, case):
                     assert c.get("cooperative", 0) == 0
         assert handed > 0, (name, metric)
 
+
+def _line_family_case64(rng, kind, jitter):
+    """_line_family_case of tests/test_gpu_parity.py in double: points on a line (or a coarse lattice) in 2-D / 3-D, tiny
+    leaves, queries off the line or next to tree points -- thousands of points nearly (or, from float32 coordinates and
+    on a lattice, exactly) equally far, box distances that drift by rounding."""
+    dim = int(rng.choice([2, 3]))
+    n = int(rng.choice([3000, 20000, 60000]))
+    nq = int(rng.choice([64, 300]))
+    leaf = int(rng.choice([1, 2, 5]))
+    scale = float(rng.choice([1.0, 37.5, 1e3]))
+    if kind == "line":
+        pts = (rng.random((n, 1)) * rng.random((1, dim)) + 0.25) * scale
+    else:  # lattice: equal distances by the hundred
+        pts = (np.round(rng.random((n, dim)) * 24) / 24 + 0.25) * scale
+    if rng.random() < 0.5:  # (coordinates that are float32 numbers: their differences and squares are exact in double)
+        pts = pts.astype(np.float32).astype(np.float64)
+    if jitter:
+        pts = pts + rng.normal(0, jitter, pts.shape) * scale
+    if rng.random() < 0.5:
+        q = (rng.random((nq, 1)) * rng.random((1, dim)) + 0.25) * scale
+    else:
+        q = pts[rng.integers(0, n, nq)] + rng.normal(0, 1e-3, (nq, dim)) * scale
+    ks = sorted({1, int(rng.choice([2, 5, 16])), int(rng.choice([24, 32]))})
+    return np.ascontiguousarray(pts), np.ascontiguousarray(q), leaf, ks
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,jitter", [("line", 0.0), ("line", 1e-9), ("lattice", 0.0), ("lattice", 1e-9)])
+def test_gpu_double_capped_knn_on_lines_and_lattices(gpu, kind, jitter):
+    """The adversarial family of the cooperative search (test_capped_k_nearest_on_lines_and_lattices_equals_the_compiled_
+    reference of tests/test_gpu_parity.py) for ptk_kernels_coop64.hpp: THE CAP ON FOR EVERY BATCH and low, so that nearly
+    every query is handed over, merged, second-swept or redone; k = 1 .. 32; equal to the compiled reference over double
+    (oracle/_ref; the restatement where that is absent)."""
+    how = "reference" if oracle.have_reference64() else "port"
+    handed = swept = 0
+    pt.set_test_knobs(knn_cap_min_nq=1)
+    try:
+        for case in range(8):
+            pts, q, leaf, ks = _line_family_case64(np.random.default_rng([707, case, int(jitter * 1e10), kind == "line"]), kind, jitter)
+            tree = pt.KdTree(pts, pt.Metric.L2Squared, leaf, device=gpu)
+            ref = oracle.Oracle(pts, leaf, how, dtype=np.float64)
+            for k in ks:
+                want = ref.search_knn(q, k)
+                for cap in (2, 24):
+                    pt.set_test_knobs(knn64_cap=cap)
+                    got = tree.search_knn(q, k).reshape(len(q), k)
+                    assert same(got, want["index"], want["distance"]), (kind, jitter, case, len(pts), leaf, k, cap)
+                    c = tree.knn_coop_counts()
+                    handed += c["cooperative"]
+                    swept += c["tie_sweeps"]
+            tree.close()
+            ref.close()
+    finally:
+        pt.set_test_knobs(knn_cap_min_nq=None, knn64_cap=None)
+    assert handed > 500, handed  # the cap did hand queries over
+    if jitter == 0.0 and kind == "lattice":
+        assert swept > 0         # equal distances: second sweeps ran
+
 @pytest.mark.gpu
 def test_gpu_double_k_larger_than_the_tree(gpu):
     """k > n_points on a float64 tree: as the float32 entry (tests/test_gpu_parity.py::test_k_larger_than_the_tree):
