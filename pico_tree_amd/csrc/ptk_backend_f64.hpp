@@ -689,9 +689,13 @@ int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq,
   const bool short_tree = k > t->n_points;
   if (short_tree) PTK_HIP(hipMemsetAsync(d_out, 0, (size_t)nq * k * sizeof(ptk_neighbor64), s));
   Stack64Lease lease(t, s);
-  const uint32_t cap = knn64_cap(t, e, nq, k, short_tree);
+  uint32_t cap = knn64_cap(t, e, nq, k, short_tree);
   const size_t perm_bytes = (permutation64_bytes(nq) + 255) & ~size_t(255);
   rc = lease.acquire(nq, perm_bytes + (cap != 0u ? knn64_coop_scratch_bytes(t, nq) : 0));
+  if (rc == PTK_ERR_NOMEM && cap != 0u) {  // (no room for the hand-over list: the uncapped search needs none)
+    cap = 0u;
+    rc = lease.acquire(nq, perm_bytes);
+  }
   if (rc != PTK_OK) return rc;
   const uint32_t* perm = nullptr;
   rc = make_permutation64(t, d_q, nq, s, lease, &perm, /*long_first=*/true);
