@@ -182,13 +182,13 @@ def _blind_disc_queries64(n):
 
 def _capped_cases64():
     yield "lidar", ds.lidar_cloud(20_000, 1).astype(np.float64), np.concatenate(
-        [ds.lidar_cloud(200, 2, pose=(3.0, 1.5)).astype(np.float64), _blind_disc_queries64(120)]), 10
+        [ds.lidar_cloud(100, 2, pose=(3.0, 1.5)).astype(np.float64), _blind_disc_queries64(60)]), 10
     yield "ties", (np.round(ds.uniform_cloud(3_000, 3, 6) * 16) / 16).astype(np.float64), \
-        (np.round(ds.uniform_cloud(150, 3, 7) * 16) / 16).astype(np.float64), 10
+        (np.round(ds.uniform_cloud(100, 3, 7) * 16) / 16).astype(np.float64), 10
     rng = np.random.default_rng(5)
     line = ((rng.random((6_000, 1)) * rng.random((1, 2)) + 0.25) * 37.5).astype(np.float32).astype(np.float64)
     yield "line", line, ((rng.random((80, 1)) * rng.random((1, 2)) + 0.25) * 37.5).astype(np.float32).astype(np.float64), 1
-    yield "dim1", ds.uniform_cloud(3_000, 1, 8).astype(np.float64), ds.uniform_cloud(150, 1, 9).astype(np.float64), 4
+    yield "dim1", ds.uniform_cloud(3_000, 1, 8).astype(np.float64), ds.uniform_cloud(100, 1, 9).astype(np.float64), 4
 
 
 @pytest.mark.parametrize("case", list(_capped_cases64()), ids=lambda c: c[0])
@@ -204,7 +204,7 @@ def test_emulated_double_capped_knn_and_its_cooperative_search_equal_oracle(case
         t = emu.EmulatedTree64(pts, leaf, metric)
         ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
         handed = sweeps = 0
-        for k in (1, 3, 16, 32):
+        for k in ((1, 3, 16, 32) if metric == "L2Squared" else (1, 16)):
             want = ref.search_knn(q, k)
             for cap, small in ((0, False), (2, True)):
                 got, nh, nr = t.search_knn_capped(q, k, cap, pool_small=small)
