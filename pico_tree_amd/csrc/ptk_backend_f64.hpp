@@ -330,7 +330,10 @@ int launch_knn64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, u
 // float32 side the cap follows the batch -- a capped launch ends with the lanes that ran to their cap -- and k = 1 is
 // capped as well: there is no two-phase search in double.  Test hook knn64_cap: that cap for every batch (0: none).
 constexpr int kKnn64CoopPool = 128;
-constexpr uint32_t kKnn64CoopSpill = 1024;  // tasks a wavefront of the cooperative search can park in HBM (48 KB)
+// Tasks a wavefront of the cooperative search can park in HBM (48 bytes each).  k > 16: four times the room and half the
+// wavefronts (the K = 32 kernel holds 232 VGPRs: two wavefronts per SIMD) -- with 1 024 a hundredth of the k = 32
+// hand-overs of config 2 lost a subtree and were searched again from the root by one lane (24 of 3 684 at 150 k queries).
+inline uint32_t knn64_coop_spill(uint32_t k) { return k > 16 ? 4096u : 1024u; }
 inline uint32_t knn64_cap(const ptk_tree64* t, double e, uint64_t nq, uint32_t k, bool short_tree) {
   const int m = t->metric.load();
   if (t->dim > 3 || (m != PTK_METRIC_L2_SQUARED && m != PTK_METRIC_L1) || e != 1.0 || k > 32 || short_tree) return 0;
@@ -340,10 +343,11 @@ inline uint32_t knn64_cap(const ptk_tree64* t, double e, uint64_t nq, uint32_t k
   // Fitted to tools/sweep_knn64_cap.py on BASELINE config 2's cloud L (profiles/r06_knn64_cap_sweep.jsonl; step ms, best
   // cap against no cap):  k = 1   20 k 0.27 (4) / 1.74, 150 k 0.41 (4) / 2.91, 900 k 0.97 (16) / 3.41, 3.6 M 2.37 (64) / 3.99,
   // 7.2 M 4.21 (128) / 5.03;  k = 4  0.37 (4) / 2.09, 0.59 (8) / 3.48, 1.32 (32) / 3.96, 3.32 (64) / 5.15, 5.99 (128) / 6.78;
-  // k = 16  0.69 (8) / 2.50, 1.10 (16) / 4.32, 2.75 (64) / 5.41, 7.14 (128) / 8.06, 11.9 (512) / 10.8;  k = 32  2.2 (8) / 3.8,
-  // 6.1 (32) / 6.4, 7.9 (512) / 6.8.  A cap too LOW is a cliff (k = 16, 150 k queries, cap 8: 69 k hand-overs, 3.2 ms), so
-  // the floors err upwards; the capped instantiation costs the bulk of a batch 5-10 % (more registers, a longer unwind
-  // loop), which the tail it removes no longer pays for at k > 8 on the largest batches and at k > 16 from 300 k on.
+  // k = 16  0.69 (8) / 2.50, 1.10 (16) / 4.32, 2.75 (64) / 5.41, 7.14 (128) / 8.06, 11.9 (512) / 10.8;  k = 32 (with the
+  // larger spill of knn64_coop_spill)  1.27 (16) / 3.21, 2.10 (32) / 5.28, 5.94 (128) / 6.53, 15.4 (256) / 13.6.  A cap too
+  // LOW is a cliff (k = 16, 150 k queries, cap 8: 69 k hand-overs, 3.2 ms), so the floors err upwards; the capped
+  // instantiation costs the bulk of a batch 2-7 % (more registers), which the tail it removes no longer pays for at
+  // k > 8 on the largest batches and at k > 16 from 1.5 M queries on.
   const double n = (double)nq;
   double cap, lo, hi;
   if (k == 1) {
@@ -356,21 +360,21 @@ inline uint32_t knn64_cap(const ptk_tree64* t, double e, uint64_t nq, uint32_t k
     if (nq >= 5000000) return 0;
     cap = n / 14000.0, lo = 16.0, hi = 256.0;
   } else {
-    if (nq >= 300000) return 0;
-    cap = n / 4700.0, lo = 8.0, hi = 32.0;
+    if (nq >= 1500000) return 0;
+    cap = n / 4700.0, lo = 16.0, hi = 128.0;
   }
   return (uint32_t)std::min(hi, std::max(lo, cap));
 }
 inline uint64_t knn64_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
-inline uint32_t knn64_coop_blocks(const ptk_tree64* t, uint64_t nq) {
-  return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 16u, std::max<uint64_t>(64, knn64_max_handover(nq)));
+inline uint32_t knn64_coop_blocks(const ptk_tree64* t, uint64_t nq, uint32_t k) {
+  return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * (k > 16 ? 8u : 16u), std::max<uint64_t>(64, knn64_max_handover(nq)));
 }
 // Transient arrays of a capped call (behind the permutation in the lease's aux block): counters, the hand-over list
 // with its tasks, the redo list, the spill runs.
-inline size_t knn64_coop_scratch_bytes(const ptk_tree64* t, uint64_t nq) {
+inline size_t knn64_coop_scratch_bytes(const ptk_tree64* t, uint64_t nq, uint32_t k) {
   const uint64_t mh = knn64_max_handover(nq);
   return ptk::kMetaWords * 4 + 256 + 3 * (mh * 4) + mh * ptk::kMaxTasks * sizeof(ptk::Task64) +
-         (size_t)knn64_coop_blocks(t, nq) * kKnn64CoopSpill * sizeof(ptk::Task64) + 2048;
+         (size_t)knn64_coop_blocks(t, nq, k) * knn64_coop_spill(k) * sizeof(ptk::Task64) + 2048;
 }
 
 template <class M>
@@ -378,7 +382,8 @@ int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* 
                         uint32_t cap, ptk::Neighbor64* d_out, hipStream_t s, Stack64Lease& lease, char* scratch) {
   auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
   const uint64_t mh = knn64_max_handover(nq);
-  const uint32_t coop_blocks = knn64_coop_blocks(t, nq);
+  const uint32_t coop_blocks = knn64_coop_blocks(t, nq, k);
+  const uint32_t spill_cap = knn64_coop_spill(k);
   char* p = scratch;
   uint32_t* meta = reinterpret_cast<uint32_t*>(p);
   p += align(ptk::kMetaWords * 4);
@@ -414,7 +419,7 @@ int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* 
                          d_q, perm, q0, n, k, d_out, lease.stack, t->slots, cap, d_ho);                               \
     }                                                                                                                 \
     hipLaunchKernelGGL((ptk::knn64_coop_kernel<KK, kKnn64CoopPool, M>), dim3(coop_blocks), dim3(64), coop_smem, s,     \
-                       t->dev, d_q, k, d_out, ho, redo_list, ptk::kMetaRedo, spill, kKnn64CoopSpill);                 \
+                       t->dev, d_q, k, d_out, ho, redo_list, ptk::kMetaRedo, spill, spill_cap);                       \
     hipLaunchKernelGGL((ptk::knn64_redo_kernel<M, KK>), dim3(redo_blocks), dim3(64), smem, s, t->dev, d_q, k, d_out,   \
                        meta, ptk::kMetaRedo, redo_list, lease.stack, t->slots);                                       \
   } while (0)
@@ -691,7 +696,7 @@ int ptk_search64_knn_device(const ptk_tree64* t, const double* d_q, uint64_t nq,
   Stack64Lease lease(t, s);
   uint32_t cap = knn64_cap(t, e, nq, k, short_tree);
   const size_t perm_bytes = (permutation64_bytes(nq) + 255) & ~size_t(255);
-  rc = lease.acquire(nq, perm_bytes + (cap != 0u ? knn64_coop_scratch_bytes(t, nq) : 0));
+  rc = lease.acquire(nq, perm_bytes + (cap != 0u ? knn64_coop_scratch_bytes(t, nq, k) : 0));
   if (rc == PTK_ERR_NOMEM && cap != 0u) {  // (no room for the hand-over list: the uncapped search needs none)
     cap = 0u;
     rc = lease.acquire(nq, perm_bytes);
