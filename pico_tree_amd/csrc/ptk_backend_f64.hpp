@@ -433,6 +433,129 @@ int launch_knn64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* 
   return PTK_OK;
 }
 
+// ---- the capped radius search (ptk_kernels_coop64.hpp) ----
+// Far children a query of the double radius search may enter before a wavefront takes it over; 0 = every query runs to
+// its end in its lane.  dim <= 3, the four non-topological metrics (no certificate is involved: the radius visitor's
+// bound never changes), trees no deeper than a key has bits for, leaves of at most 64 pieces of 32 points.  The rule is
+// radius_cap's of the float32 side (what the best caps have in common is 8-17 thousand hand-overs).  Test hook
+// radius64_cap: that cap for every batch (0: none).
+constexpr int kRadius64CoopPool = 64;
+constexpr uint32_t kRadius64CoopSpill = 1024;  // tasks a wavefront of the cooperative count can park in HBM (48 KB)
+inline uint32_t radius64_cap(const ptk_tree64* t, uint64_t nq) {
+  const int m = t->metric.load();
+  if (t->dim > 3 || m == PTK_METRIC_SO2 || m == PTK_METRIC_SE2_SQUARED) return 0;
+  if (t->max_depth > ptk::kRc64MaxDepth || t->max_leaf_count > 2048u) return 0;
+  if (nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 256)) || nq >= (1ull << 32)) return 0;
+  const int forced = knob_int("radius64_cap", -1);
+  if (forced >= 0) return (uint32_t)forced;
+  if (nq >= 1500000) return 0;
+  return (uint32_t)std::min(256.0, std::max(8.0, (double)nq / 2400.0));
+}
+inline uint64_t radius64_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
+inline uint64_t radius64_entry_cap(uint64_t nq) { return radius64_max_handover(nq) * 192; }  // entries of all hand-overs together
+inline uint32_t radius64_coop_blocks(const ptk_tree64* t, uint64_t nq) {
+  return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 12u, std::max<uint64_t>(64, radius64_max_handover(nq)));
+}
+// What a capped call carves out of the lease's aux block (behind the permutation).
+struct Radius64Scratch {
+  uint32_t* meta = nullptr;
+  ptk::Handover64* d_ho = nullptr;
+  ptk::Handover64 ho{};
+  ptk::RadiusHeavy64 hv{};
+  uint32_t* redo_list = nullptr;
+  uint32_t* over_list = nullptr;
+  ptk::Task64* spill = nullptr;
+  uint8_t* flag = nullptr;
+  uint32_t coop_blocks = 0;
+};
+inline size_t radius64_coop_scratch_bytes(const ptk_tree64* t, uint64_t nq) {
+  const uint64_t mh = radius64_max_handover(nq);
+  return ptk::kMetaWords * 4 + 256 + 8 * (mh * 4 + 256) + mh * ptk::kMaxTasks * sizeof(ptk::Task64) + radius64_entry_cap(nq) * 8 +
+         (size_t)radius64_coop_blocks(t, nq) * kRadius64CoopSpill * sizeof(ptk::Task64) + nq + 4096;
+}
+inline Radius64Scratch radius64_carve(const ptk_tree64* t, uint64_t nq, char* p) {
+  auto align = [](size_t v) { return (v + 255) & ~size_t(255); };
+  const uint64_t mh = radius64_max_handover(nq);
+  Radius64Scratch r;
+  auto take = [&](size_t bytes) {
+    char* at = p;
+    p += align(bytes);
+    return at;
+  };
+  r.meta = reinterpret_cast<uint32_t*>(take(ptk::kMetaWords * 4));
+  r.d_ho = reinterpret_cast<ptk::Handover64*>(take(sizeof(ptk::Handover64)));
+  r.ho.counter = ptk::kMetaHeavy;
+  r.ho.meta = r.meta;
+  r.ho.heavy_list = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.ho.ntasks = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.ho.tasks = reinterpret_cast<ptk::Task64*>(take(mh * ptk::kMaxTasks * sizeof(ptk::Task64)));
+  r.ho.max_heavy = (uint32_t)mh;
+  r.hv.meta = r.meta;
+  r.hv.rows = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.hv.own = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.hv.run_at = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.hv.run_n = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.hv.entries = reinterpret_cast<unsigned long long*>(take(radius64_entry_cap(nq) * 8));
+  r.hv.max_heavy = (uint32_t)mh;
+  r.hv.entry_cap = (uint32_t)std::min<uint64_t>(radius64_entry_cap(nq), 0xFFFFFFFFull);
+  r.redo_list = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.over_list = reinterpret_cast<uint32_t*>(take(mh * 4));
+  r.coop_blocks = radius64_coop_blocks(t, nq);
+  r.spill = reinterpret_cast<ptk::Task64*>(take((size_t)r.coop_blocks * kRadius64CoopSpill * sizeof(ptk::Task64)));
+  r.flag = reinterpret_cast<uint8_t*>(take(nq));
+  return r;
+}
+
+// One pass of a capped call: FILL = false the count pass (capped launch, cooperative count, recount of what that lost),
+// FILL = true the fill pass (capped launch, cooperative replay, refill of the lost rows).
+template <class M, bool FILL>
+int launch_radius64_capped(const ptk_tree64* t, const double* d_q, const uint32_t* perm, uint64_t nq, double radius, double e,
+                           uint32_t cap, uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor64* d_out, hipStream_t s,
+                           Stack64Lease& lease, const Radius64Scratch& r) {
+  const size_t smem = ptk::lds64_bytes(0, t->dim);
+  const size_t coop_smem = ptk::radius64_coop_lds_bytes(kRadius64CoopPool);
+  const uint32_t redo_blocks = (uint32_t)std::min<uint64_t>((uint64_t)t->cus, std::max<uint64_t>(1, lease.piece / 64));
+  if (!FILL) {
+    hipLaunchKernelGGL(ptk::knn64_handover_init_kernel, dim3(1), dim3(64), 0, s, r.ho, r.d_ho);
+    PTK_HIP(hipMemsetAsync(r.flag, 0, nq, s));
+  }
+  for (uint64_t q0 = 0; q0 < nq; q0 += lease.piece) {
+    const uint64_t n = std::min(lease.piece, nq - q0);
+    hipLaunchKernelGGL((ptk::radius64_capped_kernel<M, FILL>), dim3((uint32_t)((n + 63) / 64)), dim3(64), smem, s, t->dev, d_q,
+                       perm, q0, n, radius, 1.0 / e, d_counts, d_offsets, d_out, lease.stack, t->slots, cap, r.d_ho, r.flag);
+  }
+  if (!FILL) {
+    hipLaunchKernelGGL((ptk::radius64_coop_count_kernel<kRadius64CoopPool, M>), dim3(r.coop_blocks), dim3(64), coop_smem, s,
+                       t->dev, d_q, radius, 1.0 / e, d_counts, r.ho, r.hv, r.redo_list, r.spill, kRadius64CoopSpill);
+    hipLaunchKernelGGL((ptk::radius64_redo_kernel<M, false>), dim3(redo_blocks), dim3(64), smem, s, t->dev, d_q, radius, 1.0 / e,
+                       d_counts, d_offsets, d_out, r.meta, ptk::kMetaRedo, r.redo_list, lease.stack, t->slots);
+  } else {
+    hipLaunchKernelGGL((ptk::radius64_coop_replay_kernel<M>), dim3(r.coop_blocks), dim3(64), 0, s, t->dev, d_q, 1.0 / e, r.hv,
+                       d_offsets, d_out, r.over_list);
+    hipLaunchKernelGGL((ptk::radius64_redo_kernel<M, true>), dim3(redo_blocks), dim3(64), smem, s, t->dev, d_q, radius, 1.0 / e,
+                       d_counts, d_offsets, d_out, r.meta, ptk::kMetaRc64Over, r.over_list, lease.stack, t->slots);
+  }
+  PTK_HIP(hipGetLastError());
+  return PTK_OK;
+}
+#define PTK_WITH_EUCLID64(CALL)                      \
+  do {                                               \
+    const int metric_ = t->metric.load();            \
+    if (metric_ == PTK_METRIC_L1) {                  \
+      using M = ptk::Metric64L1;                     \
+      CALL;                                          \
+    } else if (metric_ == PTK_METRIC_LPINF) {        \
+      using M = ptk::Metric64LInf;                   \
+      CALL;                                          \
+    } else if (metric_ == PTK_METRIC_LNINF) {        \
+      using M = ptk::Metric64LNInf;                  \
+      CALL;                                          \
+    } else {                                         \
+      using M = ptk::Metric64L2;                     \
+      CALL;                                          \
+    }                                                \
+  } while (0)
+
 template <class M, bool FILL>
 int launch_radius64(const ptk_tree64* t, const double* d_q, const uint32_t* perm, uint64_t nq, double radius, double e,
                     uint64_t* d_counts, const uint64_t* d_offsets, ptk::Neighbor64* d_out, hipStream_t s,
@@ -784,20 +907,37 @@ int ptk_search64_radius(const ptk_tree64* t, const double* q, uint64_t nq, doubl
   uint64_t total = 0;
   if (he == hipSuccess) {
     Stack64Lease lease(t, nullptr);
-    rc = lease.acquire(nq, permutation64_bytes(nq));
+    uint32_t cap = radius64_cap(t, nq);
+    const size_t perm_bytes = (permutation64_bytes(nq) + 255) & ~size_t(255);
+    rc = lease.acquire(nq, perm_bytes + (cap != 0u ? radius64_coop_scratch_bytes(t, nq) : 0));
+    if (rc == PTK_ERR_NOMEM && cap != 0u) {  // (no room for the hand-over list: the uncapped search needs none)
+      cap = 0u;
+      rc = lease.acquire(nq, perm_bytes);
+    }
     const uint32_t* perm = nullptr;
     if (rc == PTK_OK) rc = make_permutation64(t, d_q, nq, nullptr, lease, &perm);
-    if (rc == PTK_OK)
+    Radius64Scratch rs;
+    if (rc == PTK_OK && cap != 0u) {
+      rs = radius64_carve(t, nq, lease.aux + perm_bytes);
+      t->last_meta = rs.meta;
+      PTK_WITH_EUCLID64(rc = (launch_radius64_capped<M, false>(t, d_q, perm, nq, radius, e, cap, d_c, nullptr, nullptr, nullptr,
+                                                              lease, rs)));
+    } else if (rc == PTK_OK) {
       PTK_WITH_METRIC64(rc = (launch_radius64<M, false>(t, d_q, perm, nq, radius, e, d_c, nullptr, nullptr, nullptr, lease)));
+    }
     if (rc == PTK_OK) rc = scan_counts64(d_c, d_o, nq, offsets);
     if (rc == PTK_OK) {
       total = offsets[nq];
       const size_t obytes = std::max<uint64_t>(total, 1) * sizeof(ptk_neighbor64);
       he = hipMalloc((void**)&d_out, obytes);
       if (he == hipSuccess) he = hipMemset(d_out, 0, obytes);
-      if (he == hipSuccess)
+      if (he == hipSuccess && cap != 0u) {
+        PTK_WITH_EUCLID64(rc = (launch_radius64_capped<M, true>(t, d_q, perm, nq, radius, e, cap, nullptr, d_o,
+                                                               reinterpret_cast<ptk::Neighbor64*>(d_out), nullptr, lease, rs)));
+      } else if (he == hipSuccess) {
         PTK_WITH_METRIC64(rc = (launch_radius64<M, true>(t, d_q, perm, nq, radius, e, nullptr, d_o,
                                                          reinterpret_cast<ptk::Neighbor64*>(d_out), nullptr, lease)));
+      }
       if (he == hipSuccess && rc == PTK_OK && sort) {
         hipLaunchKernelGGL(ptk::sort_rows64_kernel, dim3((uint32_t)((nq + ptk::kBlock - 1) / ptk::kBlock)), dim3(ptk::kBlock),
                            0, nullptr, d_o, nq, reinterpret_cast<ptk::Neighbor64*>(d_out));

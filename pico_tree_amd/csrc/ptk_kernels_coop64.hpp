@@ -569,4 +569,457 @@ __global__ __launch_bounds__(64) void knn64_redo_kernel(
   }
 }
 
+
+// ---- the radius search: the long queries of a double batch finished by a wavefront each ------------------------------
+// ptk_kernels_coopr.hpp in double.  The radius visitor never changes its bound (search_visitor.hpp:127-156), so the SET
+// of leaves the reference visits below a pending subtree is decided node by node whatever the order the nodes are looked
+// at in (a node's box distance is a function of its root path alone), and only the ORDER of the leaves in the row is the
+// traversal's: every subtree in the shared pool carries a KEY -- the handed-over task it belongs to, then one bit per
+// branch below it, 0 for the child the reference enters first -- the leaves with hits are listed as {key, leaf entry} in
+// whatever order the lanes meet them, and a bitonic sort of the wavefront's entries (at most 512, in LDS) restores the
+// reference's visit order.  No certificate is needed, so every metric of the double kernels takes this path.
+//
+//   count pass   radius64_capped_kernel<M, false>: a query that has entered more than `cap` far children stops, its count
+//                so far stays in counts[row], its stack goes to the hand-over list, flag[row] = 1;
+//                radius64_coop_count_kernel: a wavefront per such query, the sorted entries to `entries`, the total to
+//                counts[row]; what it cannot finish (more than 512 leaves with hits, pool and spill full, the entry block
+//                exhausted) is counted again from the root by one lane (radius64_redo_kernel<M, false>).
+//   fill pass    radius64_capped_kernel<M, true>: the same traversal stops at the same place (flag[row]) having written
+//                the row's first hits; radius64_coop_replay_kernel writes the rest from the sorted entries -- same
+//                arithmetic as the leaf scan (bit-identical distances); rows whose entries were lost are filled again
+//                from the root by one lane (radius64_redo_kernel<M, true>).
+constexpr uint32_t kRc64MaxEntries = 512;    // leaves with hits of one query the sort holds (LDS: 8 KB)
+constexpr uint32_t kRc64Lost = 0xFFFFFFFFu;  // RadiusHeavy64::run_n: this query's entries are not here (searched again)
+constexpr uint32_t kRc64KeyTop = 57;         // the first path bit of a key (bits 63:58 = the task)
+constexpr uint32_t kRc64KeyLow = 6;          // bits 5:0 = the piece of a large leaf
+constexpr uint32_t kRc64MaskBits = 32;       // points per entry (a larger leaf is listed in pieces)
+constexpr uint32_t kRc64MaxDepth = kRc64KeyTop - kRc64KeyLow;  // branches below a task a key has room for
+constexpr uint32_t kMetaRc64Entries = 28;    // word of the counters block: entries handed out of RadiusHeavy64::entries
+constexpr uint32_t kMetaRc64Over = 29;       // ... rows the fill pass must fill again from the root
+
+// What a call keeps of its handed-over queries from the count pass to the fill pass.
+struct RadiusHeavy64 {
+  uint32_t* meta;      // the counters block (kMetaHeavy, kMetaRedo, kMetaRc64Entries, kMetaRc64Over)
+  uint32_t* rows;      // [max_heavy] row of hand-over h
+  uint32_t* own;       // [max_heavy] hits its lane had found before it stopped
+  uint32_t* run_at;    // [max_heavy] where its sorted entries begin in `entries`
+  uint32_t* run_n;     // [max_heavy] how many (kRc64Lost: none)
+  unsigned long long* entries;  // [entry_cap] {(first point << cbits) | points, mask of the hits}
+  uint32_t max_heavy;
+  uint32_t entry_cap;
+};
+
+// LDS of a wavefront of radius64_coop_count_kernel: doubles {nbd, off0, off1, off2}[POOL], 64-bit words: pool keys
+// [POOL], entry keys and values [kRc64MaxEntries] each; 32-bit words: pool refs and key bits [POOL] each.
+constexpr uint32_t radius64_coop_lds_bytes(uint32_t pool) { return pool * (4u * 8u + 8u + 2u * 4u) + kRc64MaxEntries * 16u; }
+
+__device__ __forceinline__ uint32_t wave64_sum_u32(uint32_t v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += (uint32_t)__shfl_xor((int)v, d);
+  return v;
+}
+// Inclusive prefix sum over the lanes.
+__device__ __forceinline__ uint32_t wave64_scan_u32(uint32_t v, uint32_t lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = (uint32_t)__shfl_up((int)v, d);
+    if (lane >= (uint32_t)d) v += o;
+  }
+  return v;
+}
+
+// The count pass (FILL = false) and the fill pass (FILL = true) of a capped call: one query per lane.
+template <class M, bool FILL>
+__global__ __launch_bounds__(64) void radius64_capped_kernel(
+    DevTree64 t, const double* __restrict__ queries, const uint32_t* __restrict__ perm, uint64_t q0, uint64_t nq,
+    double radius, double e_inv, uint64_t* __restrict__ counts, const uint64_t* __restrict__ offsets,
+    Neighbor64* __restrict__ out, Rec64* __restrict__ stack, uint32_t slots, uint32_t cap,
+    const Handover64* __restrict__ ho, uint8_t* __restrict__ flag) {
+  const uint64_t i = (uint64_t)xcd_runs(blockIdx.x, gridDim.x) * 64 + threadIdx.x;
+  if (i >= nq) return;
+  const uint64_t qi = perm ? perm[q0 + i] : q0 + i;
+  Radius64Policy<FILL> pol;
+  pol.radius = d_mul(radius, e_inv);  // search_visitor.hpp:265
+  pol.e_inv = e_inv;
+  pol.count = 0;
+  pol.out = FILL ? out + offsets[qi] : nullptr;
+  const double* row = queries + qi * t.dim;
+  const double x0 = row[0];
+  const double x1 = t.dim > 1 ? row[1] : metric64_pad<M>();
+  const double x2 = t.dim > 2 ? row[2] : metric64_pad<M>();
+  Stack64 st;
+  st.init(0, 0, stack, slots);
+  Trav64State ts{};
+  bool resume = false;
+  for (;;) {
+    if (traverse64_3<M, Radius64Policy<FILL>, true>(t, x0, x1, x2, pol, st, cap, &ts, resume)) break;
+    if constexpr (FILL) {
+      if (flag[qi] != 0) return;  // handed over by the count pass: a wavefront writes the rest of the row
+    } else {
+      const uint32_t h = atomicAdd(&ho->meta[ho->counter], 1u);
+      if (h < ho->max_heavy) {
+        hand_over64(ho, (uint32_t)qi, h, ts, st, pol.max());
+        flag[qi] = 1;
+        break;
+      }
+    }
+    cap = 0xFFFFFFFFu;  // (no room in the list: this lane finishes its query itself, in both passes)
+    resume = true;
+  }
+  if constexpr (!FILL) counts[qi] = pol.count;
+}
+
+// grid: any number of one-wavefront blocks; block b takes entries b, b + grid, ... of the hand-over list.
+// counts[row] holds what the capped lane had counted; the total replaces it.  Rows that could not be finished go to
+// redo_list (counted at meta[kMetaRedo]).
+template <int POOL, class M>
+__global__ __launch_bounds__(64) void radius64_coop_count_kernel(
+    DevTree64 t, const double* __restrict__ queries, double radius, double e_inv, uint64_t* __restrict__ counts,
+    Handover64 ho, RadiusHeavy64 hv, uint32_t* __restrict__ redo_list, Task64* __restrict__ spill, uint32_t spill_cap) {
+  static_assert(POOL >= (int)kMaxTasks, "the pool must hold what a query starts with");
+  constexpr int U = 4;
+  const Node64* __restrict__ nodes = t.nodes;
+  const double* __restrict__ pts = t.pts;
+  const uint32_t last = t.n_points - 1;
+  Task64* const spill_w = spill + (uint64_t)blockIdx.x * spill_cap;
+  const uint32_t lane = threadIdx.x;
+  const uint64_t below = (1ull << lane) - 1ull;
+  LdsF64* pf = (LdsF64*)ptk_smem;                        // [4][POOL]: nbd, off0, off1, off2
+  LdsU64* pkey = (LdsU64*)(pf + 4 * POOL);               // [POOL]
+  LdsU64* ekey = pkey + POOL;                            // [kRc64MaxEntries]
+  LdsU64* eval = ekey + kRc64MaxEntries;                 // [kRc64MaxEntries]
+  LdsU32* pref = (LdsU32*)(eval + kRc64MaxEntries);      // [POOL]
+  LdsU32* pkbit = pref + POOL;                           // [POOL]: next key bit | sign: the handed-over form
+  const uint32_t listed = ho.meta[ho.counter];
+  const uint32_t n_heavy = listed > ho.max_heavy ? ho.max_heavy : listed;
+  const double bound = d_mul(radius, e_inv);  // (already scaled by 1 / e for the approximate search, :265)
+
+  for (uint32_t entry = blockIdx.x; entry < n_heavy; entry += gridDim.x) {  // (uniform)
+    const uint32_t qi = ho.heavy_list[entry];
+    const uint32_t nt = ho.ntasks[entry];
+    const Task64* src = ho.tasks + (uint64_t)entry * kMaxTasks;
+    const double* qrow = queries + (uint64_t)qi * t.dim;
+    const double q0 = qrow[0];
+    const double q1 = t.dim > 1 ? qrow[1] : metric64_pad<M>();
+    const double q2 = t.dim > 2 ? qrow[2] : metric64_pad<M>();
+    const uint32_t own = (uint32_t)counts[qi];
+    // (non-monotone box distances do not matter here; kTasksRedo only says so)
+    bool lost = nt == kTasksFromRoot || (nt > kMaxTasks && nt != kTasksRedo);
+    uint32_t ntasks = lost ? 0u : nt;
+    if (nt == kTasksRedo) {  // (hand_over64 wrote the tasks all the same -- how many, it did not say: count again)
+      lost = true;
+      ntasks = 0u;
+    }
+
+    // The handed-over stack, next-to-visit on top; task i gets the key prefix i.
+    uint32_t count = ntasks;  // subtrees in the pool (uniform)
+    for (uint32_t i = lane; i < ntasks; i += 64u) {
+      const Task64 tk = src[i];
+      const uint32_t sl = ntasks - 1u - i;
+      pref[sl] = tk.ref;
+      pf[0 * POOL + sl] = tk.nbd;
+      pf[1 * POOL + sl] = tk.off0;
+      pf[2 * POOL + sl] = tk.off1;
+      pf[3 * POOL + sl] = tk.off2;
+      pkey[sl] = (unsigned long long)i << (kRc64KeyTop + 1u);
+      pkbit[sl] = kRc64KeyTop | 0x80000000u;  // sign bit: the handed-over form (the parent branch is read first)
+    }
+    bool busy = false, fresh = false;
+    uint32_t ref = 0, spill_n = 0, kbit = 0, n_ent = 0, hits = 0;
+    unsigned long long key = 0ull;
+    double nbd = 0.0, off0 = 0.0, off1 = 0.0, off2 = 0.0;
+    // The piece of a leaf this lane is measuring: first point, points seen, hits among them, its number in the leaf.
+    uint32_t l_first = 0, l_pos = 0, l_mask = 0, l_piece = 0;
+
+    for (;;) {
+      if (count == 0u && spill_n != 0u) {  // (uniform) a drained pool takes back what was parked in HBM
+        const uint32_t m = spill_n < (uint32_t)(POOL / 2) ? spill_n : (uint32_t)(POOL / 2);
+        for (uint32_t i = lane; i < m; i += 64u) {
+          const Task64 tk = spill_w[spill_n - m + i];
+          pref[i] = tk.ref;
+          pf[0 * POOL + i] = tk.nbd;
+          pf[1 * POOL + i] = tk.off0;
+          pf[2 * POOL + i] = tk.off1;
+          pf[3 * POOL + i] = tk.off2;
+          pkey[i] = (unsigned long long)__double_as_longlong(tk.gmax);  // (the key travels in the word a hand-over uses for gmax)
+          pkbit[i] = tk.pad_;
+        }
+        count = m;
+        spill_n -= m;
+      }
+      // (the ballot is also where the lanes meet after the pool was written)
+      const bool want = !busy;
+      const uint64_t wmask = __ballot(want);
+      if (want) {
+        const uint32_t rank = (uint32_t)__popcll(wmask & below);
+        if (rank < count) {
+          const uint32_t sl = count - 1u - rank;
+          ref = pref[sl];
+          nbd = pf[0 * POOL + sl];
+          off0 = pf[1 * POOL + sl];
+          off1 = pf[2 * POOL + sl];
+          off2 = pf[3 * POOL + sl];
+          key = pkey[sl];
+          const uint32_t kb = pkbit[sl];
+          kbit = kb & 0x7FFFFFFFu;
+          fresh = (kb >> 31) != 0u;
+          busy = true;
+          if (!fresh && (ref & kLeafBit) != 0u) {  // a leaf begins
+            l_first = (ref & 0x7FFFFFFFu) >> t.cbits;
+            l_pos = l_mask = l_piece = 0u;
+          }
+        }
+      }
+      {
+        const uint32_t nw = (uint32_t)__popcll(wmask);
+        count -= nw < count ? nw : count;
+      }
+
+      // One node per lane.
+      bool push = false, emit = false;
+      Task64 pt{};
+      unsigned long long e_key = 0ull, e_val = 0ull;
+      if (busy) {
+        const bool is_leaf = !fresh && (ref & kLeafBit) != 0u;
+        if (!is_leaf) {
+          // A branch, or (fresh) the parent branch of a pending record whose far child is entered as traverse64_3
+          // enters it: the same arithmetic with the side given instead of chosen.
+          const Node64 nd = nodes[fresh ? (ref & 0x3FFFFFFFu) : ref];
+          const double v = sel3d(nd.axis, q0, q1, q2);
+          const bool near_left = d_sub(d_sub(d_add(nd.left_max, nd.right_min), v), v) > 0.0;
+          const bool go_left = fresh ? (ref & kRecSide) != 0u : near_left;
+          const double dv = d_sub(go_left ? nd.right_min : nd.left_max, v);
+          const double new_off = M::one(dv);
+          const uint32_t far_ref = go_left ? nd.right_ref : nd.left_ref;
+          if (fresh) {
+            off0 = nd.axis == 0 ? new_off : off0;
+            off1 = nd.axis == 1 ? new_off : off1;
+            off2 = nd.axis == 2 ? new_off : off2;
+            ref = far_ref;
+            fresh = false;
+          } else {
+            const double far_nbd = d_add(d_sub(nbd, sel3d(nd.axis, off0, off1, off2)), new_off);
+            if (bound >= far_nbd) {  // the test of kd_tree_search.hpp:99 with the radius visitor's constant max()
+              push = true;
+              pt.ref = far_ref;
+              pt.nbd = far_nbd;
+              pt.off0 = nd.axis == 0 ? new_off : off0;
+              pt.off1 = nd.axis == 1 ? new_off : off1;
+              pt.off2 = nd.axis == 2 ? new_off : off2;
+              pt.gmax = __longlong_as_double((long long)(key | (1ull << kbit)));  // visited second
+              pt.pad_ = kbit - 1u;
+            }
+            ref = go_left ? nd.left_ref : nd.right_ref;  // visited first: its bit stays 0
+            kbit -= 1u;
+          }
+          if ((ref & kLeafBit) != 0u) {  // the lane's next node is a leaf
+            l_first = (ref & 0x7FFFFFFFu) >> t.cbits;
+            l_pos = l_mask = l_piece = 0u;
+          }
+        } else {
+          const uint32_t lv = ref & 0x7FFFFFFFu;
+          const uint32_t begin = lv >> t.cbits;
+          const uint32_t cnt = lv & t.cmask;
+          double px[U], py[U], pz[U];
+#pragma unroll
+          for (int u = 0; u < U; ++u) {  // every load of the round before the first use
+            const uint32_t pu = begin + u <= last ? begin + u : last;  // in range past the leaf's end too
+            const double4 a = *reinterpret_cast<const double4*>(pts + (uint64_t)pu * kStride64D3);
+            px[u] = a.x;
+            py[u] = a.y;
+            pz[u] = a.z;
+          }
+#pragma unroll
+          for (int u = 0; u < U; ++u) {
+            if ((uint32_t)u < cnt) {
+              const double d = d_mul(M::acc(M::acc(M::one(d_sub(q0, px[u])), d_sub(q1, py[u])), d_sub(q2, pz[u])), e_inv);
+              l_mask |= (bound > d ? 1u : 0u) << l_pos;  // strict (:141)
+              ++l_pos;
+            }
+          }
+          // (a piece closes after kRc64MaskBits = 32 points -- eight steps of four -- or at the leaf's end)
+          const bool leaf_done = cnt <= (uint32_t)U;
+          if (l_pos == kRc64MaskBits || leaf_done) {
+            if (l_mask != 0u) {
+              emit = true;
+              e_key = key | (unsigned long long)l_piece;
+              e_val = (unsigned long long)((l_first << t.cbits) | l_pos) | ((unsigned long long)l_mask << 32);
+              hits += (uint32_t)__popcll((unsigned long long)l_mask);
+            }
+            l_first += l_pos;
+            l_pos = l_mask = 0u;
+            ++l_piece;
+          }
+          if (!leaf_done) {
+            ref = kLeafBit | ((begin + (uint32_t)U) << t.cbits) | (cnt - (uint32_t)U);
+          } else {
+            busy = false;
+          }
+        }
+      }
+
+      // The leaves with hits of this step go behind the entries (all lanes take part in the ballot).
+      {
+        const uint64_t em = __ballot(emit);
+        if (emit) {
+          const uint32_t at = n_ent + (uint32_t)__popcll(em & below);
+          if (at < kRc64MaxEntries) {
+            ekey[at] = e_key;
+            eval[at] = e_val;
+          }
+        }
+        n_ent += (uint32_t)__popcll(em);
+      }
+
+      // Far children kept in this step go onto the pool.
+      const uint64_t pmask = __ballot(push);
+      if (push) {
+        const uint32_t sl = count + (uint32_t)__popcll(pmask & below);
+        if (sl < (uint32_t)POOL) {
+          pref[sl] = pt.ref;
+          pf[0 * POOL + sl] = pt.nbd;
+          pf[1 * POOL + sl] = pt.off0;
+          pf[2 * POOL + sl] = pt.off1;
+          pf[3 * POOL + sl] = pt.off2;
+          pkey[sl] = (unsigned long long)__double_as_longlong(pt.gmax);
+          pkbit[sl] = pt.pad_;
+        } else if (spill_n + (sl - (uint32_t)POOL) < spill_cap) {  // no room in LDS: parked in HBM
+          spill_w[spill_n + (sl - (uint32_t)POOL)] = pt;
+        }
+      }
+      count += (uint32_t)__popcll(pmask);
+      if (count > (uint32_t)POOL) {
+        spill_n += count - (uint32_t)POOL;
+        count = (uint32_t)POOL;
+        if (spill_n > spill_cap) {  // a subtree was lost: this row is counted again from the root
+          lost = true;
+          count = 0;
+          spill_n = 0;
+          busy = false;
+        }
+      }
+      if (__ballot(busy) == 0ull && count == 0u && spill_n == 0u) break;
+    }
+    if (n_ent > kRc64MaxEntries) lost = true;
+
+    // The entries in the reference's visit order: a bitonic sort by key (n_ent padded to a power of two with keys above
+    // every real one).
+    uint32_t run = 0;
+    if (!lost && n_ent != 0u) {
+      uint32_t np = 64u;
+      while (np < n_ent) np <<= 1;
+      for (uint32_t i = n_ent + lane; i < np; i += 64u) ekey[i] = ~0ull;
+      __syncthreads();
+      for (uint32_t k = 2u; k <= np; k <<= 1) {        // (uniform)
+        for (uint32_t j = k >> 1; j != 0u; j >>= 1) {  // (uniform)
+          for (uint32_t i = lane; i < np; i += 64u) {
+            const uint32_t o = i ^ j;
+            if (o > i) {
+              const unsigned long long a = ekey[i], b = ekey[o];
+              const bool up = (i & k) == 0u;
+              if (up ? a > b : a < b) {
+                ekey[i] = b;
+                ekey[o] = a;
+                const unsigned long long v = eval[i];
+                eval[i] = eval[o];
+                eval[o] = v;
+              }
+            }
+          }
+          __syncthreads();
+        }
+      }
+      // A run of the entry block for them.
+      if (lane == 0) run = atomicAdd(&hv.meta[kMetaRc64Entries], n_ent);
+      run = (uint32_t)__shfl((int)run, 0);
+      if ((uint64_t)run + n_ent > (uint64_t)hv.entry_cap) {
+        lost = true;
+      } else {
+        for (uint32_t i = lane; i < n_ent; i += 64u) hv.entries[run + i] = eval[i];
+      }
+      __syncthreads();  // (the entries have been read before the next query writes its own)
+    }
+    const uint32_t found = wave64_sum_u32(hits);
+    if (lane == 0) {
+      hv.rows[entry] = qi;
+      hv.own[entry] = own;
+      hv.run_at[entry] = run;
+      hv.run_n[entry] = lost ? kRc64Lost : n_ent;
+      if (lost) {
+        redo_list[atomicAdd(&hv.meta[kMetaRedo], 1u)] = qi;
+      } else {
+        counts[qi] = (uint64_t)own + found;
+      }
+    }
+  }
+}
+
+// The fill pass of the handed-over queries: block b takes hand-overs b, b + grid, ...; the row's first `own` hits are the
+// capped lane's, the rest is written here from the sorted entries.  Rows whose entries were lost are listed (over_list,
+// counted at meta[kMetaRc64Over]) for radius64_redo_kernel<M, true>.
+template <class M>
+__global__ __launch_bounds__(64) void radius64_coop_replay_kernel(
+    DevTree64 t, const double* __restrict__ queries, double e_inv, RadiusHeavy64 hv, const uint64_t* __restrict__ offsets,
+    Neighbor64* __restrict__ out, uint32_t* __restrict__ over_list) {
+  const uint32_t lane = threadIdx.x;
+  const double* __restrict__ pts = t.pts;
+  const uint32_t listed = hv.meta[kMetaHeavy];
+  const uint32_t n_heavy = listed > hv.max_heavy ? hv.max_heavy : listed;
+  for (uint32_t h = blockIdx.x; h < n_heavy; h += gridDim.x) {  // (uniform)
+    const uint32_t qi = hv.rows[h];
+    const uint32_t n = hv.run_n[h];
+    if (n == kRc64Lost) {
+      if (lane == 0) over_list[atomicAdd(&hv.meta[kMetaRc64Over], 1u)] = qi;
+      continue;
+    }
+    const double* qrow = queries + (uint64_t)qi * t.dim;
+    const double q0 = qrow[0];
+    const double q1 = t.dim > 1 ? qrow[1] : metric64_pad<M>();
+    const double q2 = t.dim > 2 ? qrow[2] : metric64_pad<M>();
+    const unsigned long long* __restrict__ ent = hv.entries + hv.run_at[h];
+    uint64_t at = offsets[qi] + hv.own[h];
+    for (uint32_t i0 = 0; i0 < n; i0 += 64u) {  // (uniform)
+      const bool have = i0 + lane < n;
+      const unsigned long long e = have ? ent[i0 + lane] : 0ull;
+      uint32_t mask = (uint32_t)(e >> 32);
+      const uint32_t first = ((uint32_t)e & 0x7FFFFFFFu) >> t.cbits;
+      const uint32_t c = (uint32_t)__popcll((unsigned long long)mask);
+      const uint32_t incl = wave64_scan_u32(c, lane);
+      uint64_t w = at + (incl - c);
+      while (mask != 0u) {
+        const uint32_t b = (uint32_t)__builtin_ctz(mask);
+        mask &= mask - 1u;
+        const double4 a = *reinterpret_cast<const double4*>(pts + (uint64_t)(first + b) * kStride64D3);
+        Neighbor64 nb;
+        nb.index = (int32_t)__double_as_longlong(a.w);
+        nb.pad_ = 0;
+        nb.distance = d_mul(M::acc(M::acc(M::one(d_sub(q0, a.x)), d_sub(q1, a.y)), d_sub(q2, a.z)), e_inv);
+        out[w++] = nb;
+      }
+      at += (uint32_t)__shfl((int)incl, 63);
+    }
+  }
+}
+
+// The reference search from the root, one lane, for the rows the cooperative count could not finish: FILL = false counts
+// them again (counts[row]), FILL = true fills them again (the same values at the same places the other writers of such a
+// row put them).  `n_word`: the word of `meta` that counts `list`.
+template <class M, bool FILL>
+__global__ __launch_bounds__(64) void radius64_redo_kernel(
+    DevTree64 t, const double* __restrict__ queries, double radius, double e_inv, uint64_t* __restrict__ counts,
+    const uint64_t* __restrict__ offsets, Neighbor64* __restrict__ out, const uint32_t* __restrict__ meta, uint32_t n_word,
+    const uint32_t* __restrict__ list, Rec64* __restrict__ stack, uint32_t slots) {
+  const uint32_t n = meta[n_word];
+  for (uint32_t i = blockIdx.x * 64u + threadIdx.x; i < n; i += gridDim.x * 64u) {
+    const uint32_t qi = list[i];
+    Radius64Policy<FILL> pol;
+    pol.radius = d_mul(radius, e_inv);
+    pol.e_inv = e_inv;
+    pol.count = 0;
+    pol.out = FILL ? out + offsets[qi] : nullptr;
+    search64<M, true>(t, queries, qi, pol, stack, slots);
+    if (!FILL) counts[qi] = pol.count;
+  }
+}
+
 }  // namespace ptk

@@ -1447,6 +1447,102 @@ int emu64_knn_capped(void* h, const double* q, uint64_t nq, uint32_t k, const ui
   return emu64_knn_capped_k<32>(t, q, nq, k, perm, cap, pool_small, max_heavy, out, counts);
 }
 
+}  // extern "C"
+
+// The double radius search with its long queries finished cooperatively (ptk_kernels_coop64.hpp): both passes.
+// counts = {queries handed over, rows recounted / refilled from the root, sorted entries kept}.
+namespace {
+template <class M>
+int emu64_radius_capped_m(Emu64* t, const double* q, uint64_t nq, double radius, double e, uint32_t cap, int small,
+                          uint32_t max_heavy, uint64_t* offsets, std::vector<ptk::Neighbor64>& rows, uint32_t* counts) {
+  std::vector<uint32_t> meta(ptk::kMetaWords, 0), heavy(max_heavy + 1), ntasks(max_heavy + 1), redo(max_heavy + 1), over(max_heavy + 1);
+  std::vector<uint32_t> h_rows(max_heavy + 1), h_own(max_heavy + 1), h_at(max_heavy + 1), h_n(max_heavy + 1);
+  std::vector<ptk::Task64> tasks((size_t)std::max<uint32_t>(max_heavy, 1) * ptk::kMaxTasks);
+  const uint32_t entry_cap = small ? 600u : (uint32_t)std::max<uint64_t>(1, (uint64_t)max_heavy * 192);
+  std::vector<unsigned long long> entries(entry_cap);
+  std::vector<uint8_t> flag(nq + 1, 0);
+  ptk::Handover64 ho{};
+  ho.counter = ptk::kMetaHeavy;
+  ho.meta = meta.data();
+  ho.heavy_list = heavy.data();
+  ho.ntasks = ntasks.data();
+  ho.tasks = tasks.data();
+  ho.max_heavy = max_heavy;
+  ptk::RadiusHeavy64 hv{};
+  hv.meta = meta.data();
+  hv.rows = h_rows.data();
+  hv.own = h_own.data();
+  hv.run_at = h_at.data();
+  hv.run_n = h_n.data();
+  hv.entries = entries.data();
+  hv.max_heavy = max_heavy;
+  hv.entry_cap = entry_cap;
+  std::vector<uint32_t> order(nq);
+  for (uint64_t i = 0; i < nq; ++i) order[i] = (uint32_t)(nq - 1 - i);  // (a launch-order permutation: the batch backwards)
+  const uint32_t* perm = order.data();
+  const uint32_t spill_cap = small ? 24u : 2048u;
+  std::vector<ptk::Task64> spill((size_t)3 * spill_cap);
+  std::vector<uint64_t> cnt(nq + 1, 0);
+  const double e_inv = 1.0 / e;
+  auto one_block = [&](auto&& f) {
+    gridDim.x = 1;
+    blockDim.x = 64;
+    blockIdx.x = 0;
+    for (uint32_t l = 0; l < 64; ++l) {
+      threadIdx.x = l;
+      f();
+    }
+  };
+  for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+    ptk::radius64_capped_kernel<M, false>(t->dev, q, perm, q0, m, radius, e_inv, cnt.data(), nullptr, nullptr, t->stack.data(),
+                                          t->slots, cap, &ho, flag.data());
+  });
+  for_each_wave(3, [&] {
+    ptk::radius64_coop_count_kernel<64, M>(t->dev, q, radius, e_inv, cnt.data(), ho, hv, redo.data(), spill.data(), spill_cap);
+  });
+  one_block([&] {
+    ptk::radius64_redo_kernel<M, false>(t->dev, q, radius, e_inv, cnt.data(), nullptr, nullptr, meta.data(), ptk::kMetaRedo,
+                                        redo.data(), t->stack.data(), t->slots);
+  });
+  offsets[0] = 0;
+  for (uint64_t i = 0; i < nq; ++i) offsets[i + 1] = offsets[i] + cnt[i];
+  rows.assign(offsets[nq] + 1, ptk::Neighbor64{});
+  for_each_lane64(t, nq, [&](uint64_t q0, uint64_t m) {
+    ptk::radius64_capped_kernel<M, true>(t->dev, q, perm, q0, m, radius, e_inv, nullptr, offsets, rows.data(), t->stack.data(),
+                                         t->slots, cap, &ho, flag.data());
+  });
+  for_each_wave(3, [&] { ptk::radius64_coop_replay_kernel<M>(t->dev, q, e_inv, hv, offsets, rows.data(), over.data()); });
+  one_block([&] {
+    ptk::radius64_redo_kernel<M, true>(t->dev, q, radius, e_inv, nullptr, offsets, rows.data(), meta.data(), ptk::kMetaRc64Over,
+                                       over.data(), t->stack.data(), t->slots);
+  });
+  rows.resize(offsets[nq]);
+  counts[0] = std::min(meta[ptk::kMetaHeavy], max_heavy);
+  counts[1] = meta[ptk::kMetaRedo];
+  counts[2] = meta[ptk::kMetaRc64Entries];
+  return 0;
+}
+std::vector<ptk::Neighbor64> g_rows64;
+}  // namespace
+
+extern "C" {
+
+// dim <= 3, the four non-topological metrics.  Two calls: out == nullptr runs both passes and fills offsets; the second
+// copies the rows of that run.
+int emu64_radius_capped(void* h, const double* q, uint64_t nq, double radius, double e, uint32_t cap, int small,
+                        uint32_t max_heavy, uint64_t* offsets, ptk::Neighbor64* out, uint32_t* counts) {
+  auto* t = static_cast<Emu64*>(h);
+  if (t->dev.dim > 3 || t->metric > 3) return -2;
+  if (out != nullptr) {
+    std::memcpy(out, g_rows64.data(), g_rows64.size() * sizeof(ptk::Neighbor64));
+    return 0;
+  }
+  if (t->metric == 1) return emu64_radius_capped_m<ptk::Metric64L1>(t, q, nq, radius, e, cap, small, max_heavy, offsets, g_rows64, counts);
+  if (t->metric == 2) return emu64_radius_capped_m<ptk::Metric64LInf>(t, q, nq, radius, e, cap, small, max_heavy, offsets, g_rows64, counts);
+  if (t->metric == 3) return emu64_radius_capped_m<ptk::Metric64LNInf>(t, q, nq, radius, e, cap, small, max_heavy, offsets, g_rows64, counts);
+  return emu64_radius_capped_m<ptk::Metric64L2>(t, q, nq, radius, e, cap, small, max_heavy, offsets, g_rows64, counts);
+}
+
 // out == nullptr: count pass (offsets filled); otherwise the fill pass (+ optional row sort).
 int emu64_radius(void* h, const double* q, uint64_t nq, double radius, double e, int sort, uint64_t* offsets,
                  ptk::Neighbor64* out) {

@@ -347,6 +347,25 @@ class EmulatedTree64:
         self.last_tie_sweeps = int(counts[2])
         return out, int(counts[0]), int(counts[1])
 
+    def search_radius_capped(self, q, radius, cap, e=None, small=False, max_heavy=None):
+        """Both passes of the capped double radius search (ptk_kernels_coop64.hpp): the capped count launch, the cooperative
+        count of what it handed over, the recount of what that lost; the capped fill launch, the cooperative replay, the
+        refill of the lost rows.  Returns (offsets, rows, queries handed over, rows searched again from the root)."""
+        q = np.ascontiguousarray(q, dtype=np.float64)
+        off = np.zeros(len(q) + 1, dtype=np.uint64)
+        counts = np.zeros(3, dtype=np.uint32)
+        fn = self.lib.emu64_radius_capped
+        fn.restype = c_int
+        fn.argtypes = [c_void_p, c_void_p, c_uint64, ctypes.c_double, ctypes.c_double, c_uint32, c_int, c_uint32, c_void_p,
+                       c_void_p, c_void_p]
+        mh = len(q) if max_heavy is None else max_heavy
+        assert fn(self.h, q.ctypes.data, len(q), radius, e or 1.0, cap, int(small), mh, off.ctypes.data, None,
+                  counts.ctypes.data) == 0
+        flat = np.zeros(int(off[-1]), dtype=self.neighbor)
+        assert fn(self.h, q.ctypes.data, len(q), radius, e or 1.0, cap, int(small), mh, off.ctypes.data, flat.ctypes.data,
+                  counts.ctypes.data) == 0
+        return off, flat, int(counts[0]), int(counts[1])
+
     def search_radius(self, q, radius, e=None, sort=False):
         q = np.ascontiguousarray(q, dtype=np.float64)
         off = np.zeros(len(q) + 1, dtype=np.uint64)

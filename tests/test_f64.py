@@ -216,6 +216,40 @@ def test_emulated_double_capped_knn_and_its_cooperative_search_equal_oracle(case
             assert sweeps > 0, (name, metric)
 
 
+
+def _radius_for(ref, q, hits):
+    """A radius (in the metric's own unit) under which a query has about `hits` neighbours: the median distance of the
+    hits-th nearest."""
+    return float(np.median(ref.search_knn(q[:50], hits)["distance"][:, -1]))
+
+
+@pytest.mark.parametrize("case", list(_capped_cases64()), ids=lambda c: c[0])
+def test_emulated_double_capped_radius_and_its_cooperative_count_equal_oracle(case):
+    """The radius half of ptk_kernels_coop64.hpp in the emulator, both passes: the capped count launch, the cooperative
+    count (keyed leaf entries, sorted), the recount of what that lost; the capped fill launch, the cooperative replay,
+    the refill.  Every metric of the double kernels (no certificate is involved), exact and approximate, radii of ~60
+    and ~600 neighbours (the second overflows the 512 entries of many queries: the redo path), a small spill."""
+    from tests import emu
+
+    name, pts, q, leaf = case
+    q = q[:120]
+    for metric in ("L2Squared", "L1", "LPInf", "LNInf"):
+        t = emu.EmulatedTree64(pts, leaf, metric)
+        ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
+        handed = redone = 0
+        for hits, e in ((60, None), (60, 1.3), (600, None)):
+            if hits >= len(pts):
+                continue
+            r = _radius_for(ref, q, hits)
+            woff, wflat = ref.search_radius(q, r, e=e)
+            for cap, small in ((0, False), (3, True)):
+                off, flat, nh, nr = t.search_radius_capped(q, r, cap, e=e, small=small)
+                assert np.array_equal(off, woff) and same(flat, wflat["index"], wflat["distance"]), (name, metric, hits, e, cap)
+                handed += nh
+                redone += nr
+        assert handed > 0 and handed > redone, (name, metric, handed, redone)
+
+
 def test_host_only_double_handle_builds_the_reference_tree(tmp_path):
     g = load("g_f64_3d")
     t = pt.KdTree(g["points"], pt.Metric.L2Squared, int(g["max_leaf_size"]), device=pt.PTK_DEVICE_NONE)
@@ -518,6 +552,47 @@ def test_gpu_double_capped_knn_on_lines_and_lattices(gpu, kind, jitter):
     assert handed > 500, handed  # the cap did hand queries over
     if jitter == 0.0 and kind == "lattice":
         assert swept > 0         # equal distances: second sweeps ran
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", list(_capped_cases64()) + [("big", None, None, 10)], ids=lambda c: c[0])
+def test_gpu_double_capped_radius_and_its_cooperative_count(gpu, case):
+    """The capped double radius search on the device (every call of 256 queries or more with dim <= 3 under a
+    non-topological metric takes it): a low cap forced through the test hooks so that nearly every query is handed over,
+    the rule's own cap, and no cap -- all three the oracle's offsets and rows; exact, approximate and sorted."""
+    name, pts, q, leaf = case
+    if name == "big":
+        pts = ds.lidar_cloud(300_000, 1).astype(np.float64)
+        q = np.concatenate([ds.lidar_cloud(20_000, 2, pose=(3.0, 1.5)).astype(np.float64), _blind_disc_queries64(3_000)])
+    else:
+        q = np.concatenate([q] * 4)  # (256 queries or more: below that the launch is not capped)
+    for metric in ("L2Squared", "L1", "LPInf", "LNInf"):
+        ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
+        ref.set_threads(os.cpu_count() or 1)
+        t = _GpuTree(pts, leaf, metric, device=gpu)
+        handed = 0
+        for hits, e, sort in ((60, None, False), (40, 1.3, False), (700, None, True)):
+            if hits >= len(pts) or (name == "big" and metric != "L2Squared" and hits > 60):
+                continue
+            r = _radius_for(ref, q, hits)
+            woff, wflat = ref.search_radius(q, r, e=e, sort=sort)
+            for knobs in ({"radius64_cap": 1}, {}, {"radius64_cap": 0}):
+                pt.set_test_knobs(**knobs)
+                try:
+                    off, flat = t.search_radius(q, r, e=e, sort=sort)
+                    c = t.t.knn_coop_counts()
+                finally:
+                    pt.set_test_knobs(**{n: None for n in knobs})
+                assert np.array_equal(off, woff), (name, metric, hits, e, knobs)
+                if sort:  # (equal distances may come in either order of their indices: search_visitor.hpp sorts by distance)
+                    assert flat["distance"].tobytes() == wflat["distance"].tobytes(), (name, metric, hits, e, knobs)
+                else:
+                    assert same(flat, wflat["index"], wflat["distance"]), (name, metric, hits, e, knobs)
+                if knobs.get("radius64_cap") == 1:
+                    handed += c["cooperative"]
+                if knobs.get("radius64_cap") == 0:
+                    assert c["cooperative"] == 0
+        assert handed > 0, (name, metric)
 
 @pytest.mark.gpu
 def test_gpu_double_k_larger_than_the_tree(gpu):
