@@ -1,4 +1,4 @@
-// ptk_kernels_coop64.hpp -- double precision, dim <= 3, k <= 32: the long searches of a k-NN batch finished by a
+// ptk_kernels_coop64.hpp -- double precision, dim <= 3: the long searches of a k-NN batch (k <= 32; the radius search: below) finished by a
 // whole wavefront each.  ptk_kernels_coopk.hpp in double; the argument for why the merged row is the reference's is
 // at the head of that file and is not repeated here -- it uses nothing of the scalar type but
 //   * the box distance of a node is a function of its root path alone (`nbd - old_offset + new_offset`,
