@@ -100,6 +100,18 @@ assert t.search_knn(q, 16, perm=perm, list_in_lds=2).tobytes() == ref.search_knn
 off, flat = ref.search_radius(q, 1.0)
 goff, gflat, _ = t.search_radius_captured(q, 1.0, perm=perm)
 assert np.array_equal(goff, off) and gflat.tobytes() == flat.tobytes()
+# (double precision: the capped k-NN and radius searches with their cooperative finish, ptk_kernels_coop64.hpp)
+p64, q64 = pts[:8000].astype(np.float64), q[:200].astype(np.float64)
+t64 = emu.EmulatedTree64(p64, 10)
+ref64 = oracle.Oracle(p64, 10, "port", dtype=np.float64)
+for k in (1, 16):
+    got, handed, _ = t64.search_knn_capped(q64, k, 2)
+    want = ref64.search_knn(q64, k)
+    assert handed > 0 and np.array_equal(got["index"], want["index"]) and got["distance"].tobytes() == want["distance"].tobytes()
+woff, wflat = ref64.search_radius(q64, 4.0)
+goff, gflat, handed, _ = t64.search_radius_capped(q64, 4.0, 2)
+assert handed > 0 and np.array_equal(goff, woff) and np.array_equal(gflat["index"], wflat["index"])
+assert gflat["distance"].tobytes() == wflat["distance"].tobytes()
 print("ok")
 """
     r = _run(["python", "-c", code], UBSAN_OPTIONS="print_stacktrace=1")
