@@ -491,6 +491,19 @@ def metrics_and_f64_entries(pt, oracle, pts, q, leaf, device, steps, sample):
         res["f64"][f"knn{k}_150k"] = {"queries": int(dqs.shape[0]), "ms_per_step": round(ms_s, 4), "rows_equal": bool(ok_s),
                                       "handed_over": tree.knn_coop_counts()["cooperative"]}
         del out_s, dqs
+    # the double radius search on 20 000 queries through the host entry (both passes + the copies: there is no device-buffer
+    # form in double); capped since r06 (any such call used to take twice the cloud's longest search: 6.7 ms here)
+    qs = np.ascontiguousarray(q64[:: max(1, nq // 20_000)][:20_000])
+    tree.search_radius(qs, 1.0)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        got_r = tree.search_radius(qs, 1.0)
+    ms_r = (time.perf_counter() - t0) / 3 * 1e3
+    want_off, want_flat = ref.search_radius(qs, 1.0)
+    ok_r = np.array_equal(got_r.offsets, want_off) and np.array_equal(got_r.flat["index"], want_flat["index"]) and \
+        np.ascontiguousarray(got_r.flat["distance"]).tobytes() == np.ascontiguousarray(want_flat["distance"]).tobytes()
+    res["f64"]["radius_20k_host"] = {"queries": int(len(qs)), "radius_squared": 1.0, "ms_per_call": round(ms_r, 3), "hits": int(want_off[-1]),
+                                     "rows_equal": bool(ok_r), "handed_over": tree.knn_coop_counts()["cooperative"]}
     ref.close()
     tree.close()
     return res
