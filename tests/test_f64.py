@@ -198,7 +198,7 @@ def test_emulated_double_capped_knn_and_its_cooperative_search_equal_oracle(case
     k = 1 included (no two-phase search in double), both metrics it is shipped for, a cap of 0 / 2 far children and a
     small spill (the redo path); equal distances (a lattice, points on a line) must come out in the reference's order."""
     name, pts, q, leaf = case
-    for metric in ("L2Squared", "L1"):
+    for metric in (("L2Squared", "L1") if name in ("lidar", "ties") else ("L2Squared",)):
         from tests import emu
 
         t = emu.EmulatedTree64(pts, leaf, metric)
@@ -233,7 +233,7 @@ def test_emulated_double_capped_radius_and_its_cooperative_count_equal_oracle(ca
 
     name, pts, q, leaf = case
     q = q[:120]
-    for metric in ("L2Squared", "L1", "LPInf", "LNInf"):
+    for metric in (("L2Squared", "L1", "LPInf", "LNInf") if name == "lidar" else ("L2Squared", "LNInf")):
         t = emu.EmulatedTree64(pts, leaf, metric)
         ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
         handed = redone = 0
