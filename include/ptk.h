@@ -473,12 +473,12 @@ int ptk_debug_knn_coop_counts(const ptk_tree* tree, uint32_t counts[7]);
  * pass ran uncapped.  Synchronises the device. */
 int ptk_debug_radius_coop_counts(const ptk_tree* tree, uint32_t counts[3]);
 /* ptk_debug_knn_coop_counts for the double-precision tree: the counters of the last k-NN call that ran capped (exact,
- * dim <= 3, metric_l2_squared / metric_l1, k <= 32, 256 queries or more: ptk_kernels_coop64.hpp); zeros if none has
+ * dim <= 3, metric_l2_squared / metric_l1, k <= 32, 32 queries or more: ptk_kernels_coop64.hpp; and of the last radius call, which is capped at any size); zeros if none has
  * since the stack block was last re-allocated.  Synchronises the device. */
 int ptk_tree64_debug_knn_coop_counts(const ptk_tree64* tree, uint32_t counts[7]);
 /* The far children a query of such a search may enter before a wavefront takes it over, for a batch of nq queries
  * (it follows the batch: a capped launch ends with the lanes that ran to their cap; 0 = this search runs uncapped --
- * e != 1, fewer than 256 queries, k outside 2 .. 56), and the entries of the hand-over list of that batch (a query that
+ * e != 1, fewer than 32 queries, k outside 2 .. 56), and the entries of the hand-over list of that batch (a query that
  * finds it full goes on in its lane).  No device needed; honours PTK_KNN_CAP / PTK_KNN_CAP_MIN_NQ. */
 int ptk_debug_knn_cap(uint64_t nq, uint32_t k, float e, uint32_t* cap, uint64_t* list_entries);
 /* Piles -- subtrees all of whose points are one and the same point (the reference's builder peels one of them off per

@@ -581,9 +581,11 @@ inline uint32_t knn_coop_blocks(const ptk_tree* t, uint64_t nq) {
 // their lanes -- so the slopes err towards the higher cap: knn = 8 at 900 k queries, caps 24 / 32: 0.94 / 0.63 ms)
 // PTK_KNN_CAP = n: that cap for every batch (0: no cap).
 inline uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
-  // (below a few wavefronts of queries the two extra launches cost more than the tail: kernel ms with / without the
-  // cap at 64 / 500 / 3 000 queries, knn = 16 0.13 / 0.27 / 0.30 against 0.11 / 0.66 / 0.90.  PTK_KNN_CAP_MIN_NQ: tests)
-  if (k < 2 || e != 1.0f || nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 256))) return 0;  // (k = 1 has the two-phase search; where it does not apply -- metric_l1 on a tree with piles -- the general kernel runs uncapped)
+  // (below a wavefront of queries the two extra launches cost what a tail may or may not: ms per call with / without the
+  // cap, knn = 16, queries taken across config 2's scan -- some of them long --: 8 queries 0.19-0.21 / 0.16-0.34, 64
+  // 0.23-0.24 / 0.28-0.31, 200 0.35 / 0.53-0.62 (tools/time_tiny_batches.py; r05 had measured the first 64 rows of the
+  // batch, none of them long, and set 256).  Test hook knn_cap_min_nq.)
+  if (k < 2 || e != 1.0f || nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 32))) return 0;  // (k = 1 has the two-phase search; where it does not apply -- metric_l1 on a tree with piles -- the general kernel runs uncapped)
   const int forced = knob_int("knn_cap", -1);
   if (forced >= 0) return (uint32_t)forced;
   const double n = (double)nq;
@@ -635,11 +637,14 @@ inline uint32_t radius_cap(const ptk_tree* t, uint64_t nq) {
   // and beyond the bulk of the launch hides the tail and every cap loses (4.23 (256) / 4.05; 7.2 M 11.4 / 10.2: no query
   // of that cloud enters 384 far children, 1.2 % enter more than 256).  What the best caps have in common is 8-17 thousand
   // hand-overs -- what the wavefronts of the cooperative count get through while the capped launch ends.
-  if (nq < 256 || nq >= 1500000) return 0;
+  // (no lower limit: a call of 8 queries that holds one long one takes 0.8 ms uncapped -- the count pass's tail --, and
+  // the capped path costs a call without long queries ~30 us: tools/time_tiny_batches.py.  Test hook radius_cap_min_nq.)
+  if (nq < (uint64_t)std::max(1, knob_int("radius_cap_min_nq", 1)) || nq >= 1500000) return 0;
   return (uint32_t)std::min(256.0, std::max(8.0, (double)nq / 2400.0));
 }
 inline uint64_t radius_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
-inline uint64_t radius_entry_cap(uint64_t nq) { return radius_max_handover(nq) * 192; }  // entries of all hand-overs together
+// Entries of all hand-overs together (a few queries may all be long: room for 64 of them at least).
+inline uint64_t radius_entry_cap(uint64_t nq) { return std::max<uint64_t>(radius_max_handover(nq), 64) * 192; }
 inline uint32_t radius_coop_blocks(const ptk_tree* t, uint64_t nq) {
   return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 16u, std::max<uint64_t>(64, radius_max_handover(nq)));
 }

@@ -48,6 +48,13 @@ struct ptk_tree64 {
   mutable hipEvent_t done = nullptr;
   mutable hipStream_t last_stream = nullptr;
   mutable bool has_work = false;
+
+  // The device copies of a HOST-buffer call's queries / counts / offsets (block 0) and rows (block 1): kept on the
+  // handle up to kIoKeepBytes each (a call of 2 000 queries spent a third of its time in hipMalloc / hipFree), allocated
+  // per call beyond that.  `io_mutex` is held for the whole of such a call.
+  mutable std::mutex io_mutex;
+  mutable char* io[2] = {nullptr, nullptr};
+  mutable size_t io_capacity[2] = {0, 0};
 };
 
 namespace {
@@ -169,6 +176,39 @@ int check_search64(const ptk_tree64* t, const void* q, uint64_t nq) {
   if (t->device == kDeviceNone) return fail(PTK_ERR_DEVICE, "this handle has no device replica");
   return PTK_OK;
 }
+
+// A device buffer of a host-buffer call: block `which` of the handle when it fits what a handle keeps, else an allocation
+// of the call's own (freed by the destructor).  The caller holds t->io_mutex.
+constexpr size_t kIoKeepBytes = size_t(64) << 20;
+struct IoBuffer {
+  char* p = nullptr;
+  bool own = false;
+  IoBuffer() = default;
+  IoBuffer(const IoBuffer&) = delete;
+  IoBuffer& operator=(const IoBuffer&) = delete;
+  ~IoBuffer() {
+    if (own && p) (void)hipFree(p);
+  }
+  hipError_t get(const ptk_tree64* t, int which, size_t bytes) {
+    bytes = std::max<size_t>(bytes, 256);
+    if (bytes <= kIoKeepBytes) {
+      if (bytes > t->io_capacity[which]) {
+        if (t->io[which]) (void)hipFree(t->io[which]);
+        t->io[which] = nullptr;
+        t->io_capacity[which] = 0;
+        const size_t want = std::min(kIoKeepBytes, std::max(bytes * 2, size_t(1) << 20));
+        const hipError_t he = hipMalloc((void**)&t->io[which], want);
+        if (he != hipSuccess) return he;
+        t->io_capacity[which] = want;
+      }
+      p = t->io[which];
+      own = false;
+      return hipSuccess;
+    }
+    own = true;
+    return hipMalloc((void**)&p, bytes);
+  }
+};
 
 // Pieces of a batch that fit the stack block; *stack is valid on `s` after the call.
 struct Stack64Lease {
@@ -337,7 +377,7 @@ inline uint32_t knn64_coop_spill(uint32_t k) { return k > 16 ? 4096u : 1024u; }
 inline uint32_t knn64_cap(const ptk_tree64* t, double e, uint64_t nq, uint32_t k, bool short_tree) {
   const int m = t->metric.load();
   if (t->dim > 3 || (m != PTK_METRIC_L2_SQUARED && m != PTK_METRIC_L1) || e != 1.0 || k > 32 || short_tree) return 0;
-  if (nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 256)) || nq >= (1ull << 32)) return 0;
+  if (nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 32)) || nq >= (1ull << 32)) return 0;  // (as knn_cap)
   const int forced = knob_int("knn64_cap", -1);
   if (forced >= 0) return (uint32_t)forced;
   // Fitted to tools/sweep_knn64_cap.py on BASELINE config 2's cloud L (profiles/r06_knn64_cap_sweep.jsonl; step ms, best
@@ -445,14 +485,15 @@ inline uint32_t radius64_cap(const ptk_tree64* t, uint64_t nq) {
   const int m = t->metric.load();
   if (t->dim > 3 || m == PTK_METRIC_SO2 || m == PTK_METRIC_SE2_SQUARED) return 0;
   if (t->max_depth > ptk::kRc64MaxDepth || t->max_leaf_count > 2048u) return 0;
-  if (nq < (uint64_t)std::max(1, knob_int("knn_cap_min_nq", 256)) || nq >= (1ull << 32)) return 0;
+  // (no lower limit, as radius_cap: 8 double queries with a long one among them 0.94 ms uncapped, 0.24 capped)
+  if (nq < (uint64_t)std::max(1, knob_int("radius_cap_min_nq", 1)) || nq >= (1ull << 32)) return 0;
   const int forced = knob_int("radius64_cap", -1);
   if (forced >= 0) return (uint32_t)forced;
   if (nq >= 1500000) return 0;
   return (uint32_t)std::min(256.0, std::max(8.0, (double)nq / 2400.0));
 }
 inline uint64_t radius64_max_handover(uint64_t nq) { return std::max<uint64_t>(nq / 48, std::min<uint64_t>(nq, 24576)); }
-inline uint64_t radius64_entry_cap(uint64_t nq) { return radius64_max_handover(nq) * 192; }  // entries of all hand-overs together
+inline uint64_t radius64_entry_cap(uint64_t nq) { return std::max<uint64_t>(radius64_max_handover(nq), 64) * 192; }  // entries of all hand-overs together
 inline uint32_t radius64_coop_blocks(const ptk_tree64* t, uint64_t nq) {
   return (uint32_t)std::min<uint64_t>((uint64_t)t->cus * 12u, std::max<uint64_t>(64, radius64_max_handover(nq)));
 }
@@ -748,6 +789,8 @@ void ptk_tree64_destroy(ptk_tree64* t) {
     if (t->d_root) (void)hipFree(t->d_root);
     if (t->d_outer) (void)hipFree(t->d_outer);
     if (t->d_occ) (void)hipFree(t->d_occ);
+    for (char* b : t->io)
+      if (b) (void)hipFree(b);
   }
   delete t;
 }
@@ -867,19 +910,19 @@ int ptk_search64_knn(const ptk_tree64* t, const double* q, uint64_t nq, uint32_t
   if (out == nullptr) return fail(PTK_ERR_INVALID, "null output buffer");
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
-  double* d_q = nullptr;
-  ptk_neighbor64* d_out = nullptr;
+  std::lock_guard<std::mutex> io_lock(t->io_mutex);
+  IoBuffer bq, bo;
   const size_t qbytes = (size_t)nq * t->dim * sizeof(double), obytes = (size_t)nq * k * sizeof(ptk_neighbor64);
-  hipError_t he = hipMalloc((void**)&d_q, qbytes);
-  if (he == hipSuccess) he = hipMalloc((void**)&d_out, obytes ? obytes : 16);
+  hipError_t he = bq.get(t, 0, qbytes);
+  if (he == hipSuccess) he = bo.get(t, 1, obytes);
+  double* d_q = reinterpret_cast<double*>(bq.p);
+  ptk_neighbor64* d_out = reinterpret_cast<ptk_neighbor64*>(bo.p);
   if (he == hipSuccess) he = hipMemset(d_out, 0, obytes ? obytes : 16);  // padding bytes of the records
   if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
   if (he == hipSuccess) {
     rc = ptk_search64_knn_device(t, d_q, nq, k, e, d_out, nullptr);
     if (rc == PTK_OK) he = hipMemcpy(out, d_out, obytes, hipMemcpyDeviceToHost);
   }
-  if (d_q) (void)hipFree(d_q);
-  if (d_out) (void)hipFree(d_out);
   if (rc == PTK_OK && he != hipSuccess) rc = fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
   return rc;
 }
@@ -895,13 +938,15 @@ int ptk_search64_radius(const ptk_tree64* t, const double* q, uint64_t nq, doubl
   if (nq == 0) return PTK_OK;
   DeviceGuard guard(t->device);
   if (!guard.ok) return fail(PTK_ERR_DEVICE, "hipSetDevice(%d) failed", t->device);
-  double* d_q = nullptr;
-  uint64_t *d_c = nullptr, *d_o = nullptr;
-  ptk_neighbor64* d_out = nullptr;
+  std::lock_guard<std::mutex> io_lock(t->io_mutex);
+  IoBuffer bin, bout;
   const size_t qbytes = (size_t)nq * t->dim * sizeof(double);
-  hipError_t he = hipMalloc((void**)&d_q, qbytes);
-  if (he == hipSuccess) he = hipMalloc((void**)&d_c, (nq + 1) * 8);
-  if (he == hipSuccess) he = hipMalloc((void**)&d_o, (nq + 1) * 8);
+  const size_t q_room = (qbytes + 255) & ~size_t(255), c_room = ((nq + 1) * 8 + 255) & ~size_t(255);
+  hipError_t he = bin.get(t, 0, q_room + 2 * c_room);
+  double* d_q = reinterpret_cast<double*>(bin.p);
+  uint64_t* d_c = reinterpret_cast<uint64_t*>(bin.p + q_room);
+  uint64_t* d_o = reinterpret_cast<uint64_t*>(bin.p + q_room + c_room);
+  ptk_neighbor64* d_out = nullptr;
   if (he == hipSuccess) he = hipMemset(d_c, 0, (nq + 1) * 8);
   if (he == hipSuccess) he = hipMemcpy(d_q, q, qbytes, hipMemcpyHostToDevice);
   uint64_t total = 0;
@@ -929,7 +974,8 @@ int ptk_search64_radius(const ptk_tree64* t, const double* q, uint64_t nq, doubl
     if (rc == PTK_OK) {
       total = offsets[nq];
       const size_t obytes = std::max<uint64_t>(total, 1) * sizeof(ptk_neighbor64);
-      he = hipMalloc((void**)&d_out, obytes);
+      he = bout.get(t, 1, obytes);
+      d_out = reinterpret_cast<ptk_neighbor64*>(bout.p);
       if (he == hipSuccess) he = hipMemset(d_out, 0, obytes);
       if (he == hipSuccess && cap != 0u) {
         PTK_WITH_EUCLID64(rc = (launch_radius64_capped<M, true>(t, d_q, perm, nq, radius, e, cap, nullptr, d_o,
@@ -953,10 +999,6 @@ int ptk_search64_radius(const ptk_tree64* t, const double* q, uint64_t nq, doubl
       }
     }
   }
-  if (d_q) (void)hipFree(d_q);
-  if (d_c) (void)hipFree(d_c);
-  if (d_o) (void)hipFree(d_o);
-  if (d_out) (void)hipFree(d_out);
   if (rc == PTK_OK && he != hipSuccess) rc = fail(PTK_ERR_DEVICE, "HIP error: %s", hipGetErrorString(he));
   if (rc != PTK_OK && *out) {
     std::free(*out);

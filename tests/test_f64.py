@@ -473,7 +473,7 @@ def test_gpu_double_capped_knn_and_its_cooperative_search(gpu, case):
         pts = ds.lidar_cloud(300_000, 1).astype(np.float64)
         q = np.concatenate([ds.lidar_cloud(40_000, 2, pose=(3.0, 1.5)).astype(np.float64), _blind_disc_queries64(4_000)])
     else:
-        q = np.concatenate([q] * 4)  # (256 queries or more: below that the launch is not capped)
+        q = np.concatenate([q] * 4)
     for metric in ("L2Squared", "L1"):
         ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
         ref.set_threads(os.cpu_count() or 1)
@@ -565,7 +565,7 @@ def test_gpu_double_capped_radius_and_its_cooperative_count(gpu, case):
         pts = ds.lidar_cloud(300_000, 1).astype(np.float64)
         q = np.concatenate([ds.lidar_cloud(20_000, 2, pose=(3.0, 1.5)).astype(np.float64), _blind_disc_queries64(3_000)])
     else:
-        q = np.concatenate([q] * 4)  # (256 queries or more: below that the launch is not capped)
+        q = np.concatenate([q] * 4)
     for metric in ("L2Squared", "L1", "LPInf", "LNInf"):
         ref = oracle.Oracle(pts, leaf, "port", metric, dtype=np.float64)
         ref.set_threads(os.cpu_count() or 1)
