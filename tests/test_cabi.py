@@ -300,12 +300,12 @@ def test_knn_cap_follows_the_batch(monkeypatch):
         return c.value, entries.value
 
     monkeypatch.delenv("PTK_TEST_KNOBS", raising=False)
-    sizes = [256, 1_000, 20_000, 150_000, 600_000, 900_000, 2_400_000, 7_200_863, 50_000_000]
+    sizes = [32, 256, 1_000, 20_000, 150_000, 600_000, 900_000, 2_400_000, 7_200_863, 50_000_000]
     for k, floor, top in ((2, 8, 256), (4, 8, 256), (8, 12, 320), (16, 16, 448), (32, 32, 512), (56, 64, 768)):
         caps = [cap(nq, k)[0] for nq in sizes]
         assert caps == sorted(caps) and caps[0] == floor and caps[-1] == top, (k, caps)
     assert cap(7_200_863, 16)[0] == 448 and cap(900_000, 16)[0] == 56 and cap(900_000, 4)[0] == 24
-    assert cap(255, 16) == (0, 0) and cap(10_000, 16, e=1.5) == (0, 0) and cap(10_000, 1) == (0, 0) and cap(10_000, 57) == (0, 0)
+    assert cap(31, 16) == (0, 0) and cap(32, 16) == (16, 32) and cap(10_000, 16, e=1.5) == (0, 0) and cap(10_000, 1) == (0, 0) and cap(10_000, 57) == (0, 0)
     for nq in sizes:
         entries = cap(nq, 16)[1]
         assert min(nq, 24_576) <= entries <= max(nq // 48, 24_576)
