@@ -479,7 +479,7 @@ int ptk_tree64_debug_knn_coop_counts(const ptk_tree64* tree, uint32_t counts[7])
 /* The far children a query of such a search may enter before a wavefront takes it over, for a batch of nq queries
  * (it follows the batch: a capped launch ends with the lanes that ran to their cap; 0 = this search runs uncapped --
  * e != 1, fewer than 32 queries, k outside 2 .. 56), and the entries of the hand-over list of that batch (a query that
- * finds it full goes on in its lane).  No device needed; honours PTK_KNN_CAP / PTK_KNN_CAP_MIN_NQ. */
+ * finds it full goes on in its lane).  No device needed; honours the test hooks knn_cap / knn_cap_min_nq of PTK_TEST_KNOBS. */
 int ptk_debug_knn_cap(uint64_t nq, uint32_t k, float e, uint32_t* cap, uint64_t* list_entries);
 /* Piles -- subtrees all of whose points are one and the same point (the reference's builder peels one of them off per
  * level, kd_tree_builder.hpp:255-275) -- of this handle's device replica (dim <= 3): out[0] = piles, [1] = points they

@@ -555,7 +555,7 @@ inline float inv_ratio(float e) { return 1.0f / e; }
 
 
 // Far children a query of the general k-NN kernel may enter before it is handed to the cooperative search
-// (ptk_kernels_coopk.hpp; PTK_KNN_CAP, 0 = every query runs to its end in its lane).  Exact searches with the default
+// (ptk_kernels_coopk.hpp; test hook knn_cap, 0 = every query runs to its end in its lane).  Exact searches with the default
 // metric only: the argument that makes the merged result the reference's needs e = 1 and the error bounds of a sum of
 // squares.
 constexpr int kKnnCoopPool = 128;
@@ -579,7 +579,7 @@ inline uint32_t knn_coop_blocks(const ptk_tree* t, uint64_t nq) {
 //   k <= 8  max(nq / 30 000, (nq - 1.2 M) / 20 000)      12 .. 320     k <= 32  nq / 9 400       32 .. 512
 // (a cap that lets more queries through than the hand-over list holds is a cliff -- those queries finish alone in
 // their lanes -- so the slopes err towards the higher cap: knn = 8 at 900 k queries, caps 24 / 32: 0.94 / 0.63 ms)
-// PTK_KNN_CAP = n: that cap for every batch (0: no cap).
+// Test hook knn_cap = n: that cap for every batch (0: no cap).
 inline uint32_t knn_cap(float e, uint64_t nq, uint32_t k) {
   // (below a wavefront of queries the two extra launches cost what a tail may or may not: ms per call with / without the
   // cap, knn = 16, queries taken across config 2's scan -- some of them long --: 8 queries 0.19-0.21 / 0.16-0.34, 64
