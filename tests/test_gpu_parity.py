@@ -929,6 +929,45 @@ def test_capped_k_nearest_on_lines_and_lattices_equals_the_compiled_reference(gp
         assert swept > 0                   # equal distances: second sweeps ran
 
 
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_tiny_batches_with_long_queries_take_the_capped_searches(gpu, dtype):
+    """A call of a handful of queries with a long one among them used to pay that query's whole chain (r06 notes item
+    20): the radius searches are capped at any batch size, the k-NN searches from 32 queries on.  Queries inside the empty
+    disc under the scanner (the long searches of BASELINE config 2), batches of 1 / 7 / 33 / 64: the oracle's rows, and
+    the counters say a wavefront finished them."""
+    pts = ds.lidar_cloud(300_000, 1).astype(dtype)
+    u = ds.raw_uniform24(11, 2 * 64).reshape(64, 2)
+    r, a = 12.0 * np.sqrt(u[:, 0]), 2.0 * np.pi * u[:, 1]
+    q = np.ascontiguousarray(np.stack([r * np.cos(a), r * np.sin(a), np.zeros(64)], axis=1)).astype(dtype)
+    tree = pt.KdTree(pts, pt.Metric.L2Squared, 10, device=gpu)
+    ref = oracle.Oracle(pts, 10, "port", dtype=dtype)
+    radius = float(np.median(ref.search_knn(q, 40)["distance"][:, -1]))
+    handed_r = handed_k = 0
+    for nq in (1, 7, 33, 64):
+        qq = q[:nq]
+        want_off, want = ref.search_radius(qq, radius)
+        got = tree.search_radius(qq, dtype(radius))
+        assert np.array_equal(got.offsets, want_off) and np.array_equal(got.flat["index"], want["index"]), nq
+        assert np.ascontiguousarray(got.flat["distance"]).tobytes() == np.ascontiguousarray(want["distance"]).tobytes(), nq
+        if dtype is np.float64:
+            handed_r += tree.knn_coop_counts()["cooperative"]
+        else:  # (the counters of a float32 count pass are read between the device passes: the host entry has finished both)
+            import torch
+
+            tree.search_radius_device(torch.from_numpy(qq).cuda(), np.float32(radius))
+            handed_r += tree.radius_coop_counts()["cooperative"]
+        for k in (1, 16):
+            w = ref.search_knn(qq, k)
+            g = tree.search_knn(qq, k).reshape(nq, k)
+            assert np.array_equal(g["index"], w["index"]) and np.ascontiguousarray(g["distance"]).tobytes() == \
+                np.ascontiguousarray(w["distance"]).tobytes(), (nq, k)
+            if nq >= 32 and (k > 1 or dtype is np.float64):
+                handed_k += tree.knn_coop_counts()["cooperative"]
+    assert handed_r > 0 and handed_k > 0, (handed_r, handed_k)
+    tree.close()
+    ref.close()
+
 @pytest.mark.parametrize("cloud", ["lidar", "uniform"])
 def test_batches_that_arrive_coherent_are_not_sorted_again(gpu, cloud):
     """The reference walks the rows in the caller's order (_pyco_tree/kd_tree.hpp:128-134); the k = 1 search samples
